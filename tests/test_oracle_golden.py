@@ -1,0 +1,202 @@
+"""Pin the CPU oracle (oracle/refgraph.py) against golden vectors produced by the real
+reference (tools/gen_golden.py).  CPU only.  Tolerances: the oracle and the reference run
+the same ATen ops in the same order, so agreement is expected to ~1e-6; gates are stated
+per check."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import refgraph as R
+from tests import _golden as G
+
+torch.set_num_threads(4)
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+# ----------------------------------------------------------------------------- ops (G1)
+def test_kl_quirk_matches_reference():
+    arrays, meta = G.load("ops")
+    for i in range(3):
+        t = [_t(arrays[f"kl{i}_{n}"]).clone().requires_grad_(True) for n in ("mu0", "s0", "mu1", "s1")]
+        kl = oracle.kl_two_gauss_with_diag_cov(*t)
+        kl.backward()
+        assert abs(float(kl) - meta[f"kl{i}"]) <= 1e-6 * max(1.0, abs(meta[f"kl{i}"]))
+        for n, tt in zip(("mu0", "s0", "mu1", "s1"), t):
+            ref = arrays[f"kl{i}_d{n}"]
+            assert G.maxabs(tt.grad.numpy(), ref) <= 1e-6 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_onehot_matches_reference():
+    arrays, _ = G.load("ops")
+    out = oracle.batch_to_onehot(_t(arrays["onehot_in"]), 2).numpy()
+    assert out.dtype == np.int64
+    assert np.array_equal(out, arrays["onehot_out"])          # integer path: bit exact
+
+
+def test_l2_regularisation_matches_reference():
+    arrays, meta = G.load("ops")
+    sd = {"m.0.weight": _t(arrays["l2_w0"]), "m.0.bias": _t(arrays["l2_b0"]),
+          "m.1.weight": _t(arrays["l2_w1"]), "m.1.bias": _t(arrays["l2_b1"])}
+    assert abs(float(R._l2_regularisation(sd, "m.")) - meta["l2"]) <= 1e-6 * meta["l2"]
+
+
+def test_residual_multinoulli_matches_reference():
+    arrays, meta = G.load("ops")
+    s = [_t(arrays[f"rm_s{i}"]).clone().requires_grad_(True) for i in range(5)]
+    tgt = _t(arrays["rm_target"])
+    dummy = [torch.zeros(1, 1)] * 5
+    out = dict(s=s, posterior_mu=dummy, posterior_sigma=[torch.ones(1, 1)] * 5, prior_mu=dummy,
+               prior_sigma=[torch.ones(1, 1)] * 5)
+    total, terms = oracle.phiseg_loss(out, tgt)
+    total.backward()
+    for i in range(5):
+        assert abs(float(terms["residual_multinoulli_loss_lvl%d" % i]) - meta[f"rm_lvl{i}"]) <= 1e-5 * abs(meta[f"rm_lvl{i}"])
+        assert G.maxabs(s[i].grad.numpy(), arrays[f"rm_ds{i}"]) <= 1e-6
+
+
+# ----------------------------------------------------------------------------- PHiSeg small (G2)
+def _phiseg_inputs(arrays, batch, hw, step):
+    shapes = oracle.phiseg_eps_shapes(batch, hw, hw)
+    x, mask, eps = oracle.synthetic_batch(batch, hw, hw, seed=20201004 + step, eps_shapes=shapes + shapes)
+    if step == 0:
+        assert np.array_equal(x, arrays["x"]) and np.array_equal(mask, arrays["mask"])
+        for i in range(10):
+            assert np.array_equal(eps[i], arrays[f"eps{i}"])
+    e = [_t(a) for a in eps]
+    return _t(x), _t(mask), dict(posterior=e[:5], prior=e[5:])
+
+
+def test_phiseg_small_forward_loss_grads_adam():
+    arrays, meta = G.load("phiseg_small")
+    spec = G.spec_of(meta)
+    sd = G.leaves(oracle.deterministic_state_dict(spec, seed=meta["weight_seed"]))
+    state = {}
+    for step, st in enumerate(meta["steps"]):
+        x, mask, eps = _phiseg_inputs(arrays, meta["batch"], meta["hw"], step)
+        out = oracle.phiseg_forward(sd, x, mask, eps, training=True, bn_train=True)
+        total, terms = oracle.phiseg_loss(out, mask)
+        for k in [k for k, v in sd.items() if v.requires_grad]:
+            sd[k].grad = None
+        total.backward()
+        assert abs(float(total) - st["loss"]) <= 2e-6 * abs(st["loss"])
+        for k, v in st["loss_dict"].items():
+            assert abs(float(terms[k]) - v) <= 1e-5 * max(1.0, abs(v)), k
+        # kl_divergence_loss / reconstruction_loss alias the total
+        assert st["kl_alias"] == st["loss"] and st["recon_alias"] == st["loss"]
+        none = sorted(k for k, v in sd.items() if v.requires_grad and v.grad is None)
+        assert none == sorted(st["none_grads"]) and len(none) == 16
+        if step == 0:
+            for l in range(5):
+                assert G.maxabs(out["s"][l].detach().numpy(), arrays[f"s{l}"]) <= 1e-5
+                assert G.maxabs(out["posterior_mu"][l].detach().numpy(), arrays[f"post_mu{l}"]) <= 1e-5
+                assert G.maxabs(out["posterior_sigma"][l].detach().numpy(), arrays[f"post_sigma{l}"]) <= 1e-5
+                assert G.maxabs(out["posterior_z"][l].detach().numpy(), arrays[f"post_z{l}"]) <= 1e-5
+                assert G.maxabs(out["prior_mu"][l].detach().numpy(), arrays[f"prior_mu{l}"]) <= 1e-5
+            worst = 0.0
+            noise = G.bn_shadowed_biases(sd.keys())
+            for k, v in sd.items():
+                if v.requires_grad and v.grad is not None and k not in noise:
+                    ref = arrays["grad:" + k]
+                    worst = max(worst, G.maxabs(v.grad.numpy(), ref) / (1e-3 + float(np.abs(ref).max())))
+            assert worst <= 2e-3, worst
+            for k, v in sd.items():
+                if "running_" in k:
+                    assert G.maxabs(v.numpy(), arrays["buf1:" + k]) <= 1e-6
+        params = {k: v for k, v in sd.items() if v.requires_grad}
+        grads = {k: v.grad for k, v in params.items()}
+        new = oracle.adam_reference_step(params, grads, state)
+        for k, v in new.items():
+            sd[k] = v.requires_grad_(True)
+
+
+def test_phiseg_small_eval_argmax_bit_exact():
+    arrays, meta = G.load("phiseg_small")
+    sd = oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"])
+    x, mask, eps = _phiseg_inputs(arrays, meta["batch"], meta["hw"], 0)
+    with torch.no_grad():
+        out = oracle.phiseg_forward(sd, x, mask, eps, training=False, bn_train=False)
+        soft = oracle.phiseg_accumulate_output(out["s"], use_softmax=True)
+    for l in range(5):
+        assert G.maxabs(out["s"][l].numpy(), arrays[f"eval_s{l}"]) <= 1e-5
+    assert G.maxabs(soft.numpy(), arrays["eval_softmax"]) <= 1e-6
+    bits = np.packbits(torch.argmax(soft, dim=1).numpy().astype(np.uint8).reshape(-1))
+    assert meta["eval_margin_min"] > 1e-4, "fixture has a near-tie; argmax gate would be meaningless"
+    assert np.array_equal(bits, arrays["eval_argmax_bits"])
+    assert meta["eval_alias_inplace"] is True
+
+
+# ----------------------------------------------------------------------------- PHiSeg full-size digest (G3)
+def test_phiseg_full_digest():
+    arrays, meta = G.load("phiseg_full_digest")
+    sd = G.leaves(oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"]))
+    x, mask, eps = _phiseg_inputs(arrays, meta["batch"], meta["hw"], 0)
+    out = oracle.phiseg_forward(sd, x, mask, eps, training=True, bn_train=True)
+    total, terms = oracle.phiseg_loss(out, mask)
+    total.backward()
+    st = meta["steps"][0]
+    assert abs(float(total) - st["loss"]) <= 1e-5 * abs(st["loss"])
+    idx = arrays["s_idx"]
+    for l in range(5):
+        assert G.maxabs(out["s"][l].detach().numpy().reshape(-1)[idx], arrays[f"s{l}_samp"]) <= 1e-4
+        assert G.maxabs(out["posterior_mu"][l].detach().numpy(), arrays[f"post_mu{l}"]) <= 1e-4
+    noise = G.bn_shadowed_biases(sd.keys())
+    for k, n in st["grad_norms"].items():
+        if k in noise:
+            continue
+        mine = float(sd[k].grad.double().norm())
+        assert abs(mine - n) <= 2e-3 * max(n, 1e-3), (k, mine, n)
+
+
+# ----------------------------------------------------------------------------- U-Net small
+def test_unet_small():
+    arrays, meta = G.load("unet_small")
+    sd = G.leaves(oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"]))
+    state = {}
+    for step, st in enumerate(meta["steps"]):
+        x, mask, _ = oracle.synthetic_batch(meta["batch"], 128, 128, seed=20201004 + step)
+        pred = oracle.unet_forward(sd, _t(x))
+        loss = oracle.unet_loss(pred, _t(mask))
+        for v in sd.values():
+            v.grad = None
+        loss.backward()
+        assert abs(float(loss) - st["loss"]) <= 1e-5 * abs(st["loss"])
+        if step == 0:
+            assert G.maxabs(pred.detach().numpy(), arrays["pred"]) <= 1e-5
+            for k, v in sd.items():
+                ref = arrays["grad:" + k]
+                assert G.maxabs(v.grad.numpy(), ref) <= 1e-3 * (1e-4 + float(np.abs(ref).max())), k
+        new = oracle.adam_reference_step(dict(sd), {k: v.grad for k, v in sd.items()}, state)
+        sd = {k: v.requires_grad_(True) for k, v in new.items()}
+    for k, v in sd.items():
+        assert G.maxabs(v.detach().numpy(), arrays["final:" + k]) <= 2e-4, k
+
+
+# ----------------------------------------------------------------------------- Probabilistic U-Net small
+def test_probunet_small():
+    arrays, meta = G.load("probunet_small")
+    sd = G.leaves(oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"]))
+    st = meta["steps"][0]
+    x, mask, eps = oracle.synthetic_batch(meta["batch"], 128, 128, seed=20201004,
+                                          eps_shapes=[(meta["batch"], meta["latent_dim"])])
+    assert np.array_equal(eps[0], arrays["eps0"])
+    out = oracle.probunet_forward(sd, _t(x), _t(mask), bn_train=True)
+    loss, aux = oracle.probunet_loss(sd, out, _t(mask), _t(eps[0]), bn_train=True)
+    loss.backward()
+    assert abs(float(loss) - st["loss"]) <= 1e-5 * abs(st["loss"])
+    assert abs(float(aux["kl"]) - st["kl"]) <= 1e-4 * max(1.0, abs(st["kl"]))
+    assert G.maxabs(out["unet_features"].detach().numpy(), arrays["unet_features"]) <= 1e-4
+    assert G.maxabs(out["last_conv"].detach().numpy(), arrays["last_conv"]) <= 1e-4
+    assert G.maxabs(aux["reconstruction"].detach().numpy(), arrays["reconstruction"]) <= 1e-4
+    assert G.maxabs(out["posterior_mu"].detach().numpy(), arrays["post_mu"]) <= 1e-5
+    assert G.maxabs(out["prior_sigma"].detach().numpy(), arrays["prior_sigma"]) <= 1e-5
+    none = sorted(k for k, v in sd.items() if v.requires_grad and v.grad is None)
+    assert none == sorted(st["none_grads"])
+    noise = G.bn_shadowed_biases(sd.keys())
+    for k, v in sd.items():
+        if v.requires_grad and v.grad is not None and k not in noise:
+            ref = arrays["grad:" + k]
+            assert G.maxabs(v.grad.numpy(), ref) <= 2e-3 * (1e-3 + float(np.abs(ref).max())), k

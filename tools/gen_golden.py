@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REAL reference (build container only).
+
+Imports /root/reference read-only (never copied, never shipped), runs its
+models on CPU with fixed weights / inputs / noise, and writes plain-data
+fixtures (npz arrays + json metadata) under tests/golden/.  The GPU box never
+sees the reference; it only sees these vectors.
+
+    python tools/gen_golden.py            # regenerates every fixture
+
+Recipe for importing the reference: SURVEY.md Appendix B (three absent
+third-party modules, never called on the hot path, are stubbed).
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+for _name in ("medpy", "medpy.metric", "nibabel", "revtorch"):
+    sys.modules[_name] = types.ModuleType(_name)
+sys.modules["medpy.metric"].jc = sys.modules["medpy.metric"].dc = lambda a, b: 0.0
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+
+import torch  # noqa: E402
+
+torch.set_num_threads(4)
+from models.phiseg import PHISeg  # noqa: E402  (reference)
+from models.unet import Unet  # noqa: E402  (reference)
+from models.probabilistic_unet import ProbabilisticUnet  # noqa: E402  (reference)
+import utils as ref_utils  # noqa: E402  (reference)
+
+from oracle.refgraph import synthetic_batch, deterministic_state_dict, phiseg_eps_shapes  # noqa: E402
+
+
+# --------------------------------------------------------------------------- #
+def kinds_for(sd):
+    """(key, shape, kind) spec for oracle.deterministic_state_dict from a real state_dict."""
+    keys = list(sd.keys())
+    spec = []
+    for k in keys:
+        v = sd[k]
+        if k.endswith("num_batches_tracked"):
+            kind = "bn_nbt"
+        elif k.endswith("running_mean"):
+            kind = "bn_rm"
+        elif k.endswith("running_var"):
+            kind = "bn_rv"
+        elif v.dim() == 4:
+            kind = "conv_w"
+        else:
+            stem = k.rsplit(".", 1)[0]
+            is_conv = sd[stem + ".weight"].dim() == 4
+            if is_conv:
+                kind = "conv_b"
+            else:
+                kind = "bn_w" if k.endswith(".weight") else "bn_b"
+        spec.append((k, tuple(v.shape), kind))
+    return spec
+
+
+class NoiseFeeder:
+    """Replaces torch.randn_like / distributions' _standard_normal by a queue of given tensors."""
+
+    def __init__(self, tensors):
+        self.q = [torch.as_tensor(t) for t in tensors]
+        self.used = 0
+
+    def randn_like(self, ref, **kw):
+        t = self.q[self.used]
+        self.used += 1
+        assert tuple(t.shape) == tuple(ref.shape), (t.shape, ref.shape)
+        return t.clone()
+
+    def standard_normal(self, shape, dtype, device):
+        t = self.q[self.used]
+        self.used += 1
+        assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+        return t.clone()
+
+    def __enter__(self):
+        self._a = torch.randn_like
+        self._b = torch.distributions.normal._standard_normal
+        torch.randn_like = self.randn_like
+        torch.distributions.normal._standard_normal = self.standard_normal
+        return self
+
+    def __exit__(self, *a):
+        torch.randn_like = self._a
+        torch.distributions.normal._standard_normal = self._b
+
+
+def npf(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def save(name, arrays, meta):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    sz = os.path.getsize(os.path.join(OUT, name + ".npz"))
+    print(f"wrote {name}: {len(arrays)} arrays, {sz / 1024:.0f} KiB")
+
+
+def grads_of(net):
+    return {n: (None if p.grad is None else npf(p.grad)) for n, p in net.named_parameters()}
+
+
+# --------------------------------------------------------------------------- #
+def phiseg_case(name, filters, hw, batch, n_steps, store_full, seed):
+    net = PHISeg(input_channels=1, num_classes=2, num_filters=filters, latent_levels=5,
+                 image_size=(1, hw, hw))
+    spec = kinds_for(net.state_dict())
+    sd0 = deterministic_state_dict(spec, seed=seed)
+    net.load_state_dict(sd0)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)   # train_model.py:49
+
+    shapes = phiseg_eps_shapes(batch, hw, hw)
+    arrays, meta = {}, dict(model="PHISeg", filters=filters, hw=hw, batch=batch, weight_seed=seed,
+                            spec=[[k, list(s), kd] for k, s, kd in spec], steps=[])
+    for step in range(n_steps):
+        x, mask, eps = synthetic_batch(batch, hw, hw, seed=20201004 + step, eps_shapes=shapes + shapes)
+        xt, mt = torch.from_numpy(x), torch.from_numpy(mask)
+        with NoiseFeeder(eps) as nf:
+            s_list = net.forward(xt, mt, training=True)
+            assert nf.used == 10
+        loss = net.loss(mt)
+        opt.zero_grad()
+        loss.backward()
+        g = grads_of(net)
+        st = dict(loss=float(loss), loss_dict={k: float(v) for k, v in net.loss_dict.items()},
+                  none_grads=[k for k, v in g.items() if v is None],
+                  kl_alias=float(net.kl_divergence_loss), recon_alias=float(net.reconstruction_loss))
+        if step == 0:
+            arrays["x"], arrays["mask"] = x, mask
+            for i, e in enumerate(eps):
+                arrays[f"eps{i}"] = e
+            if store_full:
+                for l in range(5):
+                    arrays[f"s{l}"] = npf(s_list[l])
+                    for nm, lst in (("post_mu", net.posterior_mu), ("post_sigma", net.posterior_sigma),
+                                    ("post_z", net.posterior_latent_space), ("prior_mu", net.prior_mu),
+                                    ("prior_sigma", net.prior_sigma)):
+                        arrays[f"{nm}{l}"] = npf(lst[l])
+                for k, v in g.items():
+                    if v is not None:
+                        arrays["grad:" + k] = v
+                for k, v in net.state_dict().items():
+                    if "running_" in k:
+                        arrays["buf1:" + k] = npf(v)
+            else:
+                # digests only (full-size case): sampled logits, grad norms + 8 sampled entries
+                rs = np.random.Generator(np.random.PCG64(7))
+                idx = rs.integers(0, batch * 2 * hw * hw, size=256)
+                arrays["s_idx"] = idx
+                for l in range(5):
+                    arrays[f"s{l}_samp"] = npf(s_list[l]).reshape(-1)[idx]
+                    arrays[f"post_mu{l}"] = npf(net.posterior_mu[l])
+                    arrays[f"post_sigma{l}"] = npf(net.posterior_sigma[l])
+                    arrays[f"prior_mu{l}"] = npf(net.prior_mu[l])
+                    arrays[f"prior_sigma{l}"] = npf(net.prior_sigma[l])
+                gn, gs = {}, {}
+                for k, v in g.items():
+                    if v is not None:
+                        gn[k] = float(np.sqrt((v.astype(np.float64) ** 2).sum()))
+                        flat = v.reshape(-1)
+                        pick = rs.integers(0, flat.size, size=min(8, flat.size))
+                        gs[k] = [pick.tolist(), flat[pick].astype(float).tolist()]
+                st["grad_norms"], st["grad_samples"] = gn, gs
+        opt.step()
+        meta["steps"].append(st)
+    if store_full:
+        for k, v in net.state_dict().items():
+            if v.dtype.is_floating_point:
+                arrays["final:" + k] = npf(v)
+        meta["final_nbt"] = int(net.state_dict()[spec[6][0]]) if spec[6][2] == "bn_nbt" else None
+
+    # eval-mode pass (validate(): net.eval(), forward(training=False), accumulate_output(softmax), argmax)
+    net.load_state_dict(sd0)
+    net.eval()
+    x, mask, eps = synthetic_batch(batch, hw, hw, seed=20201004, eps_shapes=shapes + shapes)
+    with torch.no_grad(), NoiseFeeder(eps):
+        s_list = net.forward(torch.from_numpy(x), torch.from_numpy(mask), training=False)
+        s_copy = [t.clone() for t in s_list]
+        soft = net.accumulate_output(s_list, use_softmax=True)
+    arg = torch.argmax(soft, dim=1).numpy().astype(np.uint8)
+    acc = sum(s_copy)
+    margin = float((acc[:, 1] - acc[:, 0]).abs().min())
+    arrays["eval_argmax_bits"] = np.packbits(arg.reshape(-1))
+    meta["eval_margin_min"] = margin
+    meta["eval_alias_inplace"] = bool(not torch.equal(s_list[-1], s_copy[-1]))   # in-place accumulate quirk (phiseg.py:428-434)
+    if store_full:
+        arrays["eval_softmax"] = npf(soft)
+        for l in range(5):
+            arrays[f"eval_s{l}"] = npf(s_copy[l])
+    else:
+        arrays["eval_acc_samp"] = npf(acc).reshape(-1)[arrays["s_idx"]]
+    save(name, arrays, meta)
+
+
+def unet_case(name, filters, batch, n_steps, seed):
+    hw = 128                                                           # Unet.loss hard-codes 128 (unet.py:163)
+    net = Unet(1, 2, filters)
+    spec = kinds_for(net.state_dict())
+    sd0 = deterministic_state_dict(spec, seed=seed)
+    net.load_state_dict(sd0)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    arrays, meta = {}, dict(model="Unet", filters=filters, hw=hw, batch=batch, weight_seed=seed,
+                            spec=[[k, list(s), kd] for k, s, kd in spec], steps=[])
+    for step in range(n_steps):
+        x, mask, _ = synthetic_batch(batch, hw, hw, seed=20201004 + step)
+        pred = net.forward(torch.from_numpy(x))
+        loss = net.loss(torch.from_numpy(mask))
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            arrays["x"], arrays["mask"], arrays["pred"] = x, mask, npf(pred)
+            for k, v in grads_of(net).items():
+                arrays["grad:" + k] = v
+        opt.step()
+        meta["steps"].append(dict(loss=float(loss)))
+    for k, v in net.state_dict().items():
+        arrays["final:" + k] = npf(v)
+    save(name, arrays, meta)
+
+
+def probunet_case(name, filters, latent_dim, batch, n_steps, seed):
+    hw = 128
+    net = ProbabilisticUnet(input_channels=1, num_classes=2, num_filters=filters, latent_dim=latent_dim,
+                            no_convs_fcomb=3, image_size=(1, hw, hw))
+    spec = kinds_for(net.state_dict())
+    sd0 = deterministic_state_dict(spec, seed=seed)
+    net.load_state_dict(sd0)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    arrays, meta = {}, dict(model="ProbabilisticUnet", filters=filters, latent_dim=latent_dim, hw=hw, batch=batch,
+                            weight_seed=seed, spec=[[k, list(s), kd] for k, s, kd in spec], steps=[])
+    for step in range(n_steps):
+        x, mask, eps = synthetic_batch(batch, hw, hw, seed=20201004 + step, eps_shapes=[(batch, latent_dim)])
+        xt, mt = torch.from_numpy(x), torch.from_numpy(mask)
+        last = net.forward(xt, mt, training=True)
+        with NoiseFeeder(eps) as nf:
+            loss = net.loss(mt)
+            assert nf.used == 1
+        opt.zero_grad()
+        loss.backward()
+        g = grads_of(net)
+        if step == 0:
+            arrays["x"], arrays["mask"], arrays["eps0"] = x, mask, eps[0]
+            arrays["last_conv"] = npf(last)
+            arrays["unet_features"] = npf(net.unet_features)
+            arrays["reconstruction"] = npf(net.reconstruction)
+            arrays["post_mu"] = npf(net.posterior_latent_space.mean)
+            arrays["post_sigma"] = npf(net.posterior_latent_space.stddev)
+            arrays["prior_mu"] = npf(net.prior_latent_space.mean)
+            arrays["prior_sigma"] = npf(net.prior_latent_space.stddev)
+            for k, v in g.items():
+                if v is not None:
+                    arrays["grad:" + k] = v
+        opt.step()
+        meta["steps"].append(dict(loss=float(loss), kl=float(net.kl_divergence_loss),
+                                  recon=float(net.reconstruction_loss),
+                                  none_grads=[k for k, v in g.items() if v is None]))
+    for k, v in net.state_dict().items():
+        if v.dtype.is_floating_point:
+            arrays["final:" + k] = npf(v)
+    save(name, arrays, meta)
+
+
+def op_cases():
+    """G1: reference-authored arithmetic that is not a stock torch op."""
+    rs = np.random.Generator(np.random.PCG64(99))
+    arrays, meta = {}, {}
+    net = PHISeg(1, 2, [4, 8, 8, 8, 8, 8, 8], image_size=(1, 64, 64))
+    # KL with the sigma1*sigma0 quirk, incl. tiny sigmas (log(... + 1e-10) edge)
+    for i, scale in enumerate([1.0, 1e-3, 1e-6]):
+        mu0, mu1 = (rs.standard_normal((3, 2, 4, 4)).astype(np.float32) for _ in range(2))
+        s0, s1 = (np.abs(rs.standard_normal((3, 2, 4, 4))).astype(np.float32) * scale + 1e-7 for _ in range(2))
+        t = [torch.tensor(a, requires_grad=True) for a in (mu0, s0, mu1, s1)]
+        kl = net.KL_two_gauss_with_diag_cov(*t)
+        kl.backward()
+        for nm, a, tt in zip(("mu0", "s0", "mu1", "s1"), (mu0, s0, mu1, s1), t):
+            arrays[f"kl{i}_{nm}"] = a
+            arrays[f"kl{i}_d{nm}"] = npf(tt.grad)
+        meta[f"kl{i}"] = float(kl)
+    # one-hot of a batch of label maps (utils.py:289-311)
+    lab = (rs.uniform(size=(3, 1, 8, 8)) > 0.5).astype(np.float32)
+    arrays["onehot_in"] = lab
+    arrays["onehot_out"] = ref_utils.convert_batch_to_onehot(torch.from_numpy(lab), nlabels=2).numpy().astype(np.int64)
+    # l2_regularisation (utils.py:93-101)
+    lin = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4))
+    arrays["l2_w0"], arrays["l2_b0"] = npf(lin[0].weight), npf(lin[0].bias)
+    arrays["l2_w1"], arrays["l2_b1"] = npf(lin[1].weight), npf(lin[1].bias)
+    meta["l2"] = float(ref_utils.l2_regularisation(lin))
+    # residual multinoulli loss on cumulative logits (phiseg.py:481-513)
+    s = [rs.standard_normal((2, 2, 8, 8)).astype(np.float32) for _ in range(5)]
+    tgt = (rs.uniform(size=(2, 1, 8, 8)) > 0.5).astype(np.float32)
+    net.loss_tot = 0
+    st = [torch.tensor(a, requires_grad=True) for a in s]
+    tot = net.residual_multinoulli_loss(st, torch.from_numpy(tgt))
+    tot.backward()
+    for i in range(5):
+        arrays[f"rm_s{i}"], arrays[f"rm_ds{i}"] = s[i], npf(st[i].grad)
+        meta[f"rm_lvl{i}"] = float(net.loss_dict["residual_multinoulli_loss_lvl%d" % i])
+    arrays["rm_target"] = tgt
+    meta["rm_total"] = float(tot)
+    save("ops", arrays, meta)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    op_cases()
+    phiseg_case("phiseg_small", [4, 8, 8, 8, 8, 8, 8], 64, 2, 3, True, 1234)
+    unet_case("unet_small", [4, 8, 8, 8], 2, 3, 1235)
+    probunet_case("probunet_small", [32, 8, 8, 8, 8, 8, 8], 6, 2, 3, 1236)
+    phiseg_case("phiseg_full_digest", [32, 64, 128, 192, 192, 192, 192], 128, 2, 1, False, 1237)
