@@ -1,0 +1,210 @@
+/*
+ * uz_api.h - C ABI of libuz_hip.so: the MI355X (gfx950) implementation of the
+ * U-Net / PHiSeg / Probabilistic-U-Net forward+backward hot path of
+ * gigantenbein/UNet-Zoo.
+ *
+ * The reference has NO native / FFI boundary of its own: the path
+ * sits behind Python nn.Module classes that dispatch ATen ops.  Each entry point
+ * below therefore replaces one ATen call site of the reference; the call site
+ * it replaces is cited (file:line relative to the reference repository).
+ *
+ * Conventions
+ *  - plain C, no torch types: device pointers + sizes.  Tensors are fp32 NCHW.
+ *    A tensor argument is a *channel-slice view*: `ptr` points at channel 0 of
+ *    the view, `C` is the number of channels of the view and `Ctot` the channel
+ *    count of the underlying buffer (batch stride = Ctot*H*W floats).  Writing a
+ *    producer's output at a channel offset of a wider buffer is how torch.cat
+ *    (phiseg.py:71,315; unet.py:72) is eliminated.
+ *  - every call is asynchronous on the given hipStream_t (passed as void*); no
+ *    call synchronises the device or allocates device memory.
+ *  - return 0 on success, <0 on error; uz_last_error() gives the message
+ *    (thread local, valid until the next call on that thread).
+ *  - `accumulate != 0` means dst += result (gradient fan-in), else dst = result.
+ */
+#ifndef UZ_API_H
+#define UZ_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UZ_VERSION 100
+
+int         uz_version(void);
+const char* uz_last_error(void);
+/* number of MI355X compute units / device name of the current device (diagnostics) */
+int         uz_device_info(int* n_cu, char* name, int name_cap);
+
+/* ---------------------------------------------------------------- convolution
+ * nn.Conv2d(k=3, stride 1, pad 1) / nn.Conv2d(k=1): torchlayers.py:18, unet.py:25-29,
+ * phiseg.py:95-96,281-284, probabilistic_unet.py:95,156-163.  w is the PyTorch
+ * parameter itself, layout [Cout][Cin][ks][ks]; bias may be NULL.
+ * One fp32-MFMA implicit-GEMM kernel family serves every layer, including the 1..3-channel
+ * image / latent inputs and the 2-class 1x1 heads (channel tiles are zero padded in LDS). */
+int uz_conv_fwd(const float* x, int Cin, int CinTot,
+                const float* w, const float* bias,
+                float* y, int Cout, int CoutTot,
+                int N, int H, int W, int ks, int relu, void* stream);
+/* autograd of the above w.r.t. its input (aten::convolution_backward, input part):
+ * dx[b,ci] (+)= sum_co sum_tap dy[b,co,.] * w[co,ci,flip(tap)]                 */
+int uz_conv_bwd_data(const float* dy, int Cout, int CoutTot,
+                     const float* w,
+                     float* dx, int Cin, int CinTot,
+                     int N, int H, int W, int ks, int accumulate, void* stream);
+/* autograd w.r.t. the weight: dw[co,ci,tap] = sum_{b,y,x} dy * x_shifted.
+ * Deterministic split-K: partial slabs in `workspace` (uz_conv_bwd_weight_workspace
+ * bytes), then an ordered reduction.  db (nullable) = sum_{b,y,x} dy.           */
+size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, int W, int ks);
+int uz_conv_bwd_weight(const float* x, int Cin, int CinTot,
+                       const float* dy, int Cout, int CoutTot,
+                       float* dw, float* db,
+                       int N, int H, int W, int ks,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------- BatchNorm2d(eps, momentum) + ReLU
+ * torchlayers.py:20-21 (nn.BatchNorm2d(eps=1e-3, momentum=0.01) -> nn.ReLU).
+ * training != 0: batch statistics (biased var) normalise, running stats get the
+ * momentum update with the unbiased var; save_mean_rstd[2*C] keeps (mean, rstd) for
+ * backward.  training == 0: running stats normalise.  workspace >= uz_bn_workspace(). */
+size_t uz_bn_workspace(int C, int N, int H, int W);
+int uz_bn_relu_fwd(const float* y, int C, int CtotY,
+                   const float* gamma, const float* beta,
+                   float* running_mean, float* running_var,
+                   float* save_mean_rstd,
+                   float* a, int CtotA,
+                   int N, int H, int W, float eps, float momentum, int training, int relu,
+                   void* workspace, void* stream);
+/* native_batch_norm_backward + threshold_backward: da -> dy, dgamma, dbeta, and the
+ * conv-bias gradient dbias = sum dy (nullable).  dy may alias da.               */
+int uz_bn_relu_bwd(const float* da, int CtotDa,
+                   const float* y, int C, int CtotY,
+                   const float* gamma, const float* beta, const float* save_mean_rstd,
+                   float* dy, int CtotDy,
+                   float* dgamma, float* dbeta, float* dbias,
+                   int N, int H, int W, int relu,
+                   void* workspace, void* stream);
+/* ReLU-only units of the vanilla U-Net (unet.py:26,28,30): da * [a > 0] (threshold_backward)
+ * fused with the conv-bias gradient.                                              */
+int uz_relu_bwd(const float* da, int CtotDa, const float* a, int C, int CtotA,
+                float* dy, int CtotDy, float* dbias,
+                int N, int H, int W, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------- resampling
+ * nn.AvgPool2d(2, 2, padding=0, ceil_mode=True): phiseg.py:23, unet.py:22,
+ * probabilistic_unet.py:56.  Ho = ceil(H/2); partial windows divide by the
+ * in-bounds element count.                                                        */
+int uz_avgpool2_fwd(const float* x, int C, int CtotX, float* y, int CtotY,
+                    int N, int H, int W, void* stream);
+int uz_avgpool2_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx,
+                    int N, int H, int W, int accumulate, void* stream);
+/* F.interpolate(mode='bilinear', scale_factor=2, align_corners=ac): phiseg.py:66,213-216,
+ * 305-309 (ac=1), unet.py:67 (ac=0).  (H, W) are the INPUT sizes.                 */
+int uz_bilinear2x_fwd(const float* x, int C, int CtotX, float* y, int CtotY,
+                      int N, int H, int W, int align_corners, void* stream);
+int uz_bilinear2x_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx,
+                      int N, int H, int W, int align_corners, int accumulate, void* stream);
+/* F.interpolate(size=[Ho,Wo], mode='nearest'), integer factor: phiseg.py:321        */
+int uz_nearest_fwd(const float* x, int C, int CtotX, float* y, int CtotY,
+                   int N, int H, int W, int factor, void* stream);
+int uz_nearest_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx,
+                   int N, int H, int W, int factor, int accumulate, void* stream);
+/* torch.mean over H then W (probabilistic_unet.py:114-115): (N,C,H,W) -> (N,C)       */
+int uz_spatial_mean_fwd(const float* x, int C, int CtotX, float* y, int N, int H, int W, void* stream);
+int uz_spatial_mean_bwd(const float* dy, int C, float* dx, int CtotDx, int N, int H, int W,
+                        int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- latent heads / losses
+ * mask (N,1,H,W) float {0,1,..} -> cat([patch, onehot(mask)-0.5], 1): utils.py:289-311,
+ * phiseg.py:178-183, probabilistic_unet.py:103-109.  out has in_ch + nlabels channels. */
+int uz_posterior_input(const float* patch, int in_ch, const float* mask, int nlabels,
+                       float* out, int N, int H, int W, void* stream);
+/* Reparameterised latent sample.  act = 0: SampleZBlock tail (phiseg.py:100-105), sigma =
+ * softplus(pre_sigma) (beta 1, threshold 20); act = 1: AxisAlignedConvGaussian + rsample
+ * (probabilistic_unet.py:124-129,350), sigma = exp(pre_sigma).  z = mu + sigma * eps (z nullable:
+ * the prior's own draw is discarded in training, phiseg.py:200-202).  n = number of elements. */
+int uz_latent_sample_fwd(const float* mu, const float* pre_sigma, const float* eps,
+                         float* sigma, float* z, size_t n, int act, void* stream);
+/* dmu_pre = dmu + dz ; dpre_sigma = (dsigma + dz*eps) * dsigma/dpre, with dsigma/dpre =
+ * 1 - exp(-sigma) (softplus) or sigma (exp); dmu / dsigma / dz are nullable (treated as 0).  */
+int uz_latent_sample_bwd(const float* dmu, const float* dsigma, const float* dz,
+                         const float* eps, const float* sigma,
+                         float* dmu_pre, float* dpre_sigma, size_t n, int act, void* stream);
+/* KL_two_gauss_with_diag_cov with the reference's sigma1*sigma0 quirk (phiseg.py:436-453),
+ * times `weight` (4**level, phiseg.py:463).  Tensors are (N, per_sample) contiguous.
+ * fwd writes loss_out[0] (single block, ordered); bwd writes the four gradients * scale. */
+int uz_kl_fwd(const float* mu0, const float* s0, const float* mu1, const float* s1,
+              int N, int per_sample, float weight, float* loss_out, void* stream);
+int uz_kl_bwd(const float* mu0, const float* s0, const float* mu1, const float* s1,
+              int N, int per_sample, float weight, const float* loss_scale,
+              float* dmu0, float* ds0, float* dmu1, float* ds1, void* stream);
+/* residual_multinoulli_loss (phiseg.py:481-513), 2..8 classes, L levels of (N,K,H,W) logits
+ * given as an array of L device pointers held in DEVICE memory (s_ptrs).  level l loss =
+ * mean_b sum_pix CE(sum_{j>=l} s_j, mask).  loss_out[l], l=0..L-1.                      */
+size_t uz_ce_workspace(int N, int H, int W, int L);
+int uz_residual_ce_fwd(const float* const* s_ptrs, int L, int K, const float* mask,
+                       int N, int H, int W, float* loss_out, void* workspace, void* stream);
+int uz_residual_ce_bwd(const float* const* s_ptrs, float* const* ds_ptrs, int L, int K, const float* mask,
+                       int N, int H, int W, const float* loss_scale, void* stream);
+/* nn.CrossEntropyLoss() mean over all pixels (unet.py:159-165) = residual CE with L=1 scaled 1/(H*W) */
+/* loss_terms[0..n-1] -> total[0] = sum (ordered)                                         */
+int uz_sum_terms(const float* terms, int n, float* total, void* stream);
+/* accumulate_output(use_softmax) + argmax (phiseg.py:428-434, train_model.py:186,195):
+ * acc = sum_l s_l ; soft = softmax_c(acc) ; label = argmax_c.  soft / label nullable.     */
+int uz_accumulate_softmax_argmax(const float* const* s_ptrs, int L, int K, int N, int H, int W,
+                                 float* acc, float* soft, uint8_t* label, void* stream);
+
+/* ---------------------------------------------------------------- optimiser / vector ops
+ * torch.optim.Adam(lr, betas, eps, weight_decay as L2 added to the gradient): train_model.py:49,122.
+ * One launch over a contiguous range of the flat parameter buffer.                        */
+int uz_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                 int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                 float grad_scale, void* stream);
+int uz_axpy(float* y, const float* x, float alpha, size_t n, void* stream);     /* y += alpha*x */
+int uz_scale(float* y, float alpha, size_t n, void* stream);                    /* y *= alpha   */
+/* sqrt(sum x^2) terms of utils.l2_regularisation (utils.py:93-101): one norm per tensor of a
+ * table of (offset, count) pairs over the flat parameter buffer; out[i] = ||p_i||_2.       */
+int uz_l2_norms(const float* flat, const int64_t* offs_counts, int n_tensors, float* out, void* stream);
+int uz_l2_norms_bwd(const float* flat, const int64_t* offs_counts, int n_tensors, const float* norms,
+                    const float* scale, float* grad_flat, void* stream);          /* g += scale * p / ||p|| */
+
+/* ---------------------------------------------------------------- op tape
+ * A forward or backward pass is a static list of the calls above ("tape"), built once by
+ * the host for a (model, N, H, W) and replayed with ONE FFI call per pass - or captured
+ * into a hipGraph.  uz_op mirrors the argument lists above positionally: p[] pointers,
+ * i[] ints, f[] floats, in declaration order of the corresponding function.               */
+enum {
+  UZ_OP_CONV_FWD = 1, UZ_OP_CONV_BWD_DATA, UZ_OP_CONV_BWD_WEIGHT,
+  UZ_OP_BN_RELU_FWD, UZ_OP_BN_RELU_BWD, UZ_OP_RELU_BWD,
+  UZ_OP_AVGPOOL_FWD, UZ_OP_AVGPOOL_BWD, UZ_OP_BILINEAR_FWD, UZ_OP_BILINEAR_BWD,
+  UZ_OP_NEAREST_FWD, UZ_OP_NEAREST_BWD, UZ_OP_SPATIAL_MEAN_FWD, UZ_OP_SPATIAL_MEAN_BWD,
+  UZ_OP_POSTERIOR_INPUT, UZ_OP_LATENT_FWD, UZ_OP_LATENT_BWD, UZ_OP_KL_FWD, UZ_OP_KL_BWD,
+  UZ_OP_CE_FWD, UZ_OP_CE_BWD, UZ_OP_SUM_TERMS, UZ_OP_ACC_SOFTMAX_ARGMAX,
+  UZ_OP_ADAM, UZ_OP_AXPY, UZ_OP_SCALE, UZ_OP_L2_NORMS, UZ_OP_L2_NORMS_BWD,
+  UZ_OP_MEMSET, UZ_OP_COPY, UZ_OP_BCAST_CHANNELS, UZ_OP_BCAST_CHANNELS_BWD,
+  UZ_OP__COUNT
+};
+typedef struct uz_op {
+  int32_t  code;
+  int32_t  i[15];
+  float    f[4];
+  int64_t  n;          /* element / byte count for the vector ops */
+  void*    p[12];
+} uz_op;
+int uz_run_tape(const uz_op* ops, int n_ops, void* stream);
+/* Capture the tape into a hipGraph on `stream` and return an opaque executable handle. */
+int  uz_graph_create(const uz_op* ops, int n_ops, void* stream, void** graph_exec_out);
+int  uz_graph_launch(void* graph_exec, void* stream);
+void uz_graph_destroy(void* graph_exec);
+
+/* Fcomb input (probabilistic_unet.py:172-197) */
+/* z (N,L) tiled over HxW into channels of a (N,Ctot,H,W) buffer, and its backward (sum over pixels) */
+int uz_bcast_channels_fwd(const float* z, int L, float* y, int CtotY, int N, int H, int W, void* stream);
+int uz_bcast_channels_bwd(const float* dy, int CtotDy, int L, float* dz, int N, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UZ_API_H */

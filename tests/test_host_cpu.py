@@ -1,0 +1,59 @@
+"""CPU-tier checks of the host side: the C-ABI library loads and exports every symbol the header
+declares, the state_dict surface equals the reference's (golden key lists), plans build, and the
+product path refuses to run without a GPU (no CPU fallback)."""
+import json
+import os
+
+import pytest
+import torch
+
+import unet_zoo_amd  # noqa: F401
+from unet_zoo_amd import _ffi
+from tests import _golden as G
+
+
+def test_library_exports_every_declared_symbol():
+    L = _ffi.lib()
+    names = _ffi.header_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(L, n), n
+    assert L.uz_version() == 100
+    codes = _ffi.op_codes()
+    assert codes["UZ_OP_CONV_FWD"] == 1 and len(set(codes.values())) == len(codes)
+
+
+def test_phiseg_spec_equals_reference_state_dict():
+    from unet_zoo_amd.models.phiseg import phiseg_spec
+    for name in ("phiseg_small", "phiseg_full_digest"):
+        _, meta = G.load(name)
+        assert phiseg_spec(1, 2, meta["filters"]) == G.spec_of(meta)
+
+
+def test_phiseg_structure_only_on_cpu_and_no_fallback():
+    from unet_zoo_amd.models.phiseg import PHISeg
+    _, meta = G.load("phiseg_small")
+    net = PHISeg(1, 2, meta["filters"], image_size=(1, 64, 64), device="cpu")
+    assert list(net.state_dict().keys()) == [k for k, _, _ in G.spec_of(meta)]
+    assert sum(p.numel() for p in net.parameters()) == net._ptab.n_params
+    plan = net._build(2, 64, 64, True, True)
+    cnt = plan.summary()
+    assert cnt["fwd"] == 287 and cnt["bwd"] > 400
+    unused = sorted(k for k in net._pmap if k not in plan.param_grads)
+    assert len(unused) == 16 and all("upsampling_path.4" in k for k in unused)
+    if not torch.cuda.is_available():
+        with pytest.raises(_ffi.UzError):
+            net.forward(torch.zeros(2, 1, 64, 64), torch.zeros(2, 1, 64, 64))
+
+
+def test_full_phiseg_parameter_count():
+    from unet_zoo_amd.models.phiseg import phiseg_spec
+    spec = phiseg_spec(1, 2, [32, 64, 128, 192, 192, 192, 192])
+    n = 0
+    for _, shape, kind in spec:
+        if kind in ("conv_w", "conv_b", "bn_w", "bn_b"):
+            k = 1
+            for s in shape:
+                k *= s
+            n += k
+    assert n == 24513330 and len(spec) == 820

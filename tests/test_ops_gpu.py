@@ -1,0 +1,351 @@
+"""Per-op parity of every HIP kernel family against a plain fp32 PyTorch CPU reference of the same
+op (and against the reference-generated golden vectors for the reference-authored arithmetic).
+All calls go through the C ABI of libuz_hip.so.  Tolerances: fp32 MFMA == k-ordered fmaf chain, the
+CPU reference sums in a different order, so convolutions agree to ~1e-6 relative; gates below are
+2e-5 relative to the largest reference magnitude unless stated."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def _g():
+    from tests import _gpu
+    return _gpu
+
+
+# ------------------------------------------------------------------------------ convolution
+CONV_CASES = [
+    # N, Cin, Cout, H, W, ks
+    (2, 32, 64, 32, 32, 3),
+    (3, 5, 7, 13, 9, 3),          # ragged everything
+    (32, 192, 192, 2, 2, 3),      # deepest PHiSeg level
+    (2, 3, 32, 128, 128, 3),      # image input
+    (2, 40, 48, 64, 64, 3),
+    (4, 64, 32, 16, 16, 3),
+    (2, 8, 8, 1, 1, 3),           # 1x1 spatial (small fixture's deepest level)
+    (2, 38, 32, 16, 16, 1),       # Fcomb
+    (2, 192, 2, 8, 8, 1),         # mu / sigma / s heads
+    (1, 16, 70, 40, 24, 3),       # Cout not a multiple of the channel tile, W < 32 not a power of two
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks", CONV_CASES)
+def test_conv_fwd_bwd(N, Cin, Cout, H, W, ks):
+    g = _g()
+    x = g.rnd(N, Cin, H, W, seed=1)
+    w = g.rnd(Cout, Cin, ks, ks, seed=2, scale=0.2)
+    b = g.rnd(Cout, seed=3)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=ks // 2)
+    dy = g.rnd(*yr.shape, seed=4)
+    yr.backward(dy)
+
+    # forward through channel-slice views (concat elimination): input at offset 3 of a wider buffer,
+    # output at offset 2 of a wider buffer
+    xbuf, xv = g.view_in(x, Cin + 5, 3)
+    ybuf = torch.full((N, Cout + 4, H, W), float("nan"), device=g.dev())
+    yv = ybuf[:, 2:]
+    wd, bd = w.to(g.dev()), b.to(g.dev())
+    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, yv, Cout, Cout + 4, N, H, W, ks, 0)
+    assert g.relerr(ybuf[:, 2:2 + Cout], yr) <= TOL
+    assert torch.isnan(ybuf[:, :2]).all() and torch.isnan(ybuf[:, 2 + Cout:]).all()     # neighbours untouched
+
+    # fused ReLU epilogue
+    y2 = torch.empty(N, Cout, H, W, device=g.dev())
+    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, y2, Cout, Cout, N, H, W, ks, 1)
+    assert g.relerr(y2, F.relu(yr)) <= TOL
+
+    # data gradient, overwrite then accumulate
+    dyd = dy.to(g.dev())
+    dx = torch.full((N, Cin, H, W), float("nan"), device=g.dev())
+    g.call("uz_conv_bwd_data", dyd, Cout, Cout, wd, dx, Cin, Cin, N, H, W, ks, 0)
+    assert g.relerr(dx, xr.grad) <= TOL
+    g.call("uz_conv_bwd_data", dyd, Cout, Cout, wd, dx, Cin, Cin, N, H, W, ks, 1)
+    assert g.relerr(dx, 2 * xr.grad) <= TOL
+
+    # weight + bias gradient (deterministic split-K): run twice, must be bitwise identical
+    from unet_zoo_amd import _ffi
+    ws_bytes = _ffi.lib().uz_conv_bwd_weight_workspace(Cin, Cout, N, H, W, ks)
+    ws = torch.empty(ws_bytes // 4 + 16, device=g.dev())
+    dw = torch.full_like(wd, float("nan"))
+    db = torch.full_like(bd, float("nan"))
+    g.call("uz_conv_bwd_weight", xv, Cin, Cin + 5, dyd, Cout, Cout, dw, db, N, H, W, ks, ws, ws_bytes)
+    assert g.relerr(dw, wr.grad) <= TOL
+    assert g.relerr(db, br.grad) <= TOL
+    dw2 = torch.empty_like(dw)
+    g.call("uz_conv_bwd_weight", xv, Cin, Cin + 5, dyd, Cout, Cout, dw2, None, N, H, W, ks, ws, ws_bytes)
+    assert torch.equal(dw, dw2)
+
+
+def test_conv_full_size_linearity():
+    """BASELINE-size layer (224->128 @128x128, the heaviest PHiSeg conv): too big for a CPU oracle in
+    seconds at batch 32, so check size-independent properties: linearity in the input and agreement
+    with the CPU reference on two images of the batch."""
+    g = _g()
+    N, Cin, Cout, H, W = 8, 224, 128, 128, 128
+    x1 = torch.randn(N, Cin, H, W, device=g.dev())
+    x2 = torch.randn(N, Cin, H, W, device=g.dev())
+    w = torch.randn(Cout, Cin, 3, 3, device=g.dev()) * 0.05
+    out = [torch.empty(N, Cout, H, W, device=g.dev()) for _ in range(3)]
+    for xin, o in zip((x1, x2, x1 + 2 * x2), out):
+        g.call("uz_conv_fwd", xin, Cin, Cin, w, None, o, Cout, Cout, N, H, W, 3, 0)
+    assert g.relerr(out[2], out[0] + 2 * out[1]) <= 1e-5
+    ref = F.conv2d(x1[5:7].cpu(), w.cpu(), None, padding=1)
+    assert g.relerr(out[0][5:7], ref) <= TOL
+
+
+# ------------------------------------------------------------------------------ BatchNorm + ReLU
+@pytest.mark.parametrize("N,C,H,W", [(2, 8, 4, 4), (32, 16, 2, 2), (4, 6, 64, 64), (2, 5, 33, 17), (20, 3, 33, 17), (3, 4, 128, 128)])
+@pytest.mark.parametrize("relu", [1, 0])
+def test_bn_relu_fwd_bwd(N, C, H, W, relu):
+    g = _g()
+    from unet_zoo_amd import _ffi
+    y = g.rnd(N, C, H, W, seed=5) * 2 + 0.7
+    gamma, beta = g.rnd(C, seed=6).abs() + 0.5, g.rnd(C, seed=7) * 0.3
+    rm, rv = g.rnd(C, seed=8) * 0.1, g.rnd(C, seed=9).abs() + 0.5
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    o = F.batch_norm(yr, rm_r, rv_r, gr, br, training=True, momentum=0.01, eps=1e-3)
+    ar = F.relu(o) if relu else o
+    da = g.rnd(N, C, H, W, seed=10)
+    ar.backward(da)
+
+    ws = torch.empty(_ffi.lib().uz_bn_workspace(C, N, H, W) // 4 + 16, device=g.dev())
+    ybuf, yv = g.view_in(y, C + 3, 1)
+    abuf = torch.full((N, C + 2, H, W), float("nan"), device=g.dev())
+    av = abuf[:, 2:]
+    gd, bd, rmd, rvd = gamma.to(g.dev()), beta.to(g.dev()), rm.to(g.dev()), rv.to(g.dev())
+    save = torch.empty(2 * C, device=g.dev())
+    g.call("uz_bn_relu_fwd", yv, C, C + 3, gd, bd, rmd, rvd, save, av, C + 2, N, H, W, 1e-3, 0.01, 1, relu, ws)
+    assert g.maxabs(abuf[:, 2:], ar) <= 2e-5
+    assert g.maxabs(rmd, rm_r) <= 1e-6 and g.maxabs(rvd, rv_r) <= 1e-5
+
+    dad = da.to(g.dev())
+    dy = torch.empty(N, C, H, W, device=g.dev())
+    dgm, dbt, dbias = (torch.empty(C, device=g.dev()) for _ in range(3))
+    g.call("uz_bn_relu_bwd", dad, C, yv, C, C + 3, gd, bd, save, dy, C, dgm, dbt, dbias, N, H, W, relu, ws)
+    scale = float(yr.grad.abs().max())
+    assert g.maxabs(dy, yr.grad) <= 3e-5 * max(scale, 1.0)
+    assert g.relerr(dgm, gr.grad) <= 1e-4 and g.relerr(dbt, br.grad) <= 1e-4
+    assert float(dbias.abs().max()) <= 1e-3 * max(1.0, float(da.abs().sum()) ** 0.5)   # analytically zero
+
+    # eval mode uses the running statistics
+    oe = F.batch_norm(y, rm_r, rv_r, gamma, beta, training=False, eps=1e-3)
+    ae = F.relu(oe) if relu else oe
+    g.call("uz_bn_relu_fwd", yv, C, C + 3, gd, bd, rm_r.to(g.dev()), rv_r.to(g.dev()), None, av, C + 2, N, H, W, 1e-3, 0.01, 0, relu, ws)
+    assert g.maxabs(abuf[:, 2:], ae) <= 2e-5
+
+
+def test_relu_bwd():
+    g = _g()
+    from unet_zoo_amd import _ffi
+    N, C, H, W = 3, 6, 64, 64
+    a = F.relu(g.rnd(N, C, H, W, seed=1))
+    da = g.rnd(N, C, H, W, seed=2)
+    ws = torch.empty(_ffi.lib().uz_bn_workspace(C, N, H, W) // 4 + 16, device=g.dev())
+    dy = torch.empty(N, C, H, W, device=g.dev())
+    db = torch.empty(C, device=g.dev())
+    g.call("uz_relu_bwd", da.to(g.dev()), C, a.to(g.dev()), C, C, dy, C, db, N, H, W, ws)
+    ref = da * (a > 0)
+    assert torch.equal(dy.cpu(), ref)
+    assert g.relerr(db, ref.sum((0, 2, 3))) <= 1e-5
+
+
+# ------------------------------------------------------------------------------ resampling
+@pytest.mark.parametrize("H,W", [(8, 8), (7, 5), (1, 1), (128, 128), (3, 64)])
+def test_avgpool(H, W):
+    g = _g()
+    N, C = 2, 3
+    x = g.rnd(N, C, H, W, seed=1).requires_grad_(True)
+    yr = F.avg_pool2d(x, 2, 2, 0, ceil_mode=True)
+    dy = g.rnd(*yr.shape, seed=2)
+    yr.backward(dy)
+    y = torch.empty(*yr.shape, device=g.dev())
+    g.call("uz_avgpool2_fwd", x.detach().to(g.dev()), C, C, y, C, N, H, W)
+    assert g.maxabs(y, yr) <= 1e-6
+    dx = torch.ones(N, C, H, W, device=g.dev())
+    g.call("uz_avgpool2_bwd", dy.to(g.dev()), C, C, dx, C, N, H, W, 1)
+    assert g.maxabs(dx, x.grad + 1) <= 1e-6
+
+
+@pytest.mark.parametrize("ac", [1, 0])
+@pytest.mark.parametrize("H,W", [(4, 4), (1, 1), (2, 2), (5, 3), (32, 32), (64, 64)])
+def test_bilinear(ac, H, W):
+    g = _g()
+    N, C = 2, 3
+    x = g.rnd(N, C, H, W, seed=1).requires_grad_(True)
+    yr = F.interpolate(x, mode="bilinear", scale_factor=2, align_corners=bool(ac))
+    dy = g.rnd(*yr.shape, seed=2)
+    yr.backward(dy)
+    y = torch.empty(*yr.shape, device=g.dev())
+    g.call("uz_bilinear2x_fwd", x.detach().to(g.dev()), C, C, y, C, N, H, W, ac)
+    assert g.maxabs(y, yr) <= 2e-6
+    dx = torch.full((N, C, H, W), float("nan"), device=g.dev())
+    g.call("uz_bilinear2x_bwd", dy.to(g.dev()), C, C, dx, C, N, H, W, ac, 0)
+    assert g.maxabs(dx, x.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("f", [1, 2, 16])
+def test_nearest(f):
+    g = _g()
+    N, C, H, W = 2, 2, 8, 8
+    x = g.rnd(N, C, H, W, seed=1).requires_grad_(True)
+    yr = F.interpolate(x, size=[H * f, W * f], mode="nearest")
+    dy = g.rnd(*yr.shape, seed=2)
+    yr.backward(dy)
+    y = torch.empty(*yr.shape, device=g.dev())
+    g.call("uz_nearest_fwd", x.detach().to(g.dev()), C, C, y, C, N, H, W, f)
+    assert torch.equal(y.cpu(), yr.detach())
+    dx = torch.empty(N, C, H, W, device=g.dev())
+    g.call("uz_nearest_bwd", dy.to(g.dev()), C, C, dx, C, N, H, W, f, 0)
+    assert g.maxabs(dx, x.grad) <= 1e-4
+
+
+def test_spatial_mean_and_bcast():
+    g = _g()
+    N, C, H, W = 3, 5, 2, 2
+    x = g.rnd(N, C, H, W, seed=1).requires_grad_(True)
+    yr = torch.mean(torch.mean(x, dim=2, keepdim=True), dim=3, keepdim=True)
+    dy = g.rnd(N, C, 1, 1, seed=2)
+    yr.backward(dy)
+    y = torch.empty(N, C, device=g.dev())
+    g.call("uz_spatial_mean_fwd", x.detach().to(g.dev()), C, C, y, N, H, W)
+    assert g.maxabs(y, yr.reshape(N, C)) <= 1e-6
+    dx = torch.empty(N, C, H, W, device=g.dev())
+    g.call("uz_spatial_mean_bwd", dy.reshape(N, C).to(g.dev()), C, dx, C, N, H, W, 0)
+    assert g.maxabs(dx, x.grad) <= 1e-6
+    z = g.rnd(N, 4, seed=3)
+    buf = torch.zeros(N, 7, 8, 8, device=g.dev())
+    g.call("uz_bcast_channels_fwd", z.to(g.dev()), 4, buf[:, 3:], 7, N, 8, 8)
+    assert torch.equal(buf[:, 3:].cpu(), z[:, :, None, None].expand(N, 4, 8, 8))
+    dyb = torch.randn(N, 7, 8, 8, device=g.dev())
+    dz = torch.empty(N, 4, device=g.dev())
+    g.call("uz_bcast_channels_bwd", dyb[:, 3:], 7, 4, dz, N, 8, 8)
+    assert g.relerr(dz, dyb[:, 3:].sum((2, 3))) <= 1e-5
+
+
+# ------------------------------------------------------------------------------ heads / losses
+def test_posterior_input_bit_exact():
+    g = _g()
+    import oracle
+    arrays, _ = G.load("ops")
+    lab = torch.from_numpy(arrays["onehot_in"])
+    patch = g.rnd(3, 1, 8, 8, seed=1)
+    out = torch.empty(3, 3, 8, 8, device=g.dev())
+    g.call("uz_posterior_input", patch.to(g.dev()), 1, lab.to(g.dev()), 2, out, 3, 8, 8)
+    ref = torch.cat([patch, torch.from_numpy(arrays["onehot_out"]).float() - 0.5], dim=1)
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_latent_sample(act):
+    g = _g()
+    n = 1000
+    mu, pre, eps = g.rnd(n, seed=1), g.rnd(n, seed=2) * 3, g.rnd(n, seed=3)
+    pre[0] = 25.0          # above the softplus threshold
+    mr, pr = mu.clone().requires_grad_(True), pre.clone().requires_grad_(True)
+    sr = torch.exp(pr) if act else F.softplus(pr)
+    zr = mr + sr * eps
+    dmu, dsig, dz = g.rnd(n, seed=4), g.rnd(n, seed=5), g.rnd(n, seed=6)
+    (zr * dz + mr * dmu + sr * dsig).sum().backward()
+    sig, z = torch.empty(n, device=g.dev()), torch.empty(n, device=g.dev())
+    g.call("uz_latent_sample_fwd", mu.to(g.dev()), pre.to(g.dev()), eps.to(g.dev()), sig, z, n, act)
+    assert g.relerr(sig, sr) <= 1e-6 and g.relerr(z, zr) <= 1e-6
+    a, b = torch.empty(n, device=g.dev()), torch.empty(n, device=g.dev())
+    g.call("uz_latent_sample_bwd", dmu.to(g.dev()), dsig.to(g.dev()), dz.to(g.dev()), eps.to(g.dev()), sig, a, b, n, act)
+    assert g.relerr(a, mr.grad) <= 1e-6 and g.relerr(b, pr.grad) <= 2e-5
+
+
+def test_kl_matches_reference_golden():
+    g = _g()
+    arrays, meta = G.load("ops")
+    for i in range(3):
+        t = [torch.from_numpy(arrays[f"kl{i}_{n}"]).to(g.dev()) for n in ("mu0", "s0", "mu1", "s1")]
+        N, per = t[0].shape[0], t[0][0].numel()
+        out = torch.empty(1, device=g.dev())
+        g.call("uz_kl_fwd", *t, N, per, 1.0, out)
+        assert abs(float(out) - meta[f"kl{i}"]) <= 1e-5 * max(1.0, abs(meta[f"kl{i}"]))
+        grads = [torch.empty_like(t[0]) for _ in range(4)]
+        g.call("uz_kl_bwd", *t, N, per, 1.0, None, *grads)
+        for n, gr in zip(("mu0", "s0", "mu1", "s1"), grads):
+            ref = torch.from_numpy(arrays[f"kl{i}_d{n}"])
+            assert g.maxabs(gr, ref) <= 2e-5 * max(1.0, float(ref.abs().max())), (i, n)
+
+
+def test_residual_ce_matches_reference_golden():
+    g = _g()
+    from unet_zoo_amd import _ffi
+    arrays, meta = G.load("ops")
+    s = [torch.from_numpy(arrays[f"rm_s{i}"]).to(g.dev()).contiguous() for i in range(5)]
+    tgt = torch.from_numpy(arrays["rm_target"]).to(g.dev())
+    N, K, H, W = s[0].shape
+    tab = torch.tensor([t.data_ptr() for t in s], dtype=torch.int64, device=g.dev())
+    ws = torch.empty(_ffi.lib().uz_ce_workspace(N, H, W, 5) // 4 + 16, device=g.dev())
+    out = torch.empty(5, device=g.dev())
+    g.call("uz_residual_ce_fwd", tab, 5, K, tgt, N, H, W, out, ws)
+    for i in range(5):
+        assert abs(float(out[i]) - meta[f"rm_lvl{i}"]) <= 1e-5 * abs(meta[f"rm_lvl{i}"])
+    ds = [torch.empty_like(t) for t in s]
+    gtab = torch.tensor([t.data_ptr() for t in ds], dtype=torch.int64, device=g.dev())
+    g.call("uz_residual_ce_bwd", tab, gtab, 5, K, tgt, N, H, W, None)
+    for i in range(5):
+        assert g.maxabs(ds[i], torch.from_numpy(arrays[f"rm_ds{i}"])) <= 2e-6
+    total = torch.empty(1, device=g.dev())
+    g.call("uz_sum_terms", out, 5, total)
+    assert abs(float(total) - meta["rm_total"]) <= 1e-5 * abs(meta["rm_total"])
+
+
+def test_accumulate_softmax_argmax():
+    g = _g()
+    s = [g.rnd(2, 2, 16, 16, seed=i) for i in range(5)]
+    acc = s[-1].clone()
+    for i in range(4):
+        acc += s[i]
+    soft = F.softmax(acc, dim=1)
+    sd = [t.to(g.dev()) for t in s]
+    tab = torch.tensor([t.data_ptr() for t in sd], dtype=torch.int64, device=g.dev())
+    a, so = torch.empty(2, 2, 16, 16, device=g.dev()), torch.empty(2, 2, 16, 16, device=g.dev())
+    lab = torch.empty(2, 16, 16, dtype=torch.uint8, device=g.dev())
+    g.call("uz_accumulate_softmax_argmax", tab, 5, 2, 2, 16, 16, a, so, lab)
+    assert torch.equal(a.cpu(), acc)                       # same summation order -> bit exact
+    assert g.maxabs(so, soft) <= 1e-6
+    assert torch.equal(lab.cpu().long(), torch.argmax(soft, dim=1))
+
+
+# ------------------------------------------------------------------------------ optimiser
+def test_adam_matches_torch():
+    g = _g()
+    n = 10000
+    p0, grads = g.rnd(n, seed=1), [g.rnd(n, seed=10 + i) for i in range(3)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=1e-5)
+    p, m, v = p0.to(g.dev()), torch.zeros(n, device=g.dev()), torch.zeros(n, device=g.dev())
+    for step, gr in enumerate(grads, 1):
+        ref.grad = gr.clone()
+        opt.step()
+        g.call("uz_adam_step", p, gr.to(g.dev()), m, v, n, step, 1e-3, 0.9, 0.999, 1e-8, 1e-5, 1.0)
+    assert g.maxabs(p, ref.detach()) <= 1e-6
+
+
+def test_l2_norms():
+    g = _g()
+    flat = g.rnd(1000, seed=1).to(g.dev())
+    oc = torch.tensor([0, 100, 100, 650, 750, 250], dtype=torch.int64, device=g.dev())
+    out = torch.empty(3, device=g.dev())
+    g.call("uz_l2_norms", flat, oc, 3, out)
+    ref = torch.stack([flat[0:100].norm(), flat[100:750].norm(), flat[750:1000].norm()])
+    assert g.relerr(out, ref) <= 1e-6
+    grad = torch.zeros(1000, device=g.dev())
+    scale = torch.tensor([1e-5], device=g.dev())
+    g.call("uz_l2_norms_bwd", flat, oc, 3, out, scale, grad)
+    assert g.relerr(grad[100:750], 1e-5 * flat[100:750] / ref[1]) <= 1e-5

@@ -1,0 +1,174 @@
+"""End-to-end parity of the native PHISeg against (a) golden vectors generated from the real
+reference and (b) the CPU oracle run live on the same seeded inputs.  Gates follow BASELINE.json:
+segmentation logits within 1e-4 (fp32), bit-exact argmax label maps."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(meta, **kw):
+    from unet_zoo_amd.models.phiseg import PHISeg
+    net = PHISeg(1, 2, meta["filters"], latent_levels=5, image_size=(1, meta["hw"], meta["hw"]), **kw)
+    sd = oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"])
+    missing = net.load_state_dict(sd)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return net, sd
+
+
+def _inputs(meta, step):
+    shapes = oracle.phiseg_eps_shapes(meta["batch"], meta["hw"], meta["hw"])
+    x, mask, eps = oracle.synthetic_batch(meta["batch"], meta["hw"], meta["hw"], seed=20201004 + step, eps_shapes=shapes + shapes)
+    dev = torch.device("cuda", 0)
+    return (torch.from_numpy(x).to(dev), torch.from_numpy(mask).to(dev), [torch.from_numpy(e).to(dev) for e in eps])
+
+
+def test_state_dict_surface():
+    arrays, meta = G.load("phiseg_small")
+    net, sd = _model(meta)
+    mine = net.state_dict()
+    assert list(mine.keys()) == [k for k, _, _ in G.spec_of(meta)]
+    for k, v in mine.items():
+        assert tuple(v.shape) == tuple(sd[k].shape) and torch.equal(v.cpu(), sd[k])
+
+
+def test_phiseg_small_train_steps_vs_reference_golden():
+    from unet_zoo_amd.optim import FusedAdam
+    arrays, meta = G.load("phiseg_small")
+    net, _ = _model(meta)
+    net.train()
+    opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
+    noise = G.bn_shadowed_biases(dict(net.named_parameters()).keys())
+    for step, st in enumerate(meta["steps"]):
+        x, mask, eps = _inputs(meta, step)
+        s = net.forward(x, mask, training=True, eps=eps)
+        loss = net.loss(mask)
+        opt.zero_grad()
+        loss.backward()
+        assert abs(float(loss) - st["loss"]) <= 2e-5 * abs(st["loss"]), (step, float(loss), st["loss"])
+        for k, v in st["loss_dict"].items():
+            assert abs(float(net.loss_dict[k]) - v) <= 1e-4 * max(1.0, abs(v)), (step, k)
+        assert float(net.kl_divergence_loss) == float(loss) == float(net.reconstruction_loss)   # alias quirk
+        none = sorted(k for k, p in net.named_parameters() if p.grad is None)
+        assert none == sorted(st["none_grads"])
+        if step == 0:
+            for l in range(5):
+                assert G.maxabs(s[l].cpu().numpy(), arrays[f"s{l}"]) <= 1e-4, l            # logits gate
+                assert G.maxabs(net.posterior_mu[l].cpu().numpy(), arrays[f"post_mu{l}"]) <= 1e-4
+                assert G.maxabs(net.posterior_sigma[l].cpu().numpy(), arrays[f"post_sigma{l}"]) <= 1e-4
+                assert G.maxabs(net.posterior_latent_space[l].cpu().numpy(), arrays[f"post_z{l}"]) <= 1e-4
+                assert G.maxabs(net.prior_mu[l].cpu().numpy(), arrays[f"prior_mu{l}"]) <= 1e-4
+                assert G.maxabs(net.prior_sigma[l].cpu().numpy(), arrays[f"prior_sigma{l}"]) <= 1e-4
+            worst, wk = 0.0, None
+            for k, p in net.named_parameters():
+                if p.grad is not None and k not in noise:
+                    ref = arrays["grad:" + k]
+                    e = G.maxabs(p.grad.cpu().numpy(), ref) / (1e-3 + float(np.abs(ref).max()))
+                    if e > worst:
+                        worst, wk = e, k
+            assert worst <= 5e-3, (worst, wk)
+            for k, v in net.state_dict().items():
+                if "running_" in k:
+                    assert G.maxabs(v.cpu().numpy(), arrays["buf1:" + k]) <= 1e-5, k
+        opt.step()
+    sd = net.state_dict()
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and k not in noise:
+            tol = 3e-3 if "running_mean" in k else 5e-4
+            assert G.maxabs(v.cpu().numpy(), arrays["final:" + k]) <= tol, k
+    nbt = [int(v) for k, v in sd.items() if k.endswith("num_batches_tracked") and "upsampling_path.4" not in k]
+    assert set(nbt) == {len(meta["steps"])}
+    assert all(int(v) == 0 for k, v in sd.items() if k.endswith("num_batches_tracked") and "upsampling_path.4" in k)
+
+
+def test_phiseg_small_eval_argmax_bit_exact():
+    arrays, meta = G.load("phiseg_small")
+    net, _ = _model(meta)
+    net.eval()
+    x, mask, eps = _inputs(meta, 0)
+    with torch.no_grad():
+        s = net.forward(x, mask, training=False, eps=eps)
+        for l in range(5):
+            assert G.maxabs(s[l].cpu().numpy(), arrays[f"eval_s{l}"]) <= 1e-4
+        last_before = s[-1].clone()
+        soft = net.accumulate_output(s, use_softmax=True)
+    assert not torch.equal(s[-1], last_before)                 # accumulated in place, like the reference
+    assert G.maxabs(soft.cpu().numpy(), arrays["eval_softmax"]) <= 1e-5
+    assert meta["eval_margin_min"] > 1e-3
+    bits = np.packbits(torch.argmax(soft, dim=1).cpu().numpy().astype(np.uint8).reshape(-1))
+    assert np.array_equal(bits, arrays["eval_argmax_bits"])
+
+
+def test_phiseg_full_size_digest_vs_reference_golden():
+    """BASELINE config 4 architecture (filters 32..192, 128x128) at batch 2 against reference digests."""
+    arrays, meta = G.load("phiseg_full_digest")
+    net, _ = _model(meta)
+    net.train()
+    x, mask, eps = _inputs(meta, 0)
+    s = net.forward(x, mask, training=True, eps=eps)
+    loss = net.loss(mask)
+    loss.backward()
+    st = meta["steps"][0]
+    assert abs(float(loss) - st["loss"]) <= 2e-5 * abs(st["loss"])
+    idx = arrays["s_idx"]
+    for l in range(5):
+        assert G.maxabs(s[l].cpu().numpy().reshape(-1)[idx], arrays[f"s{l}_samp"]) <= 1e-4, l
+        assert G.maxabs(net.posterior_mu[l].cpu().numpy(), arrays[f"post_mu{l}"]) <= 1e-4
+        assert G.maxabs(net.prior_sigma[l].cpu().numpy(), arrays[f"prior_sigma{l}"]) <= 1e-4
+    noise = G.bn_shadowed_biases(st["grad_norms"].keys())
+    params = dict(net.named_parameters())
+    for k, n in st["grad_norms"].items():
+        if k in noise:
+            continue
+        mine = float(params[k].grad.double().norm())
+        assert abs(mine - n) <= 5e-3 * max(n, 1e-3), (k, mine, n)
+        pick, vals = st["grad_samples"][k]
+        got = params[k].grad.reshape(-1)[torch.tensor(pick)].cpu().numpy()
+        assert np.max(np.abs(got - np.array(vals))) <= 5e-3 * max(n, 1e-3), k
+    # eval pass: packed argmax bits must be identical
+    net.load_state_dict(oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"]))
+    net.eval()
+    with torch.no_grad():
+        s = net.forward(x, mask, training=False, eps=eps)
+        soft = net.accumulate_output(s, use_softmax=True)
+    assert G.maxabs(s[-1].cpu().numpy().reshape(-1)[idx], arrays["eval_acc_samp"]) <= 2e-4
+    assert meta["eval_margin_min"] > 1e-3, meta["eval_margin_min"]
+    bits = np.packbits(torch.argmax(soft, dim=1).cpu().numpy().astype(np.uint8).reshape(-1))
+    assert np.array_equal(bits, arrays["eval_argmax_bits"])
+
+
+def test_phiseg_vs_live_oracle_other_seed():
+    """Same seeded inputs through the HIP path and the CPU oracle (fresh seed, ragged batch of 3)."""
+    filters, hw, B = [4, 8, 8, 8, 8, 8, 8], 64, 3
+    from unet_zoo_amd.models.phiseg import PHISeg, phiseg_spec
+    sd = oracle.deterministic_state_dict(phiseg_spec(1, 2, filters), seed=77)
+    net = PHISeg(1, 2, filters, image_size=(1, hw, hw))
+    net.load_state_dict(sd)
+    net.train()
+    shapes = oracle.phiseg_eps_shapes(B, hw, hw)
+    x, mask, eps = oracle.synthetic_batch(B, hw, hw, seed=5, eps_shapes=shapes + shapes)
+    dev = torch.device("cuda", 0)
+    s = net.forward(torch.from_numpy(x).to(dev), torch.from_numpy(mask).to(dev), training=True,
+                    eps=[torch.from_numpy(e).to(dev) for e in eps])
+    loss = net.loss(torch.from_numpy(mask).to(dev))
+    loss.backward()
+    lv = G.leaves(sd)
+    e = [torch.from_numpy(a) for a in eps]
+    out = oracle.phiseg_forward(lv, torch.from_numpy(x), torch.from_numpy(mask), dict(posterior=e[:5], prior=e[5:]))
+    total, _ = oracle.phiseg_loss(out, torch.from_numpy(mask))
+    total.backward()
+    assert abs(float(loss) - float(total)) <= 2e-5 * abs(float(total))
+    for l in range(5):
+        assert G.maxabs(s[l].cpu().numpy(), out["s"][l].detach().numpy()) <= 1e-4
+    noise = G.bn_shadowed_biases(lv.keys())
+    for k, p in net.named_parameters():
+        if k in noise:
+            continue
+        ref = lv[k].grad
+        assert (p.grad is None) == (ref is None), k
+        if ref is not None:
+            assert G.maxabs(p.grad.cpu().numpy(), ref.numpy()) <= 5e-3 * (1e-3 + float(ref.abs().max())), k

@@ -1,0 +1,161 @@
+"""Common runtime of the native models: flat parameter storage, plan cache, tape execution,
+the autograd bridge that makes ``loss.backward()`` run the backward tape, and the data-parallel
+gradient all-reduce hook.
+
+Product path only: every pass runs hand-written HIP kernels through ``libuz_hip.so``.  A model can
+be *constructed* without a GPU (state_dict surface, plan building - used by the CPU test tier) but
+any attempt to execute raises: there is no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _ffi
+from ._modtree import attach
+from ._plan import ParamTable, Plan
+
+
+def default_device():
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+class _TapeLoss(torch.autograd.Function):
+    """loss = run(loss tape); backward = run(backward tape) and publish parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, plan):
+        ctx.model, ctx.plan = model, plan
+        plan.run("loss", model._stream())
+        return plan.tensor(plan.total).reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        ctx.model._run_backward(ctx.plan, gout)
+        return None, None, None
+
+
+class NativeModel(nn.Module):
+    """Base class: owns the ParamTable and the per-shape plans."""
+
+    def __init__(self):
+        super().__init__()
+        self._plans = {}
+        self._cur = None
+        self._dp_group = None
+        self._use_graphs = False
+        self._graphs = {}
+
+    # ------------------------------------------------------------------ storage
+    def _init_storage(self, spec, device=None):
+        dev = torch.device(device) if device is not None else default_device()
+        object.__setattr__(self, "_ptab", ParamTable(spec, dev))
+        attach(self, self._ptab)
+        object.__setattr__(self, "_anchor", torch.zeros(1, device=dev, requires_grad=True))
+        self._pmap = dict(self.named_parameters())
+
+    @property
+    def device(self):
+        return self._ptab.device
+
+    def _apply(self, fn, recurse=True):
+        # nn.Module.to()/cuda()/float(): parameters are views of one flat device buffer that the
+        # kernels address directly, so they may not be moved or cast; same-device calls are no-ops.
+        probe = fn(torch.zeros(1, device=self._ptab.device))
+        if probe.device != self._ptab.device or probe.dtype != torch.float32:
+            raise RuntimeError("native models are bound to their fp32 device buffers; construct the model on the target GPU")
+        return self
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _require_gpu(self):
+        if self.device.type != "cuda":
+            raise _ffi.UzError("no GPU visible: the native path has no CPU fallback (model was built in structure-only mode)")
+
+    # ------------------------------------------------------------------ plans
+    def _plan(self, key, builder):
+        p = self._plans.get(key)
+        if p is None:
+            p = builder()
+            self._plans[key] = p
+        return p
+
+    def _new_plan(self, N, bn_training):
+        return Plan(N, self._ptab, bn_training, self.device)
+
+    def enable_graphs(self, flag=True):
+        """Replay forward/backward tapes as captured hipGraphs (one graph launch instead of ~1000
+        kernel launches).  Capture happens lazily on a side stream after one eager warm-up run."""
+        self._use_graphs = bool(flag)
+
+    def _run(self, plan, which):
+        if not self._use_graphs or which == "loss":
+            plan.run(which, self._stream())
+            return
+        key = (id(plan), which)
+        g = self._graphs.get(key)
+        if g is None:
+            warm = plan.__dict__.setdefault("_warm", set())
+            if which not in warm:          # first call: eager (also sets kernel attributes)
+                warm.add(which)
+                plan.run(which, self._stream())
+                return
+            arr, n = plan.tapes[which]
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            handle = C.c_void_p()
+            _ffi.check(plan.L.uz_graph_create(arr, n, C.c_void_p(side.cuda_stream), C.byref(handle)), f"graph capture '{which}'")
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            g = handle
+            self._graphs[key] = g
+        _ffi.check(plan.L.uz_graph_launch(g, C.c_void_p(self._stream())), f"graph launch '{which}'")
+
+    # ------------------------------------------------------------------ backward
+    def set_data_parallel(self, group=True):
+        """Average gradients over the ranks of a torch.distributed process group (RCCL on ROCm)
+        right after the backward tape - one all-reduce of the flat fp32 gradient buffer."""
+        self._dp_group = group
+
+    def _run_backward(self, plan, gout):
+        plan.loss_scale_t.copy_(gout.reshape(1).to(torch.float32))
+        self._run(plan, "bwd")
+        self._post_backward(plan)
+        if self._dp_group is not None:
+            import torch.distributed as dist
+            grp = None if self._dp_group is True else self._dp_group
+            dist.all_reduce(self._ptab.gflat, op=dist.ReduceOp.SUM, group=grp)
+            self._ptab.gflat.mul_(1.0 / dist.get_world_size(grp))
+        for key in plan.param_grads:
+            p = self._pmap[key]
+            g = self._ptab.gview(key)
+            if p.grad is None or p.grad.data_ptr() == g.data_ptr():
+                p.grad = g
+            else:
+                p.grad.add_(g)
+
+    def _post_backward(self, plan):
+        pass
+
+    def zero_grad(self, set_to_none=True):
+        for p in self._pmap.values():
+            p.grad = None
+
+    def _loss_tensor(self, plan):
+        return _TapeLoss.apply(self._anchor, self, plan)
+
+    def _bump_nbt(self, plan):
+        idx = plan.__dict__.get("_nbt_idx")
+        if idx is None:
+            ks = [self._ptab.nbt_keys.index(k) for k in plan.bn_prefixes_nbt]
+            idx = torch.tensor(ks, dtype=torch.int64, device=self.device)
+            plan._nbt_idx = idx
+        if idx.numel():
+            self._ptab.nbt.index_add_(0, idx, torch.ones_like(idx))
+
+
+def conv_unit(plan, x, prefix, out=None, relu=True):
+    """Reference Conv2D unit addressed by its module prefix (`<prefix>.convolution.{0,1}`)."""
+    a = plan.conv_bn_relu(x, prefix + ".convolution.0", prefix + ".convolution.1", out=out, relu=relu)
+    plan.__dict__.setdefault("bn_prefixes_nbt", []).append(prefix + ".convolution.1.num_batches_tracked")
+    return a

@@ -1,0 +1,515 @@
+"""Static execution plan ("tape") builder.
+
+A model instance flattens itself, for a given (batch, H, W, mode), into three lists of C-ABI
+calls - forward, loss, backward - over pre-allocated device buffers.  Shapes are static, so the
+lists are built once, turned into ``uz_op`` arrays and replayed with one FFI call per pass
+(``uz_run_tape``) or as a captured hipGraph.  Nothing here computes on the host: the plan only
+decides *which* kernel runs on *which* buffer.
+
+Design points:
+  * concat-free: a producer writes straight into a channel slice of the consumer's buffer
+    (``View`` = buffer + channel offset), replacing torch.cat (phiseg.py:71,183,315; unet.py:72);
+  * gradient fan-in is resolved at plan time: the first backward writer of a gradient region
+    overwrites, later writers accumulate (no zero-fill passes);
+  * branches whose output never reaches the loss are skipped in backward, which reproduces the
+    reference's ``grad is None`` parameters.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+BN_EPS = 1e-3        # reference torchlayers.py:20
+BN_MOMENTUM = 0.01   # reference torchlayers.py:20
+_ALIGN = 64          # floats
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return n
+
+
+# ----------------------------------------------------------------------------------------------
+class ParamTable:
+    """Flat fp32 storage for all parameters / BN buffers of a model, addressed by the
+    reference's state_dict keys.  spec: ordered [(key, shape, kind)], kind in
+    conv_w conv_b bn_w bn_b bn_rm bn_rv bn_nbt (same vocabulary as the golden fixtures)."""
+
+    def __init__(self, spec, device):
+        self.spec = [(k, tuple(s), kd) for k, s, kd in spec]
+        self.device = device
+        self.poff, self.boff, self.shape, self.kind = OrderedDict(), OrderedDict(), {}, {}
+        po = bo = 0
+        self.nbt_keys = []
+        for k, s, kd in self.spec:
+            self.shape[k], self.kind[k] = s, kd
+            if kd in ("conv_w", "conv_b", "bn_w", "bn_b"):
+                self.poff[k] = po
+                po += _numel(s)
+            elif kd in ("bn_rm", "bn_rv"):
+                self.boff[k] = bo
+                bo += _numel(s)
+            elif kd == "bn_nbt":
+                self.nbt_keys.append(k)
+            else:
+                raise ValueError(kd)
+        self.n_params, self.n_buffers = po, bo
+        self.pflat = torch.zeros(max(po, 1), dtype=torch.float32, device=device)
+        self.gflat = torch.zeros(max(po, 1), dtype=torch.float32, device=device)
+        self.bflat = torch.zeros(max(bo, 1), dtype=torch.float32, device=device)
+        self.nbt = torch.zeros(max(len(self.nbt_keys), 1), dtype=torch.int64, device=device)
+
+    def pview(self, k):
+        o = self.poff[k]
+        return self.pflat[o:o + _numel(self.shape[k])].view(self.shape[k])
+
+    def gview(self, k):
+        o = self.poff[k]
+        return self.gflat[o:o + _numel(self.shape[k])].view(self.shape[k])
+
+    def bview(self, k):
+        o = self.boff[k]
+        return self.bflat[o:o + _numel(self.shape[k])].view(self.shape[k])
+
+    def nbtview(self, k):
+        return self.nbt[self.nbt_keys.index(k)]
+
+
+class Buf:
+    __slots__ = ("name", "N", "C", "H", "W", "off", "gbuf", "requires_grad")
+
+    def __init__(self, name, N, C, H, W, requires_grad=True):
+        self.name, self.N, self.C, self.H, self.W = name, int(N), int(C), int(H), int(W)
+        self.off, self.gbuf, self.requires_grad = None, None, requires_grad
+
+    @property
+    def numel(self):
+        return self.N * self.C * self.H * self.W
+
+
+class View:
+    """Channel slice [c0, c0+C) of a buffer."""
+    __slots__ = ("buf", "c0", "C")
+
+    def __init__(self, buf, c0=0, C=None):
+        self.buf, self.c0, self.C = buf, c0, buf.C - c0 if C is None else C
+        assert 0 <= self.c0 and self.c0 + self.C <= buf.C
+
+    N = property(lambda s: s.buf.N)
+    H = property(lambda s: s.buf.H)
+    W = property(lambda s: s.buf.W)
+    Ctot = property(lambda s: s.buf.C)
+
+    def slice(self, c0, C):
+        return View(self.buf, self.c0 + c0, C)
+
+    @property
+    def contiguous(self):
+        return self.c0 == 0 and self.C == self.buf.C
+
+    @property
+    def numel(self):
+        return self.N * self.C * self.H * self.W
+
+
+class Latent:
+    """One (mu, sigma, z) head: SampleZBlock tail (phiseg.py:99-106) or AxisAlignedConvGaussian
+    (probabilistic_unet.py:124-129)."""
+    def __init__(self, mu, pre, sigma, z, eps, act):
+        self.mu, self.pre, self.sigma, self.z, self.eps, self.act = mu, pre, sigma, z, eps, act
+        self.kl_dmu = self.kl_dsigma = None
+
+
+# ----------------------------------------------------------------------------------------------
+class Plan:
+    def __init__(self, N, ptab, bn_training, device):
+        self.N, self.ptab, self.bn_training, self.device = int(N), ptab, bool(bn_training), device
+        self.codes = _ffi.op_codes()
+        self.L = _ffi.lib()
+        self.bufs = []
+        self.fwd_ops, self.loss_ops, self.bwd_ops = [], [], []
+        self.target = self.fwd_ops
+        self._bwd = []                      # closures, run in reverse
+        self._ginit = {}                    # Buf -> list of (c0, c1) gradient regions already written
+        self.scratch = dict(bn=0, wgrad=0, gy=0, ce=0)   # bytes (bn, wgrad, ce) / floats (gy)
+        self.ptr_tables = []                # list of lists of pointer refs -> device int64 table
+        self.param_grads = []               # parameter keys that receive a gradient, in write order
+        self.named = {}                     # user-visible tensors: name -> View
+        self.finalized = False
+
+    # ------------------------------------------------------------------ buffers
+    def buf(self, name, C, H, W, N=None, requires_grad=True):
+        b = Buf(name, self.N if N is None else N, C, H, W, requires_grad)
+        self.bufs.append(b)
+        return View(b)
+
+    def vec(self, name, n, requires_grad=False):
+        """Small 1-D float region (loss terms, saved BN statistics, ...)."""
+        return self.buf(name, n, 1, 1, N=1, requires_grad=requires_grad)
+
+    def gview(self, v):
+        if v.buf.gbuf is None:
+            g = Buf("grad:" + v.buf.name, v.buf.N, v.buf.C, v.buf.H, v.buf.W, False)
+            self.bufs.append(g)
+            v.buf.gbuf = g
+        return View(v.buf.gbuf, v.c0, v.C)
+
+    def _claim(self, v):
+        """Returns the accumulate flag for a backward write to grad(v) and records the region."""
+        regs = self._ginit.setdefault(v.buf, [])
+        lo, hi = v.c0, v.c0 + v.C
+        covered = [c for c in range(lo, hi) if any(a <= c < b for a, b in regs)]
+        if len(covered) == hi - lo:
+            return 1
+        if covered:
+            raise RuntimeError(f"partial gradient overlap on {v.buf.name}[{lo}:{hi}] vs {regs}")
+        regs.append((lo, hi))
+        return 0
+
+    def _has_grad(self, v):
+        regs = self._ginit.get(v.buf, [])
+        return all(any(a <= c < b for a, b in regs) for c in range(v.c0, v.c0 + v.C))
+
+    # ------------------------------------------------------------------ op emission
+    def _emit(self, lst, code, p=(), i=(), f=(), n=0):
+        lst.append(dict(code=code, p=list(p), i=[int(x) for x in i], f=[float(x) for x in f], n=int(n)))
+
+    def P(self, key, extra=0):
+        return ("param", key, extra)
+
+    def G(self, key, extra=0):
+        if key not in self.param_grads:
+            self.param_grads.append(key)
+        return ("pgrad", key, extra)
+
+    def B(self, key):
+        return ("buffer", key, 0)
+
+    def loss_phase(self):
+        self.target = self.loss_ops
+
+    # ------------------------------------------------------------------ convolution family
+    def _conv_fwd(self, x, wkey, bkey, y, ks, relu, wrow0=0):
+        cout = y.C
+        cin = x.C
+        wextra = wrow0 * cin * ks * ks
+        self._emit(self.target, "UZ_OP_CONV_FWD",
+                   p=[x, self.P(wkey, wextra), self.P(bkey, wrow0) if bkey else None, y],
+                   i=[cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, ks, relu])
+
+    def _conv_bwd(self, x, wkey, gy, ks, db_key=None, wrow0=0):
+        """Weight gradient (+ optional bias gradient) and, when the input carries a gradient,
+        the data gradient.  gy: gradient w.r.t. the conv output (a View)."""
+        cin, cout = x.C, gy.C
+        wextra = wrow0 * cin * ks * ks
+        ws = self.L.uz_conv_bwd_weight_workspace(cin, cout, x.N, x.H, x.W, ks)
+        self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
+        self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
+                   p=[x, gy, self.G(wkey, wextra), self.G(db_key, wrow0) if db_key else None, ("scratch", "wgrad")],
+                   i=[cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, ks], n=ws)
+        if x.buf.requires_grad:
+            acc = self._claim(x)
+            self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
+                       p=[gy, self.P(wkey, wextra), self.gview(x)],
+                       i=[cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, ks, acc])
+
+    def _gy_scratch(self, like):
+        self.scratch["gy"] = max(self.scratch["gy"], like.N * like.C * like.H * like.W)
+        return ("gyview", like.C)
+
+    def conv_bn_relu(self, x, cprefix, bprefix, out=None, name=None, relu=True):
+        """Conv2D unit: Conv2d -> BatchNorm2d(eps=1e-3, momentum=0.01) -> ReLU (torchlayers.py:7-29)."""
+        wkey, bkey = cprefix + ".weight", cprefix + ".bias"
+        cout, _, ks, _ = self.ptab.shape[wkey]
+        name = name or cprefix
+        y = self.buf(name + ":y", cout, x.H, x.W)
+        a = out if out is not None else self.buf(name + ":a", cout, x.H, x.W)
+        assert a.C == cout and a.H == x.H and a.W == x.W
+        save = self.vec(name + ":bnsave", 2 * cout)
+        self._conv_fwd(x, wkey, bkey, y, ks, 0)
+        bnws = self.L.uz_bn_workspace(cout, x.N, x.H, x.W)
+        self.scratch["bn"] = max(self.scratch["bn"], bnws)
+        gam, bet = bprefix + ".weight", bprefix + ".bias"
+        self._emit(self.target, "UZ_OP_BN_RELU_FWD",
+                   p=[y, self.P(gam), self.P(bet), self.B(bprefix + ".running_mean"), self.B(bprefix + ".running_var"),
+                      save, a, ("scratch", "bn")],
+                   i=[cout, y.Ctot, a.Ctot, x.N, x.H, x.W, int(self.bn_training), int(relu)], f=[BN_EPS, BN_MOMENTUM])
+
+        def bwd():
+            if not self._has_grad(a):
+                return
+            if not self.bn_training:
+                raise RuntimeError("backward through eval-mode BatchNorm is not supported")
+            gy = self._gy_scratch(y)
+            gyv = _ScratchView(y.N, cout, y.H, y.W)
+            self._emit(self.bwd_ops, "UZ_OP_BN_RELU_BWD",
+                       p=[self.gview(a), y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), self.G(bkey), ("scratch", "bn")],
+                       i=[a.Ctot, cout, y.Ctot, cout, x.N, x.H, x.W, int(relu)])
+            self._conv_bwd(x, wkey, gyv, ks)
+        self._bwd.append(bwd)
+        return a
+
+    def conv_relu(self, x, prefix, out=None, name=None):
+        """nn.Conv2d(3, pad 1) + nn.ReLU(inplace=True) of the vanilla U-Net blocks (unet.py:25-30)."""
+        wkey, bkey = prefix + ".weight", prefix + ".bias"
+        cout, _, ks, _ = self.ptab.shape[wkey]
+        a = out if out is not None else self.buf((name or prefix) + ":a", cout, x.H, x.W)
+        self._conv_fwd(x, wkey, bkey, a, ks, 1)
+        self.scratch["bn"] = max(self.scratch["bn"], self.L.uz_bn_workspace(cout, x.N, x.H, x.W))
+
+        def bwd():
+            if not self._has_grad(a):
+                return
+            gy = self._gy_scratch(a)
+            gyv = _ScratchView(a.N, cout, a.H, a.W)
+            self._emit(self.bwd_ops, "UZ_OP_RELU_BWD",
+                       p=[self.gview(a), a, gy, self.G(bkey), ("scratch", "bn")],
+                       i=[a.Ctot, cout, a.Ctot, cout, x.N, x.H, x.W])
+            self._conv_bwd(x, wkey, gyv, ks)
+        self._bwd.append(bwd)
+        return a
+
+    def conv_bare(self, x, prefix, out=None, name=None, rows=None):
+        """Plain nn.Conv2d (1x1 heads: phiseg.py:95-96,281-284; unet.py:122; probabilistic_unet.py:95).
+        rows=(r0, n): use only output rows [r0, r0+n) of the parameter (mu / log-sigma halves)."""
+        wkey, bkey = prefix + ".weight", prefix + ".bias"
+        cout, _, ks, _ = self.ptab.shape[wkey]
+        r0 = 0
+        if rows is not None:
+            r0, cout = rows
+        y = out if out is not None else self.buf((name or prefix) + ":y", cout, x.H, x.W)
+        self._conv_fwd(x, wkey, bkey, y, ks, 0, wrow0=r0)
+
+        def bwd():
+            if not self._has_grad(y):
+                return
+            self._conv_bwd(x, wkey, self.gview(y), ks, db_key=bkey, wrow0=r0)
+        self._bwd.append(bwd)
+        return y
+
+    # ------------------------------------------------------------------ resampling
+    def _resample(self, fcode, bcode, x, y, extra_i=()):
+        self._emit(self.target, fcode, p=[x, y], i=[x.C, x.Ctot, y.Ctot, x.N, x.H, x.W, *extra_i])
+
+        def bwd():
+            if not self._has_grad(y) or not x.buf.requires_grad:
+                return
+            acc = self._claim(x)
+            self._emit(self.bwd_ops, bcode, p=[self.gview(y), self.gview(x)],
+                       i=[x.C, y.Ctot, x.Ctot, x.N, x.H, x.W, *extra_i, acc])
+        self._bwd.append(bwd)
+        return y
+
+    def avgpool(self, x, name):
+        """nn.AvgPool2d(2, 2, ceil_mode=True) (phiseg.py:23, unet.py:22)."""
+        y = self.buf(name, x.C, (x.H + 1) // 2, (x.W + 1) // 2, requires_grad=x.buf.requires_grad)
+        return self._resample("UZ_OP_AVGPOOL_FWD", "UZ_OP_AVGPOOL_BWD", x, y)
+
+    def bilinear(self, x, align_corners, name=None, out=None):
+        y = out if out is not None else self.buf(name, x.C, 2 * x.H, 2 * x.W, requires_grad=x.buf.requires_grad)
+        return self._resample("UZ_OP_BILINEAR_FWD", "UZ_OP_BILINEAR_BWD", x, y, (int(align_corners),))
+
+    def nearest(self, x, factor, name):
+        y = self.buf(name, x.C, x.H * factor, x.W * factor, requires_grad=x.buf.requires_grad)
+        if factor == 1:
+            pass
+        return self._resample("UZ_OP_NEAREST_FWD", "UZ_OP_NEAREST_BWD", x, y, (factor,))
+
+    def spatial_mean(self, x, name):
+        y = self.buf(name, x.C, 1, 1)
+        self._emit(self.target, "UZ_OP_SPATIAL_MEAN_FWD", p=[x, y], i=[x.C, x.Ctot, x.N, x.H, x.W])
+
+        def bwd():
+            if not self._has_grad(y):
+                return
+            acc = self._claim(x)
+            self._emit(self.bwd_ops, "UZ_OP_SPATIAL_MEAN_BWD", p=[self.gview(y), self.gview(x)],
+                       i=[x.C, x.Ctot, x.N, x.H, x.W, acc])
+        self._bwd.append(bwd)
+        return y
+
+    def bcast_channels(self, z, out):
+        """Fcomb tiling of z (N, L) over the spatial axes into channels of `out` (probabilistic_unet.py:190-197)."""
+        L = z.C
+        self._emit(self.target, "UZ_OP_BCAST_CHANNELS", p=[z, out], i=[L, out.Ctot, out.N, out.H, out.W])
+
+        def bwd():
+            if not self._has_grad(out) or not z.buf.requires_grad:
+                return
+            assert self._claim(z) == 0
+            self._emit(self.bwd_ops, "UZ_OP_BCAST_CHANNELS_BWD", p=[self.gview(out), self.gview(z)],
+                       i=[out.Ctot, L, out.N, out.H, out.W])
+        self._bwd.append(bwd)
+
+    # ------------------------------------------------------------------ inputs / latents / losses
+    def posterior_input(self, patch, mask, nlabels, name):
+        out = self.buf(name, patch.C + nlabels, patch.H, patch.W, requires_grad=False)
+        self._emit(self.target, "UZ_OP_POSTERIOR_INPUT", p=[patch, mask, out], i=[patch.C, nlabels, patch.N, patch.H, patch.W])
+        return out
+
+    def latent(self, mu, pre, eps, name, want_z=True, act=0):
+        assert mu.contiguous and pre.contiguous
+        sigma = self.buf(name + ":sigma", mu.C, mu.H, mu.W)
+        z = self.buf(name + ":z", mu.C, mu.H, mu.W) if want_z else None
+        lat = Latent(mu, pre, sigma, z, eps, act)
+        self._emit(self.target, "UZ_OP_LATENT_FWD", p=[mu, pre, eps, sigma, z], i=[act], n=mu.numel)
+
+        def bwd():
+            dz = self.gview(z) if (z is not None and self._has_grad(z)) else None
+            if dz is None and lat.kl_dmu is None:
+                return
+            assert self._claim(mu) == 0 and self._claim(pre) == 0
+            self._emit(self.bwd_ops, "UZ_OP_LATENT_BWD",
+                       p=[lat.kl_dmu, lat.kl_dsigma, dz, eps, sigma, self.gview(mu), self.gview(pre)], i=[act], n=mu.numel)
+        self._bwd.append(bwd)
+        return lat
+
+    def kl(self, q, p, weight, term):
+        """weight * KL_two_gauss_with_diag_cov(q || p) (phiseg.py:436-479)."""
+        n, per = q.mu.N, q.mu.C * q.mu.H * q.mu.W
+        self._emit(self.target, "UZ_OP_KL_FWD", p=[q.mu, q.sigma, p.mu, p.sigma, term], i=[n, per], f=[weight])
+
+        def bwd():
+            for lat, tag in ((q, "q"), (p, "p")):
+                lat.kl_dmu = self.buf(f"kl:{tag}:{lat.mu.buf.name}:dmu", lat.mu.C, lat.mu.H, lat.mu.W, requires_grad=False)
+                lat.kl_dsigma = self.buf(f"kl:{tag}:{lat.mu.buf.name}:dsigma", lat.mu.C, lat.mu.H, lat.mu.W, requires_grad=False)
+            self._emit(self.bwd_ops, "UZ_OP_KL_BWD",
+                       p=[q.mu, q.sigma, p.mu, p.sigma, self.loss_scale, q.kl_dmu, q.kl_dsigma, p.kl_dmu, p.kl_dsigma],
+                       i=[n, per], f=[weight])
+        self._bwd.append(bwd)
+
+    def residual_ce(self, s_list, mask, terms, scale_ref=None):
+        """residual_multinoulli_loss over the level logits (phiseg.py:481-513); terms: vec View of L floats."""
+        L, K = len(s_list), s_list[0].C
+        assert all(s.contiguous for s in s_list)
+        tab = self.ptr_table(list(s_list))
+        ws = self.L.uz_ce_workspace(mask.N, mask.H, mask.W, L)
+        self.scratch["ce"] = max(self.scratch["ce"], ws)
+        self._emit(self.target, "UZ_OP_CE_FWD", p=[tab, mask, terms, ("scratch", "ce")], i=[L, K, mask.N, mask.H, mask.W])
+
+        def bwd():
+            for s in s_list:
+                assert self._claim(s) == 0
+            gtab = self.ptr_table([self.gview(s) for s in s_list])
+            self._emit(self.bwd_ops, "UZ_OP_CE_BWD", p=[tab, gtab, mask, scale_ref or self.loss_scale], i=[L, K, mask.N, mask.H, mask.W])
+        self._bwd.append(bwd)
+
+    def sum_terms(self, terms, n, total):
+        self._emit(self.target, "UZ_OP_SUM_TERMS", p=[terms, total], i=[n])
+
+    def scale_(self, v, alpha, n):
+        self._emit(self.target, "UZ_OP_SCALE", p=[v], f=[alpha], n=n)
+
+    def ptr_table(self, refs):
+        self.ptr_tables.append(refs)
+        return ("ptrtab", len(self.ptr_tables) - 1)
+
+    # ------------------------------------------------------------------ finalisation
+    def finalize(self, want_backward=True):
+        assert not self.finalized
+        self.loss_scale = self.vec("loss_scale", 1)
+        if want_backward:
+            for fn in reversed(self._bwd):
+                fn()
+        self._bwd = []
+        # arena layout
+        off = 0
+        for b in self.bufs:
+            b.off = off
+            off += -(-b.numel // _ALIGN) * _ALIGN
+        self.gy_off = off
+        off += -(-self.scratch["gy"] // _ALIGN) * _ALIGN
+        self.scratch_off = {}
+        for k in ("bn", "wgrad", "ce"):
+            self.scratch_off[k] = off
+            off += -(-(self.scratch[k] // 4 + 1) // _ALIGN) * _ALIGN
+        self.arena_floats = off
+        self.arena = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.base = self.arena.data_ptr()
+        # pointer tables
+        ntab = sum(len(t) for t in self.ptr_tables)
+        self.ptrtab = torch.zeros(max(ntab, 1), dtype=torch.int64, device=self.device)
+        vals, self._tab_off, k = [], [], 0
+        for t in self.ptr_tables:
+            self._tab_off.append(k)
+            for r in t:
+                vals.append(self._resolve(r))
+                k += 1
+        if vals:
+            self.ptrtab.copy_(torch.tensor(vals, dtype=torch.int64))
+        self.tapes = {nm: self._materialize(ops) for nm, ops in (("fwd", self.fwd_ops), ("loss", self.loss_ops), ("bwd", self.bwd_ops))}
+        self.loss_scale_t = self.tensor(self.loss_scale).view(1)
+        self.loss_scale_t.fill_(1.0)
+        self.finalized = True
+        return self
+
+    def _resolve(self, r):
+        if r is None:
+            return 0
+        if isinstance(r, _ScratchView):
+            return self.base + 4 * self.gy_off
+        if isinstance(r, View):
+            assert r.buf.off is not None
+            return self.base + 4 * (r.buf.off + r.c0 * r.buf.H * r.buf.W)
+        kind = r[0]
+        if kind == "param":
+            return self.ptab.pflat.data_ptr() + 4 * (self.ptab.poff[r[1]] + r[2])
+        if kind == "pgrad":
+            return self.ptab.gflat.data_ptr() + 4 * (self.ptab.poff[r[1]] + r[2])
+        if kind == "buffer":
+            return self.ptab.bflat.data_ptr() + 4 * self.ptab.boff[r[1]]
+        if kind == "scratch":
+            return self.base + 4 * self.scratch_off[r[1]]
+        if kind == "gyview":
+            return self.base + 4 * self.gy_off
+        if kind == "ptrtab":
+            return self.ptrtab.data_ptr() + 8 * self._tab_off[r[1]]
+        if kind == "raw":
+            return int(r[1])
+        raise ValueError(r)
+
+    def _materialize(self, ops):
+        arr = (_ffi.uz_op * max(len(ops), 1))()
+        for k, o in enumerate(ops):
+            e = arr[k]
+            e.code = self.codes[o["code"]]
+            assert len(o["i"]) <= 15 and len(o["f"]) <= 4 and len(o["p"]) <= 12, o["code"]
+            for j, v in enumerate(o["i"]):
+                e.i[j] = v
+            for j, v in enumerate(o["f"]):
+                e.f[j] = v
+            e.n = o["n"]
+            for j, r in enumerate(o["p"]):
+                e.p[j] = self._resolve(r)
+        return arr, len(ops)
+
+    # ------------------------------------------------------------------ execution helpers
+    def tensor(self, v):
+        """torch view (storage only) of a plan buffer slice, NCHW."""
+        b = v.buf
+        full = self.arena[b.off:b.off + b.numel].view(b.N, b.C, b.H, b.W)
+        return full[:, v.c0:v.c0 + v.C]
+
+    def run(self, which, stream_ptr):
+        arr, n = self.tapes[which]
+        if n:
+            _ffi.check(self.L.uz_run_tape(arr, n, C.c_void_p(stream_ptr)), f"tape '{which}'")
+
+    def summary(self):
+        cnt = {}
+        for nm, ops in (("fwd", self.fwd_ops), ("loss", self.loss_ops), ("bwd", self.bwd_ops)):
+            cnt[nm] = len(ops)
+        cnt["arena_MB"] = self.arena_floats * 4 / 2 ** 20 if self.finalized else None
+        return cnt
+
+
+class _ScratchView:
+    """Shape carrier for the shared dy scratch (gradient w.r.t. a conv output, consumed at once)."""
+    def __init__(self, N, C, H, W):
+        self.N, self.C, self.H, self.W, self.Ctot = N, C, H, W, C
+        self.buf = None

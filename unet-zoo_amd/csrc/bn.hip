@@ -1,0 +1,444 @@
+// BatchNorm2d(eps, momentum) + ReLU, training and eval, forward and backward.
+// Replaces nn.BatchNorm2d(eps=1e-3, momentum=0.01) -> nn.ReLU of the reference's Conv2D unit
+// (torchlayers.py:20-21), i.e. aten::native_batch_norm(+_backward) and threshold_backward.
+//
+// Memory-bound streaming kernels.  Two regimes:
+//  * large planes (N*H*W > SMALL_LIMIT): one workgroup per (image, channel, plane chunk), float4
+//    loads, wave-shuffle + LDS reduction to fp64 partial sums, then an ordered per-channel
+//    finalise (bitwise reproducible; no atomics), then the streaming apply pass.
+//  * small planes: ONE workgroup per channel does statistics and apply in a single launch (the
+//    second read of the <= 32 KB channel comes from L1/L2).
+// Statistics are accumulated in fp64 so that E[y^2]-E[y]^2 carries no cancellation error into the
+// 30+ stacked normalisations of PHiSeg.
+#include "uz_common.h"
+
+namespace {
+
+constexpr int SMALL_LIMIT = 8192;    // N*H*W at or below which the fused single-launch path is used
+constexpr int CHUNK = 16384;         // plane elements per workgroup on the large path
+
+struct BnP {
+    const float* y; const float* da; const float* gamma; const float* beta;
+    float* rmean; float* rvar; float* save;          // save[0..C) mean, save[C..2C) rstd
+    float* out;                                        // a (fwd) or dy (bwd)
+    float* dgamma; float* dbeta; float* dbias;
+    double* part; double* part2; double* chan;        // workspace
+    int C, CtotY, CtotDa, CtotOut, N, HW, parts;
+    float eps, momentum;
+    int training, relu;
+};
+
+__device__ __forceinline__ void alpha_beta(const BnP& p, int c, float& alpha, float& beta_, float& mean, float& rstd) {
+    if (p.training) { mean = p.save[c]; rstd = p.save[p.C + c]; }
+    else { mean = p.rmean[c]; rstd = 1.0f / sqrtf(p.rvar[c] + p.eps); }
+    const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
+    alpha = g * rstd;
+    beta_ = b - mean * alpha;
+}
+
+// ------------------------------------------------------------------ forward, large path
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_stats_partial(const BnP p) {
+    __shared__ double sm[8];
+    const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
+    const float* src = p.y + ((size_t)b * p.CtotY + c) * p.HW;
+    const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
+    float s = 0.f, ss = 0.f;
+    if (VEC) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+            const float4 v = s4[i];
+            s += (v.x + v.y) + (v.z + v.w);
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) { const float v = src[i]; s += v; ss += v * v; }
+    }
+    double v2[2] = {(double)s, (double)ss};
+    uz::block_sum_d<2>(v2, sm);
+    if (threadIdx.x == 0) {
+        double* o = p.part + ((size_t)(b * p.parts + part) * p.C + c) * 2;
+        o[0] = v2[0]; o[1] = v2[1];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize(const BnP p) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= p.C) return;
+    const int P = p.N * p.parts;
+    double s = 0.0, ss = 0.0;
+    for (int i = lane; i < P; i += 64) {
+        const double* o = p.part + ((size_t)i * p.C + c) * 2;
+        s += o[0]; ss += o[1];
+    }
+    s = uz::wave_sum_d(s); ss = uz::wave_sum_d(ss);
+    if (lane == 0) {
+        const double n = (double)p.N * p.HW;
+        const double mean = s / n;
+        double var = ss / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        p.save[c] = (float)mean;
+        p.save[p.C + c] = (float)(1.0 / sqrt(var + (double)p.eps));
+        if (p.rmean) {
+            const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+            p.rmean[c] = (float)((1.0 - p.momentum) * p.rmean[c] + p.momentum * mean);
+            p.rvar[c] = (float)((1.0 - p.momentum) * p.rvar[c] + p.momentum * unb);
+        }
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply(const BnP p) {
+    const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
+    float alpha, beta_, mean, rstd;
+    alpha_beta(p, c, alpha, beta_, mean, rstd);
+    const float* src = p.y + ((size_t)b * p.CtotY + c) * p.HW;
+    float* dst = p.out + ((size_t)b * p.CtotOut + c) * p.HW;
+    const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
+    const float floor_ = p.relu ? 0.f : -INFINITY;
+    if (VEC) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+            float4 v = s4[i];
+            v.x = fmaxf(fmaf(v.x, alpha, beta_), floor_); v.y = fmaxf(fmaf(v.y, alpha, beta_), floor_);
+            v.z = fmaxf(fmaf(v.z, alpha, beta_), floor_); v.w = fmaxf(fmaf(v.w, alpha, beta_), floor_);
+            d4[i] = v;
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) dst[i] = fmaxf(fmaf(src[i], alpha, beta_), floor_);
+    }
+}
+
+// ------------------------------------------------------------------ forward, small path (one WG / channel)
+__global__ __launch_bounds__(256) void bn_fused_small_fwd(const BnP p) {
+    __shared__ double sm[8];
+    __shared__ float bc[2];
+    const int c = blockIdx.x;
+    const int total = p.N * p.HW;
+    if (p.training) {
+        double v2[2] = {0.0, 0.0};
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int b = i / p.HW, q = i - b * p.HW;
+            const double v = p.y[((size_t)b * p.CtotY + c) * p.HW + q];
+            v2[0] += v; v2[1] += v * v;
+        }
+        uz::block_sum_d<2>(v2, sm);
+        if (threadIdx.x == 0) {
+            const double n = (double)total;
+            const double mean = v2[0] / n;
+            double var = v2[1] / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            p.save[c] = (float)mean;
+            p.save[p.C + c] = (float)(1.0 / sqrt(var + (double)p.eps));
+            if (p.rmean) {
+                const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                p.rmean[c] = (float)((1.0 - p.momentum) * p.rmean[c] + p.momentum * mean);
+                p.rvar[c] = (float)((1.0 - p.momentum) * p.rvar[c] + p.momentum * unb);
+            }
+            bc[0] = p.save[c]; bc[1] = p.save[p.C + c];
+        }
+        __syncthreads();
+    }
+    float alpha, beta_, mean, rstd;
+    if (p.training) {
+        mean = bc[0]; rstd = bc[1];
+        const float g = p.gamma ? p.gamma[c] : 1.f, bb = p.beta ? p.beta[c] : 0.f;
+        alpha = g * rstd; beta_ = bb - mean * alpha;
+    } else {
+        alpha_beta(p, c, alpha, beta_, mean, rstd);
+    }
+    const float floor_ = p.relu ? 0.f : -INFINITY;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int b = i / p.HW, q = i - b * p.HW;
+        const float v = p.y[((size_t)b * p.CtotY + c) * p.HW + q];
+        p.out[((size_t)b * p.CtotOut + c) * p.HW + q] = fmaxf(fmaf(v, alpha, beta_), floor_);
+    }
+}
+
+// ------------------------------------------------------------------ backward, large path
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_partial(const BnP p) {
+    __shared__ double sm[8];
+    const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
+    float alpha, beta_, mean, rstd;
+    alpha_beta(p, c, alpha, beta_, mean, rstd);
+    const float* ys = p.y + ((size_t)b * p.CtotY + c) * p.HW;
+    const float* ds = p.da + ((size_t)b * p.CtotDa + c) * p.HW;
+    const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
+    float s1 = 0.f, s2 = 0.f;
+    auto one = [&](float yv, float dv) {
+        const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
+        s1 += dz; s2 += dz * ((yv - mean) * rstd);
+    };
+    if (VEC) {
+        const float4* y4 = reinterpret_cast<const float4*>(ys);
+        const float4* d4 = reinterpret_cast<const float4*>(ds);
+        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+            const float4 yv = y4[i], dv = d4[i];
+            one(yv.x, dv.x); one(yv.y, dv.y); one(yv.z, dv.z); one(yv.w, dv.w);
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) one(ys[i], ds[i]);
+    }
+    double v2[2] = {(double)s1, (double)s2};
+    uz::block_sum_d<2>(v2, sm);
+    if (threadIdx.x == 0) {
+        double* o = p.part + ((size_t)(b * p.parts + part) * p.C + c) * 2;
+        o[0] = v2[0]; o[1] = v2[1];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize(const BnP p) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= p.C) return;
+    const int P = p.N * p.parts;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = lane; i < P; i += 64) {
+        const double* o = p.part + ((size_t)i * p.C + c) * 2;
+        s1 += o[0]; s2 += o[1];
+    }
+    s1 = uz::wave_sum_d(s1); s2 = uz::wave_sum_d(s2);
+    if (lane == 0) {
+        const double n = (double)p.N * p.HW;
+        if (p.dbeta) p.dbeta[c] = (float)s1;
+        if (p.dgamma) p.dgamma[c] = (float)s2;
+        p.chan[c] = s1 / n;
+        p.chan[p.C + c] = s2 / n;
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply(const BnP p) {
+    __shared__ double sm[4];
+    const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
+    float alpha, beta_, mean, rstd;
+    alpha_beta(p, c, alpha, beta_, mean, rstd);
+    const float m1 = (float)p.chan[c], m2 = (float)p.chan[p.C + c];
+    const float* ys = p.y + ((size_t)b * p.CtotY + c) * p.HW;
+    const float* ds = p.da + ((size_t)b * p.CtotDa + c) * p.HW;
+    float* dst = p.out + ((size_t)b * p.CtotOut + c) * p.HW;
+    const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
+    float sd = 0.f;
+    auto one = [&](float yv, float dv) -> float {
+        const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
+        const float r = alpha * (dz - m1 - ((yv - mean) * rstd) * m2);
+        sd += r;
+        return r;
+    };
+    if (VEC) {
+        const float4* y4 = reinterpret_cast<const float4*>(ys);
+        const float4* d4 = reinterpret_cast<const float4*>(ds);
+        float4* o4 = reinterpret_cast<float4*>(dst);
+        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+            const float4 yv = y4[i], dv = d4[i];
+            float4 r;
+            r.x = one(yv.x, dv.x); r.y = one(yv.y, dv.y); r.z = one(yv.z, dv.z); r.w = one(yv.w, dv.w);
+            o4[i] = r;
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) dst[i] = one(ys[i], ds[i]);
+    }
+    if (p.dbias) {
+        double v1[1] = {(double)sd};
+        uz::block_sum_d<1>(v1, sm);
+        if (threadIdx.x == 0) p.part2[(size_t)(b * p.parts + part) * p.C + c] = v1[0];
+    }
+}
+
+// out[c] = sum_i part[i][c] (ordered), one wave per channel
+__global__ __launch_bounds__(256) void chan_partial_sum(const double* __restrict__ part, int P, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int i = lane; i < P; i += 64) s += part[(size_t)i * C + c];
+    s = uz::wave_sum_d(s);
+    if (lane == 0) out[c] = (float)s;
+}
+
+// ------------------------------------------------------------------ backward, small path
+__global__ __launch_bounds__(256) void bn_fused_small_bwd(const BnP p) {
+    __shared__ double sm[8];
+    __shared__ float bc[2];
+    const int c = blockIdx.x;
+    const int total = p.N * p.HW;
+    float alpha, beta_, mean, rstd;
+    alpha_beta(p, c, alpha, beta_, mean, rstd);
+    double v2[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int b = i / p.HW, q = i - b * p.HW;
+        const float yv = p.y[((size_t)b * p.CtotY + c) * p.HW + q];
+        const float dv = p.da[((size_t)b * p.CtotDa + c) * p.HW + q];
+        const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
+        v2[0] += dz; v2[1] += (double)(dz * ((yv - mean) * rstd));
+    }
+    uz::block_sum_d<2>(v2, sm);
+    if (threadIdx.x == 0) {
+        if (p.dbeta) p.dbeta[c] = (float)v2[0];
+        if (p.dgamma) p.dgamma[c] = (float)v2[1];
+        bc[0] = (float)(v2[0] / total); bc[1] = (float)(v2[1] / total);
+    }
+    __syncthreads();
+    const float m1 = bc[0], m2 = bc[1];
+    double sd[1] = {0.0};
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int b = i / p.HW, q = i - b * p.HW;
+        const float yv = p.y[((size_t)b * p.CtotY + c) * p.HW + q];
+        const float dv = p.da[((size_t)b * p.CtotDa + c) * p.HW + q];
+        const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
+        const float r = alpha * (dz - m1 - ((yv - mean) * rstd) * m2);
+        p.out[((size_t)b * p.CtotOut + c) * p.HW + q] = r;
+        sd[0] += r;
+    }
+    if (p.dbias) {
+        uz::block_sum_d<1>(sd, sm);
+        if (threadIdx.x == 0) p.dbias[c] = (float)sd[0];
+    }
+}
+
+// ------------------------------------------------------------------ ReLU-only backward (vanilla U-Net units)
+template <bool VEC>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ da, int CtotDa, const float* __restrict__ a, int CtotA,
+                                                        float* __restrict__ dy, int CtotDy, double* __restrict__ part2,
+                                                        int C, int HW, int parts) {
+    __shared__ double sm[4];
+    const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
+    const float* as = a + ((size_t)b * CtotA + c) * HW;
+    const float* ds = da + ((size_t)b * CtotDa + c) * HW;
+    float* dst = dy + ((size_t)b * CtotDy + c) * HW;
+    const int lo = part * CHUNK, hi = min(HW, lo + CHUNK);
+    float sd = 0.f;
+    if (VEC) {
+        const float4* a4 = reinterpret_cast<const float4*>(as);
+        const float4* d4 = reinterpret_cast<const float4*>(ds);
+        float4* o4 = reinterpret_cast<float4*>(dst);
+        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+            const float4 av = a4[i], dv = d4[i];
+            float4 r;
+            r.x = av.x > 0.f ? dv.x : 0.f; r.y = av.y > 0.f ? dv.y : 0.f;
+            r.z = av.z > 0.f ? dv.z : 0.f; r.w = av.w > 0.f ? dv.w : 0.f;
+            sd += (r.x + r.y) + (r.z + r.w);
+            o4[i] = r;
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) { const float r = as[i] > 0.f ? ds[i] : 0.f; sd += r; dst[i] = r; }
+    }
+    if (part2) {
+        double v1[1] = {(double)sd};
+        uz::block_sum_d<1>(v1, sm);
+        if (threadIdx.x == 0) part2[(size_t)(b * parts + part) * C + c] = v1[0];
+    }
+}
+
+inline bool vec_ok(int HW, const void* a, const void* b, const void* c) {
+    auto al = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    return (HW % 4 == 0) && al(a) && al(b) && al(c);
+}
+
+}  // namespace
+
+extern "C" size_t uz_bn_workspace(int C, int N, int H, int W) {
+    const int parts = uz::ceil_div(H * W, CHUNK);
+    const size_t P = (size_t)N * parts;
+    return (P * C * 3 + (size_t)2 * C) * sizeof(double) + 256;
+}
+
+namespace {
+void carve(BnP& p, void* ws) {
+    const size_t P = (size_t)p.N * p.parts;
+    p.part = static_cast<double*>(ws);
+    p.part2 = p.part + P * p.C * 2;
+    p.chan = p.part2 + P * p.C;
+}
+}  // namespace
+
+extern "C" int uz_bn_relu_fwd(const float* y, int C, int CtotY, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float* save_mean_rstd,
+                              float* a, int CtotA, int N, int H, int W, float eps, float momentum,
+                              int training, int relu, void* workspace, void* stream) {
+    UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_fwd: empty tensor");
+    UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_fwd: N or C exceeds grid limits");
+    UZ_REQUIRE(!training || save_mean_rstd, "bn_relu_fwd: training needs save_mean_rstd");
+    UZ_REQUIRE(training || (running_mean && running_var), "bn_relu_fwd: eval needs running statistics");
+    UZ_REQUIRE(!training || (size_t)N * H * W > 1, "bn_relu_fwd: Expected more than 1 value per channel when training");
+    hipStream_t st = uz::S(stream);
+    BnP p = {};
+    p.y = y; p.gamma = gamma; p.beta = beta; p.rmean = running_mean; p.rvar = running_var; p.save = save_mean_rstd;
+    p.out = a; p.C = C; p.CtotY = CtotY; p.CtotOut = CtotA; p.N = N; p.HW = H * W;
+    p.parts = uz::ceil_div(p.HW, CHUNK);
+    p.eps = eps; p.momentum = momentum; p.training = training; p.relu = relu;
+    if ((size_t)N * p.HW <= SMALL_LIMIT) {
+        hipLaunchKernelGGL(bn_fused_small_fwd, dim3(C), dim3(256), 0, st, p);
+        return uz::check_launch("bn_fused_small_fwd");
+    }
+    const bool vec = vec_ok(p.HW, y, a, nullptr);
+    const dim3 grid(p.parts, C, N);
+    if (training) {
+        UZ_REQUIRE(workspace, "bn_relu_fwd: workspace required");
+        carve(p, workspace);
+        if (vec) hipLaunchKernelGGL(bn_stats_partial<true>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(bn_stats_partial<false>, grid, dim3(256), 0, st, p);
+        if (int rc = uz::check_launch("bn_stats_partial")) return rc;
+        hipLaunchKernelGGL(bn_finalize, dim3(uz::ceil_div(C, 4)), dim3(256), 0, st, p);
+        if (int rc = uz::check_launch("bn_finalize")) return rc;
+    }
+    if (vec) hipLaunchKernelGGL(bn_apply<true>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(bn_apply<false>, grid, dim3(256), 0, st, p);
+    return uz::check_launch("bn_apply");
+}
+
+extern "C" int uz_bn_relu_bwd(const float* da, int CtotDa, const float* y, int C, int CtotY,
+                              const float* gamma, const float* beta, const float* save_mean_rstd,
+                              float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
+                              int N, int H, int W, int relu, void* workspace, void* stream) {
+    UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_bwd: empty tensor");
+    UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_bwd: N or C exceeds grid limits");
+    UZ_REQUIRE(save_mean_rstd, "bn_relu_bwd: needs the saved batch statistics");
+    hipStream_t st = uz::S(stream);
+    BnP p = {};
+    p.y = y; p.da = da; p.gamma = gamma; p.beta = beta; p.save = const_cast<float*>(save_mean_rstd);
+    p.out = dy; p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias;
+    p.C = C; p.CtotY = CtotY; p.CtotDa = CtotDa; p.CtotOut = CtotDy; p.N = N; p.HW = H * W;
+    p.parts = uz::ceil_div(p.HW, CHUNK);
+    p.training = 1; p.relu = relu;
+    if ((size_t)N * p.HW <= SMALL_LIMIT) {
+        hipLaunchKernelGGL(bn_fused_small_bwd, dim3(C), dim3(256), 0, st, p);
+        return uz::check_launch("bn_fused_small_bwd");
+    }
+    UZ_REQUIRE(workspace, "bn_relu_bwd: workspace required");
+    carve(p, workspace);
+    const bool vec = vec_ok(p.HW, y, da, dy);
+    const dim3 grid(p.parts, C, N);
+    if (vec) hipLaunchKernelGGL(bn_bwd_reduce_partial<true>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(bn_bwd_reduce_partial<false>, grid, dim3(256), 0, st, p);
+    if (int rc = uz::check_launch("bn_bwd_reduce_partial")) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(uz::ceil_div(C, 4)), dim3(256), 0, st, p);
+    if (int rc = uz::check_launch("bn_bwd_finalize")) return rc;
+    if (vec) hipLaunchKernelGGL(bn_bwd_apply<true>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(bn_bwd_apply<false>, grid, dim3(256), 0, st, p);
+    if (int rc = uz::check_launch("bn_bwd_apply")) return rc;
+    if (dbias) {
+        hipLaunchKernelGGL(chan_partial_sum, dim3(uz::ceil_div(C, 4)), dim3(256), 0, st, p.part2, N * p.parts, C, dbias);
+        if (int rc = uz::check_launch("chan_partial_sum")) return rc;
+    }
+    return 0;
+}
+
+extern "C" int uz_relu_bwd(const float* da, int CtotDa, const float* a, int C, int CtotA,
+                           float* dy, int CtotDy, float* dbias, int N, int H, int W, void* workspace, void* stream) {
+    UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "relu_bwd: empty tensor");
+    UZ_REQUIRE(N <= 65535 && C <= 65535, "relu_bwd: N or C exceeds grid limits");
+    UZ_REQUIRE(!dbias || workspace, "relu_bwd: workspace required for dbias");
+    hipStream_t st = uz::S(stream);
+    const int HW = H * W, parts = uz::ceil_div(HW, CHUNK);
+    double* part2 = dbias ? static_cast<double*>(workspace) : nullptr;
+    const dim3 grid(parts, C, N);
+    if (vec_ok(HW, da, a, dy)) hipLaunchKernelGGL(relu_bwd_kernel<true>, grid, dim3(256), 0, st, da, CtotDa, a, CtotA, dy, CtotDy, part2, C, HW, parts);
+    else hipLaunchKernelGGL(relu_bwd_kernel<false>, grid, dim3(256), 0, st, da, CtotDa, a, CtotA, dy, CtotDy, part2, C, HW, parts);
+    if (int rc = uz::check_launch("relu_bwd_kernel")) return rc;
+    if (dbias) {
+        hipLaunchKernelGGL(chan_partial_sum, dim3(uz::ceil_div(C, 4)), dim3(256), 0, st, part2, N * parts, C, dbias);
+        if (int rc = uz::check_launch("chan_partial_sum")) return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,280 @@
+// fp32 implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), im2col-free.
+//
+// Replaces nn.Conv2d(k=3,s=1,p=1) / nn.Conv2d(k=1) forward (reference torchlayers.py:18, unet.py:25-29,
+// phiseg.py:95-96,281-284) and the input-gradient half of aten::convolution_backward.
+//
+// GEMM view per 3x3 tap:  D[co][pixel] += W_tap[co][ci] * X[ci][pixel + tap offset]
+//   M = output channels  -> MFMA A operand, lane (l&31) = co,    k = l>>5
+//   N = output pixels    -> MFMA B operand, lane (l&31) = pixel, k = l>>5
+//   D: col = lane&31 = pixel (consecutive x -> coalesced 128-B row stores into NCHW),
+//      row = (r&3) + 8*(r>>2) + 4*(lane>>5) = co.
+// A workgroup (4 waves) owns a tile of 32*MSUB output channels x 256 output pixels (a TB x TH x TW
+// block of images/rows/cols, each wave 64 pixels).  Per 8-input-channel chunk it stages, into LDS,
+//   - the haloed input patch  [8][TB][(TH+2)][(TW+2)]  (zero filled outside the image = padding),
+//   - the weight panel        [tap][8][32*MSUB (+1 pad)], read straight from the PyTorch
+//     [Cout][Cin][3][3] parameter (forward) or transposed + tap-flipped (input gradient),
+// double buffered: global loads for chunk c+1 are issued before the 36 k-steps of chunk c and
+// written to the other buffer afterwards (one barrier per chunk).  All 9 taps reuse the same
+// patch through a constant LDS offset, so HBM/L2 sees each input element once per channel tile.
+#include "uz_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int CK = 8;      // input channels per LDS chunk
+constexpr int NSUB = 2;    // 32-pixel sub-tiles per wave
+
+struct ConvP {
+    const float* x; const float* w; const float* bias; float* y;
+    int N, H, W, HW;
+    int Cin, CinTot, Cout, CoutTot;   // GEMM-K channels (input view), GEMM-M channels (output view)
+    int wCi;                          // second dim of the weight tensor (the layer's true Cin)
+    int TW, TH, TB, lgTW, lgTH;
+    int tilesX, tilesY, nCoTiles;
+    int PW, PSI, PS;                  // patch row stride, patch floats per image, per channel
+    int relu, accumulate;
+};
+
+template <int KS, int MSUB, int JMAX, bool DGRAD>
+__global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const ConvP p) {
+    constexpr int KK = KS * KS, HALO = KS / 2;
+    constexpr int COT = 32 * MSUB, COTP = COT + 1;
+    constexpr int WSZ = KK * CK * COTP;
+    constexpr int WELEMS = COT * CK * KK;
+    constexpr int WREGS = (WELEMS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int BUF = WSZ + CK * p.PS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);
+    const int coT = wid % p.nCoTiles, pixT = wid / p.nCoTiles;
+    const int txi = pixT % p.tilesX, t2 = pixT / p.tilesX;
+    const int tyi = t2 % p.tilesY, tbi = t2 / p.tilesY;
+    const int x0 = txi * p.TW, y0 = tyi * p.TH, b0 = tbi * p.TB;
+    const int co0 = coT * COT;
+
+    // ---- per-thread staging map of the input patch (same for every channel and chunk)
+    int goff[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int r = tid + j * 256;
+        int g = -1;
+        if (r < p.PS) {
+            const int tb = r / p.PSI, rr = r - tb * p.PSI;
+            const int py = rr / p.PW, px = rr - py * p.PW;
+            const int b = b0 + tb, yy = y0 + py - HALO, xx = x0 + px - HALO;
+            if (b < p.N && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) g = tb * p.CinTot * p.HW + yy * p.W + xx;
+        }
+        goff[j] = g;
+    }
+    const float* xb = p.x + (size_t)b0 * p.CinTot * p.HW;
+
+    // ---- per-lane output pixels (B operand columns)
+    int poff[NSUB], oidx[NSUB];
+    const int npix = p.TB << (p.lgTW + p.lgTH);
+#pragma unroll
+    for (int n = 0; n < NSUB; ++n) {
+        const int pp = wave * (32 * NSUB) + n * 32 + l31;
+        const int tx = pp & (p.TW - 1), ty = (pp >> p.lgTW) & (p.TH - 1), tb = pp >> (p.lgTW + p.lgTH);
+        const bool v = pp < npix && (b0 + tb) < p.N && (y0 + ty) < p.H && (x0 + tx) < p.W;
+        poff[n] = v ? (tb * p.PSI + ty * p.PW + tx + h * p.PS) : (h * p.PS);
+        oidx[n] = v ? ((b0 + tb) * p.CoutTot * p.HW + (y0 + ty) * p.W + (x0 + tx)) : -1;
+    }
+
+    f32x16 acc[MSUB][NSUB];
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+        for (int n = 0; n < NSUB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    float pr[CK * JMAX], wr[WREGS];
+
+    auto gload = [&](int c) {
+        const int ci0 = c * CK;
+#pragma unroll
+        for (int ci = 0; ci < CK; ++ci) {
+            const bool cv = (ci0 + ci) < p.Cin;
+            const float* xc = xb + (size_t)(ci0 + ci) * p.HW;
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) pr[ci * JMAX + j] = (cv && goff[j] >= 0) ? xc[goff[j]] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < WREGS; ++i) {
+            const int e = tid + i * 256;
+            float v = 0.f;
+            if (e < WELEMS) {
+                if (!DGRAD) {
+                    const int co = e / (CK * KK), rem = e - co * (CK * KK), ci = rem / KK;
+                    if (co0 + co < p.Cout && ci0 + ci < p.Cin)
+                        v = p.w[((size_t)(co0 + co) * p.wCi + ci0) * KK + rem];
+                } else {   // GEMM-K index k walks the weight's dim 0, GEMM-M index m its dim 1
+                    const int k = e / (COT * KK), rem = e - k * (COT * KK), m = rem / KK;
+                    if (ci0 + k < p.Cin && co0 + m < p.Cout)
+                        v = p.w[((size_t)(ci0 + k) * p.wCi + co0) * KK + rem];
+                }
+            }
+            wr[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* Wl = lds + buf * BUF;
+        float* Pl = Wl + WSZ;
+#pragma unroll
+        for (int ci = 0; ci < CK; ++ci)
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                const int r = tid + j * 256;
+                if (r < p.PS) Pl[ci * p.PS + r] = pr[ci * JMAX + j];
+            }
+#pragma unroll
+        for (int i = 0; i < WREGS; ++i) {
+            const int e = tid + i * 256;
+            if (e < WELEMS) {
+                if (!DGRAD) {
+                    const int co = e / (CK * KK), rem = e - co * (CK * KK), ci = rem / KK, tap = rem - ci * KK;
+                    Wl[(tap * CK + ci) * COTP + co] = wr[i];
+                } else {
+                    const int k = e / (COT * KK), rem = e - k * (COT * KK), m = rem / KK, t = rem - m * KK;
+                    Wl[((KK - 1 - t) * CK + k) * COTP + m] = wr[i];
+                }
+            }
+        }
+    };
+
+    const int nChunks = (p.Cin + CK - 1) / CK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nChunks; ++c) {
+        const bool more = (c + 1) < nChunks;
+        if (more) gload(c + 1);
+        const float* Wl = lds + (c & 1) * BUF;
+        const float* Pl = Wl + WSZ;
+        const float* Al = Wl + h * COTP + l31;
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int tapoff = (tap / KS) * p.PW + (tap % KS);
+#pragma unroll
+            for (int kk = 0; kk < CK / 2; ++kk) {
+                float a[MSUB], b[NSUB];
+#pragma unroll
+                for (int m = 0; m < MSUB; ++m) a[m] = Al[(tap * CK + 2 * kk) * COTP + m * 32];
+#pragma unroll
+                for (int n = 0; n < NSUB; ++n) b[n] = Pl[poff[n] + 2 * kk * p.PS + tapoff];
+#pragma unroll
+                for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+                    for (int n = 0; n < NSUB; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (more) lstore((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, optional accumulate / ReLU, coalesced NCHW stores
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (co < p.Cout) {
+                const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+                for (int n = 0; n < NSUB; ++n) {
+                    if (oidx[n] >= 0) {
+                        float* dst = p.y + (size_t)oidx[n] + (size_t)co * p.HW;
+                        float v = acc[m][n][r] + bv;
+                        if (p.accumulate) v += *dst;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        *dst = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct Geom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB; };
+
+Geom pick_geom(int N, int H, int W, int halo) {
+    Geom g;
+    g.TW = W >= 32 ? 32 : uz::pow2_ceil(W);
+    g.TH = uz::pow2_ceil(H);
+    if (g.TH > 256 / g.TW) g.TH = 256 / g.TW;
+    g.TB = 256 / (g.TW * g.TH);
+    if (g.TB > uz::pow2_ceil(N)) g.TB = uz::pow2_ceil(N);
+    g.PW = g.TW + 2 * halo;
+    g.PSI = (g.TH + 2 * halo) * g.PW;
+    while (g.TB > 1 && g.TB * g.PSI > 1024) g.TB >>= 1;
+    g.PS = g.TB * g.PSI;
+    g.tilesX = uz::ceil_div(W, g.TW);
+    g.tilesY = uz::ceil_div(H, g.TH);
+    g.tilesB = uz::ceil_div(N, g.TB);
+    return g;
+}
+
+template <int KS, int MSUB, int JMAX, bool DG>
+int launch_one(const ConvP& p, int grid, size_t smem, hipStream_t st) {
+    static bool attr_done = false;
+    auto kern = conv_mfma_kernel<KS, MSUB, JMAX, DG>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return uz::fail("conv_mfma: cannot raise dynamic LDS limit");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p);
+    return uz::check_launch("conv_mfma_kernel");
+}
+
+template <int KS, bool DG>
+int launch_ks(const ConvP& p, int msub, int jmax, int grid, size_t smem, hipStream_t st) {
+    if (msub == 1) return jmax == 2 ? launch_one<KS, 1, 2, DG>(p, grid, smem, st) : launch_one<KS, 1, 4, DG>(p, grid, smem, st);
+    return jmax == 2 ? launch_one<KS, 2, 2, DG>(p, grid, smem, st) : launch_one<KS, 2, 4, DG>(p, grid, smem, st);
+}
+
+}  // namespace
+
+namespace uz {
+
+// x: input view (Kc channels), y: output view (Mc channels); w = PyTorch [Cout][Cin][ks][ks] parameter.
+int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
+              float* y, int Mc, int McTot, int N, int H, int W, int ks, int dgrad, int relu, int accumulate,
+              hipStream_t st) {
+    UZ_REQUIRE(ks == 1 || ks == 3, "conv: kernel size %d unsupported (1 or 3)", ks);
+    UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Kc > 0 && Mc > 0, "conv: empty tensor");
+    UZ_REQUIRE(H <= 4096 && W <= 4096, "conv: spatial size too large");
+    const Geom g = pick_geom(N, H, W, ks / 2);
+    ConvP p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.HW = H * W;
+    p.Cin = Kc; p.CinTot = KcTot; p.Cout = Mc; p.CoutTot = McTot; p.wCi = wCi;
+    p.TW = g.TW; p.TH = g.TH; p.TB = g.TB; p.lgTW = ilog2(g.TW); p.lgTH = ilog2(g.TH);
+    p.tilesX = g.tilesX; p.tilesY = g.tilesY;
+    p.PW = g.PW; p.PSI = g.PSI; p.PS = g.PS;
+    p.relu = relu; p.accumulate = accumulate;
+    const int msub = Mc <= 32 ? 1 : 2;
+    const int cot = 32 * msub;
+    p.nCoTiles = ceil_div(Mc, cot);
+    const int jmax = g.PS <= 512 ? 2 : 4;
+    const int kk = ks * ks;
+    const size_t smem = 2 * (size_t)(kk * CK * (cot + 1) + CK * g.PS) * sizeof(float);
+    const long long grid = (long long)g.tilesX * g.tilesY * g.tilesB * p.nCoTiles;
+    UZ_REQUIRE(grid < (1ll << 31), "conv: grid too large");
+    if (ks == 3) return dgrad ? launch_ks<3, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<3, false>(p, msub, jmax, (int)grid, smem, st);
+    return dgrad ? launch_ks<1, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<1, false>(p, msub, jmax, (int)grid, smem, st);
+}
+
+}  // namespace uz
+
+extern "C" int uz_conv_fwd(const float* x, int Cin, int CinTot, const float* w, const float* bias,
+                           float* y, int Cout, int CoutTot, int N, int H, int W, int ks, int relu, void* stream) {
+    return uz::conv_mfma(x, Cin, CinTot, w, Cin, bias, y, Cout, CoutTot, N, H, W, ks, 0, relu, 0, uz::S(stream));
+}
+
+extern "C" int uz_conv_bwd_data(const float* dy, int Cout, int CoutTot, const float* w,
+                                float* dx, int Cin, int CinTot, int N, int H, int W, int ks, int accumulate, void* stream) {
+    return uz::conv_mfma(dy, Cout, CoutTot, w, Cin, nullptr, dx, Cin, CinTot, N, H, W, ks, 1, 0, accumulate, uz::S(stream));
+}

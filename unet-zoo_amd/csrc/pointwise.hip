@@ -1,0 +1,366 @@
+// Latent heads, losses, optimiser and vector helpers (all HBM-bound or tiny):
+//   posterior input  = cat(patch, onehot(mask) - 0.5)      utils.py:289-311, phiseg.py:178-183
+//   latent sampling  = softplus + reparameterisation        phiseg.py:100-105
+//   KL(q||p) with the reference's sigma1*sigma0 quirk       phiseg.py:436-453, probabilistic_unet.py:291-308
+//   residual multinoulli cross entropy                      phiseg.py:481-513 (unet.py:159-165 for L=1)
+//   accumulate_output + softmax + argmax                    phiseg.py:428-434, train_model.py:186,195
+//   torch.optim.Adam step (L2 weight decay)                 train_model.py:49,122
+//   sum of 2-norms regulariser                              utils.py:93-101
+#include "uz_common.h"
+
+namespace {
+
+constexpr int MAXL = 8;
+
+// ---------------------------------------------------------------- posterior input
+__global__ __launch_bounds__(256) void posterior_input_k(const float* __restrict__ patch, int in_ch, const float* __restrict__ mask,
+                                                          int nlabels, float* __restrict__ out, int HW) {
+    const int b = blockIdx.z, c = blockIdx.y, ctot = in_ch + nlabels;
+    float* d = out + ((size_t)b * ctot + c) * HW;
+    if (c < in_ch) {
+        const float* s = patch + ((size_t)b * in_ch + c) * HW;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) d[i] = s[i];
+    } else {
+        const float lab = (float)(c - in_ch);
+        const float* m = mask + (size_t)b * HW;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) d[i] = (m[i] == lab ? 1.f : 0.f) - 0.5f;
+    }
+}
+
+// ---------------------------------------------------------------- latent sampling
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // F.softplus(beta=1, threshold=20)
+
+__global__ __launch_bounds__(256) void latent_fwd_k(const float* __restrict__ mu, const float* __restrict__ pre, const float* __restrict__ eps,
+                                                     float* __restrict__ sigma, float* __restrict__ z, size_t n, int act) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float s = act ? expf(pre[i]) : softplus_f(pre[i]);
+        sigma[i] = s;
+        if (z) z[i] = mu[i] + s * eps[i];
+    }
+}
+__global__ __launch_bounds__(256) void latent_bwd_k(const float* __restrict__ dmu, const float* __restrict__ dsigma, const float* __restrict__ dz,
+                                                     const float* __restrict__ eps, const float* __restrict__ sigma,
+                                                     float* __restrict__ dmu_pre, float* __restrict__ dpre, size_t n, int act) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gz = dz ? dz[i] : 0.f;
+        const float gm = (dmu ? dmu[i] : 0.f) + gz;
+        const float gs = (dsigma ? dsigma[i] : 0.f) + gz * eps[i];
+        dmu_pre[i] = gm;
+        // d softplus(x)/dx = sigmoid(x) = 1 - exp(-softplus(x)); identity above the threshold
+        const float s = sigma[i];
+        dpre[i] = gs * (act ? s : (s > 20.f ? 1.f : (1.f - expf(-s))));
+    }
+}
+
+// ---------------------------------------------------------------- KL
+__global__ __launch_bounds__(256) void kl_fwd_k(const float* __restrict__ mu0, const float* __restrict__ s0, const float* __restrict__ mu1,
+                                                 const float* __restrict__ s1, int total, int N, float weight, float* __restrict__ out) {
+    __shared__ double sm[4];
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const float a0 = s0[i], a1 = s1[i];
+        const float s0fs = a0 * a0, s1fs = a1 * a0;
+        const float d = mu1[i] - mu0[i];
+        const float t = (s0fs + d * d) / (s1fs + 1e-10f) + logf(s1fs + 1e-10f) - logf(s0fs + 1e-10f) - 1.f;
+        v[0] += t;
+    }
+    uz::block_sum_d<1>(v, sm);
+    if (threadIdx.x == 0) out[0] = (float)((double)weight * 0.5 * v[0] / N);
+}
+__global__ __launch_bounds__(256) void kl_bwd_k(const float* __restrict__ mu0, const float* __restrict__ s0, const float* __restrict__ mu1,
+                                                 const float* __restrict__ s1, int total, float k, const float* __restrict__ scale,
+                                                 float* __restrict__ dmu0, float* __restrict__ ds0, float* __restrict__ dmu1, float* __restrict__ ds1) {
+    const float kk = k * (scale ? scale[0] : 1.f);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const float a0 = s0[i], a1 = s1[i];
+        const float A = a0 * a0 + (mu1[i] - mu0[i]) * (mu1[i] - mu0[i]);
+        const float B = a1 * a0 + 1e-10f, C0 = a0 * a0 + 1e-10f;
+        const float d = mu1[i] - mu0[i];
+        const float g = 2.f * d / B;
+        if (dmu0) dmu0[i] = -kk * g;
+        if (dmu1) dmu1[i] = kk * g;
+        if (ds0) ds0[i] = kk * (2.f * a0 / B - A * a1 / (B * B) + a1 / B - 2.f * a0 / C0);
+        if (ds1) ds1[i] = kk * (-A * a0 / (B * B) + a0 / B);
+    }
+}
+
+// ---------------------------------------------------------------- residual multinoulli CE
+struct CeP {
+    const float* const* s; float* const* ds; const float* mask; double* part; float* out; const float* scale;
+    int L, N, HW, nblk;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void ce_fwd_k(const CeP p) {
+    __shared__ double sm[4 * MAXL];
+    const int b = blockIdx.y;
+    double acc_l[MAXL];
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) acc_l[l] = 0.0;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < p.HW; q += gridDim.x * 256) {
+        const int t = (int)p.mask[(size_t)b * p.HW + q];
+        float a[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) a[k] = 0.f;
+#pragma unroll
+        for (int l = MAXL - 1; l >= 0; --l) {
+            if (l < p.L) {
+                const float* s = p.s[l] + (size_t)b * K * p.HW + q;
+                float mx = -INFINITY, at = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    a[k] = (l == p.L - 1) ? s[(size_t)k * p.HW] : a[k] + s[(size_t)k * p.HW];
+                    mx = fmaxf(mx, a[k]);
+                    if (k == t) at = a[k];
+                }
+                float se = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) se += expf(a[k] - mx);
+                acc_l[l] += (double)(mx + logf(se) - at);
+            }
+        }
+    }
+    uz::block_sum_d<MAXL>(acc_l, sm);
+    if (threadIdx.x == 0) {
+        double* o = p.part + (size_t)(b * gridDim.x + blockIdx.x) * MAXL;
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l) o[l] = acc_l[l];
+    }
+}
+__global__ __launch_bounds__(64) void ce_finalize_k(const CeP p) {
+    const int l = threadIdx.x;
+    if (l >= p.L) return;
+    double s = 0.0;
+    for (int i = 0; i < p.nblk; ++i) s += p.part[(size_t)i * MAXL + l];
+    p.out[l] = (float)(s / p.N);
+}
+template <int K>
+__global__ __launch_bounds__(256) void ce_bwd_k(const CeP p) {
+    const int b = blockIdx.y;
+    const float k0 = (p.scale ? p.scale[0] : 1.f) / (float)p.N;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < p.HW; q += gridDim.x * 256) {
+        const int t = (int)p.mask[(size_t)b * p.HW + q];
+        float a[K], g[MAXL][K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) a[k] = 0.f;
+#pragma unroll
+        for (int l = MAXL - 1; l >= 0; --l) {
+            if (l < p.L) {
+                const float* s = p.s[l] + (size_t)b * K * p.HW + q;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    a[k] = (l == p.L - 1) ? s[(size_t)k * p.HW] : a[k] + s[(size_t)k * p.HW];
+                    mx = fmaxf(mx, a[k]);
+                }
+                float e[K], se = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) { e[k] = expf(a[k] - mx); se += e[k]; }
+#pragma unroll
+                for (int k = 0; k < K; ++k) g[l][k] = e[k] / se - (k == t ? 1.f : 0.f);
+            }
+        }
+        float cum[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) cum[k] = 0.f;
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l) {
+            if (l < p.L) {
+                float* d = p.ds[l] + (size_t)b * K * p.HW + q;
+#pragma unroll
+                for (int k = 0; k < K; ++k) { cum[k] += g[l][k]; d[(size_t)k * p.HW] = cum[k] * k0; }
+            }
+        }
+    }
+}
+
+__global__ void sum_terms_k(const float* __restrict__ t, int n, float* __restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += t[i];
+        total[0] = s;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void acc_softmax_argmax_k(const float* const* __restrict__ sp, int L, int HW,
+                                                             float* __restrict__ acc, float* __restrict__ soft, uint8_t* __restrict__ label) {
+    const int b = blockIdx.y;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < HW; q += gridDim.x * 256) {
+        float a[K];
+        const size_t base = (size_t)b * K * HW + q;
+#pragma unroll
+        for (int k = 0; k < K; ++k) a[k] = sp[L - 1][base + (size_t)k * HW];        // s_accum = output_list[-1]
+        for (int l = 0; l < L - 1; ++l)
+#pragma unroll
+            for (int k = 0; k < K; ++k) a[k] += sp[l][base + (size_t)k * HW];       // += output_list[i]
+        float mx = a[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, a[k]);
+        float e[K], se = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { e[k] = expf(a[k] - mx); se += e[k]; }
+        int best = 0; float bv = e[0] / se;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float sv = e[k] / se;
+            if (acc) acc[base + (size_t)k * HW] = a[k];
+            if (soft) soft[base + (size_t)k * HW] = sv;
+            if (sv > bv) { bv = sv; best = k; }
+        }
+        if (label) label[(size_t)b * HW + q] = (uint8_t)best;
+    }
+}
+
+// ---------------------------------------------------------------- Adam / vector ops
+__global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                               size_t n, float lr_over_bc1, float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd, float gs) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float pi = p[i];
+        const float gi = g[i] * gs + wd * pi;
+        const float mi = m[i] + (gi - m[i]) * (1.f - beta1);            // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;        // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = pi - lr_over_bc1 * (mi / denom);
+    }
+}
+__global__ __launch_bounds__(256) void axpy_k(float* __restrict__ y, const float* __restrict__ x, float a, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] += a * x[i];
+}
+__global__ __launch_bounds__(256) void scale_k(float* __restrict__ y, float a, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] *= a;
+}
+__global__ __launch_bounds__(256) void l2_norms_k(const float* __restrict__ flat, const int64_t* __restrict__ oc, float* __restrict__ out) {
+    __shared__ double sm[4];
+    const int64_t off = oc[2 * blockIdx.x], cnt = oc[2 * blockIdx.x + 1];
+    double v[1] = {0.0};
+    for (int64_t i = threadIdx.x; i < cnt; i += 256) { const double t = flat[off + i]; v[0] += t * t; }
+    uz::block_sum_d<1>(v, sm);
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)sqrt(v[0]);
+}
+__global__ __launch_bounds__(256) void l2_norms_bwd_k(const float* __restrict__ flat, const int64_t* __restrict__ oc, const float* __restrict__ norms,
+                                                       const float* __restrict__ scale, float* __restrict__ grad) {
+    const int64_t off = oc[2 * blockIdx.x], cnt = oc[2 * blockIdx.x + 1];
+    const float nrm = norms[blockIdx.x];
+    const float k = nrm > 0.f ? scale[0] / nrm : 0.f;
+    for (int64_t i = threadIdx.x; i < cnt; i += 256) grad[off + i] += k * flat[off + i];
+}
+
+inline int vgrid(size_t n) { size_t g = (n + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1; return (int)g; }
+
+}  // namespace
+
+extern "C" int uz_posterior_input(const float* patch, int in_ch, const float* mask, int nlabels, float* out, int N, int H, int W, void* stream) {
+    UZ_REQUIRE(in_ch > 0 && nlabels > 0 && N > 0 && H > 0 && W > 0 && N <= 65535, "posterior_input: bad sizes");
+    const int HW = H * W;
+    hipLaunchKernelGGL(posterior_input_k, dim3(uz::ceil_div(HW, 1024), in_ch + nlabels, N), dim3(256), 0, uz::S(stream), patch, in_ch, mask, nlabels, out, HW);
+    return uz::check_launch("posterior_input_k");
+}
+extern "C" int uz_latent_sample_fwd(const float* mu, const float* pre_sigma, const float* eps, float* sigma, float* z, size_t n, int act, void* stream) {
+    UZ_REQUIRE(n > 0 && pre_sigma && sigma, "latent_sample_fwd: bad arguments");
+    UZ_REQUIRE(!z || (mu && eps), "latent_sample_fwd: z needs mu and eps");
+    hipLaunchKernelGGL(latent_fwd_k, dim3(vgrid(n)), dim3(256), 0, uz::S(stream), mu, pre_sigma, eps, sigma, z, n, act);
+    return uz::check_launch("latent_fwd_k");
+}
+extern "C" int uz_latent_sample_bwd(const float* dmu, const float* dsigma, const float* dz, const float* eps, const float* sigma,
+                                    float* dmu_pre, float* dpre_sigma, size_t n, int act, void* stream) {
+    UZ_REQUIRE(n > 0 && eps && sigma && dmu_pre && dpre_sigma, "latent_sample_bwd: bad arguments");
+    hipLaunchKernelGGL(latent_bwd_k, dim3(vgrid(n)), dim3(256), 0, uz::S(stream), dmu, dsigma, dz, eps, sigma, dmu_pre, dpre_sigma, n, act);
+    return uz::check_launch("latent_bwd_k");
+}
+extern "C" int uz_kl_fwd(const float* mu0, const float* s0, const float* mu1, const float* s1, int N, int per_sample, float weight,
+                         float* loss_out, void* stream) {
+    UZ_REQUIRE(N > 0 && per_sample > 0, "kl_fwd: empty tensor");
+    hipLaunchKernelGGL(kl_fwd_k, dim3(1), dim3(256), 0, uz::S(stream), mu0, s0, mu1, s1, N * per_sample, N, weight, loss_out);
+    return uz::check_launch("kl_fwd_k");
+}
+extern "C" int uz_kl_bwd(const float* mu0, const float* s0, const float* mu1, const float* s1, int N, int per_sample, float weight,
+                         const float* loss_scale, float* dmu0, float* ds0, float* dmu1, float* ds1, void* stream) {
+    UZ_REQUIRE(N > 0 && per_sample > 0, "kl_bwd: empty tensor");
+    const int total = N * per_sample;
+    hipLaunchKernelGGL(kl_bwd_k, dim3(vgrid(total)), dim3(256), 0, uz::S(stream), mu0, s0, mu1, s1, total, weight * 0.5f / (float)N, loss_scale,
+                       dmu0, ds0, dmu1, ds1);
+    return uz::check_launch("kl_bwd_k");
+}
+
+static int ce_blocks(int HW) { int g = uz::ceil_div(HW, 1024); return g < 1 ? 1 : (g > 64 ? 64 : g); }
+
+extern "C" size_t uz_ce_workspace(int N, int H, int W, int L) {
+    (void)L;
+    return (size_t)N * ce_blocks(H * W) * MAXL * sizeof(double);
+}
+extern "C" int uz_residual_ce_fwd(const float* const* s_ptrs, int L, int K, const float* mask, int N, int H, int W,
+                                  float* loss_out, void* workspace, void* stream) {
+    UZ_REQUIRE(L >= 1 && L <= MAXL, "residual_ce_fwd: 1..%d levels supported", MAXL);
+    UZ_REQUIRE(K >= 2 && K <= 4, "residual_ce_fwd: 2..4 classes supported (got %d)", K);
+    UZ_REQUIRE(N > 0 && N <= 65535 && workspace, "residual_ce_fwd: bad arguments");
+    CeP p = {}; p.s = s_ptrs; p.mask = mask; p.part = static_cast<double*>(workspace); p.out = loss_out; p.L = L; p.N = N; p.HW = H * W;
+    const int gx = ce_blocks(p.HW); p.nblk = N * gx;
+    const dim3 grid(gx, N);
+    hipStream_t st = uz::S(stream);
+    if (K == 2) hipLaunchKernelGGL(ce_fwd_k<2>, grid, dim3(256), 0, st, p);
+    else if (K == 3) hipLaunchKernelGGL(ce_fwd_k<3>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(ce_fwd_k<4>, grid, dim3(256), 0, st, p);
+    if (int rc = uz::check_launch("ce_fwd_k")) return rc;
+    hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(64), 0, st, p);
+    return uz::check_launch("ce_finalize_k");
+}
+extern "C" int uz_residual_ce_bwd(const float* const* s_ptrs, float* const* ds_ptrs, int L, int K, const float* mask, int N, int H, int W,
+                                  const float* loss_scale, void* stream) {
+    UZ_REQUIRE(L >= 1 && L <= MAXL, "residual_ce_bwd: 1..%d levels supported", MAXL);
+    UZ_REQUIRE(K >= 2 && K <= 4, "residual_ce_bwd: 2..4 classes supported (got %d)", K);
+    UZ_REQUIRE(N > 0 && N <= 65535, "residual_ce_bwd: bad arguments");
+    CeP p = {}; p.s = s_ptrs; p.ds = ds_ptrs; p.mask = mask; p.scale = loss_scale; p.L = L; p.N = N; p.HW = H * W;
+    const dim3 grid(ce_blocks(p.HW), N);
+    hipStream_t st = uz::S(stream);
+    if (K == 2) hipLaunchKernelGGL(ce_bwd_k<2>, grid, dim3(256), 0, st, p);
+    else if (K == 3) hipLaunchKernelGGL(ce_bwd_k<3>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(ce_bwd_k<4>, grid, dim3(256), 0, st, p);
+    return uz::check_launch("ce_bwd_k");
+}
+extern "C" int uz_sum_terms(const float* terms, int n, float* total, void* stream) {
+    hipLaunchKernelGGL(sum_terms_k, dim3(1), dim3(64), 0, uz::S(stream), terms, n, total);
+    return uz::check_launch("sum_terms_k");
+}
+extern "C" int uz_accumulate_softmax_argmax(const float* const* s_ptrs, int L, int K, int N, int H, int W,
+                                            float* acc, float* soft, uint8_t* label, void* stream) {
+    UZ_REQUIRE(L >= 1 && K >= 2 && K <= 4 && N > 0 && N <= 65535, "accumulate_softmax_argmax: bad arguments");
+    const int HW = H * W;
+    const dim3 grid(ce_blocks(HW), N);
+    hipStream_t st = uz::S(stream);
+    if (K == 2) hipLaunchKernelGGL(acc_softmax_argmax_k<2>, grid, dim3(256), 0, st, s_ptrs, L, HW, acc, soft, label);
+    else if (K == 3) hipLaunchKernelGGL(acc_softmax_argmax_k<3>, grid, dim3(256), 0, st, s_ptrs, L, HW, acc, soft, label);
+    else hipLaunchKernelGGL(acc_softmax_argmax_k<4>, grid, dim3(256), 0, st, s_ptrs, L, HW, acc, soft, label);
+    return uz::check_launch("acc_softmax_argmax_k");
+}
+extern "C" int uz_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, int64_t step,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+    UZ_REQUIRE(step >= 1, "adam_step: step must be >= 1");
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_k, dim3(vgrid(n)), dim3(256), 0, uz::S(stream), params, grads, exp_avg, exp_avg_sq, n,
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale);
+    return uz::check_launch("adam_k");
+}
+extern "C" int uz_axpy(float* y, const float* x, float alpha, size_t n, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpy_k, dim3(vgrid(n)), dim3(256), 0, uz::S(stream), y, x, alpha, n);
+    return uz::check_launch("axpy_k");
+}
+extern "C" int uz_scale(float* y, float alpha, size_t n, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scale_k, dim3(vgrid(n)), dim3(256), 0, uz::S(stream), y, alpha, n);
+    return uz::check_launch("scale_k");
+}
+extern "C" int uz_l2_norms(const float* flat, const int64_t* offs_counts, int n_tensors, float* out, void* stream) {
+    if (n_tensors <= 0) return 0;
+    hipLaunchKernelGGL(l2_norms_k, dim3(n_tensors), dim3(256), 0, uz::S(stream), flat, offs_counts, out);
+    return uz::check_launch("l2_norms_k");
+}
+extern "C" int uz_l2_norms_bwd(const float* flat, const int64_t* offs_counts, int n_tensors, const float* norms, const float* scale,
+                               float* grad_flat, void* stream) {
+    if (n_tensors <= 0) return 0;
+    hipLaunchKernelGGL(l2_norms_bwd_k, dim3(n_tensors), dim3(256), 0, uz::S(stream), flat, offs_counts, norms, scale, grad_flat);
+    return uz::check_launch("l2_norms_bwd_k");
+}

@@ -1,0 +1,255 @@
+// Resampling ops of the encoder-decoder: 2x2 average pooling (ceil_mode), bilinear x2 (both
+// align_corners modes), nearest integer up-sampling, global spatial mean, channel broadcast.
+// Reference call sites: phiseg.py:23,66,213-216,305-309,321; unet.py:22,67;
+// probabilistic_unet.py:56,114-115,172-197.  All are HBM-bound streaming kernels: one workgroup
+// per (plane chunk, channel, image), consecutive lanes on consecutive x (coalesced), backward
+// passes written as deterministic gathers (no atomics).
+#include "uz_common.h"
+
+namespace {
+
+constexpr int PCH = 4096;   // output plane elements per workgroup
+
+struct RsP {
+    const float* src; float* dst;
+    int C, CtotS, CtotD, N, H, W;      // H, W: sizes of the LOW-resolution side
+    int Ho, Wo;                         // sizes of the HIGH-resolution side (pool input / upsample output)
+    int ac, factor, accumulate;
+    float sh, sw;
+};
+
+// ---------------------------------------------------------------- avg pool 2x2 stride 2 ceil_mode
+// here (Ho,Wo) is the pool INPUT (high-res) and (H,W) the pool OUTPUT
+__global__ __launch_bounds__(256) void avgpool_fwd_k(const RsP p) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
+    float* d = p.dst + ((size_t)b * p.CtotD + c) * p.H * p.W;
+    const int n = p.H * p.W;
+    for (int q = blockIdx.x * PCH + threadIdx.x; q < min(n, (int)(blockIdx.x + 1) * PCH); q += 256) {
+        const int oy = q / p.W, ox = q - oy * p.W;
+        const int y0 = 2 * oy, x0 = 2 * ox;
+        const int y1 = min(y0 + 2, p.Ho), x1 = min(x0 + 2, p.Wo);
+        float acc = 0.f;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) acc += s[yy * p.Wo + xx];
+        d[q] = acc / (float)((y1 - y0) * (x1 - x0));
+    }
+}
+__global__ __launch_bounds__(256) void avgpool_bwd_k(const RsP p) {   // src = dy (low res), dst = dx (high res)
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float* s = p.src + ((size_t)b * p.CtotS + c) * p.H * p.W;
+    float* d = p.dst + ((size_t)b * p.CtotD + c) * p.Ho * p.Wo;
+    const int n = p.Ho * p.Wo;
+    for (int q = blockIdx.x * PCH + threadIdx.x; q < min(n, (int)(blockIdx.x + 1) * PCH); q += 256) {
+        const int y = q / p.Wo, x = q - y * p.Wo;
+        const int oy = y >> 1, ox = x >> 1;
+        const int cnt = (min(2 * oy + 2, p.Ho) - 2 * oy) * (min(2 * ox + 2, p.Wo) - 2 * ox);
+        const float v = s[oy * p.W + ox] / (float)cnt;
+        d[q] = p.accumulate ? d[q] + v : v;
+    }
+}
+
+// ---------------------------------------------------------------- bilinear x2
+__device__ __forceinline__ void src_index(int o, float scale, int ac, int in, int& i0, int& ip, float& l0, float& l1) {
+    float r;
+    if (ac) r = scale * (float)o;                                 // area_pixel_compute_source_index, align_corners
+    else { r = scale * ((float)o + 0.5f) - 0.5f; if (r < 0.f) r = 0.f; }
+    i0 = (int)r;
+    if (i0 > in - 1) i0 = in - 1;
+    ip = (i0 < in - 1) ? 1 : 0;
+    l1 = r - (float)i0;
+    l0 = 1.f - l1;
+}
+__global__ __launch_bounds__(256) void bilinear_fwd_k(const RsP p) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float* s = p.src + ((size_t)b * p.CtotS + c) * p.H * p.W;
+    float* d = p.dst + ((size_t)b * p.CtotD + c) * p.Ho * p.Wo;
+    const int n = p.Ho * p.Wo;
+    for (int q = blockIdx.x * PCH + threadIdx.x; q < min(n, (int)(blockIdx.x + 1) * PCH); q += 256) {
+        const int oy = q / p.Wo, ox = q - oy * p.Wo;
+        int h1, hp, w1, wp; float h0l, h1l, w0l, w1l;
+        src_index(oy, p.sh, p.ac, p.H, h1, hp, h0l, h1l);
+        src_index(ox, p.sw, p.ac, p.W, w1, wp, w0l, w1l);
+        const float* r0 = s + h1 * p.W + w1;
+        const float* r1 = r0 + hp * p.W;
+        d[q] = h0l * (w0l * r0[0] + w1l * r0[wp]) + h1l * (w0l * r1[0] + w1l * r1[wp]);
+    }
+}
+// gather form of upsample_bilinear2d_backward: every low-res pixel sums the <= 7x7 high-res pixels
+// whose interpolation footprint touches it (weights recomputed exactly as in the forward)
+__global__ __launch_bounds__(256) void bilinear_bwd_k(const RsP p) {   // src = dy (high res), dst = dx (low res)
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
+    float* d = p.dst + ((size_t)b * p.CtotD + c) * p.H * p.W;
+    const int n = p.H * p.W;
+    for (int q = blockIdx.x * PCH + threadIdx.x; q < min(n, (int)(blockIdx.x + 1) * PCH); q += 256) {
+        const int iy = q / p.W, ix = q - iy * p.W;
+        float wy[7], wx[7];
+        const int oy0 = 2 * iy - 2, ox0 = 2 * ix - 2;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            int i0, ip; float l0, l1;
+            const int oy = oy0 + k, ox = ox0 + k;
+            float w = 0.f;
+            if (oy >= 0 && oy < p.Ho) {
+                src_index(oy, p.sh, p.ac, p.H, i0, ip, l0, l1);
+                w = (i0 == iy ? l0 : 0.f) + (i0 + ip == iy ? l1 : 0.f);
+            }
+            wy[k] = w;
+            w = 0.f;
+            if (ox >= 0 && ox < p.Wo) {
+                src_index(ox, p.sw, p.ac, p.W, i0, ip, l0, l1);
+                w = (i0 == ix ? l0 : 0.f) + (i0 + ip == ix ? l1 : 0.f);
+            }
+            wx[k] = w;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            if (wy[ky] != 0.f) {
+                const float* row = s + (oy0 + ky) * p.Wo + ox0;
+                float ra = 0.f;
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx)
+                    if (wx[kx] != 0.f) ra += wx[kx] * row[kx];
+                acc += wy[ky] * ra;
+            }
+        }
+        d[q] = p.accumulate ? d[q] + acc : acc;
+    }
+}
+
+// ---------------------------------------------------------------- nearest, integer factor
+__global__ __launch_bounds__(256) void nearest_fwd_k(const RsP p) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float* s = p.src + ((size_t)b * p.CtotS + c) * p.H * p.W;
+    float* d = p.dst + ((size_t)b * p.CtotD + c) * p.Ho * p.Wo;
+    const int n = p.Ho * p.Wo;
+    for (int q = blockIdx.x * PCH + threadIdx.x; q < min(n, (int)(blockIdx.x + 1) * PCH); q += 256) {
+        const int oy = q / p.Wo, ox = q - oy * p.Wo;
+        d[q] = s[(oy / p.factor) * p.W + ox / p.factor];
+    }
+}
+__global__ __launch_bounds__(256) void nearest_bwd_k(const RsP p) {   // src = dy (high res), dst = dx (low res)
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
+    float* d = p.dst + ((size_t)b * p.CtotD + c) * p.H * p.W;
+    const int n = p.H * p.W;
+    for (int q = blockIdx.x * PCH + threadIdx.x; q < min(n, (int)(blockIdx.x + 1) * PCH); q += 256) {
+        const int iy = q / p.W, ix = q - iy * p.W;
+        float acc = 0.f;
+        for (int yy = 0; yy < p.factor; ++yy)
+            for (int xx = 0; xx < p.factor; ++xx) acc += s[(iy * p.factor + yy) * p.Wo + ix * p.factor + xx];
+        d[q] = p.accumulate ? d[q] + acc : acc;
+    }
+}
+
+// ---------------------------------------------------------------- spatial mean / broadcast
+// mean over H (dim 2) then over W (dim 3), as the reference does (probabilistic_unet.py:114-115)
+__global__ __launch_bounds__(256) void spatial_mean_fwd_k(const float* __restrict__ x, int C, int Ctot, float* __restrict__ y,
+                                                           int H, int W) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float* s = x + ((size_t)b * Ctot + c) * H * W;
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < H * W; i += 256) v[0] += s[i];
+    uz::block_sum_d<1>(v, sm);
+    if (threadIdx.x == 0) y[(size_t)b * C + c] = (float)(v[0] / H / W);
+}
+__global__ __launch_bounds__(256) void spatial_mean_bwd_k(const float* __restrict__ dy, int C, float* __restrict__ dx, int Ctot,
+                                                           int H, int W, int accumulate) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    float* d = dx + ((size_t)b * Ctot + c) * H * W;
+    const float v = dy[(size_t)b * C + c] / (float)H / (float)W;
+    for (int i = threadIdx.x; i < H * W; i += 256) d[i] = accumulate ? d[i] + v : v;
+}
+__global__ __launch_bounds__(256) void bcast_fwd_k(const float* __restrict__ z, int L, float* __restrict__ y, int Ctot, int HW) {
+    const int l = blockIdx.y, b = blockIdx.z;
+    float* d = y + ((size_t)b * Ctot + l) * HW;
+    const float v = z[(size_t)b * L + l];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) d[i] = v;
+}
+__global__ __launch_bounds__(256) void bcast_bwd_k(const float* __restrict__ dy, int Ctot, int L, float* __restrict__ dz, int HW) {
+    __shared__ double sm[4];
+    const int l = blockIdx.x, b = blockIdx.y;
+    const float* s = dy + ((size_t)b * Ctot + l) * HW;
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < HW; i += 256) v[0] += s[i];
+    uz::block_sum_d<1>(v, sm);
+    if (threadIdx.x == 0) dz[(size_t)b * L + l] = (float)v[0];
+}
+
+int check_dims(const char* op, int C, int N, int H, int W) {
+    UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "%s: empty tensor", op);
+    UZ_REQUIRE(N <= 65535 && C <= 65535, "%s: N or C exceeds grid limits", op);
+    return 0;
+}
+
+}  // namespace
+
+#define RS_LAUNCH(kern, nplane)                                                                      \
+    hipLaunchKernelGGL(kern, dim3(uz::ceil_div((nplane), PCH), C, N), dim3(256), 0, uz::S(stream), p); \
+    return uz::check_launch(#kern)
+
+extern "C" int uz_avgpool2_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W, void* stream) {
+    if (int rc = check_dims("avgpool2_fwd", C, N, H, W)) return rc;
+    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N;
+    p.Ho = H; p.Wo = W; p.H = (H + 1) / 2; p.W = (W + 1) / 2;
+    RS_LAUNCH(avgpool_fwd_k, p.H * p.W);
+}
+extern "C" int uz_avgpool2_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int accumulate, void* stream) {
+    if (int rc = check_dims("avgpool2_bwd", C, N, H, W)) return rc;
+    RsP p = {}; p.src = dy; p.dst = dx; p.C = C; p.CtotS = CtotDy; p.CtotD = CtotDx; p.N = N;
+    p.Ho = H; p.Wo = W; p.H = (H + 1) / 2; p.W = (W + 1) / 2; p.accumulate = accumulate;
+    RS_LAUNCH(avgpool_bwd_k, H * W);
+}
+static void bil_scales(RsP& p) {
+    if (p.ac) { p.sh = p.Ho > 1 ? (float)(p.H - 1) / (float)(p.Ho - 1) : 0.f; p.sw = p.Wo > 1 ? (float)(p.W - 1) / (float)(p.Wo - 1) : 0.f; }
+    else { p.sh = 0.5f; p.sw = 0.5f; }     // scale_factor=2 given: scale = 1/scale_factor
+}
+extern "C" int uz_bilinear2x_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W, int align_corners, void* stream) {
+    if (int rc = check_dims("bilinear2x_fwd", C, N, H, W)) return rc;
+    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N;
+    p.H = H; p.W = W; p.Ho = 2 * H; p.Wo = 2 * W; p.ac = align_corners; bil_scales(p);
+    RS_LAUNCH(bilinear_fwd_k, p.Ho * p.Wo);
+}
+extern "C" int uz_bilinear2x_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int align_corners, int accumulate, void* stream) {
+    if (int rc = check_dims("bilinear2x_bwd", C, N, H, W)) return rc;
+    RsP p = {}; p.src = dy; p.dst = dx; p.C = C; p.CtotS = CtotDy; p.CtotD = CtotDx; p.N = N;
+    p.H = H; p.W = W; p.Ho = 2 * H; p.Wo = 2 * W; p.ac = align_corners; p.accumulate = accumulate; bil_scales(p);
+    RS_LAUNCH(bilinear_bwd_k, H * W);
+}
+extern "C" int uz_nearest_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W, int factor, void* stream) {
+    if (int rc = check_dims("nearest_fwd", C, N, H, W)) return rc;
+    UZ_REQUIRE(factor >= 1, "nearest_fwd: factor must be >= 1");
+    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N;
+    p.H = H; p.W = W; p.Ho = H * factor; p.Wo = W * factor; p.factor = factor;
+    RS_LAUNCH(nearest_fwd_k, p.Ho * p.Wo);
+}
+extern "C" int uz_nearest_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int factor, int accumulate, void* stream) {
+    if (int rc = check_dims("nearest_bwd", C, N, H, W)) return rc;
+    UZ_REQUIRE(factor >= 1, "nearest_bwd: factor must be >= 1");
+    RsP p = {}; p.src = dy; p.dst = dx; p.C = C; p.CtotS = CtotDy; p.CtotD = CtotDx; p.N = N;
+    p.H = H; p.W = W; p.Ho = H * factor; p.Wo = W * factor; p.factor = factor; p.accumulate = accumulate;
+    RS_LAUNCH(nearest_bwd_k, H * W);
+}
+extern "C" int uz_spatial_mean_fwd(const float* x, int C, int CtotX, float* y, int N, int H, int W, void* stream) {
+    if (int rc = check_dims("spatial_mean_fwd", C, N, H, W)) return rc;
+    hipLaunchKernelGGL(spatial_mean_fwd_k, dim3(C, N), dim3(256), 0, uz::S(stream), x, C, CtotX, y, H, W);
+    return uz::check_launch("spatial_mean_fwd_k");
+}
+extern "C" int uz_spatial_mean_bwd(const float* dy, int C, float* dx, int CtotDx, int N, int H, int W, int accumulate, void* stream) {
+    if (int rc = check_dims("spatial_mean_bwd", C, N, H, W)) return rc;
+    hipLaunchKernelGGL(spatial_mean_bwd_k, dim3(C, N), dim3(256), 0, uz::S(stream), dy, C, dx, CtotDx, H, W, accumulate);
+    return uz::check_launch("spatial_mean_bwd_k");
+}
+extern "C" int uz_bcast_channels_fwd(const float* z, int L, float* y, int CtotY, int N, int H, int W, void* stream) {
+    if (int rc = check_dims("bcast_channels_fwd", L, N, H, W)) return rc;
+    hipLaunchKernelGGL(bcast_fwd_k, dim3(uz::ceil_div(H * W, 1024), L, N), dim3(256), 0, uz::S(stream), z, L, y, CtotY, H * W);
+    return uz::check_launch("bcast_fwd_k");
+}
+extern "C" int uz_bcast_channels_bwd(const float* dy, int CtotDy, int L, float* dz, int N, int H, int W, void* stream) {
+    if (int rc = check_dims("bcast_channels_bwd", L, N, H, W)) return rc;
+    hipLaunchKernelGGL(bcast_bwd_k, dim3(L, N), dim3(256), 0, uz::S(stream), dy, CtotDy, L, dz, H * W);
+    return uz::check_launch("bcast_bwd_k");
+}

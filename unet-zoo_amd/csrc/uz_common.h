@@ -1,0 +1,58 @@
+// Shared helpers for the libuz_hip.so kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "uz_api.h"
+
+namespace uz {
+
+void set_error(const char* fmt, ...);
+int  fail(const char* fmt, ...);          // set_error + return -1
+int  check_launch(const char* what);      // hipGetLastError -> status
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (each with a
+// private L2).  Remap so that every XCD walks a contiguous chunk of the work list: blocks that
+// share operand panels then hit the same L2.  Bijective for any nwg (cdna guide 5.5 T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum of NV doubles (blockDim.x == 256).  Result valid in thread 0.
+template <int NV>
+__device__ __forceinline__ void block_sum_d(double (&v)[NV], double* smem /* >= 4*NV */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum_d(v[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) smem[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = smem[i] + smem[NV + i] + smem[2 * NV + i] + smem[3 * NV + i];
+    }
+}
+
+}  // namespace uz
+
+#define UZ_REQUIRE(cond, ...) do { if (!(cond)) return uz::fail(__VA_ARGS__); } while (0)
