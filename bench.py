@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one PHiSeg-7/5 training step (forward + loss + backward +
+gradient all-reduce + Adam) at 128x128, batch 32 per GPU, fp32, on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  Workload = BASELINE.json
+configs[3] (PHiSeg 7 resolution / 5 latent levels, filters 32,64,128,192,192,192,192), synthetic
+LIDC-like inputs, random-init weights, inputs resident in HBM before the timed region.
+
+Extra objects on the line:
+  roofline      step-level fp32-MFMA roofline exactly as BASELINE.md section 2 defines it
+                (achieved TFLOP/s = images/s x 100.36 GFLOP/image; peak 157.3 TFLOP/s), plus
+                `dominant_kernel`: the heaviest kernel family measured live with HIP events on the
+                launch stream (algorithmic FLOPs of its launches / their summed duration), and
+                `families`: the same for every kernel family of the step.
+  cpu_baseline  the CPU oracle (a functional torch restatement of the reference graph = "port")
+                timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FILTERS = [32, 64, 128, 192, 192, 192, 192]
+GFLOP_PER_IMAGE = 100.36          # BASELINE.md section 2 (fwd+bwd, measured from the reference graph)
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md chip-level parameters
+GB_PER_IMAGE_UNFUSED = 1.077
+GB_PER_STEP_FIXED = 0.294
+HBM_PEAK_GBS = 8000.0
+
+
+def conv_flops(op, codes):
+    """Algorithmic FLOPs of one conv-family tape op (2 * N*H*W * Cin*Cout*k*k)."""
+    i = op["i"]
+    c = op["code"]
+    if c == "UZ_OP_CONV_FWD":
+        cin, cout, n, h, w, ks = i[0], i[2], i[4], i[5], i[6], i[7]
+    elif c == "UZ_OP_CONV_BWD_DATA":
+        cout, cin, n, h, w, ks = i[0], i[2], i[4], i[5], i[6], i[7]
+    elif c == "UZ_OP_CONV_BWD_WEIGHT":
+        cin, cout, n, h, w, ks = i[0], i[2], i[4], i[5], i[6], i[7]
+    else:
+        return 0.0
+    return 2.0 * n * h * w * cin * cout * ks * ks
+
+
+def op_bytes(op, plan):
+    """Algorithmic HBM bytes of a streaming (non-conv) op: every tensor argument read or written once."""
+    c, i = op["code"], op["i"]
+    f4 = 4.0
+    if c == "UZ_OP_BN_RELU_FWD":
+        C, N, H, W, training = i[0], i[3], i[4], i[5], i[6]
+        big = N * H * W > 8192
+        return f4 * C * N * H * W * ((3 if big else 2) if training else 2)
+    if c == "UZ_OP_BN_RELU_BWD":
+        C, N, H, W = i[1], i[4], i[5], i[6]
+        big = N * H * W > 8192
+        return f4 * C * N * H * W * (5 if big else 3)
+    if c in ("UZ_OP_AVGPOOL_FWD", "UZ_OP_AVGPOOL_BWD"):
+        C, N, H, W = i[0], i[3], i[4], i[5]
+        return f4 * C * N * H * W * 1.25
+    if c in ("UZ_OP_BILINEAR_FWD", "UZ_OP_BILINEAR_BWD"):
+        C, N, H, W = i[0], i[3], i[4], i[5]
+        return f4 * C * N * H * W * 5
+    if c in ("UZ_OP_NEAREST_FWD", "UZ_OP_NEAREST_BWD"):
+        C, N, H, W, f = i[0], i[3], i[4], i[5], i[6]
+        return f4 * C * N * H * W * (1 + f * f)
+    return 0.0
+
+
+FAMILY = {"UZ_OP_CONV_FWD": "conv_fwd_mfma", "UZ_OP_CONV_BWD_DATA": "conv_dgrad_mfma", "UZ_OP_CONV_BWD_WEIGHT": "conv_wgrad_mfma",
+          "UZ_OP_BN_RELU_FWD": "bn_relu_fwd", "UZ_OP_BN_RELU_BWD": "bn_relu_bwd",
+          "UZ_OP_AVGPOOL_FWD": "resample", "UZ_OP_AVGPOOL_BWD": "resample", "UZ_OP_BILINEAR_FWD": "resample",
+          "UZ_OP_BILINEAR_BWD": "resample", "UZ_OP_NEAREST_FWD": "resample", "UZ_OP_NEAREST_BWD": "resample"}
+
+
+def profile_families(net, plan, reps=3):
+    """Live per-family timing: replay the fwd / bwd tapes one op at a time, each bracketed by HIP
+    events on the launch stream (torch.cuda.Event records on torch's current stream, which IS the
+    stream the tape is launched on)."""
+    import ctypes as C
+    from unet_zoo_amd import _ffi
+    L = _ffi.lib()
+    stream = C.c_void_p(net._stream())
+    fam = {}
+    for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
+        arr, n = plan.tapes[which]
+        for k in range(n):
+            name = FAMILY.get(ops[k]["code"], "other")
+            one = (type(arr[0]) * 1)(arr[k])
+            best = None
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _ffi.check(L.uz_run_tape(one, 1, stream), "profile op")
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                best = ms if best is None else min(best, ms)
+            d = fam.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            d["ms"] += best
+            d["flops"] += conv_flops(ops[k], None)
+            d["bytes"] += op_bytes(ops[k], plan)
+            d["launches"] += 1
+    return fam
+
+
+def cpu_baseline(batch, steps):
+    """CPU oracle timed on the host cores (bounded sample).  Only the baseline leg imports oracle/."""
+    import oracle
+    from unet_zoo_amd.models.phiseg import phiseg_spec
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = oracle.deterministic_state_dict(phiseg_spec(1, 2, FILTERS), seed=3)
+    leaves = {}
+    for k, v in sd.items():
+        t = v.clone()
+        if t.dtype.is_floating_point and "running_" not in k:
+            t.requires_grad_(True)
+        leaves[k] = t
+    shapes = oracle.phiseg_eps_shapes(batch, 128, 128)
+    state, times = {}, []
+    for step in range(steps + 1):
+        x, mask, eps = oracle.synthetic_batch(batch, 128, 128, seed=100 + step, eps_shapes=shapes + shapes)
+        e = [torch.from_numpy(a) for a in eps]
+        t0 = time.perf_counter()
+        out = oracle.phiseg_forward(leaves, torch.from_numpy(x), torch.from_numpy(mask), dict(posterior=e[:5], prior=e[5:]))
+        total, _ = oracle.phiseg_loss(out, torch.from_numpy(mask))
+        for v in leaves.values():
+            v.grad = None
+        total.backward()
+        params = {k: v for k, v in leaves.items() if v.requires_grad}
+        new = oracle.adam_reference_step(params, {k: v.grad for k, v in params.items()}, state)
+        for k, v in new.items():
+            leaves[k] = v.requires_grad_(True)
+        if step > 0:
+            times.append(time.perf_counter() - t0)
+    sec = sum(times) / len(times)
+    return dict(value=round(batch / sec, 3), unit="images/s", cores=cores, kind="port",
+                sample=f"CPU oracle (functional torch fp32 restatement of the reference graph), PHiSeg 7/5 128x128 batch {batch}, "
+                       f"{steps} timed steps after 1 warm-up, fwd+loss+bwd+Adam, {cores} threads, {sec:.2f} s/step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (weak scaling)")
+    ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-family HIP-event pass")
+    ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from unet_zoo_amd.models.phiseg import PHISeg
+    from unet_zoo_amd.synthetic import synthetic_batch
+    from unet_zoo_amd.optim import FusedAdam
+
+    torch.manual_seed(1234)          # same initial weights on every rank (DP replicas)
+    net = PHISeg(input_channels=1, num_classes=2, num_filters=FILTERS, latent_levels=5, image_size=(1, 128, 128))
+    net.train()
+    if world > 1:
+        dist.broadcast(net._ptab.pflat, src=0)
+        net.set_data_parallel(True)
+    if not args.no_graphs:
+        net.enable_graphs(True)
+    opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)        # train_model.py:49
+    x, mask, _ = synthetic_batch(args.batch, 128, 128, seed=20201004 + rank)
+    dev = torch.device("cuda", local_rank)
+    x, mask = torch.from_numpy(x).to(dev), torch.from_numpy(mask).to(dev)
+
+    def step():
+        net.forward(x, mask, training=True)
+        loss = net.loss(mask)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(max(args.warmup, 3 if not args.no_graphs else 1)):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        ips = args.batch * world * args.steps / elapsed
+        per_gpu = ips / world
+        roof = dict(bound="mfma", achieved=round(per_gpu * GFLOP_PER_IMAGE / 1e3, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(per_gpu * GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                    hbm_fraction=round((per_gpu * GB_PER_IMAGE_UNFUSED + (per_gpu / args.batch) * GB_PER_STEP_FIXED) / HBM_PEAK_GBS, 4),
+                    note="step-level, per GPU: images/s x 100.36 GFLOP/image over the 157.3 TFLOP/s fp32-MFMA peak (BASELINE.md section 2); "
+                         "hbm_fraction uses the unfused-graph bytes and cannot exceed ~0.21 in fp32")
+        if not args.no_profile and world == 1:
+            fam = profile_families(net, net._cur)
+            fams = {}
+            for k, d in fam.items():
+                e = dict(ms_per_step=round(d["ms"], 3), launches=d["launches"])
+                if d["flops"]:
+                    e["tflops"] = round(d["flops"] / d["ms"] / 1e9, 2)
+                    e["frac_of_mfma_peak"] = round(d["flops"] / d["ms"] / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)
+                elif d["bytes"]:
+                    e["gbs"] = round(d["bytes"] / d["ms"] / 1e6, 1)
+                    e["frac_of_hbm_peak"] = round(d["bytes"] / d["ms"] / 1e6 / HBM_PEAK_GBS, 4)
+                fams[k] = e
+            dom = max((k for k in fam if fam[k]["flops"]), key=lambda k: fam[k]["ms"])
+            roof["families"] = fams
+            roof["dominant_kernel"] = dict(name=dom, **fams[dom])
+        line = dict(metric="images/sec fwd+bwd PHiSeg-7 128x128 bs32", value=round(ips, 2), unit="images/s", n_gpus=world,
+                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
+                    vs_baseline=None, dtype="f32", data="synthetic",
+                    config=dict(workload="PHiSeg 7 resolution / 5 latent levels, filters 32-64-128-192x4, 1x128x128, fwd+loss+bwd+Adam",
+                                batch_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f"dp{world}",
+                                graphs=not args.no_graphs, final_loss=final_loss),
+                    roofline=roof)
+        if not args.skip_cpu and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, 2)
+        print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

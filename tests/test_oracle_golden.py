@@ -62,7 +62,7 @@ def test_residual_multinoulli_matches_reference():
 def _phiseg_inputs(arrays, batch, hw, step):
     shapes = oracle.phiseg_eps_shapes(batch, hw, hw)
     x, mask, eps = oracle.synthetic_batch(batch, hw, hw, seed=20201004 + step, eps_shapes=shapes + shapes)
-    if step == 0:
+    if step == 0 and "x" in arrays:
         assert np.array_equal(x, arrays["x"]) and np.array_equal(mask, arrays["mask"])
         for i in range(10):
             assert np.array_equal(eps[i], arrays[f"eps{i}"])
@@ -130,8 +130,9 @@ def test_phiseg_small_eval_argmax_bit_exact():
 
 
 # ----------------------------------------------------------------------------- PHiSeg full-size digest (G3)
-def test_phiseg_full_digest():
-    arrays, meta = G.load("phiseg_full_digest")
+@pytest.mark.parametrize("fixture", ["phiseg_full_digest", "phiseg_full_b32_digest"])
+def test_phiseg_full_digest(fixture):
+    arrays, meta = G.load(fixture)
     sd = G.leaves(oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"]))
     x, mask, eps = _phiseg_inputs(arrays, meta["batch"], meta["hw"], 0)
     out = oracle.phiseg_forward(sd, x, mask, eps, training=True, bn_train=True)

@@ -114,7 +114,7 @@ def grads_of(net):
 
 
 # --------------------------------------------------------------------------- #
-def phiseg_case(name, filters, hw, batch, n_steps, store_full, seed):
+def phiseg_case(name, filters, hw, batch, n_steps, store_full, seed, store_inputs=True):
     net = PHISeg(input_channels=1, num_classes=2, num_filters=filters, latent_levels=5,
                  image_size=(1, hw, hw))
     spec = kinds_for(net.state_dict())
@@ -140,9 +140,10 @@ def phiseg_case(name, filters, hw, batch, n_steps, store_full, seed):
                   none_grads=[k for k, v in g.items() if v is None],
                   kl_alias=float(net.kl_divergence_loss), recon_alias=float(net.reconstruction_loss))
         if step == 0:
-            arrays["x"], arrays["mask"] = x, mask
-            for i, e in enumerate(eps):
-                arrays[f"eps{i}"] = e
+            if store_inputs:
+                arrays["x"], arrays["mask"] = x, mask
+                for i, e in enumerate(eps):
+                    arrays[f"eps{i}"] = e
             if store_full:
                 for l in range(5):
                     arrays[f"s{l}"] = npf(s_list[l])
@@ -318,6 +319,10 @@ def op_cases():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "b32":
+        # BASELINE config 4 exactly (batch 32): digests only, inputs are regenerated from the seed
+        phiseg_case("phiseg_full_b32_digest", [32, 64, 128, 192, 192, 192, 192], 128, 32, 1, False, 1238, store_inputs=False)
+        sys.exit(0)
     op_cases()
     phiseg_case("phiseg_small", [4, 8, 8, 8, 8, 8, 8], 64, 2, 3, True, 1234)
     unet_case("unet_small", [4, 8, 8, 8], 2, 3, 1235)
