@@ -43,17 +43,24 @@ int         uz_device_info(int* n_cu, char* name, int name_cap);
  * phiseg.py:95-96,281-284, probabilistic_unet.py:95,156-163.  w is the PyTorch
  * parameter itself, layout [Cout][Cin][ks][ks]; bias may be NULL.
  * One fp32-MFMA implicit-GEMM kernel family serves every layer, including the 1..3-channel
- * image / latent inputs and the 2-class 1x1 heads (channel tiles are zero padded in LDS). */
+ * image / latent inputs and the 2-class 1x1 heads (channel tiles are zero padded in LDS).
+ * Deep, low-resolution levels (2x2 .. 16x16) cannot fill 256 CUs with output tiles alone: with a
+ * workspace of uz_conv_workspace() bytes the input-channel loop is split over workgroups and summed
+ * in a fixed order (bitwise reproducible); workspace may be NULL (no split, slower, same result up
+ * to summation order).                                                                          */
+size_t uz_conv_workspace(int Cin, int Cout, int N, int H, int W, int ks);   /* covers fwd and bwd_data */
 int uz_conv_fwd(const float* x, int Cin, int CinTot,
                 const float* w, const float* bias,
                 float* y, int Cout, int CoutTot,
-                int N, int H, int W, int ks, int relu, void* stream);
+                int N, int H, int W, int ks, int relu,
+                void* workspace, size_t workspace_bytes, void* stream);
 /* autograd of the above w.r.t. its input (aten::convolution_backward, input part):
  * dx[b,ci] (+)= sum_co sum_tap dy[b,co,.] * w[co,ci,flip(tap)]                 */
 int uz_conv_bwd_data(const float* dy, int Cout, int CoutTot,
                      const float* w,
                      float* dx, int Cin, int CinTot,
-                     int N, int H, int W, int ks, int accumulate, void* stream);
+                     int N, int H, int W, int ks, int accumulate,
+                     void* workspace, size_t workspace_bytes, void* stream);
 /* autograd w.r.t. the weight: dw[co,ci,tap] = sum_{b,y,x} dy * x_shifted.
  * Deterministic split-K: partial slabs in `workspace` (uz_conv_bwd_weight_workspace
  * bytes), then an ordered reduction.  db (nullable) = sum_{b,y,x} dy.           */

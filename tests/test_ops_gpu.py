@@ -55,25 +55,31 @@ def test_conv_fwd_bwd(N, Cin, Cout, H, W, ks):
     ybuf = torch.full((N, Cout + 4, H, W), float("nan"), device=g.dev())
     yv = ybuf[:, 2:]
     wd, bd = w.to(g.dev()), b.to(g.dev())
-    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, yv, Cout, Cout + 4, N, H, W, ks, 0)
+    from unet_zoo_amd import _ffi
+    cws_bytes = _ffi.lib().uz_conv_workspace(Cin, Cout, N, H, W, ks)
+    cws = torch.empty(cws_bytes // 4 + 16, device=g.dev())
+    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, yv, Cout, Cout + 4, N, H, W, ks, 0, cws, cws_bytes)
     assert g.relerr(ybuf[:, 2:2 + Cout], yr) <= TOL
     assert torch.isnan(ybuf[:, :2]).all() and torch.isnan(ybuf[:, 2 + Cout:]).all()     # neighbours untouched
 
     # fused ReLU epilogue
     y2 = torch.empty(N, Cout, H, W, device=g.dev())
-    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, y2, Cout, Cout, N, H, W, ks, 1)
+    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, y2, Cout, Cout, N, H, W, ks, 1, cws, cws_bytes)
     assert g.relerr(y2, F.relu(yr)) <= TOL
+    # without a workspace the input-channel loop is not split: same result up to summation order
+    y3 = torch.empty(N, Cout, H, W, device=g.dev())
+    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, y3, Cout, Cout, N, H, W, ks, 1, None, 0)
+    assert g.relerr(y3, F.relu(yr)) <= TOL
 
     # data gradient, overwrite then accumulate
     dyd = dy.to(g.dev())
     dx = torch.full((N, Cin, H, W), float("nan"), device=g.dev())
-    g.call("uz_conv_bwd_data", dyd, Cout, Cout, wd, dx, Cin, Cin, N, H, W, ks, 0)
+    g.call("uz_conv_bwd_data", dyd, Cout, Cout, wd, dx, Cin, Cin, N, H, W, ks, 0, cws, cws_bytes)
     assert g.relerr(dx, xr.grad) <= TOL
-    g.call("uz_conv_bwd_data", dyd, Cout, Cout, wd, dx, Cin, Cin, N, H, W, ks, 1)
+    g.call("uz_conv_bwd_data", dyd, Cout, Cout, wd, dx, Cin, Cin, N, H, W, ks, 1, cws, cws_bytes)
     assert g.relerr(dx, 2 * xr.grad) <= TOL
 
     # weight + bias gradient (deterministic split-K): run twice, must be bitwise identical
-    from unet_zoo_amd import _ffi
     ws_bytes = _ffi.lib().uz_conv_bwd_weight_workspace(Cin, Cout, N, H, W, ks)
     ws = torch.empty(ws_bytes // 4 + 16, device=g.dev())
     dw = torch.full_like(wd, float("nan"))
@@ -97,7 +103,7 @@ def test_conv_full_size_linearity():
     w = torch.randn(Cout, Cin, 3, 3, device=g.dev()) * 0.05
     out = [torch.empty(N, Cout, H, W, device=g.dev()) for _ in range(3)]
     for xin, o in zip((x1, x2, x1 + 2 * x2), out):
-        g.call("uz_conv_fwd", xin, Cin, Cin, w, None, o, Cout, Cout, N, H, W, 3, 0)
+        g.call("uz_conv_fwd", xin, Cin, Cin, w, None, o, Cout, Cout, N, H, W, 3, 0, None, 0)
     assert g.relerr(out[2], out[0] + 2 * out[1]) <= 1e-5
     ref = F.conv2d(x1[5:7].cpu(), w.cpu(), None, padding=1)
     assert g.relerr(out[0][5:7], ref) <= TOL

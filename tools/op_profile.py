@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-op timing of one PHiSeg step (HIP events around each tape op): which layers cost what."""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import FILTERS, conv_flops, op_bytes, FAMILY
+from unet_zoo_amd import _ffi
+from unet_zoo_amd.models.phiseg import PHISeg
+from unet_zoo_amd.synthetic import synthetic_batch
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+net = PHISeg(1, 2, FILTERS, image_size=(1, 128, 128)); net.train()
+x, m, _ = synthetic_batch(B)
+x, m = torch.from_numpy(x).cuda(), torch.from_numpy(m).cuda()
+for _ in range(2):
+    net.forward(x, m); l = net.loss(m); l.backward()
+plan = net._cur
+L = _ffi.lib(); st = C.c_void_p(net._stream())
+rows = []
+for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
+    arr, n = plan.tapes[which]
+    for k in range(n):
+        one = (type(arr[0]) * 1)(arr[k]); best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); _ffi.check(L.uz_run_tape(one, 1, st), "op"); e1.record(); e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        o = ops[k]
+        rows.append((best, which, o["code"].replace("UZ_OP_", ""), o["i"][:9], conv_flops(o, None), op_bytes(o, plan)))
+tot = sum(r[0] for r in rows)
+print(f"total {tot:.2f} ms over {len(rows)} ops")
+agg = {}
+for r in rows:
+    key = (r[2], tuple(r[3]))
+    a = agg.setdefault(key, [0.0, 0, r[4], r[5]]); a[0] += r[0]; a[1] += 1
+for (code, i), (ms, cnt, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+    extra = f"{fl / (ms / cnt) / 1e9:7.1f} TF/s" if fl else (f"{by / (ms / cnt) / 1e6:7.0f} GB/s" if by else "")
+    print(f"{ms:8.3f} ms  x{cnt:<3d} {ms / cnt * 1e3:9.1f} us  {code:18s} {list(i)}  {extra}")

@@ -198,9 +198,11 @@ class Plan:
         cout = y.C
         cin = x.C
         wextra = wrow0 * cin * ks * ks
+        ws = self.L.uz_conv_workspace(cin, cout, x.N, x.H, x.W, ks)
+        self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
         self._emit(self.target, "UZ_OP_CONV_FWD",
-                   p=[x, self.P(wkey, wextra), self.P(bkey, wrow0) if bkey else None, y],
-                   i=[cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, ks, relu])
+                   p=[x, self.P(wkey, wextra), self.P(bkey, wrow0) if bkey else None, y, ("scratch", "wgrad")],
+                   i=[cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, ks, relu], n=ws)
 
     def _conv_bwd(self, x, wkey, gy, ks, db_key=None, wrow0=0):
         """Weight gradient (+ optional bias gradient) and, when the input carries a gradient,
@@ -214,9 +216,11 @@ class Plan:
                    i=[cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, ks], n=ws)
         if x.buf.requires_grad:
             acc = self._claim(x)
+            ws2 = self.L.uz_conv_workspace(cin, cout, x.N, x.H, x.W, ks)
+            self.scratch["wgrad"] = max(self.scratch["wgrad"], ws2)
             self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
-                       p=[gy, self.P(wkey, wextra), self.gview(x)],
-                       i=[cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, ks, acc])
+                       p=[gy, self.P(wkey, wextra), self.gview(x), ("scratch", "wgrad")],
+                       i=[cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, ks, acc], n=ws2)
 
     def _gy_scratch(self, like):
         self.scratch["gy"] = max(self.scratch["gy"], like.N * like.C * like.H * like.W)

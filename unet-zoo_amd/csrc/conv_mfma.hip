@@ -33,6 +33,8 @@ struct ConvP {
     int tilesX, tilesY, nCoTiles;
     int PW, PSI, PS;                  // patch row stride, patch floats per image, per channel
     int relu, accumulate;
+    int ksplit, cps;                  // split-K over input-channel chunks: number of splits, chunks per split
+    float* slab;                      // [ksplit][N][Cout][H][W] partial sums when ksplit > 1
 };
 
 template <int KS, int MSUB, int JMAX, bool DGRAD>
@@ -46,7 +48,8 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
     const int BUF = WSZ + CK * p.PS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);
+    const int wid0 = uz::xcd_remap(blockIdx.x, gridDim.x);
+    const int ksp = wid0 % p.ksplit, wid = wid0 / p.ksplit;
     const int coT = wid % p.nCoTiles, pixT = wid / p.nCoTiles;
     const int txi = pixT % p.tilesX, t2 = pixT / p.tilesX;
     const int tyi = t2 % p.tilesY, tbi = t2 / p.tilesY;
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
         const int tx = pp & (p.TW - 1), ty = (pp >> p.lgTW) & (p.TH - 1), tb = pp >> (p.lgTW + p.lgTH);
         const bool v = pp < npix && (b0 + tb) < p.N && (y0 + ty) < p.H && (x0 + tx) < p.W;
         poff[n] = v ? (tb * p.PSI + ty * p.PW + tx + h * p.PS) : (h * p.PS);
-        oidx[n] = v ? ((b0 + tb) * p.CoutTot * p.HW + (y0 + ty) * p.W + (x0 + tx)) : -1;
+        oidx[n] = v ? ((b0 + tb) * (p.ksplit > 1 ? p.Cout : p.CoutTot) * p.HW + (y0 + ty) * p.W + (x0 + tx)) : -1;
     }
 
     f32x16 acc[MSUB][NSUB];
@@ -143,11 +146,13 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
         }
     };
 
-    const int nChunks = (p.Cin + CK - 1) / CK;
-    gload(0);
-    lstore(0);
+    const int nChunksAll = (p.Cin + CK - 1) / CK;
+    const int cBeg = ksp * p.cps;
+    const int nChunks = min(nChunksAll, cBeg + p.cps);
+    gload(cBeg);
+    lstore(cBeg & 1);
     __syncthreads();
-    for (int c = 0; c < nChunks; ++c) {
+    for (int c = cBeg; c < nChunks; ++c) {
         const bool more = (c + 1) < nChunks;
         if (more) gload(c + 1);
         const float* Wl = lds + (c & 1) * BUF;
@@ -174,6 +179,22 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
         __syncthreads();
     }
 
+    // ---- split-K: raw partial sums to this split's slab; bias / accumulate / ReLU happen in the reduce
+    if (p.ksplit > 1) {
+        float* base = p.slab + (size_t)ksp * p.N * p.Cout * p.HW;
+#pragma unroll
+        for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Cout) {
+#pragma unroll
+                    for (int n = 0; n < NSUB; ++n)
+                        if (oidx[n] >= 0) base[(size_t)oidx[n] + (size_t)co * p.HW] = acc[m][n][r];
+                }
+            }
+        return;
+    }
     // ---- epilogue: bias, optional accumulate / ReLU, coalesced NCHW stores
 #pragma unroll
     for (int m = 0; m < MSUB; ++m) {
@@ -197,7 +218,35 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
     }
 }
 
+// y[b,co,p] = (accumulate ? y : 0) + bias[co] + sum_s slab[s][b,co,p]  (fixed order), optional ReLU
+__global__ __launch_bounds__(256) void conv_splitk_reduce(const float* __restrict__ slab, int ksplit, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int Cout, int CoutTot, int N, int HW, int relu, int accumulate) {
+    const size_t n = (size_t)N * Cout * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % HW);
+        const int co = (int)((i / HW) % Cout);
+        const int b = (int)(i / ((size_t)HW * Cout));
+        float s = bias ? bias[co] : 0.f;
+        for (int k = 0; k < ksplit; ++k) s += slab[(size_t)k * n + i];
+        float* dst = y + ((size_t)b * CoutTot + co) * HW + q;
+        if (accumulate) s += *dst;
+        if (relu) s = fmaxf(s, 0.f);
+        *dst = s;
+    }
+}
+
 struct Geom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB; };
+
+// split the input-channel loop over several workgroups when the output grid alone cannot fill
+// the 256 CUs (deep, small-resolution levels: 2x2 ... 16x16 pixels)
+void pick_split(long long base_grid, int nChunks, int& ksplit, int& cps) {
+    ksplit = 1; cps = nChunks;
+    if (base_grid >= 256 || nChunks <= 1) return;
+    long long want = (512 + base_grid - 1) / base_grid;
+    if (want > nChunks) want = nChunks;
+    cps = (int)((nChunks + want - 1) / want);
+    ksplit = (nChunks + cps - 1) / cps;
+}
 
 Geom pick_geom(int N, int H, int W, int halo) {
     Geom g;
@@ -240,9 +289,17 @@ int launch_ks(const ConvP& p, int msub, int jmax, int grid, size_t smem, hipStre
 namespace uz {
 
 // x: input view (Kc channels), y: output view (Mc channels); w = PyTorch [Cout][Cin][ks][ks] parameter.
+size_t conv_workspace(int Kc, int Mc, int N, int H, int W, int ks) {
+    const Geom g = pick_geom(N, H, W, ks / 2);
+    const int cot = Mc <= 32 ? 32 : 64;
+    int ksplit, cps;
+    pick_split((long long)g.tilesX * g.tilesY * g.tilesB * ceil_div(Mc, cot), ceil_div(Kc, CK), ksplit, cps);
+    return ksplit > 1 ? (size_t)ksplit * N * Mc * H * W * sizeof(float) : 0;
+}
+
 int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
               float* y, int Mc, int McTot, int N, int H, int W, int ks, int dgrad, int relu, int accumulate,
-              hipStream_t st) {
+              void* workspace, size_t workspace_bytes, hipStream_t st) {
     UZ_REQUIRE(ks == 1 || ks == 3, "conv: kernel size %d unsupported (1 or 3)", ks);
     UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Kc > 0 && Mc > 0, "conv: empty tensor");
     UZ_REQUIRE(H <= 4096 && W <= 4096, "conv: spatial size too large");
@@ -261,20 +318,39 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     const int jmax = g.PS <= 512 ? 2 : 4;
     const int kk = ks * ks;
     const size_t smem = 2 * (size_t)(kk * CK * (cot + 1) + CK * g.PS) * sizeof(float);
-    const long long grid = (long long)g.tilesX * g.tilesY * g.tilesB * p.nCoTiles;
+    const long long base_grid = (long long)g.tilesX * g.tilesY * g.tilesB * p.nCoTiles;
+    pick_split(base_grid, ceil_div(Kc, CK), p.ksplit, p.cps);
+    const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * N * Mc * H * W * sizeof(float) : 0;
+    if (p.ksplit > 1 && (!workspace || workspace_bytes < need)) { p.ksplit = 1; p.cps = ceil_div(Kc, CK); }   // no workspace: stay unsplit
+    p.slab = static_cast<float*>(workspace);
+    const long long grid = base_grid * p.ksplit;
     UZ_REQUIRE(grid < (1ll << 31), "conv: grid too large");
-    if (ks == 3) return dgrad ? launch_ks<3, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<3, false>(p, msub, jmax, (int)grid, smem, st);
-    return dgrad ? launch_ks<1, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<1, false>(p, msub, jmax, (int)grid, smem, st);
+    int rc;
+    if (ks == 3) rc = dgrad ? launch_ks<3, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<3, false>(p, msub, jmax, (int)grid, smem, st);
+    else rc = dgrad ? launch_ks<1, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<1, false>(p, msub, jmax, (int)grid, smem, st);
+    if (rc || p.ksplit == 1) return rc;
+    const size_t n = (size_t)N * Mc * H * W;
+    int rgrid = (int)((n + 255) / 256);
+    if (rgrid > 2048) rgrid = 2048;
+    hipLaunchKernelGGL(conv_splitk_reduce, dim3(rgrid), dim3(256), 0, st, p.slab, p.ksplit, bias, y, Mc, McTot, N, H * W, relu, accumulate);
+    return check_launch("conv_splitk_reduce");
 }
 
 }  // namespace uz
 
+extern "C" size_t uz_conv_workspace(int Cin, int Cout, int N, int H, int W, int ks) {
+    const size_t a = uz::conv_workspace(Cin, Cout, N, H, W, ks), b = uz::conv_workspace(Cout, Cin, N, H, W, ks);
+    return a > b ? a : b;
+}
+
 extern "C" int uz_conv_fwd(const float* x, int Cin, int CinTot, const float* w, const float* bias,
-                           float* y, int Cout, int CoutTot, int N, int H, int W, int ks, int relu, void* stream) {
-    return uz::conv_mfma(x, Cin, CinTot, w, Cin, bias, y, Cout, CoutTot, N, H, W, ks, 0, relu, 0, uz::S(stream));
+                           float* y, int Cout, int CoutTot, int N, int H, int W, int ks, int relu,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    return uz::conv_mfma(x, Cin, CinTot, w, Cin, bias, y, Cout, CoutTot, N, H, W, ks, 0, relu, 0, workspace, workspace_bytes, uz::S(stream));
 }
 
 extern "C" int uz_conv_bwd_data(const float* dy, int Cout, int CoutTot, const float* w,
-                                float* dx, int Cin, int CinTot, int N, int H, int W, int ks, int accumulate, void* stream) {
-    return uz::conv_mfma(dy, Cout, CoutTot, w, Cin, nullptr, dx, Cin, CinTot, N, H, W, ks, 1, 0, accumulate, uz::S(stream));
+                                float* dx, int Cin, int CinTot, int N, int H, int W, int ks, int accumulate,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    return uz::conv_mfma(dy, Cout, CoutTot, w, Cin, nullptr, dx, Cin, CinTot, N, H, W, ks, 1, 0, accumulate, workspace, workspace_bytes, uz::S(stream));
 }

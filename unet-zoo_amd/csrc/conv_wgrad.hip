@@ -4,19 +4,21 @@
 //   dW[co][ci][tap] = sum_{b,y,x} dY[b,co,y,x] * X[b,ci,y+dy-1,x+dx-1]
 //
 // GEMM view: M = co (A operand, lane&31 = co), N = ci (B operand, lane&31 = ci), K = pixels
-// (two pixels per v_mfma_f32_32x32x2_f32).  A wave owns a 32co x 32ci block for ALL nine taps
-// (9 x 16 accumulator registers): one dY fragment read feeds nine MFMAs whose B fragments are the
-// same haloed X patch at nine constant LDS offsets.  A workgroup (2x2 waves) owns 64co x 64ci and
-// walks a strided subset of the 64-pixel tiles (deterministic split-K): it writes its partial sum
-// to a slab, and an ordered second kernel adds the slabs into dW (bitwise reproducible; no float
-// atomics).  LDS rows are padded to an odd stride so that the 32 channel-lanes of a fragment read
-// hit 32 different banks.
+// (two pixels per v_mfma_f32_32x32x2_f32).  A wave owns a 32co x 32ci block for five (or four) of
+// the nine taps (5 x 16 accumulator registers): one dY fragment read feeds five MFMAs whose B
+// fragments are the same haloed X patch at constant LDS offsets.  A workgroup is 8 waves:
+// (co sub-tile) x (ci sub-tile) x (tap group) x (pixel split); it owns up to 64co x 64ci and walks
+// a strided subset of the 64-pixel tiles (deterministic split-K).  The next tile's global loads are
+// issued into registers before the MFMA loop of the current tile and written to LDS after it.
+// Partial sums go to slabs; an ordered second kernel adds them into dW (bitwise reproducible; no
+// float atomics).  LDS rows are padded to an odd stride so that the 32 channel-lanes of a fragment
+// read hit 32 different banks.
+#include <type_traits>
 #include "uz_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int CT = 64;   // co and ci tile of a workgroup
 
 struct WgP {
     const float* x; const float* dy; float* slab;
@@ -28,120 +30,303 @@ struct WgP {
     int nCoT, nCiT;
 };
 
-template <int KS>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
-    constexpr int KK = KS * KS, HALO = KS / 2;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* dYl = lds;                               // [CT][PTP]
-    float* Xl = dYl + CT * p.PTP;                   // [CT][PSP] (+ slack)
-    int* tabOff = reinterpret_cast<int*>(Xl + CT * p.PSP + 64);
-    int* tabCrd = tabOff + p.PS;
+constexpr int NT = 512;   // threads per workgroup (8 waves)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+// WM x WN waves tile the (co, ci) block of 32*WM x 32*WN; NTG tap groups split the 3x3 taps (5 + 4);
+// the remaining WK = 8/(WM*WN*NTG) waves split the pixels of every tile.  Every (tap group is part
+// of the same slab, every pixel split writes its own slab.  PF: prefetch the next tile's global
+// loads into registers before the MFMA loop of the current tile (needs CIT*PS <= XR*512).
+template <int KS, int WM, int WN, bool PF>
+__global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgP p) {
+    constexpr int KK = KS * KS, HALO = KS / 2;
+    constexpr int NTG = KK == 9 ? 2 : 1, TPG = KK == 9 ? 5 : 1;      // tap groups, taps per group (max)
+    constexpr int COT = 32 * WM, CIT = 32 * WN, WK = 8 / (WM * WN * NTG);
+    constexpr int DYR = COT / 8;          // dY values staged per thread and tile
+    constexpr int XR = PF ? 18 : 1;       // X values staged per thread and tile (upper bound)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* dYl = lds;                               // [COT][PTP]
+    float* Xl = dYl + COT * p.PTP;                  // [CIT][PSP] (+ slack)
+    int* tab = reinterpret_cast<int*>(Xl + CIT * p.PSP + 64);   // [2][PS]: relative offset or -1 (per tile)
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform (scalar loop control below)
+    const int tg = wave % NTG, w2 = wave / NTG;
+    const int wmn = w2 % (WM * WN), wk = w2 / (WM * WN);
+    const int wm = wmn / WN, wn = wmn % WN;
     const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);
     const int nTile = p.nCoT * p.nCiT;
     const int split = wid / nTile, tl = wid - split * nTile;
-    const int co0 = (tl / p.nCiT) * CT, ci0 = (tl % p.nCiT) * CT;
+    const int co0 = (tl / p.nCiT) * COT, ci0 = (tl % p.nCiT) * CIT;
 
-    // zero the whole LDS image once (pad / slack / not-yet-staged words must be finite)
-    {
-        const int tot = CT * p.PTP + CT * p.PSP + 64;
-        for (int i = tid; i < tot; i += 256) lds[i] = 0.f;
+    {   // zero the whole LDS image once (pad / slack words must be finite)
+        const int tot = COT * p.PTP + CIT * p.PSP + 64;
+        for (int i = tid; i < tot; i += NT) lds[i] = 0.f;
     }
-    // relative offset + packed coordinates of every patch word (identical for all tiles)
-    for (int r = tid; r < p.PS; r += 256) {
-        const int tb = r / p.PSI, rr = r - tb * p.PSI;
-        const int py = rr / p.PW, px = rr - py * p.PW;
-        tabOff[r] = tb * p.CinTot * p.HW + (py - HALO) * p.W + (px - HALO);
-        tabCrd[r] = (tb << 20) | (py << 10) | px;
-    }
-    // this thread's dY pixel inside a tile
     const int pl = tid & 63;
     const int ptx = pl & (p.TW - 1), pty = (pl >> p.lgTW) & (p.TH - 1), ptb = pl >> (p.lgTW + p.lgTH);
     const int npix = p.TB << (p.lgTW + p.lgTH);
+    const int nsteps = (npix + 1) >> 1;
+    const int totalX = CIT * p.PS;
+    const int qs = NT / p.PS, rs = NT - qs * p.PS;
+    const int ciA = tid / p.PS, rA = tid - ciA * p.PS;
 
-    f32x16 acc[KK];
+    f32x16 acc[TPG];
 #pragma unroll
-    for (int t = 0; t < KK; ++t)
+    for (int t = 0; t < TPG; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const int q256 = 256 / p.PS, r256 = 256 - q256 * p.PS;
-    const int nsteps = (npix + 1) >> 1;
-    __syncthreads();
-
-    for (int t = split; t < p.T; t += p.S) {
+    auto tile_origin = [&](int t, int& x0, int& y0, int& b0) {
         const int txi = t % p.tilesX, t2 = t / p.tilesX;
-        const int tyi = t2 % p.tilesY, tbi = t2 / p.tilesY;
-        const int x0 = txi * p.TW, y0 = tyi * p.TH, b0 = tbi * p.TB;
-        // ---- stage dY tile: [co][pixel]
-        {
-            const bool pv = pl < npix && (b0 + ptb) < p.N && (y0 + pty) < p.H && (x0 + ptx) < p.W;
-            const float* src = p.dy + ((size_t)(b0 + ptb) * p.CoutTot + co0) * p.HW + (y0 + pty) * p.W + (x0 + ptx);
-#pragma unroll 4
-            for (int j = 0; j < CT / 4; ++j) {
-                const int co = (tid >> 6) + 4 * j;
-                const float v = (pv && (co0 + co) < p.Cout) ? src[(size_t)co * p.HW] : 0.f;
-                dYl[co * p.PTP + pl] = v;
-            }
+        x0 = txi * p.TW; y0 = (t2 % p.tilesY) * p.TH; b0 = (t2 / p.tilesY) * p.TB;
+    };
+    // per-tile table: patch word r -> offset relative to (b0, channel, y0-HALO, x0-HALO), or -1 outside the image
+    auto make_tab = [&](int t, int which) {
+        int x0, y0, b0;
+        tile_origin(t, x0, y0, b0);
+        for (int r = tid; r < p.PS; r += NT) {
+            const int tb = r / p.PSI, rr = r - tb * p.PSI;
+            const int py = rr / p.PW, px = rr - py * p.PW;
+            const int b = b0 + tb, yy = y0 + py - HALO, xx = x0 + px - HALO;
+            const bool v = b < p.N && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            tab[which * p.PS + r] = v ? (tb * p.CinTot * p.HW + py * p.W + px) : -1;   // relative to (y0-HALO, x0-HALO): never negative when valid
         }
-        // ---- stage X patch: [ci][patch word]
-        {
-            const float* src = p.x + ((size_t)b0 * p.CinTot + ci0) * p.HW + y0 * p.W + x0;
-            int ci = tid / p.PS, r = tid - ci * p.PS;
-            const int total = CT * p.PS;
-#pragma unroll 4
-            for (int e = tid; e < total; e += 256) {
-                const int crd = tabCrd[r];
-                const int tb = crd >> 20, py = (crd >> 10) & 1023, px = crd & 1023;
-                const int b = b0 + tb, yy = y0 + py - HALO, xx = x0 + px - HALO;
-                const bool v = b < p.N && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && (ci0 + ci) < p.Cin;
-                Xl[ci * p.PSP + r] = v ? src[(size_t)ci * p.HW + tabOff[r]] : 0.f;
-                ci += q256; r += r256;
+    };
+    float dreg[DYR], xreg[XR];
+    auto gload = [&](int t, int which) {
+        int x0, y0, b0;
+        tile_origin(t, x0, y0, b0);
+        const bool pv = pl < npix && (b0 + ptb) < p.N && (y0 + pty) < p.H && (x0 + ptx) < p.W;
+        const float* dsrc = p.dy + ((size_t)(b0 + ptb) * p.CoutTot + co0) * p.HW + (y0 + pty) * p.W + (x0 + ptx);
+#pragma unroll
+        for (int j = 0; j < DYR; ++j) {
+            const int co = (tid >> 6) + 8 * j;
+            dreg[j] = (pv && (co0 + co) < p.Cout) ? dsrc[(size_t)co * p.HW] : 0.f;
+        }
+        if (PF) {
+            const float* xsrc = p.x + ((size_t)b0 * p.CinTot + ci0) * p.HW + (y0 - HALO) * p.W + (x0 - HALO);
+            const int* tb = tab + which * p.PS;
+            int ci = ciA, r = rA;
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                float v = 0.f;
+                if (tid + i * NT < totalX) {
+                    const int off = tb[r];
+                    if (off >= 0 && (ci0 + ci) < p.Cin) v = xsrc[(size_t)ci * p.HW + off];
+                }
+                xreg[i] = v;
+                ci += qs; r += rs;
                 if (r >= p.PS) { r -= p.PS; ++ci; }
             }
         }
-        __syncthreads();
-        // ---- MFMA over the tile's pixels, two per instruction
-        {
-            const float* Ab = dYl + (wm * 32 + l31) * p.PTP + h;
-            const float* Bb = Xl + (wn * 32 + l31) * p.PSP;
-#pragma unroll 2
-            for (int s = 0; s < nsteps; ++s) {
-                const int pp = 2 * s + h;
-                const int tx = pp & (p.TW - 1), ty = (pp >> p.lgTW) & (p.TH - 1), tb = pp >> (p.lgTW + p.lgTH);
-                const float a = Ab[2 * s];
-                const float* bp = Bb + tb * p.PSI + ty * p.PW + tx;
+    };
+    auto lstore = [&](int t, int which) {
 #pragma unroll
-                for (int tap = 0; tap < KK; ++tap) {
-                    const float b = bp[(tap / KS) * p.PW + (tap % KS)];
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
-                }
+        for (int j = 0; j < DYR; ++j) dYl[((tid >> 6) + 8 * j) * p.PTP + pl] = dreg[j];
+        if (PF) {
+            int ci = ciA, r = rA;
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                if (tid + i * NT < totalX) Xl[ci * p.PSP + r] = xreg[i];
+                ci += qs; r += rs;
+                if (r >= p.PS) { r -= p.PS; ++ci; }
+            }
+        } else {   // direct staging (large patches of the tiny-resolution levels)
+            int x0, y0, b0;
+            tile_origin(t, x0, y0, b0);
+            const float* xsrc = p.x + ((size_t)b0 * p.CinTot + ci0) * p.HW + (y0 - HALO) * p.W + (x0 - HALO);
+            const int* tb = tab + which * p.PS;
+            int ci = ciA, r = rA;
+            for (int e = tid; e < totalX; e += NT) {
+                const int off = tb[r];
+                Xl[ci * p.PSP + r] = (off >= 0 && (ci0 + ci) < p.Cin) ? xsrc[(size_t)ci * p.HW + off] : 0.f;
+                ci += qs; r += rs;
+                if (r >= p.PS) { r -= p.PS; ++ci; }
             }
         }
+    };
+
+    int t = split;
+    if (t < p.T) make_tab(t, 0);
+    __syncthreads();
+    if (t < p.T) gload(t, 0);
+    for (int it = 0; t < p.T; t += p.S, ++it) {
+        const int cur = it & 1;
+        const int tn = t + p.S;
+        __syncthreads();                       // every wave finished the MFMAs of the previous tile
+        lstore(t, cur);
+        if (tn < p.T) make_tab(tn, cur ^ 1);
         __syncthreads();
+        if (tn < p.T) gload(tn, cur ^ 1);      // in flight during the MFMA loop below
+        {
+            // pixel pair (2s, 2s+1): the second pixel sits one word to the right (or one image further when TW == 1)
+            const float* Ab = dYl + (wm * 32 + l31) * p.PTP + h;
+            const float* Bb = Xl + (wn * 32 + l31) * p.PSP + (p.TW > 1 ? h : h * p.PSI);
+            auto mma_loop = [&](auto ntap_c, auto tap0_c) {
+                constexpr int NTAP = decltype(ntap_c)::value, TAP0 = decltype(tap0_c)::value;
+#pragma unroll 4
+                for (int s = wk; s < nsteps; s += WK) {
+                    const int p2 = 2 * s;
+                    const int po = (p2 >> (p.lgTW + p.lgTH)) * p.PSI + ((p2 >> p.lgTW) & (p.TH - 1)) * p.PW + (p2 & (p.TW - 1));
+                    const float a = Ab[p2];
+                    float b[NTAP];
+#pragma unroll
+                    for (int k = 0; k < NTAP; ++k) b[k] = Bb[po + ((TAP0 + k) / KS) * p.PW + (TAP0 + k) % KS];
+#pragma unroll
+                    for (int k = 0; k < NTAP; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[k], acc[k], 0, 0, 0);
+                }
+            };
+            if (KK == 9) {
+                if (tg == 0) mma_loop(std::integral_constant<int, 5>{}, std::integral_constant<int, 0>{});
+                else mma_loop(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
+            } else {
+                mma_loop(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            }
+        }
     }
 
-    // ---- partial slab [split][tap][co][ci]
-    float* out = p.slab + (size_t)split * KK * p.Cout * p.Cin;
+    // ---- partial slab [split * WK + wk][tap][co][ci]
+    float* out = p.slab + (size_t)(split * WK + wk) * KK * p.Cout * p.Cin;
     const int ci = ci0 + wn * 32 + l31;
+    const int tap0 = tg * TPG, ntap = (KK == 9) ? (tg == 0 ? 5 : 4) : 1;
 #pragma unroll
-    for (int tap = 0; tap < KK; ++tap)
+    for (int k = 0; k < TPG; ++k)
+        if (k < ntap) {
+            const int tap = tap0 + k;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (co < p.Cout && ci < p.Cin) out[((size_t)tap * p.Cout + co) * p.Cin + ci] = acc[tap][r];
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Cout && ci < p.Cin) out[((size_t)tap * p.Cout + co) * p.Cin + ci] = acc[k][r];
+            }
         }
 }
 
-// dW[co][ci][tap] = sum_s slab[s][tap][co][ci]  (fixed order)
+// ------------------------------------------------------------------------------------------------
+// Specialisation for the layers that carry almost all of the work: 3x3, W >= 32 (tile = 2 rows x 32
+// columns of one image, patch 4 x 34).  Every LDS offset of the MFMA loop is a compile-time
+// immediate, the 32 pixel-pair steps of a tile are fully unrolled (LDS reads are scheduled far ahead
+// of the MFMAs that consume them), and the staging map is one fixed patch word per thread
+// (408 of 512 threads active; a thread walks the input channels with a constant stride).
+template <int WM, int WN>
+__global__ __launch_bounds__(NT, 2) void wgrad_fast_kernel(const WgP p) {
+    constexpr int PW = 34, PS = 136, PSP = 137, PTP = 65;
+    constexpr int COT = 32 * WM, CIT = 32 * WN, WK = 8 / (WM * WN * 2);
+    constexpr int DYR = COT / 8, XRN = (CIT + 2) / 3, NSTEP = 32 / WK;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* dYl = lds;                       // [COT][65]
+    float* Xl = dYl + COT * PTP;            // [CIT][137]
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = wave & 1, w2 = wave >> 1;
+    const int wmn = w2 % (WM * WN), wk = w2 / (WM * WN);
+    const int wm = wmn / WN, wn = wmn % WN;
+    const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);
+    const int nTile = p.nCoT * p.nCiT;
+    const int split = wid / nTile, tl = wid - split * nTile;
+    const int co0 = (tl / p.nCiT) * COT, ci0 = (tl % p.nCiT) * CIT;
+
+    for (int i = tid; i < COT * PTP + CIT * PSP + 64; i += NT) lds[i] = 0.f;
+
+    // staging maps
+    const int pl = tid & 63, ptx = pl & 31, pty = pl >> 5, dco = tid >> 6;
+    const bool xact = tid < 3 * PS;
+    const int xg = tid / PS, xr = tid - xg * PS;
+    const int xpy = xr / PW, xpx = xr - xpy * PW;
+
+    float dreg[DYR], xreg[XRN];
+    auto gload = [&](int t) {
+        const int txi = t % p.tilesX, t2 = t / p.tilesX;
+        const int x0 = txi * 32, y0 = (t2 % p.tilesY) * 2, b0 = t2 / p.tilesY;
+        {
+            const bool pv = (y0 + pty) < p.H && (x0 + ptx) < p.W;
+            const float* dsrc = p.dy + ((size_t)b0 * p.CoutTot + co0 + dco) * p.HW + (y0 + pty) * p.W + (x0 + ptx);
+#pragma unroll
+            for (int j = 0; j < DYR; ++j) dreg[j] = (pv && (co0 + dco + 8 * j) < p.Cout) ? dsrc[(size_t)(8 * j) * p.HW] : 0.f;
+        }
+        {
+            const int yy = y0 + xpy - 1, xx = x0 + xpx - 1;
+            const bool v = xact && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            const float* xsrc = p.x + ((size_t)b0 * p.CinTot + ci0 + xg) * p.HW + yy * p.W + xx;
+#pragma unroll
+            for (int i = 0; i < XRN; ++i) {
+                const int ci = xg + 3 * i;
+                xreg[i] = (v && ci < CIT && (ci0 + ci) < p.Cin) ? xsrc[(size_t)(3 * i) * p.HW] : 0.f;
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < DYR; ++j) dYl[(dco + 8 * j) * PTP + pl] = dreg[j];
+        if (xact) {
+#pragma unroll
+            for (int i = 0; i < XRN; ++i)
+                if (xg + 3 * i < CIT) Xl[(xg + 3 * i) * PSP + xr] = xreg[i];
+        }
+    };
+
+    const float* Ab = dYl + (wm * 32 + l31) * PTP + h + 2 * wk;
+    const float* Bb = Xl + (wn * 32 + l31) * PSP + h + 2 * wk;
+
+    auto run = [&](auto ntap_c, auto tap0_c) {
+        constexpr int NTAP = decltype(ntap_c)::value, TAP0 = decltype(tap0_c)::value;
+        f32x16 acc[NTAP];
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+        int t = split;
+        if (t < p.T) gload(t);
+        for (; t < p.T; t += p.S) {
+            __syncthreads();                   // every wave finished the MFMAs of the previous tile
+            lstore();
+            __syncthreads();
+            if (t + p.S < p.T) gload(t + p.S); // in flight during the MFMA loop below
+#pragma unroll
+            for (int si = 0; si < NSTEP; ++si) {
+                constexpr int dummy = 0; (void)dummy;
+                const int s0 = si * WK;                                  // + wk folded into Ab / Bb
+                const int po = (s0 >> 4) * PW + ((2 * s0) & 31);
+                const float a = Ab[2 * s0];
+                float b[NTAP];
+#pragma unroll
+                for (int k = 0; k < NTAP; ++k) b[k] = Bb[po + ((TAP0 + k) / 3) * PW + (TAP0 + k) % 3];
+#pragma unroll
+                for (int k = 0; k < NTAP; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[k], acc[k], 0, 0, 0);
+            }
+        }
+        float* out = p.slab + (size_t)(split * WK + wk) * 9 * p.Cout * p.Cin;
+        const int ci = ci0 + wn * 32 + l31;
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Cout && ci < p.Cin) out[((size_t)(TAP0 + k) * p.Cout + co) * p.Cin + ci] = acc[k][r];
+            }
+    };
+    if (tg == 0) run(std::integral_constant<int, 5>{}, std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
+}
+
+// Ordered two-stage reduction of the partial slabs (bitwise reproducible).
+// stage 1: slab[g*RG] += slab[g*RG + 1 .. g*RG + RG-1]  for every group g of RG consecutive slabs
+__global__ __launch_bounds__(256) void wgrad_reduce_groups(float* __restrict__ slab, int S, int RG, int n) {
+    const int g = blockIdx.y;
+    const int lo = g * RG, hi = min(S, lo + RG);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = lo; k < hi; ++k) s += slab[(size_t)k * n + i];
+        slab[(size_t)lo * n + i] = s;
+    }
+}
+// stage 2: dW[co][ci][tap] = sum_g slab[g*RG][tap][co][ci]  (fixed order)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                            int S, int KK, int Cout, int Cin) {
+                                                            int S, int RG, int KK, int Cout, int Cin) {
     const int n = KK * Cout * Cin;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         float s = 0.f;
-        for (int k = 0; k < S; ++k) s += slab[(size_t)k * n + i];
+        for (int k = 0; k < S; k += RG) s += slab[(size_t)k * n + i];
         const int tap = i / (Cout * Cin), rem = i - tap * (Cout * Cin);
         dw[(size_t)rem * KK + tap] = s;
     }
@@ -162,7 +347,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     if (threadIdx.x == 0) db[c] = (float)s[0];
 }
 
-struct WGeom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB, T, S, nCoT, nCiT; };
+struct WGeom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB, T, S, nCoT, nCiT, WM, WN, WK, pf; };
 
 WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
     WGeom g;
@@ -180,8 +365,12 @@ WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
     g.tilesY = uz::ceil_div(H, g.TH);
     g.tilesB = uz::ceil_div(N, g.TB);
     g.T = g.tilesX * g.tilesY * g.tilesB;
-    g.nCoT = uz::ceil_div(Cout, CT);
-    g.nCiT = uz::ceil_div(Cin, CT);
+    g.WM = Cout > 32 ? 2 : 1;
+    g.WN = Cin > 32 ? 2 : 1;
+    g.WK = 8 / (g.WM * g.WN * (halo ? 2 : 1));
+    g.nCoT = uz::ceil_div(Cout, 32 * g.WM);
+    g.nCiT = uz::ceil_div(Cin, 32 * g.WN);
+    g.pf = (32 * g.WN * g.PS <= 18 * 512) ? 1 : 0;
     int s = 1024 / (g.nCoT * g.nCiT);
     if (s < 1) s = 1;
     if (s > g.T) s = g.T;
@@ -194,7 +383,7 @@ WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
 
 extern "C" size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, int W, int ks) {
     const WGeom g = pick_wgeom(Cin, Cout, N, H, W, ks / 2);
-    return (size_t)g.S * ks * ks * Cout * Cin * sizeof(float);
+    return (size_t)g.S * g.WK * ks * ks * Cout * Cin * sizeof(float);
 }
 
 extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
@@ -204,7 +393,7 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
     UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_bwd_weight: empty tensor");
     UZ_REQUIRE(H < 1024 && W < 1024, "conv_bwd_weight: spatial size too large");
     const WGeom g = pick_wgeom(Cin, Cout, N, H, W, ks / 2);
-    const size_t need = (size_t)g.S * ks * ks * Cout * Cin * sizeof(float);
+    const size_t need = (size_t)g.S * g.WK * ks * ks * Cout * Cin * sizeof(float);
     UZ_REQUIRE(workspace && workspace_bytes >= need, "conv_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = uz::S(stream);
     WgP p;
@@ -216,29 +405,58 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
     p.PW = g.PW; p.PSI = g.PSI; p.PS = g.PS; p.PSP = g.PS | 1;
     p.PT = 64; p.PTP = 65;
     p.nCoT = g.nCoT; p.nCiT = g.nCiT;
-    const size_t smem = ((size_t)CT * p.PTP + (size_t)CT * p.PSP + 64 + 2 * (size_t)p.PS) * sizeof(float);
+    const int cot = 32 * g.WM, cit = 32 * g.WN;
+    const size_t smem = ((size_t)cot * p.PTP + (size_t)cit * p.PSP + 64 + 2 * (size_t)p.PS) * sizeof(float);
     const int grid = g.nCoT * g.nCiT * g.S;
-    static bool attr3 = false, attr1 = false;
-    if (ks == 3) {
-        if (!attr3) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return uz::fail("wgrad: cannot raise dynamic LDS limit");
-            attr3 = true;
-        }
-        hipLaunchKernelGGL(wgrad_kernel<3>, dim3(grid), dim3(256), smem, st, p);
-    } else {
-        if (!attr1) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return uz::fail("wgrad: cannot raise dynamic LDS limit");
-            attr1 = true;
-        }
-        hipLaunchKernelGGL(wgrad_kernel<1>, dim3(grid), dim3(256), smem, st, p);
-    }
+#define UZ_WG_LAUNCH(KS_, WM_, WN_, PF_)                                                                         \
+    do {                                                                                                         \
+        static bool attr = false;                                                                                \
+        auto kern = wgrad_kernel<KS_, WM_, WN_, PF_>;                                                            \
+        if (!attr) {                                                                                             \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+                return uz::fail("wgrad: cannot raise dynamic LDS limit");                                        \
+            attr = true;                                                                                         \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);                                            \
+    } while (0)
+#define UZ_WG_PF(KS_, WM_, WN_) UZ_WG_LAUNCH(KS_, WM_, WN_, false)
+#define UZ_WG_TILE(KS_)                                                              \
+    do {                                                                             \
+        if (g.WM == 2 && g.WN == 2) UZ_WG_PF(KS_, 2, 2);                             \
+        else if (g.WM == 2) UZ_WG_PF(KS_, 2, 1);                                     \
+        else if (g.WN == 2) UZ_WG_PF(KS_, 1, 2);                                     \
+        else UZ_WG_PF(KS_, 1, 1);                                                    \
+    } while (0)
+    const bool fast = ks == 3 && g.TW == 32 && g.TH == 2 && g.TB == 1;
+#define UZ_WG_FAST(WM_, WN_)                                                                                    \
+    do {                                                                                                         \
+        static bool attr = false;                                                                                \
+        auto kern = wgrad_fast_kernel<WM_, WN_>;                                                                 \
+        if (!attr) {                                                                                             \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+                return uz::fail("wgrad: cannot raise dynamic LDS limit");                                        \
+            attr = true;                                                                                         \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);                                             \
+    } while (0)
+    if (fast) {
+        if (g.WM == 2 && g.WN == 2) UZ_WG_FAST(2, 2);
+        else if (g.WM == 2) UZ_WG_FAST(2, 1);
+        else if (g.WN == 2) UZ_WG_FAST(1, 2);
+        else UZ_WG_FAST(1, 1);
+    } else if (ks == 3) UZ_WG_TILE(3); else UZ_WG_TILE(1);
     if (int rc = uz::check_launch("wgrad_kernel")) return rc;
     const int n = ks * ks * Cout * Cin;
     int rgrid = uz::ceil_div(n, 256);
     if (rgrid > 4096) rgrid = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, st, p.slab, dw, g.S, ks * ks, Cout, Cin);
+    const int Stot = g.S * g.WK;
+    int RG = 1;
+    if (Stot > 64) {
+        RG = 32;
+        hipLaunchKernelGGL(wgrad_reduce_groups, dim3(rgrid, uz::ceil_div(Stot, RG)), dim3(256), 0, st, p.slab, Stot, RG, n);
+        if (int rc = uz::check_launch("wgrad_reduce_groups")) return rc;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, st, p.slab, dw, Stot, RG, ks * ks, Cout, Cin);
     if (int rc = uz::check_launch("wgrad_reduce_kernel")) return rc;
     if (db) {
         hipLaunchKernelGGL(channel_sum_kernel, dim3(Cout), dim3(256), 0, st, dy, CoutTot, N, H * W, db);

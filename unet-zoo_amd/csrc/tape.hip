@@ -53,9 +53,9 @@ static int run_one(const uz_op& o, void* st) {
 #define CFP(k) static_cast<const float*>(p[k])
     switch (o.code) {
         case UZ_OP_CONV_FWD:
-            return uz_conv_fwd(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], i[8], st);
+            return uz_conv_fwd(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], i[8], p[4], (size_t)o.n, st);
         case UZ_OP_CONV_BWD_DATA:
-            return uz_conv_bwd_data(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], st);
+            return uz_conv_bwd_data(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], p[3], (size_t)o.n, st);
         case UZ_OP_CONV_BWD_WEIGHT:
             return uz_conv_bwd_weight(CFP(0), i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], i[7], p[4], (size_t)o.n, st);
         case UZ_OP_BN_RELU_FWD:
