@@ -43,11 +43,23 @@ def test_state_dict_surface():
 # is enforced on the real architecture (full-size digests, batch 2 and batch 32) below.
 SMALL_LOGIT_TOL = 5e-4
 SMALL_GRAD_TOL = 5e-2
+# fixture -> (logit tol, grad tol rel. to the tensor's max, loss rel tol per step)
+# Loss tolerances grow per step: Adam's first update is lr*sign(g), so every near-zero gradient entry whose
+# sign differs between two fp32 implementations moves that weight by 2*lr (measured: ~6e-5 of all entries);
+# the CPU oracle run in fp64 instead of fp32 drifts from the fp32 reference by 7e-6 / 1e-3 at steps 1 / 2.
+TRAIN_GATES = {"phiseg_small": (SMALL_LOGIT_TOL, SMALL_GRAD_TOL, (1e-4, 3e-4, 3e-3)),
+               "phiseg_mid": (1e-4, 2e-2, (2e-5, 3e-4, 3e-3))}
+# (the largest gradient deviations sit in the KL path: d/d sigma1 = s0/B - A*s0/B^2 is a difference of
+#  near-equal terms whenever posterior ~ prior, in the reference's autograd as much as here)
 
 
-def test_phiseg_small_train_steps_vs_reference_golden():
+@pytest.mark.parametrize("fixture", ["phiseg_small", "phiseg_mid"])
+def test_phiseg_train_steps_vs_reference_golden(fixture):
+    """Train-step contract: 3 x [forward, loss, zero_grad, backward, Adam(lr 1e-3, wd 1e-5)]
+    from the reference's captured inputs / noise / initial state_dict."""
     from unet_zoo_amd.optim import FusedAdam
-    arrays, meta = G.load("phiseg_small")
+    logit_tol, grad_tol, loss_tols = TRAIN_GATES[fixture]
+    arrays, meta = G.load(fixture)
     net, _ = _model(meta)
     net.train()
     opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
@@ -58,15 +70,15 @@ def test_phiseg_small_train_steps_vs_reference_golden():
         loss = net.loss(mask)
         opt.zero_grad()
         loss.backward()
-        assert abs(float(loss) - st["loss"]) <= 1e-4 * abs(st["loss"]), (step, float(loss), st["loss"])
+        assert abs(float(loss) - st["loss"]) <= loss_tols[step] * abs(st["loss"]), (step, float(loss), st["loss"])
         for k, v in st["loss_dict"].items():
-            assert abs(float(net.loss_dict[k]) - v) <= 1e-3 * max(1.0, abs(v)), (step, k)
+            assert abs(float(net.loss_dict[k]) - v) <= 50 * loss_tols[step] * max(1.0, abs(v)), (step, k)
         assert float(net.kl_divergence_loss) == float(loss) == float(net.reconstruction_loss)   # alias quirk
         none = sorted(k for k, p in net.named_parameters() if p.grad is None)
         assert none == sorted(st["none_grads"])
         if step == 0:
             for l in range(5):
-                assert G.maxabs(s[l].cpu().numpy(), arrays[f"s{l}"]) <= SMALL_LOGIT_TOL, l
+                assert G.maxabs(s[l].cpu().numpy(), arrays[f"s{l}"]) <= logit_tol, l
                 assert G.maxabs(net.posterior_mu[l].cpu().numpy(), arrays[f"post_mu{l}"]) <= 1e-4
                 assert G.maxabs(net.posterior_sigma[l].cpu().numpy(), arrays[f"post_sigma{l}"]) <= 1e-4
                 assert G.maxabs(net.posterior_latent_space[l].cpu().numpy(), arrays[f"post_z{l}"]) <= 1e-4
@@ -79,7 +91,7 @@ def test_phiseg_small_train_steps_vs_reference_golden():
                     e = G.maxabs(p.grad.cpu().numpy(), ref) / (1e-3 + float(np.abs(ref).max()))
                     if e > worst:
                         worst, wk = e, k
-            assert worst <= SMALL_GRAD_TOL, (worst, wk)
+            assert worst <= grad_tol, (worst, wk)
             for k, v in net.state_dict().items():
                 if "running_" in k:
                     assert G.maxabs(v.cpu().numpy(), arrays["buf1:" + k]) <= 1e-5, k
@@ -87,8 +99,9 @@ def test_phiseg_small_train_steps_vs_reference_golden():
     sd = net.state_dict()
     for k, v in sd.items():
         if v.dtype.is_floating_point and k not in noise:
-            # Adam turns every gradient into a step of magnitude <= lr: 3 steps bound the drift by 3e-3
-            assert G.maxabs(v.cpu().numpy(), arrays["final:" + k]) <= 3.1e-3, k
+            # Adam turns every gradient into a step of magnitude ~lr whatever its size: an entry whose
+            # near-zero gradient has the opposite sign in the two implementations drifts by 2*lr per step
+            assert G.maxabs(v.cpu().numpy(), arrays["final:" + k]) <= 6.5e-3, k
     nbt = [int(v) for k, v in sd.items() if k.endswith("num_batches_tracked") and "upsampling_path.4" not in k]
     assert set(nbt) == {len(meta["steps"])}
     assert all(int(v) == 0 for k, v in sd.items() if k.endswith("num_batches_tracked") and "upsampling_path.4" in k)
@@ -184,3 +197,44 @@ def test_phiseg_vs_live_oracle_other_seed():
         assert (p.grad is None) == (ref is None), k
         if ref is not None:
             assert G.maxabs(p.grad.cpu().numpy(), ref.numpy()) <= 5e-3 * (1e-3 + float(ref.abs().max())), k
+
+
+def test_phiseg_accuracy_vs_fp64_ground_truth():
+    """Both the HIP path and the reference's fp32 CPU arithmetic are approximations of the same real-valued
+    graph.  Against an fp64 evaluation of the oracle, the HIP path must be as accurate as the fp32 CPU
+    path itself (logits and every parameter gradient) - i.e. the remaining HIP-vs-reference differences
+    are fp32 rounding, not algorithmic."""
+    arrays, meta = G.load("phiseg_mid")
+    net, sd0 = _model(meta)
+    net.train()
+    x, mask, eps = _inputs(meta, 0)
+    s = net.forward(x, mask, training=True, eps=eps)
+    loss = net.loss(mask)
+    loss.backward()
+
+    def cpu(dtype):
+        lv = G.leaves({k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in sd0.items()})
+        e = [t.cpu().to(dtype) for t in eps]
+        out = oracle.phiseg_forward(lv, x.cpu().to(dtype), mask.cpu().to(dtype), dict(posterior=e[:5], prior=e[5:]))
+        total, _ = oracle.phiseg_loss(out, mask.cpu().to(dtype))
+        total.backward()
+        return out, {k: v.grad for k, v in lv.items() if v.requires_grad and v.grad is not None}
+
+    o32, g32 = cpu(torch.float32)
+    o64, g64 = cpu(torch.float64)
+    for l in range(5):
+        e_hip = float((s[l].cpu().double() - o64["s"][l]).abs().max())
+        e_cpu = float((o32["s"][l].double() - o64["s"][l]).abs().max())
+        assert e_hip <= 2.0 * e_cpu + 2e-5, (l, e_hip, e_cpu)
+        assert e_hip <= 2e-4
+    noise = G.bn_shadowed_biases(g64.keys())
+    rh, rc = [], []
+    for k, p in net.named_parameters():
+        if k in noise or k not in g64:
+            continue
+        sc = float(g64[k].abs().max()) + 1e-12
+        rh.append(float((p.grad.cpu().double() - g64[k]).abs().max()) / sc)
+        rc.append(float((g32[k].double() - g64[k]).abs().max()) / sc)
+    rh, rc = np.array(rh), np.array(rc)
+    assert np.median(rh) <= 2.0 * np.median(rc) + 1e-6, (np.median(rh), np.median(rc))
+    assert rh.max() <= 3.0 * rc.max() + 1e-4, (rh.max(), rc.max())

@@ -7,7 +7,7 @@ import oracle
 from tests import _golden as G
 from tests.test_phiseg_gpu import _model, _inputs
 
-for name in ("phiseg_small", "phiseg_full_digest"):
+for name in (sys.argv[1:] or ["phiseg_small", "phiseg_full_digest"]):
     arrays, meta = G.load(name)
     net, _ = _model(meta); net.train()
     x, mask, eps = _inputs(meta, 0)

@@ -323,6 +323,10 @@ if __name__ == "__main__":
         # BASELINE config 4 exactly (batch 32): digests only, inputs are regenerated from the seed
         phiseg_case("phiseg_full_b32_digest", [32, 64, 128, 192, 192, 192, 192], 128, 32, 1, False, 1238, store_inputs=False)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mid":
+        # better-conditioned multi-step trajectory (16+ samples per BN channel at the deepest level)
+        phiseg_case("phiseg_mid", [8, 16, 16, 16, 16, 16, 16], 128, 4, 3, True, 1239)
+        sys.exit(0)
     op_cases()
     phiseg_case("phiseg_small", [4, 8, 8, 8, 8, 8, 8], 64, 2, 3, True, 1234)
     unet_case("unet_small", [4, 8, 8, 8], 2, 3, 1235)
