@@ -332,19 +332,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// db[c] = sum_{b,y,x} dy[b,c,y,x]: one block per channel, ordered.
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dy, int Ctot, int N, int HW,
-                                                           float* __restrict__ db) {
+// db[c] = sum_{b,y,x} dy[b,c,y,x]: CSB blocks per channel write fp64 partials, then one wave per
+// channel adds them in a fixed order.
+constexpr int CSB = 64;
+__global__ __launch_bounds__(256) void channel_sum_partial(const float* __restrict__ dy, int Ctot, int N, int HW,
+                                                            double* __restrict__ part) {
     __shared__ double sm[4];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, blk = blockIdx.y;
     double s[1] = {0.0};
-    const int total = N * HW;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int b = i / HW, q = i - b * HW;
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blk * 256 + threadIdx.x; i < total; i += (long long)CSB * 256) {
+        const int b = (int)(i / HW), q = (int)(i - (long long)b * HW);
         s[0] += dy[((size_t)b * Ctot + c) * HW + q];
     }
     uz::block_sum_d<1>(s, sm);
-    if (threadIdx.x == 0) db[c] = (float)s[0];
+    if (threadIdx.x == 0) part[(size_t)c * CSB + blk] = s[0];
+}
+__global__ __launch_bounds__(64) void channel_sum_final(const double* __restrict__ part, float* __restrict__ db) {
+    const int c = blockIdx.x;
+    double s = part[(size_t)c * CSB + threadIdx.x];
+    s = uz::wave_sum_d(s);
+    if (threadIdx.x == 0) db[c] = (float)s;
 }
 
 struct WGeom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB, T, S, nCoT, nCiT, WM, WN, WK, pf; };
@@ -371,10 +379,12 @@ WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
     g.nCoT = uz::ceil_div(Cout, 32 * g.WM);
     g.nCiT = uz::ceil_div(Cin, 32 * g.WN);
     g.pf = (32 * g.WN * g.PS <= 18 * 512) ? 1 : 0;
+    // pixel splits: aim at ~1024 workgroups (four rounds over the 256 CUs keep the tail short), but give
+    // every workgroup at least 4 tiles so that the LDS clear, the pipeline fill and the slab write-out
+    // are amortised (slab traffic grows with S)
     int s = 1024 / (g.nCoT * g.nCiT);
+    if (s > g.T / 4) s = g.T / 4;
     if (s < 1) s = 1;
-    if (s > g.T) s = g.T;
-    if (s > 512) s = 512;
     g.S = s;
     return g;
 }
@@ -383,7 +393,9 @@ WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
 
 extern "C" size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, int W, int ks) {
     const WGeom g = pick_wgeom(Cin, Cout, N, H, W, ks / 2);
-    return (size_t)g.S * g.WK * ks * ks * Cout * Cin * sizeof(float);
+    const size_t slabs = (size_t)g.S * g.WK * ks * ks * Cout * Cin * sizeof(float);
+    const size_t dbp = (size_t)Cout * CSB * sizeof(double);
+    return slabs > dbp ? slabs : dbp;
 }
 
 extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
@@ -459,8 +471,13 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, st, p.slab, dw, Stot, RG, ks * ks, Cout, Cin);
     if (int rc = uz::check_launch("wgrad_reduce_kernel")) return rc;
     if (db) {
-        hipLaunchKernelGGL(channel_sum_kernel, dim3(Cout), dim3(256), 0, st, dy, CoutTot, N, H * W, db);
-        if (int rc = uz::check_launch("channel_sum_kernel")) return rc;
+        // the slab workspace is free again after the reduction above; it holds the fp64 partials
+        UZ_REQUIRE(workspace_bytes >= (size_t)Cout * CSB * sizeof(double), "conv_bwd_weight: workspace too small for the bias gradient");
+        double* part = static_cast<double*>(workspace);
+        hipLaunchKernelGGL(channel_sum_partial, dim3(Cout, CSB), dim3(256), 0, st, dy, CoutTot, N, H * W, part);
+        if (int rc = uz::check_launch("channel_sum_partial")) return rc;
+        hipLaunchKernelGGL(channel_sum_final, dim3(Cout), dim3(64), 0, st, part, db);
+        if (int rc = uz::check_launch("channel_sum_final")) return rc;
     }
     return 0;
 }
