@@ -144,12 +144,12 @@ class NativeModel(nn.Module):
     def _loss_tensor(self, plan):
         return _TapeLoss.apply(self._anchor, self, plan)
 
-    def _bump_nbt(self, plan):
-        idx = plan.__dict__.get("_nbt_idx")
+    def _bump_nbt(self, plan, which="bn_prefixes_nbt"):
+        idx = plan.__dict__.get("_nbt_idx_" + which)
         if idx is None:
-            ks = [self._ptab.nbt_keys.index(k) for k in plan.bn_prefixes_nbt]
+            ks = [self._ptab.nbt_keys.index(k) for k in plan.__dict__.get(which, [])]
             idx = torch.tensor(ks, dtype=torch.int64, device=self.device)
-            plan._nbt_idx = idx
+            plan.__dict__["_nbt_idx_" + which] = idx
         if idx.numel():
             self._ptab.nbt.index_add_(0, idx, torch.ones_like(idx))
 
@@ -157,5 +157,6 @@ class NativeModel(nn.Module):
 def conv_unit(plan, x, prefix, out=None, relu=True):
     """Reference Conv2D unit addressed by its module prefix (`<prefix>.convolution.{0,1}`)."""
     a = plan.conv_bn_relu(x, prefix + ".convolution.0", prefix + ".convolution.1", out=out, relu=relu)
-    plan.__dict__.setdefault("bn_prefixes_nbt", []).append(prefix + ".convolution.1.num_batches_tracked")
+    which = "bn_prefixes_nbt_loss" if plan.in_loss_phase() else ("bn_prefixes_nbt" if plan._record_bwd else "bn_prefixes_nbt_extra")
+    plan.__dict__.setdefault(which, []).append(prefix + ".convolution.1.num_batches_tracked")
     return a

@@ -133,8 +133,11 @@ class Plan:
         self.L = _ffi.lib()
         self.bufs = []
         self.fwd_ops, self.loss_ops, self.bwd_ops = [], [], []
+        self.extra_ops = {}                 # additional forward-only tapes (e.g. "decode")
         self.target = self.fwd_ops
         self._bwd = []                      # closures, run in reverse
+        self._bwd_tail = []                 # closures run after all others (regulariser gradients)
+        self._record_bwd = True
         self._ginit = {}                    # Buf -> list of (c0, c1) gradient regions already written
         self.scratch = dict(bn=0, wgrad=0, gy=0, ce=0)   # bytes (bn, wgrad, ce) / floats (gy)
         self.ptr_tables = []                # list of lists of pointer refs -> device int64 table
@@ -192,6 +195,34 @@ class Plan:
 
     def loss_phase(self):
         self.target = self.loss_ops
+
+    def extra_phase(self, name):
+        """Switch to an extra forward-only tape (no backward is recorded for its ops)."""
+        self.target = self.extra_ops.setdefault(name, [])
+        self._record_bwd = False
+
+    def _push_bwd(self, fn):
+        if self._record_bwd:
+            self._bwd.append(fn)
+
+    def in_loss_phase(self):
+        return self.target is self.loss_ops
+
+    def l2_reg(self, keys, term, coeff):
+        """coeff * sum_k ||p_k||_2 over the listed parameter tensors (utils.l2_regularisation, utils.py:93-101)."""
+        n = len(keys)
+        tab = self.ptr_table([("raw", v) for k in keys for v in (self.ptab.poff[k], _numel(self.ptab.shape[k]))])
+        norms = self.vec("l2_norms", n)
+        self._emit(self.target, "UZ_OP_L2_NORMS", p=[("pflat",), tab, norms], i=[n])
+        self._emit(self.target, "UZ_OP_SUM_TERMS", p=[norms, term], i=[n])
+        self._emit(self.target, "UZ_OP_SCALE", p=[term], f=[coeff], n=1)
+
+        def tail():
+            sc = self.vec("l2_scale", 1)
+            self._emit(self.bwd_ops, "UZ_OP_COPY", p=[sc, self.loss_scale], n=4)
+            self._emit(self.bwd_ops, "UZ_OP_SCALE", p=[sc], f=[coeff], n=1)
+            self._emit(self.bwd_ops, "UZ_OP_L2_NORMS_BWD", p=[("pflat",), tab, norms, sc, ("gflat",)], i=[n])
+        self._bwd_tail.append(tail)
 
     # ------------------------------------------------------------------ convolution family
     def _conv_fwd(self, x, wkey, bkey, y, ks, relu, wrow0=0):
@@ -255,7 +286,7 @@ class Plan:
                        p=[self.gview(a), y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), self.G(bkey), ("scratch", "bn")],
                        i=[a.Ctot, cout, y.Ctot, cout, x.N, x.H, x.W, int(relu)])
             self._conv_bwd(x, wkey, gyv, ks)
-        self._bwd.append(bwd)
+        self._push_bwd(bwd)
         return a
 
     def conv_relu(self, x, prefix, out=None, name=None):
@@ -275,7 +306,7 @@ class Plan:
                        p=[self.gview(a), a, gy, self.G(bkey), ("scratch", "bn")],
                        i=[a.Ctot, cout, a.Ctot, cout, x.N, x.H, x.W])
             self._conv_bwd(x, wkey, gyv, ks)
-        self._bwd.append(bwd)
+        self._push_bwd(bwd)
         return a
 
     def conv_bare(self, x, prefix, out=None, name=None, rows=None):
@@ -293,7 +324,7 @@ class Plan:
             if not self._has_grad(y):
                 return
             self._conv_bwd(x, wkey, self.gview(y), ks, db_key=bkey, wrow0=r0)
-        self._bwd.append(bwd)
+        self._push_bwd(bwd)
         return y
 
     # ------------------------------------------------------------------ resampling
@@ -306,7 +337,7 @@ class Plan:
             acc = self._claim(x)
             self._emit(self.bwd_ops, bcode, p=[self.gview(y), self.gview(x)],
                        i=[x.C, y.Ctot, x.Ctot, x.N, x.H, x.W, *extra_i, acc])
-        self._bwd.append(bwd)
+        self._push_bwd(bwd)
         return y
 
     def avgpool(self, x, name):
@@ -334,7 +365,7 @@ class Plan:
             acc = self._claim(x)
             self._emit(self.bwd_ops, "UZ_OP_SPATIAL_MEAN_BWD", p=[self.gview(y), self.gview(x)],
                        i=[x.C, x.Ctot, x.N, x.H, x.W, acc])
-        self._bwd.append(bwd)
+        self._push_bwd(bwd)
         return y
 
     def bcast_channels(self, z, out):
@@ -348,7 +379,7 @@ class Plan:
             assert self._claim(z) == 0
             self._emit(self.bwd_ops, "UZ_OP_BCAST_CHANNELS_BWD", p=[self.gview(out), self.gview(z)],
                        i=[out.Ctot, L, out.N, out.H, out.W])
-        self._bwd.append(bwd)
+        self._push_bwd(bwd)
 
     # ------------------------------------------------------------------ inputs / latents / losses
     def posterior_input(self, patch, mask, nlabels, name):
@@ -370,7 +401,7 @@ class Plan:
             assert self._claim(mu) == 0 and self._claim(pre) == 0
             self._emit(self.bwd_ops, "UZ_OP_LATENT_BWD",
                        p=[lat.kl_dmu, lat.kl_dsigma, dz, eps, sigma, self.gview(mu), self.gview(pre)], i=[act], n=mu.numel)
-        self._bwd.append(bwd)
+        self._push_bwd(bwd)
         return lat
 
     def kl(self, q, p, weight, term):
@@ -385,23 +416,32 @@ class Plan:
             self._emit(self.bwd_ops, "UZ_OP_KL_BWD",
                        p=[q.mu, q.sigma, p.mu, p.sigma, self.loss_scale, q.kl_dmu, q.kl_dsigma, p.kl_dmu, p.kl_dsigma],
                        i=[n, per], f=[weight])
-        self._bwd.append(bwd)
+        self._push_bwd(bwd)
 
-    def residual_ce(self, s_list, mask, terms, scale_ref=None):
-        """residual_multinoulli_loss over the level logits (phiseg.py:481-513); terms: vec View of L floats."""
+    def residual_ce(self, s_list, mask, terms, post_scale=None):
+        """residual_multinoulli_loss over the level logits (phiseg.py:481-513); terms: vec View of L floats.
+        post_scale: extra factor on the terms (1/(H*W) turns the L=1 case into nn.CrossEntropyLoss() mean,
+        unet.py:159-165)."""
         L, K = len(s_list), s_list[0].C
         assert all(s.contiguous for s in s_list)
         tab = self.ptr_table(list(s_list))
         ws = self.L.uz_ce_workspace(mask.N, mask.H, mask.W, L)
         self.scratch["ce"] = max(self.scratch["ce"], ws)
         self._emit(self.target, "UZ_OP_CE_FWD", p=[tab, mask, terms, ("scratch", "ce")], i=[L, K, mask.N, mask.H, mask.W])
+        if post_scale is not None:
+            self._emit(self.target, "UZ_OP_SCALE", p=[terms], f=[post_scale], n=L)
 
         def bwd():
             for s in s_list:
                 assert self._claim(s) == 0
             gtab = self.ptr_table([self.gview(s) for s in s_list])
-            self._emit(self.bwd_ops, "UZ_OP_CE_BWD", p=[tab, gtab, mask, scale_ref or self.loss_scale], i=[L, K, mask.N, mask.H, mask.W])
-        self._bwd.append(bwd)
+            scale_ref = self.loss_scale
+            if post_scale is not None:
+                scale_ref = self.vec("ce_scale", 1)
+                self._emit(self.bwd_ops, "UZ_OP_COPY", p=[scale_ref, self.loss_scale], n=4)
+                self._emit(self.bwd_ops, "UZ_OP_SCALE", p=[scale_ref], f=[post_scale], n=1)
+            self._emit(self.bwd_ops, "UZ_OP_CE_BWD", p=[tab, gtab, mask, scale_ref], i=[L, K, mask.N, mask.H, mask.W])
+        self._push_bwd(bwd)
 
     def sum_terms(self, terms, n, total):
         self._emit(self.target, "UZ_OP_SUM_TERMS", p=[terms, total], i=[n])
@@ -419,6 +459,8 @@ class Plan:
         self.loss_scale = self.vec("loss_scale", 1)
         if want_backward:
             for fn in reversed(self._bwd):
+                fn()
+            for fn in self._bwd_tail:
                 fn()
         self._bwd = []
         # arena layout
@@ -447,6 +489,8 @@ class Plan:
         if vals:
             self.ptrtab.copy_(torch.tensor(vals, dtype=torch.int64))
         self.tapes = {nm: self._materialize(ops) for nm, ops in (("fwd", self.fwd_ops), ("loss", self.loss_ops), ("bwd", self.bwd_ops))}
+        for nm, ops in self.extra_ops.items():
+            self.tapes[nm] = self._materialize(ops)
         self.loss_scale_t = self.tensor(self.loss_scale).view(1)
         self.loss_scale_t.fill_(1.0)
         self.finalized = True
@@ -467,6 +511,10 @@ class Plan:
             return self.ptab.gflat.data_ptr() + 4 * (self.ptab.poff[r[1]] + r[2])
         if kind == "buffer":
             return self.ptab.bflat.data_ptr() + 4 * self.ptab.boff[r[1]]
+        if kind == "pflat":
+            return self.ptab.pflat.data_ptr()
+        if kind == "gflat":
+            return self.ptab.gflat.data_ptr()
         if kind == "scratch":
             return self.base + 4 * self.scratch_off[r[1]]
         if kind == "gyview":
