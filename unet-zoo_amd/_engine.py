@@ -122,10 +122,8 @@ class NativeModel(nn.Module):
         self._run(plan, "bwd")
         self._post_backward(plan)
         if self._dp_group is not None:
-            import torch.distributed as dist
-            grp = None if self._dp_group is True else self._dp_group
-            dist.all_reduce(self._ptab.gflat, op=dist.ReduceOp.SUM, group=grp)
-            self._ptab.gflat.mul_(1.0 / dist.get_world_size(grp))
+            from . import dp
+            dp.allreduce_mean_(self._ptab.gflat, None if self._dp_group is True else self._dp_group)
         for key in plan.param_grads:
             p = self._pmap[key]
             g = self._ptab.gview(key)

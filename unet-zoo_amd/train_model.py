@@ -1,0 +1,186 @@
+"""Drop-in counterpart of the reference harness ``train_model.py`` for the native models.
+
+Scope: the TRAIN-STEP CONTRACT of ``UNetModel`` - build
+``exp_config.model(**8 kwargs)`` (train_model.py:34-42), Adam(lr=1e-3, weight_decay=1e-5) (:49),
+ReduceLROnPlateau('min', min_lr=1e-4, patience=50000) stepped on the loss (:50-51,:134), and per
+iteration: to-device, ``forward(patch, mask, training=True)``, ``loss(mask)``, ``zero_grad``,
+``backward``, ``step`` (:100-134) - plus ``save_model`` (:558-564).  Validation metrics (GED / NCC / Dice via medpy),
+image dumps and the LIDC / UZH / BraTS loaders are outside the hot path ("next" rows of SURVEY 8f).
+
+Experiment files of the reference are plain Python modules that import ``models.phiseg``,
+``data.lidc_data`` and ``utils`` (e.g. models/experiments/phiseg_7_5_12.py:1-5).  ``load_experiment``
+executes such a file unchanged with those names aliased to the native package, so
+``python -m unet_zoo_amd.train_model EXP_PATH LOCAL dummy`` keeps the reference's CLI (:568-572).
+With torchrun (WORLD_SIZE > 1) every rank trains on its own shard and gradients are averaged over
+RCCL inside ``loss.backward()``.
+"""
+import argparse
+import importlib.util
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+from . import dp
+from .optim import FusedAdam
+from .synthetic import synthetic_batch
+
+
+# --------------------------------------------------------------------------- data stand-in
+class _Split:
+    def __init__(self, images, labels):
+        self.images, self.labels = images, labels
+        self._rng = np.random.default_rng(0)
+
+    def next_batch(self, batch_size):
+        """(x (B,1,H,W) float32 in [-0.5,0.5], s (B,H,W) labels) like BatchProvider.next_batch (batch_provider.py:43-67)."""
+        idx = self._rng.choice(len(self.images), size=batch_size, replace=len(self.images) < batch_size)
+        return self.images[idx], self.labels[idx]
+
+
+class SyntheticData:
+    """Stand-in for ``exp_config.data_loader(sys_config, exp_config)`` when LIDC-IDRI is not on disk:
+    same surface (``.train.next_batch``, ``.validation.images/labels``), synthetic LIDC-like content."""
+
+    def __init__(self, sys_config=None, exp_config=None, n_train=256, n_val=32):
+        size = getattr(exp_config, "image_size", (1, 128, 128))
+        h, w = size[1], size[2]
+        x, m, _ = synthetic_batch(n_train + n_val, h, w, seed=7)
+        self.train = _Split(x[:n_train], m[:n_train, 0])
+        self.validation = _Split(x[n_train:], m[n_train:, 0])
+        self.test = self.validation
+
+
+def lidc_data(sys_config=None, exp_config=None):
+    return SyntheticData(sys_config, exp_config)
+
+
+def normalise_image(image):
+    """utils.normalise_image (utils.py:104-115): zero mean, unit standard deviation."""
+    img = np.float32(image.copy())
+    return (img - img.mean()) / (img.std() + 1e-20)
+
+
+def load_experiment(path):
+    """Execute a reference-style experiment module (train_model.py:584) against the native package."""
+    from . import models as native_models
+    alias = {"models": native_models, "models.phiseg": native_models.phiseg, "models.unet": native_models.unet,
+             "models.probabilistic_unet": native_models.probabilistic_unet}
+    data_pkg, lidc_mod, utils_mod = types.ModuleType("data"), types.ModuleType("data.lidc_data"), types.ModuleType("utils")
+    lidc_mod.lidc_data = lidc_data
+    data_pkg.lidc_data = lidc_mod
+    utils_mod.normalise_image = normalise_image
+    alias.update({"data": data_pkg, "data.lidc_data": lidc_mod, "utils": utils_mod})
+    saved = {k: sys.modules.get(k) for k in alias}
+    sys.modules.update(alias)
+    try:
+        spec = importlib.util.spec_from_file_location(os.path.splitext(os.path.basename(path))[0], path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
+
+
+# --------------------------------------------------------------------------- harness
+class UNetModel:
+    """Wrapper that trains a native model exactly as the reference harness does (train_model.py:27-136)."""
+
+    def __init__(self, exp_config, logger=None, tensorboard=False, log_root="./logs"):
+        kwargs = dict(input_channels=exp_config.input_channels, num_classes=exp_config.n_classes,
+                      num_filters=exp_config.filter_channels, latent_levels=exp_config.latent_levels,
+                      no_convs_fcomb=exp_config.no_convs_fcomb, beta=exp_config.beta,
+                      image_size=getattr(exp_config, "image_size", (1, 128, 128)), reversible=exp_config.use_reversible)
+        try:
+            self.net = exp_config.model(**kwargs)
+        except TypeError:
+            # the reference's own Unet rejects latent_levels / image_size (unet.py:88-90) and cannot be driven by
+            # its harness; here the two unsupported keywords are dropped instead
+            kwargs.pop("latent_levels"), kwargs.pop("image_size")
+            self.net = exp_config.model(**kwargs)
+        self.exp_config, self.batch_size = exp_config, getattr(exp_config, "batch_size", 12)
+        self.logger = logger or logging.getLogger("unet_zoo_amd")
+        self.device = self.net.device
+        self.optimizer = FusedAdam(self.net, lr=1e-3, weight_decay=1e-5)
+        self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", min_lr=1e-4, patience=50000)
+        self.rank, self.local_rank, self.world = dp.init_from_env()
+        if self.world > 1:
+            dp.broadcast_(self.net._ptab.pflat)
+            self.net.set_data_parallel(True)
+        self.log_root = log_root
+        self.tot_loss = self.kl_loss = self.reconstruction_loss = 0
+        self.iteration = 0
+
+    def train_step(self, x_b, s_b):
+        patch = torch.as_tensor(x_b, dtype=torch.float32).to(self.device)
+        mask = torch.unsqueeze(torch.as_tensor(s_b, dtype=torch.float32).to(self.device), 1)
+        self.mask, self.patch = mask, patch
+        self.net.forward(patch, mask, training=True)
+        self.loss = self.net.loss(mask)
+        self.tot_loss += self.loss.detach()
+        self.reconstruction_loss += getattr(self.net, "reconstruction_loss", 0)
+        self.kl_loss += getattr(self.net, "kl_divergence_loss", 0)
+        self.optimizer.zero_grad()
+        self.loss.backward()
+        self.optimizer.step()
+        return self.loss
+
+    def train(self, data, iterations=None):
+        self.net.train()
+        n_it = iterations if iterations is not None else self.exp_config.iterations
+        log_every = getattr(self.exp_config, "logging_frequency", 1000)
+        for self.iteration in range(1, n_it):
+            x_b, s_b = data.train.next_batch(self.batch_size)
+            loss = self.train_step(x_b, s_b)
+            if self.iteration % log_every == 0:
+                self.logger.info("Iteration {} Loss {}".format(self.iteration, float(loss)))
+                self.tot_loss = self.kl_loss = self.reconstruction_loss = 0
+            self.scheduler.step(loss.detach())          # train_model.py:134 (compares on the host: one sync per step)
+        self.logger.info("Finished training.")
+
+    @torch.no_grad()
+    def validate(self, data, n_images=8):
+        """Mean validation loss over the first images (full GED / NCC / Dice evaluation: SURVEY 8f-1)."""
+        self.net.eval()
+        x = torch.as_tensor(data.validation.images[:n_images], dtype=torch.float32).to(self.device)
+        m = torch.as_tensor(data.validation.labels[:n_images], dtype=torch.float32).unsqueeze(1).to(self.device)
+        self.net.forward(x, m, training=False)
+        val = float(self.net.loss(m)) if hasattr(self.net, "elbo") or hasattr(self.net, "loss") else float("nan")
+        self.net.train()
+        return val
+
+    def save_model(self, savename):
+        """<log_root>/<log_dir_name>/<experiment_name>/<experiment_name>_<savename>.pth (train_model.py:558-564)."""
+        name = self.exp_config.experiment_name + "_" + savename + ".pth"
+        log_dir = os.path.join(self.log_root, self.exp_config.log_dir_name, self.exp_config.experiment_name)
+        os.makedirs(log_dir, exist_ok=True)
+        path = os.path.join(log_dir, name)
+        if self.rank == 0:
+            torch.save({k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()}, path)
+        return path
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Script for training (native MI355X path)")
+    ap.add_argument("EXP_PATH", type=str, help="Path to experiment config file")
+    ap.add_argument("LOCAL", type=str, help="Is this script run on the local machine or the BIWI cluster?")
+    ap.add_argument("dummy", type=str, nargs="?", default="dummy", help="(unused, kept for CLI compatibility)")
+    ap.add_argument("--iterations", type=int, default=None)
+    args = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s")
+    exp_config = load_experiment(args.EXP_PATH)
+    model = UNetModel(exp_config)
+    data = exp_config.data_loader(None, exp_config) if hasattr(exp_config, "data_loader") else SyntheticData(None, exp_config)
+    model.train(data, iterations=args.iterations)
+    print(model.save_model("last"))
+
+
+if __name__ == "__main__":
+    main()
