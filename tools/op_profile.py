@@ -36,3 +36,24 @@ for r in rows:
 for (code, i), (ms, cnt, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
     extra = f"{fl / (ms / cnt) / 1e9:7.1f} TF/s" if fl else (f"{by / (ms / cnt) / 1e6:7.0f} GB/s" if by else "")
     print(f"{ms:8.3f} ms  x{cnt:<3d} {ms / cnt * 1e3:9.1f} us  {code:18s} {list(i)}  {extra}")
+# ---- aggregate by (family, resolution)
+byres = {}
+for r in rows:
+    code, i = r[2], r[3]
+    if code.startswith("CONV_FWD") or code.startswith("CONV_BWD"):
+        H = i[5]
+    elif code.startswith("BN_RELU_FWD"):
+        H = i[4]
+    elif code.startswith("BN_RELU_BWD"):
+        H = i[5]
+    else:
+        H = i[4] if len(i) > 4 else 0
+    fam = FAMILY.get("UZ_OP_" + code, "other")
+    d = byres.setdefault((fam, H), [0.0, 0, 0.0]); d[0] += r[0]; d[1] += 1; d[2] += r[4]
+print("---- ms by family x resolution")
+for fam in sorted({k[0] for k in byres}):
+    line = f"{fam:16s}"
+    for H in (128, 64, 32, 16, 8, 4, 2):
+        d = byres.get((fam, H))
+        line += f" | {H:3d}: " + (f"{d[0]:6.2f}ms x{d[1]:<3d}" + (f"{d[2]/d[0]/1e9:5.0f}TF" if d[2] else "       ") if d else " " * 20)
+    print(line)

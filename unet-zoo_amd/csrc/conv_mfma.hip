@@ -28,7 +28,7 @@ struct ConvP {
     const float* x; const float* w; const float* bias; float* y;
     int N, H, W, HW;
     int Cin, CinTot, Cout, CoutTot;   // GEMM-K channels (input view), GEMM-M channels (output view)
-    int wCi;                          // second dim of the weight tensor (the layer's true Cin)
+    int wCi, wCo;                     // dims 1 and 0 of the weight tensor (the layer's true Cin / Cout)
     int TW, TH, TB, lgTW, lgTH;
     int tilesX, tilesY, nCoTiles;
     int PW, PSI, PS;                  // patch row stride, patch floats per image, per channel
@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
     constexpr int WELEMS = COT * CK * KK;
     constexpr int WREGS = (WELEMS + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int BUF = WSZ + CK * p.PS;
+    static_assert(WELEMS % 256 == 0, "weight panel must divide evenly over the workgroup");
+    constexpr int PSR = JMAX * 256;          // LDS patch row stride (>= PS): every thread stores, no predication
+    const int BUF = WSZ + CK * PSR;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int wid0 = uz::xcd_remap(blockIdx.x, gridDim.x);
@@ -56,21 +58,50 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
     const int x0 = txi * p.TW, y0 = tyi * p.TH, b0 = tbi * p.TB;
     const int co0 = coT * COT;
 
-    // ---- per-thread staging map of the input patch (same for every channel and chunk)
-    int goff[JMAX];
+    // ---- staging maps, all chunk-invariant and held in registers.  Global loads are raw buffer loads
+    // (uniform resource + per-lane byte offset): the hardware range check returns 0 for padding pixels,
+    // for output-channel tiles that overhang Cout and for the K tail, so staging needs no predication,
+    // no 64-bit pointer arithmetic and no per-chunk index arithmetic.
+    constexpr unsigned OOB = 0x80000000u;
+    const int nImg = min(p.TB, p.N - b0);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + (size_t)b0 * p.CinTot * p.HW), 0,
+        (unsigned)(((size_t)(nImg - 1) * p.CinTot + p.Cin) * p.HW * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (unsigned)((size_t)p.wCo * p.wCi * KK * sizeof(float)), 0x00020000);
+    unsigned goff[JMAX], gmask[JMAX];   // byte offset of this thread's patch words inside channel 0; all-ones mask = padding
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
         const int r = tid + j * 256;
-        int g = -1;
+        unsigned g = 0, gm = 0xFFFFFFFFu;
         if (r < p.PS) {
             const int tb = r / p.PSI, rr = r - tb * p.PSI;
             const int py = rr / p.PW, px = rr - py * p.PW;
             const int b = b0 + tb, yy = y0 + py - HALO, xx = x0 + px - HALO;
-            if (b < p.N && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) g = tb * p.CinTot * p.HW + yy * p.W + xx;
+            if (b < p.N && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) { g = 4u * (unsigned)(tb * p.CinTot * p.HW + yy * p.W + xx); gm = 0; }
         }
-        goff[j] = g;
+        goff[j] = g; gmask[j] = gm;
     }
-    const float* xb = p.x + (size_t)b0 * p.CinTot * p.HW;
+    unsigned woff[WREGS];       // byte offset of this thread's weight words for chunk 0 (all ones: channel tile overhang)
+    int wlds[WREGS];            // their LDS word index inside the weight panel
+#pragma unroll
+    for (int i = 0; i < WREGS; ++i) {
+        const int e = tid + i * 256;
+        unsigned wo = 0xFFFFFFFFu;
+        int wl;
+        if (!DGRAD) {
+            const int co = e / (CK * KK), rem = e - co * (CK * KK), ci = rem / KK, tap = rem - ci * KK;
+            wl = (tap * CK + ci) * COTP + co;
+            if (co0 + co < p.Cout) wo = 4u * (unsigned)((co0 + co) * p.wCi * KK + rem);
+        } else {    // GEMM-K index k walks the weight's dim 0, GEMM-M index m its dim 1; taps flipped
+            const int k = e / (COT * KK), rem = e - k * (COT * KK), m = rem / KK, t = rem - m * KK;
+            wl = ((KK - 1 - t) * CK + k) * COTP + m;
+            if (co0 + m < p.Cout) wo = 4u * (unsigned)((k * p.wCi + co0) * KK + rem);
+        }
+        woff[i] = wo; wlds[i] = wl;
+    }
+    const unsigned wstep = 4u * (unsigned)(DGRAD ? CK * p.wCi * KK : CK * KK);      // weight byte step per chunk
+    const unsigned xstep = 4u * (unsigned)p.HW;                                      // input byte step per channel
 
     // ---- per-lane output pixels (B operand columns)
     int poff[NSUB], oidx[NSUB];
@@ -80,7 +111,7 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
         const int pp = wave * (32 * NSUB) + n * 32 + l31;
         const int tx = pp & (p.TW - 1), ty = (pp >> p.lgTW) & (p.TH - 1), tb = pp >> (p.lgTW + p.lgTH);
         const bool v = pp < npix && (b0 + tb) < p.N && (y0 + ty) < p.H && (x0 + tx) < p.W;
-        poff[n] = v ? (tb * p.PSI + ty * p.PW + tx + h * p.PS) : (h * p.PS);
+        poff[n] = v ? (tb * p.PSI + ty * p.PW + tx + h * PSR) : (h * PSR);
         oidx[n] = v ? ((b0 + tb) * (p.ksplit > 1 ? p.Cout : p.CoutTot) * p.HW + (y0 + ty) * p.W + (x0 + tx)) : -1;
     }
 
@@ -94,31 +125,24 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
 
     float pr[CK * JMAX], wr[WREGS];
 
+    // Branch-free staging.  K tail (channels >= Cin in the last chunk): the input rows are forced to zero
+    // by an all-ones offset; the matching weight words are either in-bounds neighbours (finite, multiplied
+    // by zero) or past the end of the tensor (range check returns 0), so they need no mask.
     auto gload = [&](int c) {
         const int ci0 = c * CK;
 #pragma unroll
         for (int ci = 0; ci < CK; ++ci) {
-            const bool cv = (ci0 + ci) < p.Cin;
-            const float* xc = xb + (size_t)(ci0 + ci) * p.HW;
+            const unsigned cvm = (ci0 + ci) < p.Cin ? 0u : 0xFFFFFFFFu;        // uniform
+            const unsigned cbase = (unsigned)(ci0 + ci) * xstep;
 #pragma unroll
-            for (int j = 0; j < JMAX; ++j) pr[ci * JMAX + j] = (cv && goff[j] >= 0) ? xc[goff[j]] : 0.f;
+            for (int j = 0; j < JMAX; ++j)
+                pr[ci * JMAX + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (goff[j] + cbase) | gmask[j] | cvm, 0, 0));
         }
+        const unsigned wbase = (unsigned)c * wstep;
 #pragma unroll
         for (int i = 0; i < WREGS; ++i) {
-            const int e = tid + i * 256;
-            float v = 0.f;
-            if (e < WELEMS) {
-                if (!DGRAD) {
-                    const int co = e / (CK * KK), rem = e - co * (CK * KK), ci = rem / KK;
-                    if (co0 + co < p.Cout && ci0 + ci < p.Cin)
-                        v = p.w[((size_t)(co0 + co) * p.wCi + ci0) * KK + rem];
-                } else {   // GEMM-K index k walks the weight's dim 0, GEMM-M index m its dim 1
-                    const int k = e / (COT * KK), rem = e - k * (COT * KK), m = rem / KK;
-                    if (ci0 + k < p.Cin && co0 + m < p.Cout)
-                        v = p.w[((size_t)(ci0 + k) * p.wCi + co0) * KK + rem];
-                }
-            }
-            wr[i] = v;
+            const unsigned off = woff[i] == 0xFFFFFFFFu ? woff[i] : woff[i] + wbase;
+            wr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, off, 0, 0));
         }
     };
     auto lstore = [&](int buf) {
@@ -127,23 +151,9 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
 #pragma unroll
         for (int ci = 0; ci < CK; ++ci)
 #pragma unroll
-            for (int j = 0; j < JMAX; ++j) {
-                const int r = tid + j * 256;
-                if (r < p.PS) Pl[ci * p.PS + r] = pr[ci * JMAX + j];
-            }
+            for (int j = 0; j < JMAX; ++j) Pl[ci * PSR + tid + j * 256] = pr[ci * JMAX + j];
 #pragma unroll
-        for (int i = 0; i < WREGS; ++i) {
-            const int e = tid + i * 256;
-            if (e < WELEMS) {
-                if (!DGRAD) {
-                    const int co = e / (CK * KK), rem = e - co * (CK * KK), ci = rem / KK, tap = rem - ci * KK;
-                    Wl[(tap * CK + ci) * COTP + co] = wr[i];
-                } else {
-                    const int k = e / (COT * KK), rem = e - k * (COT * KK), m = rem / KK, t = rem - m * KK;
-                    Wl[((KK - 1 - t) * CK + k) * COTP + m] = wr[i];
-                }
-            }
-        }
+        for (int i = 0; i < WREGS; ++i) Wl[wlds[i]] = wr[i];
     };
 
     const int nChunksAll = (p.Cin + CK - 1) / CK;
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
 #pragma unroll
                 for (int m = 0; m < MSUB; ++m) a[m] = Al[(tap * CK + 2 * kk) * COTP + m * 32];
 #pragma unroll
-                for (int n = 0; n < NSUB; ++n) b[n] = Pl[poff[n] + 2 * kk * p.PS + tapoff];
+                for (int n = 0; n < NSUB; ++n) b[n] = Pl[poff[n] + 2 * kk * PSR + tapoff];
 #pragma unroll
                 for (int m = 0; m < MSUB; ++m)
 #pragma unroll
@@ -307,7 +317,7 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     ConvP p;
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.N = N; p.H = H; p.W = W; p.HW = H * W;
-    p.Cin = Kc; p.CinTot = KcTot; p.Cout = Mc; p.CoutTot = McTot; p.wCi = wCi;
+    p.Cin = Kc; p.CinTot = KcTot; p.Cout = Mc; p.CoutTot = McTot; p.wCi = wCi; p.wCo = dgrad ? Kc : Mc;
     p.TW = g.TW; p.TH = g.TH; p.TB = g.TB; p.lgTW = ilog2(g.TW); p.lgTH = ilog2(g.TH);
     p.tilesX = g.tilesX; p.tilesY = g.tilesY;
     p.PW = g.PW; p.PSI = g.PSI; p.PS = g.PS;
@@ -317,7 +327,7 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     p.nCoTiles = ceil_div(Mc, cot);
     const int jmax = g.PS <= 512 ? 2 : 4;
     const int kk = ks * ks;
-    const size_t smem = 2 * (size_t)(kk * CK * (cot + 1) + CK * g.PS) * sizeof(float);
+    const size_t smem = 2 * (size_t)(kk * CK * (cot + 1) + CK * jmax * 256) * sizeof(float);
     const long long base_grid = (long long)g.tilesX * g.tilesY * g.tilesB * p.nCoTiles;
     pick_split(base_grid, ceil_div(Kc, CK), p.ksplit, p.cps);
     const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * N * Mc * H * W * sizeof(float) : 0;

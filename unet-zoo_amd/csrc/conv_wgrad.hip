@@ -13,6 +13,7 @@
 // Partial sums go to slabs; an ordered second kernel adds them into dW (bitwise reproducible; no
 // float atomics).  LDS rows are padded to an odd stride so that the 32 channel-lanes of a fragment
 // read hit 32 different banks.
+#include <stdlib.h>
 #include <type_traits>
 #include "uz_common.h"
 
@@ -207,14 +208,15 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgP p) {
 // immediate, the 32 pixel-pair steps of a tile are fully unrolled (LDS reads are scheduled far ahead
 // of the MFMAs that consume them), and the staging map is one fixed patch word per thread
 // (408 of 512 threads active; a thread walks the input channels with a constant stride).
-template <int WM, int WN>
+template <int WM, int WN, int THF>
 __global__ __launch_bounds__(NT, 2) void wgrad_fast_kernel(const WgP p) {
-    constexpr int PW = 34, PS = 136, PSP = 137, PTP = 65;
+    constexpr int PW = 34, PS = (THF + 2) * PW, PSP = PS | 1, PT = 32 * THF, PTP = PT + 1;
+    constexpr int XG = NT / PS;             // channel groups of the X staging map (3 for 4x34 patches, 2 for 6x34)
     constexpr int COT = 32 * WM, CIT = 32 * WN, WK = 8 / (WM * WN * 2);
-    constexpr int DYR = COT / 8, XRN = (CIT + 2) / 3, NSTEP = 32 / WK;
+    constexpr int DYR = COT * PT / NT, XRN = (CIT + XG - 1) / XG, NSTEP = (PT / 2) / WK, DCS = NT / PT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dYl = lds;                       // [COT][65]
-    float* Xl = dYl + COT * PTP;            // [CIT][137]
+    float* Xl = dYl + COT * PTP;            // [CIT][PSP]
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -229,39 +231,51 @@ __global__ __launch_bounds__(NT, 2) void wgrad_fast_kernel(const WgP p) {
     for (int i = tid; i < COT * PTP + CIT * PSP + 64; i += NT) lds[i] = 0.f;
 
     // staging maps
-    const int pl = tid & 63, ptx = pl & 31, pty = pl >> 5, dco = tid >> 6;
-    const bool xact = tid < 3 * PS;
+    const int pl = tid & (PT - 1), ptx = pl & 31, pty = pl >> 5, dco = tid / PT;
+    const bool xact = tid < XG * PS;
     const int xg = tid / PS, xr = tid - xg * PS;
     const int xpy = xr / PW, xpx = xr - xpy * PW;
 
+    // Branch-free global staging through raw buffer loads: an all-ones offset fails the hardware range check
+    // and returns 0 (padding pixels, channel-tile overhang).
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dy), 0, (unsigned)(((size_t)(p.N - 1) * p.CoutTot + p.Cout) * p.HW * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)(((size_t)(p.N - 1) * p.CinTot + p.Cin) * p.HW * sizeof(float)), 0x00020000);
+    const unsigned dlane = 4u * (unsigned)(dco * p.HW + pty * p.W + ptx);               // this thread's dY word inside a tile
+    const unsigned xlane = 4u * (unsigned)(xg * p.HW + (xpy - 1) * p.W + (xpx - 1));    // may wrap below zero: added to the tile base
+    const int cmaxo = min(COT, p.Cout - co0), cmaxi = min(CIT, p.Cin - ci0);
     float dreg[DYR], xreg[XRN];
     auto gload = [&](int t) {
         const int txi = t % p.tilesX, t2 = t / p.tilesX;
-        const int x0 = txi * 32, y0 = (t2 % p.tilesY) * 2, b0 = t2 / p.tilesY;
+        const int x0 = txi * 32, y0 = (t2 % p.tilesY) * THF, b0 = t2 / p.tilesY;
         {
-            const bool pv = (y0 + pty) < p.H && (x0 + ptx) < p.W;
-            const float* dsrc = p.dy + ((size_t)b0 * p.CoutTot + co0 + dco) * p.HW + (y0 + pty) * p.W + (x0 + ptx);
+            const unsigned pm = ((y0 + pty) < p.H && (x0 + ptx) < p.W) ? 0u : 0xFFFFFFFFu;
+            const unsigned base = 4u * (unsigned)((b0 * p.CoutTot + co0) * p.HW + y0 * p.W + x0) + dlane;
 #pragma unroll
-            for (int j = 0; j < DYR; ++j) dreg[j] = (pv && (co0 + dco + 8 * j) < p.Cout) ? dsrc[(size_t)(8 * j) * p.HW] : 0.f;
+            for (int j = 0; j < DYR; ++j) {
+                const unsigned cm = (dco + DCS * j) < cmaxo ? 0u : 0xFFFFFFFFu;
+                dreg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, (base + 4u * (unsigned)(DCS * j * p.HW)) | pm | cm, 0, 0));
+            }
         }
         {
             const int yy = y0 + xpy - 1, xx = x0 + xpx - 1;
-            const bool v = xact && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-            const float* xsrc = p.x + ((size_t)b0 * p.CinTot + ci0 + xg) * p.HW + yy * p.W + xx;
+            const unsigned pm = (xact && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? 0u : 0xFFFFFFFFu;
+            const unsigned base = 4u * (unsigned)((b0 * p.CinTot + ci0) * p.HW + y0 * p.W + x0) + xlane;
 #pragma unroll
             for (int i = 0; i < XRN; ++i) {
-                const int ci = xg + 3 * i;
-                xreg[i] = (v && ci < CIT && (ci0 + ci) < p.Cin) ? xsrc[(size_t)(3 * i) * p.HW] : 0.f;
+                const unsigned cm = (xg + XG * i) < cmaxi ? 0u : 0xFFFFFFFFu;
+                xreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (base + 4u * (unsigned)(XG * i * p.HW)) | pm | cm, 0, 0));
             }
         }
     };
     auto lstore = [&]() {
 #pragma unroll
-        for (int j = 0; j < DYR; ++j) dYl[(dco + 8 * j) * PTP + pl] = dreg[j];
+        for (int j = 0; j < DYR; ++j) dYl[(dco + DCS * j) * PTP + pl] = dreg[j];
         if (xact) {
 #pragma unroll
             for (int i = 0; i < XRN; ++i)
-                if (xg + 3 * i < CIT) Xl[(xg + 3 * i) * PSP + xr] = xreg[i];
+                if (xg + XG * i < CIT) Xl[(xg + XG * i) * PSP + xr] = xreg[i];
         }
     };
 
@@ -355,15 +369,18 @@ __global__ __launch_bounds__(64) void channel_sum_final(const double* __restrict
     if (threadIdx.x == 0) db[c] = (float)s;
 }
 
+static int uz_wgrad_tile_rows() { static int v = getenv("UZ_WGRAD_ROWS") ? atoi(getenv("UZ_WGRAD_ROWS")) : 4; return v; }
+
 struct WGeom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB, T, S, nCoT, nCiT, WM, WN, WK, pf; };
 
 WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
     WGeom g;
     g.TW = W >= 32 ? 32 : uz::pow2_ceil(W);
+    const int npx = (halo == 1 && W >= 32 && H >= 64 && uz_wgrad_tile_rows() == 4) ? 128 : 64;   // fast kernel: 4 x 32 tiles on the large planes
     g.TH = uz::pow2_ceil(H);
-    if (g.TH > 64 / g.TW) g.TH = 64 / g.TW;
+    if (g.TH > npx / g.TW) g.TH = npx / g.TW;
     if (g.TH < 1) g.TH = 1;
-    g.TB = 64 / (g.TW * g.TH);
+    g.TB = npx / (g.TW * g.TH);
     if (g.TB > uz::pow2_ceil(N)) g.TB = uz::pow2_ceil(N);
     g.PW = g.TW + 2 * halo;
     g.PSI = (g.TH + 2 * halo) * g.PW;
@@ -415,7 +432,7 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
     p.TW = g.TW; p.TH = g.TH; p.TB = g.TB; p.lgTW = uz::ilog2(g.TW); p.lgTH = uz::ilog2(g.TH);
     p.tilesX = g.tilesX; p.tilesY = g.tilesY; p.T = g.T; p.S = g.S;
     p.PW = g.PW; p.PSI = g.PSI; p.PS = g.PS; p.PSP = g.PS | 1;
-    p.PT = 64; p.PTP = 65;
+    p.PT = g.TW * g.TH * g.TB > 64 ? 128 : 64; p.PTP = p.PT + 1;
     p.nCoT = g.nCoT; p.nCiT = g.nCiT;
     const int cot = 32 * g.WM, cit = 32 * g.WN;
     const size_t smem = ((size_t)cot * p.PTP + (size_t)cit * p.PSP + 64 + 2 * (size_t)p.PS) * sizeof(float);
@@ -439,11 +456,11 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         else if (g.WN == 2) UZ_WG_PF(KS_, 1, 2);                                     \
         else UZ_WG_PF(KS_, 1, 1);                                                    \
     } while (0)
-    const bool fast = ks == 3 && g.TW == 32 && g.TH == 2 && g.TB == 1;
-#define UZ_WG_FAST(WM_, WN_)                                                                                    \
+    const bool fast = ks == 3 && g.TW == 32 && (g.TH == 2 || g.TH == 4) && g.TB == 1;
+#define UZ_WG_FAST(WM_, WN_, THF_)                                                                                 \
     do {                                                                                                         \
         static bool attr = false;                                                                                \
-        auto kern = wgrad_fast_kernel<WM_, WN_>;                                                                 \
+        auto kern = wgrad_fast_kernel<WM_, WN_, THF_>;                                                                 \
         if (!attr) {                                                                                             \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
                 return uz::fail("wgrad: cannot raise dynamic LDS limit");                                        \
@@ -451,11 +468,16 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         }                                                                                                        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);                                             \
     } while (0)
-    if (fast) {
-        if (g.WM == 2 && g.WN == 2) UZ_WG_FAST(2, 2);
-        else if (g.WM == 2) UZ_WG_FAST(2, 1);
-        else if (g.WN == 2) UZ_WG_FAST(1, 2);
-        else UZ_WG_FAST(1, 1);
+    if (fast && g.TH == 4) {
+        if (g.WM == 2 && g.WN == 2) UZ_WG_FAST(2, 2, 4);
+        else if (g.WM == 2) UZ_WG_FAST(2, 1, 4);
+        else if (g.WN == 2) UZ_WG_FAST(1, 2, 4);
+        else UZ_WG_FAST(1, 1, 4);
+    } else if (fast) {
+        if (g.WM == 2 && g.WN == 2) UZ_WG_FAST(2, 2, 2);
+        else if (g.WM == 2) UZ_WG_FAST(2, 1, 2);
+        else if (g.WN == 2) UZ_WG_FAST(1, 2, 2);
+        else UZ_WG_FAST(1, 1, 2);
     } else if (ks == 3) UZ_WG_TILE(3); else UZ_WG_TILE(1);
     if (int rc = uz::check_launch("wgrad_kernel")) return rc;
     const int n = ks * ks * Cout * Cin;
