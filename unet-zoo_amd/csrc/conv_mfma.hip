@@ -16,6 +16,7 @@
 // double buffered: global loads for chunk c+1 are issued before the 36 k-steps of chunk c and
 // written to the other buffer afterwards (one barrier per chunk).  All 9 taps reuse the same
 // patch through a constant LDS offset, so HBM/L2 sees each input element once per channel tile.
+#include <stdlib.h>
 #include "uz_common.h"
 
 namespace {
@@ -251,8 +252,10 @@ struct Geom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB; };
 // the 256 CUs (deep, small-resolution levels: 2x2 ... 16x16 pixels)
 void pick_split(long long base_grid, int nChunks, int& ksplit, int& cps) {
     ksplit = 1; cps = nChunks;
-    if (base_grid >= 256 || nChunks <= 1) return;
-    long long want = (512 + base_grid - 1) / base_grid;
+    static const int thr = getenv("UZ_SPLIT_THR") ? atoi(getenv("UZ_SPLIT_THR")) : 512;
+    static const int tgt = getenv("UZ_SPLIT_TGT") ? atoi(getenv("UZ_SPLIT_TGT")) : 512;
+    if (base_grid >= thr || nChunks <= 1) return;
+    long long want = (tgt + base_grid - 1) / base_grid;
     if (want > nChunks) want = nChunks;
     cps = (int)((nChunks + want - 1) / want);
     ksplit = (nChunks + cps - 1) / cps;

@@ -13,6 +13,7 @@
 // Partial sums go to slabs; an ordered second kernel adds them into dW (bitwise reproducible; no
 // float atomics).  LDS rows are padded to an odd stride so that the 32 channel-lanes of a fragment
 // read hit 32 different banks.
+#include <math.h>
 #include <stdlib.h>
 #include <type_traits>
 #include "uz_common.h"
@@ -396,13 +397,24 @@ WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
     g.nCoT = uz::ceil_div(Cout, 32 * g.WM);
     g.nCiT = uz::ceil_div(Cin, 32 * g.WN);
     g.pf = (32 * g.WN * g.PS <= 18 * 512) ? 1 : 0;
-    // pixel splits: aim at ~1024 workgroups (four rounds over the 256 CUs keep the tail short), but give
-    // every workgroup at least 4 tiles so that the LDS clear, the pipeline fill and the slab write-out
-    // are amortised (slab traffic grows with S)
-    int s = 1024 / (g.nCoT * g.nCiT);
-    if (s > g.T / 4) s = g.T / 4;
-    if (s < 1) s = 1;
-    g.S = s;
+    // pixel splits S: small cost model instead of a fixed target.  More splits = more workgroups in flight
+    // (the only parallelism a low-resolution layer has) but S*WK partial slabs of Cout*Cin*k*k floats to
+    // write and re-read; fewer splits = longer serial tile loops per workgroup.
+    {
+        const int nt = g.nCoT * g.nCiT;
+        const double kk = halo ? 9.0 : 1.0, n_out = kk * Cout * Cin;
+        const double px = (double)g.TW * g.TH * g.TB;
+        const double t_tile = (32.0 * g.WM) * (32.0 * g.WN) * kk * px * 2.0 / (613e9 * 0.6) + 1.0e-6;   // s per tile per workgroup
+        const int slots = 256 * ((g.WM * g.WN == 4 && halo) ? 1 : 2);
+        double best = 1e30;
+        int s = 1;
+        for (int c = 1; c <= g.T; c *= 2) {
+            const double rounds = ceil((double)nt * c / slots);
+            const double t = rounds * ceil((double)g.T / c) * t_tile + (double)c * g.WK * n_out * 4.0 * 2.0 / 2.5e12 + 4e-6 * (c * g.WK > 64 ? 2 : 1);
+            if (t < best) { best = t; s = c; }
+        }
+        g.S = s;
+    }
     return g;
 }
 
