@@ -114,12 +114,26 @@ def profile_families(net, plan, reps=3):
     return fam
 
 
-def cpu_baseline(batch, steps):
-    """CPU oracle timed on the host cores (bounded sample).  Only the baseline leg imports oracle/."""
+def usable_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(batch, budget_s=25.0):
+    """CPU oracle timed on the host cores on a bounded sample (about `budget_s` seconds of CPU work).
+    Only this leg of bench.py imports oracle/."""
     import oracle
     from unet_zoo_amd.models.phiseg import phiseg_spec
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    cores = usable_cores()
+    threads = min(cores, 32)                  # oneDNN / OpenMP stop scaling (and thrash) far below 256 threads
+    torch.set_num_threads(threads)
     sd = oracle.deterministic_state_dict(phiseg_spec(1, 2, FILTERS), seed=3)
     leaves = {}
     for k, v in sd.items():
@@ -129,7 +143,8 @@ def cpu_baseline(batch, steps):
         leaves[k] = t
     shapes = oracle.phiseg_eps_shapes(batch, 128, 128)
     state, times = {}, []
-    for step in range(steps + 1):
+    t_start = time.perf_counter()
+    for step in range(4):
         x, mask, eps = oracle.synthetic_batch(batch, 128, 128, seed=100 + step, eps_shapes=shapes + shapes)
         e = [torch.from_numpy(a) for a in eps]
         t0 = time.perf_counter()
@@ -142,12 +157,15 @@ def cpu_baseline(batch, steps):
         new = oracle.adam_reference_step(params, {k: v.grad for k, v in params.items()}, state)
         for k, v in new.items():
             leaves[k] = v.requires_grad_(True)
-        if step > 0:
-            times.append(time.perf_counter() - t0)
-    sec = sum(times) / len(times)
-    return dict(value=round(batch / sec, 3), unit="images/s", cores=cores, kind="port",
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s:
+            break
+    timed = times[1:] if len(times) > 1 else times           # drop the warm-up step when there was time for more
+    sec = sum(timed) / len(timed)
+    return dict(value=round(batch / sec, 3), unit="images/s", cores=threads, kind="port",
                 sample=f"CPU oracle (functional torch fp32 restatement of the reference graph), PHiSeg 7/5 128x128 batch {batch}, "
-                       f"{steps} timed steps after 1 warm-up, fwd+loss+bwd+Adam, {cores} threads, {sec:.2f} s/step")
+                       f"{len(timed)} timed step(s){' after 1 warm-up' if len(times) > 1 else ' (warm-up only: budget exhausted)'}, "
+                       f"fwd+loss+bwd+Adam, {threads} threads of {cores} usable cores, {sec:.2f} s/step")
 
 
 def main():
@@ -159,7 +177,7 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-family HIP-event pass")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=4)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -251,7 +269,7 @@ def main():
                                 graphs=not args.no_graphs, final_loss=final_loss),
                     roofline=roof)
         if not args.skip_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, 2)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(line))
     if dist:
         dist.destroy_process_group()
