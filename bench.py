@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-family HIP-event pass")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
-    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=8)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -1,0 +1,228 @@
+// 1x1 convolutions with very few output channels (<= 8): the latent / logit heads of the models
+// (mu_conv, sigma_conv phiseg.py:95-96; s_layer phiseg.py:281-284; Unet.last_layer unet.py:122;
+// Fcomb.last_layer; AxisAlignedConvGaussian.conv_layer probabilistic_unet.py:95).
+// With 2..8 outputs there is no dense contraction to put on the matrix cores: the op is a streaming
+// read of the input planes (HBM-bound), so these are float4 VALU kernels:
+//   fwd        y[b,n,p]  = bias[n] + sum_c w[n][c] x[b,c,p]          reads x once
+//   bwd_data   dx[b,c,p] (+)= sum_n w[n][c] dy[b,n,p]                writes dx once
+//   bwd_weight dw[n][c] = sum_{b,p} dy[b,n,p] x[b,c,p], db[n] = sum dy   reads x once, fp64 ordered partials
+#include "uz_common.h"
+
+namespace {
+
+constexpr int MAXN = 8;
+constexpr int PIX = 1024;        // pixels per workgroup (256 threads x float4)
+
+struct C1P {
+    const float* x; const float* w; const float* bias; const float* dy; float* y; float* dx; double* part;
+    int Cin, CinTot, Cout, CoutTot, N, HW, nchunk, accumulate;
+};
+
+template <int NO, bool VEC>
+__global__ __launch_bounds__(256) void c1_fwd(const C1P p) {
+    __shared__ float ws[MAXN * 512];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < NO * p.Cin; i += 256) ws[i] = p.w[i];
+    __syncthreads();
+    const float* xb = p.x + (size_t)b * p.CinTot * p.HW;
+    float* yb = p.y + (size_t)b * p.CoutTot * p.HW;
+    if (VEC) {
+        const int q = (blockIdx.x * 256 + threadIdx.x) * 4;
+        if (q >= p.HW) return;
+        float4 acc[NO];
+#pragma unroll
+        for (int n = 0; n < NO; ++n) { const float bv = p.bias ? p.bias[n] : 0.f; acc[n] = make_float4(bv, bv, bv, bv); }
+        for (int c = 0; c < p.Cin; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)c * p.HW + q);
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+                const float wv = ws[n * p.Cin + c];
+                acc[n].x = fmaf(wv, v.x, acc[n].x); acc[n].y = fmaf(wv, v.y, acc[n].y);
+                acc[n].z = fmaf(wv, v.z, acc[n].z); acc[n].w = fmaf(wv, v.w, acc[n].w);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NO; ++n) *reinterpret_cast<float4*>(yb + (size_t)n * p.HW + q) = acc[n];
+    } else {
+        for (int q = blockIdx.x * PIX + threadIdx.x; q < min(p.HW, (int)(blockIdx.x + 1) * PIX); q += 256) {
+            float acc[NO];
+#pragma unroll
+            for (int n = 0; n < NO; ++n) acc[n] = p.bias ? p.bias[n] : 0.f;
+            for (int c = 0; c < p.Cin; ++c) {
+                const float v = xb[(size_t)c * p.HW + q];
+#pragma unroll
+                for (int n = 0; n < NO; ++n) acc[n] = fmaf(ws[n * p.Cin + c], v, acc[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < NO; ++n) yb[(size_t)n * p.HW + q] = acc[n];
+        }
+    }
+}
+
+template <int NO, bool VEC>
+__global__ __launch_bounds__(256) void c1_bwd_data(const C1P p) {
+    __shared__ float ws[MAXN * 512];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < NO * p.Cin; i += 256) ws[i] = p.w[i];
+    __syncthreads();
+    const float* db = p.dy + (size_t)b * p.CoutTot * p.HW;
+    float* xb = p.dx + (size_t)b * p.CinTot * p.HW;
+    if (VEC) {
+        const int q = (blockIdx.x * 256 + threadIdx.x) * 4;
+        if (q >= p.HW) return;
+        float4 g[NO];
+#pragma unroll
+        for (int n = 0; n < NO; ++n) g[n] = *reinterpret_cast<const float4*>(db + (size_t)n * p.HW + q);
+        for (int c = 0; c < p.Cin; ++c) {
+            float4* dst = reinterpret_cast<float4*>(xb + (size_t)c * p.HW + q);
+            float4 r = p.accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+                const float wv = ws[n * p.Cin + c];
+                r.x = fmaf(wv, g[n].x, r.x); r.y = fmaf(wv, g[n].y, r.y); r.z = fmaf(wv, g[n].z, r.z); r.w = fmaf(wv, g[n].w, r.w);
+            }
+            *dst = r;
+        }
+    } else {
+        for (int q = blockIdx.x * PIX + threadIdx.x; q < min(p.HW, (int)(blockIdx.x + 1) * PIX); q += 256) {
+            float g[NO];
+#pragma unroll
+            for (int n = 0; n < NO; ++n) g[n] = db[(size_t)n * p.HW + q];
+            for (int c = 0; c < p.Cin; ++c) {
+                float* dst = xb + (size_t)c * p.HW + q;
+                float r = p.accumulate ? *dst : 0.f;
+#pragma unroll
+                for (int n = 0; n < NO; ++n) r = fmaf(ws[n * p.Cin + c], g[n], r);
+                *dst = r;
+            }
+        }
+    }
+}
+
+// grid (Cin, nchunk): block (c, k) reduces its slice of the N*HW pixels for channel c against all NO outputs
+template <int NO>
+__global__ __launch_bounds__(256) void c1_bwd_weight_partial(const C1P p) {
+    __shared__ double sm[4 * 2 * MAXN];
+    const int c = blockIdx.x, k = blockIdx.y;
+    const bool do_bias = (c == 0);            // the c == 0 blocks also sum dy for the bias gradient
+    const long long total = (long long)p.N * p.HW;
+    const long long per = (total + p.nchunk - 1) / p.nchunk;
+    const long long lo = k * per, hi = min(total, lo + per);
+    float acc[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) acc[n] = 0.f;
+    double dacc[2 * NO];
+#pragma unroll
+    for (int n = 0; n < 2 * NO; ++n) dacc[n] = 0.0;
+    int cnt = 0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const int b = (int)(i / p.HW), q = (int)(i - (long long)b * p.HW);
+        const float xv = p.x[((size_t)b * p.CinTot + c) * p.HW + q];
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+            const float g = p.dy[((size_t)b * p.CoutTot + n) * p.HW + q];
+            acc[n] = fmaf(g, xv, acc[n]);
+            if (do_bias) dacc[NO + n] += g;
+        }
+        if (++cnt == 64) {          // flush the fp32 running sums into fp64 regularly
+#pragma unroll
+            for (int n = 0; n < NO; ++n) { dacc[n] += acc[n]; acc[n] = 0.f; }
+            cnt = 0;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NO; ++n) dacc[n] += acc[n];
+    uz::block_sum_d<2 * NO>(dacc, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int n = 0; n < NO; ++n) p.part[((size_t)k * NO + n) * p.Cin + c] = dacc[n];
+        if (do_bias) {
+            double* pb = p.part + (size_t)p.nchunk * NO * p.Cin;
+#pragma unroll
+            for (int n = 0; n < NO; ++n) pb[k * NO + n] = dacc[NO + n];
+        }
+    }
+}
+template <int NO>
+__global__ __launch_bounds__(256) void c1_bwd_weight_final(const double* __restrict__ part, int nchunk, int Cin, float* __restrict__ dw,
+                                                            float* __restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < NO * Cin) {
+        double s = 0.0;
+        for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * NO * Cin + i];
+        dw[i] = (float)s;
+    }
+    if (db && i < NO) {
+        const double* pb = part + (size_t)nchunk * NO * Cin;
+        double s = 0.0;
+        for (int k = 0; k < nchunk; ++k) s += pb[k * NO + i];
+        db[i] = (float)s;
+    }
+}
+inline bool vec4(int HW, const void* a, const void* b) {
+    return HW % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0;
+}
+
+}  // namespace
+
+namespace uz {
+
+bool conv1x1_small_ok(int Cin, int Cout) { return Cout <= MAXN && Cin <= 512; }
+
+#define C1_DISPATCH(KERN, VECFLAG, GRID)                                                                     \
+    switch (p.Cout) {                                                                                        \
+        case 1: if (VECFLAG) hipLaunchKernelGGL((KERN<1, true>), GRID, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERN<1, false>), GRID, dim3(256), 0, st, p); break; \
+        case 2: if (VECFLAG) hipLaunchKernelGGL((KERN<2, true>), GRID, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERN<2, false>), GRID, dim3(256), 0, st, p); break; \
+        case 3: if (VECFLAG) hipLaunchKernelGGL((KERN<3, true>), GRID, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERN<3, false>), GRID, dim3(256), 0, st, p); break; \
+        case 4: if (VECFLAG) hipLaunchKernelGGL((KERN<4, true>), GRID, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERN<4, false>), GRID, dim3(256), 0, st, p); break; \
+        case 6: if (VECFLAG) hipLaunchKernelGGL((KERN<6, true>), GRID, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERN<6, false>), GRID, dim3(256), 0, st, p); break; \
+        case 8: if (VECFLAG) hipLaunchKernelGGL((KERN<8, true>), GRID, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERN<8, false>), GRID, dim3(256), 0, st, p); break; \
+        default: return -2;                                                                                  \
+    }
+
+// returns -2 when this (Cout) is not covered (caller falls back to the MFMA kernel)
+int conv1x1_small_fwd(const float* x, int Cin, int CinTot, const float* w, const float* bias, float* y, int Cout, int CoutTot,
+                      int N, int H, int W, hipStream_t st) {
+    C1P p = {}; p.x = x; p.w = w; p.bias = bias; p.y = y; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot; p.N = N; p.HW = H * W;
+    const bool v = vec4(p.HW, x, y);
+    const dim3 grid(ceil_div(p.HW, PIX), N);
+    C1_DISPATCH(c1_fwd, v, grid)
+    return check_launch("c1_fwd");
+}
+int conv1x1_small_bwd_data(const float* dy, int Cout, int CoutTot, const float* w, float* dx, int Cin, int CinTot,
+                           int N, int H, int W, int accumulate, hipStream_t st) {
+    C1P p = {}; p.dy = dy; p.w = w; p.dx = dx; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot; p.N = N; p.HW = H * W;
+    p.accumulate = accumulate;
+    const bool v = vec4(p.HW, dy, dx);
+    const dim3 grid(ceil_div(p.HW, PIX), N);
+    C1_DISPATCH(c1_bwd_data, v, grid)
+    return check_launch("c1_bwd_data");
+}
+size_t conv1x1_small_bwd_weight_ws(int Cin, int Cout, int N, int H, int W) {
+    const long long total = (long long)N * H * W;
+    int nchunk = (int)((total + 16383) / 16384);
+    if (nchunk > 64) nchunk = 64;
+    return ((size_t)nchunk * Cout * Cin + (size_t)nchunk * Cout) * sizeof(double);
+}
+int conv1x1_small_bwd_weight(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* dw, float* db,
+                             int N, int H, int W, void* ws, hipStream_t st) {
+    C1P p = {}; p.x = x; p.dy = dy; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot; p.N = N; p.HW = H * W;
+    const long long total = (long long)N * H * W;
+    p.nchunk = (int)((total + 16383) / 16384);
+    if (p.nchunk > 64) p.nchunk = 64;
+    p.part = static_cast<double*>(ws);
+    const dim3 grid(Cin, p.nchunk);
+    const int fg = ceil_div(Cout * Cin, 256);
+#define C1_W(NO_)                                                                                              \
+    case NO_:                                                                                                  \
+        hipLaunchKernelGGL(c1_bwd_weight_partial<NO_>, grid, dim3(256), 0, st, p);                            \
+        hipLaunchKernelGGL(c1_bwd_weight_final<NO_>, dim3(fg), dim3(256), 0, st, p.part, p.nchunk, Cin, dw, db); \
+        break;
+    switch (Cout) {
+        C1_W(1) C1_W(2) C1_W(3) C1_W(4) C1_W(6) C1_W(8)
+        default: return -2;
+    }
+    return check_launch("c1_bwd_weight");
+}
+
+}  // namespace uz

@@ -16,7 +16,6 @@
 // double buffered: global loads for chunk c+1 are issued before the 36 k-steps of chunk c and
 // written to the other buffer afterwards (one barrier per chunk).  All 9 taps reuse the same
 // patch through a constant LDS offset, so HBM/L2 sees each input element once per channel tile.
-#include <stdlib.h>
 #include "uz_common.h"
 
 namespace {
@@ -252,10 +251,8 @@ struct Geom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB; };
 // the 256 CUs (deep, small-resolution levels: 2x2 ... 16x16 pixels)
 void pick_split(long long base_grid, int nChunks, int& ksplit, int& cps) {
     ksplit = 1; cps = nChunks;
-    static const int thr = getenv("UZ_SPLIT_THR") ? atoi(getenv("UZ_SPLIT_THR")) : 512;
-    static const int tgt = getenv("UZ_SPLIT_TGT") ? atoi(getenv("UZ_SPLIT_TGT")) : 512;
-    if (base_grid >= thr || nChunks <= 1) return;
-    long long want = (tgt + base_grid - 1) / base_grid;
+    if (base_grid >= 512 || nChunks <= 1) return;          // 2 workgroups per CU already: no split
+    long long want = (512 + base_grid - 1) / base_grid;
     if (want > nChunks) want = nChunks;
     cps = (int)((nChunks + want - 1) / want);
     ksplit = (nChunks + cps - 1) / cps;
@@ -359,11 +356,19 @@ extern "C" size_t uz_conv_workspace(int Cin, int Cout, int N, int H, int W, int 
 extern "C" int uz_conv_fwd(const float* x, int Cin, int CinTot, const float* w, const float* bias,
                            float* y, int Cout, int CoutTot, int N, int H, int W, int ks, int relu,
                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (ks == 1 && !relu && uz::conv1x1_small_ok(Cin, Cout)) {        // 2..8-output heads: streaming VALU kernel
+        const int rc = uz::conv1x1_small_fwd(x, Cin, CinTot, w, bias, y, Cout, CoutTot, N, H, W, uz::S(stream));
+        if (rc != -2) return rc;
+    }
     return uz::conv_mfma(x, Cin, CinTot, w, Cin, bias, y, Cout, CoutTot, N, H, W, ks, 0, relu, 0, workspace, workspace_bytes, uz::S(stream));
 }
 
 extern "C" int uz_conv_bwd_data(const float* dy, int Cout, int CoutTot, const float* w,
                                 float* dx, int Cin, int CinTot, int N, int H, int W, int ks, int accumulate,
                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) {
+        const int rc = uz::conv1x1_small_bwd_data(dy, Cout, CoutTot, w, dx, Cin, CinTot, N, H, W, accumulate, uz::S(stream));
+        if (rc != -2) return rc;
+    }
     return uz::conv_mfma(dy, Cout, CoutTot, w, Cin, nullptr, dx, Cin, CinTot, N, H, W, ks, 1, 0, accumulate, workspace, workspace_bytes, uz::S(stream));
 }

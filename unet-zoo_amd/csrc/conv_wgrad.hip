@@ -370,14 +370,12 @@ __global__ __launch_bounds__(64) void channel_sum_final(const double* __restrict
     if (threadIdx.x == 0) db[c] = (float)s;
 }
 
-static int uz_wgrad_tile_rows() { static int v = getenv("UZ_WGRAD_ROWS") ? atoi(getenv("UZ_WGRAD_ROWS")) : 4; return v; }
-
 struct WGeom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB, T, S, nCoT, nCiT, WM, WN, WK, pf; };
 
 WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
     WGeom g;
     g.TW = W >= 32 ? 32 : uz::pow2_ceil(W);
-    const int npx = (halo == 1 && W >= 32 && H >= 64 && uz_wgrad_tile_rows() == 4) ? 128 : 64;   // fast kernel: 4 x 32 tiles on the large planes
+    const int npx = (halo == 1 && W >= 32 && H >= 64) ? 128 : 64;   // fast kernel: 4 x 32 tiles on the large planes
     g.TH = uz::pow2_ceil(H);
     if (g.TH > npx / g.TW) g.TH = npx / g.TW;
     if (g.TH < 1) g.TH = 1;
@@ -424,7 +422,12 @@ extern "C" size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, 
     const WGeom g = pick_wgeom(Cin, Cout, N, H, W, ks / 2);
     const size_t slabs = (size_t)g.S * g.WK * ks * ks * Cout * Cin * sizeof(float);
     const size_t dbp = (size_t)Cout * CSB * sizeof(double);
-    return slabs > dbp ? slabs : dbp;
+    size_t need = slabs > dbp ? slabs : dbp;
+    if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) {
+        const size_t sm = uz::conv1x1_small_bwd_weight_ws(Cin, Cout, N, H, W);
+        if (sm > need) need = sm;
+    }
+    return need;
 }
 
 extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
@@ -433,6 +436,11 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
     UZ_REQUIRE(ks == 1 || ks == 3, "conv_bwd_weight: kernel size %d unsupported", ks);
     UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_bwd_weight: empty tensor");
     UZ_REQUIRE(H < 1024 && W < 1024, "conv_bwd_weight: spatial size too large");
+    if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) {                 // 2..8-output heads: streaming VALU kernel
+        UZ_REQUIRE(workspace && workspace_bytes >= uz::conv1x1_small_bwd_weight_ws(Cin, Cout, N, H, W), "conv_bwd_weight: workspace too small");
+        const int rc = uz::conv1x1_small_bwd_weight(x, Cin, CinTot, dy, Cout, CoutTot, dw, db, N, H, W, workspace, uz::S(stream));
+        if (rc != -2) return rc;
+    }
     const WGeom g = pick_wgeom(Cin, Cout, N, H, W, ks / 2);
     const size_t need = (size_t)g.S * g.WK * ks * ks * Cout * Cin * sizeof(float);
     UZ_REQUIRE(workspace && workspace_bytes >= need, "conv_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);

@@ -53,6 +53,16 @@ __device__ __forceinline__ void block_sum_d(double (&v)[NV], double* smem /* >= 
     }
 }
 
+// conv1x1_small.hip: streaming VALU kernels for 1x1 convolutions with <= 8 outputs (-2 = shape not covered)
+bool conv1x1_small_ok(int Cin, int Cout);
+int conv1x1_small_fwd(const float* x, int Cin, int CinTot, const float* w, const float* bias, float* y, int Cout, int CoutTot,
+                      int N, int H, int W, hipStream_t st);
+int conv1x1_small_bwd_data(const float* dy, int Cout, int CoutTot, const float* w, float* dx, int Cin, int CinTot,
+                           int N, int H, int W, int accumulate, hipStream_t st);
+size_t conv1x1_small_bwd_weight_ws(int Cin, int Cout, int N, int H, int W);
+int conv1x1_small_bwd_weight(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* dw, float* db,
+                             int N, int H, int W, void* ws, hipStream_t st);
+
 }  // namespace uz
 
 #define UZ_REQUIRE(cond, ...) do { if (!(cond)) return uz::fail(__VA_ARGS__); } while (0)
