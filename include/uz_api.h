@@ -163,6 +163,16 @@ int uz_sum_terms(const float* terms, int n, float* total, void* stream);
 int uz_accumulate_softmax_argmax(const float* const* s_ptrs, int L, int K, int N, int H, int W,
                                  float* acc, float* soft, uint8_t* label, void* stream);
 
+/* ---------------------------------------------------------------- validation metrics (train_model.py:186-230)
+ * out[i][j][0..2] = |a_i==label & b_j==label|, |a_i==label|, |b_j==label| over HW pixels (int32, exact): the integer core of
+ * utils.generalised_energy_distance (utils.py:148-200; IoU = medpy.metric.jc, MedPy 0.4.0) and of the per-label Dice
+ * (train_model.py:212-224; medpy.metric.dc).  a: (Na, HW) uint8 label maps, b: (Nb, HW).                               */
+int uz_label_pair_counts(const uint8_t* a, int Na, const uint8_t* b, int Nb, int HW, int label, int32_t* out, void* stream);
+/* utils.variance_ncc_dist (utils.py:202-247): pixel-wise cross-entropy maps E_ss (HW) and E_sy (M, HW) of N softmax samples
+ * (N,K,HW) against M one-hot ground truths (M,K,HW); then ncc(E_ss, E_sy[j]) for every j (utils.py:130-145).              */
+int uz_ncc_maps(const float* soft, const float* gt_onehot, int N, int M, int K, int HW, float* E_ss, float* E_sy, void* stream);
+int uz_ncc(const float* a, const float* v, int M, int HW, float* out, void* stream);
+
 /* ---------------------------------------------------------------- optimiser / vector ops
  * torch.optim.Adam(lr, betas, eps, weight_decay as L2 added to the gradient): train_model.py:49,122.
  * One launch over a contiguous range of the flat parameter buffer.                        */

@@ -62,5 +62,8 @@ def test_train_step_contract_runs(which, tmp_path):
     sd = torch.load(path)
     assert list(sd.keys()) == list(after.keys())
     h.net.load_state_dict(sd)
-    if which == "phiseg":
-        assert h.validate(data, n_images=4) > 0
+    if which in ("phiseg", "probunet"):
+        h.exp_config.validation_samples, h.exp_config.num_validation_images = 4, 2
+        m = h.validate(data)
+        assert 0.0 <= m["dice"] <= 1.0 and -1.0 <= m["ncc"] <= 1.0 and m["ged"] >= -1e-9
+        assert os.path.exists(os.path.join(str(tmp_path), "t", "t", "t_best_ged.pth"))

@@ -24,7 +24,17 @@ sys.path.insert(0, ROOT)
 
 for _name in ("medpy", "medpy.metric", "nibabel", "revtorch"):
     sys.modules[_name] = types.ModuleType(_name)
-sys.modules["medpy.metric"].jc = sys.modules["medpy.metric"].dc = lambda a, b: 0.0
+# MedPy==0.4.0 (requirements.txt:17) is not vendored; its binary Jaccard / Dice coefficients are restated here so that the
+# reference's own metric functions (utils.generalised_energy_distance, variance_ncc_dist) can produce golden values
+def _jc(a, b):
+    import numpy as _np
+    a, b = _np.asarray(a).astype(bool), _np.asarray(b).astype(bool)
+    return float(_np.count_nonzero(a & b)) / float(_np.count_nonzero(a | b))
+def _dc(a, b):
+    import numpy as _np
+    a, b = _np.asarray(a).astype(bool), _np.asarray(b).astype(bool)
+    return 2.0 * _np.count_nonzero(a & b) / float(_np.count_nonzero(a) + _np.count_nonzero(b))
+sys.modules["medpy.metric"].jc, sys.modules["medpy.metric"].dc = _jc, _dc
 sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference")
 
@@ -317,8 +327,36 @@ def op_cases():
     save("ops", arrays, meta)
 
 
+def metric_cases():
+    """Golden values of the reference's validation metrics (utils.py:148-247) on synthetic samples."""
+    rs = np.random.Generator(np.random.PCG64(5))
+    arrays, meta = {}, {}
+    H = W = 32
+    yy, xx = np.mgrid[0:H, 0:W]
+    def disc(cy, cx, r):
+        return ((yy - cy) ** 2 + (xx - cx) ** 2 <= r * r).astype(np.int64)
+    for case in range(3):
+        N, M = (6, 4) if case < 2 else (4, 3)
+        samples = np.stack([disc(16 + rs.normal(0, 2), 16 + rs.normal(0, 2), 6 + rs.normal(0, 1.5)) for _ in range(N)])
+        gts = np.stack([disc(16 + rs.normal(0, 2), 15 + rs.normal(0, 2), 6 + rs.normal(0, 1.5)) for _ in range(M)])
+        if case == 1:
+            samples[0] = 0          # empty prediction vs non-empty gt, and
+            gts[1] = 0              # empty gt: exercises the 0 / 1 conventions
+        logits = rs.standard_normal((N, 2, H, W)).astype(np.float32) + 3.0 * np.stack([1 - samples, samples], 1).astype(np.float32)
+        soft = torch.softmax(torch.from_numpy(logits), dim=1)
+        ged = ref_utils.generalised_energy_distance(torch.from_numpy(samples), torch.from_numpy(gts), nlabels=1, label_range=range(1, 2))
+        onehot = ref_utils.convert_batch_to_onehot(torch.from_numpy(gts).unsqueeze(1), nlabels=2)
+        ncc = ref_utils.variance_ncc_dist(soft, onehot)
+        arrays[f"m{case}_samples"], arrays[f"m{case}_gts"], arrays[f"m{case}_soft"] = samples.astype(np.uint8), gts.astype(np.uint8), soft.numpy()
+        meta[f"m{case}_ged"], meta[f"m{case}_ncc"] = float(ged), float(np.asarray(ncc).reshape(-1)[0])
+    save("metrics", arrays, meta)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        metric_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "b32":
         # BASELINE config 4 exactly (batch 32): digests only, inputs are regenerated from the seed
         phiseg_case("phiseg_full_b32_digest", [32, 64, 128, 192, 192, 192, 192], 128, 32, 1, False, 1238, store_inputs=False)

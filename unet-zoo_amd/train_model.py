@@ -5,7 +5,8 @@ Scope: the TRAIN-STEP CONTRACT of ``UNetModel`` - build
 ReduceLROnPlateau('min', min_lr=1e-4, patience=50000) stepped on the loss (:50-51,:134), and per
 iteration: to-device, ``forward(patch, mask, training=True)``, ``loss(mask)``, ``zero_grad``,
 ``backward``, ``step`` (:100-134) - plus ``save_model`` (:558-564).  Validation metrics (GED / NCC / Dice via medpy),
-image dumps and the LIDC / UZH / BraTS loaders are outside the hot path ("next" rows of SURVEY 8f).
+the device-side validation loop (N prior samples, GED / NCC / Dice) is `validate`; image dumps and the
+LIDC / UZH / BraTS loaders stay outside the hot path.
 
 Experiment files of the reference are plain Python modules that import ``models.phiseg``,
 ``data.lidc_data`` and ``utils`` (e.g. models/experiments/phiseg_7_5_12.py:1-5).  ``load_experiment``
@@ -50,8 +51,15 @@ class SyntheticData:
         h, w = size[1], size[2]
         x, m, _ = synthetic_batch(n_train + n_val, h, w, seed=7)
         self.train = _Split(x[:n_train], m[:n_train, 0])
-        self.validation = _Split(x[n_train:], m[n_train:, 0])
+        # validation labels carry several annotators per image, (n, H, W, A), like the LIDC HDF5 (lidc_data_loader.py:92-110)
+        n_ann = getattr(exp_config, "num_labels_per_subject", 4)
+        ann = [m[n_train:, 0]]
+        for a in range(1, n_ann):
+            ann.append(np.roll(m[n_train:, 0], shift=(a, -a), axis=(1, 2)))
+        self.validation = _Split(x[n_train:, 0], np.stack(ann, axis=-1))
         self.test = self.validation
+        if exp_config is not None and not hasattr(exp_config, "annotator_range"):
+            exp_config.annotator_range = range(n_ann)            # injected by the loader in the reference (lidc_data.py:31-32)
 
 
 def lidc_data(sys_config=None, exp_config=None):
@@ -139,6 +147,9 @@ class UNetModel:
         for self.iteration in range(1, n_it):
             x_b, s_b = data.train.next_batch(self.batch_size)
             loss = self.train_step(x_b, s_b)
+            val_every = getattr(self.exp_config, "validation_frequency", 0)
+            if val_every and self.iteration % val_every == 0:
+                self.validate(data)
             if self.iteration % log_every == 0:
                 self.logger.info("Iteration {} Loss {}".format(self.iteration, float(loss)))
                 self.tot_loss = self.kl_loss = self.reconstruction_loss = 0
@@ -146,15 +157,64 @@ class UNetModel:
         self.logger.info("Finished training.")
 
     @torch.no_grad()
-    def validate(self, data, n_images=8):
-        """Mean validation loss over the first images (full GED / NCC / Dice evaluation: SURVEY 8f-1)."""
+    def validate(self, data):
+        """UNetModel.validate (train_model.py:138-275) on the device: per validation image, `validation_samples`
+        prior samples in eval mode -> accumulate_output(softmax) -> loss -> argmax -> GED / NCC / Dice
+        (unet_zoo_amd.metrics), then the running means and the best-model checkpoints."""
+        from . import metrics
+        cfg = self.exp_config
         self.net.eval()
-        x = torch.as_tensor(data.validation.images[:n_images], dtype=torch.float32).to(self.device)
-        m = torch.as_tensor(data.validation.labels[:n_images], dtype=torch.float32).unsqueeze(1).to(self.device)
-        self.net.forward(x, m, training=False)
-        val = float(self.net.loss(m)) if hasattr(self.net, "elbo") or hasattr(self.net, "loss") else float("nan")
+        self.save_model("validation_ckpt")
+        n_samples = getattr(cfg, "validation_samples", 16)
+        n_classes = cfg.n_classes
+        n_img = data.validation.images.shape[0] if getattr(cfg, "num_validation_images", "all") == "all" \
+            else min(cfg.num_validation_images, data.validation.images.shape[0])
+        ann_range = list(getattr(cfg, "annotator_range", range(data.validation.labels.shape[-1])))
+        rng = np.random.default_rng(self.iteration)
+        ged_l, dice_l, ncc_l, elbo_l = [], [], [], []
+        for ii in range(n_img):
+            s_gt_arr = data.validation.labels[ii]                                   # (H, W, A)
+            patch = torch.as_tensor(data.validation.images[ii], dtype=torch.float32).to(self.device)
+            val_patch = patch.reshape(1, 1, *patch.shape[-2:])
+            s_b = s_gt_arr[:, :, rng.choice(ann_range)]
+            val_mask = torch.as_tensor(s_b, dtype=torch.float32).to(self.device).reshape(1, 1, *patch.shape[-2:])
+            val_masks = torch.as_tensor(s_gt_arr, dtype=torch.float32).to(self.device).permute(2, 0, 1).contiguous()   # (A, H, W)
+            patch_arr = val_patch.repeat(n_samples, 1, 1, 1)
+            mask_arr = val_mask.repeat(n_samples, 1, 1, 1)
+            out = self.net.forward(patch_arr, mask_arr, training=False)
+            if isinstance(out, list):                                               # PHISeg: list of level logits
+                soft = self.net.accumulate_output(out, use_softmax=True)
+                elbo_l.append(float(self.net.loss(mask_arr)))
+            else:                                                                   # ProbabilisticUnet: one sample per row
+                soft = torch.softmax(self.net.sample(testing=True), dim=1)
+                elbo_l.append(float("nan"))
+            pred = torch.argmax(soft, dim=1)                                        # (N, H, W)
+            ged_l.append(metrics.generalised_energy_distance(pred, val_masks.long(), nlabels=n_classes - 1,
+                                                             label_range=range(1, n_classes)))
+            onehot = torch.stack([(val_masks == k) for k in range(n_classes)], dim=1).long()        # (A, K, H, W)
+            ncc_l.append(metrics.variance_ncc_dist(soft, onehot))
+            s_mean = torch.argmax(torch.mean(soft, dim=0), dim=0)
+            dice_l.append(metrics.per_label_dice(s_mean, val_mask.reshape(*patch.shape[-2:]).long(), n_classes))
+        dice = torch.tensor(dice_l)
+        self.avg_dice = float(dice.mean())
+        self.foreground_dice = float(dice.mean(dim=0)[1]) if n_classes > 1 else float("nan")
+        self.val_elbo = float(np.nanmean(elbo_l)) if len(elbo_l) else float("nan")
+        self.avg_ged, self.avg_ncc = float(np.mean(ged_l)), float(np.mean(ncc_l))
+        self.logger.info(" - Foreground dice: %.4f" % self.foreground_dice)
+        self.logger.info(" - Mean (neg.) ELBO: %.4f" % self.val_elbo)
+        self.logger.info(" - Mean GED: %.4f" % self.avg_ged)
+        self.logger.info(" - Mean NCC: %.4f" % self.avg_ncc)
+        best = self.__dict__.setdefault("_best", dict(dice=-1.0, loss=float("inf"), ged=float("inf"), ncc=-1.0))
+        if float(dice.mean(dim=0).mean()) >= best["dice"]:
+            best["dice"] = float(dice.mean(dim=0).mean()); self.save_model("best_dice")
+        if self.val_elbo <= best["loss"]:
+            best["loss"] = self.val_elbo; self.save_model("best_loss")
+        if self.avg_ged <= best["ged"]:
+            best["ged"] = self.avg_ged; self.save_model("best_ged")
+        if self.avg_ncc >= best["ncc"]:
+            best["ncc"] = self.avg_ncc; self.save_model("best_ncc")
         self.net.train()
-        return val
+        return dict(dice=self.avg_dice, foreground_dice=self.foreground_dice, elbo=self.val_elbo, ged=self.avg_ged, ncc=self.avg_ncc)
 
     def save_model(self, savename):
         """<log_root>/<log_dir_name>/<experiment_name>/<experiment_name>_<savename>.pth (train_model.py:558-564)."""
