@@ -213,6 +213,20 @@ typedef struct uz_op {
 int uz_run_tape(const uz_op* ops, int n_ops, void* stream);
 /* Capture the tape into a hipGraph on `stream` and return an opaque executable handle. */
 int  uz_graph_create(const uz_op* ops, int n_ops, void* stream, void** graph_exec_out);
+/* Lane capture: like uz_graph_create, but the captured graph carries the tape's dependency DAG
+ * instead of one chain.  Ops are partitioned into lanes (each with its own scratch copy, resolved
+ * by the host into the op's pointers); op k follows the previous op of its lane and the earlier
+ * ops listed in wait[0..n_wait) (which must have signal != 0).  Independent chains of the tape
+ * overlap on the device at replay; results are bit-identical to uz_run_tape.                   */
+#define UZ_MAX_LANES 8
+typedef struct uz_sched {
+  int32_t lane;
+  int32_t signal;
+  int32_t n_wait;
+  int32_t wait[UZ_MAX_LANES];
+} uz_sched;
+int  uz_graph_create_lanes(const uz_op* ops, const uz_sched* sched, int n_ops, int n_lanes,
+                           void* stream, void** graph_exec_out);
 int  uz_graph_launch(void* graph_exec, void* stream);
 void uz_graph_destroy(void* graph_exec);
 

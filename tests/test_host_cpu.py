@@ -74,3 +74,61 @@ def test_unet_and_probunet_specs_equal_reference_state_dict():
     big = probunet_spec(1, 2, [32, 64, 128, 192, 192, 192, 192], 6, 3)
     n = sum(int(torch.tensor(s).prod()) if len(s) else 1 for _, s, kd in big if kd in ("conv_w", "conv_b", "bn_w", "bn_b"))
     assert n == 17956988
+
+
+def _check_lane_schedule(plan, which, ops):
+    """Brute force: every pair of ops touching overlapping memory with at least one write must be
+    ordered by lane order + event waits; groups stay contiguous on one lane (private scratch)."""
+    sc, n = plan.scheds[which], len(ops)
+    hb = [0] * n                                    # bitset of ops that happen before op k
+    last = {}
+    for k, o in enumerate(ops):
+        m = 0
+        if o["lane"] in last:
+            j = last[o["lane"]]
+            m |= hb[j] | (1 << j)
+        for w in range(sc[k].n_wait):
+            j = sc[k].wait[w]
+            assert j < k and sc[j].signal and ops[j]["lane"] != o["lane"]
+            m |= hb[j] | (1 << j)
+        hb[k] = m
+        last[o["lane"]] = k
+        if k and ops[k - 1]["gid"] == o["gid"]:
+            assert ops[k - 1]["lane"] == o["lane"]
+    acc = []
+    for o in ops:
+        wr = plan._WRITES[o["code"]]
+        r, w = [], []
+        for j, ref in enumerate(o["p"]):
+            (w if j in wr else r).extend(plan._resources(ref))
+        acc.append((r, w))
+
+    def overlap(xs, ys):
+        return any(a[0] == b[0] and a[1] < b[2] and b[1] < a[2] for a in xs for b in ys)
+    pairs = 0
+    for j in range(n):
+        rj, wj = acc[j]
+        for k in range(j + 1, n):
+            rk, wk = acc[k]
+            if overlap(wj, rk) or overlap(wj, wk) or overlap(rj, wk):
+                pairs += 1
+                assert (hb[k] >> j) & 1, (which, j, ops[j]["code"], k, ops[k]["code"])
+    return pairs, len({o["lane"] for o in ops})
+
+
+@pytest.mark.parametrize("lanes", ["1", "3", "4"])
+def test_lane_schedule_preserves_every_dependency(lanes, monkeypatch):
+    from unet_zoo_amd.models.phiseg import PHISeg
+    from unet_zoo_amd.models.probabilistic_unet import ProbabilisticUnet
+    monkeypatch.setenv("UZ_LANES", lanes)
+    _, meta = G.load("phiseg_small")
+    net = PHISeg(1, 2, meta["filters"], image_size=(1, 64, 64), device="cpu")
+    plan = net._build(2, 64, 64, True, True)
+    for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
+        pairs, used = _check_lane_schedule(plan, which, ops)
+        assert pairs > 100 and used == min(int(lanes), 4)
+    _, meta = G.load("probunet_small")
+    pu = ProbabilisticUnet(1, 2, meta["filters"], latent_dim=meta["latent_dim"], no_convs_fcomb=3, device="cpu")
+    for plan in (pu._build(2, 64, 64, True, True), pu._build(2, 64, 64, False, False)):
+        for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops), *plan.extra_ops.items()):
+            _check_lane_schedule(plan, which, ops)

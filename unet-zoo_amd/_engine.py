@@ -86,7 +86,9 @@ class NativeModel(nn.Module):
 
     def enable_graphs(self, flag=True):
         """Replay forward/backward tapes as captured hipGraphs (one graph launch instead of ~1000
-        kernel launches).  Capture happens lazily on a side stream after one eager warm-up run."""
+        kernel launches).  Capture happens lazily on a side stream after one eager warm-up run, over
+        `plan.n_lanes` dependency lanes (UZ_LANES, default 2 - measured best on MI355X) so that independent chains of the
+        tape - posterior / prior encoders, the likelihood branches - overlap on the device."""
         self._use_graphs = bool(flag)
 
     def _run(self, plan, which):
@@ -105,7 +107,11 @@ class NativeModel(nn.Module):
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             handle = C.c_void_p()
-            _ffi.check(plan.L.uz_graph_create(arr, n, C.c_void_p(side.cuda_stream), C.byref(handle)), f"graph capture '{which}'")
+            if plan.n_lanes > 1:
+                _ffi.check(plan.L.uz_graph_create_lanes(arr, plan.scheds[which], n, plan.n_lanes, C.c_void_p(side.cuda_stream),
+                                                        C.byref(handle)), f"graph capture '{which}'")
+            else:
+                _ffi.check(plan.L.uz_graph_create(arr, n, C.c_void_p(side.cuda_stream), C.byref(handle)), f"graph capture '{which}'")
             torch.cuda.current_stream(self.device).wait_stream(side)
             g = handle
             self._graphs[key] = g

@@ -19,6 +19,13 @@ class UzError(RuntimeError):
     pass
 
 
+UZ_MAX_LANES = 8
+
+
+class uz_sched(C.Structure):
+    _fields_ = [("lane", C.c_int32), ("signal", C.c_int32), ("n_wait", C.c_int32), ("wait", C.c_int32 * UZ_MAX_LANES)]
+
+
 class uz_op(C.Structure):
     _fields_ = [("code", C.c_int32), ("i", C.c_int32 * 15), ("f", C.c_float * 4), ("n", C.c_int64), ("p", C.c_void_p * 12)]
 
@@ -55,7 +62,7 @@ def prototypes():
     header stays the single source of truth for the binding."""
     with open(HEADER_PATH) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
-    text = re.sub(r"typedef struct uz_op \{.*?\} uz_op;", "", text, flags=re.S)
+    text = re.sub(r"typedef struct (\w+) \{.*?\} \1;", "", text, flags=re.S)
     text = re.sub(r"enum\s*\{.*?\};", "", text, flags=re.S)
     text = "\n".join(ln for ln in text.splitlines() if not ln.lstrip().startswith("#") and 'extern "C"' not in ln)
     out = {}

@@ -15,6 +15,7 @@ Design points:
     reference's ``grad is None`` parameters.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -144,6 +145,11 @@ class Plan:
         self.param_grads = []               # parameter keys that receive a gradient, in write order
         self.named = {}                     # user-visible tensors: name -> View
         self.finalized = False
+        self._gid = 0                       # scheduling group of the ops being emitted (see _schedule)
+        self.n_lanes = max(1, min(int(os.environ.get("UZ_LANES", "2")), 8))
+
+    def _newgroup(self):
+        self._gid += 1
 
     # ------------------------------------------------------------------ buffers
     def buf(self, name, C, H, W, N=None, requires_grad=True):
@@ -180,7 +186,7 @@ class Plan:
 
     # ------------------------------------------------------------------ op emission
     def _emit(self, lst, code, p=(), i=(), f=(), n=0):
-        lst.append(dict(code=code, p=list(p), i=[int(x) for x in i], f=[float(x) for x in f], n=int(n)))
+        lst.append(dict(code=code, p=list(p), i=[int(x) for x in i], f=[float(x) for x in f], n=int(n), gid=self._gid))
 
     def P(self, key, extra=0):
         return ("param", key, extra)
@@ -213,6 +219,7 @@ class Plan:
         n = len(keys)
         tab = self.ptr_table([("raw", v) for k in keys for v in (self.ptab.poff[k], _numel(self.ptab.shape[k]))])
         norms = self.vec("l2_norms", n)
+        self._newgroup()
         self._emit(self.target, "UZ_OP_L2_NORMS", p=[("pflat",), tab, norms], i=[n])
         self._emit(self.target, "UZ_OP_SUM_TERMS", p=[norms, term], i=[n])
         self._emit(self.target, "UZ_OP_SCALE", p=[term], f=[coeff], n=1)
@@ -231,6 +238,7 @@ class Plan:
         wextra = wrow0 * cin * ks * ks
         ws = self.L.uz_conv_workspace(cin, cout, x.N, x.H, x.W, ks)
         self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
+        self._newgroup()
         self._emit(self.target, "UZ_OP_CONV_FWD",
                    p=[x, self.P(wkey, wextra), self.P(bkey, wrow0) if bkey else None, y, ("scratch", "wgrad")],
                    i=[cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, ks, relu], n=ws)
@@ -329,6 +337,7 @@ class Plan:
 
     # ------------------------------------------------------------------ resampling
     def _resample(self, fcode, bcode, x, y, extra_i=()):
+        self._newgroup()
         self._emit(self.target, fcode, p=[x, y], i=[x.C, x.Ctot, y.Ctot, x.N, x.H, x.W, *extra_i])
 
         def bwd():
@@ -357,6 +366,7 @@ class Plan:
 
     def spatial_mean(self, x, name):
         y = self.buf(name, x.C, 1, 1)
+        self._newgroup()
         self._emit(self.target, "UZ_OP_SPATIAL_MEAN_FWD", p=[x, y], i=[x.C, x.Ctot, x.N, x.H, x.W])
 
         def bwd():
@@ -371,6 +381,7 @@ class Plan:
     def bcast_channels(self, z, out):
         """Fcomb tiling of z (N, L) over the spatial axes into channels of `out` (probabilistic_unet.py:190-197)."""
         L = z.C
+        self._newgroup()
         self._emit(self.target, "UZ_OP_BCAST_CHANNELS", p=[z, out], i=[L, out.Ctot, out.N, out.H, out.W])
 
         def bwd():
@@ -384,6 +395,7 @@ class Plan:
     # ------------------------------------------------------------------ inputs / latents / losses
     def posterior_input(self, patch, mask, nlabels, name):
         out = self.buf(name, patch.C + nlabels, patch.H, patch.W, requires_grad=False)
+        self._newgroup()
         self._emit(self.target, "UZ_OP_POSTERIOR_INPUT", p=[patch, mask, out], i=[patch.C, nlabels, patch.N, patch.H, patch.W])
         return out
 
@@ -392,6 +404,7 @@ class Plan:
         sigma = self.buf(name + ":sigma", mu.C, mu.H, mu.W)
         z = self.buf(name + ":z", mu.C, mu.H, mu.W) if want_z else None
         lat = Latent(mu, pre, sigma, z, eps, act)
+        self._newgroup()
         self._emit(self.target, "UZ_OP_LATENT_FWD", p=[mu, pre, eps, sigma, z], i=[act], n=mu.numel)
 
         def bwd():
@@ -407,6 +420,7 @@ class Plan:
     def kl(self, q, p, weight, term):
         """weight * KL_two_gauss_with_diag_cov(q || p) (phiseg.py:436-479)."""
         n, per = q.mu.N, q.mu.C * q.mu.H * q.mu.W
+        self._newgroup()
         self._emit(self.target, "UZ_OP_KL_FWD", p=[q.mu, q.sigma, p.mu, p.sigma, term], i=[n, per], f=[weight])
 
         def bwd():
@@ -427,6 +441,7 @@ class Plan:
         tab = self.ptr_table(list(s_list))
         ws = self.L.uz_ce_workspace(mask.N, mask.H, mask.W, L)
         self.scratch["ce"] = max(self.scratch["ce"], ws)
+        self._newgroup()
         self._emit(self.target, "UZ_OP_CE_FWD", p=[tab, mask, terms, ("scratch", "ce")], i=[L, K, mask.N, mask.H, mask.W])
         if post_scale is not None:
             self._emit(self.target, "UZ_OP_SCALE", p=[terms], f=[post_scale], n=L)
@@ -444,9 +459,11 @@ class Plan:
         self._push_bwd(bwd)
 
     def sum_terms(self, terms, n, total):
+        self._newgroup()
         self._emit(self.target, "UZ_OP_SUM_TERMS", p=[terms, total], i=[n])
 
     def scale_(self, v, alpha, n):
+        self._newgroup()
         self._emit(self.target, "UZ_OP_SCALE", p=[v], f=[alpha], n=n)
 
     def ptr_table(self, refs):
@@ -459,8 +476,10 @@ class Plan:
         self.loss_scale = self.vec("loss_scale", 1)
         if want_backward:
             for fn in reversed(self._bwd):
+                self._newgroup()
                 fn()
             for fn in self._bwd_tail:
+                self._newgroup()
                 fn()
         self._bwd = []
         # arena layout
@@ -468,12 +487,16 @@ class Plan:
         for b in self.bufs:
             b.off = off
             off += -(-b.numel // _ALIGN) * _ALIGN
-        self.gy_off = off
-        off += -(-self.scratch["gy"] // _ALIGN) * _ALIGN
-        self.scratch_off = {}
-        for k in ("bn", "wgrad", "ce"):
-            self.scratch_off[k] = off
-            off += -(-(self.scratch[k] // 4 + 1) // _ALIGN) * _ALIGN
+        # scratch regions are private to a scheduling group, so every capture lane gets its own copy
+        self.gy_off, self.scratch_off = [], []
+        for _ in range(self.n_lanes):
+            self.gy_off.append(off)
+            off += -(-self.scratch["gy"] // _ALIGN) * _ALIGN
+            so = {}
+            for k in ("bn", "wgrad", "ce"):
+                so[k] = off
+                off += -(-(self.scratch[k] // 4 + 1) // _ALIGN) * _ALIGN
+            self.scratch_off.append(so)
         self.arena_floats = off
         self.arena = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.base = self.arena.data_ptr()
@@ -488,19 +511,20 @@ class Plan:
                 k += 1
         if vals:
             self.ptrtab.copy_(torch.tensor(vals, dtype=torch.int64))
-        self.tapes = {nm: self._materialize(ops) for nm, ops in (("fwd", self.fwd_ops), ("loss", self.loss_ops), ("bwd", self.bwd_ops))}
-        for nm, ops in self.extra_ops.items():
+        self.tapes, self.scheds = {}, {}
+        for nm, ops in (("fwd", self.fwd_ops), ("loss", self.loss_ops), ("bwd", self.bwd_ops), *self.extra_ops.items()):
+            self.scheds[nm] = self._schedule(ops)
             self.tapes[nm] = self._materialize(ops)
         self.loss_scale_t = self.tensor(self.loss_scale).view(1)
         self.loss_scale_t.fill_(1.0)
         self.finalized = True
         return self
 
-    def _resolve(self, r):
+    def _resolve(self, r, lane=0):
         if r is None:
             return 0
         if isinstance(r, _ScratchView):
-            return self.base + 4 * self.gy_off
+            return self.base + 4 * self.gy_off[lane]
         if isinstance(r, View):
             assert r.buf.off is not None
             return self.base + 4 * (r.buf.off + r.c0 * r.buf.H * r.buf.W)
@@ -516,9 +540,9 @@ class Plan:
         if kind == "gflat":
             return self.ptab.gflat.data_ptr()
         if kind == "scratch":
-            return self.base + 4 * self.scratch_off[r[1]]
+            return self.base + 4 * self.scratch_off[lane][r[1]]
         if kind == "gyview":
-            return self.base + 4 * self.gy_off
+            return self.base + 4 * self.gy_off[lane]
         if kind == "ptrtab":
             return self.ptrtab.data_ptr() + 8 * self._tab_off[r[1]]
         if kind == "raw":
@@ -537,8 +561,123 @@ class Plan:
                 e.f[j] = v
             e.n = o["n"]
             for j, r in enumerate(o["p"]):
-                e.p[j] = self._resolve(r)
+                e.p[j] = self._resolve(r, o.get("lane", 0))
         return arr, len(ops)
+
+    # ------------------------------------------------------------------ lane scheduling
+    # Which p[] slots an op writes (every other slot is read).  Scratch slots are private to a
+    # group and parameters are read-only inside a tape, so neither creates a dependency.
+    _WRITES = {
+        "UZ_OP_CONV_FWD": (3,), "UZ_OP_CONV_BWD_DATA": (2,), "UZ_OP_CONV_BWD_WEIGHT": (2, 3),
+        "UZ_OP_BN_RELU_FWD": (3, 4, 5, 6), "UZ_OP_BN_RELU_BWD": (5, 6, 7, 8), "UZ_OP_RELU_BWD": (2, 3),
+        "UZ_OP_AVGPOOL_FWD": (1,), "UZ_OP_AVGPOOL_BWD": (1,), "UZ_OP_BILINEAR_FWD": (1,), "UZ_OP_BILINEAR_BWD": (1,),
+        "UZ_OP_NEAREST_FWD": (1,), "UZ_OP_NEAREST_BWD": (1,), "UZ_OP_SPATIAL_MEAN_FWD": (1,), "UZ_OP_SPATIAL_MEAN_BWD": (1,),
+        "UZ_OP_POSTERIOR_INPUT": (2,), "UZ_OP_LATENT_FWD": (3, 4), "UZ_OP_LATENT_BWD": (5, 6),
+        "UZ_OP_KL_FWD": (4,), "UZ_OP_KL_BWD": (5, 6, 7, 8), "UZ_OP_CE_FWD": (2,), "UZ_OP_CE_BWD": (1,),
+        "UZ_OP_SUM_TERMS": (1,), "UZ_OP_SCALE": (0,), "UZ_OP_COPY": (0,), "UZ_OP_MEMSET": (0,),
+        "UZ_OP_L2_NORMS": (2,), "UZ_OP_L2_NORMS_BWD": (4,),
+        "UZ_OP_BCAST_CHANNELS": (1,), "UZ_OP_BCAST_CHANNELS_BWD": (1,),
+    }
+
+    def _resources(self, r):
+        """Dependency-relevant resources behind one pointer ref: (space, lo, hi) half-open ranges."""
+        if r is None or isinstance(r, _ScratchView):
+            return []
+        if isinstance(r, View):
+            return [(("buf", id(r.buf)), r.c0, r.c0 + r.C)]
+        kind = r[0]
+        if kind == "pgrad":
+            lo = self.ptab.poff[r[1]]
+            return [(("gflat",), lo, lo + _numel(self.ptab.shape[r[1]]))]
+        if kind == "gflat":
+            return [(("gflat",), 0, 1 << 62)]
+        if kind == "buffer":
+            return [(("bnbuf", r[1]), 0, 1)]
+        if kind == "ptrtab":
+            return [x for q in self.ptr_tables[r[1]] for x in self._resources(q)]
+        if kind in ("param", "pflat", "scratch", "gyview", "raw"):
+            return []
+        raise ValueError(r)
+
+    def _schedule(self, ops):
+        """Assigns every op a capture lane and the cross-lane waits that keep the tape's read/write
+        order (RAW, WAR and WAW on buffer channel ranges, gradient ranges and BN running buffers).
+        Ops of one group (one layer's forward, or one layer's backward) stay on one lane back to
+        back.  Returns the ctypes uz_sched array for uz_graph_create_lanes."""
+        n, K = len(ops), self.n_lanes
+        sched = (_ffi.uz_sched * max(n, 1))()
+        groups = []                                         # [first, last] op index per group, in order
+        for k, o in enumerate(ops):
+            if groups and ops[groups[-1][1]]["gid"] == o["gid"]:
+                groups[-1][1] = k
+            else:
+                groups.append([k, k])
+        hist = {}                                           # space -> list of [lo, hi, last_writer_gi, readers{gi}]
+        anc = []                                            # per group: bitset of transitive predecessors
+        lane_of, tail = [], [None] * K                      # group -> lane; lane -> last group
+        for gi, (a, b) in enumerate(groups):
+            reads, writes = [], []
+            for o in ops[a:b + 1]:
+                wr = self._WRITES[o["code"]]
+                for j, r in enumerate(o["p"]):
+                    (writes if j in wr else reads).extend(self._resources(r))
+            deps = set()
+            for space, lo, hi in reads:
+                for e in hist.get(space, ()):
+                    if e[0] < hi and lo < e[1] and e[2] is not None:
+                        deps.add(e[2])
+            for space, lo, hi in writes:
+                for e in hist.get(space, ()):
+                    if e[0] < hi and lo < e[1]:
+                        if e[2] is not None:
+                            deps.add(e[2])
+                        deps.update(e[3])
+            deps.discard(gi)
+            mask = 0
+            for d in deps:
+                mask |= anc[d] | (1 << d)
+            # lane choice: continue a lane whose tail is a predecessor (no false ordering); the
+            # most recent such tail first.  Otherwise take an empty lane, else the lane that has
+            # been idle the longest.
+            cands = [l for l in range(K) if tail[l] is not None and (mask >> tail[l]) & 1]
+            if cands:
+                lane = max(cands, key=lambda l: tail[l])
+            else:
+                empty = [l for l in range(K) if tail[l] is None]
+                lane = empty[0] if empty else min(range(K), key=lambda l: tail[l])
+            if tail[lane] is not None:
+                mask |= anc[tail[lane]] | (1 << tail[lane])
+            # waits: latest dependency per foreign lane, unless already implied
+            implied = anc[tail[lane]] | (1 << tail[lane]) if tail[lane] is not None else 0
+            per_lane = {}
+            for d in deps:
+                if lane_of[d] != lane and not (implied >> d) & 1:
+                    per_lane[lane_of[d]] = max(per_lane.get(lane_of[d], -1), d)
+            waits = sorted(per_lane.values())
+            waits = [d for d in waits if not any(d != e and (anc[e] >> d) & 1 for e in waits)]
+            anc.append(mask)
+            lane_of.append(lane)
+            tail[lane] = gi
+            for o in ops[a:b + 1]:
+                o["lane"] = lane
+            sched[a].n_wait = len(waits)
+            for w, d in enumerate(waits):
+                sched[a].wait[w] = groups[d][1]
+                sched[groups[d][1]].signal = 1
+            for k in range(a, b + 1):
+                sched[k].lane = lane
+            # history update
+            for space, lo, hi in reads:
+                for e in hist.setdefault(space, []):
+                    if e[0] < hi and lo < e[1]:
+                        e[3].add(gi)
+                hist[space].append([lo, hi, None, {gi}])
+            for space, lo, hi in writes:
+                lst = hist.setdefault(space, [])
+                keep = [e for e in lst if not (lo <= e[0] and e[1] <= hi)]     # fully covered entries are superseded
+                keep.append([lo, hi, gi, set()])
+                hist[space] = keep
+        return sched
 
     # ------------------------------------------------------------------ execution helpers
     def tensor(self, v):

@@ -4,6 +4,7 @@
 // it into a hipGraph so that the ~1000 launches of a PHiSeg step cost one graph launch.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "uz_common.h"
 
@@ -151,6 +152,89 @@ extern "C" int uz_graph_create(const uz_op* ops, int n_ops, void* stream, void**
     const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e2 != hipSuccess) return uz::fail("graph_create: hipGraphInstantiate failed: %s", hipGetErrorString(e2));
+    *graph_exec_out = exec;
+    return 0;
+}
+// Lane capture: the tape is captured on ONE stream, but before each scheduling group the capture
+// dependency set is replaced (hipStreamUpdateCaptureDependencies) by the tail node of the group's
+// lane plus the tail nodes of the groups it waits for, so the captured graph carries the tape's true
+// DAG instead of one chain.  Independent chains (posterior / prior encoders, likelihood branches)
+// then overlap on the device at replay.  sched[k].lane also selects the scratch copy the host
+// resolved into the op, which is why groups sharing a lane must stay ordered.
+extern "C" int uz_graph_create_lanes(const uz_op* ops, const uz_sched* sched, int n_ops, int n_lanes,
+                                     void* stream, void** graph_exec_out) {
+    hipStream_t st = uz::S(stream);
+    UZ_REQUIRE(st != nullptr, "graph_create_lanes: capture needs a non-default stream");
+    UZ_REQUIRE(n_lanes >= 1 && n_lanes <= UZ_MAX_LANES, "graph_create_lanes: n_lanes %d outside [1,%d]", n_lanes, UZ_MAX_LANES);
+    for (int k = 0; k < n_ops; ++k) {
+        UZ_REQUIRE(sched[k].lane >= 0 && sched[k].lane < n_lanes, "graph_create_lanes: op %d lane %d", k, sched[k].lane);
+        UZ_REQUIRE(sched[k].n_wait >= 0 && sched[k].n_wait <= UZ_MAX_LANES, "graph_create_lanes: op %d n_wait %d", k, sched[k].n_wait);
+        for (int w = 0; w < sched[k].n_wait; ++w)
+            UZ_REQUIRE(sched[k].wait[w] >= 0 && sched[k].wait[w] < k && sched[sched[k].wait[w]].signal,
+                       "graph_create_lanes: op %d waits on op %d which is not an earlier signalling op", k, sched[k].wait[w]);
+    }
+    constexpr int TAILCAP = 4;                      // capture tail of one op: normally exactly one node
+    struct Tail { hipGraphNode_t n[TAILCAP]; int cnt; };
+    Tail* tails = static_cast<Tail*>(calloc(static_cast<size_t>(n_ops) + 1, sizeof(Tail)));
+    if (!tails) return uz::fail("graph_create_lanes: out of host memory");
+    Tail lane_tail[UZ_MAX_LANES] = {};
+    bool lane_used[UZ_MAX_LANES] = {};
+    int rc = 0;
+    auto ok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == 0) rc = uz::fail("graph_create_lanes: %s: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    if (!ok(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture")) { free(tails); return rc; }
+    auto current_tail = [&](Tail& t) {
+        hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+        unsigned long long id = 0;
+        hipGraph_t g = nullptr;
+        const hipGraphNode_t* deps = nullptr;
+        size_t nd = 0;
+        if (!ok(hipStreamGetCaptureInfo_v2(st, &status, &id, &g, &deps, &nd), "hipStreamGetCaptureInfo_v2")) return;
+        if (nd > TAILCAP) { rc = uz::fail("graph_create_lanes: capture tail of %zu nodes", nd); return; }
+        t.cnt = static_cast<int>(nd);
+        for (size_t j = 0; j < nd; ++j) t.n[j] = deps[j];
+    };
+    for (int k = 0; k < n_ops && rc == 0; ++k) {
+        const int lane = sched[k].lane;
+        const bool group_start = (k == 0) || sched[k].n_wait > 0 || sched[k - 1].lane != lane || sched[k - 1].signal;
+        if (group_start) {
+            hipGraphNode_t deps[TAILCAP * (UZ_MAX_LANES + 1)];
+            int nd = 0;
+            if (lane_used[lane]) for (int j = 0; j < lane_tail[lane].cnt; ++j) deps[nd++] = lane_tail[lane].n[j];
+            for (int w = 0; w < sched[k].n_wait; ++w) {
+                const Tail& t = tails[sched[k].wait[w]];
+                for (int j = 0; j < t.cnt; ++j) deps[nd++] = t.n[j];
+            }
+            if (!ok(hipStreamUpdateCaptureDependencies(st, deps, static_cast<size_t>(nd), hipStreamSetCaptureDependencies), "hipStreamUpdateCaptureDependencies")) break;
+        }
+        if (run_one(ops[k], stream) != 0) {
+            char prev[600];
+            strncpy(prev, uz::g_err, sizeof(prev) - 1);
+            prev[sizeof(prev) - 1] = 0;
+            rc = uz::fail("tape op %d (code %d): %s", k, ops[k].code, prev);
+            break;
+        }
+        current_tail(lane_tail[lane]);
+        lane_used[lane] = true;
+        if (sched[k].signal) tails[k] = lane_tail[lane];
+    }
+    if (rc == 0) {                                   // join: the capture ends with every lane's tail as a dependency
+        hipGraphNode_t deps[TAILCAP * UZ_MAX_LANES];
+        int nd = 0;
+        for (int l = 0; l < n_lanes; ++l)
+            if (lane_used[l]) for (int j = 0; j < lane_tail[l].cnt; ++j) deps[nd++] = lane_tail[l].n[j];
+        ok(hipStreamUpdateCaptureDependencies(st, deps, static_cast<size_t>(nd), hipStreamSetCaptureDependencies), "join dependencies");
+    }
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc == 0 && (e != hipSuccess || !graph)) rc = uz::fail("graph_create_lanes: hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    free(tails);
+    hipGraphExec_t exec = nullptr;
+    if (rc == 0) ok(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc != 0) { if (exec) (void)hipGraphExecDestroy(exec); return rc; }
     *graph_exec_out = exec;
     return 0;
 }
