@@ -406,7 +406,7 @@ WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
         const int slots = 256 * ((g.WM * g.WN == 4 && halo) ? 1 : 2);
         double best = 1e30;
         int s = 1;
-        for (int c = 1; c <= g.T; c *= 2) {
+        for (int c = 1; c <= g.T && c <= 4096; ++c) {       // any split count: nt * c should land just under a whole number of rounds
             const double rounds = ceil((double)nt * c / slots);
             const double t = rounds * ceil((double)g.T / c) * t_tile + (double)c * g.WK * n_out * 4.0 * 2.0 / 2.5e12 + 4e-6 * (c * g.WK > 64 ? 2 : 1);
             if (t < best) { best = t; s = c; }
