@@ -13,9 +13,11 @@ LIDC-like inputs, random-init weights, inputs resident in HBM bef
 Extra objects on the line:
   roofline      step-level fp32-MFMA roofline exactly as BASELINE.md section 2 defines it
                 (achieved TFLOP/s = images/s x 100.36 GFLOP/image; peak 157.3 TFLOP/s), plus
-                `dominant_kernel`: the heaviest kernel family measured live with HIP events on the
-                launch stream (algorithmic FLOPs of its launches / their summed duration), and
-                `families`: the same for every kernel family of the step.
+                `dominant_kernel`: the single heaviest kernel (3x3 conv 224->128 at 32x128x128) timed
+                live with HIP events on its launch stream - algorithmic FLOPs per launch / average
+                launch duration - with its PMC-measured HBM bytes per launch as `traffic`;
+                `families`: summed algorithmic FLOPs (or bytes) / summed duration of every kernel
+                family of the step, each op bracketed by HIP events; `dominant_family` = the heaviest.
   cpu_baseline  the CPU oracle (a functional torch restatement of the reference graph = "port")
                 timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -112,6 +114,43 @@ def profile_families(net, plan, reps=3):
             d["bytes"] += op_bytes(ops[k], plan)
             d["launches"] += 1
     return fam
+
+
+def dominant_kernel_live(dev, reps=20):
+    """The single heaviest kernel of the step - conv_mfma_kernel<3,2,2,false> on the 3x3 224 -> 128
+    layer at 32 x 128 x 128 - timed live with HIP events on the stream it is launched on.
+    Algorithmic FLOPs per launch = 2*N*H*W*Cin*Cout*9; HBM bytes per launch come from the committed
+    PMC passes (profiles/r1_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE, calibrated)."""
+    import ctypes as C
+    from unet_zoo_amd import _ffi
+    L = _ffi.lib()
+    Cin, Cout, N, H, W = 224, 128, 32, 128, 128
+    x = torch.randn(N, Cin, H, W, device=dev)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
+    y = torch.empty(N, Cout, H, W, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def launch():
+        _ffi.check(L.uz_conv_fwd(x.data_ptr(), Cin, Cin, w.data_ptr(), None, y.data_ptr(), Cout, Cout, N, H, W, 3, 0, None, 0, st), "conv_fwd")
+    launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * N * H * W * Cin * Cout * 9
+    out = dict(kernel="conv_mfma_kernel<3,2,2,false>", layer="3x3 224->128 @ 32x128x128", flops_per_launch=flops,
+               avg_launch_ms=round(ms, 4), achieved=round(flops / ms / 1e9, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+               frac=round(flops / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), traffic=None)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        k = pmc["kernels"]["conv_mfma_kernel<3,2,2,false> (forward)"]
+        out.update(traffic=k["hbm_bytes"], algorithmic_bytes=k["algorithmic_bytes"], traffic_source="profiles/r1_pmc_traffic.json")
+    except Exception:
+        pass
+    return out
 
 
 def usable_cores():
@@ -260,7 +299,9 @@ def main():
                 fams[k] = e
             dom = max((k for k in fam if fam[k]["flops"]), key=lambda k: fam[k]["ms"])
             roof["families"] = fams
-            roof["dominant_kernel"] = dict(name=dom, **fams[dom])
+            roof["dominant_family"] = dict(name=dom, **fams[dom])
+            roof["dominant_kernel"] = dominant_kernel_live(dev)
+            roof["traffic"] = roof["dominant_kernel"]["traffic"]
         line = dict(metric="images/sec fwd+bwd PHiSeg-7 128x128 bs32", value=round(ips, 2), unit="images/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype="f32", data="synthetic",

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Workload for the HBM-traffic PMC passes (run under `rocprofv3 --pmc FETCH_SIZE` and, separately,
+`--pmc WRITE_SIZE`): the dominant PHiSeg layer (3x3, 224 -> 128 channels, 32 x 128 x 128) forward,
+data gradient and weight gradient through the C ABI, plus the calibration kernel
+`channel_sum_partial` (bias gradient: one coalesced dword per lane over a known byte count, the same
+access width as the conv staging loads) - MI355X_MICROARCH.md asks to calibrate FETCH_SIZE on the
+access pattern in use before trusting an absolute number."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unet_zoo_amd import _ffi
+
+Cin, Cout, N, H, W, ks = 224, 128, 32, 128, 128, 3
+L = _ffi.lib(); dev = torch.device("cuda", 0)
+x = torch.randn(N, Cin, H, W, device=dev); dy = torch.randn(N, Cout, H, W, device=dev)
+w = torch.randn(Cout, Cin, ks, ks, device=dev) * 0.05
+y = torch.empty(N, Cout, H, W, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty(Cout, device=dev)
+wsb = max(L.uz_conv_bwd_weight_workspace(Cin, Cout, N, H, W, ks), L.uz_conv_workspace(Cin, Cout, N, H, W, ks))
+ws = torch.zeros(wsb // 4 + 64, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
+    _ffi.check(L.uz_conv_fwd(x.data_ptr(), Cin, Cin, w.data_ptr(), None, y.data_ptr(), Cout, Cout, N, H, W, ks, 0, ws.data_ptr(), wsb, st), "fwd")
+    _ffi.check(L.uz_conv_bwd_data(dy.data_ptr(), Cout, Cout, w.data_ptr(), dx.data_ptr(), Cin, Cin, N, H, W, ks, 0, ws.data_ptr(), wsb, st), "dgrad")
+    _ffi.check(L.uz_conv_bwd_weight(x.data_ptr(), Cin, Cin, dy.data_ptr(), Cout, Cout, dw.data_ptr(), db.data_ptr(), N, H, W, ks, ws.data_ptr(), wsb, st), "wgrad")
+torch.cuda.synchronize()
+print("algorithmic bytes: x", x.numel() * 4, "y", y.numel() * 4, "w", w.numel() * 4, "calibration read (dy)", dy.numel() * 4)
