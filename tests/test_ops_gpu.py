@@ -33,6 +33,9 @@ CONV_CASES = [
     (2, 38, 32, 16, 16, 1),       # Fcomb
     (2, 192, 2, 8, 8, 1),         # mu / sigma / s heads
     (1, 16, 70, 40, 24, 3),       # Cout not a multiple of the channel tile, W < 32 not a power of two
+    (5, 72, 40, 16, 16, 3),       # 16-wide weight-gradient tiles, ragged channel tiles, odd batch
+    (6, 33, 96, 8, 8, 3),         # 8-wide weight-gradient tiles
+    (3, 20, 36, 20, 16, 3),       # H not a multiple of the 4-row tile
 ]
 
 

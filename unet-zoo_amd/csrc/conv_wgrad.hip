@@ -204,14 +204,15 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Specialisation for the layers that carry almost all of the work: 3x3, W >= 32 (tile = 2 rows x 32
-// columns of one image, patch 4 x 34).  Every LDS offset of the MFMA loop is a compile-time
+// Specialisation for the layers that carry almost all of the work: 3x3, tile = THF rows x TW columns
+// of one image (TW = 32 for W >= 32, else W = 16 or 8; patch (THF+2) x (TW+2)).  Every LDS offset of the MFMA loop is a compile-time
 // immediate, the 32 pixel-pair steps of a tile are fully unrolled (LDS reads are scheduled far ahead
 // of the MFMAs that consume them), and the staging map is one fixed patch word per thread
 // (408 of 512 threads active; a thread walks the input channels with a constant stride).
-template <int WM, int WN, int THF>
+template <int WM, int WN, int THF, int TW>
 __global__ __launch_bounds__(NT, 2) void wgrad_fast_kernel(const WgP p) {
-    constexpr int PW = 34, PS = (THF + 2) * PW, PSP = PS | 1, PT = 32 * THF, PTP = PT + 1;
+    constexpr int PW = TW + 2, PS = (THF + 2) * PW, PSP = PS | 1, PT = TW * THF, PTP = PT + 1;
+    static_assert(TW == 32 || TW == 16 || TW == 8, "tile width");
     constexpr int XG = NT / PS;             // channel groups of the X staging map (3 for 4x34 patches, 2 for 6x34)
     constexpr int COT = 32 * WM, CIT = 32 * WN, WK = 8 / (WM * WN * 2);
     constexpr int DYR = COT * PT / NT, XRN = (CIT + XG - 1) / XG, NSTEP = (PT / 2) / WK, DCS = NT / PT;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_fast_kernel(const WgP p) {
     for (int i = tid; i < COT * PTP + CIT * PSP + 64; i += NT) lds[i] = 0.f;
 
     // staging maps
-    const int pl = tid & (PT - 1), ptx = pl & 31, pty = pl >> 5, dco = tid / PT;
+    const int pl = tid & (PT - 1), ptx = pl & (TW - 1), pty = pl / TW, dco = tid / PT;
     const bool xact = tid < XG * PS;
     const int xg = tid / PS, xr = tid - xg * PS;
     const int xpy = xr / PW, xpx = xr - xpy * PW;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_fast_kernel(const WgP p) {
     float dreg[DYR], xreg[XRN];
     auto gload = [&](int t) {
         const int txi = t % p.tilesX, t2 = t / p.tilesX;
-        const int x0 = txi * 32, y0 = (t2 % p.tilesY) * THF, b0 = t2 / p.tilesY;
+        const int x0 = txi * TW, y0 = (t2 % p.tilesY) * THF, b0 = t2 / p.tilesY;
         {
             const unsigned pm = ((y0 + pty) < p.H && (x0 + ptx) < p.W) ? 0u : 0xFFFFFFFFu;
             const unsigned base = 4u * (unsigned)((b0 * p.CoutTot + co0) * p.HW + y0 * p.W + x0) + dlane;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_fast_kernel(const WgP p) {
             for (int si = 0; si < NSTEP; ++si) {
                 constexpr int dummy = 0; (void)dummy;
                 const int s0 = si * WK;                                  // + wk folded into Ab / Bb
-                const int po = (s0 >> 4) * PW + ((2 * s0) & 31);
+                const int po = ((2 * s0) / TW) * PW + ((2 * s0) & (TW - 1));
                 const float a = Ab[2 * s0];
                 float b[NTAP];
 #pragma unroll
@@ -476,11 +477,12 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         else if (g.WN == 2) UZ_WG_PF(KS_, 1, 2);                                     \
         else UZ_WG_PF(KS_, 1, 1);                                                    \
     } while (0)
-    const bool fast = ks == 3 && g.TW == 32 && (g.TH == 2 || g.TH == 4) && g.TB == 1;
-#define UZ_WG_FAST(WM_, WN_, THF_)                                                                                 \
+    const bool fast = ks == 3 && g.TB == 1 &&
+                      ((g.TW == 32 && (g.TH == 2 || g.TH == 4)) || (g.TW == 16 && g.TH == 4) || (g.TW == 8 && g.TH == 8));
+#define UZ_WG_FAST(WM_, WN_, THF_, TW_)                                                                            \
     do {                                                                                                         \
         static bool attr = false;                                                                                \
-        auto kern = wgrad_fast_kernel<WM_, WN_, THF_>;                                                                 \
+        auto kern = wgrad_fast_kernel<WM_, WN_, THF_, TW_>;                                                      \
         if (!attr) {                                                                                             \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
                 return uz::fail("wgrad: cannot raise dynamic LDS limit");                                        \
@@ -488,16 +490,18 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         }                                                                                                        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);                                             \
     } while (0)
-    if (fast && g.TH == 4) {
-        if (g.WM == 2 && g.WN == 2) UZ_WG_FAST(2, 2, 4);
-        else if (g.WM == 2) UZ_WG_FAST(2, 1, 4);
-        else if (g.WN == 2) UZ_WG_FAST(1, 2, 4);
-        else UZ_WG_FAST(1, 1, 4);
-    } else if (fast) {
-        if (g.WM == 2 && g.WN == 2) UZ_WG_FAST(2, 2, 2);
-        else if (g.WM == 2) UZ_WG_FAST(2, 1, 2);
-        else if (g.WN == 2) UZ_WG_FAST(1, 2, 2);
-        else UZ_WG_FAST(1, 1, 2);
+#define UZ_WG_FAST_T(THF_, TW_)                                                      \
+    do {                                                                             \
+        if (g.WM == 2 && g.WN == 2) UZ_WG_FAST(2, 2, THF_, TW_);                     \
+        else if (g.WM == 2) UZ_WG_FAST(2, 1, THF_, TW_);                             \
+        else if (g.WN == 2) UZ_WG_FAST(1, 2, THF_, TW_);                             \
+        else UZ_WG_FAST(1, 1, THF_, TW_);                                            \
+    } while (0)
+    if (fast) {
+        if (g.TW == 32 && g.TH == 4) UZ_WG_FAST_T(4, 32);
+        else if (g.TW == 32) UZ_WG_FAST_T(2, 32);
+        else if (g.TW == 16) UZ_WG_FAST_T(4, 16);
+        else UZ_WG_FAST_T(8, 8);
     } else if (ks == 3) UZ_WG_TILE(3); else UZ_WG_TILE(1);
     if (int rc = uz::check_launch("wgrad_kernel")) return rc;
     const int n = ks * ks * Cout * Cin;
