@@ -247,15 +247,24 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const float* __restric
 
 struct Geom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB; };
 
-// split the input-channel loop over several workgroups when the output grid alone cannot fill
-// the 256 CUs (deep, small-resolution levels: 2x2 ... 16x16 pixels)
-void pick_split(long long base_grid, int nChunks, int& ksplit, int& cps) {
+// Split the input-channel loop over several workgroups when the output grid alone cannot fill the
+// 256 CUs (deep, small-resolution levels: 2x2 ... 16x16 pixels).  Small cost model: MFMA time of the
+// busiest CU (whole rounds of 256 workgroups x chunks per workgroup) + the slab round trip through
+// HBM + the reduce launch; every split count is tried because base_grid * ksplit should land just
+// under a whole number of rounds.
+void pick_split(long long base_grid, int nChunks, int msub, int kk, double out_bytes, int& ksplit, int& cps) {
     ksplit = 1; cps = nChunks;
     if (base_grid >= 512 || nChunks <= 1) return;          // 2 workgroups per CU already: no split
-    long long want = (512 + base_grid - 1) / base_grid;
-    if (want > nChunks) want = nChunks;
-    cps = (int)((nChunks + want - 1) / want);
-    ksplit = (nChunks + cps - 1) / cps;
+    const double t_chunk = kk * (CK / 2) * msub * NSUB * 64.0 / 2.4e9 / 0.85;     // s per chunk per workgroup, MFMA-bound
+    double best = 1e30;
+    for (int want = 1; want <= nChunks; ++want) {
+        const int c = (nChunks + want - 1) / want, k = (nChunks + c - 1) / c;
+        if (k != want) continue;                            // same split as a smaller `want`
+        const double rounds = (double)((base_grid * k + 255) / 256);
+        const double lonely = base_grid * k <= 256 ? 1.2 : 1.0;     // one workgroup per CU: nothing overlaps its staging and barriers
+        const double t = rounds * (c * t_chunk * lonely + 1.5e-6) + (k > 1 ? (k + 2.0) * out_bytes / 3.0e12 + 4e-6 : 0.0);
+        if (t < best) { best = t; ksplit = k; cps = c; }
+    }
 }
 
 Geom pick_geom(int N, int H, int W, int halo) {
@@ -303,7 +312,8 @@ size_t conv_workspace(int Kc, int Mc, int N, int H, int W, int ks) {
     const Geom g = pick_geom(N, H, W, ks / 2);
     const int cot = Mc <= 32 ? 32 : 64;
     int ksplit, cps;
-    pick_split((long long)g.tilesX * g.tilesY * g.tilesB * ceil_div(Mc, cot), ceil_div(Kc, CK), ksplit, cps);
+    pick_split((long long)g.tilesX * g.tilesY * g.tilesB * ceil_div(Mc, cot), ceil_div(Kc, CK), cot / 32, ks * ks,
+               (double)N * Mc * H * W * sizeof(float), ksplit, cps);
     return ksplit > 1 ? (size_t)ksplit * N * Mc * H * W * sizeof(float) : 0;
 }
 
@@ -329,7 +339,7 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     const int kk = ks * ks;
     const size_t smem = 2 * (size_t)(kk * CK * (cot + 1) + CK * jmax * 256) * sizeof(float);
     const long long base_grid = (long long)g.tilesX * g.tilesY * g.tilesB * p.nCoTiles;
-    pick_split(base_grid, ceil_div(Kc, CK), p.ksplit, p.cps);
+    pick_split(base_grid, ceil_div(Kc, CK), msub, kk, (double)N * Mc * H * W * sizeof(float), p.ksplit, p.cps);
     const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * N * Mc * H * W * sizeof(float) : 0;
     if (p.ksplit > 1 && (!workspace || workspace_bytes < need)) { p.ksplit = 1; p.cps = ceil_div(Kc, CK); }   // no workspace: stay unsplit
     p.slab = static_cast<float*>(workspace);
