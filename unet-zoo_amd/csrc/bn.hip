@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int SMALL_LIMIT = 8192;    // N*H*W at or below which the fused single-launch path is used
+constexpr int SMALL_LIMIT = 4096;    // N*H*W at or below which the fused single-launch path is used
 constexpr int CHUNK = 16384;         // plane elements per workgroup on the large path
 
 struct BnP {
@@ -62,36 +62,53 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const BnP p) {
     }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize(const BnP p) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= p.C) return;
-    const int P = p.N * p.parts;
-    double s = 0.0, ss = 0.0;
-    for (int i = lane; i < P; i += 64) {
-        const double* o = p.part + ((size_t)i * p.C + c) * 2;
-        s += o[0]; ss += o[1];
-    }
-    s = uz::wave_sum_d(s); ss = uz::wave_sum_d(ss);
-    if (lane == 0) {
-        const double n = (double)p.N * p.HW;
-        const double mean = s / n;
-        double var = ss / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        p.save[c] = (float)mean;
-        p.save[p.C + c] = (float)(1.0 / sqrt(var + (double)p.eps));
-        if (p.rmean) {
-            const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-            p.rmean[c] = (float)((1.0 - p.momentum) * p.rmean[c] + p.momentum * mean);
-            p.rvar[c] = (float)((1.0 - p.momentum) * p.rvar[c] + p.momentum * unb);
+// Ordered sum of the per-(image, chunk) fp64 partials of channel c, done by the first wave of every
+// workgroup that needs it (identical order everywhere, so every workgroup gets the same bits) - this
+// replaces a separate "finalize" launch per layer.
+__device__ __forceinline__ void channel_totals(const BnP& p, int c, double* red, double& t0, double& t1) {
+    if (threadIdx.x < 64) {
+        const int P = p.N * p.parts;
+        double s = 0.0, ss = 0.0;
+        for (int i = threadIdx.x; i < P; i += 64) {
+            const double* o = p.part + ((size_t)i * p.C + c) * 2;
+            s += o[0]; ss += o[1];
         }
+        s = uz::wave_sum_d(s); ss = uz::wave_sum_d(ss);
+        if (threadIdx.x == 0) { red[0] = s; red[1] = ss; }
     }
+    __syncthreads();
+    t0 = red[0]; t1 = red[1];
 }
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
+    __shared__ double red[2];
     const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
     float alpha, beta_, mean, rstd;
-    alpha_beta(p, c, alpha, beta_, mean, rstd);
+    if (p.training) {
+        double s, ss;
+        channel_totals(p, c, red, s, ss);
+        const double n = (double)p.N * p.HW;
+        const double m = s / n;
+        double var = ss / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        if (b == 0 && part == 0 && threadIdx.x == 0) {          // one workgroup per channel publishes the statistics
+            p.save[c] = mean;
+            p.save[p.C + c] = rstd;
+            if (p.rmean) {
+                const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                p.rmean[c] = (float)((1.0 - p.momentum) * p.rmean[c] + p.momentum * m);
+                p.rvar[c] = (float)((1.0 - p.momentum) * p.rvar[c] + p.momentum * unb);
+            }
+        }
+        const float g = p.gamma ? p.gamma[c] : 1.f, bb = p.beta ? p.beta[c] : 0.f;
+        alpha = g * rstd;
+        beta_ = bb - mean * alpha;
+    } else {
+        alpha_beta(p, c, alpha, beta_, mean, rstd);
+    }
     const float* src = p.y + ((size_t)b * p.CtotY + c) * p.HW;
     float* dst = p.out + ((size_t)b * p.CtotOut + c) * p.HW;
     const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
@@ -189,32 +206,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_partial(const BnP p) {
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize(const BnP p) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= p.C) return;
-    const int P = p.N * p.parts;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = lane; i < P; i += 64) {
-        const double* o = p.part + ((size_t)i * p.C + c) * 2;
-        s1 += o[0]; s2 += o[1];
-    }
-    s1 = uz::wave_sum_d(s1); s2 = uz::wave_sum_d(s2);
-    if (lane == 0) {
-        const double n = (double)p.N * p.HW;
-        if (p.dbeta) p.dbeta[c] = (float)s1;
-        if (p.dgamma) p.dgamma[c] = (float)s2;
-        p.chan[c] = s1 / n;
-        p.chan[p.C + c] = s2 / n;
-    }
-}
-
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const BnP p) {
     __shared__ double sm[4];
+    __shared__ double red[2];
     const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
     float alpha, beta_, mean, rstd;
     alpha_beta(p, c, alpha, beta_, mean, rstd);
-    const float m1 = (float)p.chan[c], m2 = (float)p.chan[p.C + c];
+    double s1, s2;
+    channel_totals(p, c, red, s1, s2);
+    if (b == 0 && part == 0 && threadIdx.x == 0) {
+        if (p.dbeta) p.dbeta[c] = (float)s1;
+        if (p.dgamma) p.dgamma[c] = (float)s2;
+    }
+    const double n = (double)p.N * p.HW;
+    const float m1 = (float)(s1 / n), m2 = (float)(s2 / n);
     const float* ys = p.y + ((size_t)b * p.CtotY + c) * p.HW;
     const float* ds = p.da + ((size_t)b * p.CtotDa + c) * p.HW;
     float* dst = p.out + ((size_t)b * p.CtotOut + c) * p.HW;
@@ -379,8 +385,6 @@ extern "C" int uz_bn_relu_fwd(const float* y, int C, int CtotY, const float* gam
         if (vec) hipLaunchKernelGGL(bn_stats_partial<true>, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(bn_stats_partial<false>, grid, dim3(256), 0, st, p);
         if (int rc = uz::check_launch("bn_stats_partial")) return rc;
-        hipLaunchKernelGGL(bn_finalize, dim3(uz::ceil_div(C, 4)), dim3(256), 0, st, p);
-        if (int rc = uz::check_launch("bn_finalize")) return rc;
     }
     if (vec) hipLaunchKernelGGL(bn_apply<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(bn_apply<false>, grid, dim3(256), 0, st, p);
@@ -412,8 +416,6 @@ extern "C" int uz_bn_relu_bwd(const float* da, int CtotDa, const float* y, int C
     if (vec) hipLaunchKernelGGL(bn_bwd_reduce_partial<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(bn_bwd_reduce_partial<false>, grid, dim3(256), 0, st, p);
     if (int rc = uz::check_launch("bn_bwd_reduce_partial")) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize, dim3(uz::ceil_div(C, 4)), dim3(256), 0, st, p);
-    if (int rc = uz::check_launch("bn_bwd_finalize")) return rc;
     if (vec) hipLaunchKernelGGL(bn_bwd_apply<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(bn_bwd_apply<false>, grid, dim3(256), 0, st, p);
     if (int rc = uz::check_launch("bn_bwd_apply")) return rc;

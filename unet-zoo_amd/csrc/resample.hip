@@ -76,32 +76,38 @@ __global__ __launch_bounds__(256) void bilinear_fwd_k(const RsP p) {
     }
 }
 // gather form of upsample_bilinear2d_backward: every low-res pixel sums the <= 7x7 high-res pixels
-// whose interpolation footprint touches it (weights recomputed exactly as in the forward)
+// whose interpolation footprint touches it (weights recomputed exactly as in the forward).  The
+// per-row / per-column tap weights depend only on the coordinate, so a workgroup tabulates them once
+// in LDS (planes up to 128 x 128 low-res; larger planes compute them per pixel).
+__device__ __forceinline__ float tap_weight(int o, int osize, float scale, int ac, int isize, int i) {
+    if (o < 0 || o >= osize) return 0.f;
+    int i0, ip; float l0, l1;
+    src_index(o, scale, ac, isize, i0, ip, l0, l1);
+    return (i0 == i ? l0 : 0.f) + (i0 + ip == i ? l1 : 0.f);
+}
+constexpr int BTAB = 128;
 __global__ __launch_bounds__(256) void bilinear_bwd_k(const RsP p) {   // src = dy (high res), dst = dx (low res)
+    __shared__ float wyT[BTAB * 7], wxT[BTAB * 7];
     const int c = blockIdx.y, b = blockIdx.z;
     const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
     float* d = p.dst + ((size_t)b * p.CtotD + c) * p.H * p.W;
     const int n = p.H * p.W;
+    const bool tab = p.H <= BTAB && p.W <= BTAB;
+    if (tab) {
+        for (int e = threadIdx.x; e < (p.H + p.W) * 7; e += 256) {
+            if (e < p.H * 7) { const int i = e / 7, k = e - i * 7; wyT[e] = tap_weight(2 * i - 2 + k, p.Ho, p.sh, p.ac, p.H, i); }
+            else { const int e2 = e - p.H * 7, i = e2 / 7, k = e2 - i * 7; wxT[e2] = tap_weight(2 * i - 2 + k, p.Wo, p.sw, p.ac, p.W, i); }
+        }
+        __syncthreads();
+    }
     for (int q = blockIdx.x * PCH + threadIdx.x; q < min(n, (int)(blockIdx.x + 1) * PCH); q += 256) {
         const int iy = q / p.W, ix = q - iy * p.W;
         float wy[7], wx[7];
         const int oy0 = 2 * iy - 2, ox0 = 2 * ix - 2;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
-            int i0, ip; float l0, l1;
-            const int oy = oy0 + k, ox = ox0 + k;
-            float w = 0.f;
-            if (oy >= 0 && oy < p.Ho) {
-                src_index(oy, p.sh, p.ac, p.H, i0, ip, l0, l1);
-                w = (i0 == iy ? l0 : 0.f) + (i0 + ip == iy ? l1 : 0.f);
-            }
-            wy[k] = w;
-            w = 0.f;
-            if (ox >= 0 && ox < p.Wo) {
-                src_index(ox, p.sw, p.ac, p.W, i0, ip, l0, l1);
-                w = (i0 == ix ? l0 : 0.f) + (i0 + ip == ix ? l1 : 0.f);
-            }
-            wx[k] = w;
+            wy[k] = tab ? wyT[iy * 7 + k] : tap_weight(oy0 + k, p.Ho, p.sh, p.ac, p.H, iy);
+            wx[k] = tab ? wxT[ix * 7 + k] : tap_weight(ox0 + k, p.Wo, p.sw, p.ac, p.W, ix);
         }
         float acc = 0.f;
 #pragma unroll
