@@ -311,7 +311,42 @@ __global__ __launch_bounds__(NT, 2) void wgrad_fast_kernel(const WgP p) {
                 for (int k = 0; k < NTAP; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[k], acc[k], 0, 0, 0);
             }
         }
-        float* out = p.slab + (size_t)(split * WK + wk) * 9 * p.Cout * p.Cin;
+        // The WK pixel-pair groups of the workgroup hold partial sums of the same outputs: fold them
+        // pairwise through LDS (fixed order ((0+2)+(1+3)), three taps per round so the staging area
+        // suffices) and let group 0 write ONE slab per workgroup instead of WK.
+        if constexpr (WK > 1) {
+            constexpr int NW = 2 * WM * WN, RT = 3;             // waves per wk group, taps per round
+            float* red = lds;
+            const int slot = wmn * 2 + tg;
+#pragma unroll
+            for (int stride = WK / 2; stride >= 1; stride >>= 1) {
+#pragma unroll
+                for (int k0 = 0; k0 < 5; k0 += RT) {
+                    __syncthreads();
+                    if (wk >= stride && wk < 2 * stride) {
+                        float* dstp = red + (size_t)(((wk - stride) * NW + slot) * RT) * 16 * 64 + lane;
+#pragma unroll
+                        for (int kk = 0; kk < RT; ++kk)
+                            if (k0 + kk < NTAP) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) dstp[(kk * 16 + r) * 64] = acc[k0 + kk][r];
+                            }
+                    }
+                    __syncthreads();
+                    if (wk < stride) {
+                        const float* srcp = red + (size_t)((wk * NW + slot) * RT) * 16 * 64 + lane;
+#pragma unroll
+                        for (int kk = 0; kk < RT; ++kk)
+                            if (k0 + kk < NTAP) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[k0 + kk][r] += srcp[(kk * 16 + r) * 64];
+                            }
+                    }
+                }
+            }
+            if (wk != 0) return;
+        }
+        float* out = p.slab + (size_t)split * 9 * p.Cout * p.Cin;
         const int ci = ci0 + wn * 32 + l31;
 #pragma unroll
         for (int k = 0; k < NTAP; ++k)
@@ -371,7 +406,7 @@ __global__ __launch_bounds__(64) void channel_sum_final(const double* __restrict
     if (threadIdx.x == 0) db[c] = (float)s;
 }
 
-struct WGeom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB, T, S, nCoT, nCiT, WM, WN, WK, pf; };
+struct WGeom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB, T, S, nCoT, nCiT, WM, WN, WK, pf, fast, SW; };   // SW: slabs per pixel split
 
 WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
     WGeom g;
@@ -396,6 +431,9 @@ WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
     g.nCoT = uz::ceil_div(Cout, 32 * g.WM);
     g.nCiT = uz::ceil_div(Cin, 32 * g.WN);
     g.pf = (32 * g.WN * g.PS <= 18 * 512) ? 1 : 0;
+    g.fast = halo == 1 && g.TB == 1 &&
+             ((g.TW == 32 && (g.TH == 2 || g.TH == 4)) || (g.TW == 16 && g.TH == 4) || (g.TW == 8 && g.TH == 8));
+    g.SW = g.fast ? 1 : g.WK;                 // the fast kernels fold their WK partial sums in LDS
     // pixel splits S: small cost model instead of a fixed target.  More splits = more workgroups in flight
     // (the only parallelism a low-resolution layer has) but S*WK partial slabs of Cout*Cin*k*k floats to
     // write and re-read; fewer splits = longer serial tile loops per workgroup.
@@ -409,7 +447,7 @@ WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
         int s = 1;
         for (int c = 1; c <= g.T && c <= 4096; ++c) {       // any split count: nt * c should land just under a whole number of rounds
             const double rounds = ceil((double)nt * c / slots);
-            const double t = rounds * ceil((double)g.T / c) * t_tile + (double)c * g.WK * n_out * 4.0 * 2.0 / 2.5e12 + 4e-6 * (c * g.WK > 64 ? 2 : 1);
+            const double t = rounds * ceil((double)g.T / c) * t_tile + (double)c * g.SW * n_out * 4.0 * 2.0 / 2.5e12 + 4e-6 * (c * g.SW > 64 ? 2 : 1);
             if (t < best) { best = t; s = c; }
         }
         g.S = s;
@@ -421,7 +459,7 @@ WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
 
 extern "C" size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, int W, int ks) {
     const WGeom g = pick_wgeom(Cin, Cout, N, H, W, ks / 2);
-    const size_t slabs = (size_t)g.S * g.WK * ks * ks * Cout * Cin * sizeof(float);
+    const size_t slabs = (size_t)g.S * g.SW * ks * ks * Cout * Cin * sizeof(float);
     const size_t dbp = (size_t)Cout * CSB * sizeof(double);
     size_t need = slabs > dbp ? slabs : dbp;
     if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) {
@@ -443,7 +481,7 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         if (rc != -2) return rc;
     }
     const WGeom g = pick_wgeom(Cin, Cout, N, H, W, ks / 2);
-    const size_t need = (size_t)g.S * g.WK * ks * ks * Cout * Cin * sizeof(float);
+    const size_t need = (size_t)g.S * g.SW * ks * ks * Cout * Cin * sizeof(float);
     UZ_REQUIRE(workspace && workspace_bytes >= need, "conv_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = uz::S(stream);
     WgP p;
@@ -456,7 +494,11 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
     p.PT = g.TW * g.TH * g.TB > 64 ? 128 : 64; p.PTP = p.PT + 1;
     p.nCoT = g.nCoT; p.nCiT = g.nCiT;
     const int cot = 32 * g.WM, cit = 32 * g.WN;
-    const size_t smem = ((size_t)cot * p.PTP + (size_t)cit * p.PSP + 64 + 2 * (size_t)p.PS) * sizeof(float);
+    size_t smem = ((size_t)cot * p.PTP + (size_t)cit * p.PSP + 64 + 2 * (size_t)p.PS) * sizeof(float);
+    if (g.fast && g.WK > 1) {                 // LDS for the in-workgroup fold: WK/2 writer groups x waves x 3 taps x 16 x 64 floats
+        const size_t fold = (size_t)(g.WK / 2) * (2 * g.WM * g.WN) * 3 * 16 * 64 * sizeof(float);
+        if (fold > smem) smem = fold;
+    }
     const int grid = g.nCoT * g.nCiT * g.S;
 #define UZ_WG_LAUNCH(KS_, WM_, WN_, PF_)                                                                         \
     do {                                                                                                         \
@@ -477,8 +519,7 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         else if (g.WN == 2) UZ_WG_PF(KS_, 1, 2);                                     \
         else UZ_WG_PF(KS_, 1, 1);                                                    \
     } while (0)
-    const bool fast = ks == 3 && g.TB == 1 &&
-                      ((g.TW == 32 && (g.TH == 2 || g.TH == 4)) || (g.TW == 16 && g.TH == 4) || (g.TW == 8 && g.TH == 8));
+    const bool fast = g.fast != 0;
 #define UZ_WG_FAST(WM_, WN_, THF_, TW_)                                                                            \
     do {                                                                                                         \
         static bool attr = false;                                                                                \
@@ -507,7 +548,7 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
     const int n = ks * ks * Cout * Cin;
     int rgrid = uz::ceil_div(n, 256);
     if (rgrid > 4096) rgrid = 4096;
-    const int Stot = g.S * g.WK;
+    const int Stot = g.S * g.SW;
     int RG = 1;
     if (Stot > 64) {
         RG = 32;
