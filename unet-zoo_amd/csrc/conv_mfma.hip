@@ -16,6 +16,7 @@
 // double buffered: global loads for chunk c+1 are issued before the 36 k-steps of chunk c and
 // written to the other buffer afterwards (one barrier per chunk).  All 9 taps reuse the same
 // patch through a constant LDS offset, so HBM/L2 sees each input element once per channel tile.
+#include <stdlib.h>
 #include "uz_common.h"
 
 namespace {
@@ -254,6 +255,10 @@ struct Geom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB; };
 // under a whole number of rounds.
 void pick_split(long long base_grid, int nChunks, int msub, int kk, double out_bytes, int& ksplit, int& cps) {
     ksplit = 1; cps = nChunks;
+    if (const char* f = getenv("UZ_FORCE_KSPLIT")) {        // experiments only
+        const int want = atoi(f);
+        if (want >= 1 && want <= nChunks) { cps = (nChunks + want - 1) / want; ksplit = (nChunks + cps - 1) / cps; return; }
+    }
     if (base_grid >= 512 || nChunks <= 1) return;          // 2 workgroups per CU already: no split
     const double t_chunk = kk * (CK / 2) * msub * NSUB * 64.0 / 2.4e9 / 0.85;     // s per chunk per workgroup, MFMA-bound
     double best = 1e30;
