@@ -15,7 +15,7 @@ constexpr int PIX = 1024;        // pixels per workgroup (256 threads x float4)
 
 struct C1P {
     const float* x; const float* w; const float* bias; const float* dy; float* y; float* dx; double* part;
-    int Cin, CinTot, Cout, CoutTot, N, HW, nchunk, accumulate;
+    int Cin, CinTot, Cout, CoutTot, N, HW, nchunk, accumulate, cgroup;
 };
 
 template <int NO, bool VEC>
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void c1_fwd(const C1P p) {
         float4 acc[NO];
 #pragma unroll
         for (int n = 0; n < NO; ++n) { const float bv = p.bias ? p.bias[n] : 0.f; acc[n] = make_float4(bv, bv, bv, bv); }
+#pragma unroll 8
         for (int c = 0; c < p.Cin; ++c) {
             const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)c * p.HW + q);
 #pragma unroll
@@ -67,13 +68,15 @@ __global__ __launch_bounds__(256) void c1_bwd_data(const C1P p) {
     __syncthreads();
     const float* db = p.dy + (size_t)b * p.CoutTot * p.HW;
     float* xb = p.dx + (size_t)b * p.CinTot * p.HW;
+    const int c_lo = blockIdx.z * p.cgroup, c_hi = min(p.Cin, c_lo + p.cgroup);   // input-channel group of this workgroup
     if (VEC) {
         const int q = (blockIdx.x * 256 + threadIdx.x) * 4;
         if (q >= p.HW) return;
         float4 g[NO];
 #pragma unroll
         for (int n = 0; n < NO; ++n) g[n] = *reinterpret_cast<const float4*>(db + (size_t)n * p.HW + q);
-        for (int c = 0; c < p.Cin; ++c) {
+#pragma unroll 4
+        for (int c = c_lo; c < c_hi; ++c) {
             float4* dst = reinterpret_cast<float4*>(xb + (size_t)c * p.HW + q);
             float4 r = p.accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void c1_bwd_data(const C1P p) {
             float g[NO];
 #pragma unroll
             for (int n = 0; n < NO; ++n) g[n] = db[(size_t)n * p.HW + q];
-            for (int c = 0; c < p.Cin; ++c) {
+            for (int c = c_lo; c < c_hi; ++c) {
                 float* dst = xb + (size_t)c * p.HW + q;
                 float r = p.accumulate ? *dst : 0.f;
 #pragma unroll
@@ -106,32 +109,69 @@ __global__ __launch_bounds__(256) void c1_bwd_weight_partial(const C1P p) {
     const int c = blockIdx.x, k = blockIdx.y;
     const bool do_bias = (c == 0);            // the c == 0 blocks also sum dy for the bias gradient
     const long long total = (long long)p.N * p.HW;
-    const long long per = (total + p.nchunk - 1) / p.nchunk;
+    const long long per = ((total + p.nchunk - 1) / p.nchunk + 1023) / 1024 * 1024;     // multiple of the float4 sweep
     const long long lo = k * per, hi = min(total, lo + per);
-    float acc[NO];
-#pragma unroll
-    for (int n = 0; n < NO; ++n) acc[n] = 0.f;
     double dacc[2 * NO];
 #pragma unroll
     for (int n = 0; n < 2 * NO; ++n) dacc[n] = 0.0;
-    int cnt = 0;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        const int b = (int)(i / p.HW), q = (int)(i - (long long)b * p.HW);
-        const float xv = p.x[((size_t)b * p.CinTot + c) * p.HW + q];
+    // fp32 running sums are flushed into fp64 every 32 steps; (b, q) advance incrementally (no per-step division)
+    if (p.HW % 4 == 0 && per % 4 == 0) {
+        float4 acc[NO], bacc[NO];
+#pragma unroll
+        for (int n = 0; n < NO; ++n) { acc[n] = make_float4(0.f, 0.f, 0.f, 0.f); bacc[n] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        long long i = lo + 4 * threadIdx.x;
+        int b = (int)(i / p.HW), q = (int)(i - (long long)b * p.HW), cnt = 0;
+        for (; i < hi; i += 1024) {
+            const float4 xv = *reinterpret_cast<const float4*>(p.x + ((size_t)b * p.CinTot + c) * p.HW + q);
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+                const float4 g = *reinterpret_cast<const float4*>(p.dy + ((size_t)b * p.CoutTot + n) * p.HW + q);
+                acc[n].x = fmaf(g.x, xv.x, acc[n].x); acc[n].y = fmaf(g.y, xv.y, acc[n].y);
+                acc[n].z = fmaf(g.z, xv.z, acc[n].z); acc[n].w = fmaf(g.w, xv.w, acc[n].w);
+                if (do_bias) { bacc[n].x += g.x; bacc[n].y += g.y; bacc[n].z += g.z; bacc[n].w += g.w; }
+            }
+            q += 1024;
+            while (q >= p.HW) { q -= p.HW; ++b; }
+            if (++cnt == 32) {
+#pragma unroll
+                for (int n = 0; n < NO; ++n) {
+                    dacc[n] += (double)((acc[n].x + acc[n].y) + (acc[n].z + acc[n].w));
+                    dacc[NO + n] += (double)((bacc[n].x + bacc[n].y) + (bacc[n].z + bacc[n].w));
+                    acc[n] = make_float4(0.f, 0.f, 0.f, 0.f); bacc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                cnt = 0;
+            }
+        }
 #pragma unroll
         for (int n = 0; n < NO; ++n) {
-            const float g = p.dy[((size_t)b * p.CoutTot + n) * p.HW + q];
-            acc[n] = fmaf(g, xv, acc[n]);
-            if (do_bias) dacc[NO + n] += g;
+            dacc[n] += (double)((acc[n].x + acc[n].y) + (acc[n].z + acc[n].w));
+            dacc[NO + n] += (double)((bacc[n].x + bacc[n].y) + (bacc[n].z + bacc[n].w));
         }
-        if (++cnt == 64) {          // flush the fp32 running sums into fp64 regularly
+    } else {
+        float acc[NO];
 #pragma unroll
-            for (int n = 0; n < NO; ++n) { dacc[n] += acc[n]; acc[n] = 0.f; }
-            cnt = 0;
+        for (int n = 0; n < NO; ++n) acc[n] = 0.f;
+        long long i = lo + threadIdx.x;
+        int b = (int)(i / p.HW), q = (int)(i - (long long)b * p.HW), cnt = 0;
+        for (; i < hi; i += 256) {
+            const float xv = p.x[((size_t)b * p.CinTot + c) * p.HW + q];
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+                const float g = p.dy[((size_t)b * p.CoutTot + n) * p.HW + q];
+                acc[n] = fmaf(g, xv, acc[n]);
+                if (do_bias) dacc[NO + n] += g;
+            }
+            q += 256;
+            while (q >= p.HW) { q -= p.HW; ++b; }
+            if (++cnt == 64) {
+#pragma unroll
+                for (int n = 0; n < NO; ++n) { dacc[n] += acc[n]; acc[n] = 0.f; }
+                cnt = 0;
+            }
         }
+#pragma unroll
+        for (int n = 0; n < NO; ++n) dacc[n] += acc[n];
     }
-#pragma unroll
-    for (int n = 0; n < NO; ++n) dacc[n] += acc[n];
     uz::block_sum_d<2 * NO>(dacc, sm);
     if (threadIdx.x == 0) {
 #pragma unroll
@@ -194,7 +234,13 @@ int conv1x1_small_bwd_data(const float* dy, int Cout, int CoutTot, const float* 
     C1P p = {}; p.dy = dy; p.w = w; p.dx = dx; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot; p.N = N; p.HW = H * W;
     p.accumulate = accumulate;
     const bool v = vec4(p.HW, dy, dx);
-    const dim3 grid(ceil_div(p.HW, PIX), N);
+    // low-resolution planes have few pixel blocks: split the input channels over grid.z until ~1024 workgroups exist
+    const int pixblk = ceil_div(p.HW, PIX) * N;
+    int groups = ceil_div(1024, pixblk);
+    if (groups > ceil_div(Cin, 8)) groups = ceil_div(Cin, 8);
+    if (groups < 1) groups = 1;
+    p.cgroup = ceil_div(Cin, groups);
+    const dim3 grid(ceil_div(p.HW, PIX), N, ceil_div(Cin, p.cgroup));
     C1_DISPATCH(c1_bwd_data, v, grid)
     return check_launch("c1_bwd_data");
 }
