@@ -229,20 +229,33 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
     }
 }
 
-// y[b,co,p] = (accumulate ? y : 0) + bias[co] + sum_s slab[s][b,co,p]  (fixed order), optional ReLU
+// y[b,co,p] = (accumulate ? y : 0) + bias[co] + sum_s slab[s][b,co,p]  (fixed order), optional ReLU.
+// V = 4: float4 sweep (HW % 4 == 0, 16-byte aligned output view); one 32-bit division pair per vector.
+template <int V>
 __global__ __launch_bounds__(256) void conv_splitk_reduce(const float* __restrict__ slab, int ksplit, const float* __restrict__ bias,
                                                           float* __restrict__ y, int Cout, int CoutTot, int N, int HW, int relu, int accumulate) {
-    const size_t n = (size_t)N * Cout * HW;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % HW);
-        const int co = (int)((i / HW) % Cout);
-        const int b = (int)(i / ((size_t)HW * Cout));
-        float s = bias ? bias[co] : 0.f;
-        for (int k = 0; k < ksplit; ++k) s += slab[(size_t)k * n + i];
-        float* dst = y + ((size_t)b * CoutTot + co) * HW + q;
-        if (accumulate) s += *dst;
-        if (relu) s = fmaxf(s, 0.f);
-        *dst = s;
+    const unsigned n = (unsigned)N * Cout * HW;              // < 2^31 floats per slab (checked by the host)
+    const unsigned chw = (unsigned)Cout * HW;
+    for (unsigned i = (blockIdx.x * 256u + threadIdx.x) * V; i < n; i += gridDim.x * 256u * V) {
+        const unsigned b = i / chw, r = i - b * chw, co = r / (unsigned)HW;
+        float* dst = y + (size_t)b * CoutTot * HW + r;
+        const float bv = bias ? bias[co] : 0.f;
+        if (V == 4) {
+            float4 s = make_float4(bv, bv, bv, bv);
+            for (int k = 0; k < ksplit; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)k * n + i);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+            if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+            *reinterpret_cast<float4*>(dst) = s;
+        } else {
+            float s = bv;
+            for (int k = 0; k < ksplit; ++k) s += slab[(size_t)k * n + i];
+            if (accumulate) s += *dst;
+            if (relu) s = fmaxf(s, 0.f);
+            *dst = s;
+        }
     }
 }
 
@@ -355,9 +368,12 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     else rc = dgrad ? launch_ks<1, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<1, false>(p, msub, jmax, (int)grid, smem, st);
     if (rc || p.ksplit == 1) return rc;
     const size_t n = (size_t)N * Mc * H * W;
-    int rgrid = (int)((n + 255) / 256);
+    UZ_REQUIRE(n < (1ull << 31), "conv: split-K slab too large");
+    const bool v4 = (H * W) % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.slab) & 15) == 0;
+    int rgrid = (int)((n / (v4 ? 4 : 1) + 255) / 256);
     if (rgrid > 2048) rgrid = 2048;
-    hipLaunchKernelGGL(conv_splitk_reduce, dim3(rgrid), dim3(256), 0, st, p.slab, p.ksplit, bias, y, Mc, McTot, N, H * W, relu, accumulate);
+    if (v4) hipLaunchKernelGGL(conv_splitk_reduce<4>, dim3(rgrid), dim3(256), 0, st, p.slab, p.ksplit, bias, y, Mc, McTot, N, H * W, relu, accumulate);
+    else hipLaunchKernelGGL(conv_splitk_reduce<1>, dim3(rgrid), dim3(256), 0, st, p.slab, p.ksplit, bias, y, Mc, McTot, N, H * W, relu, accumulate);
     return check_launch("conv_splitk_reduce");
 }
 
