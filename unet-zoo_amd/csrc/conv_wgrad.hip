@@ -371,16 +371,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_groups(float* __restrict__ s
         slab[(size_t)lo * n + i] = s;
     }
 }
-// stage 2: dW[co][ci][tap] = sum_g slab[g*RG][tap][co][ci]  (fixed order)
+// stage 2: dW[co][ci][tap] = sum_g slab[g*RG][tap][co][ci]  (fixed order).  One thread per (co, ci): KK coalesced
+// read streams (lane = consecutive ci) and KK consecutive output floats per thread.
+template <int KK>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                            int S, int RG, int KK, int Cout, int Cin) {
-    const int n = KK * Cout * Cin;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < S; k += RG) s += slab[(size_t)k * n + i];
-        const int tap = i / (Cout * Cin), rem = i - tap * (Cout * Cin);
-        dw[(size_t)rem * KK + tap] = s;
+                                                            int S, int RG, int Cout, int Cin) {
+    const int m = Cout * Cin, n = KK * m;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    float s[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) s[t] = 0.f;
+    for (int k = 0; k < S; k += RG) {
+        const float* src = slab + (size_t)k * n + j;
+#pragma unroll
+        for (int t = 0; t < KK; ++t) s[t] += src[(size_t)t * m];
     }
+#pragma unroll
+    for (int t = 0; t < KK; ++t) dw[(size_t)j * KK + t] = s[t];
 }
 
 // db[c] = sum_{b,y,x} dy[b,c,y,x]: CSB blocks per channel write fp64 partials, then one wave per
@@ -555,7 +563,9 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         hipLaunchKernelGGL(wgrad_reduce_groups, dim3(rgrid, uz::ceil_div(Stot, RG)), dim3(256), 0, st, p.slab, Stot, RG, n);
         if (int rc = uz::check_launch("wgrad_reduce_groups")) return rc;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, st, p.slab, dw, Stot, RG, ks * ks, Cout, Cin);
+    const int fgrid = uz::ceil_div(Cout * Cin, 256);
+    if (ks == 3) hipLaunchKernelGGL(wgrad_reduce_kernel<9>, dim3(fgrid), dim3(256), 0, st, p.slab, dw, Stot, RG, Cout, Cin);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(fgrid), dim3(256), 0, st, p.slab, dw, Stot, RG, Cout, Cin);
     if (int rc = uz::check_launch("wgrad_reduce_kernel")) return rc;
     if (db) {
         // the slab workspace is free again after the reduction above; it holds the fp64 partials
