@@ -116,11 +116,22 @@ def profile_families(net, plan, reps=3):
     return fam
 
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
+SPLIT_PRODUCTS = 6                # bf16 piece products per fp32 product in conv_split.hip
+
+
+def conv_math():
+    return os.environ.get("UZ_CONV_MATH", "default")
+
+
 def dominant_kernel_live(dev, reps=20):
-    """The single heaviest kernel of the step - conv_mfma_kernel<3,2,2,false> on the 3x3 224 -> 128
-    layer at 32 x 128 x 128 - timed live with HIP events on the stream it is launched on.
-    Algorithmic FLOPs per launch = 2*N*H*W*Cin*Cout*9; HBM bytes per launch come from the committed
-    PMC passes (profiles/r1_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE, calibrated)."""
+    """The single heaviest kernel of the step - the 3x3 forward convolution 224 -> 128 at 32 x 128 x 128 -
+    timed live with HIP events on the stream it is launched on.  Algorithmic FLOPs per launch =
+    2*N*H*W*Cin*Cout*9.  In the default mode this layer runs on conv_split_kernel<2> (three bf16 pieces
+    per fp32 operand, six piece products on the bf16 matrix pipe, fp32 accumulate): its roof is the
+    dense bf16 MFMA peak divided by the six products.  With UZ_CONV_MATH=f32 it runs on
+    conv_mfma_kernel<3,2,2,false> against the fp32 MFMA peak.  HBM bytes per launch come from the
+    committed PMC passes (profiles/r1_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE, calibrated)."""
     import ctypes as C
     from unet_zoo_amd import _ffi
     L = _ffi.lib()
@@ -128,10 +139,13 @@ def dominant_kernel_live(dev, reps=20):
     x = torch.randn(N, Cin, H, W, device=dev)
     w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
     y = torch.empty(N, Cout, H, W, device=dev)
+    wsb = L.uz_conv_workspace(Cin, Cout, N, H, W, 3)
+    ws = torch.zeros(wsb // 4 + 64, device=dev)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def launch():
-        _ffi.check(L.uz_conv_fwd(x.data_ptr(), Cin, Cin, w.data_ptr(), None, y.data_ptr(), Cout, Cout, N, H, W, 3, 0, None, 0, st), "conv_fwd")
+        _ffi.check(L.uz_conv_fwd(x.data_ptr(), Cin, Cin, w.data_ptr(), None, y.data_ptr(), Cout, Cout, N, H, W, 3, 0,
+                                 ws.data_ptr(), wsb, st), "conv_fwd")
     launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -141,16 +155,37 @@ def dominant_kernel_live(dev, reps=20):
     e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * N * H * W * Cin * Cout * 9
-    out = dict(kernel="conv_mfma_kernel<3,2,2,false>", layer="3x3 224->128 @ 32x128x128", flops_per_launch=flops,
-               avg_launch_ms=round(ms, 4), achieved=round(flops / ms / 1e9, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-               frac=round(flops / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), traffic=None)
+    split = conv_math() != "f32"
+    peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS if split else PEAK_F32_MFMA_TFLOPS
+    out = dict(kernel="conv_split_kernel<2> (+ pack_weights_kernel)" if split else "conv_mfma_kernel<3,2,2,false>",
+               layer="3x3 224->128 @ 32x128x128", flops_per_launch=flops,
+               avg_launch_ms=round(ms, 4), achieved=round(flops / ms / 1e9, 2), peak=round(peak, 1), unit="TFLOP/s",
+               frac=round(flops / ms / 1e9 / peak, 4), traffic=None,
+               peak_note=("dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product" if split else "fp32 MFMA peak"))
+    if split:
+        out["bf16_mfma_tflops"] = round(SPLIT_PRODUCTS * flops / ms / 1e9, 1)
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-        k = pmc["kernels"]["conv_mfma_kernel<3,2,2,false> (forward)"]
+        k = pmc["kernels"]["conv_split_kernel<2> (forward)" if split else "conv_mfma_kernel<3,2,2,false> (forward)"]
         out.update(traffic=k["hbm_bytes"], algorithmic_bytes=k["algorithmic_bytes"], traffic_source="profiles/r1_pmc_traffic.json")
     except Exception:
         pass
     return out
+
+
+def fp32_only_leg(args):
+    """Same benchmark in a child process with UZ_CONV_MATH=f32 (every convolution on the fp32 MFMA kernels)."""
+    import subprocess
+    env = dict(os.environ, UZ_CONV_MATH="f32")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--batch", str(args.batch), "--skip-cpu", "--no-profile", "--no-f32-leg"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return dict(value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"], frac=d["roofline"]["frac"],
+                    note="identical run with UZ_CONV_MATH=f32: all convolutions on v_mfma_f32_32x32x2_f32")
+    except Exception as e:                                   # never fail the headline line because of the extra leg
+        return dict(error=str(e)[:200])
 
 
 def usable_cores():
@@ -217,6 +252,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-family HIP-event pass")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32-MFMA-only measurement (child process)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -307,8 +343,14 @@ def main():
                     vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload="PHiSeg 7 resolution / 5 latent levels, filters 32-64-128-192x4, 1x128x128, fwd+loss+bwd+Adam",
                                 batch_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f"dp{world}",
-                                graphs=not args.no_graphs, final_loss=final_loss),
+                                graphs=not args.no_graphs, final_loss=final_loss,
+                                conv_math=("fp32 MFMA only (UZ_CONV_MATH=f32)" if conv_math() == "f32" else
+                                           "fp32 in / fp32 out; large 3x3 layers (fwd, dgrad): operands split exactly into 3 bf16 pieces, "
+                                           "6 piece products on the bf16 matrix pipe, fp32 accumulate (error vs fp64 1.7x the fp32-MFMA "
+                                           "kernel's, logits 2.6e-5 from the reference); other layers and all weight gradients: fp32 MFMA")),
                     roofline=roof)
+        if world == 1 and not args.no_f32_leg and conv_math() != "f32":
+            line["fp32_mfma_only"] = fp32_only_leg(args)
         if not args.skip_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(line))
