@@ -470,6 +470,10 @@ extern "C" size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, 
     const size_t slabs = (size_t)g.S * g.SW * ks * ks * Cout * Cin * sizeof(float);
     const size_t dbp = (size_t)Cout * CSB * sizeof(double);
     size_t need = slabs > dbp ? slabs : dbp;
+    if (uz::wgrad_split_ok(Cin, Cout, N, H, W, ks)) {
+        const size_t sp = (size_t)uz::wgrad_split_splits(Cin, Cout, N, H, W) * ks * ks * Cout * Cin * sizeof(float);
+        if (sp > need) need = sp;
+    }
     if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) {
         const size_t sm = uz::conv1x1_small_bwd_weight_ws(Cin, Cout, N, H, W);
         if (sm > need) need = sm;
@@ -508,6 +512,13 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         if (fold > smem) smem = fold;
     }
     const int grid = g.nCoT * g.nCiT * g.S;
+    int Stot = g.S * g.SW;
+    const bool split_math = uz::wgrad_split_ok(Cin, Cout, N, H, W, ks);
+    if (split_math) {                              // large layers: split-bf16 matrix pipe (conv_wgrad_split.hip), same slab layout
+        Stot = uz::wgrad_split_splits(Cin, Cout, N, H, W);
+        UZ_REQUIRE(workspace_bytes >= (size_t)Stot * 9 * Cout * Cin * sizeof(float), "conv_bwd_weight: workspace too small for the split path");
+        if (int rc = uz::wgrad_split(x, Cin, CinTot, dy, Cout, CoutTot, p.slab, N, H, W, Stot, st)) return rc;
+    }
 #define UZ_WG_LAUNCH(KS_, WM_, WN_, PF_)                                                                         \
     do {                                                                                                         \
         static bool attr = false;                                                                                \
@@ -546,7 +557,8 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         else if (g.WN == 2) UZ_WG_FAST(1, 2, THF_, TW_);                             \
         else UZ_WG_FAST(1, 1, THF_, TW_);                                            \
     } while (0)
-    if (fast) {
+    if (split_math) {
+    } else if (fast) {
         if (g.TW == 32 && g.TH == 4) UZ_WG_FAST_T(4, 32);
         else if (g.TW == 32) UZ_WG_FAST_T(2, 32);
         else if (g.TW == 16) UZ_WG_FAST_T(4, 16);
@@ -556,7 +568,6 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
     const int n = ks * ks * Cout * Cin;
     int rgrid = uz::ceil_div(n, 256);
     if (rgrid > 4096) rgrid = 4096;
-    const int Stot = g.S * g.SW;
     int RG = 1;
     if (Stot > 64) {
         RG = 32;

@@ -1,0 +1,250 @@
+// 3x3 weight gradient on the bf16 matrix pipe with fp32-accurate results (split operands, see
+// conv_split.hip for the arithmetic: a = a1 + a2 + a3 exactly, six piece products, fp32 accumulate).
+//
+//   dW[co][ci][tap] = sum_{b,y,x} dY[b,co,y,x] * X[b,ci,y+dy,x+dx]
+// GEMM view: M = co (A = dY), N = ci (B = X shifted by the tap), K = pixels, 16 per MFMA.
+// Workgroup (512 threads) = one 64 x 64 (co x ci) tile of all nine taps and one of S pixel splits; it
+// walks its pixel tiles of 4 rows x 32 columns.  Waves = (co half) x (ci half) x (tap group 5 + 4).
+// LDS holds the three bf16 planes of dY [co][128 px] and of the haloed X patch [ci][6 rows][40 px]
+// (row stride 80 B so that every k-step starts 16-byte aligned).  A k-step is 16 consecutive pixels of
+// one row; the B fragment of tap (dy, dx) starts dx pixels (2 bytes each) past an aligned address, so
+// a lane reads five dwords (b128 + b32) per row and plane and forms the three dx variants in
+// registers: dx = 0 -> dwords 0..3, dx = 2 -> dwords 1..4, dx = 1 -> v_alignbit of neighbours.
+// The next tile's global loads are in flight during the MFMAs; partial sums go to one slab per
+// workgroup and the ordered reduce kernels of conv_wgrad.hip add them (bitwise reproducible).
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include "uz_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NT = 512;
+constexpr int TW = 32, TH = 4, PT = TW * TH;            // 128 pixels per tile
+constexpr int COT = 64, CIT = 64;
+constexpr int DYROW = PT * 2 + 16;                       // bytes per co row of one dY plane (272: 16-byte aligned, skewed banks)
+constexpr int DYPLANE = COT * DYROW;
+constexpr int XROW = 80;                                 // bytes per patch row (34 px used of 40)
+constexpr int XCH = (TH + 2) * XROW + 16;                // bytes per ci of one X plane (496)
+constexpr int XPLANE = CIT * XCH;
+constexpr int XPAIRS = (TH + 2) * 17;                    // pixel pairs per ci (6 rows x 17)
+constexpr int XSLOTS = (CIT * XPAIRS + NT - 1) / NT;     // 13 pairs per thread
+constexpr int DYSLOTS = COT * PT / 4 / NT;               // 4 float4 per thread
+
+struct WS {
+    const float* x; const float* dy; float* slab;
+    int N, H, W, HW, Cin, CinTot, Cout, CoutTot;
+    int tilesX, tilesY, T, S, nCoT, nCiT;
+};
+
+__device__ __forceinline__ void split3(float v0, float v1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const f32x2 a = {v0, v1};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
+    const f32x2 r1 = {v0 - __builtin_bit_cast(float, p1 << 16), v1 - __builtin_bit_cast(float, p1 & 0xFFFF0000u)};
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+    const f32x2 r2 = {r1.x - __builtin_bit_cast(float, p2 << 16), r1.y - __builtin_bit_cast(float, p2 & 0xFFFF0000u)};
+    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
+__global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* dYl = lds;
+    char* Xl = lds + 3 * DYPLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = wave & 1, wn = (wave >> 1) & 1, wm = wave >> 2;
+    const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);
+    const int nTile = p.nCoT * p.nCiT;
+    const int split = wid / nTile, tl = wid - split * nTile;
+    const int co0 = (tl / p.nCiT) * COT, ci0 = (tl % p.nCiT) * CIT;
+
+    // the pad words of the patch rows (columns 34..39) and row tails are never read by a valid fragment
+    // except as dword 4 of the last k-step half: zero the whole image once so they are finite
+    for (int i = tid * 16; i < 3 * DYPLANE + 3 * XPLANE; i += NT * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0u, 0u, 0u, 0u};
+
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dy), 0, (unsigned)(((size_t)(p.N - 1) * p.CoutTot + p.Cout) * p.HW * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)(((size_t)(p.N - 1) * p.CinTot + p.Cin) * p.HW * sizeof(float)), 0x00020000);
+
+    // ---- staging maps
+    // dY: float4 e = tid + i * 512 -> co = e / 32, quad q = e % 32 (row q / 8, columns 4 (q % 8) ..)
+    unsigned dyo[DYSLOTS], dym[DYSLOTS];
+    int dyl[DYSLOTS];
+#pragma unroll
+    for (int i = 0; i < DYSLOTS; ++i) {
+        const int e = tid + i * NT, co = e >> 5, q = e & 31, row = q >> 3, c4 = (q & 7) * 4;
+        dyo[i] = 4u * (unsigned)(co * p.HW + row * p.W + c4);
+        dym[i] = (co0 + co) < p.Cout ? 0u : 0xFFFFFFFFu;          // all-ones: the range check returns 0
+        dyl[i] = co * DYROW + (row * TW + c4) * 2;
+    }
+    f32x4 dreg[DYSLOTS];
+    float xreg[XSLOTS][2];
+    auto gload = [&](int t) __attribute__((always_inline)) {
+        const int txi = t % p.tilesX, t2 = t / p.tilesX;
+        const int x0 = txi * TW, y0 = (t2 % p.tilesY) * TH, b0 = t2 / p.tilesY;
+        const unsigned dbase = 4u * (unsigned)((b0 * p.CoutTot + co0) * p.HW + y0 * p.W + x0);
+#pragma unroll
+        for (int i = 0; i < DYSLOTS; ++i) {
+            const int row = ((tid + i * NT) & 31) >> 3;
+            const unsigned m = (y0 + row) < p.H ? 0u : 0xFFFFFFFFu;
+            dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (dbase + dyo[i]) | dym[i] | m, 0, 0));
+        }
+        const int xbase = (b0 * p.CinTot + ci0) * p.HW + y0 * p.W + x0;
+#pragma unroll
+        for (int i = 0; i < XSLOTS; ++i) {
+            const int e = tid + i * NT;
+            const int ci = e / XPAIRS, rem = e - ci * XPAIRS, prow = rem / 17, pj = rem - prow * 17;
+            const int yy = y0 + prow - 1, xx = x0 + 2 * pj - 1;
+            const bool rowok = e < CIT * XPAIRS && (ci0 + ci) < p.Cin && yy >= 0 && yy < p.H;
+            const int off = xbase + ci * p.HW + (prow - 1) * p.W + 2 * pj - 1;
+            const unsigned o0 = (rowok && xx >= 0 && xx < p.W) ? 4u * (unsigned)off : 0xFFFFFFFFu;
+            const unsigned o1 = (rowok && xx + 1 < p.W) ? 4u * (unsigned)(off + 1) : 0xFFFFFFFFu;
+            xreg[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, o0, 0, 0));
+            xreg[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, o1, 0, 0));
+        }
+    };
+    auto lstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < DYSLOTS; ++i) {
+            unsigned a1, a2, a3, b1, b2, b3;
+            split3(dreg[i][0], dreg[i][1], a1, a2, a3);
+            split3(dreg[i][2], dreg[i][3], b1, b2, b3);
+            char* d = dYl + dyl[i];
+            *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2*>(d + DYPLANE) = make_uint2(a2, b2);
+            *reinterpret_cast<uint2*>(d + 2 * DYPLANE) = make_uint2(a3, b3);
+        }
+#pragma unroll
+        for (int i = 0; i < XSLOTS; ++i) {
+            const int e = tid + i * NT;
+            if (e < CIT * XPAIRS) {
+                const int ci = e / XPAIRS, rem = e - ci * XPAIRS, prow = rem / 17, pj = rem - prow * 17;
+                unsigned a1, a2, a3;
+                split3(xreg[i][0], xreg[i][1], a1, a2, a3);
+                char* d = Xl + ci * XCH + prow * XROW + pj * 4;
+                *reinterpret_cast<unsigned*>(d) = a1;
+                *reinterpret_cast<unsigned*>(d + XPLANE) = a2;
+                *reinterpret_cast<unsigned*>(d + 2 * XPLANE) = a3;
+            }
+        }
+    };
+
+    const char* Ab = dYl + (wm * 32 + l31) * DYROW + h * 16;
+    const char* Bb = Xl + (wn * 32 + l31) * XCH + h * 16;
+
+    auto run = [&](auto ntap_c, auto tap0_c) __attribute__((always_inline)) {
+        constexpr int NTAP = decltype(ntap_c)::value, TAP0 = decltype(tap0_c)::value;
+        constexpr int DY0 = TAP0 / 3;                        // first patch-row offset this tap group needs (0 or 1)
+        f32x16 acc[NTAP];
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+        int t = split;
+        if (t < p.T) gload(t);
+        for (; t < p.T; t += p.S) {
+            __syncthreads();                   // every wave finished the MFMAs of the previous tile
+            lstore();
+            __syncthreads();
+            if (t + p.S < p.T) gload(t + p.S); // in flight during the MFMA loop below
+#pragma unroll
+            for (int s = 0; s < PT / 16; ++s) {
+                const int srow = s >> 1, scol = (s & 1) * 16;
+                bf16x8 a[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(Ab + q * DYPLANE + (srow * TW + scol) * 2);
+                // B fragments of the two patch rows this tap group touches: [row][plane][dx]
+                bf16x8 b[2][3][3];
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const char* src = Bb + q * XPLANE + (srow + DY0 + d) * XROW + scol * 2;
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(src);
+                        const unsigned v4 = *reinterpret_cast<const unsigned*>(src + 16);
+                        b[d][q][0] = __builtin_bit_cast(bf16x8, v);
+                        b[d][q][2] = __builtin_bit_cast(bf16x8, u32x4{v.y, v.z, v.w, v4});
+                        b[d][q][1] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(v.y, v.x, 16), __builtin_amdgcn_alignbit(v.z, v.y, 16),
+                                                                       __builtin_amdgcn_alignbit(v.w, v.z, 16), __builtin_amdgcn_alignbit(v4, v.w, 16)});
+                    }
+#pragma unroll
+                for (int k = 0; k < NTAP; ++k) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int tap = TAP0 + k, d = tap / 3 - DY0, dx = tap % 3;
+                    f32x16 acc_k = acc[k];
+                    acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[d][1][dx], acc_k, 0, 0, 0);
+                    acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[d][0][dx], acc_k, 0, 0, 0);
+                    acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[d][2][dx], acc_k, 0, 0, 0);
+                    acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[d][0][dx], acc_k, 0, 0, 0);
+                    acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[d][1][dx], acc_k, 0, 0, 0);
+                    acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[d][0][dx], acc_k, 0, 0, 0);
+                    acc[k] = acc_k;
+                }
+            }
+        }
+        float* out = p.slab + (size_t)split * 9 * p.Cout * p.Cin;
+        const int ci = ci0 + wn * 32 + l31;
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Cout && ci < p.Cin) out[((size_t)(TAP0 + k) * p.Cout + co) * p.Cin + ci] = acc[k][r];
+            }
+    };
+    if (tg == 0) run(std::integral_constant<int, 5>{}, std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
+}
+
+}  // namespace
+
+namespace uz {
+
+// layers that take the split-bf16 weight gradient: 3x3, rows a multiple of 32 wide (aligned float4 /
+// bf16-pair staging), at least 32 channels on both sides and enough pixels to amortise the tile loop
+bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks) {
+    static const int mode = [] { const char* e = getenv("UZ_CONV_MATH"); return !e ? 1 : !strcmp(e, "f32") ? 0 : !strcmp(e, "split") ? 2 : 1; }();
+    if (!mode || ks != 3 || W % 32 != 0 || Cin < 32 || Cout < 32) return false;
+    if (mode == 2) return true;
+    return Cin >= 64 && Cout >= 64 && (long long)N * H * W >= 32 * 1024;     // 32-channel sides leave half of the 64 x 64 tile empty
+}
+
+// number of pixel splits: one workgroup per CU (147 KB of LDS), at most one split per pixel tile
+int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
+    const int nt = ceil_div(Cout, COT) * ceil_div(Cin, CIT);
+    const int T = N * ceil_div(H, TH) * (W / TW);
+    int s = 256 / nt;
+    if (s < 1) s = 1;
+    if (s > T) s = T;
+    return s;
+}
+
+int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* slab,
+                int N, int H, int W, int S, hipStream_t st) {
+    WS p;
+    p.x = x; p.dy = dy; p.slab = slab;
+    p.N = N; p.H = H; p.W = W; p.HW = H * W; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot;
+    p.tilesX = W / TW; p.tilesY = ceil_div(H, TH); p.T = N * p.tilesX * p.tilesY; p.S = S;
+    p.nCoT = ceil_div(Cout, COT); p.nCiT = ceil_div(Cin, CIT);
+    UZ_REQUIRE((size_t)N * CinTot * p.HW < (1ull << 30) && (size_t)N * CoutTot * p.HW < (1ull << 30), "wgrad_split: tensor too large for 32-bit offsets");
+    constexpr size_t smem = 3 * (size_t)DYPLANE + 3 * (size_t)XPLANE;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail("wgrad_split: cannot raise dynamic LDS limit");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wgrad_split_kernel, dim3(p.nCoT * p.nCiT * S), dim3(NT), smem, st, p);
+    return check_launch("wgrad_split_kernel");
+}
+
+}  // namespace uz

@@ -60,6 +60,12 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
                void* workspace, hipStream_t st);
 
+// conv_wgrad_split.hip: 3x3 weight gradient on the bf16 matrix pipe with three-way split operands
+bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks);
+int wgrad_split_splits(int Cin, int Cout, int N, int H, int W);
+int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* slab,
+                int N, int H, int W, int S, hipStream_t st);
+
 // conv1x1_small.hip: streaming VALU kernels for 1x1 convolutions with <= 8 outputs (-2 = shape not covered)
 bool conv1x1_small_ok(int Cin, int Cout);
 int conv1x1_small_fwd(const float* x, int Cin, int CinTot, const float* w, const float* bias, float* y, int Cout, int CoutTot,
