@@ -303,7 +303,8 @@ bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks) {
     if (!mode || ks != 3 || W < 32 || H < 16 || Kc < 16 || Mc < 32) return mode == 2 && ks == 3;
     if (mode == 2) return true;
     const long long grid = (long long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * ((Mc + 63) / 64);
-    return grid >= 192;
+    static const int min_grid = [] { const char* e = getenv("UZ_SPLIT_MIN_GRID"); return e ? atoi(e) : 64; }();
+    return grid >= min_grid;
 }
 
 // bytes of the packed weight image (one direction) the kernel reads; lives in the caller's conv workspace
