@@ -188,7 +188,7 @@ def test_avgpool(H, W):
 
 
 @pytest.mark.parametrize("ac", [1, 0])
-@pytest.mark.parametrize("H,W", [(4, 4), (1, 1), (2, 2), (5, 3), (32, 32), (64, 64)])
+@pytest.mark.parametrize("H,W", [(4, 4), (1, 1), (2, 2), (5, 3), (32, 32), (64, 64), (20, 12), (9, 64)])
 def test_bilinear(ac, H, W):
     g = _g()
     N, C = 2, 3
@@ -202,6 +202,8 @@ def test_bilinear(ac, H, W):
     dx = torch.full((N, C, H, W), float("nan"), device=g.dev())
     g.call("uz_bilinear2x_bwd", dy.to(g.dev()), C, C, dx, C, N, H, W, ac, 0)
     assert g.maxabs(dx, x.grad) <= 1e-5
+    g.call("uz_bilinear2x_bwd", dy.to(g.dev()), C, C, dx, C, N, H, W, ac, 1)         # accumulate
+    assert g.maxabs(dx, 2 * x.grad) <= 2e-5
 
 
 @pytest.mark.parametrize("f", [1, 2, 16])

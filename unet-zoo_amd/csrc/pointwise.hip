@@ -53,19 +53,26 @@ __global__ __launch_bounds__(256) void latent_bwd_k(const float* __restrict__ dm
 }
 
 // ---------------------------------------------------------------- KL
-__global__ __launch_bounds__(256) void kl_fwd_k(const float* __restrict__ mu0, const float* __restrict__ s0, const float* __restrict__ mu1,
-                                                 const float* __restrict__ s1, int total, int N, float weight, float* __restrict__ out) {
-    __shared__ double sm[4];
-    double v[1] = {0.0};
-    for (int i = threadIdx.x; i < total; i += 256) {
+// one workgroup of 1024 threads (the result is a single ordered fp64 sum; the largest level has 1M elements)
+__global__ __launch_bounds__(1024) void kl_fwd_k(const float* __restrict__ mu0, const float* __restrict__ s0, const float* __restrict__ mu1,
+                                                  const float* __restrict__ s1, int total, int N, float weight, float* __restrict__ out) {
+    __shared__ double sm[16];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < total; i += 1024) {
         const float a0 = s0[i], a1 = s1[i];
         const float s0fs = a0 * a0, s1fs = a1 * a0;
         const float d = mu1[i] - mu0[i];
         const float t = (s0fs + d * d) / (s1fs + 1e-10f) + logf(s1fs + 1e-10f) - logf(s0fs + 1e-10f) - 1.f;
-        v[0] += t;
+        v += t;
     }
-    uz::block_sum_d<1>(v, sm);
-    if (threadIdx.x == 0) out[0] = (float)((double)weight * 0.5 * v[0] / N);
+    v = uz::wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += sm[w];
+        out[0] = (float)((double)weight * 0.5 * s / N);
+    }
 }
 __global__ __launch_bounds__(256) void kl_bwd_k(const float* __restrict__ mu0, const float* __restrict__ s0, const float* __restrict__ mu1,
                                                  const float* __restrict__ s1, int total, float k, const float* __restrict__ scale,
@@ -272,7 +279,7 @@ extern "C" int uz_latent_sample_bwd(const float* dmu, const float* dsigma, const
 extern "C" int uz_kl_fwd(const float* mu0, const float* s0, const float* mu1, const float* s1, int N, int per_sample, float weight,
                          float* loss_out, void* stream) {
     UZ_REQUIRE(N > 0 && per_sample > 0, "kl_fwd: empty tensor");
-    hipLaunchKernelGGL(kl_fwd_k, dim3(1), dim3(256), 0, uz::S(stream), mu0, s0, mu1, s1, N * per_sample, N, weight, loss_out);
+    hipLaunchKernelGGL(kl_fwd_k, dim3(1), dim3(1024), 0, uz::S(stream), mu0, s0, mu1, s1, N * per_sample, N, weight, loss_out);
     return uz::check_launch("kl_fwd_k");
 }
 extern "C" int uz_kl_bwd(const float* mu0, const float* s0, const float* mu1, const float* s1, int N, int per_sample, float weight,
