@@ -42,8 +42,16 @@ int         uz_device_info(int* n_cu, char* name, int name_cap);
  * nn.Conv2d(k=3, stride 1, pad 1) / nn.Conv2d(k=1): torchlayers.py:18, unet.py:25-29,
  * phiseg.py:95-96,281-284, probabilistic_unet.py:95,156-163.  w is the PyTorch
  * parameter itself, layout [Cout][Cin][ks][ks]; bias may be NULL.
- * One fp32-MFMA implicit-GEMM kernel family serves every layer, including the 1..3-channel
- * image / latent inputs and the 2-class 1x1 heads (channel tiles are zero padded in LDS).
+ * fp32 in, fp32 out, fp32 accumulation everywhere.  Two implicit-GEMM kernel families:
+ *  - fp32 MFMA (v_mfma_f32_32x32x2_f32) for every shape, including the 1..3-channel image /
+ *    latent inputs (channel tiles are zero padded in LDS); 1x1 heads with <= 8 outputs run on
+ *    streaming VALU kernels instead;
+ *  - for the large 3x3 layers, the bf16 matrix pipe with exactly split operands (each fp32 value
+ *    = three bf16 pieces, six piece products, fp32 accumulate: conv_split.hip,
+ *    conv_wgrad_split.hip) - fp32-accurate (error vs fp64 within 2x of the fp32-MFMA kernels,
+ *    see DESIGN.md) at 1.5-1.7x the speed.  Environment switch, read once per process:
+ *    UZ_CONV_MATH=f32 (fp32 MFMA only) | split (split path on every eligible 3x3 shape) | unset.
+ *    The forward / data-gradient split path keeps its packed weight image in `workspace`.
  * Deep, low-resolution levels (2x2 .. 16x16) cannot fill 256 CUs with output tiles alone: with a
  * workspace of uz_conv_workspace() bytes the input-channel loop is split over workgroups and summed
  * in a fixed order (bitwise reproducible); workspace may be NULL (no split, slower, same result up

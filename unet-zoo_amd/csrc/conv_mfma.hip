@@ -63,7 +63,6 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
     // (uniform resource + per-lane byte offset): the hardware range check returns 0 for padding pixels,
     // for output-channel tiles that overhang Cout and for the K tail, so staging needs no predication,
     // no 64-bit pointer arithmetic and no per-chunk index arithmetic.
-    constexpr unsigned OOB = 0x80000000u;
     const int nImg = min(p.TB, p.N - b0);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x + (size_t)b0 * p.CinTot * p.HW), 0,
@@ -268,10 +267,6 @@ struct Geom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB; };
 // under a whole number of rounds.
 void pick_split(long long base_grid, int nChunks, int msub, int kk, double out_bytes, int& ksplit, int& cps) {
     ksplit = 1; cps = nChunks;
-    if (const char* f = getenv("UZ_FORCE_KSPLIT")) {        // experiments only
-        const int want = atoi(f);
-        if (want >= 1 && want <= nChunks) { cps = (nChunks + want - 1) / want; ksplit = (nChunks + cps - 1) / cps; return; }
-    }
     if (base_grid >= 512 || nChunks <= 1) return;          // 2 workgroups per CU already: no split
     const double t_chunk = kk * (CK / 2) * msub * NSUB * 64.0 / 2.4e9 / 0.85;     // s per chunk per workgroup, MFMA-bound
     double best = 1e30;
