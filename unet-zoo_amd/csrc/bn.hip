@@ -24,6 +24,7 @@ struct BnP {
     float* dgamma; float* dbeta; float* dbias;
     double* part; double* part2; double* chan;        // workspace
     int C, CtotY, CtotDa, CtotOut, N, HW, parts;
+    int nb, ngrp;                                      // reduction kernels: images per workgroup, number of image groups
     float eps, momentum;
     int training, relu;
 };
@@ -40,24 +41,29 @@ __device__ __forceinline__ void alpha_beta(const BnP& p, int c, float& alpha, fl
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_stats_partial(const BnP p) {
     __shared__ double sm[8];
-    const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
-    const float* src = p.y + ((size_t)b * p.CtotY + c) * p.HW;
+    const int c = blockIdx.y, grp = blockIdx.z, part = blockIdx.x;
     const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
-    float s = 0.f, ss = 0.f;
-    if (VEC) {
-        const float4* s4 = reinterpret_cast<const float4*>(src);
-        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
-            const float4 v = s4[i];
-            s += (v.x + v.y) + (v.z + v.w);
-            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    double v2[2] = {0.0, 0.0};
+    // one workgroup sweeps the chunk of p.nb consecutive images before it pays for the block reduction
+    for (int b = grp * p.nb; b < min(p.N, (grp + 1) * p.nb); ++b) {
+        const float* src = p.y + ((size_t)b * p.CtotY + c) * p.HW;
+        float s = 0.f, ss = 0.f;
+        if (VEC) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll 4
+            for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+                const float4 v = s4[i];
+                s += (v.x + v.y) + (v.z + v.w);
+                ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+        } else {
+            for (int i = lo + threadIdx.x; i < hi; i += 256) { const float v = src[i]; s += v; ss += v * v; }
         }
-    } else {
-        for (int i = lo + threadIdx.x; i < hi; i += 256) { const float v = src[i]; s += v; ss += v * v; }
+        v2[0] += (double)s; v2[1] += (double)ss;
     }
-    double v2[2] = {(double)s, (double)ss};
     uz::block_sum_d<2>(v2, sm);
     if (threadIdx.x == 0) {
-        double* o = p.part + ((size_t)(b * p.parts + part) * p.C + c) * 2;
+        double* o = p.part + ((size_t)(grp * p.parts + part) * p.C + c) * 2;
         o[0] = v2[0]; o[1] = v2[1];
     }
 }
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const BnP p) {
 // replaces a separate "finalize" launch per layer.
 __device__ __forceinline__ void channel_totals(const BnP& p, int c, double* red, double& t0, double& t1) {
     if (threadIdx.x < 64) {
-        const int P = p.N * p.parts;
+        const int P = p.ngrp * p.parts;
         double s = 0.0, ss = 0.0;
         for (int i = threadIdx.x; i < P; i += 64) {
             const double* o = p.part + ((size_t)i * p.C + c) * 2;
@@ -177,31 +183,35 @@ __global__ __launch_bounds__(256) void bn_fused_small_fwd(const BnP p) {
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_partial(const BnP p) {
     __shared__ double sm[8];
-    const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
+    const int c = blockIdx.y, grp = blockIdx.z, part = blockIdx.x;
     float alpha, beta_, mean, rstd;
     alpha_beta(p, c, alpha, beta_, mean, rstd);
-    const float* ys = p.y + ((size_t)b * p.CtotY + c) * p.HW;
-    const float* ds = p.da + ((size_t)b * p.CtotDa + c) * p.HW;
     const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
-    float s1 = 0.f, s2 = 0.f;
-    auto one = [&](float yv, float dv) {
-        const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
-        s1 += dz; s2 += dz * ((yv - mean) * rstd);
-    };
-    if (VEC) {
-        const float4* y4 = reinterpret_cast<const float4*>(ys);
-        const float4* d4 = reinterpret_cast<const float4*>(ds);
-        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
-            const float4 yv = y4[i], dv = d4[i];
-            one(yv.x, dv.x); one(yv.y, dv.y); one(yv.z, dv.z); one(yv.w, dv.w);
+    double v2[2] = {0.0, 0.0};
+    for (int b = grp * p.nb; b < min(p.N, (grp + 1) * p.nb); ++b) {
+        const float* ys = p.y + ((size_t)b * p.CtotY + c) * p.HW;
+        const float* ds = p.da + ((size_t)b * p.CtotDa + c) * p.HW;
+        float s1 = 0.f, s2 = 0.f;
+        auto one = [&](float yv, float dv) {
+            const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
+            s1 += dz; s2 += dz * ((yv - mean) * rstd);
+        };
+        if (VEC) {
+            const float4* y4 = reinterpret_cast<const float4*>(ys);
+            const float4* d4 = reinterpret_cast<const float4*>(ds);
+#pragma unroll 4
+            for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+                const float4 yv = y4[i], dv = d4[i];
+                one(yv.x, dv.x); one(yv.y, dv.y); one(yv.z, dv.z); one(yv.w, dv.w);
+            }
+        } else {
+            for (int i = lo + threadIdx.x; i < hi; i += 256) one(ys[i], ds[i]);
         }
-    } else {
-        for (int i = lo + threadIdx.x; i < hi; i += 256) one(ys[i], ds[i]);
+        v2[0] += (double)s1; v2[1] += (double)s2;
     }
-    double v2[2] = {(double)s1, (double)s2};
     uz::block_sum_d<2>(v2, sm);
     if (threadIdx.x == 0) {
-        double* o = p.part + ((size_t)(b * p.parts + part) * p.C + c) * 2;
+        double* o = p.part + ((size_t)(grp * p.parts + part) * p.C + c) * 2;
         o[0] = v2[0]; o[1] = v2[1];
     }
 }
@@ -350,6 +360,15 @@ extern "C" size_t uz_bn_workspace(int C, int N, int H, int W) {
 }
 
 namespace {
+// images per reduction workgroup: keep about 2048 workgroups (8 per CU) so that the fp64 block reduction is
+// amortised over several planes without starving the chip
+void reduction_groups(BnP& p) {
+    long long nb = (long long)p.N * p.parts * p.C / 2048;
+    if (nb < 1) nb = 1;
+    if (nb > 8) nb = 8;
+    p.nb = (int)nb;
+    p.ngrp = uz::ceil_div(p.N, p.nb);
+}
 void carve(BnP& p, void* ws) {
     const size_t P = (size_t)p.N * p.parts;
     p.part = static_cast<double*>(ws);
@@ -379,11 +398,13 @@ extern "C" int uz_bn_relu_fwd(const float* y, int C, int CtotY, const float* gam
     }
     const bool vec = vec_ok(p.HW, y, a, nullptr);
     const dim3 grid(p.parts, C, N);
+    reduction_groups(p);
+    const dim3 rgrid(p.parts, C, p.ngrp);
     if (training) {
         UZ_REQUIRE(workspace, "bn_relu_fwd: workspace required");
         carve(p, workspace);
-        if (vec) hipLaunchKernelGGL(bn_stats_partial<true>, grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(bn_stats_partial<false>, grid, dim3(256), 0, st, p);
+        if (vec) hipLaunchKernelGGL(bn_stats_partial<true>, rgrid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(bn_stats_partial<false>, rgrid, dim3(256), 0, st, p);
         if (int rc = uz::check_launch("bn_stats_partial")) return rc;
     }
     if (vec) hipLaunchKernelGGL(bn_apply<true>, grid, dim3(256), 0, st, p);
@@ -413,8 +434,10 @@ extern "C" int uz_bn_relu_bwd(const float* da, int CtotDa, const float* y, int C
     carve(p, workspace);
     const bool vec = vec_ok(p.HW, y, da, dy);
     const dim3 grid(p.parts, C, N);
-    if (vec) hipLaunchKernelGGL(bn_bwd_reduce_partial<true>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(bn_bwd_reduce_partial<false>, grid, dim3(256), 0, st, p);
+    reduction_groups(p);
+    const dim3 rgrid(p.parts, C, p.ngrp);
+    if (vec) hipLaunchKernelGGL(bn_bwd_reduce_partial<true>, rgrid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(bn_bwd_reduce_partial<false>, rgrid, dim3(256), 0, st, p);
     if (int rc = uz::check_launch("bn_bwd_reduce_partial")) return rc;
     if (vec) hipLaunchKernelGGL(bn_bwd_apply<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(bn_bwd_apply<false>, grid, dim3(256), 0, st, p);
