@@ -146,7 +146,7 @@ class Plan:
         self.named = {}                     # user-visible tensors: name -> View
         self.finalized = False
         self._gid = 0                       # scheduling group of the ops being emitted (see _schedule)
-        self.n_lanes = max(1, min(int(os.environ.get("UZ_LANES", "2")), 8))
+        self.n_lanes = max(1, min(int(os.environ.get("UZ_LANES", "3")), 8))
 
     def _newgroup(self):
         self._gid += 1
@@ -599,74 +599,72 @@ class Plan:
             return []
         raise ValueError(r)
 
+    @staticmethod
+    def _op_cost(o):
+        """Rough duration (s) of one op on MI355X - only the RELATIVE sizes matter: the list scheduler
+        below uses them to decide which chains can share a lane."""
+        c, i = o["code"], o["i"]
+        if c in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA", "UZ_OP_CONV_BWD_WEIGHT"):
+            cin, cout, N, H, W, ks = i[0], i[2], i[4], i[5], i[6], i[7]
+            flop = 2.0 * N * H * W * cin * cout * ks * ks
+            rate = 150e12 if (N * H * W >= 32768 and min(cin, cout) >= 32) else 70e12
+            return flop / rate + (12e-6 if c != "UZ_OP_CONV_BWD_WEIGHT" else 20e-6)
+        if c == "UZ_OP_BN_RELU_FWD":
+            return i[0] * i[3] * i[4] * i[5] * 12.0 / 4e12 + 10e-6
+        if c in ("UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
+            return i[1] * i[4] * i[5] * i[6] * 20.0 / 4e12 + 14e-6
+        if c in ("UZ_OP_AVGPOOL_FWD", "UZ_OP_AVGPOOL_BWD", "UZ_OP_BILINEAR_FWD", "UZ_OP_BILINEAR_BWD", "UZ_OP_NEAREST_FWD", "UZ_OP_NEAREST_BWD"):
+            return i[0] * i[3] * i[4] * i[5] * 24.0 / 2e12 + 6e-6
+        return 6e-6
+
     def _schedule(self, ops):
-        """Assigns every op a capture lane and the cross-lane waits that keep the tape's read/write
-        order (RAW, WAR and WAW on buffer channel ranges, gradient ranges and BN running buffers).
-        Ops of one group (one layer's forward, or one layer's backward) stay on one lane back to
-        back.  Returns the ctypes uz_sched array for uz_graph_create_lanes."""
+        """Turns the tape into a DAG schedule for uz_graph_create_lanes and REORDERS `ops` in place.
+
+        1. Hazard analysis in program order: a group (one layer's forward, or one layer's backward;
+           its ops stay back to back) depends on every earlier group it has a RAW, WAR or WAW conflict
+           with (buffer channel ranges, gradient ranges, BN running buffers).
+        2. Event-driven list scheduling on n_lanes lanes with the cost model above: the ready group
+           that can start first goes to the lane that is free first.  A lane is a scratch copy, so the
+           groups of a lane must stay ordered; simulating time is what lets an independent chain (the
+           prior encoder next to the posterior encoder, the likelihood branches) claim a lane for
+           itself instead of queueing behind whatever happened to use that lane last in program order.
+        3. The tape is rewritten in simulated start order (a topological order of the DAG, so the
+           eager runner stays correct) and every group gets: its lane, and the cross-lane groups it
+           must wait for that are not already implied by its lane predecessor.
+        Returns the ctypes uz_sched array (indexed like the reordered ops)."""
         n, K = len(ops), self.n_lanes
         sched = (_ffi.uz_sched * max(n, 1))()
-        groups = []                                         # [first, last] op index per group, in order
+        if n == 0:
+            return sched
+        groups = []                                         # [first, last] op index per group, program order
         for k, o in enumerate(ops):
             if groups and ops[groups[-1][1]]["gid"] == o["gid"]:
                 groups[-1][1] = k
             else:
                 groups.append([k, k])
+        G = len(groups)
+        # ---- 1. hazards
         hist = {}                                           # space -> list of [lo, hi, last_writer_gi, readers{gi}]
-        anc = []                                            # per group: bitset of transitive predecessors
-        lane_of, tail = [], [None] * K                      # group -> lane; lane -> last group
+        deps = []
         for gi, (a, b) in enumerate(groups):
             reads, writes = [], []
             for o in ops[a:b + 1]:
                 wr = self._WRITES[o["code"]]
                 for j, r in enumerate(o["p"]):
                     (writes if j in wr else reads).extend(self._resources(r))
-            deps = set()
+            d = set()
             for space, lo, hi in reads:
                 for e in hist.get(space, ()):
                     if e[0] < hi and lo < e[1] and e[2] is not None:
-                        deps.add(e[2])
+                        d.add(e[2])
             for space, lo, hi in writes:
                 for e in hist.get(space, ()):
                     if e[0] < hi and lo < e[1]:
                         if e[2] is not None:
-                            deps.add(e[2])
-                        deps.update(e[3])
-            deps.discard(gi)
-            mask = 0
-            for d in deps:
-                mask |= anc[d] | (1 << d)
-            # lane choice: continue a lane whose tail is a predecessor (no false ordering); the
-            # most recent such tail first.  Otherwise take an empty lane, else the lane that has
-            # been idle the longest.
-            cands = [l for l in range(K) if tail[l] is not None and (mask >> tail[l]) & 1]
-            if cands:
-                lane = max(cands, key=lambda l: tail[l])
-            else:
-                empty = [l for l in range(K) if tail[l] is None]
-                lane = empty[0] if empty else min(range(K), key=lambda l: tail[l])
-            if tail[lane] is not None:
-                mask |= anc[tail[lane]] | (1 << tail[lane])
-            # waits: latest dependency per foreign lane, unless already implied
-            implied = anc[tail[lane]] | (1 << tail[lane]) if tail[lane] is not None else 0
-            per_lane = {}
-            for d in deps:
-                if lane_of[d] != lane and not (implied >> d) & 1:
-                    per_lane[lane_of[d]] = max(per_lane.get(lane_of[d], -1), d)
-            waits = sorted(per_lane.values())
-            waits = [d for d in waits if not any(d != e and (anc[e] >> d) & 1 for e in waits)]
-            anc.append(mask)
-            lane_of.append(lane)
-            tail[lane] = gi
-            for o in ops[a:b + 1]:
-                o["lane"] = lane
-            sched[a].n_wait = len(waits)
-            for w, d in enumerate(waits):
-                sched[a].wait[w] = groups[d][1]
-                sched[groups[d][1]].signal = 1
-            for k in range(a, b + 1):
-                sched[k].lane = lane
-            # history update
+                            d.add(e[2])
+                        d.update(e[3])
+            d.discard(gi)
+            deps.append(d)
             for space, lo, hi in reads:
                 for e in hist.setdefault(space, []):
                     if e[0] < hi and lo < e[1]:
@@ -677,6 +675,78 @@ class Plan:
                 keep = [e for e in lst if not (lo <= e[0] and e[1] <= hi)]     # fully covered entries are superseded
                 keep.append([lo, hi, gi, set()])
                 hist[space] = keep
+        # ---- 2. list scheduling in simulated time
+        cost = [sum(self._op_cost(o) for o in ops[a:b + 1]) for a, b in groups]
+        succ = [[] for _ in range(G)]
+        indeg = [len(d) for d in deps]
+        for gi, d in enumerate(deps):
+            for e in d:
+                succ[e].append(gi)
+        ready_at = [0.0] * G
+        ready = [gi for gi in range(G) if indeg[gi] == 0]
+        free = [0.0] * K
+        tail = [None] * K
+        finish = [0.0] * G
+        order, lane_of = [], [None] * G
+        while ready:
+            # the group that can start first (ties: program order); its lane: free by then and, if possible,
+            # one whose tail it depends on anyway - otherwise the lane that is free first
+            fmin = min(free)
+            gi = min(ready, key=lambda g: (max(ready_at[g], fmin), g))
+            ready.remove(gi)
+            start = max(ready_at[gi], fmin)
+            cands = [l for l in range(K) if free[l] <= start]
+            pref = [l for l in cands if tail[l] is not None and tail[l] in deps[gi]]
+            lane = pref[0] if pref else min(cands, key=lambda l: (free[l], l))
+            lane_of[gi] = lane
+            finish[gi] = start + cost[gi]
+            free[lane] = finish[gi]
+            tail[lane] = gi
+            order.append(gi)
+            for sgi in succ[gi]:
+                indeg[sgi] -= 1
+                ready_at[sgi] = max(ready_at[sgi], finish[gi])
+                if indeg[sgi] == 0:
+                    ready.append(sgi)
+        assert len(order) == G, "dependency cycle in the tape"
+        # ---- 3. rewrite the tape in schedule order, compute waits
+        new_ops, first, last = [], [0] * G, [0] * G
+        for gi in order:
+            a, b = groups[gi]
+            first[gi] = len(new_ops)
+            new_ops.extend(ops[a:b + 1])
+            last[gi] = len(new_ops) - 1
+        ops[:] = new_ops
+        sched = (_ffi.uz_sched * max(n, 1))()
+        anc = [0] * G                                       # bitset of transitive predecessors (incl. lane order)
+        ltail = [None] * K
+        for gi in order:
+            lane = lane_of[gi]
+            mask = 0
+            for d in deps[gi]:
+                mask |= anc[d] | (1 << d)
+            implied = 0
+            if ltail[lane] is not None:
+                implied = anc[ltail[lane]] | (1 << ltail[lane])
+                mask |= implied
+            per_lane = {}
+            for d in deps[gi]:
+                if lane_of[d] != lane and not (implied >> d) & 1:
+                    cur = per_lane.get(lane_of[d])
+                    if cur is None or first[d] > first[cur]:
+                        per_lane[lane_of[d]] = d
+            waits = list(per_lane.values())
+            waits = [d for d in waits if not any(d != e and (anc[e] >> d) & 1 for e in waits)]
+            anc[gi] = mask
+            ltail[lane] = gi
+            k0 = first[gi]
+            sched[k0].n_wait = len(waits)
+            for w, d in enumerate(sorted(waits, key=lambda d: first[d])):
+                sched[k0].wait[w] = last[d]
+                sched[last[d]].signal = 1
+            for k in range(first[gi], last[gi] + 1):
+                sched[k].lane = lane
+                ops[k]["lane"] = lane
         return sched
 
     # ------------------------------------------------------------------ execution helpers
