@@ -607,8 +607,14 @@ class Plan:
         if c in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA", "UZ_OP_CONV_BWD_WEIGHT"):
             cin, cout, N, H, W, ks = i[0], i[2], i[4], i[5], i[6], i[7]
             flop = 2.0 * N * H * W * cin * cout * ks * ks
-            rate = 150e12 if (N * H * W >= 32768 and min(cin, cout) >= 32) else 70e12
-            return flop / rate + (12e-6 if c != "UZ_OP_CONV_BWD_WEIGHT" else 20e-6)
+            # measured fp32-equivalent TFLOP/s per plane size at batch 32 (tools/op_profile.py), forward / data
+            # gradient and weight gradient; small channel counts and 1x1 kernels run far below these
+            px = N * H * W
+            table = ((262144, 180, 130), (65536, 190, 148), (16384, 115, 114), (4096, 70, 64), (1024, 35, 29), (256, 11, 9), (0, 3, 2.5))
+            rate = next((f if c != "UZ_OP_CONV_BWD_WEIGHT" else w) for lim, f, w in table if px >= lim) * 1e12
+            if min(cin, cout) < 32 or ks == 1:
+                rate = min(rate, 20e12)
+            return flop / rate + 4e-6
         if c == "UZ_OP_BN_RELU_FWD":
             return i[0] * i[3] * i[4] * i[5] * 12.0 / 4e12 + 10e-6
         if c in ("UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
