@@ -322,7 +322,7 @@ namespace uz {
 
 // x: input view (Kc channels), y: output view (Mc channels); w = PyTorch [Cout][Cin][ks][ks] parameter.
 size_t conv_workspace(int Kc, int Mc, int N, int H, int W, int ks) {
-    if (conv_split_ok(Kc, Mc, N, H, W, ks)) return conv_split_workspace(Kc, Mc);
+    if (conv_split_ok(Kc, Mc, N, H, W, ks)) return conv_split_workspace(Kc, Mc, W);
     const Geom g = pick_geom(N, H, W, ks / 2);
     const int cot = Mc <= 32 ? 32 : 64;
     int ksplit, cps;
@@ -338,7 +338,7 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Kc > 0 && Mc > 0, "conv: empty tensor");
     UZ_REQUIRE(H <= 4096 && W <= 4096, "conv: spatial size too large");
     // large 3x3 layers: split-bf16 matrix pipe (conv_split.hip); its packed weight image lives in the workspace
-    if (conv_split_ok(Kc, Mc, N, H, W, ks) && workspace && workspace_bytes >= conv_split_workspace(Kc, Mc))
+    if (conv_split_ok(Kc, Mc, N, H, W, ks) && workspace && workspace_bytes >= conv_split_workspace(Kc, Mc, W))
         return conv_split(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, dgrad, relu, accumulate, workspace, st);
     const Geom g = pick_geom(N, H, W, ks / 2);
     ConvP p;

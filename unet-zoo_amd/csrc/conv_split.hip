@@ -28,9 +28,18 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NT = 512, CK = 16, NSUB = 2, KK = 9;
-constexpr int TW = 32, TH = 16, PW = TW + 2, PSI = (TH + 2) * PW;   // 612 patch pixels
-constexpr int PSR = 640;                                            // padded patch slots (2 per thread, 100 of the second used)
+constexpr int CK = 16, NSUB = 2, KK = 9, TH = 16;
+// Two tile geometries share the kernel: 512 threads on 16 x 32 pixels (planes at least 32 wide) and 256 threads
+// on 16 x 16 pixels (one 16 x 16 plane per workgroup, 32 output channels, 60 KB of LDS -> two workgroups per CU).
+template <int NTv, int TWv> struct Geo {
+    static constexpr int NT = NTv, TW = TWv, PW = TWv + 2, PSI = (TH + 2) * PW;      // 612 / 324 patch pixels
+    static constexpr int EXTRA = PSI - NT;                                            // rows beyond one per thread: 100 / 68
+    static constexpr int G = EXTRA * 4 <= NT ? 4 : 2;                                 // threads sharing one extra row
+    static constexpr int CE = CK / G;                                                 // channels of an extra row per thread
+    static constexpr int PSR = (NT + NT / G + 15) / 16 * 16;                          // padded patch rows: 640 / 384
+    static_assert(EXTRA > 0 && EXTRA <= NT / G, "extra patch rows must fit the shared-row scheme");
+    static_assert(NT / 64 * 32 * NSUB == TH * TW, "one wave covers 64 pixels");
+};
 
 struct SP {
     const float* x; const char* wp; const float* bias; float* y;     // wp: packed split weights (pack_weights_kernel)
@@ -86,13 +95,15 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     split_store16(v, packed + (size_t)(c * nCoTiles + coT) * 3 * wplane + (tapL * COT + m) * (CK * 2), wplane);
 }
 
-template <int MSUB>
-__global__ __launch_bounds__(NT) void conv_split_kernel(const SP p) {
+template <int MSUB, int NTv, int TWv>
+__global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
+    using GEO = Geo<NTv, TWv>;
+    constexpr int NT = GEO::NT, TW = GEO::TW, PW = GEO::PW, PSI = GEO::PSI, PSR = GEO::PSR, G = GEO::G, CE = GEO::CE;
     constexpr int COT = 32 * MSUB;
     constexpr int WPLANE = KK * COT * CK * 2;            // bytes per weight plane
     constexpr int PPLANE = PSR * CK * 2;                 // bytes per patch plane
     constexpr int WVEC = 3 * WPLANE / 16;                // 16-byte vectors of one packed weight block (3456 / 1728)
-    constexpr int WREGS = (WVEC + NT - 1) / NT;          // 7 / 4 per thread
+    constexpr int WREGS = (WVEC + NT - 1) / NT;          // per thread
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Wl = lds;
     char* Pl = lds + 3 * WPLANE;
@@ -111,12 +122,12 @@ __global__ __launch_bounds__(NT) void conv_split_kernel(const SP p) {
         const_cast<float*>(p.x + (size_t)b0 * p.CinTot * p.HW), 0, (unsigned)((size_t)p.Cin * p.HW * sizeof(float)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(p.wp), 0, (unsigned)((size_t)p.nChunks * p.nCoTiles * 3 * WPLANE), 0x00020000);
-    // patch rows: row tid (all 16 channels) for every thread; rows 512..639 are shared out four threads per
-    // row, four channels each (so no thread carries a second full row in registers)
+    // patch rows: row tid (all 16 channels) for every thread; the rows beyond NT are shared out G threads per
+    // row, CE channels each (so no thread carries a second full row in registers)
     unsigned goff[2], gmask[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int r = j == 0 ? tid : NT + (tid >> 2);
+        const int r = j == 0 ? tid : NT + tid / G;
         unsigned g = 0, gm = 0xFFFFFFFFu;
         if (r < PSI) {
             const int py = r / PW, px = r - py * PW;
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(NT) void conv_split_kernel(const SP p) {
         }
         goff[j] = g; gmask[j] = gm;
     }
-    const int prow1 = NT + (tid >> 2), q4 = tid & 3;
+    const int prow1 = NT + tid / G, q4 = tid & (G - 1);
     const unsigned xstep = 4u * (unsigned)p.HW;
     const unsigned wblock = 3u * WPLANE;
 
@@ -133,8 +144,8 @@ __global__ __launch_bounds__(NT) void conv_split_kernel(const SP p) {
     int poff[NSUB], oidx[NSUB];
 #pragma unroll
     for (int n = 0; n < NSUB; ++n) {
-        const int pp = wave * (32 * NSUB) + n * 32 + l31;          // 0..511 inside the tile
-        const int tx = pp & (TW - 1), ty = pp >> 5;
+        const int pp = wave * (32 * NSUB) + n * 32 + l31;          // pixel index inside the tile
+        const int tx = pp & (TW - 1), ty = pp / TW;
         const bool v = (y0 + ty) < p.H && (x0 + tx) < p.W;
         poff[n] = (ty * PW + tx) * (CK * 2) + h * 16;               // byte offset of this lane's fragment for tap (0, 0)
         oidx[n] = v ? (b0 * p.CoutTot * p.HW + (y0 + ty) * p.W + (x0 + tx)) : -1;
@@ -148,8 +159,8 @@ __global__ __launch_bounds__(NT) void conv_split_kernel(const SP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    float pr[CK], pr1[4];             // raw patch values of the next chunk: own row, quarter of a shared row
-    unsigned pk[3][CK / 2], pk1[3][2]; // ... and their three bf16 planes, packed pairwise as they get split
+    float pr[CK], pr1[CE];            // raw patch values of the next chunk: own row, share of an extra row
+    unsigned pk[3][CK / 2], pk1[3][CE / 2]; // ... and their three bf16 planes, packed pairwise as they get split
     u32x4 wq[WREGS];
     // Staging of the next chunk is spread over the nine taps of the MFMA loop so that neither the memory
     // pipeline's queue nor the VALU work of the operand split ever stands between two MFMAs for long:
@@ -167,9 +178,9 @@ __global__ __launch_bounds__(NT) void conv_split_kernel(const SP p) {
         }
     };
     auto shared_row_loads = [&](int c) {
-        const int k0 = c * CK + 4 * q4;
+        const int k0 = c * CK + CE * q4;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < CE; ++kk) {
             const unsigned kvm = (k0 + kk) < p.Cin ? 0u : 0xFFFFFFFFu;
             pr1[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (goff[1] + (unsigned)(k0 + kk) * xstep) | gmask[1] | kvm, 0, 0));
         }
@@ -192,8 +203,8 @@ __global__ __launch_bounds__(NT) void conv_split_kernel(const SP p) {
                 split3(pr[2 * i0 + 2], pr[2 * i0 + 3], pk[0][i0 + 1], pk[1][i0 + 1], pk[2][i0 + 1]);
             }
             if (tap == 4) {
-                split3(pr1[0], pr1[1], pk1[0][0], pk1[1][0], pk1[2][0]);
-                split3(pr1[2], pr1[3], pk1[0][1], pk1[1][1], pk1[2][1]);
+#pragma unroll
+                for (int i = 0; i < CE / 2; ++i) split3(pr1[2 * i], pr1[2 * i + 1], pk1[0][i], pk1[1][i], pk1[2][i]);
             }
         }
     };
@@ -205,9 +216,12 @@ __global__ __launch_bounds__(NT) void conv_split_kernel(const SP p) {
             d[0] = u32x4{pk[q][0], pk[q][1], pk[q][2], pk[q][3]};
             d[1] = u32x4{pk[q][4], pk[q][5], pk[q][6], pk[q][7]};
         }
-        char* dst1 = Pl + prow1 * (CK * 2) + q4 * 8;
+        char* dst1 = Pl + prow1 * (CK * 2) + q4 * (CE * 2);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(dst1 + q * PPLANE) = make_uint2(pk1[q][0], pk1[q][1]);
+        for (int q = 0; q < 3; ++q) {
+            if (CE == 4) *reinterpret_cast<uint2*>(dst1 + q * PPLANE) = make_uint2(pk1[q][0], pk1[q][1]);
+            else *reinterpret_cast<u32x4*>(dst1 + q * PPLANE) = u32x4{pk1[q][0], pk1[q][1], pk1[q][CE / 2 - 2], pk1[q][CE / 2 - 1]};
+        }
 #pragma unroll
         for (int i = 0; i < WREGS; ++i)
             if (tid + i * NT < WVEC) *reinterpret_cast<u32x4*>(Wl + 16 * (tid + i * NT)) = wq[i];
@@ -277,39 +291,52 @@ __global__ __launch_bounds__(NT) void conv_split_kernel(const SP p) {
     }
 }
 
-template <int MSUB>
+template <int MSUB, int NTv, int TWv>
 int launch(const SP& p, int grid, hipStream_t st) {
-    constexpr size_t smem = 3 * (size_t)(KK * 32 * MSUB * CK * 2) + 3 * (size_t)(PSR * CK * 2);
+    constexpr size_t smem = 3 * (size_t)(KK * 32 * MSUB * CK * 2) + 3 * (size_t)(Geo<NTv, TWv>::PSR * CK * 2);
     static bool attr_done = false;
-    auto kern = conv_split_kernel<MSUB>;
+    auto kern = conv_split_kernel<MSUB, NTv, TWv>;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return uz::fail("conv_split: cannot raise dynamic LDS limit");
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTv), smem, st, p);
     return uz::check_launch("conv_split_kernel");
 }
+
+// tile geometry of a layer: 16 x 32 tiles (512 threads, 64- or 32-channel tiles) when the plane is wider than 16,
+// else 16 x 16 tiles (256 threads, 32-channel tiles)
+inline bool small_geo(int W) { return W <= 16; }
+inline int tile_w(int W) { return small_geo(W) ? 16 : 32; }
+inline int tile_cot(int Mc, int W) { return (small_geo(W) || Mc <= 32) ? 32 : 64; }
 
 }  // namespace
 
 namespace uz {
 
-// Which layers take the split-bf16 path: 3x3, planes at least 32 wide and 16 high (one 16 x 32 tile
-// per workgroup), enough channels for a dense contraction, and enough tiles to occupy the chip.
+// Which layers take the split-bf16 path: 3x3, enough channels for a dense contraction and enough tiles to occupy
+// the chip.  Planes at least 32 wide use 16 x 32 tiles; 16 x 16 planes one tile per image.
 bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks) {
     // UZ_CONV_MATH: "f32" = fp32 MFMA only; "split" = split-bf16 on every 3x3 shape (tests); default = where it pays
     static const int mode = [] { const char* e = getenv("UZ_CONV_MATH"); return !e ? 1 : !strcmp(e, "f32") ? 0 : !strcmp(e, "split") ? 2 : 1; }();
-    if (!mode || ks != 3 || W < 32 || H < 16 || Kc < 16 || Mc < 32) return mode == 2 && ks == 3;
+    if (!mode || ks != 3) return false;
     if (mode == 2) return true;
-    const long long grid = (long long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * ((Mc + 63) / 64);
-    static const int min_grid = [] { const char* e = getenv("UZ_SPLIT_MIN_GRID"); return e ? atoi(e) : 64; }();
-    return grid >= min_grid;
+    constexpr int min_grid = 64;        // measured: 128 -> 128 @ 32 x 32 (128 tiles) already gains 20 % over the fp32 kernel
+    if (W >= 32 && H >= 16 && Kc >= 16 && Mc >= 32) {
+        const long long grid = (long long)N * ((H + TH - 1) / TH) * ((W + 31) / 32) * ((Mc + 63) / 64);
+        return grid >= min_grid;
+    }
+    if (W == 16 && H == 16 && Kc >= 64 && Mc >= 64) {      // one 16 x 16 tile per image and 32 channels
+        const long long grid = (long long)N * ((Mc + 31) / 32);
+        return grid >= 128;
+    }
+    return false;
 }
 
 // bytes of the packed weight image (one direction) the kernel reads; lives in the caller's conv workspace
-size_t conv_split_workspace(int Kc, int Mc) {
-    const int cot = Mc <= 32 ? 32 : 64;
+size_t conv_split_workspace(int Kc, int Mc, int W) {
+    const int cot = tile_cot(Mc, W);
     return (size_t)ceil_div(Kc, CK) * ceil_div(Mc, cot) * 3 * (KK * cot * CK * 2);
 }
 
@@ -320,19 +347,20 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     p.x = x; p.wp = static_cast<const char*>(workspace); p.bias = bias; p.y = y;
     p.N = N; p.H = H; p.W = W; p.HW = H * W;
     p.Cin = Kc; p.CinTot = KcTot; p.Cout = Mc; p.CoutTot = McTot;
-    p.tilesX = ceil_div(W, TW); p.tilesY = ceil_div(H, TH);
+    const int tw = tile_w(W), cot = tile_cot(Mc, W);
+    p.tilesX = ceil_div(W, tw); p.tilesY = ceil_div(H, TH);
     p.relu = relu; p.accumulate = accumulate;
-    const int msub = Mc <= 32 ? 1 : 2;
-    p.nCoTiles = ceil_div(Mc, 32 * msub);
+    p.nCoTiles = ceil_div(Mc, cot);
     p.nChunks = ceil_div(Kc, CK);
     const long long grid = (long long)p.tilesX * p.tilesY * N * p.nCoTiles;
     UZ_REQUIRE(grid < (1ll << 31), "conv_split: grid too large");
     UZ_REQUIRE((size_t)Kc * p.HW * 4 < (1ull << 32) && (size_t)McTot * p.HW * N < (1ull << 31), "conv_split: tensor too large for 32-bit offsets");
-    const int rows = p.nChunks * p.nCoTiles * KK * 32 * msub;
-    if (dgrad) hipLaunchKernelGGL(pack_weights_kernel<true>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, static_cast<char*>(workspace), Mc, Kc, wCi, p.nChunks, p.nCoTiles, 32 * msub);
-    else hipLaunchKernelGGL(pack_weights_kernel<false>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, static_cast<char*>(workspace), Mc, Kc, wCi, p.nChunks, p.nCoTiles, 32 * msub);
+    const int rows = p.nChunks * p.nCoTiles * KK * cot;
+    if (dgrad) hipLaunchKernelGGL(pack_weights_kernel<true>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, static_cast<char*>(workspace), Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
+    else hipLaunchKernelGGL(pack_weights_kernel<false>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, static_cast<char*>(workspace), Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
     if (int rc = check_launch("pack_weights_kernel")) return rc;
-    return msub == 1 ? launch<1>(p, (int)grid, st) : launch<2>(p, (int)grid, st);
+    if (tw == 16) return launch<1, 256, 16>(p, (int)grid, st);
+    return cot == 32 ? launch<1, 512, 32>(p, (int)grid, st) : launch<2, 512, 32>(p, (int)grid, st);
 }
 
 }  // namespace uz

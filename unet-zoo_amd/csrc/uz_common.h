@@ -55,7 +55,7 @@ __device__ __forceinline__ void block_sum_d(double (&v)[NV], double* smem /* >= 
 
 // conv_split.hip: 3x3 forward / data gradient on the bf16 matrix pipe with three-way split operands (fp32-accurate)
 bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks);
-size_t conv_split_workspace(int Kc, int Mc);
+size_t conv_split_workspace(int Kc, int Mc, int W);
 int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
                void* workspace, hipStream_t st);
