@@ -305,9 +305,9 @@ int launch(const SP& p, int grid, hipStream_t st) {
     return uz::check_launch("conv_split_kernel");
 }
 
-// tile geometry of a layer: 16 x 32 tiles (512 threads, 64- or 32-channel tiles) when the plane is wider than 16,
+// tile geometry of a layer: 16 x 32 tiles (512 threads, 64- or 32-channel tiles) when the plane is wider than 32,
 // else 16 x 16 tiles (256 threads, 32-channel tiles)
-inline bool small_geo(int W) { return W <= 16; }
+inline bool small_geo(int W) { return W <= 32; }       // measured: 16 x 16 tiles win or tie on 32 x 32 planes (128 -> 128: 91 -> 67 us), lose on 64 x 64
 inline int tile_w(int W) { return small_geo(W) ? 16 : 32; }
 inline int tile_cot(int Mc, int W) { return (small_geo(W) || Mc <= 32) ? 32 : 64; }
 
@@ -316,19 +316,20 @@ inline int tile_cot(int Mc, int W) { return (small_geo(W) || Mc <= 32) ? 32 : 64
 namespace uz {
 
 // Which layers take the split-bf16 path: 3x3, enough channels for a dense contraction and enough tiles to occupy
-// the chip.  Planes at least 32 wide use 16 x 32 tiles; 16 x 16 planes one tile per image.
+// the chip.  Planes wider than 32 use 16 x 32 tiles; 32 x 32 and 16 x 16 planes use 16 x 16 tiles.
 bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks) {
     // UZ_CONV_MATH: "f32" = fp32 MFMA only; "split" = split-bf16 on every 3x3 shape (tests); default = where it pays
     static const int mode = [] { const char* e = getenv("UZ_CONV_MATH"); return !e ? 1 : !strcmp(e, "f32") ? 0 : !strcmp(e, "split") ? 2 : 1; }();
     if (!mode || ks != 3) return false;
     if (mode == 2) return true;
     constexpr int min_grid = 64;        // measured: 128 -> 128 @ 32 x 32 (128 tiles) already gains 20 % over the fp32 kernel
-    if (W >= 32 && H >= 16 && Kc >= 16 && Mc >= 32) {
+    if (!small_geo(W)) {
+        if (H < 16 || Kc < 16 || Mc < 32) return false;
         const long long grid = (long long)N * ((H + TH - 1) / TH) * ((W + 31) / 32) * ((Mc + 63) / 64);
         return grid >= min_grid;
     }
-    if (W == 16 && H == 16 && Kc >= 64 && Mc >= 64) {      // one 16 x 16 tile per image and 32 channels
-        const long long grid = (long long)N * ((Mc + 31) / 32);
+    if (W >= 16 && H >= 16 && Kc >= 32 && Mc >= 32) {       // 16 x 16 tiles, 32 output channels per workgroup, two workgroups per CU
+        const long long grid = (long long)N * ((H + TH - 1) / TH) * ((W + 15) / 16) * ((Mc + 31) / 32);
         return grid >= 128;
     }
     return false;
