@@ -26,17 +26,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NT = 512;
-constexpr int TW = 32, TH = 4, PT = TW * TH;            // 128 pixels per tile
+constexpr int NT = 512, PT = 128;                        // 128 pixels per tile
 constexpr int COT = 64, CIT = 64;
 constexpr int DYROW = PT * 2 + 16;                       // bytes per co row of one dY plane (272: 16-byte aligned, skewed banks)
 constexpr int DYPLANE = COT * DYROW;
-constexpr int XROW = 80;                                 // bytes per patch row (34 px used of 40)
-constexpr int XCH = (TH + 2) * XROW + 16;                // bytes per ci of one X plane (496)
+constexpr int XCH = 496;                                 // bytes per ci of one X plane: 6 rows x 80 B or 10 rows x 48 B, + 16
 constexpr int XPLANE = CIT * XCH;
-constexpr int XPAIRS = (TH + 2) * 17;                    // pixel pairs per ci (6 rows x 17)
-constexpr int XSLOTS = (CIT * XPAIRS + NT - 1) / NT;     // 13 pairs per thread
 constexpr int DYSLOTS = COT * PT / 4 / NT;               // 4 float4 per thread
+// tile geometry: 4 rows x 32 columns (planes whose width is a multiple of 32) or 8 rows x 16 columns (16-wide planes)
+template <int TWv> struct WGeo {
+    static constexpr int TW = TWv, TH = PT / TWv;
+    static constexpr int XROW = (TWv + 8) * 2;           // bytes per patch row: TW + 2 pixels, padded to a 16-byte multiple (80 / 48)
+    static constexpr int PAIRS_ROW = (TWv + 2) / 2;      // 17 / 9 pixel pairs per patch row
+    static constexpr int XPAIRS = (TH + 2) * PAIRS_ROW;  // 102 / 90 per ci
+    static constexpr int XSLOTS = (CIT * XPAIRS + NT - 1) / NT;
+    static_assert((TH + 2) * XROW + 16 == XCH, "patch image per channel");
+};
 
 struct WS {
     const float* x; const float* dy; float* slab;
@@ -53,7 +58,11 @@ __device__ __forceinline__ void split3(float v0, float v1, unsigned& p1, unsigne
     p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
+template <int TWv>
 __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
+    using GEO = WGeo<TWv>;
+    constexpr int TW = GEO::TW, TH = GEO::TH, XROW = GEO::XROW, PAIRS_ROW = GEO::PAIRS_ROW, XPAIRS = GEO::XPAIRS, XSLOTS = GEO::XSLOTS;
+    constexpr int QROW = TW / 4, SROW = TW / 16;          // float4 quads / 16-pixel k-steps per tile row
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dYl = lds;
     char* Xl = lds + 3 * DYPLANE;
@@ -76,16 +85,8 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         const_cast<float*>(p.x), 0, (unsigned)(((size_t)(p.N - 1) * p.CinTot + p.Cin) * p.HW * sizeof(float)), 0x00020000);
 
     // ---- staging maps
-    // dY: float4 e = tid + i * 512 -> co = e / 32, quad q = e % 32 (row q / 8, columns 4 (q % 8) ..)
-    unsigned dyo[DYSLOTS], dym[DYSLOTS];
-    int dyl[DYSLOTS];
-#pragma unroll
-    for (int i = 0; i < DYSLOTS; ++i) {
-        const int e = tid + i * NT, co = e >> 5, q = e & 31, row = q >> 3, c4 = (q & 7) * 4;
-        dyo[i] = 4u * (unsigned)(co * p.HW + row * p.W + c4);
-        dym[i] = (co0 + co) < p.Cout ? 0u : 0xFFFFFFFFu;          // all-ones: the range check returns 0
-        dyl[i] = co * DYROW + (row * TW + c4) * 2;
-    }
+    // dY: float4 e = tid + i * 512 -> co = e / 32, quad q = e % 32 (row q / QROW, columns 4 (q % QROW) ..); the
+    // per-slot offsets are recomputed per tile (a handful of integer ops) rather than held in registers
     f32x4 dreg[DYSLOTS];
     float xreg[XSLOTS][2];
     auto gload = [&](int t) __attribute__((always_inline)) {
@@ -94,15 +95,15 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         const unsigned dbase = 4u * (unsigned)((b0 * p.CoutTot + co0) * p.HW + y0 * p.W + x0);
 #pragma unroll
         for (int i = 0; i < DYSLOTS; ++i) {
-            const int row = ((tid + i * NT) & 31) >> 3;
-            const unsigned m = (y0 + row) < p.H ? 0u : 0xFFFFFFFFu;
-            dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (dbase + dyo[i]) | dym[i] | m, 0, 0));
+            const int e = tid + i * NT, co = e >> 5, q = e & 31, row = q / QROW, c4 = (q % QROW) * 4;
+            const unsigned m = ((y0 + row) < p.H && (co0 + co) < p.Cout) ? 0u : 0xFFFFFFFFu;      // all-ones: the range check returns 0
+            dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (dbase + 4u * (unsigned)(co * p.HW + row * p.W + c4)) | m, 0, 0));
         }
         const int xbase = (b0 * p.CinTot + ci0) * p.HW + y0 * p.W + x0;
 #pragma unroll
         for (int i = 0; i < XSLOTS; ++i) {
             const int e = tid + i * NT;
-            const int ci = e / XPAIRS, rem = e - ci * XPAIRS, prow = rem / 17, pj = rem - prow * 17;
+            const int ci = e / XPAIRS, rem = e - ci * XPAIRS, prow = rem / PAIRS_ROW, pj = rem - prow * PAIRS_ROW;
             const int yy = y0 + prow - 1, xx = x0 + 2 * pj - 1;
             const bool rowok = e < CIT * XPAIRS && (ci0 + ci) < p.Cin && yy >= 0 && yy < p.H;
             const int off = xbase + ci * p.HW + (prow - 1) * p.W + 2 * pj - 1;
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             unsigned a1, a2, a3, b1, b2, b3;
             split3(dreg[i][0], dreg[i][1], a1, a2, a3);
             split3(dreg[i][2], dreg[i][3], b1, b2, b3);
-            char* d = dYl + dyl[i];
+            const int e = tid + i * NT, co = e >> 5, q = e & 31;
+            char* d = dYl + co * DYROW + ((q / QROW) * TW + (q % QROW) * 4) * 2;
             *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
             *reinterpret_cast<uint2*>(d + DYPLANE) = make_uint2(a2, b2);
             *reinterpret_cast<uint2*>(d + 2 * DYPLANE) = make_uint2(a3, b3);
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         for (int i = 0; i < XSLOTS; ++i) {
             const int e = tid + i * NT;
             if (e < CIT * XPAIRS) {
-                const int ci = e / XPAIRS, rem = e - ci * XPAIRS, prow = rem / 17, pj = rem - prow * 17;
+                const int ci = e / XPAIRS, rem = e - ci * XPAIRS, prow = rem / PAIRS_ROW, pj = rem - prow * PAIRS_ROW;
                 unsigned a1, a2, a3;
                 split3(xreg[i][0], xreg[i][1], a1, a2, a3);
                 char* d = Xl + ci * XCH + prow * XROW + pj * 4;
@@ -158,36 +160,46 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             if (t + p.S < p.T) gload(t + p.S); // in flight during the MFMA loop below
 #pragma unroll
             for (int s = 0; s < PT / 16; ++s) {
-                const int srow = s >> 1, scol = (s & 1) * 16;
+                const int srow = s / SROW, scol = (s % SROW) * 16;
                 bf16x8 a[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(Ab + q * DYPLANE + (srow * TW + scol) * 2);
-                // B fragments of the two patch rows this tap group touches: [row][plane][dx]
-                bf16x8 b[2][3][3];
+                // B fragments: per patch row d and plane q five dwords (b128 + b32); the three dx variants of a row are
+                // formed right before their MFMAs (dx = 0: dwords 0..3, dx = 2: dwords 1..4, dx = 1: v_alignbit of
+                // neighbours) so that only one row's raw dwords and one shifted triple are live at a time
 #pragma unroll
-                for (int d = 0; d < 2; ++d)
+                for (int d = 0; d < 2; ++d) {
+                    u32x4 v[3];
+                    unsigned v4[3];
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         const char* src = Bb + q * XPLANE + (srow + DY0 + d) * XROW + scol * 2;
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(src);
-                        const unsigned v4 = *reinterpret_cast<const unsigned*>(src + 16);
-                        b[d][q][0] = __builtin_bit_cast(bf16x8, v);
-                        b[d][q][2] = __builtin_bit_cast(bf16x8, u32x4{v.y, v.z, v.w, v4});
-                        b[d][q][1] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(v.y, v.x, 16), __builtin_amdgcn_alignbit(v.z, v.y, 16),
-                                                                       __builtin_amdgcn_alignbit(v.w, v.z, 16), __builtin_amdgcn_alignbit(v4, v.w, 16)});
+                        v[q] = *reinterpret_cast<const u32x4*>(src);
+                        v4[q] = *reinterpret_cast<const unsigned*>(src + 16);
                     }
 #pragma unroll
-                for (int k = 0; k < NTAP; ++k) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int tap = TAP0 + k, d = tap / 3 - DY0, dx = tap % 3;
-                    f32x16 acc_k = acc[k];
-                    acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[d][1][dx], acc_k, 0, 0, 0);
-                    acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[d][0][dx], acc_k, 0, 0, 0);
-                    acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[d][2][dx], acc_k, 0, 0, 0);
-                    acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[d][0][dx], acc_k, 0, 0, 0);
-                    acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[d][1][dx], acc_k, 0, 0, 0);
-                    acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[d][0][dx], acc_k, 0, 0, 0);
-                    acc[k] = acc_k;
+                    for (int dx = 0; dx < 3; ++dx) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int tap = (DY0 + d) * 3 + dx, k = tap - TAP0;
+                        if (k >= 0 && k < NTAP) {
+                            bf16x8 b[3];
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) {
+                                if (dx == 0) b[q] = __builtin_bit_cast(bf16x8, v[q]);
+                                else if (dx == 2) b[q] = __builtin_bit_cast(bf16x8, u32x4{v[q].y, v[q].z, v[q].w, v4[q]});
+                                else b[q] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(v[q].y, v[q].x, 16), __builtin_amdgcn_alignbit(v[q].z, v[q].y, 16),
+                                                                             __builtin_amdgcn_alignbit(v[q].w, v[q].z, 16), __builtin_amdgcn_alignbit(v4[q], v[q].w, 16)});
+                            }
+                            f32x16 acc_k = acc[k < 0 ? 0 : (k >= NTAP ? NTAP - 1 : k)];
+                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc_k, 0, 0, 0);
+                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc_k, 0, 0, 0);
+                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc_k, 0, 0, 0);
+                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc_k, 0, 0, 0);
+                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc_k, 0, 0, 0);
+                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc_k, 0, 0, 0);
+                            acc[k < 0 ? 0 : (k >= NTAP ? NTAP - 1 : k)] = acc_k;
+                        }
+                    }
                 }
             }
         }
@@ -209,23 +221,40 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
 
 namespace uz {
 
-// layers that take the split-bf16 weight gradient: 3x3, rows a multiple of 32 wide (aligned float4 /
-// bf16-pair staging), at least 32 channels on both sides and enough pixels to amortise the tile loop
+// layers that take the split-bf16 weight gradient: 3x3, rows a multiple of 32 wide or exactly 16 wide (aligned
+// float4 / bf16-pair staging), at least 64 channels on both sides (32-channel sides leave half of the 64 x 64
+// tile empty) and enough pixels to amortise the tile loop
 bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks) {
     static const int mode = [] { const char* e = getenv("UZ_CONV_MATH"); return !e ? 1 : !strcmp(e, "f32") ? 0 : !strcmp(e, "split") ? 2 : 1; }();
-    if (!mode || ks != 3 || W % 32 != 0 || Cin < 32 || Cout < 32) return false;
+    if (!mode || ks != 3 || (W % 32 != 0 && W != 16) || Cin < 32 || Cout < 32) return false;
     if (mode == 2) return true;
-    return Cin >= 64 && Cout >= 64 && (long long)N * H * W >= 32 * 1024;     // 32-channel sides leave half of the 64 x 64 tile empty
+    return Cin >= 64 && Cout >= 64 && (long long)N * H * W >= 8 * 1024;
 }
+
+static inline int tile_w(int W) { return W == 16 ? 16 : 32; }
 
 // number of pixel splits: one workgroup per CU (147 KB of LDS), at most one split per pixel tile
 int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
     const int nt = ceil_div(Cout, COT) * ceil_div(Cin, CIT);
-    const int T = N * ceil_div(H, TH) * (W / TW);
+    const int tw = tile_w(W);
+    const int T = N * ceil_div(H, PT / tw) * (W / tw);
     int s = 256 / nt;
     if (s < 1) s = 1;
     if (s > T) s = T;
     return s;
+}
+
+template <int TWv>
+static int launch_wgrad(const WS& p, int grid, hipStream_t st) {
+    constexpr size_t smem = 3 * (size_t)DYPLANE + 3 * (size_t)XPLANE;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<TWv>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail("wgrad_split: cannot raise dynamic LDS limit");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wgrad_split_kernel<TWv>, dim3(grid), dim3(NT), smem, st, p);
+    return check_launch("wgrad_split_kernel");
 }
 
 int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* slab,
@@ -233,18 +262,12 @@ int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, 
     WS p;
     p.x = x; p.dy = dy; p.slab = slab;
     p.N = N; p.H = H; p.W = W; p.HW = H * W; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot;
-    p.tilesX = W / TW; p.tilesY = ceil_div(H, TH); p.T = N * p.tilesX * p.tilesY; p.S = S;
+    const int tw = tile_w(W);
+    p.tilesX = W / tw; p.tilesY = ceil_div(H, PT / tw); p.T = N * p.tilesX * p.tilesY; p.S = S;
     p.nCoT = ceil_div(Cout, COT); p.nCiT = ceil_div(Cin, CIT);
     UZ_REQUIRE((size_t)N * CinTot * p.HW < (1ull << 30) && (size_t)N * CoutTot * p.HW < (1ull << 30), "wgrad_split: tensor too large for 32-bit offsets");
-    constexpr size_t smem = 3 * (size_t)DYPLANE + 3 * (size_t)XPLANE;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return fail("wgrad_split: cannot raise dynamic LDS limit");
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(wgrad_split_kernel, dim3(p.nCoT * p.nCiT * S), dim3(NT), smem, st, p);
-    return check_launch("wgrad_split_kernel");
+    const int grid = p.nCoT * p.nCiT * S;
+    return tw == 16 ? launch_wgrad<16>(p, grid, st) : launch_wgrad<32>(p, grid, st);
 }
 
 }  // namespace uz
