@@ -52,7 +52,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform (scalar loop control below)
-    const int tg = wave % NTG, w2 = wave / NTG;
+    // NTG == 2 (3x3: 5 + 4 taps): waves w and w + 4 share a SIMD and get different tap groups
+    const int tg = NTG == 2 ? ((wave ^ (wave >> 2)) & 1) : 0, w2 = wave / NTG;
     const int wmn = w2 % (WM * WN), wk = w2 / (WM * WN);
     const int wm = wmn / WN, wn = wmn % WN;
     const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);
@@ -222,7 +223,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_fast_kernel(const WgP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tg = wave & 1, w2 = wave >> 1;
+    // waves w and w + 4 share a SIMD: give them different tap groups (5 + 4 taps) so every SIMD carries 9 taps' worth
+    const int tg = (wave ^ (wave >> 2)) & 1, w2 = wave >> 1;
     const int wmn = w2 % (WM * WN), wk = w2 / (WM * WN);
     const int wm = wmn / WN, wn = wmn % WN;
     const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tg = wave & 1, wn = (wave >> 1) & 1, wm = wave >> 2;
+    // waves w and w + 4 share a SIMD: give them different tap groups (5 + 4 taps) so every SIMD carries 9 taps' worth
+    const int tg = (wave ^ (wave >> 2)) & 1, wn = (wave >> 1) & 1, wm = wave >> 2;
     const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);
     const int nTile = p.nCoT * p.nCiT;
     const int split = wid / nTile, tl = wid - split * nTile;
