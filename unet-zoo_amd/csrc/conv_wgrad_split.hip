@@ -27,19 +27,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NT = 512, PT = 128;                        // 128 pixels per tile
-constexpr int COT = 64, CIT = 64;
 constexpr int DYROW = PT * 2 + 16;                       // bytes per co row of one dY plane (272: 16-byte aligned, skewed banks)
-constexpr int DYPLANE = COT * DYROW;
 constexpr int XCH = 496;                                 // bytes per ci of one X plane: 6 rows x 80 B or 10 rows x 48 B, + 16
-constexpr int XPLANE = CIT * XCH;
-constexpr int DYSLOTS = COT * PT / 4 / NT;               // 4 float4 per thread
 // tile geometry: 4 rows x 32 columns (planes whose width is a multiple of 32) or 8 rows x 16 columns (16-wide planes)
 template <int TWv> struct WGeo {
     static constexpr int TW = TWv, TH = PT / TWv;
     static constexpr int XROW = (TWv + 8) * 2;           // bytes per patch row: TW + 2 pixels, padded to a 16-byte multiple (80 / 48)
     static constexpr int PAIRS_ROW = (TWv + 2) / 2;      // 17 / 9 pixel pairs per patch row
     static constexpr int XPAIRS = (TH + 2) * PAIRS_ROW;  // 102 / 90 per ci
-    static constexpr int XSLOTS = (CIT * XPAIRS + NT - 1) / NT;
     static_assert((TH + 2) * XROW + 16 == XCH, "patch image per channel");
 };
 
@@ -58,11 +53,17 @@ __device__ __forceinline__ void split3(float v0, float v1, unsigned& p1, unsigne
     p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
-template <int TWv>
+// CT = channel tile on both sides: 64 (waves = co half x ci half x tap group) or 32 (waves = pixel quarter x tap
+// group; the four pixel quarters are folded through LDS at the end; 74 KB of LDS -> two workgroups per CU)
+template <int TWv, int CT>
 __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
     using GEO = WGeo<TWv>;
-    constexpr int TW = GEO::TW, TH = GEO::TH, XROW = GEO::XROW, PAIRS_ROW = GEO::PAIRS_ROW, XPAIRS = GEO::XPAIRS, XSLOTS = GEO::XSLOTS;
+    constexpr int TW = GEO::TW, TH = GEO::TH, XROW = GEO::XROW, PAIRS_ROW = GEO::PAIRS_ROW, XPAIRS = GEO::XPAIRS;
     constexpr int QROW = TW / 4, SROW = TW / 16;          // float4 quads / 16-pixel k-steps per tile row
+    constexpr int COT = CT, CIT = CT, WK = CT == 64 ? 1 : 4;
+    constexpr int DYPLANE = COT * DYROW, XPLANE = CIT * XCH;
+    constexpr int DYSLOTS = COT * PT / 4 / NT;            // float4 per thread: 4 / 2
+    constexpr int XSLOTS = (CIT * XPAIRS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dYl = lds;
     char* Xl = lds + 3 * DYPLANE;
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // waves w and w + 4 share a SIMD: give them different tap groups (5 + 4 taps) so every SIMD carries 9 taps' worth
-    const int tg = (wave ^ (wave >> 2)) & 1, wn = (wave >> 1) & 1, wm = wave >> 2;
+    const int tg = (wave ^ (wave >> 2)) & 1;
+    const int wn = CT == 64 ? (wave >> 1) & 1 : 0, wm = CT == 64 ? wave >> 2 : 0;
+    const int wk = CT == 64 ? 0 : wave >> 1;             // pixel quarter: k-steps s with s % 4 == wk
     const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);
     const int nTile = p.nCoT * p.nCiT;
     const int split = wid / nTile, tl = wid - split * nTile;
@@ -160,7 +163,8 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             __syncthreads();
             if (t + p.S < p.T) gload(t + p.S); // in flight during the MFMA loop below
 #pragma unroll
-            for (int s = 0; s < PT / 16; ++s) {
+            for (int si = 0; si < PT / 16 / WK; ++si) {
+                const int s = si * WK + wk;                 // WK == 1: compile-time; WK == 4: wave-uniform
                 const int srow = s / SROW, scol = (s % SROW) * 16;
                 bf16x8 a[3];
 #pragma unroll
@@ -204,6 +208,39 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
                 }
             }
         }
+        if constexpr (WK > 1) {
+            // fold the WK pixel-quarter partial sums pairwise through LDS (fixed order ((0+2)+(1+3)), three taps per
+            // round so that the dead staging area suffices); group 0 writes the slab
+            constexpr int RT = 3;
+            float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+            for (int stride = WK / 2; stride >= 1; stride >>= 1) {
+#pragma unroll
+                for (int k0 = 0; k0 < 5; k0 += RT) {
+                    __syncthreads();
+                    if (wk >= stride && wk < 2 * stride) {
+                        float* dstp = red + (size_t)(((wk - stride) * 2 + tg) * RT) * 16 * 64 + lane;
+#pragma unroll
+                        for (int kk = 0; kk < RT; ++kk)
+                            if (k0 + kk < NTAP) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) dstp[(kk * 16 + r) * 64] = acc[k0 + kk][r];
+                            }
+                    }
+                    __syncthreads();
+                    if (wk < stride) {
+                        const float* srcp = red + (size_t)((wk * 2 + tg) * RT) * 16 * 64 + lane;
+#pragma unroll
+                        for (int kk = 0; kk < RT; ++kk)
+                            if (k0 + kk < NTAP) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[k0 + kk][r] += srcp[(kk * 16 + r) * 64];
+                            }
+                    }
+                }
+            }
+            if (wk != 0) return;
+        }
         float* out = p.slab + (size_t)split * 9 * p.Cout * p.Cin;
         const int ci = ci0 + wn * 32 + l31;
 #pragma unroll
@@ -223,38 +260,43 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
 namespace uz {
 
 // layers that take the split-bf16 weight gradient: 3x3, rows a multiple of 32 wide or exactly 16 wide (aligned
-// float4 / bf16-pair staging), at least 64 channels on both sides (32-channel sides leave half of the 64 x 64
-// tile empty) and enough pixels to amortise the tile loop
+// float4 / bf16-pair staging) and either at least 64 channels on both sides (64 x 64 tile; a 32-channel side
+// would leave half of it empty) or at most 32 on both (32 x 32 tile: the full-resolution 32 -> 32 layers and the
+// 1- and 3-channel input layers), with enough pixels to amortise the tile loop
 bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks) {
     static const int mode = [] { const char* e = getenv("UZ_CONV_MATH"); return !e ? 1 : !strcmp(e, "f32") ? 0 : !strcmp(e, "split") ? 2 : 1; }();
-    if (!mode || ks != 3 || (W % 32 != 0 && W != 16) || Cin < 32 || Cout < 32) return false;
+    if (!mode || ks != 3 || (W % 32 != 0 && W != 16)) return false;
     if (mode == 2) return true;
-    return Cin >= 64 && Cout >= 64 && (long long)N * H * W >= 8 * 1024;
+    const long long px = (long long)N * H * W;
+    return (Cin >= 64 && Cout >= 64 && px >= 8 * 1024) || (Cin <= 32 && Cout <= 32 && Cout >= 16 && px >= 128 * 1024);
 }
 
 static inline int tile_w(int W) { return W == 16 ? 16 : 32; }
+static inline int chan_tile(int Cin, int Cout) { return (Cin <= 32 && Cout <= 32) ? 32 : 64; }
 
-// number of pixel splits: one workgroup per CU (147 KB of LDS), at most one split per pixel tile
+// number of pixel splits: one (64-channel tiles, 147 KB of LDS) or two (32-channel tiles, 74 KB) workgroups per CU,
+// at most one split per pixel tile
 int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
-    const int nt = ceil_div(Cout, COT) * ceil_div(Cin, CIT);
+    const int ct = chan_tile(Cin, Cout);
+    const int nt = ceil_div(Cout, ct) * ceil_div(Cin, ct);
     const int tw = tile_w(W);
     const int T = N * ceil_div(H, PT / tw) * (W / tw);
-    int s = 256 / nt;
+    int s = (ct == 64 ? 256 : 512) / nt;
     if (s < 1) s = 1;
     if (s > T) s = T;
     return s;
 }
 
-template <int TWv>
+template <int TWv, int CT>
 static int launch_wgrad(const WS& p, int grid, hipStream_t st) {
-    constexpr size_t smem = 3 * (size_t)DYPLANE + 3 * (size_t)XPLANE;
+    constexpr size_t smem = 3 * (size_t)(CT * DYROW) + 3 * (size_t)(CT * XCH);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<TWv>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<TWv, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return fail("wgrad_split: cannot raise dynamic LDS limit");
         attr_done = true;
     }
-    hipLaunchKernelGGL(wgrad_split_kernel<TWv>, dim3(grid), dim3(NT), smem, st, p);
+    hipLaunchKernelGGL((wgrad_split_kernel<TWv, CT>), dim3(grid), dim3(NT), smem, st, p);
     return check_launch("wgrad_split_kernel");
 }
 
@@ -263,12 +305,13 @@ int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, 
     WS p;
     p.x = x; p.dy = dy; p.slab = slab;
     p.N = N; p.H = H; p.W = W; p.HW = H * W; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot;
-    const int tw = tile_w(W);
+    const int tw = tile_w(W), ct = chan_tile(Cin, Cout);
     p.tilesX = W / tw; p.tilesY = ceil_div(H, PT / tw); p.T = N * p.tilesX * p.tilesY; p.S = S;
-    p.nCoT = ceil_div(Cout, COT); p.nCiT = ceil_div(Cin, CIT);
+    p.nCoT = ceil_div(Cout, ct); p.nCiT = ceil_div(Cin, ct);
     UZ_REQUIRE((size_t)N * CinTot * p.HW < (1ull << 30) && (size_t)N * CoutTot * p.HW < (1ull << 30), "wgrad_split: tensor too large for 32-bit offsets");
     const int grid = p.nCoT * p.nCiT * S;
-    return tw == 16 ? launch_wgrad<16>(p, grid, st) : launch_wgrad<32>(p, grid, st);
+    if (ct == 32) return tw == 16 ? launch_wgrad<16, 32>(p, grid, st) : launch_wgrad<32, 32>(p, grid, st);
+    return tw == 16 ? launch_wgrad<16, 64>(p, grid, st) : launch_wgrad<32, 64>(p, grid, st);
 }
 
 }  // namespace uz
