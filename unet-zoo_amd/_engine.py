@@ -87,7 +87,7 @@ class NativeModel(nn.Module):
     def enable_graphs(self, flag=True):
         """Replay forward/backward tapes as captured hipGraphs (one graph launch instead of ~1000
         kernel launches).  Capture happens lazily on a side stream after one eager warm-up run, over
-        `plan.n_lanes` dependency lanes (UZ_LANES, default 3 - measured best on MI355X) so that independent chains of the
+        `plan.n_lanes` dependency lanes (UZ_LANES, default 2 - measured best on MI355X) so that independent chains of the
         tape - posterior / prior encoders, the likelihood branches - overlap on the device."""
         self._use_graphs = bool(flag)
 

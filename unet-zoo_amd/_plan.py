@@ -146,7 +146,7 @@ class Plan:
         self.named = {}                     # user-visible tensors: name -> View
         self.finalized = False
         self._gid = 0                       # scheduling group of the ops being emitted (see _schedule)
-        self.n_lanes = max(1, min(int(os.environ.get("UZ_LANES", "3")), 8))
+        self.n_lanes = max(1, min(int(os.environ.get("UZ_LANES", "2")), 8))
 
     def _newgroup(self):
         self._gid += 1
@@ -623,17 +623,32 @@ class Plan:
             return i[0] * i[3] * i[4] * i[5] * 24.0 / 2e12 + 6e-6
         return 6e-6
 
+    @staticmethod
+    def _op_heavy(o):
+        """True for ops that fill the chip on their own (only one of those is simulated in flight at a time)."""
+        c, i = o["code"], o["i"]
+        if c in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA", "UZ_OP_CONV_BWD_WEIGHT"):
+            return i[4] * i[5] * i[6] >= 2048 and i[0] * i[2] >= 32 * 32      # measured: 512..8192 pixels all within 1 %
+        if c in ("UZ_OP_BN_RELU_FWD", "UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
+            C, N, H, W = (i[0], i[3], i[4], i[5]) if c == "UZ_OP_BN_RELU_FWD" else (i[1], i[4], i[5], i[6])
+            return C * N * H * W >= 4.0e6
+        if c in ("UZ_OP_AVGPOOL_FWD", "UZ_OP_AVGPOOL_BWD", "UZ_OP_BILINEAR_FWD", "UZ_OP_BILINEAR_BWD", "UZ_OP_NEAREST_FWD", "UZ_OP_NEAREST_BWD"):
+            return i[0] * i[3] * i[4] * i[5] >= 2.0e6
+        return False
+
     def _schedule(self, ops):
         """Turns the tape into a DAG schedule for uz_graph_create_lanes and REORDERS `ops` in place.
 
         1. Hazard analysis in program order: a group (one layer's forward, or one layer's backward;
            its ops stay back to back) depends on every earlier group it has a RAW, WAR or WAW conflict
            with (buffer channel ranges, gradient ranges, BN running buffers).
-        2. Event-driven list scheduling on n_lanes lanes with the cost model above: the ready group
-           that can start first goes to the lane that is free first.  A lane is a scratch copy, so the
-           groups of a lane must stay ordered; simulating time is what lets an independent chain (the
-           prior encoder next to the posterior encoder, the likelihood branches) claim a lane for
-           itself instead of queueing behind whatever happened to use that lane last in program order.
+        2. Event-driven list scheduling in simulated time (cost model above) on n_lanes lanes (a lane is a
+           scratch copy, so the groups of a lane stay ordered): among the groups that are ready, the one
+           with the longest remaining critical path starts first; at most ONE device-filling ("heavy")
+           group is in flight at a time, light groups start whenever a lane is free.  This staggers the
+           independent chains (posterior / prior encoders, likelihood branches) so that the latency-bound
+           deep levels of one run beside the device-filling layers of another, instead of both being
+           deep - and the chip idle - at the same time.
         3. The tape is rewritten in simulated start order (a topological order of the DAG, so the
            eager runner stays correct) and every group gets: its lane, and the cross-lane groups it
            must wait for that are not already implied by its lane predecessor.
@@ -694,26 +709,42 @@ class Plan:
         tail = [None] * K
         finish = [0.0] * G
         order, lane_of = [], [None] * G
-        while ready:
-            # the group that can start first (ties: program order); its lane: free by then and, if possible,
-            # one whose tail it depends on anyway - otherwise the lane that is free first
-            fmin = min(free)
-            gi = min(ready, key=lambda g: (max(ready_at[g], fmin), g))
-            ready.remove(gi)
-            start = max(ready_at[gi], fmin)
-            cands = [l for l in range(K) if free[l] <= start]
-            pref = [l for l in cands if tail[l] is not None and tail[l] in deps[gi]]
-            lane = pref[0] if pref else min(cands, key=lambda l: (free[l], l))
-            lane_of[gi] = lane
-            finish[gi] = start + cost[gi]
-            free[lane] = finish[gi]
-            tail[lane] = gi
-            order.append(gi)
-            for sgi in succ[gi]:
-                indeg[sgi] -= 1
-                ready_at[sgi] = max(ready_at[sgi], finish[gi])
-                if indeg[sgi] == 0:
-                    ready.append(sgi)
+        # one device-filling group at a time (critical path first); light groups start whenever a lane is free
+        heavy = [any(self._op_heavy(o) for o in ops[a:b + 1]) for a, b in groups]
+        blevel = [0.0] * G
+        for gi in reversed(range(G)):
+            blevel[gi] = cost[gi] + max((blevel[sg] for sg in succ[gi]), default=0.0)
+        t, running = 0.0, []
+        while len(order) < G:
+            running = [(f, g) for f, g in running if f > t + 1e-12]
+            busy_lanes = {lane_of[g] for _, g in running}
+            heavy_busy = any(heavy[g] for _, g in running)
+            started = False
+            for gi in sorted((g for g in ready if ready_at[g] <= t + 1e-12), key=lambda g: (-blevel[g], g)):
+                lanes_free = [l for l in range(K) if l not in busy_lanes]
+                if not lanes_free or (heavy[gi] and heavy_busy):
+                    continue
+                pref = [l for l in lanes_free if tail[l] is not None and tail[l] in deps[gi]]
+                lane = pref[0] if pref else min(lanes_free, key=lambda l: (free[l], l))
+                lane_of[gi] = lane
+                finish[gi] = t + cost[gi]
+                free[lane] = finish[gi]
+                tail[lane] = gi
+                order.append(gi)
+                ready.remove(gi)
+                running.append((finish[gi], gi))
+                busy_lanes.add(lane)
+                heavy_busy = heavy_busy or heavy[gi]
+                started = True
+                for sgi in succ[gi]:
+                    indeg[sgi] -= 1
+                    ready_at[sgi] = max(ready_at[sgi], finish[gi])
+                    if indeg[sgi] == 0:
+                        ready.append(sgi)
+            if not started:
+                nxt = [f for f, _ in running] + [ready_at[g] for g in ready if ready_at[g] > t + 1e-12]
+                assert nxt, "dependency cycle in the tape"
+                t = min(nxt)
         assert len(order) == G, "dependency cycle in the tape"
         # ---- 3. rewrite the tape in schedule order, compute waits
         new_ops, first, last = [], [0] * G, [0] * G
