@@ -610,7 +610,7 @@ class Plan:
             # measured fp32-equivalent TFLOP/s per plane size at batch 32 (tools/op_profile.py), forward / data
             # gradient and weight gradient; small channel counts and 1x1 kernels run far below these
             px = N * H * W
-            table = ((262144, 180, 130), (65536, 190, 148), (16384, 115, 114), (4096, 70, 64), (1024, 35, 29), (256, 11, 9), (0, 3, 2.5))
+            table = ((262144, 180, 150), (65536, 190, 159), (16384, 148, 122), (4096, 97, 85), (1024, 37, 31), (256, 11, 9), (0, 3, 2.2))
             rate = next((f if c != "UZ_OP_CONV_BWD_WEIGHT" else w) for lim, f, w in table if px >= lim) * 1e12
             if min(cin, cout) < 32 or ks == 1:
                 rate = min(rate, 20e12)
