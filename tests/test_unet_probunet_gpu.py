@@ -94,3 +94,46 @@ def test_probunet_small_vs_reference_golden():
     assert G.maxabs(z.cpu().numpy(), out["posterior_mu"].numpy()) <= 1e-4
     assert G.maxabs(rec.cpu().numpy(), ref.numpy()) <= 2e-4
     assert net.sample(testing=True).shape == rec.shape
+
+
+@pytest.mark.parametrize("model", ["unet", "probunet"])
+def test_graph_replay_is_bit_identical_to_eager(model):
+    """hipGraph replay with dependency lanes reproduces the eager tapes bit for bit for the other two models too
+    (different DAG shapes: skip connections only / two Gaussian encoders + a 1x1 fcomb chain + an L2 regulariser)."""
+    from unet_zoo_amd.optim import FusedAdam
+    name = "unet_small" if model == "unet" else "probunet_small"
+    arrays, meta = G.load(name)
+    results = []
+    for graphs in (False, True):
+        if model == "unet":
+            from unet_zoo_amd.models.unet import Unet
+            net = Unet(1, 2, meta["filters"])
+        else:
+            from unet_zoo_amd.models.probabilistic_unet import ProbabilisticUnet
+            net = ProbabilisticUnet(1, 2, meta["filters"], latent_dim=meta["latent_dim"], no_convs_fcomb=3, image_size=(1, 128, 128))
+        net.load_state_dict(oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"]))
+        net.train()
+        net.enable_graphs(graphs)
+        opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
+        losses = []
+        for step in range(4):                       # graph mode: eager warm-up, capture, replay, replay
+            if model == "unet":
+                x, mask, _ = oracle.synthetic_batch(meta["batch"], 128, 128, seed=20201004 + step % 2)
+                xd, md = torch.from_numpy(x).to(DEV()), torch.from_numpy(mask).to(DEV())
+                net.forward(xd)
+                loss = net.loss(md)
+            else:
+                x, mask, eps = oracle.synthetic_batch(meta["batch"], 128, 128, seed=20201004 + step % 2,
+                                                      eps_shapes=[(meta["batch"], meta["latent_dim"])])
+                xd, md = torch.from_numpy(x).to(DEV()), torch.from_numpy(mask).to(DEV())
+                net.forward(xd, md, training=True)
+                loss = net.loss(md, eps=torch.from_numpy(eps[0]).to(DEV()))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        results.append((losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}))
+    (l0, s0), (l1, s1) = results
+    assert l0 == l1
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
