@@ -36,6 +36,8 @@ CONV_CASES = [
     (5, 72, 40, 16, 16, 3),       # 16-wide weight-gradient tiles, ragged channel tiles, odd batch
     (6, 33, 96, 8, 8, 3),         # 8-wide weight-gradient tiles
     (3, 20, 36, 20, 16, 3),       # H not a multiple of the 4-row tile
+    (2, 48, 80, 37, 96, 3),       # three 32-wide tiles per row, ragged rows, channel tiles with overhang (split kernels when forced)
+    (2, 70, 33, 50, 64, 3),       # Cin, Cout with K / M tails on 64-wide planes
 ]
 
 
