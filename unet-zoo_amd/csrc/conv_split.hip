@@ -19,14 +19,12 @@
 #include <stdlib.h>
 #include <string.h>
 #include "uz_common.h"
+#include "split_bf16.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using uz::f32x16; using uz::f32x4; using uz::bf16x8; using uz::u32x4; using uz::split3;
+
 
 constexpr int CK = 16, NSUB = 2, KK = 9, TH = 16;
 // Two tile geometries share the kernel: 512 threads on 16 x 32 pixels (planes at least 32 wide) and 256 threads
@@ -49,15 +47,6 @@ struct SP {
     int relu, accumulate;
 };
 
-// v = h1 + h2 + h3 exactly (h_i bf16): returns the three pieces of two values packed as bf16 pairs
-__device__ __forceinline__ void split3(float v0, float v1, unsigned& p1, unsigned& p2, unsigned& p3) {
-    const f32x2 a = {v0, v1};
-    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
-    const f32x2 r1 = {v0 - __builtin_bit_cast(float, p1 << 16), v1 - __builtin_bit_cast(float, p1 & 0xFFFF0000u)};
-    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
-    const f32x2 r2 = {r1.x - __builtin_bit_cast(float, p2 << 16), r1.y - __builtin_bit_cast(float, p2 & 0xFFFF0000u)};
-    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-}
 
 // 16 fp32 values (one LDS row of 16 channels) -> three 32-byte bf16 rows at dst + plane * plane_stride (bytes)
 __device__ __forceinline__ void split_store16(const float (&v)[CK], char* dst, int plane_stride) {

@@ -16,15 +16,12 @@
 #include <string.h>
 #include <type_traits>
 #include "uz_common.h"
+#include "split_bf16.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using uz::f32x16; using uz::f32x4; using uz::bf16x8; using uz::u32x4; using uz::split3;
+
 
 constexpr int NT = 512, PT = 128;                        // 128 pixels per tile
 constexpr int DYROW = PT * 2 + 16;                       // bytes per co row of one dY plane (272: 16-byte aligned, skewed banks)
@@ -44,14 +41,6 @@ struct WS {
     int tilesX, tilesY, T, S, nCoT, nCiT;
 };
 
-__device__ __forceinline__ void split3(float v0, float v1, unsigned& p1, unsigned& p2, unsigned& p3) {
-    const f32x2 a = {v0, v1};
-    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
-    const f32x2 r1 = {v0 - __builtin_bit_cast(float, p1 << 16), v1 - __builtin_bit_cast(float, p1 & 0xFFFF0000u)};
-    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
-    const f32x2 r2 = {r1.x - __builtin_bit_cast(float, p2 << 16), r1.y - __builtin_bit_cast(float, p2 & 0xFFFF0000u)};
-    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-}
 
 // CT = channel tile on both sides: 64 (waves = co half x ci half x tap group) or 32 (waves = pixel quarter x tap
 // group; the four pixel quarters are folded through LDS at the end; 74 KB of LDS -> two workgroups per CU)
