@@ -1,0 +1,1 @@
+"""Experiment files of the native package (same attribute surface as the reference experiment modules)."""
