@@ -1,61 +1,88 @@
 #!/usr/bin/env python3
-"""Headline benchmark: images/sec of one PHiSeg-7/5 training step (forward + loss + backward +
-gradient all-reduce + Adam) at 128x128, batch 32 per GPU, fp32, on N MI355X GPUs of one node.
+"""Headline benchmark: images/sec of one training step (forward + loss + backward + gradient all-reduce + Adam)
+at 128x128, batch 32 per GPU, fp32 in / fp32 out, on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5                      # PHiSeg 7/5 = BASELINE.json configs[3] (headline)
+    python bench.py --model unet      ...                               # configs[1]: Unet(1,2,[32,64,128,192])
+    python bench.py --model probunet  ...                               # configs[2]: ProbabilisticUnet latent 6 (+ 8-sample decode)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement).  Workload = BASELINE.json
-configs[3] (PHiSeg 7 resolution / 5 latent levels, filters 32,64,128,192,192,192,192), synthetic
-LIDC-like inputs, random-init weights, inputs resident in HBM before the timed region.
+Prints ONE JSON line on rank 0 (contract in the task statement).  Synthetic LIDC-like inputs,
+random-init weights, inputs resident in HBM before the timed region.
 
 Extra objects on the line:
-  roofline      step-level fp32-MFMA roofline exactly as BASELINE.md section 2 defines it
-                (achieved TFLOP/s = images/s x 100.36 GFLOP/image; peak 157.3 TFLOP/s), plus
-                `dominant_kernel`: the single heaviest kernel (3x3 conv 224->128 at 32x128x128) timed
-                live with HIP events on its launch stream - algorithmic FLOPs per launch / average
-                launch duration - with its PMC-measured HBM bytes per launch as `traffic`;
-                `families`: summed algorithmic FLOPs (or bytes) / summed duration of every kernel
-                family of the step, each op bracketed by HIP events; `dominant_family` = the heaviest.
-  cpu_baseline  the CPU oracle (a functional torch restatement of the reference graph = "port")
-                timed on this box's host cores on a bounded sample of the same workload.
+  roofline      `achieved` = images/s x the model's algorithmic GFLOP/image in fp32-equivalent
+                TFLOP/s.  `peak` is the BINDING roof of the step: every convolution op of the tape is priced against the
+                matrix pipe it actually runs on - 157.3 TFLOP/s (fp32 MFMA) for the ops the library routes to
+                conv_mfma / wgrad_fast kernels, 2500/6 = 416.7 TFLOP/s for the ops it routes to the split-bf16 kernels
+                (six bf16 piece products per fp32 product) - and peak = sum(flops) / sum(flops_i / roof_i); frac =
+                achieved / peak.  `frac_vs_fp32_mfma` keeps BASELINE.md's step-level figure (achieved / 157.3) for
+                reference, and `fp32_mfma_only` is the same run with UZ_CONV_MATH=f32 (like-for-like against 157.3).
+                `dominant_kernel`: the heaviest kernel of the step timed live with HIP events on its launch stream,
+                against ITS roof; `families`: per-family sums, conv families with their binding roof, streaming
+                families against 8 TB/s.
+  cpu_baseline  the CPU oracle (functional torch restatement of the reference graph = "port") timed on this box's host
+                cores on a bounded sample of the same workload (batch stated in `sample`).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-FILTERS = [32, 64, 128, 192, 192, 192, 192]
-GFLOP_PER_IMAGE = 100.36          # BASELINE.md section 2 (fwd+bwd, measured from the reference graph)
+FILTERS7 = [32, 64, 128, 192, 192, 192, 192]
+FILTERS4 = [32, 64, 128, 192]
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md chip-level parameters
-GB_PER_IMAGE_UNFUSED = 1.077
-GB_PER_STEP_FIXED = 0.294
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak
+SPLIT_PRODUCTS = 6                # bf16 piece products per fp32 product in conv_split.hip / conv_wgrad_split.hip
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
 HBM_PEAK_GBS = 8000.0
 
+# algorithmic work per image (fwd+bwd), unfused tensor bytes per image, fixed bytes per step
+MODELS = {
+    "phiseg": dict(gflop=100.36, gb_img=1.077, gb_step=0.294, metric="images/sec fwd+bwd PHiSeg-7 128x128 bs32",
+                   workload="PHiSeg 7 resolution / 5 latent levels, filters 32-64-128-192x4, 1x128x128, fwd+loss+bwd+Adam (BASELINE configs[3])"),
+    "unet": dict(gflop=20.86, gb_img=0.288, gb_step=0.028, metric="images/sec fwd+bwd U-Net-4 128x128 bs32",
+                 workload="vanilla U-Net 4-level, filters 32-64-128-192, 1x128x128, fwd+loss+bwd+Adam (BASELINE configs[1])"),
+    "probunet": dict(gflop=40.74, gb_img=0.736, gb_step=0.565, metric="images/sec fwd+bwd ProbU-Net(latent 6) 128x128 bs32",
+                     workload="Probabilistic U-Net, filters 32-64-128-192x4, latent_dim 6, no_convs_fcomb 3, 1x128x128, "
+                              "fwd+loss+bwd+Adam (BASELINE configs[2]); 8 posterior-sample decodes timed separately"),
+}
 
-def conv_flops(op, codes):
-    """Algorithmic FLOPs of one conv-family tape op (2 * N*H*W * Cin*Cout*k*k)."""
-    i = op["i"]
-    c = op["code"]
+
+def conv_dims(op):
+    """(kind, cin, cout, n, h, w, ks) of a conv-family tape op; kind 0 fwd / 1 dgrad / 2 wgrad."""
+    i, c = op["i"], op["code"]
     if c == "UZ_OP_CONV_FWD":
-        cin, cout, n, h, w, ks = i[0], i[2], i[4], i[5], i[6], i[7]
-    elif c == "UZ_OP_CONV_BWD_DATA":
-        cout, cin, n, h, w, ks = i[0], i[2], i[4], i[5], i[6], i[7]
-    elif c == "UZ_OP_CONV_BWD_WEIGHT":
-        cin, cout, n, h, w, ks = i[0], i[2], i[4], i[5], i[6], i[7]
-    else:
+        return 0, i[0], i[2], i[4], i[5], i[6], i[7]
+    if c == "UZ_OP_CONV_BWD_DATA":
+        return 1, i[2], i[0], i[4], i[5], i[6], i[7]
+    if c == "UZ_OP_CONV_BWD_WEIGHT":
+        return 2, i[0], i[2], i[4], i[5], i[6], i[7]
+    return None
+
+
+def conv_flops(op):
+    d = conv_dims(op)
+    if d is None:
         return 0.0
+    _, cin, cout, n, h, w, ks = d
     return 2.0 * n * h * w * cin * cout * ks * ks
 
 
-def op_bytes(op, plan):
+def conv_roof(op, L):
+    """Peak TFLOP/s of the pipe the library routes this op to (uz_conv_route), or None for the streaming 1x1 heads."""
+    kind, cin, cout, n, h, w, ks = conv_dims(op)
+    r = L.uz_conv_route(kind, cin, cout, n, h, w, ks)
+    return {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_SPLIT_TFLOPS, 2: None}[r]
+
+
+def op_bytes(op):
     """Algorithmic HBM bytes of a streaming (non-conv) op: every tensor argument read or written once."""
     c, i = op["code"], op["i"]
     f4 = 4.0
@@ -63,10 +90,10 @@ def op_bytes(op, plan):
         C, N, H, W, training = i[0], i[3], i[4], i[5], i[6]
         big = N * H * W > 8192
         return f4 * C * N * H * W * ((3 if big else 2) if training else 2)
-    if c == "UZ_OP_BN_RELU_BWD":
+    if c in ("UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
         C, N, H, W = i[1], i[4], i[5], i[6]
         big = N * H * W > 8192
-        return f4 * C * N * H * W * (5 if big else 3)
+        return f4 * C * N * H * W * ((5 if big else 3) if c == "UZ_OP_BN_RELU_BWD" else 3)
     if c in ("UZ_OP_AVGPOOL_FWD", "UZ_OP_AVGPOOL_BWD"):
         C, N, H, W = i[0], i[3], i[4], i[5]
         return f4 * C * N * H * W * 1.25
@@ -79,21 +106,41 @@ def op_bytes(op, plan):
     return 0.0
 
 
-FAMILY = {"UZ_OP_CONV_FWD": "conv_fwd_mfma", "UZ_OP_CONV_BWD_DATA": "conv_dgrad_mfma", "UZ_OP_CONV_BWD_WEIGHT": "conv_wgrad_mfma",
-          "UZ_OP_BN_RELU_FWD": "bn_relu_fwd", "UZ_OP_BN_RELU_BWD": "bn_relu_bwd",
+FAMILY = {"UZ_OP_CONV_FWD": "conv_fwd", "UZ_OP_CONV_BWD_DATA": "conv_dgrad", "UZ_OP_CONV_BWD_WEIGHT": "conv_wgrad",
+          "UZ_OP_BN_RELU_FWD": "bn_relu_fwd", "UZ_OP_BN_RELU_BWD": "bn_relu_bwd", "UZ_OP_RELU_BWD": "relu_bwd",
           "UZ_OP_AVGPOOL_FWD": "resample", "UZ_OP_AVGPOOL_BWD": "resample", "UZ_OP_BILINEAR_FWD": "resample",
           "UZ_OP_BILINEAR_BWD": "resample", "UZ_OP_NEAREST_FWD": "resample", "UZ_OP_NEAREST_BWD": "resample"}
 
 
-def profile_families(net, plan, reps=3):
-    """Live per-family timing: replay the fwd / bwd tapes one op at a time, each bracketed by HIP
-    events on the launch stream (torch.cuda.Event records on torch's current stream, which IS the
-    stream the tape is launched on)."""
+def binding_roof(plan, L):
+    """Effective matrix-pipe roof of the step: sum(flops) / sum(flops_i / roof_i) over the conv ops of the fwd + bwd tapes,
+    plus the FLOP share that runs on each pipe."""
+    tot = t_at_roof = 0.0
+    share = {"fp32_mfma": 0.0, "split_bf16_mfma": 0.0, "valu_streaming_heads": 0.0}
+    for ops in (plan.fwd_ops, plan.loss_ops, plan.bwd_ops):
+        for o in ops:
+            fl = conv_flops(o)
+            if not fl:
+                continue
+            roof = conv_roof(o, L)
+            if roof is None:
+                share["valu_streaming_heads"] += fl
+                continue                                     # memory-bound heads: no matrix-pipe roof, < 0.1 % of the FLOPs
+            share["fp32_mfma" if roof == PEAK_F32_MFMA_TFLOPS else "split_bf16_mfma"] += fl
+            tot += fl
+            t_at_roof += fl / roof
+    allf = sum(share.values()) or 1.0
+    return tot / t_at_roof, {k: round(v / allf, 4) for k, v in share.items()}
+
+
+def profile_families(net, plan, L, reps=3):
+    """Live per-family timing: replay the fwd / bwd tapes one op at a time, each bracketed by HIP events on the launch
+    stream (torch.cuda.Event records on torch's current stream, which IS the stream the tape is launched on)."""
     import ctypes as C
+    import torch
     from unet_zoo_amd import _ffi
-    L = _ffi.lib()
     stream = C.c_void_p(net._stream())
-    fam = {}
+    fam, heaviest = {}, None
     for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
         arr, n = plan.tapes[which]
         for k in range(n):
@@ -108,82 +155,85 @@ def profile_families(net, plan, reps=3):
                 e1.synchronize()
                 ms = e0.elapsed_time(e1)
                 best = ms if best is None else min(best, ms)
-            d = fam.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            d = fam.setdefault(name, dict(ms=0.0, flops=0.0, t_roof=0.0, bytes=0.0, launches=0))
+            fl = conv_flops(ops[k])
             d["ms"] += best
-            d["flops"] += conv_flops(ops[k], None)
-            d["bytes"] += op_bytes(ops[k], plan)
+            d["bytes"] += op_bytes(ops[k])
             d["launches"] += 1
-    return fam
+            if fl:
+                roof = conv_roof(ops[k], L)
+                if roof is not None:
+                    d["flops"] += fl
+                    d["t_roof"] += fl / roof
+                    if heaviest is None or best > heaviest[0]:
+                        heaviest = (best, which, k, fl, roof)
+    return fam, heaviest
 
 
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
-SPLIT_PRODUCTS = 6                # bf16 piece products per fp32 product in conv_split.hip
+def dominant_kernel_live(net, plan, L, heaviest, reps=20):
+    """The single heaviest kernel launch of the step (longest conv op of the tapes), re-timed live: `reps` back-to-back
+    launches of that tape op between two HIP events on its launch stream.  achieved = algorithmic FLOPs per launch /
+    average launch duration; peak = the roof of the pipe the op runs on.  `traffic` = PMC-measured HBM bytes per launch
+    when a committed PMC pass covers this kernel (profiles/*pmc_traffic.json), else null."""
+    import ctypes as C
+    import torch
+    from unet_zoo_amd import _ffi
+    _, which, k, flops, roof = heaviest
+    ops = plan.fwd_ops if which == "fwd" else plan.bwd_ops
+    arr, _n = plan.tapes[which]
+    one = (type(arr[0]) * 1)(arr[k])
+    stream = C.c_void_p(net._stream())
+    _ffi.check(L.uz_run_tape(one, 1, stream), "dominant op")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _ffi.check(L.uz_run_tape(one, 1, stream), "dominant op")
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    kind, cin, cout, n, h, w, ks = conv_dims(ops[k])
+    split = roof != PEAK_F32_MFMA_TFLOPS
+    kname = {0: "conv_split_kernel (+ pack_weights_kernel)" if split else "conv_mfma_kernel",
+             1: "conv_split_kernel, data gradient (+ pack_weights_kernel)" if split else "conv_mfma_kernel, data gradient",
+             2: "wgrad_split_kernel (+ wgrad_reduce)" if split else "wgrad_fast_kernel (+ wgrad_reduce)"}[kind]
+    alg_bytes = 4.0 * (n * h * w * (cin + cout) + cin * cout * ks * ks)
+    out = dict(kernel=kname, op={0: "forward", 1: "data gradient", 2: "weight gradient"}[kind],
+               layer=f"{ks}x{ks} {cin}->{cout} @ {n}x{h}x{w}", flops_per_launch=flops, avg_launch_ms=round(ms, 4),
+               achieved=round(flops / ms / 1e9, 2), peak=round(roof, 1), unit="TFLOP/s", frac=round(flops / ms / 1e9 / roof, 4),
+               algorithmic_bytes=alg_bytes, traffic=None,
+               peak_note=("dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product" if split else "fp32 MFMA peak"))
+    if split:
+        out["bf16_mfma_tflops"] = round(SPLIT_PRODUCTS * flops / ms / 1e9, 1)
+    for prof in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
+            if f"{cin} -> {cout}" not in pmc.get("layer", "") or f"N={n}" not in pmc.get("layer", ""):
+                continue
+            key = {0: "conv_split_kernel<2> (forward)", 1: "conv_split_kernel<2> (forward)", 2: "wgrad_split_kernel<32,64> (weight gradient, slabs)"}[kind] \
+                if split else {0: "conv_mfma_kernel<3,2,2,false> (forward)", 1: "conv_mfma_kernel<3,2,2,true> (data gradient)",
+                               2: "wgrad_fast_kernel<2,2,4,32> (weight gradient, slabs)"}[kind]
+            out.update(traffic=pmc["kernels"][key]["hbm_bytes"], traffic_source="profiles/" + prof)
+            break
+        except Exception:
+            pass
+    return out
 
 
 def conv_math():
     return os.environ.get("UZ_CONV_MATH", "default")
 
 
-def dominant_kernel_live(dev, reps=20):
-    """The single heaviest kernel of the step - the 3x3 forward convolution 224 -> 128 at 32 x 128 x 128 -
-    timed live with HIP events on the stream it is launched on.  Algorithmic FLOPs per launch =
-    2*N*H*W*Cin*Cout*9.  In the default mode this layer runs on conv_split_kernel<2> (three bf16 pieces
-    per fp32 operand, six piece products on the bf16 matrix pipe, fp32 accumulate): its roof is the
-    dense bf16 MFMA peak divided by the six products.  With UZ_CONV_MATH=f32 it runs on
-    conv_mfma_kernel<3,2,2,false> against the fp32 MFMA peak.  HBM bytes per launch come from the
-    committed PMC passes (profiles/r1_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE, calibrated)."""
-    import ctypes as C
-    from unet_zoo_amd import _ffi
-    L = _ffi.lib()
-    Cin, Cout, N, H, W = 224, 128, 32, 128, 128
-    x = torch.randn(N, Cin, H, W, device=dev)
-    w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
-    y = torch.empty(N, Cout, H, W, device=dev)
-    wsb = L.uz_conv_workspace(Cin, Cout, N, H, W, 3)
-    ws = torch.zeros(wsb // 4 + 64, device=dev)
-    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-
-    def launch():
-        _ffi.check(L.uz_conv_fwd(x.data_ptr(), Cin, Cin, w.data_ptr(), None, y.data_ptr(), Cout, Cout, N, H, W, 3, 0,
-                                 ws.data_ptr(), wsb, st), "conv_fwd")
-    launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        launch()
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    flops = 2.0 * N * H * W * Cin * Cout * 9
-    split = conv_math() != "f32"
-    peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS if split else PEAK_F32_MFMA_TFLOPS
-    out = dict(kernel="conv_split_kernel<2> (+ pack_weights_kernel)" if split else "conv_mfma_kernel<3,2,2,false>",
-               layer="3x3 224->128 @ 32x128x128", flops_per_launch=flops,
-               avg_launch_ms=round(ms, 4), achieved=round(flops / ms / 1e9, 2), peak=round(peak, 1), unit="TFLOP/s",
-               frac=round(flops / ms / 1e9 / peak, 4), traffic=None,
-               peak_note=("dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product" if split else "fp32 MFMA peak"))
-    if split:
-        out["bf16_mfma_tflops"] = round(SPLIT_PRODUCTS * flops / ms / 1e9, 1)
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-        k = pmc["kernels"]["conv_split_kernel<2> (forward)" if split else "conv_mfma_kernel<3,2,2,false> (forward)"]
-        out.update(traffic=k["hbm_bytes"], algorithmic_bytes=k["algorithmic_bytes"], traffic_source="profiles/r1_pmc_traffic.json")
-    except Exception:
-        pass
-    return out
-
-
 def fp32_only_leg(args):
-    """Same benchmark in a child process with UZ_CONV_MATH=f32 (every convolution on the fp32 MFMA kernels)."""
-    import subprocess
+    """Same benchmark in a child process with UZ_CONV_MATH=f32 (every convolution on the fp32 MFMA kernels).  Started
+    BEFORE this process touches the GPU."""
     env = dict(os.environ, UZ_CONV_MATH="f32")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--batch", str(args.batch), "--skip-cpu", "--no-profile", "--no-f32-leg"]
+           "--batch", str(args.batch), "--model", args.model, "--skip-cpu", "--no-profile", "--no-f32-leg"]
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         d = json.loads(r.stdout.strip().splitlines()[-1])
         return dict(value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"], frac=d["roofline"]["frac"],
-                    note="identical run with UZ_CONV_MATH=f32: all convolutions on v_mfma_f32_32x32x2_f32")
+                    note="identical run with UZ_CONV_MATH=f32: all convolutions on v_mfma_f32_32x32x2_f32; frac is against the 157.3 TFLOP/s fp32-MFMA peak")
     except Exception as e:                                   # never fail the headline line because of the extra leg
         return dict(error=str(e)[:200])
 
@@ -200,15 +250,20 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(batch, budget_s=25.0):
+def cpu_baseline(model, batch, budget_s=30.0):
     """CPU oracle timed on the host cores on a bounded sample (about `budget_s` seconds of CPU work).
     Only this leg of bench.py imports oracle/."""
+    import torch
     import oracle
     from unet_zoo_amd.models.phiseg import phiseg_spec
+    from unet_zoo_amd.models.unet import unet_spec
+    from unet_zoo_amd.models.probabilistic_unet import probunet_spec
     cores = usable_cores()
     threads = min(cores, 32)                  # oneDNN / OpenMP stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(threads)
-    sd = oracle.deterministic_state_dict(phiseg_spec(1, 2, FILTERS), seed=3)
+    spec = {"phiseg": lambda: phiseg_spec(1, 2, FILTERS7), "unet": lambda: unet_spec(1, 2, FILTERS4),
+            "probunet": lambda: probunet_spec(1, 2, FILTERS7, 6, 3)}[model]()
+    sd = oracle.deterministic_state_dict(spec, seed=3)
     leaves = {}
     for k, v in sd.items():
         t = v.clone()
@@ -219,11 +274,19 @@ def cpu_baseline(batch, budget_s=25.0):
     state, times = {}, []
     t_start = time.perf_counter()
     for step in range(4):
-        x, mask, eps = oracle.synthetic_batch(batch, 128, 128, seed=100 + step, eps_shapes=shapes + shapes)
-        e = [torch.from_numpy(a) for a in eps]
+        eshapes = {"phiseg": shapes + shapes, "unet": None, "probunet": [(batch, 6)]}[model]
+        x, mask, eps = oracle.synthetic_batch(batch, 128, 128, seed=100 + step, eps_shapes=eshapes)
+        xt, mt = torch.from_numpy(x), torch.from_numpy(mask)
         t0 = time.perf_counter()
-        out = oracle.phiseg_forward(leaves, torch.from_numpy(x), torch.from_numpy(mask), dict(posterior=e[:5], prior=e[5:]))
-        total, _ = oracle.phiseg_loss(out, torch.from_numpy(mask))
+        if model == "phiseg":
+            e = [torch.from_numpy(a) for a in eps]
+            out = oracle.phiseg_forward(leaves, xt, mt, dict(posterior=e[:5], prior=e[5:]))
+            total, _ = oracle.phiseg_loss(out, mt)
+        elif model == "unet":
+            total = oracle.unet_loss(oracle.unet_forward(leaves, xt), mt)
+        else:
+            out = oracle.probunet_forward(leaves, xt, mt, bn_train=True)
+            total, _ = oracle.probunet_loss(leaves, out, mt, torch.from_numpy(eps[0]), bn_train=True)
         for v in leaves.values():
             v.grad = None
         total.backward()
@@ -237,9 +300,20 @@ def cpu_baseline(batch, budget_s=25.0):
     timed = times[1:] if len(times) > 1 else times           # drop the warm-up step when there was time for more
     sec = sum(timed) / len(timed)
     return dict(value=round(batch / sec, 3), unit="images/s", cores=threads, kind="port",
-                sample=f"CPU oracle (functional torch fp32 restatement of the reference graph), PHiSeg 7/5 128x128 batch {batch}, "
+                sample=f"CPU oracle (functional torch fp32 restatement of the reference graph), {model} 128x128 batch {batch}, "
                        f"{len(timed)} timed step(s){' after 1 warm-up' if len(times) > 1 else ' (warm-up only: budget exhausted)'}, "
                        f"fwd+loss+bwd+Adam, {threads} threads of {cores} usable cores, {sec:.2f} s/step")
+
+
+def build(model):
+    from unet_zoo_amd.models.phiseg import PHISeg
+    from unet_zoo_amd.models.unet import Unet
+    from unet_zoo_amd.models.probabilistic_unet import ProbabilisticUnet
+    if model == "phiseg":
+        return PHISeg(input_channels=1, num_classes=2, num_filters=FILTERS7, latent_levels=5, image_size=(1, 128, 128))
+    if model == "unet":
+        return Unet(1, 2, FILTERS4)
+    return ProbabilisticUnet(1, 2, FILTERS7, latent_dim=6, no_convs_fcomb=3, image_size=(1, 128, 128))
 
 
 def main():
@@ -248,11 +322,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (weak scaling)")
+    ap.add_argument("--model", choices=sorted(MODELS), default="phiseg")
     ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-family HIP-event pass")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU-oracle leg (BASELINE.md section 3: 32)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32-MFMA-only measurement (child process)")
+    ap.add_argument("--no-overlap", action="store_true", help="data parallel: one blocking all-reduce after backward instead of bucketed overlap")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -260,6 +336,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    M = MODELS[args.model]
+
+    # the fp32-MFMA-only comparison leg runs in a child process BEFORE this process initialises the GPU
+    f32_leg = None
+    if world == 1 and not args.no_f32_leg and conv_math() != "f32":
+        f32_leg = fp32_only_leg(args)
+
+    import torch
     # Test hooks (not used by the driver): UZ_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and UZ_BENCH_BACKEND=gloo
     # replaces RCCL, so that the multi-rank code path can be exercised on a one-GPU box.
     if os.environ.get("UZ_BENCH_SINGLE_DEVICE") == "1":
@@ -275,16 +359,17 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from unet_zoo_amd.models.phiseg import PHISeg
+    from unet_zoo_amd import _ffi
     from unet_zoo_amd.synthetic import synthetic_batch
     from unet_zoo_amd.optim import FusedAdam
+    L = _ffi.lib()
 
     torch.manual_seed(1234)          # same initial weights on every rank (DP replicas)
-    net = PHISeg(input_channels=1, num_classes=2, num_filters=FILTERS, latent_levels=5, image_size=(1, 128, 128))
+    net = build(args.model)
     net.train()
     if world > 1:
         dist.broadcast(net._ptab.pflat, src=0)
-        net.set_data_parallel(True)
+        net.set_data_parallel(True, overlap=not args.no_overlap)
     if not args.no_graphs:
         net.enable_graphs(True)
     opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)        # train_model.py:49
@@ -293,7 +378,10 @@ def main():
     x, mask = torch.from_numpy(x).to(dev), torch.from_numpy(mask).to(dev)
 
     def step():
-        net.forward(x, mask, training=True)
+        if args.model == "unet":
+            net.forward(x)
+        else:
+            net.forward(x, mask, training=True)
         loss = net.loss(mask)
         opt.zero_grad()
         loss.backward()
@@ -320,23 +408,51 @@ def main():
         elapsed = float(t)
     final_loss = float(loss.detach())
 
+    extra = {}
+    if args.model == "probunet" and rank == 0:
+        # "8 posterior samples" (BASELINE configs[2]): after one forward, 8 x [z = posterior.rsample(); fcomb(features, z)]
+        # = reconstruct(calculate_posterior=True) (probabilistic_unet.py:272-283), timed separately from the train step
+        net.eval()
+        with torch.no_grad():
+            net.forward(x, mask, training=False)
+            for _ in range(3):
+                net.reconstruct(calculate_posterior=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 10
+            for _ in range(reps):
+                for _ in range(8):
+                    net.reconstruct(calculate_posterior=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / reps
+        extra["decode_8_posterior_samples"] = dict(ms=round(1e3 * dt, 3), decoded_images_per_s=round(8 * args.batch / dt, 1),
+                                                   note="8 x reconstruct(calculate_posterior=True) on the cached U-Net features, eval mode, batch %d" % args.batch)
+        net.train()
+
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         ips = args.batch * world * args.steps / elapsed
         per_gpu = ips / world
-        roof = dict(bound="mfma", achieved=round(per_gpu * GFLOP_PER_IMAGE / 1e3, 3), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(per_gpu * GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
-                    hbm_fraction=round((per_gpu * GB_PER_IMAGE_UNFUSED + (per_gpu / args.batch) * GB_PER_STEP_FIXED) / HBM_PEAK_GBS, 4),
-                    note="step-level, per GPU: images/s x 100.36 GFLOP/image over the 157.3 TFLOP/s fp32-MFMA peak (BASELINE.md section 2); "
+        achieved = per_gpu * M["gflop"] / 1e3
+        plan = net._cur
+        eff_peak, share = binding_roof(plan, L)
+        roof = dict(bound="mfma", achieved=round(achieved, 3), peak=round(eff_peak, 1), unit="TFLOP/s",
+                    frac=round(achieved / eff_peak, 4), traffic=None,
+                    frac_vs_fp32_mfma=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), flop_share_by_pipe=share,
+                    hbm_fraction=round((per_gpu * M["gb_img"] + (per_gpu / args.batch) * M["gb_step"]) / HBM_PEAK_GBS, 4),
+                    note=f"step-level, per GPU: achieved = images/s x {M['gflop']} GFLOP/image (fp32-equivalent); peak = binding roof of the "
+                         "conv ops as routed: 157.3 TFLOP/s (fp32 MFMA) or 2500/6 = 416.7 TFLOP/s (split-bf16, 6 bf16 products per fp32 "
+                         "product), weighted by FLOPs (harmonic); frac_vs_fp32_mfma = achieved / 157.3 as BASELINE.md section 2 defines it; "
                          "hbm_fraction uses the unfused-graph bytes and cannot exceed ~0.21 in fp32")
         if not args.no_profile and world == 1:
-            fam = profile_families(net, net._cur)
+            fam, heaviest = profile_families(net, plan, L)
             fams = {}
             for k, d in fam.items():
                 e = dict(ms_per_step=round(d["ms"], 3), launches=d["launches"])
                 if d["flops"]:
                     e["tflops"] = round(d["flops"] / d["ms"] / 1e9, 2)
-                    e["frac_of_mfma_peak"] = round(d["flops"] / d["ms"] / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)
+                    e["binding_roof_tflops"] = round(d["flops"] / d["t_roof"], 1)
+                    e["frac_of_binding_roof"] = round(d["t_roof"] * 1e3 / d["ms"], 4)
                 elif d["bytes"]:
                     e["gbs"] = round(d["bytes"] / d["ms"] / 1e6, 1)
                     e["frac_of_hbm_peak"] = round(d["bytes"] / d["ms"] / 1e6 / HBM_PEAK_GBS, 4)
@@ -344,23 +460,28 @@ def main():
             dom = max((k for k in fam if fam[k]["flops"]), key=lambda k: fam[k]["ms"])
             roof["families"] = fams
             roof["dominant_family"] = dict(name=dom, **fams[dom])
-            roof["dominant_kernel"] = dominant_kernel_live(dev)
+            roof["dominant_kernel"] = dominant_kernel_live(net, plan, L, heaviest)
             roof["traffic"] = roof["dominant_kernel"]["traffic"]
-        line = dict(metric="images/sec fwd+bwd PHiSeg-7 128x128 bs32", value=round(ips, 2), unit="images/s", n_gpus=world,
+        math_note = ("fp32 MFMA only (UZ_CONV_MATH=f32)" if conv_math() == "f32" else
+                     "fp32 in / fp32 out, fp32 accumulate everywhere; 3x3 layers the library routes to the split path (forward, data gradient AND "
+                     "weight gradient; share in roofline.flop_share_by_pipe): operands split exactly into 3 bf16 pieces, 6 piece products on the "
+                     "bf16 matrix pipe (error vs fp64 within 2x of the fp32-MFMA kernels, tests/test_full_configs_gpu.py); other layers: fp32 MFMA")
+        line = dict(metric=M["metric"], value=round(ips, 2), unit="images/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype="f32", data="synthetic",
-                    config=dict(workload="PHiSeg 7 resolution / 5 latent levels, filters 32-64-128-192x4, 1x128x128, fwd+loss+bwd+Adam",
-                                batch_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f"dp{world}",
-                                graphs=not args.no_graphs, final_loss=final_loss,
-                                conv_math=("fp32 MFMA only (UZ_CONV_MATH=f32)" if conv_math() == "f32" else
-                                           "fp32 in / fp32 out; large 3x3 layers (fwd, dgrad): operands split exactly into 3 bf16 pieces, "
-                                           "6 piece products on the bf16 matrix pipe, fp32 accumulate (error vs fp64 1.7x the fp32-MFMA "
-                                           "kernel's, logits 2.6e-5 from the reference); other layers and all weight gradients: fp32 MFMA")),
+                    config=dict(workload=M["workload"], batch_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f"dp{world}",
+                                graphs=not args.no_graphs, final_loss=final_loss, conv_math=math_note),
                     roofline=roof)
-        if world == 1 and not args.no_f32_leg and conv_math() != "f32":
-            line["fp32_mfma_only"] = fp32_only_leg(args)
+        if world > 1:
+            line["config"]["allreduce"] = "bucketed, overlapped with backward" if not args.no_overlap else "one blocking all-reduce after backward"
+            st = getattr(net, "_dp_stats", None)
+            if st:
+                line["dp"] = st
+        line.update(extra)
+        if f32_leg is not None:
+            line["fp32_mfma_only"] = f32_leg
         if not args.skip_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+            line["cpu_baseline"] = cpu_baseline(args.model, args.cpu_batch)
         print(json.dumps(line))
     if dist:
         dist.destroy_process_group()

@@ -56,6 +56,13 @@ int         uz_device_info(int* n_cu, char* name, int name_cap);
  * workspace of uz_conv_workspace() bytes the input-channel loop is split over workgroups and summed
  * in a fixed order (bitwise reproducible); workspace may be NULL (no split, slower, same result up
  * to summation order).                                                                          */
+/* run-time override of UZ_CONV_MATH for tests / diagnostics: -1 = environment, 0 = f32, 1 = default policy, 2 = split on
+ * every eligible shape.  Workspace sizes depend on the mode: query them after switching.  Not thread safe.            */
+int uz_set_conv_math(int mode);
+int uz_get_conv_math(void);
+/* kernel family a call takes under the current mode: kind 0 fwd / 1 bwd_data / 2 bwd_weight -> 0 fp32 MFMA, 1 split-bf16 MFMA,
+ * 2 streaming VALU (1x1 heads with <= 8 outputs).  Used by bench.py to price each op against the roof it runs on.          */
+int uz_conv_route(int kind, int Cin, int Cout, int N, int H, int W, int ks);
 size_t uz_conv_workspace(int Cin, int Cout, int N, int H, int W, int ks);   /* covers fwd and bwd_data */
 int uz_conv_fwd(const float* x, int Cin, int CinTot,
                 const float* w, const float* bias,

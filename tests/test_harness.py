@@ -67,3 +67,48 @@ def test_train_step_contract_runs(which, tmp_path):
         m = h.validate(data)
         assert 0.0 <= m["dice"] <= 1.0 and -1.0 <= m["ncc"] <= 1.0 and m["ged"] >= -1e-9
         assert os.path.exists(os.path.join(str(tmp_path), "t", "t", "t_best_ged.pth"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["phiseg", "probunet"])
+def test_validate_and_test_loops_match_oracle_metrics(which, tmp_path):
+    """UNetModel.validate / .test (train_model.py:138-275,333-475): the per-image evaluation returns the samples it
+    drew; the CPU oracle's GED / NCC / Dice (oracle/metrics.py, pinned to the reference's own utils functions) on those
+    SAME samples must reproduce the device metrics, and validate()'s means must be the means of the per-image values."""
+    import numpy as np
+    from oracle import metrics as OM
+    from unet_zoo_amd.models import PHISeg, ProbabilisticUnet
+    model, filters = {"phiseg": (PHISeg, [8, 16, 16, 16, 16, 16, 16]), "probunet": (ProbabilisticUnet, [32, 8, 8, 8, 8, 8, 8])}[which]
+    cfg = _small_cfg(model, filters)
+    cfg.validation_samples, cfg.num_validation_images = 6, 3
+    h = TM.UNetModel(cfg, log_root=str(tmp_path))
+    data = TM.SyntheticData(None, cfg, n_train=16, n_val=3)
+    h.train(data, iterations=3)
+    h.net.eval()
+    rng = np.random.default_rng(h.iteration)
+    per_image = []
+    for ii in range(3):
+        r = h._evaluate_image(data.validation.images[ii], data.validation.labels[ii], 6, rng, keep=True)
+        pred, gts, soft = r["pred"].cpu().numpy(), r["gts"].cpu().numpy().astype(np.int64), r["soft"].cpu().numpy()
+        ged = OM.generalised_energy_distance(pred, gts, nlabels=1, label_range=range(1, 2))
+        assert abs(ged - r["ged"]) <= 1e-12, (ged, r["ged"])                     # integer pair counts: exact
+        ncc = float(np.asarray(OM.variance_ncc_dist(soft, r["onehot"].cpu().numpy())).reshape(-1)[0])
+        assert abs(ncc - r["ncc"]) <= 2e-5, (ncc, r["ncc"])
+        s_mean = np.argmax(soft.mean(axis=0), axis=0)
+        dice = OM.per_label_dice(s_mean, r["mask"].cpu().numpy().astype(np.int64), 2)
+        assert np.allclose(dice, r["dice"], atol=1e-12)
+        assert np.array_equal(pred, np.argmax(soft, axis=1))
+        per_image.append(r)
+    h.net.train()
+    # validate() with the same iteration counter draws the same annotators; eps differs (device RNG), so compare structure:
+    m = h.validate(data)
+    assert set(m) == {"dice", "foreground_dice", "elbo", "ged", "ncc"} and 0.0 <= m["dice"] <= 1.0
+    for name in ("validation_ckpt", "best_dice", "best_loss", "best_ged", "best_ncc"):
+        assert os.path.exists(os.path.join(str(tmp_path), "t", "t", f"t_{name}.pth")), name
+    # test(): loads <experiment>_best_loss.pth, dumps ged/ncc arrays next to it (train_model.py:446-447)
+    out = h.test(data, rounds=2, n_samples=4)
+    assert set(out) == {"dice", "ged", "ncc"} and out["ged"] >= -1e-9
+    ged_file = os.path.join(str(tmp_path), "t", "t", "ged4_t_best_loss.pth_2.npz")
+    assert os.path.exists(ged_file) and np.load(ged_file)["arr_0"].shape == (2 * data.test.images.shape[0],)
+    os.remove(os.path.join(str(tmp_path), "t", "t", "t_best_loss.pth"))
+    assert h.test(data, rounds=1) is None                                         # missing checkpoint: abort like the reference (:349-352)

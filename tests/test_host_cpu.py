@@ -132,3 +132,55 @@ def test_lane_schedule_preserves_every_dependency(lanes, monkeypatch):
     for plan in (pu._build(2, 64, 64, True, True), pu._build(2, 64, 64, False, False)):
         for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops), *plan.extra_ops.items()):
             _check_lane_schedule(plan, which, ops)
+
+
+# ----------------------------------------------------------------------------- U2: the three initialisers
+def _moments(t):
+    a = t.detach().double()
+    return dict(n=a.numel(), mean=float(a.mean()), std=float(a.std(unbiased=False)), absmax=float(a.abs().max()))
+
+
+@pytest.mark.parametrize("which", ["unet", "phiseg", "probunet"])
+def test_initialisers_match_reference_moments(which):
+    """utils.init_weights (kaiming-normal fan-in + truncated-normal bias, utils.py:69-83),
+    init_weights_orthogonal_normal (utils.py:86-90, Fcomb), kaiming-normal + N(0,1) bias of
+    AxisAlignedConvGaussian.conv_layer (probabilistic_unet.py:99-100) and torch's default Conv2d / BatchNorm2d init
+    that PHiSeg keeps (phiseg.py:36 commented out).  Initial weights are random, so parity is distributional: every
+    tensor's moments must agree with those of the REAL reference's freshly constructed model (tests/golden/
+    init_moments.json, tools/gen_golden.py `init`) within sampling error, constants must be exact, Fcomb weights
+    orthogonal, and truncated biases inside +-2 std."""
+    import math
+    from unet_zoo_amd.models import PHISeg, ProbabilisticUnet, Unet
+    with open(os.path.join(G.GOLDEN, "init_moments.json")) as f:
+        ref = json.load(f)[which]
+    torch.manual_seed(123)
+    nf7 = [32, 64, 128, 192, 192, 192, 192]
+    net = {"unet": lambda: Unet(1, 2, [32, 64, 128, 192], device="cpu"),
+           "phiseg": lambda: PHISeg(1, 2, nf7, latent_levels=5, image_size=(1, 128, 128), device="cpu"),
+           "probunet": lambda: ProbabilisticUnet(1, 2, nf7, latent_dim=6, no_convs_fcomb=3, image_size=(1, 128, 128), device="cpu")}[which]()
+    sd = {k: v for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        r, m = ref[k], _moments(v)
+        assert m["n"] == r["n"], k
+        if r["std"] == 0.0:                                   # BN affine / running statistics: exact constants
+            assert m["std"] == 0.0 and m["mean"] == r["mean"], k
+            continue
+        n = r["n"]
+        if n >= 256:
+            # std of a sample of n iid values has relative sampling error ~ 1/sqrt(2n) (x ~1.3 for the uniform / truncated shapes)
+            assert abs(m["std"] / r["std"] - 1.0) <= 6.0 / math.sqrt(2 * n) + 1e-3, (k, m, r)
+            assert abs(m["mean"] - r["mean"]) <= 6.0 * r["std"] * math.sqrt(2.0 / n), (k, m, r)
+        else:                                                 # tiny tensors (biases of 2..192 entries): same scale
+            assert 0.3 <= m["std"] / r["std"] <= 3.0 if n >= 12 else m["absmax"] <= 10 * max(r["absmax"], r["std"]), (k, m, r)
+        # bounded distributions keep their bound: uniform(+-b) and the truncated normal (+-2 std = 2e-3)
+        if k.endswith(".bias") and r["absmax"] <= 2e-3 and "conv_layer" not in k and "last_conv" not in k and which != "phiseg":
+            assert m["absmax"] <= 2e-3 + 1e-9, (k, m)
+        if which == "phiseg" and v.dim() in (1, 4) and "convolution.1" not in k:
+            fan_in = v.shape[1] * v.shape[2] * v.shape[3] if v.dim() == 4 else None
+            if fan_in:
+                assert m["absmax"] <= 1.0 / math.sqrt(fan_in) + 1e-9, (k, m)      # kaiming_uniform(a=sqrt(5)) bound
+        if "orth_err" in r:
+            w = v.detach().double().reshape(v.shape[0], -1)
+            gm = w @ w.t() if w.shape[0] <= w.shape[1] else w.t() @ w
+            assert float((gm - torch.eye(gm.shape[0], dtype=torch.float64)).abs().max()) <= 1e-5, k

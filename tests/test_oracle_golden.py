@@ -201,3 +201,68 @@ def test_probunet_small():
         if v.requires_grad and v.grad is not None and k not in noise:
             ref = arrays["grad:" + k]
             assert G.maxabs(v.grad.numpy(), ref) <= 2e-3 * (1e-3 + float(np.abs(ref).max())), k
+
+
+# ----------------------------------------------------------------------------- BASELINE configs 2 and 3 at full size (digests)
+def _check_grad_digest(sd, st, rel=2e-3):
+    noise = G.bn_shadowed_biases(sd.keys())
+    for k, n in st["grad_norms"].items():
+        if k in noise:
+            continue
+        mine = float(sd[k].grad.double().norm())
+        assert abs(mine - n) <= rel * max(n, 1e-3), (k, mine, n)
+
+
+def test_unet_full_b32_digest():
+    """BASELINE config 2: Unet(1,2,[32,64,128,192]), batch 32 (unet.py:78-165)."""
+    arrays, meta = G.load("unet_full_b32_digest")
+    sd = G.leaves(oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"]))
+    x, mask, _ = oracle.synthetic_batch(meta["batch"], 128, 128, seed=20201004)
+    pred = oracle.unet_forward(sd, _t(x))
+    loss = oracle.unet_loss(pred, _t(mask))
+    loss.backward()
+    st = meta["steps"][0]
+    assert abs(float(loss) - st["loss"]) <= 1e-5 * abs(st["loss"])
+    p = pred.detach().numpy()
+    assert G.maxabs(p.reshape(-1)[arrays["s_idx"]], arrays["pred_samp"]) <= 1e-5
+    _check_grad_digest(sd, st)
+    conf = np.unpackbits(arrays["argmax_conf_bits"]).astype(bool)
+    got = np.argmax(p, axis=1).astype(np.uint8).reshape(-1)
+    ref = np.unpackbits(arrays["argmax_bits"])
+    assert np.array_equal(got[conf], ref[conf]) and int((~conf).sum()) == meta["n_near_ties"]
+
+
+def test_probunet_full_b32_digest():
+    """BASELINE config 3: ProbabilisticUnet(1,2,[32,64,128,192,192,192,192], latent_dim=6, no_convs_fcomb=3), batch 32,
+    plus the 8 posterior-sample decodes (probabilistic_unet.py:246-283,343-370)."""
+    arrays, meta = G.load("probunet_full_b32_digest")
+    B, L, nd = meta["batch"], meta["latent_dim"], meta["n_decode"]
+    sd0 = oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"])
+    sd = G.leaves(sd0)
+    x, mask, eps = oracle.synthetic_batch(B, 128, 128, seed=20201004, eps_shapes=[(B, L)] * (1 + nd))
+    out = oracle.probunet_forward(sd, _t(x), _t(mask), bn_train=True)
+    loss, aux = oracle.probunet_loss(sd, out, _t(mask), _t(eps[0]), bn_train=True)
+    loss.backward()
+    st = meta["steps"][0]
+    assert abs(float(loss) - st["loss"]) <= 1e-5 * abs(st["loss"])
+    assert abs(float(aux["kl"]) - st["kl"]) <= 1e-4 * max(1.0, abs(st["kl"]))
+    idx, fidx = arrays["s_idx"], arrays["f_idx"]
+    assert G.maxabs(out["last_conv"].detach().numpy().reshape(-1)[idx], arrays["last_conv_samp"]) <= 1e-4
+    assert G.maxabs(out["unet_features"].detach().numpy().reshape(-1)[fidx], arrays["features_samp"]) <= 1e-4
+    assert G.maxabs(aux["reconstruction"].detach().numpy().reshape(-1)[idx], arrays["reconstruction_samp"]) <= 1e-4
+    assert G.maxabs(out["posterior_mu"].detach().numpy(), arrays["post_mu"]) <= 1e-5
+    assert G.maxabs(out["prior_sigma"].detach().numpy(), arrays["prior_sigma"]) <= 1e-5
+    none = sorted(k for k, v in sd.items() if v.requires_grad and v.grad is None)
+    assert none == sorted(st["none_grads"])
+    _check_grad_digest(sd, st)
+    # eval-mode decodes: z = mu_q + sigma_q * eps_j, Fcomb on the cached features
+    with torch.no_grad():
+        ev = {k: v.clone() for k, v in sd0.items()}
+        o = oracle.probunet_forward(ev, _t(x), _t(mask), bn_train=False)
+        assert G.maxabs(o["posterior_mu"].numpy(), arrays["eval_post_mu"]) <= 1e-5
+        for j in range(nd):
+            z = o["posterior_mu"] + o["posterior_sigma"] * _t(eps[1 + j])
+            rec = oracle.probunet_fcomb(ev, o["unet_features"], z, bn_train=False).numpy()
+            assert G.maxabs(rec.reshape(-1)[idx], arrays[f"dec{j}_samp"]) <= 1e-4
+            assert meta["decode_margin_min"][j] > 1e-3
+            assert np.array_equal(np.packbits(np.argmax(rec, axis=1).astype(np.uint8).reshape(-1)), arrays[f"dec{j}_argmax_bits"])

@@ -67,6 +67,7 @@ def test_phiseg_train_steps_vs_reference_golden(fixture):
     net.train()
     opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
     noise = G.bn_shadowed_biases(dict(net.named_parameters()).keys())
+    theta0 = {k: v.detach().cpu().numpy().copy() for k, v in net.named_parameters()}
     for step, st in enumerate(meta["steps"]):
         x, mask, eps = _inputs(meta, step)
         s = net.forward(x, mask, training=True, eps=eps)
@@ -98,13 +99,28 @@ def test_phiseg_train_steps_vs_reference_golden(fixture):
             for k, v in net.state_dict().items():
                 if "running_" in k:
                     assert G.maxabs(v.cpu().numpy(), arrays["buf1:" + k]) <= 1e-5, k
+            g_hip = {k: p.grad.cpu().numpy().copy() for k, p in net.named_parameters() if p.grad is not None}
         opt.step()
+        if step == 0:
+            # post-step parameters (row H): the first Adam update must equal the reference's on every entry whose
+            # gradient sign is determined (see _golden.check_first_adam_step) - a wrong-sign / wrong-scale optimiser fails
+            theta1 = {k: v.detach().cpu().numpy() for k, v in net.named_parameters()}
+            g_ref = {k: arrays["grad:" + k] for k in g_hip}
+            cover = G.check_first_adam_step(theta0, theta1, g_hip, g_ref, skip=noise)
+            assert cover >= 0.5
+            for k in st["none_grads"]:                       # skipped, not zero-stepped (no weight decay either)
+                assert np.array_equal(theta1[k], theta0[k]), k
     sd = net.state_dict()
     for k, v in sd.items():
         if v.dtype.is_floating_point and k not in noise:
             # Adam turns every gradient into a step of magnitude ~lr whatever its size: an entry whose
-            # near-zero gradient has the opposite sign in the two implementations drifts by 2*lr per step
-            assert G.maxabs(v.cpu().numpy(), arrays["final:" + k]) <= 6.5e-3, k
+            # near-zero gradient has the opposite sign in the two implementations drifts by 2*lr per step, so after
+            # 3 steps only a statistical statement is possible: the bulk of the entries agrees closely (a systematic
+            # optimiser error would move EVERY entry by ~3*lr); the sharp per-entry gate is the step-1 check above
+            d = np.abs(v.cpu().numpy().astype(np.float64) - arrays["final:" + k]).reshape(-1)
+            assert d.max() <= 6.5e-3, k
+            if d.size >= 64:
+                assert np.median(d) <= 5e-4, (k, float(np.median(d)))
     nbt = [int(v) for k, v in sd.items() if k.endswith("num_batches_tracked") and "upsampling_path.4" not in k]
     assert set(nbt) == {len(meta["steps"])}
     assert all(int(v) == 0 for k, v in sd.items() if k.endswith("num_batches_tracked") and "upsampling_path.4" in k)
@@ -153,10 +169,14 @@ def test_phiseg_full_size_digest_vs_reference_golden(fixture):
         if k in noise:
             continue
         mine = float(params[k].grad.double().norm())
-        assert abs(mine - n) <= 1e-2 * max(n, 1e-3), (k, mine, n)
+        # calibrated on test_phiseg_accuracy_vs_fp64_ground_truth[phiseg_full_digest]: the reference's own fp32 CPU
+        # gradients deviate from fp64 by up to ~1e-2 of a tensor's scale in the KL path (difference of near-equal terms),
+        # ~1e-4 elsewhere; two fp32 implementations can differ by the sum of their errors
+        tol = 1e-2 if ("sample_z_path" in k or "mu_conv" in k or "sigma_conv" in k) else 4e-3
+        assert abs(mine - n) <= tol * max(n, 1e-3), (k, mine, n)
         pick, vals = st["grad_samples"][k]
         got = params[k].grad.reshape(-1)[torch.tensor(pick)].cpu().numpy()
-        assert np.max(np.abs(got - np.array(vals))) <= 1e-2 * max(n, 1e-3), k
+        assert np.max(np.abs(got - np.array(vals))) <= tol * max(n, 1e-3), k
     # eval pass: packed argmax bits must be identical
     net.load_state_dict(oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"]))
     net.eval()
@@ -202,12 +222,16 @@ def test_phiseg_vs_live_oracle_other_seed():
             assert G.maxabs(p.grad.cpu().numpy(), ref.numpy()) <= 5e-3 * (1e-3 + float(ref.abs().max())), k
 
 
-def test_phiseg_accuracy_vs_fp64_ground_truth():
+@pytest.mark.parametrize("fixture", ["phiseg_mid", "phiseg_full_digest"])
+def test_phiseg_accuracy_vs_fp64_ground_truth(fixture):
     """Both the HIP path and the reference's fp32 CPU arithmetic are approximations of the same real-valued
     graph.  Against an fp64 evaluation of the oracle, the HIP path must be as accurate as the fp32 CPU
     path itself (logits and every parameter gradient) - i.e. the remaining HIP-vs-reference differences
-    are fp32 rounding, not algorithmic."""
-    arrays, meta = G.load("phiseg_mid")
+    are fp32 rounding, not algorithmic.  `phiseg_full_digest` is the BASELINE architecture (filters 32..192, 128x128,
+    batch 2): there the default mode routes the large layers to the split-bf16 kernels, so this is also their
+    end-to-end accuracy gate.  Per-tensor bound: 3x the fp32 CPU path's own error plus a floor of 2e-5 of the tensor's
+    gradient scale (tensors the CPU happens to get almost exactly right would otherwise set an unreachable bar)."""
+    arrays, meta = G.load(fixture)
     net, sd0 = _model(meta)
     net.train()
     x, mask, eps = _inputs(meta, 0)
@@ -231,16 +255,22 @@ def test_phiseg_accuracy_vs_fp64_ground_truth():
         assert e_hip <= 2.0 * e_cpu + 2e-5, (l, e_hip, e_cpu)
         assert e_hip <= 2e-4
     noise = G.bn_shadowed_biases(g64.keys())
-    rh, rc = [], []
+    rh, rc, keys = [], [], []
     for k, p in net.named_parameters():
         if k in noise or k not in g64:
             continue
         sc = float(g64[k].abs().max()) + 1e-12
         rh.append(float((p.grad.cpu().double() - g64[k]).abs().max()) / sc)
         rc.append(float((g32[k].double() - g64[k]).abs().max()) / sc)
+        keys.append(k)
     rh, rc = np.array(rh), np.array(rc)
+    worst = int(np.argmax(rh / (3.0 * rc + 2e-5)))
+    print(f"{fixture}: grad err vs fp64 rel. to tensor max  HIP median {np.median(rh):.2e} max {rh.max():.2e} | fp32 CPU median "
+          f"{np.median(rc):.2e} max {rc.max():.2e} | worst per-tensor ratio {rh[worst] / (3.0 * rc[worst] + 2e-5):.2f} at {keys[worst]}")
     assert np.median(rh) <= 2.0 * np.median(rc) + 1e-6, (np.median(rh), np.median(rc))
     assert rh.max() <= 3.0 * rc.max() + 1e-4, (rh.max(), rc.max())
+    bad = [(keys[i], rh[i], rc[i]) for i in range(len(keys)) if rh[i] > 3.0 * rc[i] + 2e-5]
+    assert len(bad) <= max(2, len(keys) // 100), bad[:10]          # per tensor, allowing 1 % stragglers of the 394 tensors
 
 
 @pytest.mark.parametrize("lanes", ["1", "4"])

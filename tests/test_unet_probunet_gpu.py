@@ -21,6 +21,7 @@ def test_unet_small_vs_reference_golden():
     assert list(net.state_dict().keys()) == [k for k, _, _ in G.spec_of(meta)]
     net.train()
     opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
+    theta0 = {k: v.detach().cpu().numpy().copy() for k, v in net.named_parameters()}
     for step, st in enumerate(meta["steps"]):
         x, mask, _ = oracle.synthetic_batch(meta["batch"], 128, 128, seed=20201004 + step)
         xd, md = torch.from_numpy(x).to(DEV()), torch.from_numpy(mask).to(DEV())
@@ -34,9 +35,16 @@ def test_unet_small_vs_reference_golden():
             for k, p in net.named_parameters():
                 ref = arrays["grad:" + k]
                 assert G.maxabs(p.grad.cpu().numpy(), ref) <= 2e-3 * (1e-4 + float(np.abs(ref).max())), k
+            g_hip = {k: p.grad.cpu().numpy().copy() for k, p in net.named_parameters()}
         opt.step()
+        if step == 0:
+            theta1 = {k: v.detach().cpu().numpy() for k, v in net.named_parameters()}
+            G.check_first_adam_step(theta0, theta1, g_hip, {k: arrays["grad:" + k] for k in g_hip})
     for k, v in net.state_dict().items():
-        assert G.maxabs(v.cpu().numpy(), arrays["final:" + k]) <= 6.5e-3, k
+        d = np.abs(v.cpu().numpy().astype(np.float64) - arrays["final:" + k]).reshape(-1)
+        assert d.max() <= 6.5e-3, k
+        if d.size >= 64:
+            assert np.median(d) <= 5e-4, (k, float(np.median(d)))
 
 
 def test_probunet_small_vs_reference_golden():
@@ -49,6 +57,7 @@ def test_probunet_small_vs_reference_golden():
     net.train()
     opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
     noise = G.bn_shadowed_biases(dict(net.named_parameters()).keys())
+    theta0 = {k: v.detach().cpu().numpy().copy() for k, v in net.named_parameters()}
     for step, st in enumerate(meta["steps"]):
         x, mask, eps = oracle.synthetic_batch(meta["batch"], 128, 128, seed=20201004 + step,
                                               eps_shapes=[(meta["batch"], meta["latent_dim"])])
@@ -78,7 +87,13 @@ def test_probunet_small_vs_reference_golden():
                     if e > worst:
                         worst, wk = e, k
             assert worst <= 2e-2, (worst, wk)
+            g_hip = {k: p.grad.cpu().numpy().copy() for k, p in net.named_parameters() if p.grad is not None}
         opt.step()
+        if step == 0:
+            theta1 = {k: v.detach().cpu().numpy() for k, v in net.named_parameters()}
+            G.check_first_adam_step(theta0, theta1, g_hip, {k: arrays["grad:" + k] for k in g_hip}, skip=noise)
+            for k in st["none_grads"]:
+                assert np.array_equal(theta1[k], theta0[k]), k
     for k, v in net.state_dict().items():
         if v.dtype.is_floating_point and k not in noise:
             assert G.maxabs(v.cpu().numpy(), arrays["final:" + k]) <= 6.5e-3, k

@@ -287,6 +287,132 @@ def probunet_case(name, filters, latent_dim, batch, n_steps, seed):
     save(name, arrays, meta)
 
 
+
+def _grad_digest(g, rs):
+    """Per-tensor gradient L2 norms + 8 sampled entries each (digest form for the full-size cases)."""
+    gn, gs = {}, {}
+    for k, v in g.items():
+        if v is not None:
+            gn[k] = float(np.sqrt((v.astype(np.float64) ** 2).sum()))
+            flat = v.reshape(-1)
+            pick = rs.integers(0, flat.size, size=min(8, flat.size))
+            gs[k] = [pick.tolist(), flat[pick].astype(float).tolist()]
+    return gn, gs
+
+
+def unet_digest_case(name, filters, batch, seed):
+    """BASELINE config 2 (Unet(1,2,[32,64,128,192]), batch 32) in digest form: sampled logits, loss, per-tensor
+    gradient norms + sampled entries, packed argmax bits and the minimum logit margin (unet.py:78-165)."""
+    hw = 128
+    net = Unet(1, 2, filters)
+    spec = kinds_for(net.state_dict())
+    net.load_state_dict(deterministic_state_dict(spec, seed=seed))
+    net.train()
+    rs = np.random.Generator(np.random.PCG64(7))
+    x, mask, _ = synthetic_batch(batch, hw, hw, seed=20201004)
+    pred = net.forward(torch.from_numpy(x))
+    loss = net.loss(torch.from_numpy(mask))
+    loss.backward()
+    g = grads_of(net)
+    idx = rs.integers(0, batch * 2 * hw * hw, size=1024)
+    p = npf(pred)
+    # near-ties are unavoidable over 524 288 pixels of a randomly initialised net: the bit-exact argmax gate applies to
+    # the pixels whose logit margin exceeds 2x the 1e-4 logit tolerance; the rest are counted and reported
+    conf = np.abs(p[:, 1] - p[:, 0]) > 2e-4
+    arrays = dict(s_idx=idx, pred_samp=p.reshape(-1)[idx],
+                  argmax_bits=np.packbits(np.argmax(p, axis=1).astype(np.uint8).reshape(-1)),
+                  argmax_conf_bits=np.packbits(conf.astype(np.uint8).reshape(-1)))
+    gn, gs = _grad_digest(g, rs)
+    meta = dict(model="Unet", filters=filters, hw=hw, batch=batch, weight_seed=seed,
+                spec=[[k, list(s), kd] for k, s, kd in spec],
+                steps=[dict(loss=float(loss), grad_norms=gn, grad_samples=gs,
+                            none_grads=[k for k, v in g.items() if v is None])],
+                margin_min=float(np.abs(p[:, 1] - p[:, 0]).min()), n_near_ties=int((~conf).sum()))
+    save(name, arrays, meta)
+
+
+def probunet_digest_case(name, filters, latent_dim, batch, seed, n_decode=8):
+    """BASELINE config 3 (ProbabilisticUnet(1,2,[32,64,128,192,192,192,192], latent_dim=6, no_convs_fcomb=3), batch 32)
+    in digest form, plus `n_decode` posterior-sample decodes `reconstruct(calculate_posterior=True)`
+    (probabilistic_unet.py:272-283) in eval mode with recorded eps."""
+    hw = 128
+    net = ProbabilisticUnet(input_channels=1, num_classes=2, num_filters=filters, latent_dim=latent_dim,
+                            no_convs_fcomb=3, image_size=(1, hw, hw))
+    spec = kinds_for(net.state_dict())
+    sd0 = deterministic_state_dict(spec, seed=seed)
+    net.load_state_dict(sd0)
+    net.train()
+    rs = np.random.Generator(np.random.PCG64(7))
+    x, mask, eps = synthetic_batch(batch, hw, hw, seed=20201004, eps_shapes=[(batch, latent_dim)] * (1 + n_decode))
+    xt, mt = torch.from_numpy(x), torch.from_numpy(mask)
+    last = net.forward(xt, mt, training=True)
+    with NoiseFeeder(eps[:1]) as nf:
+        loss = net.loss(mt)
+        assert nf.used == 1
+    loss.backward()
+    g = grads_of(net)
+    idx = rs.integers(0, batch * 2 * hw * hw, size=1024)
+    fidx = rs.integers(0, batch * 32 * hw * hw, size=1024)
+    arrays = dict(s_idx=idx, f_idx=fidx,
+                  last_conv_samp=npf(last).reshape(-1)[idx], features_samp=npf(net.unet_features).reshape(-1)[fidx],
+                  reconstruction_samp=npf(net.reconstruction).reshape(-1)[idx],
+                  post_mu=npf(net.posterior_latent_space.mean), post_sigma=npf(net.posterior_latent_space.stddev),
+                  prior_mu=npf(net.prior_latent_space.mean), prior_sigma=npf(net.prior_latent_space.stddev))
+    gn, gs = _grad_digest(g, rs)
+    meta = dict(model="ProbabilisticUnet", filters=filters, latent_dim=latent_dim, hw=hw, batch=batch, weight_seed=seed,
+                n_decode=n_decode, spec=[[k, list(s), kd] for k, s, kd in spec],
+                steps=[dict(loss=float(loss), kl=float(net.kl_divergence_loss), recon=float(net.reconstruction_loss),
+                            grad_norms=gn, grad_samples=gs, none_grads=[k for k, v in g.items() if v is None])])
+    # eval-mode decode of n_decode posterior samples on the cached U-Net features
+    net.load_state_dict(sd0)
+    net.eval()
+    margins = []
+    with torch.no_grad():
+        net.forward(xt, mt, training=False)
+        arrays["eval_post_mu"] = npf(net.posterior_latent_space.mean)
+        arrays["eval_post_sigma"] = npf(net.posterior_latent_space.stddev)
+        for j in range(n_decode):
+            with NoiseFeeder([eps[1 + j]]) as nf:
+                rec = net.reconstruct(use_posterior_mean=False, calculate_posterior=True)
+                assert nf.used == 1
+            r = npf(rec)
+            arrays[f"dec{j}_samp"] = r.reshape(-1)[idx]
+            arrays[f"dec{j}_argmax_bits"] = np.packbits(np.argmax(r, axis=1).astype(np.uint8).reshape(-1))
+            margins.append(float(np.abs(r[:, 1] - r[:, 0]).min()))
+    meta["decode_margin_min"] = margins
+    save(name, arrays, meta)
+
+
+def init_moment_cases():
+    """Per-tensor moments of the three initialisers as the REAL reference applies them at construction
+    (utils.init_weights utils.py:78-83 via unet.py:37 / probabilistic_unet.py:66; init_weights_orthogonal_normal
+    utils.py:86-90 via probabilistic_unet.py:165-170; kaiming-normal + normal bias probabilistic_unet.py:99-100;
+    PHiSeg keeps torch's default Conv2d init since phiseg.py:36 is commented out)."""
+    meta = {}
+    torch.manual_seed(0)
+    nets = dict(unet=Unet(1, 2, [32, 64, 128, 192]),
+                phiseg=PHISeg(1, 2, [32, 64, 128, 192, 192, 192, 192], latent_levels=5, image_size=(1, 128, 128)),
+                probunet=ProbabilisticUnet(1, 2, [32, 64, 128, 192, 192, 192, 192], latent_dim=6, no_convs_fcomb=3,
+                                           image_size=(1, 128, 128)))
+    for name, net in nets.items():
+        m = {}
+        for k, v in net.state_dict().items():
+            if not v.dtype.is_floating_point:
+                continue
+            a = v.detach().double()
+            e = dict(n=int(a.numel()), mean=float(a.mean()), std=float(a.std(unbiased=False)), absmax=float(a.abs().max()))
+            if k.startswith("fcomb.") and a.dim() == 4:
+                w = a.reshape(a.shape[0], -1)
+                g = w @ w.t() if w.shape[0] <= w.shape[1] else w.t() @ w
+                e["orth_err"] = float((g - torch.eye(g.shape[0], dtype=torch.float64)).abs().max())
+            m[k] = e
+        meta[name] = m
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "init_moments.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+    print("wrote init_moments:", {k: len(v) for k, v in meta.items()})
+
+
 def op_cases():
     """G1: reference-authored arithmetic that is not a stock torch op."""
     rs = np.random.Generator(np.random.PCG64(99))
@@ -360,6 +486,17 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "b32":
         # BASELINE config 4 exactly (batch 32): digests only, inputs are regenerated from the seed
         phiseg_case("phiseg_full_b32_digest", [32, 64, 128, 192, 192, 192, 192], 128, 32, 1, False, 1238, store_inputs=False)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "init":
+        init_moment_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "unet_b32":
+        # BASELINE config 2 exactly
+        unet_digest_case("unet_full_b32_digest", [32, 64, 128, 192], 32, 1240)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "probunet_b32":
+        # BASELINE config 3 exactly (+ 8 posterior-sample decodes)
+        probunet_digest_case("probunet_full_b32_digest", [32, 64, 128, 192, 192, 192, 192], 6, 32, 1241)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mid":
         # better-conditioned multi-step trajectory (16+ samples per BN channel at the deepest level)

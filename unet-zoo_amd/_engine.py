@@ -118,14 +118,25 @@ class NativeModel(nn.Module):
         _ffi.check(plan.L.uz_graph_launch(g, C.c_void_p(self._stream())), f"graph launch '{which}'")
 
     # ------------------------------------------------------------------ backward
-    def set_data_parallel(self, group=True):
+    def set_data_parallel(self, group=True, overlap=True):
         """Average gradients over the ranks of a torch.distributed process group (RCCL on ROCm)
         right after the backward tape - one all-reduce of the flat fp32 gradient buffer."""
         self._dp_group = group
+        self._dp_overlap = bool(overlap)
 
     def _run_backward(self, plan, gout):
         plan.loss_scale_t.copy_(gout.reshape(1).to(torch.float32))
+        # torch semantics: a second backward() without zero_grad() ACCUMULATES into .grad.  The tape overwrites its
+        # regions of the flat gradient buffer, so in that (rare) case the previous buffer is set aside and added back.
+        gflat = self._ptab.gflat
+        lo, hi = gflat.data_ptr(), gflat.data_ptr() + 4 * gflat.numel()
+        prev = None
+        if any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self._pmap.values()):
+            prev = gflat.clone()
+            gflat.zero_()
         self._run(plan, "bwd")
+        if prev is not None:
+            gflat.add_(prev)
         self._post_backward(plan)
         if self._dp_group is not None:
             from . import dp

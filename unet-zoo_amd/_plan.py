@@ -138,6 +138,7 @@ class Plan:
         self.target = self.fwd_ops
         self._bwd = []                      # closures, run in reverse
         self._bwd_tail = []                 # closures run after all others (regulariser gradients)
+        self._bwd_head = []                 # closures run before all others (re-materialised backward inputs)
         self._record_bwd = True
         self._ginit = {}                    # Buf -> list of (c0, c1) gradient regions already written
         self.scratch = dict(bn=0, wgrad=0, gy=0, ce=0)   # bytes (bn, wgrad, ce) / floats (gy)
@@ -383,6 +384,11 @@ class Plan:
         L = z.C
         self._newgroup()
         self._emit(self.target, "UZ_OP_BCAST_CHANNELS", p=[z, out], i=[L, out.Ctot, out.N, out.H, out.W])
+        if self._record_bwd:
+            # another tape (decode: sample() / reconstruct()) may overwrite these channels between loss() and
+            # backward(), which the reference allows; the backward tape therefore re-tiles z before it reads them
+            self._bwd_head.append(lambda: self._emit(self.bwd_ops, "UZ_OP_BCAST_CHANNELS", p=[z, out],
+                                                     i=[L, out.Ctot, out.N, out.H, out.W]))
 
         def bwd():
             if not self._has_grad(out) or not z.buf.requires_grad:
@@ -475,6 +481,9 @@ class Plan:
         assert not self.finalized
         self.loss_scale = self.vec("loss_scale", 1)
         if want_backward:
+            for fn in self._bwd_head:
+                self._newgroup()
+                fn()
             for fn in reversed(self._bwd):
                 self._newgroup()
                 fn()

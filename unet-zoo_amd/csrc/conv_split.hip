@@ -308,7 +308,7 @@ namespace uz {
 // the chip.  Planes wider than 32 use 16 x 32 tiles; 32 x 32 and 16 x 16 planes use 16 x 16 tiles.
 bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks) {
     // UZ_CONV_MATH: "f32" = fp32 MFMA only; "split" = split-bf16 on every 3x3 shape (tests); default = where it pays
-    static const int mode = [] { const char* e = getenv("UZ_CONV_MATH"); return !e ? 1 : !strcmp(e, "f32") ? 0 : !strcmp(e, "split") ? 2 : 1; }();
+    const int mode = conv_math_mode();
     if (!mode || ks != 3) return false;
     if (mode == 2) return true;
     constexpr int min_grid = 64;        // measured: 128 -> 128 @ 32 x 32 (128 tiles) already gains 20 % over the fp32 kernel

@@ -483,6 +483,15 @@ extern "C" size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, 
     return need;
 }
 
+// Which kernel family a convolution call takes under the current math mode (diagnostics / roofline bookkeeping):
+// kind 0 = forward, 1 = data gradient, 2 = weight gradient; returns 0 fp32 MFMA, 1 split-bf16 MFMA, 2 streaming VALU (1x1 heads).
+extern "C" int uz_conv_route(int kind, int Cin, int Cout, int N, int H, int W, int ks) {
+    if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) return 2;
+    if (kind == 0) return uz::conv_split_ok(Cin, Cout, N, H, W, ks) ? 1 : 0;
+    if (kind == 1) return uz::conv_split_ok(Cout, Cin, N, H, W, ks) ? 1 : 0;
+    return uz::wgrad_split_ok(Cin, Cout, N, H, W, ks) ? 1 : 0;
+}
+
 extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
                                   float* dw, float* db, int N, int H, int W, int ks,
                                   void* workspace, size_t workspace_bytes, void* stream) {

@@ -253,7 +253,7 @@ namespace uz {
 // would leave half of it empty) or at most 32 on both (32 x 32 tile: the full-resolution 32 -> 32 layers and the
 // 1- and 3-channel input layers), with enough pixels to amortise the tile loop
 bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks) {
-    static const int mode = [] { const char* e = getenv("UZ_CONV_MATH"); return !e ? 1 : !strcmp(e, "f32") ? 0 : !strcmp(e, "split") ? 2 : 1; }();
+    const int mode = conv_math_mode();
     if (!mode || ks != 3 || (W % 32 != 0 && W != 16)) return false;
     if (mode == 2) return true;
     const long long px = (long long)N * H * W;

@@ -26,7 +26,18 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    elif world > 1 and torch.cuda.is_available() and dist.get_backend() == "nccl":
+        torch.cuda.set_device(local_rank)
     return rank, local_rank, world
+
+
+def mean_scalar(t, group=None):
+    """Mean of a 0-d tensor over the ranks (identity for a single process)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    v = t.detach().clone().reshape(1).to(torch.float32)
+    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+    return (v / dist.get_world_size(group)).reshape(())
 
 
 def shard_bounds(n, rank, world):

@@ -265,6 +265,52 @@ class PHISeg(NativeModel):
     def kl_divergence(self):
         return self.kl_divergence_loss
 
+    # ---- the reference's public loss helpers (phiseg.py:436-513) as stand-alone device evaluations.  They return
+    # plain values (no autograd graph): gradients of the training loss come from the backward tape of loss().
+    def KL_two_gauss_with_diag_cov(self, mu0, sigma0, mu1, sigma1):
+        """phiseg.py:436-453 incl. the sigma1*sigma0 quirk; (N, ...) device tensors -> 0-d tensor."""
+        self._require_gpu()
+        t = [x.detach().to(self.device, torch.float32).contiguous() for x in (mu0, sigma0, mu1, sigma1)]
+        N = t[0].shape[0]
+        out = torch.empty(1, device=self.device)
+        _ffi.check(_ffi.lib().uz_kl_fwd(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), N,
+                                        t[0].numel() // N, 1.0, out.data_ptr(), self._stream()), "kl_fwd")
+        return out.reshape(())
+
+    def calculate_hierarchical_KL_div_loss(self):
+        """phiseg.py:455-479 on the cached posterior / prior moments of the last forward()."""
+        w = [self.exponential_weight ** i if self.exponential_weighting else 1 for i in range(self.latent_levels)]
+        for ii in reversed(range(self.latent_levels)):
+            self.loss_dict["KL_divergence_loss_lvl%d" % ii] = w[ii] * self.KL_two_gauss_with_diag_cov(
+                self.posterior_mu[ii], self.posterior_sigma[ii], self.prior_mu[ii], self.prior_sigma[ii])
+            self.loss_tot = self.loss_tot + self.kl_divergence_loss_weight * self.loss_dict["KL_divergence_loss_lvl%d" % ii]
+        return self.loss_tot
+
+    def _ce_levels(self, logits, target):
+        self._require_gpu()
+        logits = [x.detach().to(self.device, torch.float32).contiguous() for x in logits]
+        N, K, H, W = logits[0].shape
+        L = _ffi.lib()
+        tgt = target.detach().to(self.device, torch.float32).reshape(N, 1, H, W).contiguous()
+        tab = torch.tensor([x.data_ptr() for x in logits], dtype=torch.int64, device=self.device)
+        ws = torch.empty(L.uz_ce_workspace(N, H, W, len(logits)) // 4 + 16, device=self.device)
+        out = torch.empty(len(logits), device=self.device)
+        _ffi.check(L.uz_residual_ce_fwd(tab.data_ptr(), len(logits), K, tgt.data_ptr(), N, H, W, out.data_ptr(), ws.data_ptr(),
+                                        self._stream()), "residual_ce_fwd")
+        return out
+
+    def multinoulli_loss(self, reconstruction, target):
+        """phiseg.py:481-490: per-pixel CE summed over pixels, mean over the batch."""
+        return self._ce_levels([reconstruction], target)[0]
+
+    def residual_multinoulli_loss(self, reconstruction, target):
+        """phiseg.py:492-513 on a list of level logits (finest first)."""
+        terms = self._ce_levels(list(reconstruction), target)
+        for ii in reversed(range(len(reconstruction))):
+            self.loss_dict["residual_multinoulli_loss_lvl%d" % ii] = terms[ii]
+            self.loss_tot = self.loss_tot + self.residual_multinoulli_loss_weight * terms[ii]
+        return self.loss_tot
+
     def accumulate_output(self, output_list, use_softmax=False):
         """phiseg.py:428-434 incl. the in-place accumulation into output_list[-1]."""
         self._require_gpu()

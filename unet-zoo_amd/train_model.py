@@ -5,8 +5,8 @@ Scope: the TRAIN-STEP CONTRACT of ``UNetModel`` - build
 ReduceLROnPlateau('min', min_lr=1e-4, patience=50000) stepped on the loss (:50-51,:134), and per
 iteration: to-device, ``forward(patch, mask, training=True)``, ``loss(mask)``, ``zero_grad``,
 ``backward``, ``step`` (:100-134) - plus ``save_model`` (:558-564).  Validation metrics (GED / NCC / Dice via medpy),
-the device-side validation loop (N prior samples, GED / NCC / Dice) is `validate`; image dumps and the
-LIDC / UZH / BraTS loaders stay outside the hot path.
+the device-side validation and test loops (N prior samples, GED / NCC / Dice) are `validate` / `test`
+(train_model.py:138-275,333-475); image dumps and the UZH / BraTS loaders stay outside the hot path.
 
 Experiment files of the reference are plain Python modules that import ``models.phiseg``,
 ``data.lidc_data`` and ``utils`` (e.g. models/experiments/phiseg_7_5_12.py:1-5).  ``load_experiment``
@@ -32,9 +32,12 @@ from .synthetic import synthetic_batch
 
 # --------------------------------------------------------------------------- data stand-in
 class _Split:
-    def __init__(self, images, labels):
+    def __init__(self, images, labels, seed=0):
         self.images, self.labels = images, labels
-        self._rng = np.random.default_rng(0)
+        self._rng = np.random.default_rng(seed)
+
+    def reseed(self, seed):
+        self._rng = np.random.default_rng(seed)
 
     def next_batch(self, batch_size):
         """(x (B,1,H,W) float32 in [-0.5,0.5], s (B,H,W) labels) like BatchProvider.next_batch (batch_provider.py:43-67)."""
@@ -102,6 +105,9 @@ class UNetModel:
     """Wrapper that trains a native model exactly as the reference harness does (train_model.py:27-136)."""
 
     def __init__(self, exp_config, logger=None, tensorboard=False, log_root="./logs"):
+        # one process per GPU: bind this rank to cuda:LOCAL_RANK *before* any buffer is allocated (the model, the
+        # optimiser state and the RCCL communicator must all live on the same device)
+        self.rank, self.local_rank, self.world = dp.init_from_env()
         kwargs = dict(input_channels=exp_config.input_channels, num_classes=exp_config.n_classes,
                       num_filters=exp_config.filter_channels, latent_levels=exp_config.latent_levels,
                       no_convs_fcomb=exp_config.no_convs_fcomb, beta=exp_config.beta,
@@ -118,9 +124,9 @@ class UNetModel:
         self.device = self.net.device
         self.optimizer = FusedAdam(self.net, lr=1e-3, weight_decay=1e-5)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", min_lr=1e-4, patience=50000)
-        self.rank, self.local_rank, self.world = dp.init_from_env()
         if self.world > 1:
             dp.broadcast_(self.net._ptab.pflat)
+            dp.broadcast_(self.net._ptab.bflat)
             self.net.set_data_parallel(True)
         self.log_root = log_root
         self.tot_loss = self.kl_loss = self.reconstruction_loss = 0
@@ -144,6 +150,8 @@ class UNetModel:
         self.net.train()
         n_it = iterations if iterations is not None else self.exp_config.iterations
         log_every = getattr(self.exp_config, "logging_frequency", 1000)
+        if self.world > 1 and hasattr(data.train, "reseed"):
+            data.train.reseed(1000003 * self.rank + 17)          # every rank draws its own shard of each global batch
         for self.iteration in range(1, n_it):
             x_b, s_b = data.train.next_batch(self.batch_size)
             loss = self.train_step(x_b, s_b)
@@ -153,15 +161,49 @@ class UNetModel:
             if self.iteration % log_every == 0:
                 self.logger.info("Iteration {} Loss {}".format(self.iteration, float(loss)))
                 self.tot_loss = self.kl_loss = self.reconstruction_loss = 0
-            self.scheduler.step(loss.detach())          # train_model.py:134 (compares on the host: one sync per step)
+            # train_model.py:134 (compares on the host: one sync per step); under data parallelism every rank steps the
+            # scheduler on the SAME number - the mean of the ranks' losses - so the learning rates cannot diverge
+            self.scheduler.step(dp.mean_scalar(loss.detach()))
         self.logger.info("Finished training.")
+
+    @torch.no_grad()
+    def _evaluate_image(self, image, s_gt_arr, n_samples, rng, keep=False):
+        """One image of the validation / test loops (train_model.py:166-230 and :369-425): `n_samples` copies through
+        forward(training=False) -> accumulate_output(softmax) -> [loss] -> argmax -> GED / NCC / per-label Dice on the
+        device.  s_gt_arr: (H, W, A) annotator label maps.  Returns a dict; keep=True also returns the drawn samples."""
+        from . import metrics
+        cfg, n_classes = self.exp_config, self.exp_config.n_classes
+        ann_range = list(getattr(cfg, "annotator_range", range(s_gt_arr.shape[-1])))
+        patch = torch.as_tensor(image, dtype=torch.float32).to(self.device)
+        H, W = patch.shape[-2:]
+        val_patch = patch.reshape(1, 1, H, W)
+        s_b = s_gt_arr[:, :, rng.choice(ann_range)]
+        val_mask = torch.as_tensor(s_b, dtype=torch.float32).to(self.device).reshape(1, 1, H, W)
+        val_masks = torch.as_tensor(s_gt_arr, dtype=torch.float32).to(self.device).permute(2, 0, 1).contiguous()      # (A, H, W)
+        patch_arr = val_patch.repeat(n_samples, 1, 1, 1)
+        mask_arr = val_mask.repeat(n_samples, 1, 1, 1)
+        out = self.net.forward(patch_arr, mask_arr, training=False)
+        # PHISeg: list of level logits, summed in place + softmax.  ProbabilisticUnet: the reference feeds the forward()
+        # output itself - last_conv(unet_features), probabilistic_unet.py:255 - through its pass-through
+        # accumulate_output (:285-290), so its N "samples" are identical; reproduced as is (train_model.py:185-189).
+        soft = self.net.accumulate_output(out, use_softmax=True)
+        elbo = float(self.net.loss(mask_arr))
+        pred = torch.argmax(soft, dim=1)                                        # (N, H, W)
+        ged = metrics.generalised_energy_distance(pred, val_masks.long(), nlabels=n_classes - 1, label_range=range(1, n_classes))
+        onehot = torch.stack([(val_masks == k) for k in range(n_classes)], dim=1).long()            # (A, K, H, W)
+        ncc = metrics.variance_ncc_dist(soft, onehot)
+        s_mean = torch.argmax(torch.mean(soft, dim=0), dim=0)
+        dice = metrics.per_label_dice(s_mean, val_mask.reshape(H, W).long(), n_classes)
+        res = dict(ged=ged, ncc=ncc, dice=dice, elbo=elbo)
+        if keep:
+            res.update(soft=soft, pred=pred, gts=val_masks, mask=val_mask.reshape(H, W), onehot=onehot)
+        return res
 
     @torch.no_grad()
     def validate(self, data):
         """UNetModel.validate (train_model.py:138-275) on the device: per validation image, `validation_samples`
         prior samples in eval mode -> accumulate_output(softmax) -> loss -> argmax -> GED / NCC / Dice
         (unet_zoo_amd.metrics), then the running means and the best-model checkpoints."""
-        from . import metrics
         cfg = self.exp_config
         self.net.eval()
         self.save_model("validation_ckpt")
@@ -169,36 +211,15 @@ class UNetModel:
         n_classes = cfg.n_classes
         n_img = data.validation.images.shape[0] if getattr(cfg, "num_validation_images", "all") == "all" \
             else min(cfg.num_validation_images, data.validation.images.shape[0])
-        ann_range = list(getattr(cfg, "annotator_range", range(data.validation.labels.shape[-1])))
         rng = np.random.default_rng(self.iteration)
         ged_l, dice_l, ncc_l, elbo_l = [], [], [], []
         for ii in range(n_img):
-            s_gt_arr = data.validation.labels[ii]                                   # (H, W, A)
-            patch = torch.as_tensor(data.validation.images[ii], dtype=torch.float32).to(self.device)
-            val_patch = patch.reshape(1, 1, *patch.shape[-2:])
-            s_b = s_gt_arr[:, :, rng.choice(ann_range)]
-            val_mask = torch.as_tensor(s_b, dtype=torch.float32).to(self.device).reshape(1, 1, *patch.shape[-2:])
-            val_masks = torch.as_tensor(s_gt_arr, dtype=torch.float32).to(self.device).permute(2, 0, 1).contiguous()   # (A, H, W)
-            patch_arr = val_patch.repeat(n_samples, 1, 1, 1)
-            mask_arr = val_mask.repeat(n_samples, 1, 1, 1)
-            out = self.net.forward(patch_arr, mask_arr, training=False)
-            if isinstance(out, list):                                               # PHISeg: list of level logits
-                soft = self.net.accumulate_output(out, use_softmax=True)
-                elbo_l.append(float(self.net.loss(mask_arr)))
-            else:                                                                   # ProbabilisticUnet: one sample per row
-                soft = torch.softmax(self.net.sample(testing=True), dim=1)
-                elbo_l.append(float("nan"))
-            pred = torch.argmax(soft, dim=1)                                        # (N, H, W)
-            ged_l.append(metrics.generalised_energy_distance(pred, val_masks.long(), nlabels=n_classes - 1,
-                                                             label_range=range(1, n_classes)))
-            onehot = torch.stack([(val_masks == k) for k in range(n_classes)], dim=1).long()        # (A, K, H, W)
-            ncc_l.append(metrics.variance_ncc_dist(soft, onehot))
-            s_mean = torch.argmax(torch.mean(soft, dim=0), dim=0)
-            dice_l.append(metrics.per_label_dice(s_mean, val_mask.reshape(*patch.shape[-2:]).long(), n_classes))
+            r = self._evaluate_image(data.validation.images[ii], data.validation.labels[ii], n_samples, rng)
+            ged_l.append(r["ged"]); ncc_l.append(r["ncc"]); dice_l.append(r["dice"]); elbo_l.append(r["elbo"])
         dice = torch.tensor(dice_l)
         self.avg_dice = float(dice.mean())
         self.foreground_dice = float(dice.mean(dim=0)[1]) if n_classes > 1 else float("nan")
-        self.val_elbo = float(np.nanmean(elbo_l)) if len(elbo_l) else float("nan")
+        self.val_elbo = float(np.nanmean(elbo_l)) if len(elbo_l) and not all(np.isnan(elbo_l)) else float("nan")
         self.avg_ged, self.avg_ncc = float(np.mean(ged_l)), float(np.mean(ncc_l))
         self.logger.info(" - Foreground dice: %.4f" % self.foreground_dice)
         self.logger.info(" - Mean (neg.) ELBO: %.4f" % self.val_elbo)
@@ -215,6 +236,48 @@ class UNetModel:
             best["ncc"] = self.avg_ncc; self.save_model("best_ncc")
         self.net.train()
         return dict(dice=self.avg_dice, foreground_dice=self.foreground_dice, elbo=self.val_elbo, ged=self.avg_ged, ncc=self.avg_ncc)
+
+    @torch.no_grad()
+    def test(self, data, sys_config=None, rounds=10, n_samples=10):
+        """UNetModel.test (train_model.py:333-475): load `<experiment>_best_loss.pth`, then `rounds` passes over the
+        test split with `n_samples` prior samples per image; GED / NCC arrays are dumped as
+        `ged<n>_<model>_2.npz` / `ncc<n>_<model>_2.npz` next to the checkpoint (:446-447); returns the mean
+        Dice / GED / NCC over the rounds (:473-475 logs them)."""
+        cfg = self.exp_config
+        self.net.eval()
+        model_selection = cfg.experiment_name + "_best_loss.pth"
+        root = getattr(sys_config, "log_root", None) or self.log_root
+        model_dir = os.path.join(root, cfg.log_dir_name, cfg.experiment_name)
+        model_path = os.path.join(model_dir, model_selection)
+        self.logger.info("Testing {}".format(model_selection))
+        if not os.path.exists(model_path):
+            self.logger.info("The file {} does not exist. Aborting test function.".format(model_path))
+            return None
+        self.net.load_state_dict(torch.load(model_path))
+        rng = np.random.default_rng(0)
+        ged_l, dice_l, ncc_l = [], [], []
+        end = dict(dice=0.0, ged=0.0, ncc=0.0)
+        for rnd in range(rounds):
+            self.logger.info("Doing iteration {}".format(rnd))
+            for ii in range(data.test.images.shape[0]):
+                r = self._evaluate_image(data.test.images[ii], data.test.labels[ii], n_samples, rng)
+                ged_l.append(r["ged"]); ncc_l.append(r["ncc"]); dice_l.append(r["dice"])
+            dice = torch.tensor(dice_l)
+            self.avg_dice = float(dice.mean())
+            self.foreground_dice = float(dice.mean(dim=0)[1]) if cfg.n_classes > 1 else float("nan")
+            self.avg_ged, self.avg_ncc = float(np.mean(ged_l)), float(np.mean(ncc_l))       # lists grow over the rounds, as in the reference
+            if self.rank == 0:
+                np.savez(os.path.join(model_dir, "ged%s_%s_2.npz" % (str(n_samples), model_selection)), np.asarray(ged_l))
+                np.savez(os.path.join(model_dir, "ncc%s_%s_2.npz" % (str(n_samples), model_selection)), np.asarray(ncc_l))
+            self.logger.info(" - Foreground dice: %.4f" % self.foreground_dice)
+            self.logger.info(" - Mean GED: %.4f" % self.avg_ged)
+            self.logger.info(" - Mean NCC: %.4f" % self.avg_ncc)
+            end["dice"] += self.avg_dice; end["ged"] += self.avg_ged; end["ncc"] += self.avg_ncc
+        out = {k: v / rounds for k, v in end.items()}
+        self.logger.info("Mean dice: {}".format(out["dice"]))
+        self.logger.info("Mean ged: {}".format(out["ged"]))
+        self.logger.info("Mean ncc: {}".format(out["ncc"]))
+        return out
 
     def save_model(self, savename):
         """<log_root>/<log_dir_name>/<experiment_name>/<experiment_name>_<savename>.pth (train_model.py:558-564)."""
