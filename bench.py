@@ -15,8 +15,8 @@ Extra objects on the line:
   roofline      `achieved` = images/s x the model's algorithmic GFLOP/image in fp32-equivalent
                 TFLOP/s.  `peak` is the BINDING roof of the step: every convolution op of the tape is priced against the
                 matrix pipe it actually runs on - 157.3 TFLOP/s (fp32 MFMA) for the ops the library routes to
-                conv_mfma / wgrad_fast kernels, 2500/6 = 416.7 TFLOP/s for the ops it routes to the split-bf16 kernels
-                (six bf16 piece products per fp32 product) - and peak = sum(flops) / sum(flops_i / roof_i); frac =
+                conv_mfma / wgrad_fast kernels, 2500/3 = 833.3 TFLOP/s for the ops it routes to the split-fp16 kernels
+                (three fp16 piece products per fp32 product) - and peak = sum(flops) / sum(flops_i / roof_i); frac =
                 achieved / peak.  `frac_vs_fp32_mfma` keeps BASELINE.md's step-level figure (achieved / 157.3) for
                 reference, and `fp32_mfma_only` is the same run with UZ_CONV_MATH=f32 (like-for-like against 157.3).
                 `dominant_kernel`: the heaviest kernel of the step timed live with HIP events on its launch stream,
@@ -38,9 +38,9 @@ sys.path.insert(0, ROOT)
 FILTERS7 = [32, 64, 128, 192, 192, 192, 192]
 FILTERS4 = [32, 64, 128, 192]
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md chip-level parameters
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak
-SPLIT_PRODUCTS = 6                # bf16 piece products per fp32 product in conv_split.hip / conv_wgrad_split.hip
-PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA peak
+SPLIT_PRODUCTS = 3                # fp16 piece products per fp32 product in conv_split.hip / conv_wgrad_split.hip (split_f16.h)
+PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS
 HBM_PEAK_GBS = 8000.0
 
 # algorithmic work per image (fwd+bwd), unfused tensor bytes per image, fixed bytes per step
@@ -116,7 +116,7 @@ def binding_roof(plan, L):
     """Effective matrix-pipe roof of the step: sum(flops) / sum(flops_i / roof_i) over the conv ops of the fwd + bwd tapes,
     plus the FLOP share that runs on each pipe."""
     tot = t_at_roof = 0.0
-    share = {"fp32_mfma": 0.0, "split_bf16_mfma": 0.0, "valu_streaming_heads": 0.0}
+    share = {"fp32_mfma": 0.0, "split_fp16_mfma": 0.0, "valu_streaming_heads": 0.0}
     for ops in (plan.fwd_ops, plan.loss_ops, plan.bwd_ops):
         for o in ops:
             fl = conv_flops(o)
@@ -126,7 +126,7 @@ def binding_roof(plan, L):
             if roof is None:
                 share["valu_streaming_heads"] += fl
                 continue                                     # memory-bound heads: no matrix-pipe roof, < 0.1 % of the FLOPs
-            share["fp32_mfma" if roof == PEAK_F32_MFMA_TFLOPS else "split_bf16_mfma"] += fl
+            share["fp32_mfma" if roof == PEAK_F32_MFMA_TFLOPS else "split_fp16_mfma"] += fl
             tot += fl
             t_at_roof += fl / roof
     allf = sum(share.values()) or 1.0
@@ -164,7 +164,7 @@ def profile_families(net, plan, L, reps=3):
                 roof = conv_roof(ops[k], L)
                 if roof is not None:
                     d["flops"] += fl
-                    d["t_roof"] += fl / roof
+                    d["t_roof"] += fl / (roof * 1e12)                 # seconds at the roof
                     if heaviest is None or best > heaviest[0]:
                         heaviest = (best, which, k, fl, roof)
     return fam, heaviest
@@ -201,15 +201,15 @@ def dominant_kernel_live(net, plan, L, heaviest, reps=20):
                layer=f"{ks}x{ks} {cin}->{cout} @ {n}x{h}x{w}", flops_per_launch=flops, avg_launch_ms=round(ms, 4),
                achieved=round(flops / ms / 1e9, 2), peak=round(roof, 1), unit="TFLOP/s", frac=round(flops / ms / 1e9 / roof, 4),
                algorithmic_bytes=alg_bytes, traffic=None,
-               peak_note=("dense bf16 MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product" if split else "fp32 MFMA peak"))
+               peak_note=("dense fp16 MFMA peak 2500 TFLOP/s / 3 piece products per fp32 product" if split else "fp32 MFMA peak"))
     if split:
-        out["bf16_mfma_tflops"] = round(SPLIT_PRODUCTS * flops / ms / 1e9, 1)
+        out["fp16_mfma_tflops"] = round(SPLIT_PRODUCTS * flops / ms / 1e9, 1)
     for prof in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
             if f"{cin} -> {cout}" not in pmc.get("layer", "") or f"N={n}" not in pmc.get("layer", ""):
                 continue
-            key = {0: "conv_split_kernel<2> (forward)", 1: "conv_split_kernel<2> (forward)", 2: "wgrad_split_kernel<32,64> (weight gradient, slabs)"}[kind] \
+            key = {0: "conv_split_kernel<2> f16 (forward)", 1: "conv_split_kernel<2> f16 (forward)", 2: "wgrad_split_kernel<32,64> f16 (weight gradient, slabs)"}[kind] \
                 if split else {0: "conv_mfma_kernel<3,2,2,false> (forward)", 1: "conv_mfma_kernel<3,2,2,true> (data gradient)",
                                2: "wgrad_fast_kernel<2,2,4,32> (weight gradient, slabs)"}[kind]
             out.update(traffic=pmc["kernels"][key]["hbm_bytes"], traffic_source="profiles/" + prof)
@@ -441,7 +441,7 @@ def main():
                     frac_vs_fp32_mfma=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), flop_share_by_pipe=share,
                     hbm_fraction=round((per_gpu * M["gb_img"] + (per_gpu / args.batch) * M["gb_step"]) / HBM_PEAK_GBS, 4),
                     note=f"step-level, per GPU: achieved = images/s x {M['gflop']} GFLOP/image (fp32-equivalent); peak = binding roof of the "
-                         "conv ops as routed: 157.3 TFLOP/s (fp32 MFMA) or 2500/6 = 416.7 TFLOP/s (split-bf16, 6 bf16 products per fp32 "
+                         "conv ops as routed: 157.3 TFLOP/s (fp32 MFMA) or 2500/3 = 833.3 TFLOP/s (split-fp16, 3 fp16 products per fp32 "
                          "product), weighted by FLOPs (harmonic); frac_vs_fp32_mfma = achieved / 157.3 as BASELINE.md section 2 defines it; "
                          "hbm_fraction uses the unfused-graph bytes and cannot exceed ~0.21 in fp32")
         if not args.no_profile and world == 1:
@@ -451,7 +451,7 @@ def main():
                 e = dict(ms_per_step=round(d["ms"], 3), launches=d["launches"])
                 if d["flops"]:
                     e["tflops"] = round(d["flops"] / d["ms"] / 1e9, 2)
-                    e["binding_roof_tflops"] = round(d["flops"] / d["t_roof"], 1)
+                    e["binding_roof_tflops"] = round(d["flops"] / d["t_roof"] / 1e12, 1)
                     e["frac_of_binding_roof"] = round(d["t_roof"] * 1e3 / d["ms"], 4)
                 elif d["bytes"]:
                     e["gbs"] = round(d["bytes"] / d["ms"] / 1e6, 1)
@@ -464,8 +464,8 @@ def main():
             roof["traffic"] = roof["dominant_kernel"]["traffic"]
         math_note = ("fp32 MFMA only (UZ_CONV_MATH=f32)" if conv_math() == "f32" else
                      "fp32 in / fp32 out, fp32 accumulate everywhere; 3x3 layers the library routes to the split path (forward, data gradient AND "
-                     "weight gradient; share in roofline.flop_share_by_pipe): operands split exactly into 3 bf16 pieces, 6 piece products on the "
-                     "bf16 matrix pipe (error vs fp64 within 2x of the fp32-MFMA kernels, tests/test_full_configs_gpu.py); other layers: fp32 MFMA")
+                     "weight gradient; share in roofline.flop_share_by_pipe): operands scaled by a power of two and split into 2 fp16 pieces, 3 piece "
+                     "products on the fp16 matrix pipe (error vs fp64 no larger than the fp32-MFMA kernels', tests/test_full_configs_gpu.py); other layers: fp32 MFMA")
         line = dict(metric=M["metric"], value=round(ips, 2), unit="images/s", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype="f32", data="synthetic",
@@ -474,9 +474,10 @@ def main():
                     roofline=roof)
         if world > 1:
             line["config"]["allreduce"] = "bucketed, overlapped with backward" if not args.no_overlap else "one blocking all-reduce after backward"
-            st = getattr(net, "_dp_stats", None)
-            if st:
-                line["dp"] = st
+            sync = getattr(net, "_dp", None)
+            if sync is not None:
+                line["dp"] = dict(backend=sync.backend, buckets_MB=[round(4 * (hi - lo) / 1e6, 1) for lo, hi in sync.buckets],
+                                  exposed_allreduce_ms_last_step=sync.exposed_ms())
         line.update(extra)
         if f32_leg is not None:
             line["fp32_mfma_only"] = f32_leg

@@ -46,10 +46,9 @@ int         uz_device_info(int* n_cu, char* name, int name_cap);
  *  - fp32 MFMA (v_mfma_f32_32x32x2_f32) for every shape, including the 1..3-channel image /
  *    latent inputs (channel tiles are zero padded in LDS); 1x1 heads with <= 8 outputs run on
  *    streaming VALU kernels instead;
- *  - for the large 3x3 layers, the bf16 matrix pipe with exactly split operands (each fp32 value
- *    = three bf16 pieces, six piece products, fp32 accumulate: conv_split.hip,
- *    conv_wgrad_split.hip) - fp32-accurate (error vs fp64 within 2x of the fp32-MFMA kernels,
- *    see DESIGN.md) at 1.5-1.7x the speed.  Environment switch, read once per process:
+ *  - for the large 3x3 layers, the fp16 matrix pipe with split operands (each fp32 value, scaled by a power of two,
+ *    = two fp16 pieces of 11 significand bits; three piece products, fp32 accumulate: split_f16.h, conv_split.hip,
+ *    conv_wgrad_split.hip) - fp32-accurate (error vs fp64 no larger than the fp32-MFMA kernels').  Environment switch, read once per process:
  *    UZ_CONV_MATH=f32 (fp32 MFMA only) | split (split path on every eligible 3x3 shape) | unset.
  *    The forward / data-gradient split path keeps its packed weight image in `workspace`.
  * Deep, low-resolution levels (2x2 .. 16x16) cannot fill 256 CUs with output tiles alone: with a
@@ -60,14 +59,20 @@ int         uz_device_info(int* n_cu, char* name, int name_cap);
  * every eligible shape.  Workspace sizes depend on the mode: query them after switching.  Not thread safe.            */
 int uz_set_conv_math(int mode);
 int uz_get_conv_math(void);
-/* kernel family a call takes under the current mode: kind 0 fwd / 1 bwd_data / 2 bwd_weight -> 0 fp32 MFMA, 1 split-bf16 MFMA,
+/* kernel family a call takes under the current mode: kind 0 fwd / 1 bwd_data / 2 bwd_weight -> 0 fp32 MFMA, 1 split-fp16 MFMA,
  * 2 streaming VALU (1x1 heads with <= 8 outputs).  Used by bench.py to price each op against the roof it runs on.          */
 int uz_conv_route(int kind, int Cin, int Cout, int N, int H, int W, int ks);
 size_t uz_conv_workspace(int Cin, int Cout, int N, int H, int W, int ks);   /* covers fwd and bwd_data */
+/* Magnitude bounds (`*_amax`, all nullable): device scalars holding an UPPER BOUND of max|tensor| (any bound within ~2^10 of
+ * the true maximum keeps full accuracy).  The split-fp16 kernels scale their operands by a power of two derived from the bound
+ * before splitting them into fp16 pieces; NULL makes the call measure the tensor itself (one extra pass - the stand-alone
+ * path; the model plans pass bounds that the producing kernels maintain: y_amax / a_amax / dy_amax outputs below are
+ * atomic-max accumulated into a slot the caller zeroes once per pass).  The fp32-MFMA kernels ignore the input bounds.   */
 int uz_conv_fwd(const float* x, int Cin, int CinTot,
                 const float* w, const float* bias,
                 float* y, int Cout, int CoutTot,
                 int N, int H, int W, int ks, int relu,
+                const float* x_amax, const float* w_amax, float* y_amax,
                 void* workspace, size_t workspace_bytes, void* stream);
 /* autograd of the above w.r.t. its input (aten::convolution_backward, input part):
  * dx[b,ci] (+)= sum_co sum_tap dy[b,co,.] * w[co,ci,flip(tap)]                 */
@@ -75,6 +80,7 @@ int uz_conv_bwd_data(const float* dy, int Cout, int CoutTot,
                      const float* w,
                      float* dx, int Cin, int CinTot,
                      int N, int H, int W, int ks, int accumulate,
+                     const float* dy_amax, const float* w_amax,
                      void* workspace, size_t workspace_bytes, void* stream);
 /* autograd w.r.t. the weight: dw[co,ci,tap] = sum_{b,y,x} dy * x_shifted.
  * Deterministic split-K: partial slabs in `workspace` (uz_conv_bwd_weight_workspace
@@ -84,6 +90,7 @@ int uz_conv_bwd_weight(const float* x, int Cin, int CinTot,
                        const float* dy, int Cout, int CoutTot,
                        float* dw, float* db,
                        int N, int H, int W, int ks,
+                       const float* x_amax, const float* dy_amax,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- BatchNorm2d(eps, momentum) + ReLU
@@ -98,7 +105,7 @@ int uz_bn_relu_fwd(const float* y, int C, int CtotY,
                    float* save_mean_rstd,
                    float* a, int CtotA,
                    int N, int H, int W, float eps, float momentum, int training, int relu,
-                   void* workspace, void* stream);
+                   float* a_amax, void* workspace, void* stream);
 /* native_batch_norm_backward + threshold_backward: da -> dy, dgamma, dbeta, and the
  * conv-bias gradient dbias = sum dy (nullable).  dy may alias da.               */
 int uz_bn_relu_bwd(const float* da, int CtotDa,
@@ -107,25 +114,25 @@ int uz_bn_relu_bwd(const float* da, int CtotDa,
                    float* dy, int CtotDy,
                    float* dgamma, float* dbeta, float* dbias,
                    int N, int H, int W, int relu,
-                   void* workspace, void* stream);
+                   float* dy_amax, void* workspace, void* stream);
 /* ReLU-only units of the vanilla U-Net (unet.py:26,28,30): da * [a > 0] (threshold_backward)
  * fused with the conv-bias gradient.                                              */
 int uz_relu_bwd(const float* da, int CtotDa, const float* a, int C, int CtotA,
                 float* dy, int CtotDy, float* dbias,
-                int N, int H, int W, void* workspace, void* stream);
+                int N, int H, int W, float* dy_amax, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------- resampling
  * nn.AvgPool2d(2, 2, padding=0, ceil_mode=True): phiseg.py:23, unet.py:22,
  * probabilistic_unet.py:56.  Ho = ceil(H/2); partial windows divide by the
  * in-bounds element count.                                                        */
 int uz_avgpool2_fwd(const float* x, int C, int CtotX, float* y, int CtotY,
-                    int N, int H, int W, void* stream);
+                    int N, int H, int W, const float* x_amax, float* y_amax, void* stream);   /* |y| <= bound of |x| is forwarded */
 int uz_avgpool2_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx,
                     int N, int H, int W, int accumulate, void* stream);
 /* F.interpolate(mode='bilinear', scale_factor=2, align_corners=ac): phiseg.py:66,213-216,
  * 305-309 (ac=1), unet.py:67 (ac=0).  (H, W) are the INPUT sizes.                 */
 int uz_bilinear2x_fwd(const float* x, int C, int CtotX, float* y, int CtotY,
-                      int N, int H, int W, int align_corners, void* stream);
+                      int N, int H, int W, int align_corners, const float* x_amax, float* y_amax, void* stream);
 int uz_bilinear2x_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx,
                       int N, int H, int W, int align_corners, int accumulate, void* stream);
 /* F.interpolate(size=[Ho,Wo], mode='nearest'), integer factor: phiseg.py:321        */
@@ -195,6 +202,8 @@ int uz_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
                  int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                  float grad_scale, void* stream);
 int uz_axpy(float* y, const float* x, float alpha, size_t n, void* stream);     /* y += alpha*x */
+/* slot[0] = max(slot[0], max_i |x_i|) (slot holds a non-negative float; zero it first for a plain maximum) */
+int uz_absmax(const float* x, size_t n, float* slot, void* stream);
 int uz_scale(float* y, float alpha, size_t n, void* stream);                    /* y *= alpha   */
 /* sqrt(sum x^2) terms of utils.l2_regularisation (utils.py:93-101): one norm per tensor of a
  * table of (offset, count) pairs over the flat parameter buffer; out[i] = ||p_i||_2.       */
@@ -216,6 +225,8 @@ enum {
   UZ_OP_CE_FWD, UZ_OP_CE_BWD, UZ_OP_SUM_TERMS, UZ_OP_ACC_SOFTMAX_ARGMAX,
   UZ_OP_ADAM, UZ_OP_AXPY, UZ_OP_SCALE, UZ_OP_L2_NORMS, UZ_OP_L2_NORMS_BWD,
   UZ_OP_MEMSET, UZ_OP_COPY, UZ_OP_BCAST_CHANNELS, UZ_OP_BCAST_CHANNELS_BWD,
+  UZ_OP_ABSMAX,          /* p[0] = src, p[1] = slot, n = count */
+  UZ_OP_EVENT_RECORD,    /* p[0] = event (uz_event_create): marks "every earlier op this one depends on is done" */
   UZ_OP__COUNT
 };
 typedef struct uz_op {
@@ -244,6 +255,35 @@ int  uz_graph_create_lanes(const uz_op* ops, const uz_sched* sched, int n_ops, i
                            void* stream, void** graph_exec_out);
 int  uz_graph_launch(void* graph_exec, void* stream);
 void uz_graph_destroy(void* graph_exec);
+
+/* ---------------------------------------------------------------- data-parallel gradient exchange (RCCL over xGMI)
+ * New component (the reference has no communication layer): one process per GPU, full replica, and
+ * between loss.backward() and optimizer.step() (train_model.py:121-122) the flat fp32 gradient buffer is averaged over the
+ * ranks.  librccl.so is bound at run time (uz_comm_load: path or NULL for the default search); the 128-byte unique id is
+ * created on rank 0 (uz_comm_unique_id) and handed to the other ranks by the host (torch.distributed store / file / pipe);
+ * uz_comm_init is collective.  Every call below is asynchronous on the given stream.                                       */
+int  uz_comm_load(const char* librccl_path);
+int  uz_comm_version(void);                                   /* RCCL version code, < 0 when RCCL cannot be loaded */
+int  uz_comm_unique_id(void* out_128B);
+int  uz_comm_init(int rank, int nranks, const void* unique_id_128B, void** comm_out);
+void uz_comm_destroy(void* comm);
+int  uz_comm_size(void* comm);
+int  uz_allreduce_mean_f32(void* comm, float* flat, size_t count, void* stream);         /* in place, ncclAvg */
+/* several slices {offset, count} (in floats, pairs in HOST memory) of one buffer in ONE RCCL group launch */
+int  uz_allreduce_mean_f32_multi(void* comm, float* flat, const int64_t* offs_counts, int n_slices, void* stream);
+int  uz_broadcast_f32(void* comm, float* flat, size_t count, int root, void* stream);
+/* streams / events for overlapping the collective with the rest of the backward tape: a UZ_OP_EVENT_RECORD op inside the
+ * backward tape (also when the tape is replayed as a hipGraph: external event-record node) marks a gradient bucket final;
+ * the communication stream waits for it (uz_stream_wait_event) and runs the bucket's all-reduce beside the remaining
+ * backward kernels; the compute stream finally waits for an event recorded behind the last all-reduce.                     */
+int  uz_stream_create(void** stream_out, int high_priority);
+void uz_stream_destroy(void* stream);
+int  uz_stream_synchronize(void* stream);
+int  uz_event_create(void** event_out, int timing);
+void uz_event_destroy(void* event);
+int  uz_event_record(void* event, void* stream);
+int  uz_stream_wait_event(void* stream, void* event);
+int  uz_event_elapsed_ms(void* start, void* stop, float* ms_out);
 
 /* Fcomb input (probabilistic_unet.py:172-197) */
 /* z (N,L) tiled over HxW into channels of a (N,Ctot,H,W) buffer, and its backward (sum over pixels) */

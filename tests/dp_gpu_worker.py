@@ -1,20 +1,21 @@
-"""Worker of tests/test_dp_gpu.py: launched with torch.distributed.run, WORLD_SIZE ranks all on cuda:0 (gloo),
-checks the data-parallel gradient path of the native PHISeg on the device:
-  1. after the first loss.backward() every rank holds the SAME flat gradient buffer, equal to the mean of the
-     ranks' local gradients (same weights, same injected noise, different data per rank);
-  2. after two more steps (hipGraph capture + replay with the all-reduce between backward and Adam) the
-     parameters are still bit-identical on every rank."""
+"""Worker of tests/test_dp_gpu.py: launched with torch.distributed.run, WORLD_SIZE ranks all on cuda:0 (gloo - RCCL refuses
+two ranks on one device), checks the data-parallel gradient path of the native PHISeg on the device against the ORACLE:
+  1. after the first loss.backward() every rank holds the SAME flat gradient buffer, and it equals
+     mean_r(oracle_gradients(shard_r)) computed by the CPU oracle per shard (SURVEY.md 8e parity gate);
+  2. after two more steps (hipGraph capture + replay, bucketed exchange between backward and Adam) the parameters are still
+     bit-identical on every rank."""
 import os
 import sys
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import oracle                                              # noqa: E402  (test infrastructure: noise shapes only)
-from unet_zoo_amd.models.phiseg import PHISeg            # noqa: E402
+import oracle                                              # noqa: E402  (test infrastructure: the checker)
+from tests import _golden as G                           # noqa: E402
+from unet_zoo_amd.models.phiseg import PHISeg, phiseg_spec  # noqa: E402
 from unet_zoo_amd.optim import FusedAdam                 # noqa: E402
-from unet_zoo_amd.synthetic import synthetic_batch       # noqa: E402
 
 
 def main():
@@ -23,49 +24,63 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     filters = [8, 16, 16, 16, 16, 16, 16]
-    B, HW = 4, 64
-    x, mask, _ = synthetic_batch(B, HW, HW, seed=100 + rank)
-    x, mask = torch.from_numpy(x).to(dev), torch.from_numpy(mask).to(dev)
+    B, HW = 4, 128
+    sd0 = oracle.deterministic_state_dict(phiseg_spec(1, 2, filters), seed=21)
     shapes = oracle.phiseg_eps_shapes(B, HW, HW)
-    eps = [torch.full(tuple(s), 0.1 * (k + 1), device=dev) for k, s in enumerate(list(shapes) + list(shapes))]
 
-    def make(dp):
-        torch.manual_seed(7)
-        net = PHISeg(1, 2, filters, latent_levels=5, image_size=(1, HW, HW))
-        net.train()
-        dist.broadcast(net._ptab.pflat, src=0)
-        if dp:
-            net.set_data_parallel(True)
-        net.enable_graphs(True)
-        return net, FusedAdam(net, lr=1e-3, weight_decay=1e-5)
+    def shard(r):
+        return oracle.synthetic_batch(B, HW, HW, seed=100 + r, eps_shapes=shapes + shapes)
 
-    def step(net, opt):
-        net.forward(x, mask, training=True, eps=eps)
-        loss = net.loss(mask)
+    x, mask, eps = shard(rank)
+    xd, md = torch.from_numpy(x).to(dev), torch.from_numpy(mask).to(dev)
+    ed = [torch.from_numpy(e).to(dev) for e in eps]
+    net = PHISeg(1, 2, filters, latent_levels=5, image_size=(1, HW, HW))
+    net.load_state_dict(sd0)
+    net.train()
+    net.set_data_parallel(True)                            # gloo group -> GradSync's torch backend, same buckets / order
+    net._dp.broadcast_params()
+    net.enable_graphs(True)
+    opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
+
+    def step():
+        net.forward(xd, md, training=True, eps=ed)
+        loss = net.loss(md)
         net.zero_grad()
         loss.backward()
         g = net._ptab.gflat.clone()
         opt.step()
         return g
 
-    net0, opt0 = make(False)
-    g_local = step(net0, opt0)
-    mean = g_local.clone()
-    dist.all_reduce(mean)
-    mean /= world
-    net1, opt1 = make(True)
-    g_dp = step(net1, opt1)
-    dev_rel = float((g_dp - mean).abs().max() / (mean.abs().max() + 1e-30))
+    g_dp = step()
+    # oracle: mean over the ranks' shards of the per-shard gradients (every rank computes all shards on the CPU)
+    ref = None
+    for r in range(world):
+        xr, mr, er = shard(r)
+        lv = G.leaves(sd0)
+        e = [torch.from_numpy(a) for a in er]
+        out = oracle.phiseg_forward(lv, torch.from_numpy(xr), torch.from_numpy(mr), dict(posterior=e[:5], prior=e[5:]))
+        total, _ = oracle.phiseg_loss(out, torch.from_numpy(mr))
+        total.backward()
+        gr = {k: v.grad for k, v in lv.items() if v.requires_grad}
+        ref = gr if ref is None else {k: (None if v is None else v + gr[k]) for k, v in ref.items()}
+    noise = G.bn_shadowed_biases(ref.keys())
+    worst = 0.0
+    for k, v in ref.items():
+        if v is None or k in noise:
+            continue
+        v = v / world
+        mine = net._ptab.gview(k).cpu() if False else g_dp[net._ptab.poff[k]:net._ptab.poff[k] + v.numel()].view(v.shape).cpu()
+        worst = max(worst, float((mine - v).abs().max() / (1e-3 + v.abs().max())))
     for _ in range(2):
-        step(net1, opt1)
-    ref_g, ref_p = g_dp.clone(), net1._ptab.pflat.clone()
+        step()
+    ref_g, ref_p = g_dp.clone(), net._ptab.pflat.clone()
     dist.broadcast(ref_g, src=0)
     dist.broadcast(ref_p, src=0)
-    same = torch.equal(ref_g, g_dp) and torch.equal(ref_p, net1._ptab.pflat)
-    print(f"rank {rank}: identical_across_ranks={same} rel_dev_from_mean_of_local={dev_rel:.3e}", flush=True)
+    same = torch.equal(ref_g, g_dp) and torch.equal(ref_p, net._ptab.pflat)
+    print(f"rank {rank}: identical_across_ranks={same} worst_rel_dev_from_mean_of_oracle_shard_grads={worst:.3e}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
-    sys.exit(0 if (same and dev_rel < 1e-5) else 1)
+    sys.exit(0 if (same and worst < 2e-2) else 1)
 
 
 if __name__ == "__main__":

@@ -59,3 +59,74 @@ def test_shard_bounds_cover_batch():
 def test_single_process_is_a_noop():
     t = torch.arange(4.0)
     assert dp.allreduce_mean_(t.clone()).equal(t)
+
+
+def test_gradient_buckets_follow_the_subnetworks():
+    from unet_zoo_amd.models.phiseg import PHISeg
+    from unet_zoo_amd.models.probabilistic_unet import ProbabilisticUnet
+    from unet_zoo_amd.models.unet import Unet
+    nf7 = [32, 64, 128, 192, 192, 192, 192]
+    net = PHISeg(1, 2, nf7, image_size=(1, 128, 128), device="cpu")
+    b = dp.param_buckets(net._ptab)
+    assert [hi - lo for lo, hi in b] == [9429332, 5655242, 9428756]          # posterior | likelihood | prior
+    assert b[0][0] == 0 and b[-1][1] == net._ptab.n_params and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    pu = ProbabilisticUnet(1, 2, nf7, latent_dim=6, no_convs_fcomb=3, device="cpu")
+    bp = dp.param_buckets(pu._ptab)
+    assert bp[0][0] == 0 and bp[-1][1] == pu._ptab.n_params and all(x[1] == y[0] for x, y in zip(bp, bp[1:])) and len(bp) == 3
+    assert dp.param_buckets(Unet(1, 2, [32, 64, 128, 192], device="cpu")._ptab) == [(0, 2260194)]
+
+
+def test_bucket_events_are_scheduled_behind_every_writer_of_their_bucket():
+    """The data-parallel plan carries one UZ_OP_EVENT_RECORD per bucket; the lane scheduler must order it behind every
+    op that writes a gradient of that bucket (brute-force check of tests/test_host_cpu.py) and may hoist it ahead of the
+    rest of the tape - that hoisting is the overlap."""
+    from tests.test_host_cpu import _check_lane_schedule
+    from unet_zoo_amd.models.phiseg import PHISeg
+    net = PHISeg(1, 2, [4, 8, 8, 8, 8, 8, 8], image_size=(1, 64, 64), device="cpu")
+    net._dp = type("S", (), dict(overlap=True, buckets=dp.param_buckets(net._ptab, min_floats=1)))()
+    plan = net._build(2, 64, 64, True, True)
+    ops = plan.bwd_ops
+    marks = [k for k, o in enumerate(ops) if o["code"] == "UZ_OP_EVENT_RECORD"]
+    assert len(marks) == 3 == len(plan.grad_buckets)
+    _check_lane_schedule(plan, "bwd", ops)
+    for k in marks:
+        b = ops[k]["p"][0][1]
+        lo, hi = plan.grad_buckets[b]
+        writers = [j for j, o in enumerate(ops) for idx in plan._WRITES[o["code"]] if idx < len(o["p"])
+                   for (space, a, c) in plan._resources(o["p"][idx]) if space == ("gflat",) and a < hi and lo < c]
+        assert writers and max(writers) < k
+    assert min(marks) < len(ops) - 3          # at least one bucket is final well before the tape ends
+
+
+def _sync_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dp.init_from_env(backend="gloo")
+    from unet_zoo_amd.models.phiseg import PHISeg
+    torch.manual_seed(0)
+    net = PHISeg(1, 2, [4, 8, 8, 8, 8, 8, 8], image_size=(1, 64, 64), device="cpu")
+    net.set_data_parallel(True)                              # gloo group -> torch backend of GradSync
+    assert net._dp.backend == "torch" and net._dp.world == world
+    net._ptab.pflat.fill_(float(rank))
+    net._dp.broadcast_params()
+    plan = net._build(2, 64, 64, True, True)
+    g = torch.Generator().manual_seed(200 + rank)
+    net._ptab.gflat.copy_(torch.randn(net._ptab.n_params, generator=g))
+    net._dp.sync(plan)
+    np.save(os.path.join(out_dir, f"s{rank}.npy"), torch.cat([net._ptab.gflat, net._ptab.pflat[:4]]).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_buckets_world2_gloo(tmp_path):
+    """N>1 path of the product's gradient exchange (bucket partition, bucket order taken from the scheduled tape,
+    averaging, parameter broadcast) with two gloo ranks: every rank ends with mean_r(g_r)."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_sync_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"s{r}.npy") for r in range(world)]
+    n = got[0].size - 4
+    ref = sum(torch.randn(n, generator=torch.Generator().manual_seed(200 + r)) for r in range(world)) / world
+    for a in got:
+        assert np.allclose(a[:n], ref.numpy(), atol=1e-6)
+        assert np.all(a[n:] == 0.0)
+    assert np.array_equal(got[0], got[1])

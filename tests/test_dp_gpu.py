@@ -19,10 +19,11 @@ def test_two_rank_gradient_allreduce_and_graph_replay_on_device():
 
 
 def test_rccl_backend_world_size_one_step():
-    """The real RCCL backend (world_size 1): init with device_id, parameter broadcast, gradient all-reduce between
-    hipGraph replays and barrier run through on the box's ROCm stack (tools/nccl_world1_check.py)."""
+    """The real RCCL path of the product (world_size 1): uz_comm_* over librccl.so, bucket events inside the backward
+    hipGraph, per-bucket ncclAllReduce(avg) on the communication stream (the collective IS issued), Adam behind the last
+    all-reduce; parameters stay bit-identical to a non-DP run (tools/nccl_world1_check.py)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", UZ_CHECK_BATCH="8")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_world1_check.py")], cwd=root, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "nccl world 1: ms/step" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -38,7 +38,7 @@ def test_phiseg_structure_only_on_cpu_and_no_fallback():
     assert sum(p.numel() for p in net.parameters()) == net._ptab.n_params
     plan = net._build(2, 64, 64, True, True)
     cnt = plan.summary()
-    assert cnt["fwd"] == 287 and cnt["bwd"] > 400
+    assert cnt["fwd"] == 287 + 2 and cnt["bwd"] > 400        # + the two head ops (zero the bound slots, measure the parameter bound)
     unused = sorted(k for k in net._pmap if k not in plan.param_grads)
     assert len(unused) == 16 and all("upsampling_path.4" in k for k in unused)
     if not torch.cuda.is_available():

@@ -63,25 +63,25 @@ def test_conv_fwd_bwd(N, Cin, Cout, H, W, ks):
     from unet_zoo_amd import _ffi
     cws_bytes = _ffi.lib().uz_conv_workspace(Cin, Cout, N, H, W, ks)
     cws = torch.empty(cws_bytes // 4 + 16, device=g.dev())
-    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, yv, Cout, Cout + 4, N, H, W, ks, 0, cws, cws_bytes)
+    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, yv, Cout, Cout + 4, N, H, W, ks, 0, None, None, None, cws, cws_bytes)
     assert g.relerr(ybuf[:, 2:2 + Cout], yr) <= TOL
     assert torch.isnan(ybuf[:, :2]).all() and torch.isnan(ybuf[:, 2 + Cout:]).all()     # neighbours untouched
 
     # fused ReLU epilogue
     y2 = torch.empty(N, Cout, H, W, device=g.dev())
-    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, y2, Cout, Cout, N, H, W, ks, 1, cws, cws_bytes)
+    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, y2, Cout, Cout, N, H, W, ks, 1, None, None, None, cws, cws_bytes)
     assert g.relerr(y2, F.relu(yr)) <= TOL
     # without a workspace the input-channel loop is not split: same result up to summation order
     y3 = torch.empty(N, Cout, H, W, device=g.dev())
-    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, y3, Cout, Cout, N, H, W, ks, 1, None, 0)
+    g.call("uz_conv_fwd", xv, Cin, Cin + 5, wd, bd, y3, Cout, Cout, N, H, W, ks, 1, None, None, None, None, 0)
     assert g.relerr(y3, F.relu(yr)) <= TOL
 
     # data gradient, overwrite then accumulate
     dyd = dy.to(g.dev())
     dx = torch.full((N, Cin, H, W), float("nan"), device=g.dev())
-    g.call("uz_conv_bwd_data", dyd, Cout, Cout, wd, dx, Cin, Cin, N, H, W, ks, 0, cws, cws_bytes)
+    g.call("uz_conv_bwd_data", dyd, Cout, Cout, wd, dx, Cin, Cin, N, H, W, ks, 0, None, None, cws, cws_bytes)
     assert g.relerr(dx, xr.grad) <= TOL
-    g.call("uz_conv_bwd_data", dyd, Cout, Cout, wd, dx, Cin, Cin, N, H, W, ks, 1, cws, cws_bytes)
+    g.call("uz_conv_bwd_data", dyd, Cout, Cout, wd, dx, Cin, Cin, N, H, W, ks, 1, None, None, cws, cws_bytes)
     assert g.relerr(dx, 2 * xr.grad) <= TOL
 
     # weight + bias gradient (deterministic split-K): run twice, must be bitwise identical
@@ -89,11 +89,11 @@ def test_conv_fwd_bwd(N, Cin, Cout, H, W, ks):
     ws = torch.empty(ws_bytes // 4 + 16, device=g.dev())
     dw = torch.full_like(wd, float("nan"))
     db = torch.full_like(bd, float("nan"))
-    g.call("uz_conv_bwd_weight", xv, Cin, Cin + 5, dyd, Cout, Cout, dw, db, N, H, W, ks, ws, ws_bytes)
+    g.call("uz_conv_bwd_weight", xv, Cin, Cin + 5, dyd, Cout, Cout, dw, db, N, H, W, ks, None, None, ws, ws_bytes)
     assert g.relerr(dw, wr.grad) <= TOL
     assert g.relerr(db, br.grad) <= TOL
     dw2 = torch.empty_like(dw)
-    g.call("uz_conv_bwd_weight", xv, Cin, Cin + 5, dyd, Cout, Cout, dw2, None, N, H, W, ks, ws, ws_bytes)
+    g.call("uz_conv_bwd_weight", xv, Cin, Cin + 5, dyd, Cout, Cout, dw2, None, N, H, W, ks, None, None, ws, ws_bytes)
     assert torch.equal(dw, dw2)
 
 
@@ -108,7 +108,7 @@ def test_conv_full_size_linearity():
     w = torch.randn(Cout, Cin, 3, 3, device=g.dev()) * 0.05
     out = [torch.empty(N, Cout, H, W, device=g.dev()) for _ in range(3)]
     for xin, o in zip((x1, x2, x1 + 2 * x2), out):
-        g.call("uz_conv_fwd", xin, Cin, Cin, w, None, o, Cout, Cout, N, H, W, 3, 0, None, 0)
+        g.call("uz_conv_fwd", xin, Cin, Cin, w, None, o, Cout, Cout, N, H, W, 3, 0, None, None, None, None, 0)
     assert g.relerr(out[2], out[0] + 2 * out[1]) <= 1e-5
     ref = F.conv2d(x1[5:7].cpu(), w.cpu(), None, padding=1)
     assert g.relerr(out[0][5:7], ref) <= TOL
@@ -137,14 +137,14 @@ def test_bn_relu_fwd_bwd(N, C, H, W, relu):
     av = abuf[:, 2:]
     gd, bd, rmd, rvd = gamma.to(g.dev()), beta.to(g.dev()), rm.to(g.dev()), rv.to(g.dev())
     save = torch.empty(2 * C, device=g.dev())
-    g.call("uz_bn_relu_fwd", yv, C, C + 3, gd, bd, rmd, rvd, save, av, C + 2, N, H, W, 1e-3, 0.01, 1, relu, ws)
+    g.call("uz_bn_relu_fwd", yv, C, C + 3, gd, bd, rmd, rvd, save, av, C + 2, N, H, W, 1e-3, 0.01, 1, relu, None, ws)
     assert g.maxabs(abuf[:, 2:], ar) <= 2e-5
     assert g.maxabs(rmd, rm_r) <= 1e-6 and g.maxabs(rvd, rv_r) <= 1e-5
 
     dad = da.to(g.dev())
     dy = torch.empty(N, C, H, W, device=g.dev())
     dgm, dbt, dbias = (torch.empty(C, device=g.dev()) for _ in range(3))
-    g.call("uz_bn_relu_bwd", dad, C, yv, C, C + 3, gd, bd, save, dy, C, dgm, dbt, dbias, N, H, W, relu, ws)
+    g.call("uz_bn_relu_bwd", dad, C, yv, C, C + 3, gd, bd, save, dy, C, dgm, dbt, dbias, N, H, W, relu, None, ws)
     scale = float(yr.grad.abs().max())
     assert g.maxabs(dy, yr.grad) <= 3e-5 * max(scale, 1.0)
     assert g.relerr(dgm, gr.grad) <= 1e-4 and g.relerr(dbt, br.grad) <= 1e-4
@@ -153,7 +153,7 @@ def test_bn_relu_fwd_bwd(N, C, H, W, relu):
     # eval mode uses the running statistics
     oe = F.batch_norm(y, rm_r, rv_r, gamma, beta, training=False, eps=1e-3)
     ae = F.relu(oe) if relu else oe
-    g.call("uz_bn_relu_fwd", yv, C, C + 3, gd, bd, rm_r.to(g.dev()), rv_r.to(g.dev()), None, av, C + 2, N, H, W, 1e-3, 0.01, 0, relu, ws)
+    g.call("uz_bn_relu_fwd", yv, C, C + 3, gd, bd, rm_r.to(g.dev()), rv_r.to(g.dev()), None, av, C + 2, N, H, W, 1e-3, 0.01, 0, relu, None, ws)
     assert g.maxabs(abuf[:, 2:], ae) <= 2e-5
 
 
@@ -166,7 +166,7 @@ def test_relu_bwd():
     ws = torch.empty(_ffi.lib().uz_bn_workspace(C, N, H, W) // 4 + 16, device=g.dev())
     dy = torch.empty(N, C, H, W, device=g.dev())
     db = torch.empty(C, device=g.dev())
-    g.call("uz_relu_bwd", da.to(g.dev()), C, a.to(g.dev()), C, C, dy, C, db, N, H, W, ws)
+    g.call("uz_relu_bwd", da.to(g.dev()), C, a.to(g.dev()), C, C, dy, C, db, N, H, W, None, ws)
     ref = da * (a > 0)
     assert torch.equal(dy.cpu(), ref)
     assert g.relerr(db, ref.sum((0, 2, 3))) <= 1e-5
@@ -182,7 +182,7 @@ def test_avgpool(H, W):
     dy = g.rnd(*yr.shape, seed=2)
     yr.backward(dy)
     y = torch.empty(*yr.shape, device=g.dev())
-    g.call("uz_avgpool2_fwd", x.detach().to(g.dev()), C, C, y, C, N, H, W)
+    g.call("uz_avgpool2_fwd", x.detach().to(g.dev()), C, C, y, C, N, H, W, None, None)
     assert g.maxabs(y, yr) <= 1e-6
     dx = torch.ones(N, C, H, W, device=g.dev())
     g.call("uz_avgpool2_bwd", dy.to(g.dev()), C, C, dx, C, N, H, W, 1)
@@ -199,7 +199,7 @@ def test_bilinear(ac, H, W):
     dy = g.rnd(*yr.shape, seed=2)
     yr.backward(dy)
     y = torch.empty(*yr.shape, device=g.dev())
-    g.call("uz_bilinear2x_fwd", x.detach().to(g.dev()), C, C, y, C, N, H, W, ac)
+    g.call("uz_bilinear2x_fwd", x.detach().to(g.dev()), C, C, y, C, N, H, W, ac, None, None)
     assert g.maxabs(y, yr) <= 2e-6
     dx = torch.full((N, C, H, W), float("nan"), device=g.dev())
     g.call("uz_bilinear2x_bwd", dy.to(g.dev()), C, C, dx, C, N, H, W, ac, 0)
@@ -364,8 +364,8 @@ def test_l2_norms():
     assert g.relerr(grad[100:750], 1e-5 * flat[100:750] / ref[1]) <= 1e-5
 
 
-def test_conv_split_bf16_math_on_every_conv_shape():
-    """The split-bf16 kernels (conv_split.hip: three bf16 pieces per fp32 operand, six products, fp32
+def test_conv_split_fp16_math_on_every_conv_shape():
+    """The split-fp16 kernels (conv_split.hip: two fp16 pieces per scaled fp32 operand, three products, fp32
     accumulate) normally take only the large layers.  UZ_CONV_MATH=split forces them onto every 3x3
     shape - ragged tiles, 1..3-channel inputs, K tails, channel-tile overhang - and the same parity
     assertions (same tolerance as the fp32-MFMA kernels) must hold.  The switch is read once per

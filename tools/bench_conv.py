@@ -24,11 +24,11 @@ def t(fn):
         e0.record(); fn(); e1.record(); e1.synchronize(); best = min(best, e0.elapsed_time(e1))
     return best
 if which in ("all", "fwd"):
-    ms = t(lambda: _ffi.check(L.uz_conv_fwd(x.data_ptr(), Cin, Cin, w.data_ptr(), None, y.data_ptr(), Cout, Cout, N, H, W, ks, 0, ws.data_ptr(), wsb, st), "fwd"))
+    ms = t(lambda: _ffi.check(L.uz_conv_fwd(x.data_ptr(), Cin, Cin, w.data_ptr(), None, y.data_ptr(), Cout, Cout, N, H, W, ks, 0, None, None, None, ws.data_ptr(), wsb, st), "fwd"))
     print(f"fwd   {ms*1e3:9.1f} us {fl/ms/1e9:7.1f} TF/s")
 if which in ("all", "dgrad"):
-    ms = t(lambda: _ffi.check(L.uz_conv_bwd_data(dy.data_ptr(), Cout, Cout, w.data_ptr(), dx.data_ptr(), Cin, Cin, N, H, W, ks, 0, ws.data_ptr(), wsb, st), "dgrad"))
+    ms = t(lambda: _ffi.check(L.uz_conv_bwd_data(dy.data_ptr(), Cout, Cout, w.data_ptr(), dx.data_ptr(), Cin, Cin, N, H, W, ks, 0, None, None, ws.data_ptr(), wsb, st), "dgrad"))
     print(f"dgrad {ms*1e3:9.1f} us {fl/ms/1e9:7.1f} TF/s")
 if which in ("all", "wgrad"):
-    ms = t(lambda: _ffi.check(L.uz_conv_bwd_weight(x.data_ptr(), Cin, Cin, dy.data_ptr(), Cout, Cout, dw.data_ptr(), None, N, H, W, ks, ws.data_ptr(), wsb, st), "wgrad"))
+    ms = t(lambda: _ffi.check(L.uz_conv_bwd_weight(x.data_ptr(), Cin, Cin, dy.data_ptr(), Cout, Cout, dw.data_ptr(), None, N, H, W, ks, None, None, ws.data_ptr(), wsb, st), "wgrad"))
     print(f"wgrad {ms*1e3:9.1f} us {fl/ms/1e9:7.1f} TF/s")

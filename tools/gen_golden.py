@@ -413,6 +413,47 @@ def init_moment_cases():
     print("wrote init_moments:", {k: len(v) for k, v in meta.items()})
 
 
+def phiseg_f64_case(name, filters, hw, batch, seed, n_samp=256):
+    """fp64 ground truth of the REAL reference on the headline configuration: the reference model run in double precision
+    (net.double()) next to its own fp32 run, same weights / inputs / noise.  Stored per parameter tensor: up to `n_samp`
+    sampled gradient entries in fp64 and in the reference's fp32, so that a test can measure any implementation's error
+    against the real-valued graph and compare it with the reference's OWN fp32 error on the same entries."""
+    shapes = phiseg_eps_shapes(batch, hw, hw)
+    x, mask, eps = synthetic_batch(batch, hw, hw, seed=20201004, eps_shapes=shapes + shapes)
+    rs = np.random.Generator(np.random.PCG64(11))
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        net = PHISeg(input_channels=1, num_classes=2, num_filters=filters, latent_levels=5, image_size=(1, hw, hw))
+        spec = kinds_for(net.state_dict())
+        net.load_state_dict(deterministic_state_dict(spec, seed=seed))
+        net = net.to(dt)
+        net.train()
+        with NoiseFeeder([torch.from_numpy(e).to(dt) for e in eps]):
+            s_list = net.forward(torch.from_numpy(x).to(dt), torch.from_numpy(mask).to(dt), training=True)
+        loss = net.loss(torch.from_numpy(mask).to(dt))
+        loss.backward()
+        res[dt] = (float(loss), [t.detach() for t in s_list], {n: (None if p.grad is None else p.grad.detach()) for n, p in net.named_parameters()})
+        del net
+    arrays, meta = {}, dict(model="PHISeg", filters=filters, hw=hw, batch=batch, weight_seed=seed,
+                            spec=[[k, list(s), kd] for k, s, kd in spec], loss32=res[torch.float32][0], loss64=res[torch.float64][0])
+    idx = rs.integers(0, batch * 2 * hw * hw, size=1024)
+    arrays["s_idx"] = idx
+    for l in range(5):
+        arrays[f"s{l}_f64"] = res[torch.float64][1][l].numpy().reshape(-1)[idx]
+        arrays[f"s{l}_f32"] = res[torch.float32][1][l].numpy().reshape(-1)[idx]
+    for k, g64 in res[torch.float64][2].items():
+        if g64 is None:
+            continue
+        g32 = res[torch.float32][2][k]
+        flat = g64.reshape(-1)
+        pick = np.arange(flat.numel()) if flat.numel() <= n_samp else np.sort(rs.choice(flat.numel(), size=n_samp, replace=False))
+        arrays["i:" + k] = pick.astype(np.int64)
+        arrays["g64:" + k] = flat.numpy()[pick]
+        arrays["g32:" + k] = g32.reshape(-1).numpy()[pick]
+        arrays["m64:" + k] = np.array([float(g64.abs().max()), float(g64.double().norm())])
+    save(name, arrays, meta)
+
+
 def op_cases():
     """G1: reference-authored arithmetic that is not a stock torch op."""
     rs = np.random.Generator(np.random.PCG64(99))
@@ -486,6 +527,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "b32":
         # BASELINE config 4 exactly (batch 32): digests only, inputs are regenerated from the seed
         phiseg_case("phiseg_full_b32_digest", [32, 64, 128, 192, 192, 192, 192], 128, 32, 1, False, 1238, store_inputs=False)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "f64":
+        b = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+        phiseg_f64_case("phiseg_full_b%d_f64" % b, [32, 64, 128, 192, 192, 192, 192], 128, b, 1238)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "init":
         init_moment_cases()

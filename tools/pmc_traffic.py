@@ -19,9 +19,9 @@ wsb = max(L.uz_conv_bwd_weight_workspace(Cin, Cout, N, H, W, ks), L.uz_conv_work
 ws = torch.zeros(wsb // 4 + 64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
-    _ffi.check(L.uz_conv_fwd(x.data_ptr(), Cin, Cin, w.data_ptr(), None, y.data_ptr(), Cout, Cout, N, H, W, ks, 0, ws.data_ptr(), wsb, st), "fwd")
-    _ffi.check(L.uz_conv_bwd_data(dy.data_ptr(), Cout, Cout, w.data_ptr(), dx.data_ptr(), Cin, Cin, N, H, W, ks, 0, ws.data_ptr(), wsb, st), "dgrad")
-    _ffi.check(L.uz_conv_bwd_weight(x.data_ptr(), Cin, Cin, dy.data_ptr(), Cout, Cout, dw.data_ptr(), db.data_ptr(), N, H, W, ks, ws.data_ptr(), wsb, st), "wgrad")
+    _ffi.check(L.uz_conv_fwd(x.data_ptr(), Cin, Cin, w.data_ptr(), None, y.data_ptr(), Cout, Cout, N, H, W, ks, 0, None, None, None, ws.data_ptr(), wsb, st), "fwd")
+    _ffi.check(L.uz_conv_bwd_data(dy.data_ptr(), Cout, Cout, w.data_ptr(), dx.data_ptr(), Cin, Cin, N, H, W, ks, 0, None, None, ws.data_ptr(), wsb, st), "dgrad")
+    _ffi.check(L.uz_conv_bwd_weight(x.data_ptr(), Cin, Cin, dy.data_ptr(), Cout, Cout, dw.data_ptr(), db.data_ptr(), N, H, W, ks, None, None, ws.data_ptr(), wsb, st), "wgrad")
 # memory-bound class: BatchNorm(train)+ReLU forward / backward on a 128-channel 128x128 plane set (large path)
 C = 128
 yb = torch.randn(N, C, H, W, device=dev); ab = torch.empty_like(yb); dab = torch.randn_like(yb); dyb = torch.empty_like(yb)
@@ -32,9 +32,9 @@ bws = torch.zeros(L.uz_bn_workspace(C, N, H, W) // 4 + 64, device=dev)
 import ctypes as Cc
 for _ in range(2):
     _ffi.check(L.uz_bn_relu_fwd(yb.data_ptr(), C, C, gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(), save.data_ptr(), ab.data_ptr(), C,
-                                N, H, W, Cc.c_float(1e-3), Cc.c_float(0.01), 1, 1, bws.data_ptr(), st), "bn fwd")
+                                N, H, W, Cc.c_float(1e-3), Cc.c_float(0.01), 1, 1, None, bws.data_ptr(), st), "bn fwd")
     _ffi.check(L.uz_bn_relu_bwd(dab.data_ptr(), C, yb.data_ptr(), C, C, gam.data_ptr(), bet.data_ptr(), save.data_ptr(), dyb.data_ptr(), C,
-                                dg.data_ptr(), dbt.data_ptr(), dbi.data_ptr(), N, H, W, 1, bws.data_ptr(), st), "bn bwd")
+                                dg.data_ptr(), dbt.data_ptr(), dbi.data_ptr(), N, H, W, 1, None, bws.data_ptr(), st), "bn bwd")
 torch.cuda.synchronize()
 print("bn plane bytes", yb.numel() * 4)
 print("algorithmic bytes: x", x.numel() * 4, "y", y.numel() * 4, "w", w.numel() * 4, "calibration read (dy)", dy.numel() * 4)

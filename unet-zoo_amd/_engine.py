@@ -82,7 +82,11 @@ class NativeModel(nn.Module):
         return p
 
     def _new_plan(self, N, bn_training):
-        return Plan(N, self._ptab, bn_training, self.device)
+        plan = Plan(N, self._ptab, bn_training, self.device)
+        dp = getattr(self, "_dp", None)
+        if dp is not None and dp.overlap:
+            plan.grad_buckets = list(dp.buckets)
+        return plan
 
     def enable_graphs(self, flag=True):
         """Replay forward/backward tapes as captured hipGraphs (one graph launch instead of ~1000
@@ -118,11 +122,17 @@ class NativeModel(nn.Module):
         _ffi.check(plan.L.uz_graph_launch(g, C.c_void_p(self._stream())), f"graph launch '{which}'")
 
     # ------------------------------------------------------------------ backward
-    def set_data_parallel(self, group=True, overlap=True):
-        """Average gradients over the ranks of a torch.distributed process group (RCCL on ROCm)
-        right after the backward tape - one all-reduce of the flat fp32 gradient buffer."""
+    def set_data_parallel(self, group=True, overlap=True, backend=None):
+        """Average gradients over the ranks (one process per GPU) inside loss.backward(): the flat fp32 gradient buffer
+        is all-reduced bucket by bucket (one bucket per sub-network) over RCCL, each bucket as soon as the backward tape
+        has finished it, on a communication stream beside the remaining backward kernels (dp.GradSync).  `group`: a
+        torch.distributed group or True for the default group; backend None picks RCCL through the C ABI when the
+        process group runs on nccl, torch.distributed collectives otherwise (gloo test double)."""
+        from . import dp
         self._dp_group = group
-        self._dp_overlap = bool(overlap)
+        self._dp = dp.GradSync(self, None if group is True else group, backend=backend, overlap=overlap)
+        self._plans.clear()                # plans built before this call carry no bucket events
+        self._graphs.clear()
 
     def _run_backward(self, plan, gout):
         plan.loss_scale_t.copy_(gout.reshape(1).to(torch.float32))
@@ -138,9 +148,8 @@ class NativeModel(nn.Module):
         if prev is not None:
             gflat.add_(prev)
         self._post_backward(plan)
-        if self._dp_group is not None:
-            from . import dp
-            dp.allreduce_mean_(self._ptab.gflat, None if self._dp_group is True else self._dp_group)
+        if getattr(self, "_dp", None) is not None:
+            self._dp.sync(plan, serial=prev is not None)
         for key in plan.param_grads:
             p = self._pmap[key]
             g = self._ptab.gview(key)

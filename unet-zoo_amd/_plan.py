@@ -82,11 +82,12 @@ class ParamTable:
 
 
 class Buf:
-    __slots__ = ("name", "N", "C", "H", "W", "off", "gbuf", "requires_grad")
+    __slots__ = ("name", "N", "C", "H", "W", "off", "gbuf", "requires_grad", "amax", "amax_cov")
 
     def __init__(self, name, N, C, H, W, requires_grad=True):
         self.name, self.N, self.C, self.H, self.W = name, int(N), int(C), int(H), int(W)
         self.off, self.gbuf, self.requires_grad = None, None, requires_grad
+        self.amax, self.amax_cov = None, []      # magnitude-bound slot and the channel ranges whose producers maintain it
 
     @property
     def numel(self):
@@ -146,6 +147,14 @@ class Plan:
         self.param_grads = []               # parameter keys that receive a gradient, in write order
         self.named = {}                     # user-visible tensors: name -> View
         self.finalized = False
+        # Magnitude bounds for the split-fp16 convolutions: slot 0 bounds |parameters| (measured at the head of the forward
+        # tape), one slot per activation buffer (atomic-max maintained by the kernels that write it) and one per Conv unit for
+        # the gradient w.r.t. its output.  Forward-side slots are zeroed at the head of the forward tape, backward-side slots
+        # at the head of the backward tape.
+        self.n_amax, self.n_amax_fwd = 1, None
+        self._amax_bwd = []                 # slot indices used by backward producers
+        self.grad_buckets = []              # [(lo, hi)] float ranges of the flat gradient buffer that get a "final" event (data parallel)
+        self.events = []                    # hipEvent_t handles (uz_event_create), one per gradient bucket
         self._gid = 0                       # scheduling group of the ops being emitted (see _schedule)
         self.n_lanes = max(1, min(int(os.environ.get("UZ_LANES", "2")), 8))
 
@@ -168,6 +177,35 @@ class Plan:
             self.bufs.append(g)
             v.buf.gbuf = g
         return View(v.buf.gbuf, v.c0, v.C)
+
+    # ------------------------------------------------------------------ magnitude bounds
+    def _new_amax(self, bwd=False):
+        k = self.n_amax
+        self.n_amax += 1
+        if bwd:
+            self._amax_bwd.append(k)
+        return k
+
+    def amax_out(self, v):
+        """Slot reference a producer of view `v` accumulates max|v| into (creates the buffer's slot on first use)."""
+        if isinstance(v, _ScratchView):
+            return ("amax", v.amax) if v.amax is not None else None
+        b = v.buf
+        if b.amax is None:
+            b.amax = self._new_amax()
+        b.amax_cov.append((v.c0, v.c0 + v.C))
+        return ("amax", b.amax)
+
+    def amax_in(self, v):
+        """Slot reference bounding |v| for a consumer, or None when some producer of its channels keeps no bound
+        (the kernel then measures the tensor itself)."""
+        if isinstance(v, _ScratchView):
+            return ("amax", v.amax) if v.amax is not None else None
+        b = v.buf
+        if b.amax is None:
+            return None
+        ok = all(any(a <= c < e for a, e in b.amax_cov) for c in range(v.c0, v.c0 + v.C))
+        return ("amax", b.amax) if ok else None
 
     def _claim(self, v):
         """Returns the accumulate flag for a backward write to grad(v) and records the region."""
@@ -241,7 +279,8 @@ class Plan:
         self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
         self._newgroup()
         self._emit(self.target, "UZ_OP_CONV_FWD",
-                   p=[x, self.P(wkey, wextra), self.P(bkey, wrow0) if bkey else None, y, ("scratch", "wgrad")],
+                   p=[x, self.P(wkey, wextra), self.P(bkey, wrow0) if bkey else None, y, ("scratch", "wgrad"),
+                      self.amax_in(x), ("amax", 0), self.amax_out(y) if (relu and ks == 3) else None],
                    i=[cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, ks, relu], n=ws)
 
     def _conv_bwd(self, x, wkey, gy, ks, db_key=None, wrow0=0):
@@ -252,14 +291,15 @@ class Plan:
         ws = self.L.uz_conv_bwd_weight_workspace(cin, cout, x.N, x.H, x.W, ks)
         self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
         self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
-                   p=[x, gy, self.G(wkey, wextra), self.G(db_key, wrow0) if db_key else None, ("scratch", "wgrad")],
+                   p=[x, gy, self.G(wkey, wextra), self.G(db_key, wrow0) if db_key else None, ("scratch", "wgrad"),
+                      self.amax_in(x), self.amax_in(gy)],
                    i=[cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, ks], n=ws)
         if x.buf.requires_grad:
             acc = self._claim(x)
             ws2 = self.L.uz_conv_workspace(cin, cout, x.N, x.H, x.W, ks)
             self.scratch["wgrad"] = max(self.scratch["wgrad"], ws2)
             self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
-                       p=[gy, self.P(wkey, wextra), self.gview(x), ("scratch", "wgrad")],
+                       p=[gy, self.P(wkey, wextra), self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0)],
                        i=[cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, ks, acc], n=ws2)
 
     def _gy_scratch(self, like):
@@ -281,7 +321,7 @@ class Plan:
         gam, bet = bprefix + ".weight", bprefix + ".bias"
         self._emit(self.target, "UZ_OP_BN_RELU_FWD",
                    p=[y, self.P(gam), self.P(bet), self.B(bprefix + ".running_mean"), self.B(bprefix + ".running_var"),
-                      save, a, ("scratch", "bn")],
+                      save, a, ("scratch", "bn"), self.amax_out(a)],
                    i=[cout, y.Ctot, a.Ctot, x.N, x.H, x.W, int(self.bn_training), int(relu)], f=[BN_EPS, BN_MOMENTUM])
 
         def bwd():
@@ -290,9 +330,10 @@ class Plan:
             if not self.bn_training:
                 raise RuntimeError("backward through eval-mode BatchNorm is not supported")
             gy = self._gy_scratch(y)
-            gyv = _ScratchView(y.N, cout, y.H, y.W)
+            gyv = _ScratchView(y.N, cout, y.H, y.W, amax=self._new_amax(bwd=True))
             self._emit(self.bwd_ops, "UZ_OP_BN_RELU_BWD",
-                       p=[self.gview(a), y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), self.G(bkey), ("scratch", "bn")],
+                       p=[self.gview(a), y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), self.G(bkey), ("scratch", "bn"),
+                          ("amax", gyv.amax)],
                        i=[a.Ctot, cout, y.Ctot, cout, x.N, x.H, x.W, int(relu)])
             self._conv_bwd(x, wkey, gyv, ks)
         self._push_bwd(bwd)
@@ -310,9 +351,9 @@ class Plan:
             if not self._has_grad(a):
                 return
             gy = self._gy_scratch(a)
-            gyv = _ScratchView(a.N, cout, a.H, a.W)
+            gyv = _ScratchView(a.N, cout, a.H, a.W, amax=self._new_amax(bwd=True))
             self._emit(self.bwd_ops, "UZ_OP_RELU_BWD",
-                       p=[self.gview(a), a, gy, self.G(bkey), ("scratch", "bn")],
+                       p=[self.gview(a), a, gy, self.G(bkey), ("scratch", "bn"), ("amax", gyv.amax)],
                        i=[a.Ctot, cout, a.Ctot, cout, x.N, x.H, x.W])
             self._conv_bwd(x, wkey, gyv, ks)
         self._push_bwd(bwd)
@@ -339,7 +380,12 @@ class Plan:
     # ------------------------------------------------------------------ resampling
     def _resample(self, fcode, bcode, x, y, extra_i=()):
         self._newgroup()
-        self._emit(self.target, fcode, p=[x, y], i=[x.C, x.Ctot, y.Ctot, x.N, x.H, x.W, *extra_i])
+        pp = [x, y]
+        if fcode in ("UZ_OP_AVGPOOL_FWD", "UZ_OP_BILINEAR_FWD"):
+            # pooling and interpolation are convex combinations: the output inherits the input's magnitude bound
+            xin = self.amax_in(x)
+            pp += [xin, self.amax_out(y) if xin is not None else None]
+        self._emit(self.target, fcode, p=pp, i=[x.C, x.Ctot, y.Ctot, x.N, x.H, x.W, *extra_i])
 
         def bwd():
             if not self._has_grad(y) or not x.buf.requires_grad:
@@ -490,7 +536,30 @@ class Plan:
             for fn in self._bwd_tail:
                 self._newgroup()
                 fn()
+            # data parallel: one event per gradient bucket, recorded as soon as every writer of that slice of the flat
+            # gradient buffer is done (the scheduler hoists the marker to that point of the DAG); the communication
+            # stream waits for it and all-reduces the bucket beside the rest of the backward tape
+            for b, (lo, hi) in enumerate(self.grad_buckets):
+                self._newgroup()
+                self._emit(self.bwd_ops, "UZ_OP_EVENT_RECORD", p=[("event", b), ("gflat_range", lo, hi)])
         self._bwd = []
+        # magnitude-bound slots: zero the forward-side slots and measure the parameter bound at the head of the forward tape,
+        # zero the backward-side slots at the head of the backward tape (group 0 of each tape: everything else depends on it)
+        self.n_amax_fwd = self.n_amax
+        bwd_slots = sorted(self._amax_bwd)
+        fwd_slots = [k for k in range(self.n_amax) if k not in set(bwd_slots)]
+        # renumber so that forward slots are [0, nf) and backward slots [nf, n): one memset each
+        remap = {k: i for i, k in enumerate(fwd_slots + bwd_slots)}
+        self._amax_remap, self.n_amax_fwd = remap, len(fwd_slots)
+        head = self._gid = -1
+        if self.fwd_ops:
+            ops0 = []
+            ops0.append(dict(code="UZ_OP_MEMSET", p=[("amaxrange", 0, self.n_amax_fwd)], i=[], f=[], n=4 * self.n_amax_fwd, gid=head))
+            ops0.append(dict(code="UZ_OP_ABSMAX", p=[("pflat",), ("amaxw", 0)], i=[], f=[], n=self.ptab.n_params, gid=head))
+            self.fwd_ops[:0] = ops0
+        if self.bwd_ops and bwd_slots:
+            self.bwd_ops[:0] = [dict(code="UZ_OP_MEMSET", p=[("amaxrange", self.n_amax_fwd, self.n_amax)], i=[], f=[],
+                                     n=4 * (self.n_amax - self.n_amax_fwd), gid=head)]
         # arena layout
         off = 0
         for b in self.bufs:
@@ -506,6 +575,13 @@ class Plan:
                 so[k] = off
                 off += -(-(self.scratch[k] // 4 + 1) // _ALIGN) * _ALIGN
             self.scratch_off.append(so)
+        if self.grad_buckets and self.device.type == "cuda":
+            for _ in self.grad_buckets:
+                h = C.c_void_p()
+                _ffi.check(self.L.uz_event_create(C.byref(h), 0), "event_create")
+                self.events.append(h.value)
+        self.amax_off = off
+        off += -(-self.n_amax // _ALIGN) * _ALIGN
         self.arena_floats = off
         self.arena = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.base = self.arena.data_ptr()
@@ -556,6 +632,16 @@ class Plan:
             return self.ptrtab.data_ptr() + 8 * self._tab_off[r[1]]
         if kind == "raw":
             return int(r[1])
+        if kind == "amax":
+            return self.base + 4 * (self.amax_off + self._amax_remap[r[1]])
+        if kind == "amaxw":
+            return self.base + 4 * (self.amax_off + self._amax_remap[0])
+        if kind == "amaxrange":
+            return self.base + 4 * (self.amax_off + r[1])
+        if kind == "event":
+            return self.events[r[1]] if self.events else 0
+        if kind == "gflat_range":
+            return 0
         raise ValueError(r)
 
     def _materialize(self, ops):
@@ -585,7 +671,7 @@ class Plan:
         "UZ_OP_KL_FWD": (4,), "UZ_OP_KL_BWD": (5, 6, 7, 8), "UZ_OP_CE_FWD": (2,), "UZ_OP_CE_BWD": (1,),
         "UZ_OP_SUM_TERMS": (1,), "UZ_OP_SCALE": (0,), "UZ_OP_COPY": (0,), "UZ_OP_MEMSET": (0,),
         "UZ_OP_L2_NORMS": (2,), "UZ_OP_L2_NORMS_BWD": (4,),
-        "UZ_OP_BCAST_CHANNELS": (1,), "UZ_OP_BCAST_CHANNELS_BWD": (1,),
+        "UZ_OP_BCAST_CHANNELS": (1,), "UZ_OP_BCAST_CHANNELS_BWD": (1,), "UZ_OP_EVENT_RECORD": (0,), "UZ_OP_ABSMAX": (1,),
     }
 
     def _resources(self, r):
@@ -604,6 +690,21 @@ class Plan:
             return [(("bnbuf", r[1]), 0, 1)]
         if kind == "ptrtab":
             return [x for q in self.ptr_tables[r[1]] for x in self._resources(q)]
+        if kind == "amax":
+            # Bound slots are atomic-max accumulated by the same kernels that write the data they bound, so every
+            # producer -> consumer order is already implied by the data buffers; only the zeroing (and the parameter-bound
+            # measurement) at the head of the tape must come first.  Producers and consumers therefore both count as READERS
+            # of the slot (no false write-write serialisation between the producers of one concat buffer).
+            return [(("amax",), r[1], r[1] + 1)]
+        if kind == "amaxw":
+            return [(("amax",), 0, 1)]
+        if kind == "amaxrange":
+            inv = {v: k for k, v in self._amax_remap.items()}
+            return [(("amax",), inv[j], inv[j] + 1) for j in range(r[1], r[2])]
+        if kind == "gflat_range":
+            return [(("gflat",), r[1], r[2])]
+        if kind == "event":
+            return [(("event", r[1]), 0, 1)]
         if kind in ("param", "pflat", "scratch", "gyview", "raw"):
             return []
         raise ValueError(r)
@@ -723,6 +824,9 @@ class Plan:
         blevel = [0.0] * G
         for gi in reversed(range(G)):
             blevel[gi] = cost[gi] + max((blevel[sg] for sg in succ[gi]), default=0.0)
+        for gi, (a, b) in enumerate(groups):
+            if any(o["code"] == "UZ_OP_EVENT_RECORD" for o in ops[a:b + 1]):
+                blevel[gi], cost[gi] = 1e9, 1e-7      # bucket-final markers cost nothing and must fire the moment their bucket is done
         t, running = 0.0, []
         while len(order) < G:
             running = [(f, g) for f, g in running if f > t + 1e-12]
@@ -817,6 +921,7 @@ class Plan:
 
 class _ScratchView:
     """Shape carrier for the shared dy scratch (gradient w.r.t. a conv output, consumed at once)."""
-    def __init__(self, N, C, H, W):
+    def __init__(self, N, C, H, W, amax=None):
         self.N, self.C, self.H, self.W, self.Ctot = N, C, H, W, C
         self.buf = None
+        self.amax = amax          # magnitude-bound slot of this unit's dy

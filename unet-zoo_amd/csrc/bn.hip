@@ -11,6 +11,7 @@
 // Statistics are accumulated in fp64 so that E[y^2]-E[y]^2 carries no cancellation error into the
 // 30+ stacked normalisations of PHiSeg.
 #include "uz_common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -27,6 +28,7 @@ struct BnP {
     int nb, ngrp;                                      // reduction kernels: images per workgroup, number of image groups
     float eps, momentum;
     int training, relu;
+    float* amax;                                       // nullable: atomic max of |out| (bound for a following split-fp16 convolution)
 };
 
 __device__ __forceinline__ void alpha_beta(const BnP& p, int c, float& alpha, float& beta_, float& mean, float& rstd) {
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
     float* dst = p.out + ((size_t)b * p.CtotOut + c) * p.HW;
     const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
     const float floor_ = p.relu ? 0.f : -INFINITY;
+    float vmax = 0.f;
     if (VEC) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
         float4* d4 = reinterpret_cast<float4*>(dst);
@@ -127,10 +130,16 @@ __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
             v.x = fmaxf(fmaf(v.x, alpha, beta_), floor_); v.y = fmaxf(fmaf(v.y, alpha, beta_), floor_);
             v.z = fmaxf(fmaf(v.z, alpha, beta_), floor_); v.w = fmaxf(fmaf(v.w, alpha, beta_), floor_);
             d4[i] = v;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
     } else {
-        for (int i = lo + threadIdx.x; i < hi; i += 256) dst[i] = fmaxf(fmaf(src[i], alpha, beta_), floor_);
+        for (int i = lo + threadIdx.x; i < hi; i += 256) {
+            const float v = fmaxf(fmaf(src[i], alpha, beta_), floor_);
+            dst[i] = v;
+            vmax = fmaxf(vmax, fabsf(v));
+        }
     }
+    if (p.amax) uz::amax_publish(vmax, p.amax);
 }
 
 // ------------------------------------------------------------------ forward, small path (one WG / channel)
@@ -172,11 +181,14 @@ __global__ __launch_bounds__(256) void bn_fused_small_fwd(const BnP p) {
         alpha_beta(p, c, alpha, beta_, mean, rstd);
     }
     const float floor_ = p.relu ? 0.f : -INFINITY;
+    float vmax = 0.f;
     for (int i = threadIdx.x; i < total; i += 256) {
         const int b = i / p.HW, q = i - b * p.HW;
-        const float v = p.y[((size_t)b * p.CtotY + c) * p.HW + q];
-        p.out[((size_t)b * p.CtotOut + c) * p.HW + q] = fmaxf(fmaf(v, alpha, beta_), floor_);
+        const float v = fmaxf(fmaf(p.y[((size_t)b * p.CtotY + c) * p.HW + q], alpha, beta_), floor_);
+        p.out[((size_t)b * p.CtotOut + c) * p.HW + q] = v;
+        vmax = fmaxf(vmax, fabsf(v));
     }
+    if (p.amax) uz::amax_publish(vmax, p.amax);
 }
 
 // ------------------------------------------------------------------ backward, large path
@@ -235,11 +247,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnP p) {
     const float* ds = p.da + ((size_t)b * p.CtotDa + c) * p.HW;
     float* dst = p.out + ((size_t)b * p.CtotOut + c) * p.HW;
     const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
-    float sd = 0.f;
+    float sd = 0.f, vmax = 0.f;
     auto one = [&](float yv, float dv) -> float {
         const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
         const float r = alpha * (dz - m1 - ((yv - mean) * rstd) * m2);
         sd += r;
+        vmax = fmaxf(vmax, fabsf(r));
         return r;
     };
     if (VEC) {
@@ -255,6 +268,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnP p) {
     } else {
         for (int i = lo + threadIdx.x; i < hi; i += 256) dst[i] = one(ys[i], ds[i]);
     }
+    if (p.amax) uz::amax_publish(vmax, p.amax);
     if (p.dbias) {
         double v1[1] = {(double)sd};
         uz::block_sum_d<1>(v1, sm);
@@ -297,6 +311,7 @@ __global__ __launch_bounds__(256) void bn_fused_small_bwd(const BnP p) {
     __syncthreads();
     const float m1 = bc[0], m2 = bc[1];
     double sd[1] = {0.0};
+    float vmax = 0.f;
     for (int i = threadIdx.x; i < total; i += 256) {
         const int b = i / p.HW, q = i - b * p.HW;
         const float yv = p.y[((size_t)b * p.CtotY + c) * p.HW + q];
@@ -305,7 +320,9 @@ __global__ __launch_bounds__(256) void bn_fused_small_bwd(const BnP p) {
         const float r = alpha * (dz - m1 - ((yv - mean) * rstd) * m2);
         p.out[((size_t)b * p.CtotOut + c) * p.HW + q] = r;
         sd[0] += r;
+        vmax = fmaxf(vmax, fabsf(r));
     }
+    if (p.amax) uz::amax_publish(vmax, p.amax);
     if (p.dbias) {
         uz::block_sum_d<1>(sd, sm);
         if (threadIdx.x == 0) p.dbias[c] = (float)sd[0];
@@ -316,14 +333,14 @@ __global__ __launch_bounds__(256) void bn_fused_small_bwd(const BnP p) {
 template <bool VEC>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ da, int CtotDa, const float* __restrict__ a, int CtotA,
                                                         float* __restrict__ dy, int CtotDy, double* __restrict__ part2,
-                                                        int C, int HW, int parts) {
+                                                        int C, int HW, int parts, float* __restrict__ amax) {
     __shared__ double sm[4];
     const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
     const float* as = a + ((size_t)b * CtotA + c) * HW;
     const float* ds = da + ((size_t)b * CtotDa + c) * HW;
     float* dst = dy + ((size_t)b * CtotDy + c) * HW;
     const int lo = part * CHUNK, hi = min(HW, lo + CHUNK);
-    float sd = 0.f;
+    float sd = 0.f, vmax = 0.f;
     if (VEC) {
         const float4* a4 = reinterpret_cast<const float4*>(as);
         const float4* d4 = reinterpret_cast<const float4*>(ds);
@@ -335,10 +352,12 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
             r.z = av.z > 0.f ? dv.z : 0.f; r.w = av.w > 0.f ? dv.w : 0.f;
             sd += (r.x + r.y) + (r.z + r.w);
             o4[i] = r;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
         }
     } else {
-        for (int i = lo + threadIdx.x; i < hi; i += 256) { const float r = as[i] > 0.f ? ds[i] : 0.f; sd += r; dst[i] = r; }
+        for (int i = lo + threadIdx.x; i < hi; i += 256) { const float r = as[i] > 0.f ? ds[i] : 0.f; sd += r; dst[i] = r; vmax = fmaxf(vmax, fabsf(r)); }
     }
+    if (amax) uz::amax_publish(vmax, amax);
     if (part2) {
         double v1[1] = {(double)sd};
         uz::block_sum_d<1>(v1, sm);
@@ -380,7 +399,7 @@ void carve(BnP& p, void* ws) {
 extern "C" int uz_bn_relu_fwd(const float* y, int C, int CtotY, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float* save_mean_rstd,
                               float* a, int CtotA, int N, int H, int W, float eps, float momentum,
-                              int training, int relu, void* workspace, void* stream) {
+                              int training, int relu, float* a_amax, void* workspace, void* stream) {
     UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_fwd: empty tensor");
     UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_fwd: N or C exceeds grid limits");
     UZ_REQUIRE(!training || save_mean_rstd, "bn_relu_fwd: training needs save_mean_rstd");
@@ -391,7 +410,7 @@ extern "C" int uz_bn_relu_fwd(const float* y, int C, int CtotY, const float* gam
     p.y = y; p.gamma = gamma; p.beta = beta; p.rmean = running_mean; p.rvar = running_var; p.save = save_mean_rstd;
     p.out = a; p.C = C; p.CtotY = CtotY; p.CtotOut = CtotA; p.N = N; p.HW = H * W;
     p.parts = uz::ceil_div(p.HW, CHUNK);
-    p.eps = eps; p.momentum = momentum; p.training = training; p.relu = relu;
+    p.eps = eps; p.momentum = momentum; p.training = training; p.relu = relu; p.amax = a_amax;
     if ((size_t)N * p.HW <= SMALL_LIMIT) {
         hipLaunchKernelGGL(bn_fused_small_fwd, dim3(C), dim3(256), 0, st, p);
         return uz::check_launch("bn_fused_small_fwd");
@@ -415,7 +434,7 @@ extern "C" int uz_bn_relu_fwd(const float* y, int C, int CtotY, const float* gam
 extern "C" int uz_bn_relu_bwd(const float* da, int CtotDa, const float* y, int C, int CtotY,
                               const float* gamma, const float* beta, const float* save_mean_rstd,
                               float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
-                              int N, int H, int W, int relu, void* workspace, void* stream) {
+                              int N, int H, int W, int relu, float* dy_amax, void* workspace, void* stream) {
     UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_bwd: empty tensor");
     UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_bwd: N or C exceeds grid limits");
     UZ_REQUIRE(save_mean_rstd, "bn_relu_bwd: needs the saved batch statistics");
@@ -425,7 +444,7 @@ extern "C" int uz_bn_relu_bwd(const float* da, int CtotDa, const float* y, int C
     p.out = dy; p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias;
     p.C = C; p.CtotY = CtotY; p.CtotDa = CtotDa; p.CtotOut = CtotDy; p.N = N; p.HW = H * W;
     p.parts = uz::ceil_div(p.HW, CHUNK);
-    p.training = 1; p.relu = relu;
+    p.training = 1; p.relu = relu; p.amax = dy_amax;
     if ((size_t)N * p.HW <= SMALL_LIMIT) {
         hipLaunchKernelGGL(bn_fused_small_bwd, dim3(C), dim3(256), 0, st, p);
         return uz::check_launch("bn_fused_small_bwd");
@@ -450,7 +469,7 @@ extern "C" int uz_bn_relu_bwd(const float* da, int CtotDa, const float* y, int C
 }
 
 extern "C" int uz_relu_bwd(const float* da, int CtotDa, const float* a, int C, int CtotA,
-                           float* dy, int CtotDy, float* dbias, int N, int H, int W, void* workspace, void* stream) {
+                           float* dy, int CtotDy, float* dbias, int N, int H, int W, float* dy_amax, void* workspace, void* stream) {
     UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "relu_bwd: empty tensor");
     UZ_REQUIRE(N <= 65535 && C <= 65535, "relu_bwd: N or C exceeds grid limits");
     UZ_REQUIRE(!dbias || workspace, "relu_bwd: workspace required for dbias");
@@ -458,8 +477,8 @@ extern "C" int uz_relu_bwd(const float* da, int CtotDa, const float* a, int C, i
     const int HW = H * W, parts = uz::ceil_div(HW, CHUNK);
     double* part2 = dbias ? static_cast<double*>(workspace) : nullptr;
     const dim3 grid(parts, C, N);
-    if (vec_ok(HW, da, a, dy)) hipLaunchKernelGGL(relu_bwd_kernel<true>, grid, dim3(256), 0, st, da, CtotDa, a, CtotA, dy, CtotDy, part2, C, HW, parts);
-    else hipLaunchKernelGGL(relu_bwd_kernel<false>, grid, dim3(256), 0, st, da, CtotDa, a, CtotA, dy, CtotDy, part2, C, HW, parts);
+    if (vec_ok(HW, da, a, dy)) hipLaunchKernelGGL(relu_bwd_kernel<true>, grid, dim3(256), 0, st, da, CtotDa, a, CtotA, dy, CtotDy, part2, C, HW, parts, dy_amax);
+    else hipLaunchKernelGGL(relu_bwd_kernel<false>, grid, dim3(256), 0, st, da, CtotDa, a, CtotA, dy, CtotDy, part2, C, HW, parts, dy_amax);
     if (int rc = uz::check_launch("relu_bwd_kernel")) return rc;
     if (dbias) {
         hipLaunchKernelGGL(chan_partial_sum, dim3(uz::ceil_div(C, 4)), dim3(256), 0, st, part2, N * parts, C, dbias);

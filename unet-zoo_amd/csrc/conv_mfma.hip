@@ -18,6 +18,7 @@
 // patch through a constant LDS offset, so HBM/L2 sees each input element once per channel tile.
 #include <stdlib.h>
 #include "uz_common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -36,6 +37,7 @@ struct ConvP {
     int relu, accumulate;
     int ksplit, cps;                  // split-K over input-channel chunks: number of splits, chunks per split
     float* slab;                      // [ksplit][N][Cout][H][W] partial sums when ksplit > 1
+    float* y_amax;                    // nullable: atomic max of |y| (bound for a following split-fp16 convolution)
 };
 
 template <int KS, int MSUB, int JMAX, bool DGRAD>
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
         return;
     }
     // ---- epilogue: bias, optional accumulate / ReLU, coalesced NCHW stores
+    float vmax = 0.f;
 #pragma unroll
     for (int m = 0; m < MSUB; ++m) {
 #pragma unroll
@@ -221,20 +224,24 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
                         if (p.accumulate) v += *dst;
                         if (p.relu) v = fmaxf(v, 0.f);
                         *dst = v;
+                        vmax = fmaxf(vmax, fabsf(v));
                     }
                 }
             }
         }
     }
+    if (p.y_amax) uz::amax_publish(vmax, p.y_amax);
 }
 
 // y[b,co,p] = (accumulate ? y : 0) + bias[co] + sum_s slab[s][b,co,p]  (fixed order), optional ReLU.
 // V = 4: float4 sweep (HW % 4 == 0, 16-byte aligned output view); one 32-bit division pair per vector.
 template <int V>
 __global__ __launch_bounds__(256) void conv_splitk_reduce(const float* __restrict__ slab, int ksplit, const float* __restrict__ bias,
-                                                          float* __restrict__ y, int Cout, int CoutTot, int N, int HW, int relu, int accumulate) {
+                                                          float* __restrict__ y, int Cout, int CoutTot, int N, int HW, int relu, int accumulate,
+                                                          float* __restrict__ y_amax) {
     const unsigned n = (unsigned)N * Cout * HW;              // < 2^31 floats per slab (checked by the host)
     const unsigned chw = (unsigned)Cout * HW;
+    float vmax = 0.f;
     for (unsigned i = (blockIdx.x * 256u + threadIdx.x) * V; i < n; i += gridDim.x * 256u * V) {
         const unsigned b = i / chw, r = i - b * chw, co = r / (unsigned)HW;
         float* dst = y + (size_t)b * CoutTot * HW + r;
@@ -248,14 +255,17 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const float* __restric
             if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
             if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
             *reinterpret_cast<float4*>(dst) = s;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(s.x), fabsf(s.y))), fmaxf(fabsf(s.z), fabsf(s.w)));
         } else {
             float s = bv;
             for (int k = 0; k < ksplit; ++k) s += slab[(size_t)k * n + i];
             if (accumulate) s += *dst;
             if (relu) s = fmaxf(s, 0.f);
             *dst = s;
+            vmax = fmaxf(vmax, fabsf(s));
         }
     }
+    if (y_amax) uz::amax_publish(vmax, y_amax);
 }
 
 struct Geom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB; };
@@ -333,13 +343,14 @@ size_t conv_workspace(int Kc, int Mc, int N, int H, int W, int ks) {
 
 int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
               float* y, int Mc, int McTot, int N, int H, int W, int ks, int dgrad, int relu, int accumulate,
+              const float* x_amax, const float* w_amax, float* y_amax,
               void* workspace, size_t workspace_bytes, hipStream_t st) {
     UZ_REQUIRE(ks == 1 || ks == 3, "conv: kernel size %d unsupported (1 or 3)", ks);
     UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Kc > 0 && Mc > 0, "conv: empty tensor");
     UZ_REQUIRE(H <= 4096 && W <= 4096, "conv: spatial size too large");
     // large 3x3 layers: split-bf16 matrix pipe (conv_split.hip); its packed weight image lives in the workspace
     if (conv_split_ok(Kc, Mc, N, H, W, ks) && workspace && workspace_bytes >= conv_split_workspace(Kc, Mc, W))
-        return conv_split(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, dgrad, relu, accumulate, workspace, st);
+        return conv_split(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, dgrad, relu, accumulate, x_amax, w_amax, y_amax, workspace, st);
     const Geom g = pick_geom(N, H, W, ks / 2);
     ConvP p;
     p.x = x; p.w = w; p.bias = bias; p.y = y;
@@ -348,7 +359,7 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     p.TW = g.TW; p.TH = g.TH; p.TB = g.TB; p.lgTW = ilog2(g.TW); p.lgTH = ilog2(g.TH);
     p.tilesX = g.tilesX; p.tilesY = g.tilesY;
     p.PW = g.PW; p.PSI = g.PSI; p.PS = g.PS;
-    p.relu = relu; p.accumulate = accumulate;
+    p.relu = relu; p.accumulate = accumulate; p.y_amax = y_amax;
     const int msub = Mc <= 32 ? 1 : 2;
     const int cot = 32 * msub;
     p.nCoTiles = ceil_div(Mc, cot);
@@ -360,6 +371,7 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * N * Mc * H * W * sizeof(float) : 0;
     if (p.ksplit > 1 && (!workspace || workspace_bytes < need)) { p.ksplit = 1; p.cps = ceil_div(Kc, CK); }   // no workspace: stay unsplit
     p.slab = static_cast<float*>(workspace);
+    if (p.ksplit > 1) p.y_amax = nullptr;               // split-K: the reduce kernel sees the final values
     const long long grid = base_grid * p.ksplit;
     UZ_REQUIRE(grid < (1ll << 31), "conv: grid too large");
     int rc;
@@ -371,8 +383,8 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     const bool v4 = (H * W) % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.slab) & 15) == 0;
     int rgrid = (int)((n / (v4 ? 4 : 1) + 255) / 256);
     if (rgrid > 2048) rgrid = 2048;
-    if (v4) hipLaunchKernelGGL(conv_splitk_reduce<4>, dim3(rgrid), dim3(256), 0, st, p.slab, p.ksplit, bias, y, Mc, McTot, N, H * W, relu, accumulate);
-    else hipLaunchKernelGGL(conv_splitk_reduce<1>, dim3(rgrid), dim3(256), 0, st, p.slab, p.ksplit, bias, y, Mc, McTot, N, H * W, relu, accumulate);
+    if (v4) hipLaunchKernelGGL(conv_splitk_reduce<4>, dim3(rgrid), dim3(256), 0, st, p.slab, p.ksplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax);
+    else hipLaunchKernelGGL(conv_splitk_reduce<1>, dim3(rgrid), dim3(256), 0, st, p.slab, p.ksplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax);
     return check_launch("conv_splitk_reduce");
 }
 
@@ -385,20 +397,22 @@ extern "C" size_t uz_conv_workspace(int Cin, int Cout, int N, int H, int W, int 
 
 extern "C" int uz_conv_fwd(const float* x, int Cin, int CinTot, const float* w, const float* bias,
                            float* y, int Cout, int CoutTot, int N, int H, int W, int ks, int relu,
+                           const float* x_amax, const float* w_amax, float* y_amax,
                            void* workspace, size_t workspace_bytes, void* stream) {
     if (ks == 1 && !relu && uz::conv1x1_small_ok(Cin, Cout)) {        // 2..8-output heads: streaming VALU kernel
         const int rc = uz::conv1x1_small_fwd(x, Cin, CinTot, w, bias, y, Cout, CoutTot, N, H, W, uz::S(stream));
         if (rc != -2) return rc;
     }
-    return uz::conv_mfma(x, Cin, CinTot, w, Cin, bias, y, Cout, CoutTot, N, H, W, ks, 0, relu, 0, workspace, workspace_bytes, uz::S(stream));
+    return uz::conv_mfma(x, Cin, CinTot, w, Cin, bias, y, Cout, CoutTot, N, H, W, ks, 0, relu, 0, x_amax, w_amax, y_amax, workspace, workspace_bytes, uz::S(stream));
 }
 
 extern "C" int uz_conv_bwd_data(const float* dy, int Cout, int CoutTot, const float* w,
                                 float* dx, int Cin, int CinTot, int N, int H, int W, int ks, int accumulate,
+                                const float* dy_amax, const float* w_amax,
                                 void* workspace, size_t workspace_bytes, void* stream) {
     if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) {
         const int rc = uz::conv1x1_small_bwd_data(dy, Cout, CoutTot, w, dx, Cin, CinTot, N, H, W, accumulate, uz::S(stream));
         if (rc != -2) return rc;
     }
-    return uz::conv_mfma(dy, Cout, CoutTot, w, Cin, nullptr, dx, Cin, CinTot, N, H, W, ks, 1, 0, accumulate, workspace, workspace_bytes, uz::S(stream));
+    return uz::conv_mfma(dy, Cout, CoutTot, w, Cin, nullptr, dx, Cin, CinTot, N, H, W, ks, 1, 0, accumulate, dy_amax, w_amax, nullptr, workspace, workspace_bytes, uz::S(stream));
 }

@@ -1,32 +1,31 @@
-// 3x3 convolution (forward and data gradient) on the bf16 matrix pipe with fp32-accurate results.
+// 3x3 convolution (forward and data gradient) on the fp16 matrix pipe with fp32-accurate results.
 //
-// MI355X runs v_mfma_f32_32x32x16_bf16 at 16x the FLOP rate of v_mfma_f32_32x32x2_f32.  Every fp32
-// operand is split EXACTLY into three bf16 pieces, a = a1 + a2 + a3 (8 + 8 + 8 significand bits), and
-// the product a*b is accumulated in fp32 from the six piece products whose weight is >= 2^-16:
-//   a1b1, a1b2, a2b1, a1b3, a3b1, a2b2            (bf16 x bf16 is exact in fp32)
-// The three dropped terms are <= 2^-24 |ab| each, i.e. below the rounding of the fp32 accumulation
-// itself; measured against an fp64 evaluation the split convolution is as accurate as the fp32-MFMA
-// kernel and as the reference's CPU arithmetic (tests/test_ops_gpu.py).
-// Six bf16 MFMAs per 16-deep k-step cost 192 cycles against 512 for the eight fp32 MFMAs they replace.
+// MI355X runs v_mfma_f32_32x32x16_f16 at 16x the FLOP rate of v_mfma_f32_32x32x2_f32.  Every fp32 operand is scaled by a
+// power of two (from an upper bound of its tensor's magnitudes, so that nothing overflows fp16) and split into TWO fp16
+// pieces, a*s = a1 + a2 (11 + 11 significand bits, remainder <= 2^-22 |a|); the product a*b is accumulated in fp32 from
+// the three piece products a2b1, a1b2, a1b1 (fp16 x fp16 is exact in fp32; the dropped a2b2 is <= 2^-22 |ab|), and the
+// epilogue undoes the scales exactly.  Measured against an fp64 evaluation the result is as accurate as the fp32-MFMA
+// kernel and as the reference's CPU arithmetic (tests/test_full_configs_gpu.py): three partial sums
+// per 16-deep k-step round less often than the sixteen of a k-ordered fmaf chain.
+// Three fp16 MFMAs per 16-deep k-step cost 96 cycles against 512 for the eight fp32 MFMAs they replace.
 //
 // Tile: 64 (32) output channels x 512 pixels (16 rows x 32 columns of one image) per 512-thread
-// workgroup, one workgroup per CU = two waves per SIMD.  Per 16-channel chunk the haloed 18 x 34
-// patch and the 9-tap weight panel are fetched to registers (raw buffer loads, hardware range check
-// = padding), split into the three bf16 planes and written to LDS in MFMA fragment order
+// workgroup.  Per 16-channel chunk the haloed 18 x 34 patch and the 9-tap weight panel are fetched to registers (raw
+// buffer loads, hardware range check = padding), split into the two fp16 planes and written to LDS in MFMA fragment order
 // ([plane][tap][co][16 ci] and [plane][pixel][16 ci]: every fragment is one ds_read_b128); the next
-// chunk's global loads are in flight during the 216 (108) MFMAs of the current one.
+// chunk's global loads are in flight during the 108 (54) MFMAs of the current one.
 // dgrad is the same kernel with the weight panel gathered transposed and tap-flipped.
 #include <stdlib.h>
 #include <string.h>
 #include "uz_common.h"
-#include "split_bf16.h"
+#include "split_f16.h"
 
 namespace {
 
-using uz::f32x16; using uz::f32x4; using uz::bf16x8; using uz::u32x4; using uz::split3;
+using uz::f32x16; using uz::f32x4; using uz::f16x8; using uz::u32x4; using uz::split2;
 
 
-constexpr int CK = 16, NSUB = 2, KK = 9, TH = 16;
+constexpr int CK = 16, NSUB = 2, KK = 9, TH = 16, NP = 2;      // NP fp16 planes per operand
 // Two tile geometries share the kernel: 512 threads on 16 x 32 pixels (planes at least 32 wide) and 256 threads
 // on 16 x 16 pixels (one 16 x 16 plane per workgroup, 32 output channels, 60 KB of LDS -> two workgroups per CU).
 template <int NTv, int TWv> struct Geo {
@@ -45,26 +44,26 @@ struct SP {
     int Cin, CinTot, Cout, CoutTot;   // GEMM-K channels (input view), GEMM-M channels (output view)
     int tilesX, tilesY, nCoTiles, nChunks;
     int relu, accumulate;
+    const float* x_amax; const float* w_amax;     // device scalars: upper bounds of |x| and |w| (never null here)
+    float* y_amax;                                // nullable: atomic max of |y| (bound for the next layer's split)
 };
 
 
-// 16 fp32 values (one LDS row of 16 channels) -> three 32-byte bf16 rows at dst + plane * plane_stride (bytes)
-__device__ __forceinline__ void split_store16(const float (&v)[CK], char* dst, int plane_stride) {
-    unsigned p1[8], p2[8], p3[8];
+// 16 fp32 values (one LDS row of 16 channels), scaled -> two 32-byte fp16 rows at dst + plane * plane_stride (bytes)
+__device__ __forceinline__ void split_store16(const float (&v)[CK], float scale, char* dst, int plane_stride) {
+    unsigned p1[8], p2[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) split3(v[2 * i], v[2 * i + 1], p1[i], p2[i], p3[i]);
+    for (int i = 0; i < 8; ++i) split2(v[2 * i] * scale, v[2 * i + 1] * scale, p1[i], p2[i]);
     u32x4* d1 = reinterpret_cast<u32x4*>(dst);
     u32x4* d2 = reinterpret_cast<u32x4*>(dst + plane_stride);
-    u32x4* d3 = reinterpret_cast<u32x4*>(dst + 2 * plane_stride);
     d1[0] = u32x4{p1[0], p1[1], p1[2], p1[3]}; d1[1] = u32x4{p1[4], p1[5], p1[6], p1[7]};
     d2[0] = u32x4{p2[0], p2[1], p2[2], p2[3]}; d2[1] = u32x4{p2[4], p2[5], p2[6], p2[7]};
-    d3[0] = u32x4{p3[0], p3[1], p3[2], p3[3]}; d3[1] = u32x4{p3[4], p3[5], p3[6], p3[7]};
 }
 
 // Weight panel of one layer and direction, split once per call into the kernel's LDS image:
-// packed[chunk][coTile][plane 3][tap 9][co COT][k 16] bf16.  One thread per (chunk, coTile, tap, co) row.
+// packed[chunk][coTile][plane 2][tap 9][co COT][k 16] fp16, scaled by split_scale(*w_amax).  One thread per (chunk, coTile, tap, co) row.
 template <bool DGRAD>
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, char* __restrict__ packed,
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, char* __restrict__ packed, const float* __restrict__ w_amax,
                                                            int Mc, int Kc, int wCi, int nChunks, int nCoTiles, int COT) {
     const int rows = nChunks * nCoTiles * KK * COT;
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
     const int tapL = DGRAD ? KK - 1 - tap : tap;
     const int wplane = KK * COT * CK * 2;
-    split_store16(v, packed + (size_t)(c * nCoTiles + coT) * 3 * wplane + (tapL * COT + m) * (CK * 2), wplane);
+    split_store16(v, uz::split_scale(*w_amax), packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * (CK * 2), wplane);
 }
 
 template <int MSUB, int NTv, int TWv>
@@ -91,11 +90,11 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
     constexpr int COT = 32 * MSUB;
     constexpr int WPLANE = KK * COT * CK * 2;            // bytes per weight plane
     constexpr int PPLANE = PSR * CK * 2;                 // bytes per patch plane
-    constexpr int WVEC = 3 * WPLANE / 16;                // 16-byte vectors of one packed weight block (3456 / 1728)
+    constexpr int WVEC = NP * WPLANE / 16;               // 16-byte vectors of one packed weight block (2304 / 1152)
     constexpr int WREGS = (WVEC + NT - 1) / NT;          // per thread
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Wl = lds;
-    char* Pl = lds + 3 * WPLANE;
+    char* Pl = lds + NP * WPLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x + (size_t)b0 * p.CinTot * p.HW), 0, (unsigned)((size_t)p.Cin * p.HW * sizeof(float)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(p.wp), 0, (unsigned)((size_t)p.nChunks * p.nCoTiles * 3 * WPLANE), 0x00020000);
+        const_cast<char*>(p.wp), 0, (unsigned)((size_t)p.nChunks * p.nCoTiles * NP * WPLANE), 0x00020000);
     // patch rows: row tid (all 16 channels) for every thread; the rows beyond NT are shared out G threads per
     // row, CE channels each (so no thread carries a second full row in registers)
     unsigned goff[2], gmask[2];
@@ -127,7 +126,8 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
     }
     const int prow1 = NT + tid / G, q4 = tid & (G - 1);
     const unsigned xstep = 4u * (unsigned)p.HW;
-    const unsigned wblock = 3u * WPLANE;
+    const unsigned wblock = (unsigned)NP * WPLANE;
+    const float xs = uz::split_scale(*p.x_amax);
 
     // ---- per-lane output pixels (B operand columns)
     int poff[NSUB], oidx[NSUB];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     float pr[CK], pr1[CE];            // raw patch values of the next chunk: own row, share of an extra row
-    unsigned pk[3][CK / 2], pk1[3][CE / 2]; // ... and their three bf16 planes, packed pairwise as they get split
+    unsigned pk[NP][CK / 2], pk1[NP][CE / 2]; // ... and their two fp16 planes, packed pairwise as they get split
     u32x4 wq[WREGS];
     // Staging of the next chunk is spread over the nine taps of the MFMA loop so that neither the memory
     // pipeline's queue nor the VALU work of the operand split ever stands between two MFMAs for long:
@@ -188,26 +188,26 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
             if (tap == 8) { for (int i = 5; i < WREGS; ++i) weight_load(c, i); }
             if (tap < 8) {
                 const int i0 = 2 * (tap - 4);
-                split3(pr[2 * i0], pr[2 * i0 + 1], pk[0][i0], pk[1][i0], pk[2][i0]);
-                split3(pr[2 * i0 + 2], pr[2 * i0 + 3], pk[0][i0 + 1], pk[1][i0 + 1], pk[2][i0 + 1]);
+                split2(pr[2 * i0] * xs, pr[2 * i0 + 1] * xs, pk[0][i0], pk[1][i0]);
+                split2(pr[2 * i0 + 2] * xs, pr[2 * i0 + 3] * xs, pk[0][i0 + 1], pk[1][i0 + 1]);
             }
             if (tap == 4) {
 #pragma unroll
-                for (int i = 0; i < CE / 2; ++i) split3(pr1[2 * i], pr1[2 * i + 1], pk1[0][i], pk1[1][i], pk1[2][i]);
+                for (int i = 0; i < CE / 2; ++i) split2(pr1[2 * i] * xs, pr1[2 * i + 1] * xs, pk1[0][i], pk1[1][i]);
             }
         }
     };
     auto lstore = [&]() {
         char* dst = Pl + tid * (CK * 2);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NP; ++q) {
             u32x4* d = reinterpret_cast<u32x4*>(dst + q * PPLANE);
             d[0] = u32x4{pk[q][0], pk[q][1], pk[q][2], pk[q][3]};
             d[1] = u32x4{pk[q][4], pk[q][5], pk[q][6], pk[q][7]};
         }
         char* dst1 = Pl + prow1 * (CK * 2) + q4 * (CE * 2);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NP; ++q) {
             if (CE == 4) *reinterpret_cast<uint2*>(dst1 + q * PPLANE) = make_uint2(pk1[q][0], pk1[q][1]);
             else *reinterpret_cast<u32x4*>(dst1 + q * PPLANE) = u32x4{pk1[q][0], pk1[q][1], pk1[q][CE / 2 - 2], pk1[q][CE / 2 - 1]};
         }
@@ -228,17 +228,17 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             const int tapoff = ((tap / 3) * PW + (tap % 3)) * (CK * 2);
-            bf16x8 a[MSUB][3], b[NSUB][3];
+            f16x8 a[MSUB][NP], b[NSUB][NP];
 #pragma unroll
             for (int m = 0; m < MSUB; ++m)
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    a[m][q] = *reinterpret_cast<const bf16x8*>(Al + q * WPLANE + (tap * COT + m * 32) * (CK * 2));
+                for (int q = 0; q < NP; ++q)
+                    a[m][q] = *reinterpret_cast<const f16x8*>(Al + q * WPLANE + (tap * COT + m * 32) * (CK * 2));
 #pragma unroll
             for (int n = 0; n < NSUB; ++n)
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    b[n][q] = *reinterpret_cast<const bf16x8*>(Pl + q * PPLANE + poff[n] + tapoff);
+                for (int q = 0; q < NP; ++q)
+                    b[n][q] = *reinterpret_cast<const f16x8*>(Pl + q * PPLANE + poff[n] + tapoff);
             if (more) stage(c + 1, tap);
             // smallest products first
 #pragma unroll
@@ -246,18 +246,17 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
 #pragma unroll
                 for (int n = 0; n < NSUB; ++n) {
                     f32x16 t = acc[m][n];
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[n][1], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b[n][0], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[n][2], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[n][0], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[n][1], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[n][0], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][1], b[n][0], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], b[n][1], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], b[n][0], t, 0, 0, 0);
                     acc[m][n] = t;
                 }
         }
     }
 
-    // ---- epilogue: bias, optional accumulate / ReLU, coalesced NCHW stores
+    // ---- epilogue: undo the operand scales (exact), bias, optional accumulate / ReLU, coalesced NCHW stores
+    const float inv_x = uz::split_inv_scale(*p.x_amax), inv_w = uz::split_inv_scale(*p.w_amax);
+    float vmax = 0.f;
 #pragma unroll
     for (int m = 0; m < MSUB; ++m) {
 #pragma unroll
@@ -269,20 +268,22 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
                 for (int n = 0; n < NSUB; ++n) {
                     if (oidx[n] >= 0) {
                         float* dst = p.y + (size_t)oidx[n] + (size_t)co * p.HW;
-                        float v = acc[m][n][r] + bv;
+                        float v = acc[m][n][r] * inv_x * inv_w + bv;
                         if (p.accumulate) v += *dst;
                         if (p.relu) v = fmaxf(v, 0.f);
                         *dst = v;
+                        vmax = fmaxf(vmax, fabsf(v));
                     }
                 }
             }
         }
     }
+    if (p.y_amax) uz::amax_publish(vmax, p.y_amax);
 }
 
 template <int MSUB, int NTv, int TWv>
 int launch(const SP& p, int grid, hipStream_t st) {
-    constexpr size_t smem = 3 * (size_t)(KK * 32 * MSUB * CK * 2) + 3 * (size_t)(Geo<NTv, TWv>::PSR * CK * 2);
+    constexpr size_t smem = NP * (size_t)(KK * 32 * MSUB * CK * 2) + NP * (size_t)(Geo<NTv, TWv>::PSR * CK * 2);
     static bool attr_done = false;
     auto kern = conv_split_kernel<MSUB, NTv, TWv>;
     if (!attr_done) {
@@ -304,10 +305,10 @@ inline int tile_cot(int Mc, int W) { return (small_geo(W) || Mc <= 32) ? 32 : 64
 
 namespace uz {
 
-// Which layers take the split-bf16 path: 3x3, enough channels for a dense contraction and enough tiles to occupy
+// Which layers take the split-fp16 path: 3x3, enough channels for a dense contraction and enough tiles to occupy
 // the chip.  Planes wider than 32 use 16 x 32 tiles; 32 x 32 and 16 x 16 planes use 16 x 16 tiles.
 bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks) {
-    // UZ_CONV_MATH: "f32" = fp32 MFMA only; "split" = split-bf16 on every 3x3 shape (tests); default = where it pays
+    // UZ_CONV_MATH: "f32" = fp32 MFMA only; "split" = split-fp16 on every 3x3 shape (tests); default = where it pays
     const int mode = conv_math_mode();
     if (!mode || ks != 3) return false;
     if (mode == 2) return true;
@@ -324,17 +325,61 @@ bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks) {
     return false;
 }
 
-// bytes of the packed weight image (one direction) the kernel reads; lives in the caller's conv workspace
+// workspace = [64 bytes: fallback bound slots (x, w)] [packed weight image of one direction]
+constexpr size_t WS_HEAD = 64;
 size_t conv_split_workspace(int Kc, int Mc, int W) {
     const int cot = tile_cot(Mc, W);
-    return (size_t)ceil_div(Kc, CK) * ceil_div(Mc, cot) * 3 * (KK * cot * CK * 2);
+    return WS_HEAD + (size_t)ceil_div(Kc, CK) * ceil_div(Mc, cot) * NP * (KK * cot * CK * 2);
 }
 
+namespace {
+// absmax fallback (callers that supply no bound): grid-stride max over a channel-slice view -> atomicMax into a zeroed slot
+__global__ __launch_bounds__(256) void absmax_view_kernel(const float* __restrict__ x, int C, int Ctot, int HW, size_t n, float* slot) {
+    float m = 0.f;
+    const size_t per = (size_t)C * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / per, r = i - b * per;
+        m = fmaxf(m, fabsf(x[b * (size_t)Ctot * HW + r]));
+    }
+    uz::amax_publish(m, slot);
+}
+}  // namespace
+
+int absmax_view(const float* x, int C, int Ctot, int N, int HW, float* slot, hipStream_t st) {
+    const size_t n = (size_t)N * C * HW;
+    int grid = (int)((n + 256 * 16 - 1) / (256 * 16));
+    grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
+    hipLaunchKernelGGL(absmax_view_kernel, dim3(grid), dim3(256), 0, st, x, C, Ctot, HW, n, slot);
+    return check_launch("absmax_view_kernel");
+}
+int absmax_flat(const float* x, size_t n, float* slot, hipStream_t st) {
+    int grid = (int)((n + 256 * 16 - 1) / (256 * 16));
+    grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
+    hipLaunchKernelGGL(absmax_view_kernel, dim3(grid), dim3(256), 0, st, x, 1, 1, 1, n, slot);
+    return check_launch("absmax_view_kernel");
+}
+
+// x_amax / w_amax: device scalars bounding |x| and |w| (any upper bound within ~2^10 of the true maximum keeps full
+// accuracy); NULL = measure here (one extra pass over the tensor: the stand-alone C-ABI path, the model plans pass
+// bounds that the producing kernels maintain).  y_amax (nullable): atomic max of |y| for the next consumer.
 int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
-               void* workspace, hipStream_t st) {
+               const float* x_amax, const float* w_amax, float* y_amax, void* workspace, hipStream_t st) {
     SP p;
-    p.x = x; p.wp = static_cast<const char*>(workspace); p.bias = bias; p.y = y;
+    float* slots = static_cast<float*>(workspace);
+    char* image = static_cast<char*>(workspace) + WS_HEAD;
+    if (!x_amax || !w_amax) {
+        if (hipMemsetAsync(slots, 0, WS_HEAD, st) != hipSuccess) return fail("conv_split: memset failed");
+        if (!x_amax) { if (int rc = absmax_view(x, Kc, KcTot, N, H * W, slots, st)) return rc; x_amax = slots; }
+        if (!w_amax) {
+            // the weight view may be a row / column slice of the parameter: bound over the enclosing rows is still a bound
+            const size_t nw = dgrad ? (size_t)Kc * wCi * KK : (size_t)Mc * wCi * KK;
+            if (int rc = absmax_flat(w, nw, slots + 1, st)) return rc;
+            w_amax = slots + 1;
+        }
+    }
+    p.x = x; p.wp = image; p.bias = bias; p.y = y;
+    p.x_amax = x_amax; p.w_amax = w_amax; p.y_amax = y_amax;
     p.N = N; p.H = H; p.W = W; p.HW = H * W;
     p.Cin = Kc; p.CinTot = KcTot; p.Cout = Mc; p.CoutTot = McTot;
     const int tw = tile_w(W), cot = tile_cot(Mc, W);
@@ -346,11 +391,17 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     UZ_REQUIRE(grid < (1ll << 31), "conv_split: grid too large");
     UZ_REQUIRE((size_t)Kc * p.HW * 4 < (1ull << 32) && (size_t)McTot * p.HW * N < (1ull << 31), "conv_split: tensor too large for 32-bit offsets");
     const int rows = p.nChunks * p.nCoTiles * KK * cot;
-    if (dgrad) hipLaunchKernelGGL(pack_weights_kernel<true>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, static_cast<char*>(workspace), Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
-    else hipLaunchKernelGGL(pack_weights_kernel<false>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, static_cast<char*>(workspace), Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
+    if (dgrad) hipLaunchKernelGGL(pack_weights_kernel<true>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
+    else hipLaunchKernelGGL(pack_weights_kernel<false>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
     if (int rc = check_launch("pack_weights_kernel")) return rc;
     if (tw == 16) return launch<1, 256, 16>(p, (int)grid, st);
     return cot == 32 ? launch<1, 512, 32>(p, (int)grid, st) : launch<2, 512, 32>(p, (int)grid, st);
 }
 
 }  // namespace uz
+
+extern "C" int uz_absmax(const float* x, size_t n, float* slot, void* stream) {
+    UZ_REQUIRE(x && slot, "absmax: null argument");
+    if (n == 0) return 0;
+    return uz::absmax_flat(x, n, slot, uz::S(stream));
+}

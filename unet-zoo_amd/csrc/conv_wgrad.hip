@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "uz_common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -473,7 +474,7 @@ extern "C" size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, 
     const size_t dbp = (size_t)Cout * CSB * sizeof(double);
     size_t need = slabs > dbp ? slabs : dbp;
     if (uz::wgrad_split_ok(Cin, Cout, N, H, W, ks)) {
-        const size_t sp = (size_t)uz::wgrad_split_splits(Cin, Cout, N, H, W) * ks * ks * Cout * Cin * sizeof(float);
+        const size_t sp = (size_t)uz::wgrad_split_splits(Cin, Cout, N, H, W) * ks * ks * Cout * Cin * sizeof(float) + 64;    // + fallback bound slots
         if (sp > need) need = sp;
     }
     if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) {
@@ -484,7 +485,7 @@ extern "C" size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, 
 }
 
 // Which kernel family a convolution call takes under the current math mode (diagnostics / roofline bookkeeping):
-// kind 0 = forward, 1 = data gradient, 2 = weight gradient; returns 0 fp32 MFMA, 1 split-bf16 MFMA, 2 streaming VALU (1x1 heads).
+// kind 0 = forward, 1 = data gradient, 2 = weight gradient; returns 0 fp32 MFMA, 1 split-fp16 MFMA, 2 streaming VALU (1x1 heads).
 extern "C" int uz_conv_route(int kind, int Cin, int Cout, int N, int H, int W, int ks) {
     if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) return 2;
     if (kind == 0) return uz::conv_split_ok(Cin, Cout, N, H, W, ks) ? 1 : 0;
@@ -494,6 +495,7 @@ extern "C" int uz_conv_route(int kind, int Cin, int Cout, int N, int H, int W, i
 
 extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
                                   float* dw, float* db, int N, int H, int W, int ks,
+                                  const float* x_amax, const float* dy_amax,
                                   void* workspace, size_t workspace_bytes, void* stream) {
     UZ_REQUIRE(ks == 1 || ks == 3, "conv_bwd_weight: kernel size %d unsupported", ks);
     UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_bwd_weight: empty tensor");
@@ -525,10 +527,17 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
     const int grid = g.nCoT * g.nCiT * g.S;
     int Stot = g.S * g.SW;
     const bool split_math = uz::wgrad_split_ok(Cin, Cout, N, H, W, ks);
-    if (split_math) {                              // large layers: split-bf16 matrix pipe (conv_wgrad_split.hip), same slab layout
+    if (split_math) {                              // large layers: split-fp16 matrix pipe (conv_wgrad_split.hip), same slab layout
         Stot = uz::wgrad_split_splits(Cin, Cout, N, H, W);
-        UZ_REQUIRE(workspace_bytes >= (size_t)Stot * 9 * Cout * Cin * sizeof(float), "conv_bwd_weight: workspace too small for the split path");
-        if (int rc = uz::wgrad_split(x, Cin, CinTot, dy, Cout, CoutTot, p.slab, N, H, W, Stot, st)) return rc;
+        const size_t slab_bytes = (size_t)Stot * 9 * Cout * Cin * sizeof(float);
+        UZ_REQUIRE(workspace_bytes >= slab_bytes + 64, "conv_bwd_weight: workspace too small for the split path");
+        if (!x_amax || !dy_amax) {             // no bounds from the caller: measure them (stand-alone C-ABI path)
+            float* slots = reinterpret_cast<float*>(static_cast<char*>(workspace) + slab_bytes);
+            if (hipMemsetAsync(slots, 0, 64, st) != hipSuccess) return uz::fail("conv_bwd_weight: memset failed");
+            if (!x_amax) { if (int rc = uz::absmax_view(x, Cin, CinTot, N, H * W, slots, st)) return rc; x_amax = slots; }
+            if (!dy_amax) { if (int rc = uz::absmax_view(dy, Cout, CoutTot, N, H * W, slots + 1, st)) return rc; dy_amax = slots + 1; }
+        }
+        if (int rc = uz::wgrad_split(x, Cin, CinTot, dy, Cout, CoutTot, p.slab, N, H, W, Stot, x_amax, dy_amax, st)) return rc;
     }
 #define UZ_WG_LAUNCH(KS_, WM_, WN_, PF_)                                                                         \
     do {                                                                                                         \

@@ -1,11 +1,11 @@
-// 3x3 weight gradient on the bf16 matrix pipe with fp32-accurate results (split operands, see
-// conv_split.hip for the arithmetic: a = a1 + a2 + a3 exactly, six piece products, fp32 accumulate).
+// 3x3 weight gradient on the fp16 matrix pipe with fp32-accurate results (split operands, see conv_split.hip /
+// split_f16.h for the arithmetic: a * s = a1 + a2 with two fp16 pieces, three piece products, fp32 accumulate).
 //
 //   dW[co][ci][tap] = sum_{b,y,x} dY[b,co,y,x] * X[b,ci,y+dy,x+dx]
 // GEMM view: M = co (A = dY), N = ci (B = X shifted by the tap), K = pixels, 16 per MFMA.
 // Workgroup (512 threads) = one 64 x 64 (co x ci) tile of all nine taps and one of S pixel splits; it
 // walks its pixel tiles of 4 rows x 32 columns.  Waves = (co half) x (ci half) x (tap group 5 + 4).
-// LDS holds the three bf16 planes of dY [co][128 px] and of the haloed X patch [ci][6 rows][40 px]
+// LDS holds the two fp16 planes of dY [co][128 px] and of the haloed X patch [ci][6 rows][40 px]
 // (row stride 80 B so that every k-step starts 16-byte aligned).  A k-step is 16 consecutive pixels of
 // one row; the B fragment of tap (dy, dx) starts dx pixels (2 bytes each) past an aligned address, so
 // a lane reads five dwords (b128 + b32) per row and plane and forms the three dx variants in
@@ -16,14 +16,14 @@
 #include <string.h>
 #include <type_traits>
 #include "uz_common.h"
-#include "split_bf16.h"
+#include "split_f16.h"
 
 namespace {
 
-using uz::f32x16; using uz::f32x4; using uz::bf16x8; using uz::u32x4; using uz::split3;
+using uz::f32x16; using uz::f32x4; using uz::f16x8; using uz::u32x4; using uz::split2;
 
 
-constexpr int NT = 512, PT = 128;                        // 128 pixels per tile
+constexpr int NT = 512, PT = 128, NP = 2;                // 128 pixels per tile, NP fp16 planes per operand
 constexpr int DYROW = PT * 2 + 16;                       // bytes per co row of one dY plane (272: 16-byte aligned, skewed banks)
 constexpr int XCH = 496;                                 // bytes per ci of one X plane: 6 rows x 80 B or 10 rows x 48 B, + 16
 // tile geometry: 4 rows x 32 columns (planes whose width is a multiple of 32) or 8 rows x 16 columns (16-wide planes)
@@ -39,6 +39,7 @@ struct WS {
     const float* x; const float* dy; float* slab;
     int N, H, W, HW, Cin, CinTot, Cout, CoutTot;
     int tilesX, tilesY, T, S, nCoT, nCiT;
+    const float* x_amax; const float* dy_amax;          // device scalars: upper bounds of |x| and |dy|
 };
 
 
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
     constexpr int XSLOTS = (CIT * XPAIRS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dYl = lds;
-    char* Xl = lds + 3 * DYPLANE;
+    char* Xl = lds + NP * DYPLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
 
     // the pad words of the patch rows (columns 34..39) and row tails are never read by a valid fragment
     // except as dword 4 of the last k-step half: zero the whole image once so they are finite
-    for (int i = tid * 16; i < 3 * DYPLANE + 3 * XPLANE; i += NT * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid * 16; i < NP * DYPLANE + NP * XPLANE; i += NT * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0u, 0u, 0u, 0u};
 
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.dy), 0, (unsigned)(((size_t)(p.N - 1) * p.CoutTot + p.Cout) * p.HW * sizeof(float)), 0x00020000);
@@ -106,29 +107,28 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             xreg[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, o1, 0, 0));
         }
     };
+    const float sdy = uz::split_scale(*p.dy_amax), sx = uz::split_scale(*p.x_amax);
     auto lstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < DYSLOTS; ++i) {
-            unsigned a1, a2, a3, b1, b2, b3;
-            split3(dreg[i][0], dreg[i][1], a1, a2, a3);
-            split3(dreg[i][2], dreg[i][3], b1, b2, b3);
+            unsigned a1, a2, b1, b2;
+            split2(dreg[i][0] * sdy, dreg[i][1] * sdy, a1, a2);
+            split2(dreg[i][2] * sdy, dreg[i][3] * sdy, b1, b2);
             const int e = tid + i * NT, co = e >> 5, q = e & 31;
             char* d = dYl + co * DYROW + ((q / QROW) * TW + (q % QROW) * 4) * 2;
             *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
             *reinterpret_cast<uint2*>(d + DYPLANE) = make_uint2(a2, b2);
-            *reinterpret_cast<uint2*>(d + 2 * DYPLANE) = make_uint2(a3, b3);
         }
 #pragma unroll
         for (int i = 0; i < XSLOTS; ++i) {
             const int e = tid + i * NT;
             if (e < CIT * XPAIRS) {
                 const int ci = e / XPAIRS, rem = e - ci * XPAIRS, prow = rem / PAIRS_ROW, pj = rem - prow * PAIRS_ROW;
-                unsigned a1, a2, a3;
-                split3(xreg[i][0], xreg[i][1], a1, a2, a3);
+                unsigned a1, a2;
+                split2(xreg[i][0] * sx, xreg[i][1] * sx, a1, a2);
                 char* d = Xl + ci * XCH + prow * XROW + pj * 4;
                 *reinterpret_cast<unsigned*>(d) = a1;
                 *reinterpret_cast<unsigned*>(d + XPLANE) = a2;
-                *reinterpret_cast<unsigned*>(d + 2 * XPLANE) = a3;
             }
         }
     };
@@ -155,18 +155,18 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             for (int si = 0; si < PT / 16 / WK; ++si) {
                 const int s = si * WK + wk;                 // WK == 1: compile-time; WK == 4: wave-uniform
                 const int srow = s / SROW, scol = (s % SROW) * 16;
-                bf16x8 a[3];
+                f16x8 a[NP];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(Ab + q * DYPLANE + (srow * TW + scol) * 2);
+                for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const f16x8*>(Ab + q * DYPLANE + (srow * TW + scol) * 2);
                 // B fragments: per patch row d and plane q five dwords (b128 + b32); the three dx variants of a row are
                 // formed right before their MFMAs (dx = 0: dwords 0..3, dx = 2: dwords 1..4, dx = 1: v_alignbit of
                 // neighbours) so that only one row's raw dwords and one shifted triple are live at a time
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
-                    u32x4 v[3];
-                    unsigned v4[3];
+                    u32x4 v[NP];
+                    unsigned v4[NP];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
+                    for (int q = 0; q < NP; ++q) {
                         const char* src = Bb + q * XPLANE + (srow + DY0 + d) * XROW + scol * 2;
                         v[q] = *reinterpret_cast<const u32x4*>(src);
                         v4[q] = *reinterpret_cast<const unsigned*>(src + 16);
@@ -176,21 +176,18 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
                         constexpr int dummy = 0; (void)dummy;
                         const int tap = (DY0 + d) * 3 + dx, k = tap - TAP0;
                         if (k >= 0 && k < NTAP) {
-                            bf16x8 b[3];
+                            f16x8 b[NP];
 #pragma unroll
-                            for (int q = 0; q < 3; ++q) {
-                                if (dx == 0) b[q] = __builtin_bit_cast(bf16x8, v[q]);
-                                else if (dx == 2) b[q] = __builtin_bit_cast(bf16x8, u32x4{v[q].y, v[q].z, v[q].w, v4[q]});
-                                else b[q] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(v[q].y, v[q].x, 16), __builtin_amdgcn_alignbit(v[q].z, v[q].y, 16),
+                            for (int q = 0; q < NP; ++q) {
+                                if (dx == 0) b[q] = __builtin_bit_cast(f16x8, v[q]);
+                                else if (dx == 2) b[q] = __builtin_bit_cast(f16x8, u32x4{v[q].y, v[q].z, v[q].w, v4[q]});
+                                else b[q] = __builtin_bit_cast(f16x8, u32x4{__builtin_amdgcn_alignbit(v[q].y, v[q].x, 16), __builtin_amdgcn_alignbit(v[q].z, v[q].y, 16),
                                                                              __builtin_amdgcn_alignbit(v[q].w, v[q].z, 16), __builtin_amdgcn_alignbit(v4[q], v[q].w, 16)});
                             }
                             f32x16 acc_k = acc[k < 0 ? 0 : (k >= NTAP ? NTAP - 1 : k)];
-                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc_k, 0, 0, 0);
-                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc_k, 0, 0, 0);
-                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc_k, 0, 0, 0);
-                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc_k, 0, 0, 0);
-                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc_k, 0, 0, 0);
-                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc_k, 0, 0, 0);
+                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc_k, 0, 0, 0);
+                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc_k, 0, 0, 0);
+                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc_k, 0, 0, 0);
                             acc[k < 0 ? 0 : (k >= NTAP ? NTAP - 1 : k)] = acc_k;
                         }
                     }
@@ -232,12 +229,13 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         }
         float* out = p.slab + (size_t)split * 9 * p.Cout * p.Cin;
         const int ci = ci0 + wn * 32 + l31;
+        const float inv_dy = uz::split_inv_scale(*p.dy_amax), inv_x = uz::split_inv_scale(*p.x_amax);      // exact powers of two
 #pragma unroll
         for (int k = 0; k < NTAP; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (co < p.Cout && ci < p.Cin) out[((size_t)(TAP0 + k) * p.Cout + co) * p.Cin + ci] = acc[k][r];
+                if (co < p.Cout && ci < p.Cin) out[((size_t)(TAP0 + k) * p.Cout + co) * p.Cin + ci] = acc[k][r] * inv_dy * inv_x;
             }
     };
     if (tg == 0) run(std::integral_constant<int, 5>{}, std::integral_constant<int, 0>{});
@@ -248,8 +246,8 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
 
 namespace uz {
 
-// layers that take the split-bf16 weight gradient: 3x3, rows a multiple of 32 wide or exactly 16 wide (aligned
-// float4 / bf16-pair staging) and either at least 64 channels on both sides (64 x 64 tile; a 32-channel side
+// layers that take the split-fp16 weight gradient: 3x3, rows a multiple of 32 wide or exactly 16 wide (aligned
+// float4 / fp16-pair staging) and either at least 64 channels on both sides (64 x 64 tile; a 32-channel side
 // would leave half of it empty) or at most 32 on both (32 x 32 tile: the full-resolution 32 -> 32 layers and the
 // 1- and 3-channel input layers), with enough pixels to amortise the tile loop
 bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks) {
@@ -278,7 +276,7 @@ int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
 
 template <int TWv, int CT>
 static int launch_wgrad(const WS& p, int grid, hipStream_t st) {
-    constexpr size_t smem = 3 * (size_t)(CT * DYROW) + 3 * (size_t)(CT * XCH);
+    constexpr size_t smem = NP * (size_t)(CT * DYROW) + NP * (size_t)(CT * XCH);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<TWv, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -290,9 +288,9 @@ static int launch_wgrad(const WS& p, int grid, hipStream_t st) {
 }
 
 int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* slab,
-                int N, int H, int W, int S, hipStream_t st) {
+                int N, int H, int W, int S, const float* x_amax, const float* dy_amax, hipStream_t st) {
     WS p;
-    p.x = x; p.dy = dy; p.slab = slab;
+    p.x = x; p.dy = dy; p.slab = slab; p.x_amax = x_amax; p.dy_amax = dy_amax;
     p.N = N; p.H = H; p.W = W; p.HW = H * W; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot;
     const int tw = tile_w(W), ct = chan_tile(Cin, Cout);
     p.tilesX = W / tw; p.tilesY = ceil_div(H, PT / tw); p.T = N * p.tilesX * p.tilesY; p.S = S;

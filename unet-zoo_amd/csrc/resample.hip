@@ -16,11 +16,19 @@ struct RsP {
     int Ho, Wo;                         // sizes of the HIGH-resolution side (pool input / upsample output)
     int ac, factor, accumulate;
     float sh, sw;
+    const float* x_amax; float* y_amax;   // forward pooling / interpolation are convex combinations: |y| <= bound of |x|
 };
+
+// the output bound of a pooling / interpolation pass is its input's bound (one lane of the grid forwards it)
+__device__ __forceinline__ void forward_bound(const RsP& p) {
+    if (p.y_amax && p.x_amax && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned*>(p.y_amax), __builtin_bit_cast(unsigned, *p.x_amax));
+}
 
 // ---------------------------------------------------------------- avg pool 2x2 stride 2 ceil_mode
 // here (Ho,Wo) is the pool INPUT (high-res) and (H,W) the pool OUTPUT
 __global__ __launch_bounds__(256) void avgpool_fwd_k(const RsP p) {
+    forward_bound(p);
     const int c = blockIdx.y, b = blockIdx.z;
     const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
     float* d = p.dst + ((size_t)b * p.CtotD + c) * p.H * p.W;
@@ -61,6 +69,7 @@ __device__ __forceinline__ void src_index(int o, float scale, int ac, int in, in
     l0 = 1.f - l1;
 }
 __global__ __launch_bounds__(256) void bilinear_fwd_k(const RsP p) {
+    forward_bound(p);
     const int c = blockIdx.y, b = blockIdx.z;
     const float* s = p.src + ((size_t)b * p.CtotS + c) * p.H * p.W;
     float* d = p.dst + ((size_t)b * p.CtotD + c) * p.Ho * p.Wo;
@@ -240,9 +249,10 @@ int check_dims(const char* op, int C, int N, int H, int W) {
     hipLaunchKernelGGL(kern, dim3(uz::ceil_div((nplane), PCH), C, N), dim3(256), 0, uz::S(stream), p); \
     return uz::check_launch(#kern)
 
-extern "C" int uz_avgpool2_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W, void* stream) {
+extern "C" int uz_avgpool2_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W,
+                               const float* x_amax, float* y_amax, void* stream) {
     if (int rc = check_dims("avgpool2_fwd", C, N, H, W)) return rc;
-    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N;
+    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N; p.x_amax = x_amax; p.y_amax = y_amax;
     p.Ho = H; p.Wo = W; p.H = (H + 1) / 2; p.W = (W + 1) / 2;
     RS_LAUNCH(avgpool_fwd_k, p.H * p.W);
 }
@@ -256,9 +266,10 @@ static void bil_scales(RsP& p) {
     if (p.ac) { p.sh = p.Ho > 1 ? (float)(p.H - 1) / (float)(p.Ho - 1) : 0.f; p.sw = p.Wo > 1 ? (float)(p.W - 1) / (float)(p.Wo - 1) : 0.f; }
     else { p.sh = 0.5f; p.sw = 0.5f; }     // scale_factor=2 given: scale = 1/scale_factor
 }
-extern "C" int uz_bilinear2x_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W, int align_corners, void* stream) {
+extern "C" int uz_bilinear2x_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W, int align_corners,
+                                 const float* x_amax, float* y_amax, void* stream) {
     if (int rc = check_dims("bilinear2x_fwd", C, N, H, W)) return rc;
-    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N;
+    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N; p.x_amax = x_amax; p.y_amax = y_amax;
     p.H = H; p.W = W; p.Ho = 2 * H; p.Wo = 2 * W; p.ac = align_corners; bil_scales(p);
     RS_LAUNCH(bilinear_fwd_k, p.Ho * p.Wo);
 }

@@ -70,23 +70,23 @@ static int run_one(const uz_op& o, void* st) {
 #define CFP(k) static_cast<const float*>(p[k])
     switch (o.code) {
         case UZ_OP_CONV_FWD:
-            return uz_conv_fwd(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], i[8], p[4], (size_t)o.n, st);
+            return uz_conv_fwd(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(5), CFP(6), FP(7), p[4], (size_t)o.n, st);
         case UZ_OP_CONV_BWD_DATA:
-            return uz_conv_bwd_data(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], p[3], (size_t)o.n, st);
+            return uz_conv_bwd_data(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, st);
         case UZ_OP_CONV_BWD_WEIGHT:
-            return uz_conv_bwd_weight(CFP(0), i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], i[7], p[4], (size_t)o.n, st);
+            return uz_conv_bwd_weight(CFP(0), i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], i[7], CFP(5), CFP(6), p[4], (size_t)o.n, st);
         case UZ_OP_BN_RELU_FWD:
-            return uz_bn_relu_fwd(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], p[7], st);
+            return uz_bn_relu_fwd(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], FP(8), p[7], st);
         case UZ_OP_BN_RELU_BWD:
-            return uz_bn_relu_bwd(CFP(0), i[0], CFP(1), i[1], i[2], CFP(2), CFP(3), CFP(4), FP(5), i[3], FP(6), FP(7), FP(8), i[4], i[5], i[6], i[7], p[9], st);
+            return uz_bn_relu_bwd(CFP(0), i[0], CFP(1), i[1], i[2], CFP(2), CFP(3), CFP(4), FP(5), i[3], FP(6), FP(7), FP(8), i[4], i[5], i[6], i[7], FP(10), p[9], st);
         case UZ_OP_RELU_BWD:
-            return uz_relu_bwd(CFP(0), i[0], CFP(1), i[1], i[2], FP(2), i[3], FP(3), i[4], i[5], i[6], p[4], st);
+            return uz_relu_bwd(CFP(0), i[0], CFP(1), i[1], i[2], FP(2), i[3], FP(3), i[4], i[5], i[6], FP(5), p[4], st);
         case UZ_OP_AVGPOOL_FWD:
-            return uz_avgpool2_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], st);
+            return uz_avgpool2_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], CFP(2), FP(3), st);
         case UZ_OP_AVGPOOL_BWD:
             return uz_avgpool2_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], st);
         case UZ_OP_BILINEAR_FWD:
-            return uz_bilinear2x_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], st);
+            return uz_bilinear2x_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], CFP(2), FP(3), st);
         case UZ_OP_BILINEAR_BWD:
             return uz_bilinear2x_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], i[7], st);
         case UZ_OP_NEAREST_FWD:
@@ -135,6 +135,10 @@ static int run_one(const uz_op& o, void* st) {
             return uz_bcast_channels_fwd(CFP(0), i[0], FP(1), i[1], i[2], i[3], i[4], st);
         case UZ_OP_BCAST_CHANNELS_BWD:
             return uz_bcast_channels_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], st);
+        case UZ_OP_ABSMAX:
+            return uz_absmax(CFP(0), (size_t)o.n, FP(1), st);
+        case UZ_OP_EVENT_RECORD:
+            return uz_event_record(p[0], st);
         default:
             return uz::fail("run_tape: unknown op code %d", o.code);
     }

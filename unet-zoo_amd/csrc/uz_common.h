@@ -10,7 +10,7 @@ namespace uz {
 void set_error(const char* fmt, ...);
 int  fail(const char* fmt, ...);          // set_error + return -1
 int  check_launch(const char* what);      // hipGetLastError -> status
-int  conv_math_mode();                    // 0 fp32 MFMA only | 1 split-bf16 where it pays | 2 split-bf16 wherever eligible
+int  conv_math_mode();                    // 0 fp32 MFMA only | 1 split-fp16 where it pays | 2 split-fp16 wherever eligible
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -54,18 +54,18 @@ __device__ __forceinline__ void block_sum_d(double (&v)[NV], double* smem /* >= 
     }
 }
 
-// conv_split.hip: 3x3 forward / data gradient on the bf16 matrix pipe with three-way split operands (fp32-accurate)
+// conv_split.hip: 3x3 forward / data gradient on the fp16 matrix pipe with two-piece split operands (fp32-accurate)
 bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks);
 size_t conv_split_workspace(int Kc, int Mc, int W);
 int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
-               void* workspace, hipStream_t st);
+               const float* x_amax, const float* w_amax, float* y_amax, void* workspace, hipStream_t st);
 
-// conv_wgrad_split.hip: 3x3 weight gradient on the bf16 matrix pipe with three-way split operands
+// conv_wgrad_split.hip: 3x3 weight gradient on the fp16 matrix pipe with two-piece split operands
 bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks);
 int wgrad_split_splits(int Cin, int Cout, int N, int H, int W);
 int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* slab,
-                int N, int H, int W, int S, hipStream_t st);
+                int N, int H, int W, int S, const float* x_amax, const float* dy_amax, hipStream_t st);
 
 // conv1x1_small.hip: streaming VALU kernels for 1x1 convolutions with <= 8 outputs (-2 = shape not covered)
 bool conv1x1_small_ok(int Cin, int Cout);

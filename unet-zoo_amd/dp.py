@@ -63,3 +63,148 @@ def broadcast_(flat, src=0, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)
     return flat
+
+
+# ----------------------------------------------------------------------------------------------
+# Bucketed, overlapped gradient exchange
+# ----------------------------------------------------------------------------------------------
+def param_buckets(ptab, min_floats=1 << 20):
+    """Contiguous [lo, hi) float ranges of the flat gradient buffer, one per sub-network (first component of the
+    state_dict key: posterior / likelihood / prior for PHiSeg; unet / prior / posterior / fcomb for the Probabilistic
+    U-Net).  Neighbours smaller than `min_floats` are merged - a ring all-reduce of a few hundred KB is latency, not
+    bandwidth.  The backward tape finishes these ranges at different times (PHiSeg: prior at ~49 %, likelihood at ~84 %
+    of the tape), which is what the overlap exploits."""
+    runs = []
+    for key, off in ptab.poff.items():
+        top = key.split(".", 1)[0]
+        n = 1
+        for s_ in ptab.shape[key]:
+            n *= int(s_)
+        if runs and runs[-1][0] == top and runs[-1][2] == off:
+            runs[-1][2] = off + n
+        else:
+            runs.append([top, off, off + n])
+    out = []
+    for _, lo, hi in runs:
+        if out and (hi - lo < min_floats or out[-1][1] - out[-1][0] < min_floats):
+            out[-1][1] = hi
+        else:
+            out.append([lo, hi])
+    return [(lo, hi) for lo, hi in out]
+
+
+class GradSync:
+    """Averages the flat gradient buffer over the ranks, one bucket at a time, overlapped with the backward tape.
+
+    backend "rccl": RCCL through this package's own C ABI (uz_comm_* over librccl.so) on a private high-priority
+    communication stream; torch.distributed is used ONCE, to hand rank 0's 128-byte unique id to the other ranks.
+    The backward tape records one event per bucket (UZ_OP_EVENT_RECORD, also inside the hipGraph); per bucket the
+    communication stream waits for that event and runs ncclAllReduce(avg) while the compute stream continues; the
+    compute stream then waits for ONE event behind the last all-reduce, so Adam starts as soon as the gradients are
+    averaged.  No host synchronisation anywhere.
+    backend "torch": torch.distributed collectives (gloo on a one-GPU test box, where RCCL refuses two ranks per
+    device): same buckets, same order, blocking."""
+
+    def __init__(self, model, group=None, backend=None, overlap=True):
+        import ctypes as C
+        from . import _ffi
+        self.model, self.group, self.overlap = model, group, bool(overlap)
+        self.C, self._ffi, self.L = C, _ffi, _ffi.lib()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if backend is None:
+            backend = os.environ.get("UZ_DP_BACKEND") or \
+                ("rccl" if (dist.is_initialized() and dist.get_backend(group) == "nccl") else "torch")
+        self.backend = backend
+        self.comm = self.stream = self.done = None
+        self.t0 = self.t1 = None
+        self.buckets = param_buckets(model._ptab)
+        if backend == "rccl":
+            self._init_rccl()
+
+    # ------------------------------------------------------------------ RCCL through the C ABI
+    def _init_rccl(self):
+        C, L, check = self.C, self.L, self._ffi.check
+        lib = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")     # the copy this process already maps
+        check(L.uz_comm_load(lib.encode() if os.path.exists(lib) else None), "comm_load")
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            check(L.uz_comm_unique_id(uid), "comm_unique_id")
+        if self.world > 1:
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            uid = (C.c_char * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        check(L.uz_comm_init(self.rank, self.world, uid, C.byref(h)), "comm_init")
+        self.comm = h.value
+        s = C.c_void_p()
+        check(L.uz_stream_create(C.byref(s), 1), "stream_create")
+        self.stream = s.value
+        ev = []
+        for timing in (0, 1, 1):
+            e = C.c_void_p()
+            check(L.uz_event_create(C.byref(e), timing), "event_create")
+            ev.append(e.value)
+        self.done, self.t0, self.t1 = ev
+
+    def broadcast_params(self):
+        """Replicas start from rank 0's parameters and BatchNorm buffers."""
+        pt = self.model._ptab
+        if self.world == 1:
+            return
+        if self.backend == "rccl":
+            st = self.model._stream()
+            self._ffi.check(self.L.uz_broadcast_f32(self.comm, pt.pflat.data_ptr(), pt.n_params, 0, st), "broadcast")
+            self._ffi.check(self.L.uz_broadcast_f32(self.comm, pt.bflat.data_ptr(), pt.n_buffers, 0, st), "broadcast")
+        else:
+            broadcast_(pt.pflat, 0, self.group)
+            broadcast_(pt.bflat, 0, self.group)
+
+    def order(self, plan):
+        """Bucket indices in the order the (scheduled) backward tape finishes them."""
+        pos = {}
+        for k, o in enumerate(plan.bwd_ops):
+            if o["code"] == "UZ_OP_EVENT_RECORD":
+                pos[o["p"][0][1]] = k
+        return sorted(pos, key=pos.get)
+
+    def sync(self, plan, serial=False):
+        """Called right after the backward tape has been launched on the compute stream.  serial=True: the caller
+        touched the gradient buffer after the tape (gradient accumulation), so the bucket events are stale - exchange
+        everything behind the compute stream's current position instead."""
+        gflat = self.model._ptab.gflat
+        base = gflat.data_ptr()
+        if self.backend != "rccl":
+            if self.world > 1:
+                for b in (self.order(plan) if plan.events else range(len(self.buckets))):
+                    lo, hi = self.buckets[b]
+                    dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                gflat.mul_(1.0 / self.world)
+            return
+        L, check, cs = self.L, self._ffi.check, self.model._stream()
+        check(L.uz_event_record(self.t0, cs), "event_record")              # compute stream: backward tape done
+        if self.overlap and plan.events and not serial:
+            for b in self.order(plan):
+                lo, hi = self.buckets[b]
+                check(L.uz_stream_wait_event(self.stream, plan.events[b]), "stream_wait_event")
+                check(L.uz_allreduce_mean_f32(self.comm, base + 4 * lo, hi - lo, self.stream), "allreduce")
+        else:                                                                # one blocking-order all-reduce behind the whole tape
+            check(L.uz_stream_wait_event(self.stream, self.t0), "stream_wait_event")
+            check(L.uz_allreduce_mean_f32(self.comm, base, gflat.numel(), self.stream), "allreduce")
+        check(L.uz_event_record(self.t1, self.stream), "event_record")
+        check(L.uz_stream_wait_event(cs, self.t1), "stream_wait_event")    # Adam (compute stream) starts behind the last all-reduce
+
+    def exposed_ms(self):
+        """Time between the end of the backward tape and the end of the last all-reduce of the most recent step
+        (= what the collective adds to the step; <= 0 means fully hidden).  Synchronises."""
+        if self.backend != "rccl" or self.t0 is None:
+            return None
+        torch.cuda.synchronize()
+        ms = self.C.c_float()
+        self._ffi.check(self.L.uz_event_elapsed_ms(self.t0, self.t1, self.C.byref(ms)), "event_elapsed")
+        return float(ms.value)
+
+    def close(self):
+        if self.comm:
+            self.L.uz_comm_destroy(self.comm)
+            self.comm = None

@@ -175,9 +175,11 @@ class ProbabilisticUnet(NativeModel):
             self._bump_nbt(plan)
         self._cur = plan
         L = self.latent_dim
+        # validate_args=False: torch.distributions' argument check is a device -> host synchronisation per forward (and it
+        # raises on sigma == 0, which exp(log sigma) reaches by underflow on un-normalised synthetic data)
         if segm is not None:
-            self.posterior_latent_space = Independent(Normal(loc=T(io["q_mu"]).reshape(N, L), scale=T(io["q"].sigma).reshape(N, L)), 1)
-        self.prior_latent_space = Independent(Normal(loc=T(io["p_mu"]).reshape(N, L), scale=T(io["p"].sigma).reshape(N, L)), 1)
+            self.posterior_latent_space = Independent(Normal(loc=T(io["q_mu"]).reshape(N, L), scale=T(io["q"].sigma).reshape(N, L), validate_args=False), 1)
+        self.prior_latent_space = Independent(Normal(loc=T(io["p_mu"]).reshape(N, L), scale=T(io["p"].sigma).reshape(N, L), validate_args=False), 1)
         self.unet_features = T(io["features"])
         return T(io["last_conv"])
 
