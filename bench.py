@@ -409,6 +409,7 @@ def main():
     final_loss = float(loss.detach())
 
     extra = {}
+    train_plan = net._cur
     if args.model == "probunet" and rank == 0:
         # "8 posterior samples" (BASELINE configs[2]): after one forward, 8 x [z = posterior.rsample(); fcomb(features, z)]
         # = reconstruct(calculate_posterior=True) (probabilistic_unet.py:272-283), timed separately from the train step
@@ -434,7 +435,7 @@ def main():
         ips = args.batch * world * args.steps / elapsed
         per_gpu = ips / world
         achieved = per_gpu * M["gflop"] / 1e3
-        plan = net._cur
+        plan = train_plan
         eff_peak, share = binding_roof(plan, L)
         roof = dict(bound="mfma", achieved=round(achieved, 3), peak=round(eff_peak, 1), unit="TFLOP/s",
                     frac=round(achieved / eff_peak, 4), traffic=None,

@@ -3,7 +3,9 @@
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from bench import FILTERS, conv_flops, op_bytes, FAMILY
+from bench import FILTERS7 as FILTERS, conv_flops as _cf, op_bytes as _ob, FAMILY
+conv_flops = lambda o, _=None: _cf(o)
+op_bytes = lambda o, _=None: _ob(o)
 from unet_zoo_amd import _ffi
 from unet_zoo_amd.models.phiseg import PHISeg
 from unet_zoo_amd.synthetic import synthetic_batch

@@ -26,6 +26,7 @@ from . import _ffi
 BN_EPS = 1e-3        # reference torchlayers.py:20
 BN_MOMENTUM = 0.01   # reference torchlayers.py:20
 _ALIGN = 64          # floats
+_AMAX_FLOATS = 256   # floats per magnitude-bound slot: 16 sub-slots 64 bytes apart (csrc/split_f16.h)
 
 
 def _numel(shape):
@@ -554,12 +555,12 @@ class Plan:
         head = self._gid = -1
         if self.fwd_ops:
             ops0 = []
-            ops0.append(dict(code="UZ_OP_MEMSET", p=[("amaxrange", 0, self.n_amax_fwd)], i=[], f=[], n=4 * self.n_amax_fwd, gid=head))
+            ops0.append(dict(code="UZ_OP_MEMSET", p=[("amaxrange", 0, self.n_amax_fwd)], i=[], f=[], n=4 * _AMAX_FLOATS * self.n_amax_fwd, gid=head))
             ops0.append(dict(code="UZ_OP_ABSMAX", p=[("pflat",), ("amaxw", 0)], i=[], f=[], n=self.ptab.n_params, gid=head))
             self.fwd_ops[:0] = ops0
         if self.bwd_ops and bwd_slots:
             self.bwd_ops[:0] = [dict(code="UZ_OP_MEMSET", p=[("amaxrange", self.n_amax_fwd, self.n_amax)], i=[], f=[],
-                                     n=4 * (self.n_amax - self.n_amax_fwd), gid=head)]
+                                     n=4 * _AMAX_FLOATS * (self.n_amax - self.n_amax_fwd), gid=head)]
         # arena layout
         off = 0
         for b in self.bufs:
@@ -581,7 +582,7 @@ class Plan:
                 _ffi.check(self.L.uz_event_create(C.byref(h), 0), "event_create")
                 self.events.append(h.value)
         self.amax_off = off
-        off += -(-self.n_amax // _ALIGN) * _ALIGN
+        off += self.n_amax * _AMAX_FLOATS
         self.arena_floats = off
         self.arena = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.base = self.arena.data_ptr()
@@ -633,11 +634,11 @@ class Plan:
         if kind == "raw":
             return int(r[1])
         if kind == "amax":
-            return self.base + 4 * (self.amax_off + self._amax_remap[r[1]])
+            return self.base + 4 * (self.amax_off + _AMAX_FLOATS * self._amax_remap[r[1]])
         if kind == "amaxw":
-            return self.base + 4 * (self.amax_off + self._amax_remap[0])
+            return self.base + 4 * (self.amax_off + _AMAX_FLOATS * self._amax_remap[0])
         if kind == "amaxrange":
-            return self.base + 4 * (self.amax_off + r[1])
+            return self.base + 4 * (self.amax_off + _AMAX_FLOATS * r[1])
         if kind == "event":
             return self.events[r[1]] if self.events else 0
         if kind == "gflat_range":

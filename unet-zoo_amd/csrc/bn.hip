@@ -24,12 +24,26 @@ struct BnP {
     float* out;                                        // a (fwd) or dy (bwd)
     float* dgamma; float* dbeta; float* dbias;
     double* part; double* part2; double* chan;        // workspace
+    float* mm;                                         // workspace: per-(group, chunk, channel) {max, max of the negated} partials for the output bound
     int C, CtotY, CtotDa, CtotOut, N, HW, parts;
     int nb, ngrp;                                      // reduction kernels: images per workgroup, number of image groups
     float eps, momentum;
     int training, relu;
     float* amax;                                       // nullable: atomic max of |out| (bound for a following split-fp16 convolution)
 };
+
+// block-wide maxima of two floats (blockDim.x == 256); result valid in thread 0
+__device__ __forceinline__ void block_max2(float& a, float& b, float* smf /* >= 8 */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a = fmaxf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { smf[wave * 2] = a; smf[wave * 2 + 1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = fmaxf(fmaxf(smf[0], smf[2]), fmaxf(smf[4], smf[6]));
+        b = fmaxf(fmaxf(smf[1], smf[3]), fmaxf(smf[5], smf[7]));
+    }
+}
 
 __device__ __forceinline__ void alpha_beta(const BnP& p, int c, float& alpha, float& beta_, float& mean, float& rstd) {
     if (p.training) { mean = p.save[c]; rstd = p.save[p.C + c]; }
@@ -43,9 +57,11 @@ __device__ __forceinline__ void alpha_beta(const BnP& p, int c, float& alpha, fl
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_stats_partial(const BnP p) {
     __shared__ double sm[8];
+    __shared__ float smf[8];
     const int c = blockIdx.y, grp = blockIdx.z, part = blockIdx.x;
     const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
     double v2[2] = {0.0, 0.0};
+    float vmx = -INFINITY, vmn = -INFINITY;             // max(y), max(-y): the normalised output's range follows from them exactly
     // one workgroup sweeps the chunk of p.nb consecutive images before it pays for the block reduction
     for (int b = grp * p.nb; b < min(p.N, (grp + 1) * p.nb); ++b) {
         const float* src = p.y + ((size_t)b * p.CtotY + c) * p.HW;
@@ -57,32 +73,42 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const BnP p) {
                 const float4 v = s4[i];
                 s += (v.x + v.y) + (v.z + v.w);
                 ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                vmx = fmaxf(fmaxf(vmx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+                vmn = fmaxf(fmaxf(vmn, fmaxf(-v.x, -v.y)), fmaxf(-v.z, -v.w));
             }
         } else {
-            for (int i = lo + threadIdx.x; i < hi; i += 256) { const float v = src[i]; s += v; ss += v * v; }
+            for (int i = lo + threadIdx.x; i < hi; i += 256) { const float v = src[i]; s += v; ss += v * v; vmx = fmaxf(vmx, v); vmn = fmaxf(vmn, -v); }
         }
         v2[0] += (double)s; v2[1] += (double)ss;
     }
     uz::block_sum_d<2>(v2, sm);
+    block_max2(vmx, vmn, smf);
     if (threadIdx.x == 0) {
-        double* o = p.part + ((size_t)(grp * p.parts + part) * p.C + c) * 2;
-        o[0] = v2[0]; o[1] = v2[1];
+        const size_t e = (size_t)(grp * p.parts + part) * p.C + c;
+        p.part[e * 2] = v2[0]; p.part[e * 2 + 1] = v2[1];
+        p.mm[e * 2] = vmx; p.mm[e * 2 + 1] = vmn;
     }
 }
 
 // Ordered sum of the per-(image, chunk) fp64 partials of channel c, done by the first wave of every
 // workgroup that needs it (identical order everywhere, so every workgroup gets the same bits) - this
 // replaces a separate "finalize" launch per layer.
-__device__ __forceinline__ void channel_totals(const BnP& p, int c, double* red, double& t0, double& t1) {
+__device__ __forceinline__ void channel_totals(const BnP& p, int c, double* red, double& t0, double& t1, float* redf = nullptr) {
     if (threadIdx.x < 64) {
         const int P = p.ngrp * p.parts;
         double s = 0.0, ss = 0.0;
+        float ma = -INFINITY, mb = -INFINITY;
         for (int i = threadIdx.x; i < P; i += 64) {
             const double* o = p.part + ((size_t)i * p.C + c) * 2;
             s += o[0]; ss += o[1];
+            if (redf) { ma = fmaxf(ma, p.mm[((size_t)i * p.C + c) * 2]); mb = fmaxf(mb, p.mm[((size_t)i * p.C + c) * 2 + 1]); }
         }
         s = uz::wave_sum_d(s); ss = uz::wave_sum_d(ss);
-        if (threadIdx.x == 0) { red[0] = s; red[1] = ss; }
+        if (redf) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o, 64)); mb = fmaxf(mb, __shfl_xor(mb, o, 64)); }
+        }
+        if (threadIdx.x == 0) { red[0] = s; red[1] = ss; if (redf) { redf[0] = ma; redf[1] = mb; } }
     }
     __syncthreads();
     t0 = red[0]; t1 = red[1];
@@ -91,11 +117,12 @@ __device__ __forceinline__ void channel_totals(const BnP& p, int c, double* red,
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
     __shared__ double red[2];
+    __shared__ float redf[2];
     const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
     float alpha, beta_, mean, rstd;
     if (p.training) {
         double s, ss;
-        channel_totals(p, c, red, s, ss);
+        channel_totals(p, c, red, s, ss, redf);
         const double n = (double)p.N * p.HW;
         const double m = s / n;
         double var = ss / n - m * m;
@@ -114,9 +141,17 @@ __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
         const float g = p.gamma ? p.gamma[c] : 1.f, bb = p.beta ? p.beta[c] : 0.f;
         alpha = g * rstd;
         beta_ = bb - mean * alpha;
+        if (p.amax && b == 0 && part == 0 && threadIdx.x == 0) {
+            // the output is affine in y: its extremes sit at max(y) and min(y) = -max(-y) of the channel (exact; one
+            // publication per channel instead of one per workgroup)
+            const float floor0 = p.relu ? 0.f : -INFINITY;
+            const float e0 = fmaxf(fmaf(redf[0], alpha, beta_), floor0), e1 = fmaxf(fmaf(-redf[1], alpha, beta_), floor0);
+            uz::amax_publish_one(fmaxf(fabsf(e0), fabsf(e1)), p.amax, (unsigned)c);
+        }
     } else {
         alpha_beta(p, c, alpha, beta_, mean, rstd);
     }
+    const bool track = p.amax && !p.training;            // eval mode: no statistics pass to take the range from
     const float* src = p.y + ((size_t)b * p.CtotY + c) * p.HW;
     float* dst = p.out + ((size_t)b * p.CtotOut + c) * p.HW;
     const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
@@ -139,7 +174,7 @@ __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
             vmax = fmaxf(vmax, fabsf(v));
         }
     }
-    if (p.amax) uz::amax_publish(vmax, p.amax);
+    if (track) uz::amax_publish(vmax, p.amax);
 }
 
 // ------------------------------------------------------------------ forward, small path (one WG / channel)
@@ -195,18 +230,22 @@ __global__ __launch_bounds__(256) void bn_fused_small_fwd(const BnP p) {
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_partial(const BnP p) {
     __shared__ double sm[8];
+    __shared__ float smf[8];
     const int c = blockIdx.y, grp = blockIdx.z, part = blockIdx.x;
     float alpha, beta_, mean, rstd;
     alpha_beta(p, c, alpha, beta_, mean, rstd);
     const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
     double v2[2] = {0.0, 0.0};
+    float mdz = 0.f, mxh = 0.f;                          // max |dz|, max |x_hat|: bound of the gradient this layer hands down
     for (int b = grp * p.nb; b < min(p.N, (grp + 1) * p.nb); ++b) {
         const float* ys = p.y + ((size_t)b * p.CtotY + c) * p.HW;
         const float* ds = p.da + ((size_t)b * p.CtotDa + c) * p.HW;
         float s1 = 0.f, s2 = 0.f;
         auto one = [&](float yv, float dv) {
             const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
-            s1 += dz; s2 += dz * ((yv - mean) * rstd);
+            const float xh = (yv - mean) * rstd;
+            s1 += dz; s2 += dz * xh;
+            mdz = fmaxf(mdz, fabsf(dz)); mxh = fmaxf(mxh, fabsf(xh));
         };
         if (VEC) {
             const float4* y4 = reinterpret_cast<const float4*>(ys);
@@ -222,9 +261,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_partial(const BnP p) {
         v2[0] += (double)s1; v2[1] += (double)s2;
     }
     uz::block_sum_d<2>(v2, sm);
+    block_max2(mdz, mxh, smf);
     if (threadIdx.x == 0) {
-        double* o = p.part + ((size_t)(grp * p.parts + part) * p.C + c) * 2;
-        o[0] = v2[0]; o[1] = v2[1];
+        const size_t e = (size_t)(grp * p.parts + part) * p.C + c;
+        p.part[e * 2] = v2[0]; p.part[e * 2 + 1] = v2[1];
+        p.mm[e * 2] = mdz; p.mm[e * 2 + 1] = mxh;
     }
 }
 
@@ -232,27 +273,30 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const BnP p) {
     __shared__ double sm[4];
     __shared__ double red[2];
+    __shared__ float redf[2];
     const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
     float alpha, beta_, mean, rstd;
     alpha_beta(p, c, alpha, beta_, mean, rstd);
     double s1, s2;
-    channel_totals(p, c, red, s1, s2);
+    channel_totals(p, c, red, s1, s2, redf);
+    const double n = (double)p.N * p.HW;
+    const float m1 = (float)(s1 / n), m2 = (float)(s2 / n);
     if (b == 0 && part == 0 && threadIdx.x == 0) {
         if (p.dbeta) p.dbeta[c] = (float)s1;
         if (p.dgamma) p.dgamma[c] = (float)s2;
+        // |dy| = |alpha| |dz - m1 - x_hat m2| <= |alpha| (max|dz| + |m1| + max|x_hat| |m2|): an upper bound within a small factor
+        // of the true maximum, one publication per channel (the split-fp16 consumers need a bound, not the maximum)
+        if (p.amax) uz::amax_publish_one(fabsf(alpha) * (redf[0] + fabsf(m1) + redf[1] * fabsf(m2)), p.amax, (unsigned)c);
     }
-    const double n = (double)p.N * p.HW;
-    const float m1 = (float)(s1 / n), m2 = (float)(s2 / n);
     const float* ys = p.y + ((size_t)b * p.CtotY + c) * p.HW;
     const float* ds = p.da + ((size_t)b * p.CtotDa + c) * p.HW;
     float* dst = p.out + ((size_t)b * p.CtotOut + c) * p.HW;
     const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
-    float sd = 0.f, vmax = 0.f;
+    float sd = 0.f;
     auto one = [&](float yv, float dv) -> float {
         const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
         const float r = alpha * (dz - m1 - ((yv - mean) * rstd) * m2);
         sd += r;
-        vmax = fmaxf(vmax, fabsf(r));
         return r;
     };
     if (VEC) {
@@ -268,7 +312,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnP p) {
     } else {
         for (int i = lo + threadIdx.x; i < hi; i += 256) dst[i] = one(ys[i], ds[i]);
     }
-    if (p.amax) uz::amax_publish(vmax, p.amax);
     if (p.dbias) {
         double v1[1] = {(double)sd};
         uz::block_sum_d<1>(v1, sm);
@@ -375,7 +418,7 @@ inline bool vec_ok(int HW, const void* a, const void* b, const void* c) {
 extern "C" size_t uz_bn_workspace(int C, int N, int H, int W) {
     const int parts = uz::ceil_div(H * W, CHUNK);
     const size_t P = (size_t)N * parts;
-    return (P * C * 3 + (size_t)2 * C) * sizeof(double) + 256;
+    return (P * C * 3 + (size_t)2 * C) * sizeof(double) + P * C * 2 * sizeof(float) + 256;
 }
 
 namespace {
@@ -393,6 +436,7 @@ void carve(BnP& p, void* ws) {
     p.part = static_cast<double*>(ws);
     p.part2 = p.part + P * p.C * 2;
     p.chan = p.part2 + P * p.C;
+    p.mm = reinterpret_cast<float*>(p.chan + 2 * p.C);
 }
 }  // namespace
 

@@ -167,15 +167,28 @@ extern "C" int uz_event_create(void** event_out, int timing) {
     return 0;
 }
 extern "C" void uz_event_destroy(void* event) { if (event) (void)hipEventDestroy(static_cast<hipEvent_t>(event)); }
-// Works both on a live stream and on a stream under capture (then it becomes an external event-record node of the graph,
-// i.e. every later replay of the graph re-records the event at that point of the DAG).
+// Works both on a live stream and on a stream under capture.  Under capture the record becomes an event-record NODE of the
+// graph being built (added explicitly behind the stream's current capture dependencies, which it then replaces), so every
+// later replay of the graph re-records the event at that point of the DAG and streams outside the graph can wait for it.
 extern "C" int uz_event_record(void* event, void* stream) {
+    hipStream_t st = uz::S(stream);
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(uz::S(stream), &cs);
-    const hipError_t e = cs == hipStreamCaptureStatusActive
-                             ? hipEventRecordWithFlags(static_cast<hipEvent_t>(event), uz::S(stream), hipEventRecordExternal)
-                             : hipEventRecord(static_cast<hipEvent_t>(event), uz::S(stream));
-    return e == hipSuccess ? 0 : uz::fail("event_record: %s", hipGetErrorString(e));
+    (void)hipStreamIsCapturing(st, &cs);
+    if (cs != hipStreamCaptureStatusActive) {
+        const hipError_t e = hipEventRecord(static_cast<hipEvent_t>(event), st);
+        return e == hipSuccess ? 0 : uz::fail("event_record: %s", hipGetErrorString(e));
+    }
+    unsigned long long id = 0;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t* deps = nullptr;
+    size_t nd = 0;
+    hipError_t e = hipStreamGetCaptureInfo_v2(st, &cs, &id, &graph, &deps, &nd);
+    if (e != hipSuccess || !graph) return uz::fail("event_record: hipStreamGetCaptureInfo_v2: %s", hipGetErrorString(e));
+    hipGraphNode_t node = nullptr;
+    e = hipGraphAddEventRecordNode(&node, graph, deps, nd, static_cast<hipEvent_t>(event));
+    if (e != hipSuccess) return uz::fail("event_record: hipGraphAddEventRecordNode: %s", hipGetErrorString(e));
+    e = hipStreamUpdateCaptureDependencies(st, &node, 1, hipStreamSetCaptureDependencies);
+    return e == hipSuccess ? 0 : uz::fail("event_record: hipStreamUpdateCaptureDependencies: %s", hipGetErrorString(e));
 }
 extern "C" int uz_stream_wait_event(void* stream, void* event) {
     const hipError_t e = hipStreamWaitEvent(uz::S(stream), static_cast<hipEvent_t>(event), 0);

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
     const int tapL = DGRAD ? KK - 1 - tap : tap;
     const int wplane = KK * COT * CK * 2;
-    split_store16(v, uz::split_scale(*w_amax), packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * (CK * 2), wplane);
+    split_store16(v, uz::split_scale(uz::amax_read(w_amax)), packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * (CK * 2), wplane);
 }
 
 template <int MSUB, int NTv, int TWv>
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
     const int prow1 = NT + tid / G, q4 = tid & (G - 1);
     const unsigned xstep = 4u * (unsigned)p.HW;
     const unsigned wblock = (unsigned)NP * WPLANE;
-    const float xs = uz::split_scale(*p.x_amax);
+    const float xs = uz::split_scale(uz::amax_read(p.x_amax));
 
     // ---- per-lane output pixels (B operand columns)
     int poff[NSUB], oidx[NSUB];
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
     }
 
     // ---- epilogue: undo the operand scales (exact), bias, optional accumulate / ReLU, coalesced NCHW stores
-    const float inv_x = uz::split_inv_scale(*p.x_amax), inv_w = uz::split_inv_scale(*p.w_amax);
+    const float inv_x = uz::split_inv_scale(uz::amax_read(p.x_amax)), inv_w = uz::split_inv_scale(uz::amax_read(p.w_amax));
     float vmax = 0.f;
 #pragma unroll
     for (int m = 0; m < MSUB; ++m) {
@@ -325,8 +325,8 @@ bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks) {
     return false;
 }
 
-// workspace = [64 bytes: fallback bound slots (x, w)] [packed weight image of one direction]
-constexpr size_t WS_HEAD = 64;
+// workspace = [two fallback bound slots (x, w)] [packed weight image of one direction]
+constexpr size_t WS_HEAD = 2 * AMAX_FLOATS * sizeof(float);
 size_t conv_split_workspace(int Kc, int Mc, int W) {
     const int cot = tile_cot(Mc, W);
     return WS_HEAD + (size_t)ceil_div(Kc, CK) * ceil_div(Mc, cot) * NP * (KK * cot * CK * 2);
@@ -374,8 +374,8 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
         if (!w_amax) {
             // the weight view may be a row / column slice of the parameter: bound over the enclosing rows is still a bound
             const size_t nw = dgrad ? (size_t)Kc * wCi * KK : (size_t)Mc * wCi * KK;
-            if (int rc = absmax_flat(w, nw, slots + 1, st)) return rc;
-            w_amax = slots + 1;
+            if (int rc = absmax_flat(w, nw, slots + AMAX_FLOATS, st)) return rc;
+            w_amax = slots + AMAX_FLOATS;
         }
     }
     p.x = x; p.wp = image; p.bias = bias; p.y = y;

@@ -474,7 +474,7 @@ extern "C" size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, 
     const size_t dbp = (size_t)Cout * CSB * sizeof(double);
     size_t need = slabs > dbp ? slabs : dbp;
     if (uz::wgrad_split_ok(Cin, Cout, N, H, W, ks)) {
-        const size_t sp = (size_t)uz::wgrad_split_splits(Cin, Cout, N, H, W) * ks * ks * Cout * Cin * sizeof(float) + 64;    // + fallback bound slots
+        const size_t sp = (size_t)uz::wgrad_split_splits(Cin, Cout, N, H, W) * ks * ks * Cout * Cin * sizeof(float) + 2 * uz::AMAX_FLOATS * sizeof(float);    // + fallback bound slots
         if (sp > need) need = sp;
     }
     if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) {
@@ -530,12 +530,13 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
     if (split_math) {                              // large layers: split-fp16 matrix pipe (conv_wgrad_split.hip), same slab layout
         Stot = uz::wgrad_split_splits(Cin, Cout, N, H, W);
         const size_t slab_bytes = (size_t)Stot * 9 * Cout * Cin * sizeof(float);
-        UZ_REQUIRE(workspace_bytes >= slab_bytes + 64, "conv_bwd_weight: workspace too small for the split path");
+        constexpr size_t slot_bytes = uz::AMAX_FLOATS * sizeof(float);
+        UZ_REQUIRE(workspace_bytes >= slab_bytes + 2 * slot_bytes, "conv_bwd_weight: workspace too small for the split path");
         if (!x_amax || !dy_amax) {             // no bounds from the caller: measure them (stand-alone C-ABI path)
             float* slots = reinterpret_cast<float*>(static_cast<char*>(workspace) + slab_bytes);
-            if (hipMemsetAsync(slots, 0, 64, st) != hipSuccess) return uz::fail("conv_bwd_weight: memset failed");
+            if (hipMemsetAsync(slots, 0, 2 * slot_bytes, st) != hipSuccess) return uz::fail("conv_bwd_weight: memset failed");
             if (!x_amax) { if (int rc = uz::absmax_view(x, Cin, CinTot, N, H * W, slots, st)) return rc; x_amax = slots; }
-            if (!dy_amax) { if (int rc = uz::absmax_view(dy, Cout, CoutTot, N, H * W, slots + 1, st)) return rc; dy_amax = slots + 1; }
+            if (!dy_amax) { if (int rc = uz::absmax_view(dy, Cout, CoutTot, N, H * W, slots + uz::AMAX_FLOATS, st)) return rc; dy_amax = slots + uz::AMAX_FLOATS; }
         }
         if (int rc = uz::wgrad_split(x, Cin, CinTot, dy, Cout, CoutTot, p.slab, N, H, W, Stot, x_amax, dy_amax, st)) return rc;
     }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             xreg[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, o1, 0, 0));
         }
     };
-    const float sdy = uz::split_scale(*p.dy_amax), sx = uz::split_scale(*p.x_amax);
+    const float sdy = uz::split_scale(uz::amax_read(p.dy_amax)), sx = uz::split_scale(uz::amax_read(p.x_amax));
     auto lstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < DYSLOTS; ++i) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         }
         float* out = p.slab + (size_t)split * 9 * p.Cout * p.Cin;
         const int ci = ci0 + wn * 32 + l31;
-        const float inv_dy = uz::split_inv_scale(*p.dy_amax), inv_x = uz::split_inv_scale(*p.x_amax);      // exact powers of two
+        const float inv_dy = uz::split_inv_scale(uz::amax_read(p.dy_amax)), inv_x = uz::split_inv_scale(uz::amax_read(p.x_amax));      // exact powers of two
 #pragma unroll
         for (int k = 0; k < NTAP; ++k)
 #pragma unroll

@@ -5,6 +5,7 @@
 // per (plane chunk, channel, image), consecutive lanes on consecutive x (coalesced), backward
 // passes written as deterministic gathers (no atomics).
 #include "uz_common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -22,7 +23,7 @@ struct RsP {
 // the output bound of a pooling / interpolation pass is its input's bound (one lane of the grid forwards it)
 __device__ __forceinline__ void forward_bound(const RsP& p) {
     if (p.y_amax && p.x_amax && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
-        atomicMax(reinterpret_cast<unsigned*>(p.y_amax), __builtin_bit_cast(unsigned, *p.x_amax));
+        uz::amax_publish_one(uz::amax_read(p.x_amax), p.y_amax, 0u);
 }
 
 // ---------------------------------------------------------------- avg pool 2x2 stride 2 ceil_mode

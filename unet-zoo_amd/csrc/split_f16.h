@@ -45,14 +45,34 @@ __device__ __forceinline__ void split2(float v0, float v1, unsigned& p1, unsigne
     p2 = __builtin_bit_cast(unsigned, h2);
 }
 
-// running |v| maximum -> one atomic per wave; slot holds the float bits of a non-negative value (ordered like unsigned)
+// ---- magnitude-bound slots.  A slot is AMAX_SUB sub-slots AMAX_STRIDE floats (64 bytes) apart; its value is the maximum
+// over the sub-slots.  Same-address float atomics serialise at the memory side (MI355X_MICROARCH.md, Global float atomics:
+// every workgroup into one row is 14x slower), so producers (a) spread their updates over the sub-slots and (b) read the
+// sub-slot first and skip the atomic when it already covers their value - after the first wave of updates almost all do.
+// Values are non-negative floats, whose bit patterns order like unsigned integers.
+constexpr int AMAX_SUB = 16, AMAX_STRIDE = 16, AMAX_FLOATS = AMAX_SUB * AMAX_STRIDE;
+
+__device__ __forceinline__ float amax_read(const float* slot) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < AMAX_SUB; ++i) m = fmaxf(m, slot[i * AMAX_STRIDE]);      // uniform address: scalar loads
+    return m;
+}
+// one lane publishes m (key selects the sub-slot)
+__device__ __forceinline__ void amax_publish_one(float m, float* slot, unsigned key) {
+    unsigned* p = reinterpret_cast<unsigned*>(slot) + (key % AMAX_SUB) * AMAX_STRIDE;
+    const unsigned bits = __builtin_bit_cast(unsigned, m);
+    if (bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, bits);
+}
+// every wave of the workgroup calls this with its lanes' running maxima: wave reduce, lane 0 publishes
 __device__ __forceinline__ void amax_publish(float m, float* slot) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, m));
+    if ((threadIdx.x & 63) == 0 && m > 0.f)
+        amax_publish_one(m, slot, blockIdx.x * 7u + blockIdx.y * 3u + blockIdx.z + (threadIdx.x >> 6));
 }
 
-// conv_split.hip: absmax of a channel-slice view (fallback when the caller supplies no bound); slot must be zeroed
+// conv_split.hip: absmax of a channel-slice view (fallback when the caller supplies no bound); slot (AMAX_FLOATS floats) must be zeroed
 int absmax_view(const float* x, int C, int Ctot, int N, int HW, float* slot, hipStream_t st);
 int absmax_flat(const float* x, size_t n, float* slot, hipStream_t st);
 
