@@ -359,6 +359,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if world > 1:
+        # data parallel: train on a created stream - the overlapped gradient exchange needs a second stream, and the legacy
+        # default stream serialises against it (dp.GradSync.sync)
+        torch.cuda.set_stream(torch.cuda.Stream(torch.device("cuda", local_rank)))
     from unet_zoo_amd import _ffi
     from unet_zoo_amd.synthetic import synthetic_batch
     from unet_zoo_amd.optim import FusedAdam

@@ -10,6 +10,8 @@ import torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+if not os.environ.get("UZ_NULL_STREAM"):
+    torch.cuda.set_stream(torch.cuda.Stream())          # as bench.py / train_model.py do for data-parallel runs
 from unet_zoo_amd.models.phiseg import PHISeg
 from unet_zoo_amd.optim import FusedAdam
 from unet_zoo_amd.synthetic import synthetic_batch
@@ -53,6 +55,17 @@ def run(dp, overlap=True, steps=8, timed=0):
 
 
 print("rccl version code", _ffi.lib().uz_comm_version())
+if os.environ.get("UZ_DP_DIAG") or os.environ.get("UZ_DP_ONLY"):
+    if os.environ.get("UZ_SIDE_STREAM"):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            p1, l1, ms1, ex1, nb, nev = run(True, overlap=True, timed=10)
+    else:
+        p1, l1, ms1, ex1, nb, nev = run(True, overlap=True, timed=10)
+    print(f"DIAG {os.environ.get('UZ_DP_DIAG')} side {os.environ.get('UZ_SIDE_STREAM')} prio {os.environ.get('UZ_DP_STREAM_PRIORITY')} lanes {os.environ.get('UZ_LANES')}: dp overlap {ms1:.3f} ms/step exposed {ex1}")
+    dist.destroy_process_group()
+    sys.exit(0)
 p0, l0, ms0, _, _, _ = run(False, timed=10)
 p1, l1, ms1, ex1, nb, nev = run(True, overlap=True, timed=10)
 p2, l2, ms2, ex2, _, _ = run(True, overlap=False, timed=10)

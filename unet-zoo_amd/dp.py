@@ -138,7 +138,7 @@ class GradSync:
         check(L.uz_comm_init(self.rank, self.world, uid, C.byref(h)), "comm_init")
         self.comm = h.value
         s = C.c_void_p()
-        check(L.uz_stream_create(C.byref(s), 1), "stream_create")
+        check(L.uz_stream_create(C.byref(s), int(os.environ.get("UZ_DP_STREAM_PRIORITY", "1"))), "stream_create")
         self.stream = s.value
         ev = []
         for timing in (0, 1, 1):
@@ -182,12 +182,31 @@ class GradSync:
                 gflat.mul_(1.0 / self.world)
             return
         L, check, cs = self.L, self._ffi.check, self.model._stream()
+        if not cs and self.overlap and not serial:
+            # The legacy default (NULL) stream serialises against other streams' dependencies: measured on MI355X / ROCm 7.2,
+            # a second stream merely WAITING on events recorded between the backward graphs costs +6 ms per step there and the
+            # overlapped all-reduce +15 ms, against +0.2 ms on any created stream.  Run data-parallel training under
+            # torch.cuda.stream(...) / torch.cuda.set_stream(...) (bench.py and train_model.py do); on the NULL stream fall
+            # back to one exchange behind the whole tape.
+            if not getattr(self, "_warned_null", False):
+                import warnings
+                warnings.warn("data-parallel overlap is disabled on the legacy default stream; make a created stream current "
+                              "(torch.cuda.set_stream(torch.cuda.Stream())) to overlap the gradient all-reduce with backward")
+                self._warned_null = True
+            serial = True
         check(L.uz_event_record(self.t0, cs), "event_record")              # compute stream: backward tape done
+        diag = os.environ.get("UZ_DP_DIAG", "")
         if self.overlap and plan.events and not serial:
             for b in self.order(plan):
                 lo, hi = self.buckets[b]
+                if diag == "nocomm":
+                    continue
+                if diag == "samestream":
+                    check(L.uz_allreduce_mean_f32(self.comm, base + 4 * lo, hi - lo, cs), "allreduce")
+                    continue
                 check(L.uz_stream_wait_event(self.stream, plan.events[b]), "stream_wait_event")
-                check(L.uz_allreduce_mean_f32(self.comm, base + 4 * lo, hi - lo, self.stream), "allreduce")
+                if diag != "waitonly":
+                    check(L.uz_allreduce_mean_f32(self.comm, base + 4 * lo, hi - lo, self.stream), "allreduce")
         else:                                                                # one blocking-order all-reduce behind the whole tape
             check(L.uz_stream_wait_event(self.stream, self.t0), "stream_wait_event")
             check(L.uz_allreduce_mean_f32(self.comm, base, gflat.numel(), self.stream), "allreduce")

@@ -108,6 +108,8 @@ class UNetModel:
         # one process per GPU: bind this rank to cuda:LOCAL_RANK *before* any buffer is allocated (the model, the
         # optimiser state and the RCCL communicator must all live on the same device)
         self.rank, self.local_rank, self.world = dp.init_from_env()
+        if self.world > 1 and torch.cuda.is_available():
+            torch.cuda.set_stream(torch.cuda.Stream())      # overlapped gradient exchange needs a created (non-default) stream
         kwargs = dict(input_channels=exp_config.input_channels, num_classes=exp_config.n_classes,
                       num_filters=exp_config.filter_channels, latent_levels=exp_config.latent_levels,
                       no_convs_fcomb=exp_config.no_convs_fcomb, beta=exp_config.beta,
