@@ -202,6 +202,11 @@ int uz_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
                  int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                  float grad_scale, void* stream);
 int uz_axpy(float* y, const float* x, float alpha, size_t n, void* stream);     /* y += alpha*x */
+/* Additive coupling of revtorch's ReversibleBlock (torchlayers.py:55-82: y1 = x1 + F(x2), y2 = x2 + G(y1), and its inversion
+ * x2 = y2 - G(y1), x1 = y1 - F(x2) in the recomputing backward pass): y = (accumulate ? y : 0) + a + alpha * b on
+ * channel-slice views of C channels (b nullable: plain strided copy / gradient fan-in).                                    */
+int uz_add_views(const float* a, int CtotA, const float* b, int CtotB, float* y, int CtotY, int C, int N, int H, int W,
+                 float alpha, int accumulate, const float* a_amax, const float* b_amax, float* y_amax, void* stream);
 /* slot[0] = max(slot[0], max_i |x_i|) (slot holds a non-negative float; zero it first for a plain maximum) */
 int uz_absmax(const float* x, size_t n, float* slot, void* stream);
 int uz_scale(float* y, float alpha, size_t n, void* stream);                    /* y *= alpha   */
@@ -226,6 +231,7 @@ enum {
   UZ_OP_ADAM, UZ_OP_AXPY, UZ_OP_SCALE, UZ_OP_L2_NORMS, UZ_OP_L2_NORMS_BWD,
   UZ_OP_MEMSET, UZ_OP_COPY, UZ_OP_BCAST_CHANNELS, UZ_OP_BCAST_CHANNELS_BWD,
   UZ_OP_ABSMAX,          /* p[0] = src, p[1] = slot, n = count */
+  UZ_OP_ADD_VIEWS,       /* p = a, b, y, a_amax, b_amax, y_amax; i = CtotA, CtotB, CtotY, C, N, H, W, accumulate; f[0] = alpha */
   UZ_OP_EVENT_RECORD,    /* p[0] = event (uz_event_create): marks "every earlier op this one depends on is done" */
   UZ_OP__COUNT
 };

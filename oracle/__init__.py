@@ -17,6 +17,11 @@ reference itself, generated in the build container by
 ``tools/gen_golden.py`` (imports ``/root/reference`` read-only) and committed
 as data under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks the
 oracle against every one of them.
+
+One exception, PARITY UNPINNED: the reversible blocks (``rev_sequence``) wrap
+``revtorch==0.2.0`` (requirements.txt:38), which is neither vendored under
+/root/reference nor installable here; its published additive-coupling algorithm
+is restated and no reference output pins it.
 """
 from .refgraph import (  # noqa: F401
     phiseg_forward, phiseg_loss, phiseg_accumulate_output, phiseg_eps_shapes,
@@ -24,4 +29,5 @@ from .refgraph import (  # noqa: F401
     probunet_forward, probunet_loss, probunet_fcomb,
     kl_two_gauss_with_diag_cov, batch_to_onehot,
     adam_reference_step, synthetic_batch, deterministic_state_dict,
+    rev_sequence, revtorch_second_bn_update,
 )

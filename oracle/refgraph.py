@@ -48,6 +48,49 @@ def conv_bare(sd, p, x):
     return F.conv2d(x, w, sd[p + ".convolution.0.bias"], padding=1 if w.shape[-1] == 3 else 0)
 
 
+def rev_sequence(sd, p, x, bn_train):
+    """ReversibleSequence (torchlayers.py:55-82).  `inital_conv` (sic): a 1x1 Conv2D unit when the channel counts differ;
+    then revtorch ReversibleBlocks.  revtorch==0.2.0 (requirements.txt:38) is NOT vendored under /root/reference and cannot be
+    installed here, so its published algorithm is restated - PARITY UNPINNED for this function (no reference run, no golden
+    vector): per block, with the channels split in halves (x1, x2),  y1 = x1 + F(x2),  y2 = x2 + G(y1),  output cat(y1, y2);
+    F / G = the block's `f_block` / `g_block` (here one 3x3 Conv2D unit each).  revtorch's backward pass inverts the block
+    (x2 = y2 - G(y1), x1 = y1 - F(x2)) and back-propagates through the recomputed F and G; plain autograd through this
+    forward gives the same gradients up to rounding, which is what the oracle uses.  Side effect of the recomputation that
+    the oracle does NOT reproduce by itself: BatchNorm running statistics of F and G are updated a second time per training
+    step (see `revtorch_second_bn_update`)."""
+    if f"{p}.inital_conv.convolution.0.weight" in sd:
+        x = conv_unit(sd, p + ".inital_conv", x, bn_train)
+    i = 0
+    while f"{p}.sequence.reversible_blocks.{i}.f_block.0.convolution.0.weight" in sd:
+        b = f"{p}.sequence.reversible_blocks.{i}"
+        x1, x2 = torch.chunk(x, 2, dim=1)
+        y1 = x1 + conv_unit(sd, b + ".f_block.0", x2, bn_train)
+        y2 = x2 + conv_unit(sd, b + ".g_block.0", y1, bn_train)
+        x = torch.cat([y1, y2], dim=1)
+        i += 1
+    return x
+
+
+def revtorch_second_bn_update(sd_before, sd_after):
+    """revtorch re-runs F and G in training mode while it recomputes activations in backward, so each of their BatchNorms
+    applies its momentum update twice per step with (numerically) the same batch statistics and counts two batches.
+    Given the buffers before the forward pass and after it, returns the state after the backward pass as well."""
+    out = {k: v.clone() for k, v in sd_after.items()}
+    for k, v in sd_after.items():
+        if ".reversible_blocks." not in k:
+            continue
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            batch = (v - (1 - BN_MOMENTUM) * sd_before[k]) / BN_MOMENTUM
+            out[k] = (1 - BN_MOMENTUM) * v + BN_MOMENTUM * batch
+        elif k.endswith("num_batches_tracked"):
+            out[k] = v + (v - sd_before[k])
+    return out
+
+
+def _is_rev(sd, p):
+    return f"{p}.sequence.reversible_blocks.0.f_block.0.convolution.0.weight" in sd
+
+
 def avgpool(x):
     """nn.AvgPool2d(2, 2, padding=0, ceil_mode=True) (phiseg.py:23, unet.py:22, probabilistic_unet.py:56)."""
     return F.avg_pool2d(x, kernel_size=2, stride=2, padding=0, ceil_mode=True)
@@ -106,8 +149,11 @@ def _phiseg_encoder(sd, root, x, eps, bn_train, z_override=None):
         if i != 0:
             x = avgpool(x)
             base = 1
-        for j in range(3):
-            x = conv_unit(sd, f"{root}.contracting_path.{i}.layers.{base + j}", x, bn_train)
+        if _is_rev(sd, f"{root}.contracting_path.{i}.layers.{base}"):          # phiseg.py:25-26
+            x = rev_sequence(sd, f"{root}.contracting_path.{i}.layers.{base}", x, bn_train)
+        else:
+            for j in range(3):
+                x = conv_unit(sd, f"{root}.contracting_path.{i}.layers.{base + j}", x, bn_train)
         if i != PHISEG_RES_LEVELS - 1:
             blocks.append(x)
     L = PHISEG_LAT_LEVELS
@@ -116,12 +162,18 @@ def _phiseg_encoder(sd, root, x, eps, bn_train, z_override=None):
     for i in range(L):                                       # phiseg.py:196-202
         if i != 0:
             u = up2(z[-i], True)                             # phiseg.py:66
-            for j in range(2):
-                u = conv_unit(sd, f"{root}.upsampling_path.{i - 1}.upconv_layer.{j}", u, bn_train)
+            if _is_rev(sd, f"{root}.upsampling_path.{i - 1}.upconv_layer"):   # phiseg.py:53-54
+                u = rev_sequence(sd, f"{root}.upsampling_path.{i - 1}.upconv_layer", u, bn_train)
+            else:
+                for j in range(2):
+                    u = conv_unit(sd, f"{root}.upsampling_path.{i - 1}.upconv_layer.{j}", u, bn_train)
             pre = torch.cat([u, blocks[-i]], dim=1)          # phiseg.py:71
         h = pre
-        for j in range(2):                                   # SampleZBlock, phiseg.py:99-106
-            h = conv_unit(sd, f"{root}.sample_z_path.{i}.conv.{j}", h, bn_train)
+        if _is_rev(sd, f"{root}.sample_z_path.{i}.conv.0"):  # phiseg.py:87-88
+            h = rev_sequence(sd, f"{root}.sample_z_path.{i}.conv.0", h, bn_train)
+        else:
+            for j in range(2):                               # SampleZBlock, phiseg.py:99-106
+                h = conv_unit(sd, f"{root}.sample_z_path.{i}.conv.{j}", h, bn_train)
         p = f"{root}.sample_z_path.{i}"
         m = F.conv2d(h, sd[p + ".mu_conv.0.weight"], sd[p + ".mu_conv.0.bias"])
         s = F.softplus(F.conv2d(h, sd[p + ".sigma_conv.0.weight"], sd[p + ".sigma_conv.0.bias"]))
@@ -140,8 +192,11 @@ def _phiseg_likelihood(sd, z, image_hw, bn_train):
     root = "likelihood"
     for i in range(L):                                       # phiseg.py:293-300
         h = z[-i - 1]
-        for j in range(2):
-            h = conv_unit(sd, f"{root}.likelihood_ups_path.{i}.convolution.{j}", h, bn_train)
+        if _is_rev(sd, f"{root}.likelihood_ups_path.{i}"):   # phiseg.py:261-262
+            h = rev_sequence(sd, f"{root}.likelihood_ups_path.{i}", h, bn_train)
+        else:
+            for j in range(2):
+                h = conv_unit(sd, f"{root}.likelihood_ups_path.{i}.convolution.{j}", h, bn_train)
         for t in range(lvl_diff):                            # increase_resolution, phiseg.py:209-221
             h = up2(h, True)
             h = conv_unit(sd, f"{root}.likelihood_post_ups_path.{i}.{2 * t + 1}.convolution.0", h, bn_train)
@@ -149,8 +204,11 @@ def _phiseg_likelihood(sd, z, image_hw, bn_train):
     post_c[L - 1] = post_z[L - 1]
     for i in reversed(range(L - 1)):                         # phiseg.py:304-317
         h = torch.cat([post_z[i], up2(post_c[i + 1], True)], dim=1)
-        for j in range(2):
-            h = conv_unit(sd, f"{root}.likelihood_post_c_path.{i}.convolution.{j}", h, bn_train)
+        if _is_rev(sd, f"{root}.likelihood_post_c_path.{i}"):                  # phiseg.py:274-275
+            h = rev_sequence(sd, f"{root}.likelihood_post_c_path.{i}", h, bn_train)
+        else:
+            for j in range(2):
+                h = conv_unit(sd, f"{root}.likelihood_post_c_path.{i}.convolution.{j}", h, bn_train)
         post_c[i] = h
     for i in range(L):                                       # phiseg.py:319-321
         s_in = conv_bare(sd, f"{root}.s_layer.{i}.convolution.0", post_c[-i - 1])
@@ -215,22 +273,30 @@ def _unet_block(sd, p, x, first_idx):
     return x
 
 
-def unet_forward(sd, x, prefix="", apply_last_layer=True):
-    """Unet.forward (unet.py:129-157)."""
+def unet_forward(sd, x, prefix="", apply_last_layer=True, bn_train=True):
+    """Unet.forward (unet.py:129-157); reversible variant: every block body is a ReversibleSequence (unet.py:32-35)."""
     n = 0
-    while f"{prefix}contracting_path.{n}.layers.{0 if n == 0 else 1}.weight" in sd:
+    rev = _is_rev(sd, f"{prefix}contracting_path.0.layers.0")
+    while (f"{prefix}contracting_path.{n}.layers.{0 if n == 0 else 1}.weight" in sd
+           or _is_rev(sd, f"{prefix}contracting_path.{n}.layers.{0 if n == 0 else 1}")):
         n += 1
     blocks = []
     for i in range(n):
         if i != 0:
             x = avgpool(x)
-        x = _unet_block(sd, f"{prefix}contracting_path.{i}.layers", x, 0 if i == 0 else 1)
+        if rev:
+            x = rev_sequence(sd, f"{prefix}contracting_path.{i}.layers.{0 if i == 0 else 1}", x, bn_train)
+        else:
+            x = _unet_block(sd, f"{prefix}contracting_path.{i}.layers", x, 0 if i == 0 else 1)
         if i != n - 1:
             blocks.append(x)
     for i in range(n - 1):                                   # UpConvBlock, unet.py:65-75
         up = up2(x, False)
         x = torch.cat([up, blocks[-i - 1]], dim=1)
-        x = _unet_block(sd, f"{prefix}upsampling_path.{i}.conv_block.layers", x, 0)
+        if rev:
+            x = rev_sequence(sd, f"{prefix}upsampling_path.{i}.conv_block.layers.0", x, bn_train)
+        else:
+            x = _unet_block(sd, f"{prefix}upsampling_path.{i}.conv_block.layers", x, 0)
     if apply_last_layer:
         x = F.conv2d(x, sd[prefix + "last_layer.weight"], sd[prefix + "last_layer.bias"])
     return x
@@ -281,7 +347,7 @@ def probunet_forward(sd, patch, segm, bn_train=True):
         out["posterior_mu"], out["posterior_sigma"] = _axis_aligned_gaussian(
             sd, "posterior", torch.cat([patch, onehot - 0.5], dim=1), bn_train)
     out["prior_mu"], out["prior_sigma"] = _axis_aligned_gaussian(sd, "prior", patch, bn_train)
-    out["unet_features"] = unet_forward(sd, patch, prefix="unet.", apply_last_layer=False)
+    out["unet_features"] = unet_forward(sd, patch, prefix="unet.", apply_last_layer=False, bn_train=bn_train)
     out["last_conv"] = conv_bare(sd, "last_conv", out["unet_features"])
     return out
 

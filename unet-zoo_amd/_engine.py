@@ -193,7 +193,8 @@ class NativeModel(nn.Module):
                 p.grad.add_(g)
 
     def _post_backward(self, plan):
-        pass
+        if plan.__dict__.get("bn_prefixes_nbt_bwd"):           # reversible blocks re-ran their BatchNorms while recomputing
+            self._bump_nbt(plan, "bn_prefixes_nbt_bwd")
 
     def zero_grad(self, set_to_none=True):
         for p in self._pmap.values():
@@ -212,9 +213,17 @@ class NativeModel(nn.Module):
             self._ptab.nbt.index_add_(0, idx, torch.ones_like(idx))
 
 
-def conv_unit(plan, x, prefix, out=None, relu=True):
-    """Reference Conv2D unit addressed by its module prefix (`<prefix>.convolution.{0,1}`)."""
-    a = plan.conv_bn_relu(x, prefix + ".convolution.0", prefix + ".convolution.1", out=out, relu=relu)
-    which = "bn_prefixes_nbt_loss" if plan.in_loss_phase() else ("bn_prefixes_nbt" if plan._record_bwd else "bn_prefixes_nbt_extra")
+def conv_unit(plan, x, prefix, out=None, relu=True, recompute=False, **kw):
+    """Reference Conv2D unit addressed by its module prefix (`<prefix>.convolution.{0,1}`).  recompute=True: the unit is
+    re-run inside the backward tape (reversible blocks) - its BatchNorm counts another tracked batch there."""
+    a = plan.conv_bn_relu(x, prefix + ".convolution.0", prefix + ".convolution.1", out=out, relu=relu, **kw)
+    if recompute:
+        which = "bn_prefixes_nbt_bwd"
+    elif plan.target is plan.fwd_ops:
+        which = "bn_prefixes_nbt"
+    elif plan.in_loss_phase():
+        which = "bn_prefixes_nbt_loss"
+    else:
+        which = "bn_prefixes_nbt_extra"
     plan.__dict__.setdefault(which, []).append(prefix + ".convolution.1.num_batches_tracked")
     return a

@@ -50,6 +50,19 @@ def conv_unit_spec(prefix, cin, cout, k=3, norm=True):
     return out
 
 
+def rev_sequence_spec(prefix, cin, cout, depth):
+    """Entries of one reference ReversibleSequence (torchlayers.py:55-82): `inital_conv` (sic) = 1x1 Conv2D unit when the
+    channel counts differ, then `depth` revtorch ReversibleBlocks whose F / G are one 3x3 Conv2D unit on half the channels.
+    Key names follow revtorch 0.2.0's module attributes (`reversible_blocks`, `f_block`, `g_block`)."""
+    out = []
+    if cin != cout:
+        out += conv_unit_spec(f"{prefix}.inital_conv", cin, cout, k=1)
+    for i in range(depth):
+        out += conv_unit_spec(f"{prefix}.sequence.reversible_blocks.{i}.f_block.0", cout // 2, cout // 2)
+        out += conv_unit_spec(f"{prefix}.sequence.reversible_blocks.{i}.g_block.0", cout // 2, cout // 2)
+    return out
+
+
 def plain_conv_spec(prefix, cin, cout, k):
     return [(f"{prefix}.weight", (cout, cin, k, k), "conv_w"), (f"{prefix}.bias", (cout,), "conv_b")]
 

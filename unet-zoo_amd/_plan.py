@@ -83,12 +83,13 @@ class ParamTable:
 
 
 class Buf:
-    __slots__ = ("name", "N", "C", "H", "W", "off", "gbuf", "requires_grad", "amax", "amax_cov")
+    __slots__ = ("name", "N", "C", "H", "W", "off", "gbuf", "requires_grad", "amax", "amax_cov", "alias")
 
     def __init__(self, name, N, C, H, W, requires_grad=True):
         self.name, self.N, self.C, self.H, self.W = name, int(N), int(C), int(H), int(W)
         self.off, self.gbuf, self.requires_grad = None, None, requires_grad
         self.amax, self.amax_cov = None, []      # magnitude-bound slot and the channel ranges whose producers maintain it
+        self.alias = None                        # pooled scratch: several differently shaped Bufs share one arena region
 
     @property
     def numel(self):
@@ -307,15 +308,17 @@ class Plan:
         self.scratch["gy"] = max(self.scratch["gy"], like.N * like.C * like.H * like.W)
         return ("gyview", like.C)
 
-    def conv_bn_relu(self, x, cprefix, bprefix, out=None, name=None, relu=True):
-        """Conv2D unit: Conv2d -> BatchNorm2d(eps=1e-3, momentum=0.01) -> ReLU (torchlayers.py:7-29)."""
+    def conv_bn_relu(self, x, cprefix, bprefix, out=None, name=None, relu=True, ybuf=None, save=None, a_grad=None):
+        """Conv2D unit: Conv2d -> BatchNorm2d(eps=1e-3, momentum=0.01) -> ReLU (torchlayers.py:7-29).
+        ybuf / save: caller-owned buffers for the pre-normalisation output and the saved statistics (reversible blocks share
+        them); a_grad: view holding the gradient w.r.t. the unit's output instead of grad(a) (no copy)."""
         wkey, bkey = cprefix + ".weight", cprefix + ".bias"
         cout, _, ks, _ = self.ptab.shape[wkey]
         name = name or cprefix
-        y = self.buf(name + ":y", cout, x.H, x.W)
+        y = ybuf if ybuf is not None else self.buf(name + ":y", cout, x.H, x.W)
         a = out if out is not None else self.buf(name + ":a", cout, x.H, x.W)
         assert a.C == cout and a.H == x.H and a.W == x.W
-        save = self.vec(name + ":bnsave", 2 * cout)
+        save = save if save is not None else self.vec(name + ":bnsave", 2 * cout)
         self._conv_fwd(x, wkey, bkey, y, ks, 0)
         bnws = self.L.uz_bn_workspace(cout, x.N, x.H, x.W)
         self.scratch["bn"] = max(self.scratch["bn"], bnws)
@@ -326,19 +329,150 @@ class Plan:
                    i=[cout, y.Ctot, a.Ctot, x.N, x.H, x.W, int(self.bn_training), int(relu)], f=[BN_EPS, BN_MOMENTUM])
 
         def bwd():
-            if not self._has_grad(a):
+            if a_grad is None and not self._has_grad(a):
                 return
             if not self.bn_training:
                 raise RuntimeError("backward through eval-mode BatchNorm is not supported")
             gy = self._gy_scratch(y)
             gyv = _ScratchView(y.N, cout, y.H, y.W, amax=self._new_amax(bwd=True))
+            ga = a_grad if a_grad is not None else self.gview(a)
             self._emit(self.bwd_ops, "UZ_OP_BN_RELU_BWD",
-                       p=[self.gview(a), y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), self.G(bkey), ("scratch", "bn"),
+                       p=[ga, y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), self.G(bkey), ("scratch", "bn"),
                           ("amax", gyv.amax)],
-                       i=[a.Ctot, cout, y.Ctot, cout, x.N, x.H, x.W, int(relu)])
+                       i=[ga.Ctot, cout, y.Ctot, cout, x.N, x.H, x.W, int(relu)])
             self._conv_bwd(x, wkey, gyv, ks)
         self._push_bwd(bwd)
         return a
+
+    # ------------------------------------------------------------------ reversible blocks
+    def _pool(self, key, C, H, W, vec=False):
+        """Scratch activations of the reversible blocks: one buffer per (branch, role, shape), re-used by every block that
+        needs that role - nothing inside a reversible sequence is kept for the backward pass, it is recomputed."""
+        pool = self.__dict__.setdefault("_rev_pool", {})
+        slots = self.__dict__.setdefault("_rev_slots", {})
+        k = (key, C, H, W)
+        if k not in pool:
+            v = self.vec("revpool:" + "/".join(map(str, k)), C) if vec else self.buf("revpool:" + "/".join(map(str, k)), C, H, W)
+            # all shapes of one (branch, role) share ONE region sized for the largest of them: a reversible sequence's scratch is
+            # dead as soon as the next sequence of the branch starts (forward) or has been back-propagated (backward)
+            slot = slots.setdefault(key[:2], {"floats": 0, "off": None})
+            slot["floats"] = max(slot["floats"], v.buf.numel)
+            v.buf.alias = slot
+            pool[k] = v
+        return pool[k]
+
+    def add_views(self, a, b, y, alpha=1.0, accumulate=0, target=None):
+        self._emit(target if target is not None else self.target, "UZ_OP_ADD_VIEWS",
+                   p=[a, b, y, self.amax_in(a), self.amax_in(b) if b is not None else None,
+                      self.amax_out(y) if (self.amax_in(a) is not None and (b is None or self.amax_in(b) is not None)) else None],
+                   i=[a.Ctot, b.Ctot if b is not None else 0, y.Ctot, y.C, y.N, y.H, y.W, accumulate], f=[alpha])
+
+    def rev_sequence(self, x, prefix, cout, depth, unit, out=None):
+        """ReversibleSequence (torchlayers.py:55-82): an optional 1x1 Conv2D unit to `cout` channels (`inital_conv`), then
+        `depth` additive-coupling blocks of revtorch (revtorch==0.2.0, requirements.txt:38, not vendored - restated from
+        its published algorithm): split the channels into halves (x1, x2);
+            y1 = x1 + F(x2),  y2 = x2 + G(y1),      F, G = Conv2D(c/2 -> c/2, 3x3) units (conv + BN + ReLU)
+        and in the backward pass recompute the inputs from the outputs instead of storing them:
+            x2 = y2 - G(y1),  x1 = y1 - F(x2),      then back-propagate through G and F on the recomputed tensors.
+        The blocks' activations live in pooled scratch buffers (forward and backward share them); only the sequence's
+        output is kept - that is the memory saving the reference advertises (README.md:4-5).  Like revtorch, the
+        recomputation re-runs F and G in training mode, so their BatchNorm running statistics receive a second momentum
+        update per step.  `unit(plan, x, prefix, **kw)` emits one Conv2D unit."""
+        branch = prefix.split(".", 1)[0]
+        N, H, W, h = x.N, x.H, x.W, cout // 2
+        assert cout % 2 == 0
+        seq_out = self.buf(prefix + ":revout", cout, H, W)
+        widened = x.C != cout
+        if widened:
+            # the 1x1 unit's output is only the first block's input: it is recomputed in backward like every other block
+            # input, so it lives in pooled scratch, and its gradient IS the dX the blocks form in the sequence's gradient buffer
+            x = unit(self, x, prefix + ".inital_conv", out=self._pool((branch, "xin"), cout, H, W), a_grad=self.gview(seq_out))
+        record = self._record_bwd
+        blocks = []
+        cur = x
+        for i in range(depth):
+            y = seq_out if i == depth - 1 else self._pool((branch, "x%d" % (i & 1)), cout, H, W)
+            bp = f"{prefix}.sequence.reversible_blocks.{i}"
+            self._rev_block(cur, y, bp, unit, h, branch, forward=True)
+            blocks.append((cur, y, bp))
+            cur = y
+        if out is not None:                                  # consumer-owned slice of a concat buffer: strided copy
+            self._newgroup()
+            self.add_views(seq_out, None, out)
+
+        def bwd():
+            gsrc = seq_out
+            if out is not None:
+                if not self._has_grad(out):
+                    return
+                acc = self._claim(seq_out)
+                self.add_views(self.gview(out), None, self.gview(seq_out), accumulate=acc, target=self.bwd_ops)
+            if not self._has_grad(seq_out):
+                return
+            ycur = seq_out
+            for i in reversed(range(depth)):
+                xin, _, bp = blocks[i]
+                xrec = self._pool((branch, "x%d" % (i & 1)), cout, H, W)       # same ping-pong pair as the forward pass
+                self._ginit.pop(xrec.buf, None)
+                xrec.buf.gbuf = self.gview(seq_out).buf           # dX is formed in place in the sequence's gradient buffer
+                self._ginit[xrec.buf] = [(0, cout)]
+                self._rev_block(xrec, ycur, bp, unit, h, branch, forward=False)
+                ycur = xrec
+            if x.buf.requires_grad and not widened:
+                acc = self._claim(x)
+                self._newgroup()
+                self.add_views(self.gview(seq_out), None, self.gview(x), accumulate=acc, target=self.bwd_ops)
+        if record:
+            self._push_bwd(bwd)
+        return out if out is not None else seq_out
+
+    def _rev_block(self, xv, yv, bp, unit, h, branch, forward):
+        """One additive-coupling block.  forward=True: y from x (forward tape).  forward=False (inside the backward tape):
+        x recomputed from y into `xv`, then the gradients of F, G and dX (in place in the shared gradient buffer)."""
+        N, H, W = xv.N, xv.H, xv.W
+        x1, x2, y1, y2 = xv.slice(0, h), xv.slice(h, h), yv.slice(0, h), yv.slice(h, h)
+        bufs = {}
+        for tag in ("F", "G"):
+            ybuf, abuf = self._pool((branch, tag + "y"), h, H, W), self._pool((branch, tag + "a"), h, H, W)
+            save = self._pool((branch, tag + "s"), 2 * h, 1, 1, vec=True)
+            for b in (ybuf, abuf):
+                self._ginit.pop(b.buf, None)
+            bufs[tag] = (ybuf, abuf, save)
+        if forward:
+            rec, self._record_bwd = self._record_bwd, False      # nothing of the block is recorded: backward recomputes it
+            tF = unit(self, x2, bp + ".f_block.0", out=bufs["F"][1], ybuf=bufs["F"][0], save=bufs["F"][2])
+            self._newgroup()
+            self.add_views(x1, tF, y1)
+            tG = unit(self, y1, bp + ".g_block.0", out=bufs["G"][1], ybuf=bufs["G"][0], save=bufs["G"][2])
+            self._newgroup()
+            self.add_views(x2, tG, y2)
+            self._record_bwd = rec
+            return
+        gy = self.gview(yv)
+        gy1, gy2 = gy.slice(0, h), gy.slice(h, h)
+        tgt, rec, saved_bwd = self.target, self._record_bwd, self._bwd
+        self.target, self._record_bwd, self._bwd = self.bwd_ops, True, []
+        try:
+            # x2 = y2 - G(y1); gradients through G: dy1 += G'(dy2) (in place in the gradient buffer)
+            self._newgroup()
+            tG = unit(self, y1, bp + ".g_block.0", out=bufs["G"][1], ybuf=bufs["G"][0], save=bufs["G"][2], a_grad=gy2, recompute=True)
+            self._newgroup()
+            self.add_views(y2, tG, x2, alpha=-1.0)
+            g_closures, self._bwd = self._bwd, []
+            # x1 = y1 - F(x2); gradients through F: dx2 = dy2 + F'(dy1_total) (in place), dx1 = dy1_total (already there)
+            self._newgroup()
+            tF = unit(self, x2, bp + ".f_block.0", out=bufs["F"][1], ybuf=bufs["F"][0], save=bufs["F"][2], a_grad=gy1, recompute=True)
+            self._newgroup()
+            self.add_views(y1, tF, x1, alpha=-1.0)
+            f_closures = self._bwd
+            for fn in reversed(g_closures):
+                self._newgroup()
+                fn()
+            for fn in reversed(f_closures):
+                self._newgroup()
+                fn()
+        finally:
+            self.target, self._record_bwd, self._bwd = tgt, rec, saved_bwd
 
     def conv_relu(self, x, prefix, out=None, name=None):
         """nn.Conv2d(3, pad 1) + nn.ReLU(inplace=True) of the vanilla U-Net blocks (unet.py:25-30)."""
@@ -563,7 +697,13 @@ class Plan:
                                      n=4 * _AMAX_FLOATS * (self.n_amax - self.n_amax_fwd), gid=head)]
         # arena layout
         off = 0
+        for slot in self.__dict__.get("_rev_slots", {}).values():
+            slot["off"] = off
+            off += -(-slot["floats"] // _ALIGN) * _ALIGN
         for b in self.bufs:
+            if b.alias is not None:
+                b.off = b.alias["off"]
+                continue
             b.off = off
             off += -(-b.numel // _ALIGN) * _ALIGN
         # scratch regions are private to a scheduling group, so every capture lane gets its own copy
@@ -646,10 +786,29 @@ class Plan:
         raise ValueError(r)
 
     def _materialize(self, ops):
+        skip = int(os.environ.get("UZ_DIAG_SKIP_SMALL", "0"))      # DIAGNOSTIC ONLY: drop ops on planes <= skip (results invalid)
+        if skip:
+            def small(o):
+                c, i = o["code"], o["i"]
+                if c.startswith("UZ_OP_CONV"):
+                    return i[5] <= skip
+                if c == "UZ_OP_BN_RELU_FWD":
+                    return i[4] <= skip
+                if c in ("UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
+                    return i[5] <= skip
+                if c.startswith("UZ_OP_AVGPOOL") or c.startswith("UZ_OP_BILINEAR"):
+                    return i[4] <= skip
+                return False
+            for o in ops:
+                if small(o):
+                    o["skip"] = True
         arr = (_ffi.uz_op * max(len(ops), 1))()
         for k, o in enumerate(ops):
             e = arr[k]
-            e.code = self.codes[o["code"]]
+            e.code = self.codes["UZ_OP_SCALE"] if o.get("skip") else self.codes[o["code"]]
+            if o.get("skip"):                              # a no-op in place of the skipped kernel keeps the tape / schedule shape
+                e.n = 0
+                continue
             assert len(o["i"]) <= 15 and len(o["f"]) <= 4 and len(o["p"]) <= 12, o["code"]
             for j, v in enumerate(o["i"]):
                 e.i[j] = v
@@ -673,6 +832,7 @@ class Plan:
         "UZ_OP_SUM_TERMS": (1,), "UZ_OP_SCALE": (0,), "UZ_OP_COPY": (0,), "UZ_OP_MEMSET": (0,),
         "UZ_OP_L2_NORMS": (2,), "UZ_OP_L2_NORMS_BWD": (4,),
         "UZ_OP_BCAST_CHANNELS": (1,), "UZ_OP_BCAST_CHANNELS_BWD": (1,), "UZ_OP_EVENT_RECORD": (0,), "UZ_OP_ABSMAX": (1,),
+        "UZ_OP_ADD_VIEWS": (2,),
     }
 
     def _resources(self, r):
@@ -680,6 +840,8 @@ class Plan:
         if r is None or isinstance(r, _ScratchView):
             return []
         if isinstance(r, View):
+            if r.buf.alias is not None:                  # pooled scratch: differently shaped Bufs overlap in memory -> whole-region hazards
+                return [(("pool", id(r.buf.alias)), 0, 1 << 30)]
             return [(("buf", id(r.buf)), r.c0, r.c0 + r.C)]
         kind = r[0]
         if kind == "pgrad":
@@ -740,6 +902,8 @@ class Plan:
         c, i = o["code"], o["i"]
         if c in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA", "UZ_OP_CONV_BWD_WEIGHT"):
             return i[4] * i[5] * i[6] >= 2048 and i[0] * i[2] >= 32 * 32      # measured: 512..8192 pixels all within 1 %
+        if os.environ.get("UZ_SCHED_STREAM_LIGHT") == "1" and not c.startswith("UZ_OP_CONV"):
+            return False                                   # experiment: streaming kernels may run beside a device-filling convolution
         if c in ("UZ_OP_BN_RELU_FWD", "UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
             C, N, H, W = (i[0], i[3], i[4], i[5]) if c == "UZ_OP_BN_RELU_FWD" else (i[1], i[4], i[5], i[6])
             return C * N * H * W >= 4.0e6

@@ -49,19 +49,23 @@ struct SP {
 };
 
 
-// 16 fp32 values (one LDS row of 16 channels), scaled -> two 32-byte fp16 rows at dst + plane * plane_stride (bytes)
-__device__ __forceinline__ void split_store16(const float (&v)[CK], float scale, char* dst, int plane_stride) {
+// LDS images are [plane][k half][row][8 k] fp16: a row's 16 k-values live in two 16-byte pieces, one per MFMA lane half
+// (lanes 0..31 hold k 0..7, lanes 32..63 k 8..15 of a 32x32x16 fragment).  Consecutive rows are then 16 bytes apart, so the
+// 64 lanes of a fragment read (one ds_read_b128) cover two contiguous 512-byte runs - conflict free; with whole 32-byte
+// rows every second 16-lane group of the read collided on its banks (2-way).
+// 16 fp32 values (one row of 16 channels), scaled -> fp16 pieces at dst + plane * plane_stride + half * half_stride (bytes)
+__device__ __forceinline__ void split_store16(const float (&v)[CK], float scale, char* dst, int plane_stride, int half_stride) {
     unsigned p1[8], p2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) split2(v[2 * i] * scale, v[2 * i + 1] * scale, p1[i], p2[i]);
-    u32x4* d1 = reinterpret_cast<u32x4*>(dst);
-    u32x4* d2 = reinterpret_cast<u32x4*>(dst + plane_stride);
-    d1[0] = u32x4{p1[0], p1[1], p1[2], p1[3]}; d1[1] = u32x4{p1[4], p1[5], p1[6], p1[7]};
-    d2[0] = u32x4{p2[0], p2[1], p2[2], p2[3]}; d2[1] = u32x4{p2[4], p2[5], p2[6], p2[7]};
+    *reinterpret_cast<u32x4*>(dst) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+    *reinterpret_cast<u32x4*>(dst + half_stride) = u32x4{p1[4], p1[5], p1[6], p1[7]};
+    *reinterpret_cast<u32x4*>(dst + plane_stride) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+    *reinterpret_cast<u32x4*>(dst + plane_stride + half_stride) = u32x4{p2[4], p2[5], p2[6], p2[7]};
 }
 
 // Weight panel of one layer and direction, split once per call into the kernel's LDS image:
-// packed[chunk][coTile][plane 2][tap 9][co COT][k 16] fp16, scaled by split_scale(*w_amax).  One thread per (chunk, coTile, tap, co) row.
+// packed[chunk][coTile][plane 2][k half 2][tap 9][co COT][8 k] fp16, scaled by split_scale(*w_amax).  One thread per (chunk, coTile, tap, co) row.
 template <bool DGRAD>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, char* __restrict__ packed, const float* __restrict__ w_amax,
                                                            int Mc, int Kc, int wCi, int nChunks, int nCoTiles, int COT) {
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
     const int tapL = DGRAD ? KK - 1 - tap : tap;
     const int wplane = KK * COT * CK * 2;
-    split_store16(v, uz::split_scale(uz::amax_read(w_amax)), packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * (CK * 2), wplane);
+    split_store16(v, uz::split_scale(uz::amax_read(w_amax)), packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * 16, wplane, wplane / 2);
 }
 
 template <int MSUB, int NTv, int TWv>
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
         const int pp = wave * (32 * NSUB) + n * 32 + l31;          // pixel index inside the tile
         const int tx = pp & (TW - 1), ty = pp / TW;
         const bool v = (y0 + ty) < p.H && (x0 + tx) < p.W;
-        poff[n] = (ty * PW + tx) * (CK * 2) + h * 16;               // byte offset of this lane's fragment for tap (0, 0)
+        poff[n] = (ty * PW + tx) * 16 + h * (PPLANE / 2);           // byte offset of this lane's fragment for tap (0, 0)
         oidx[n] = v ? (b0 * p.CoutTot * p.HW + (y0 + ty) * p.W + (x0 + tx)) : -1;
     }
 
@@ -198,14 +202,14 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
         }
     };
     auto lstore = [&]() {
-        char* dst = Pl + tid * (CK * 2);
+        char* dst = Pl + tid * 16;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            u32x4* d = reinterpret_cast<u32x4*>(dst + q * PPLANE);
-            d[0] = u32x4{pk[q][0], pk[q][1], pk[q][2], pk[q][3]};
-            d[1] = u32x4{pk[q][4], pk[q][5], pk[q][6], pk[q][7]};
+            *reinterpret_cast<u32x4*>(dst + q * PPLANE) = u32x4{pk[q][0], pk[q][1], pk[q][2], pk[q][3]};                     // k 0..7
+            *reinterpret_cast<u32x4*>(dst + q * PPLANE + PPLANE / 2) = u32x4{pk[q][4], pk[q][5], pk[q][6], pk[q][7]};       // k 8..15
         }
-        char* dst1 = Pl + prow1 * (CK * 2) + q4 * (CE * 2);
+        // shared rows: this thread holds channels [CE * q4, CE * q4 + CE) of row prow1 (CE = 4: 8 bytes, CE = 8: one 16-byte piece)
+        char* dst1 = Pl + prow1 * 16 + ((CE * q4) >> 3) * (PPLANE / 2) + ((CE * q4) & 7) * 2;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             if (CE == 4) *reinterpret_cast<uint2*>(dst1 + q * PPLANE) = make_uint2(pk1[q][0], pk1[q][1]);
@@ -224,16 +228,16 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
         lstore();
         __syncthreads();
         const bool more = c + 1 < nChunks;
-        const char* Al = Wl + l31 * (CK * 2) + h * 16;
+        const char* Al = Wl + l31 * 16 + h * (WPLANE / 2);
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
-            const int tapoff = ((tap / 3) * PW + (tap % 3)) * (CK * 2);
+            const int tapoff = ((tap / 3) * PW + (tap % 3)) * 16;
             f16x8 a[MSUB][NP], b[NSUB][NP];
 #pragma unroll
             for (int m = 0; m < MSUB; ++m)
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    a[m][q] = *reinterpret_cast<const f16x8*>(Al + q * WPLANE + (tap * COT + m * 32) * (CK * 2));
+                    a[m][q] = *reinterpret_cast<const f16x8*>(Al + q * WPLANE + (tap * COT + m * 32) * 16);
 #pragma unroll
             for (int n = 0; n < NSUB; ++n)
 #pragma unroll

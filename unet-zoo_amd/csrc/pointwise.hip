@@ -7,10 +7,39 @@
 //   torch.optim.Adam step (L2 weight decay)                 train_model.py:49,122
 //   sum of 2-norms regulariser                              utils.py:93-101
 #include "uz_common.h"
+#include "split_f16.h"
 
 namespace {
 
 constexpr int MAXL = 8;
+
+// ---------------------------------------------------------------- additive coupling of the reversible blocks
+// y = (accumulate ? y : 0) + a + alpha * b on channel-slice views (b nullable).  V = 4: float4 sweep of 16-byte aligned planes.
+template <int V>
+__global__ __launch_bounds__(256) void add_views_k(const float* __restrict__ a, int CtotA, const float* __restrict__ b, int CtotB,
+                                                    float* __restrict__ y, int CtotY, int C, int HW, float alpha, int accumulate,
+                                                    const float* a_amax, const float* b_amax, float* y_amax) {
+    if (y_amax && a_amax && (b_amax || !b) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        uz::amax_publish_one(uz::amax_read(a_amax) + (b ? fabsf(alpha) * uz::amax_read(b_amax) : 0.f), y_amax, 0u);   // |y| <= |a| + |alpha| |b|
+    const int bi = blockIdx.y;
+    const size_t per = (size_t)C * HW;
+    const float* as = a + (size_t)bi * CtotA * HW;
+    const float* bs = b ? b + (size_t)bi * CtotB * HW : nullptr;
+    float* ys = y + (size_t)bi * CtotY * HW;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; i < per; i += (size_t)gridDim.x * 256 * V) {
+        if (V == 4) {
+            float4 v = *reinterpret_cast<const float4*>(as + i);
+            if (bs) { const float4 w = *reinterpret_cast<const float4*>(bs + i); v.x = fmaf(alpha, w.x, v.x); v.y = fmaf(alpha, w.y, v.y); v.z = fmaf(alpha, w.z, v.z); v.w = fmaf(alpha, w.w, v.w); }
+            if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(ys + i); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *reinterpret_cast<float4*>(ys + i) = v;
+        } else {
+            float v = as[i];
+            if (bs) v = fmaf(alpha, bs[i], v);
+            if (accumulate) v += ys[i];
+            ys[i] = v;
+        }
+    }
+}
 
 // ---------------------------------------------------------------- posterior input
 __global__ __launch_bounds__(256) void posterior_input_k(const float* __restrict__ patch, int in_ch, const float* __restrict__ mask,
@@ -349,6 +378,20 @@ extern "C" int uz_adam_step(float* params, const float* grads, float* exp_avg, f
     hipLaunchKernelGGL(adam_k, dim3(vgrid(n)), dim3(256), 0, uz::S(stream), params, grads, exp_avg, exp_avg_sq, n,
                        (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale);
     return uz::check_launch("adam_k");
+}
+extern "C" int uz_add_views(const float* a, int CtotA, const float* b, int CtotB, float* y, int CtotY, int C, int N, int H, int W,
+                            float alpha, int accumulate, const float* a_amax, const float* b_amax, float* y_amax, void* stream) {
+    UZ_REQUIRE(a && y && C > 0 && N > 0 && H > 0 && W > 0, "add_views: bad arguments");
+    UZ_REQUIRE(N <= 65535, "add_views: N exceeds grid limits");
+    const int HW = H * W;
+    const size_t per = (size_t)C * HW;
+    auto al = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool v4 = HW % 4 == 0 && al(a) && al(b) && al(y);
+    int gx = (int)((per / (v4 ? 4 : 1) + 255) / 256);
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    if (v4) hipLaunchKernelGGL(add_views_k<4>, dim3(gx, N), dim3(256), 0, uz::S(stream), a, CtotA, b, CtotB, y, CtotY, C, HW, alpha, accumulate, a_amax, b_amax, y_amax);
+    else hipLaunchKernelGGL(add_views_k<1>, dim3(gx, N), dim3(256), 0, uz::S(stream), a, CtotA, b, CtotB, y, CtotY, C, HW, alpha, accumulate, a_amax, b_amax, y_amax);
+    return uz::check_launch("add_views_k");
 }
 extern "C" int uz_axpy(float* y, const float* x, float alpha, size_t n, void* stream) {
     if (n == 0) return 0;

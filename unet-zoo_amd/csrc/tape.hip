@@ -135,6 +135,8 @@ static int run_one(const uz_op& o, void* st) {
             return uz_bcast_channels_fwd(CFP(0), i[0], FP(1), i[1], i[2], i[3], i[4], st);
         case UZ_OP_BCAST_CHANNELS_BWD:
             return uz_bcast_channels_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], st);
+        case UZ_OP_ADD_VIEWS:
+            return uz_add_views(CFP(0), i[0], CFP(1), i[1], FP(2), i[2], i[3], i[4], i[5], i[6], f[0], i[7], CFP(3), CFP(4), FP(5), st);
         case UZ_OP_ABSMAX:
             return uz_absmax(CFP(0), (size_t)o.n, FP(1), st);
         case UZ_OP_EVENT_RECORD:

@@ -18,7 +18,7 @@ import torch
 
 from .. import _ffi
 from .._engine import NativeModel, conv_unit
-from .._modtree import conv_unit_spec, plain_conv_spec, init_default
+from .._modtree import conv_unit_spec, plain_conv_spec, rev_sequence_spec, init_default
 from .._plan import View
 
 RES_LEVELS = 7
@@ -26,32 +26,45 @@ LAT_LEVELS = 5
 LVL_DIFF = RES_LEVELS - LAT_LEVELS
 
 
-def _encoder_spec(root, in_ch, nf):
-    """Posterior / prior parameter entries in the reference's registration order (phiseg.py:144-173)."""
+def _encoder_spec(root, in_ch, nf, reversible=False):
+    """Posterior / prior parameter entries in the reference's registration order (phiseg.py:144-173); with
+    reversible=True every Conv2D stack is a ReversibleSequence (phiseg.py:25-26,53-54,87-88)."""
     out = []
     for i in range(RES_LEVELS):
         cin = in_ch if i == 0 else nf[i - 1]
         base = 0 if i == 0 else 1          # layers.0 is the AvgPool2d when pooling
+        if reversible:
+            out += rev_sequence_spec(f"{root}.contracting_path.{i}.layers.{base}", cin, nf[i], 3)
+            continue
         for j in range(3):
             out += conv_unit_spec(f"{root}.contracting_path.{i}.layers.{base + j}", cin if j == 0 else nf[i], nf[i])
     for k in range(LAT_LEVELS):
+        if reversible:
+            out += rev_sequence_spec(f"{root}.upsampling_path.{k}.upconv_layer", 2, 2 * nf[0], 2)
+            continue
         out += conv_unit_spec(f"{root}.upsampling_path.{k}.upconv_layer.0", 2, 2 * nf[0])
         out += conv_unit_spec(f"{root}.upsampling_path.{k}.upconv_layer.1", 2 * nf[0], 2 * nf[0])
     for k in range(LAT_LEVELS):
         i = LAT_LEVELS - 1 - k
         cin = nf[i + LVL_DIFF] if k == 0 else 2 * nf[0] + nf[i + LVL_DIFF]
         p = f"{root}.sample_z_path.{k}"
-        out += conv_unit_spec(p + ".conv.0", cin, cin) + conv_unit_spec(p + ".conv.1", cin, cin)
+        if reversible:
+            out += rev_sequence_spec(p + ".conv.0", cin, cin, 3)
+        else:
+            out += conv_unit_spec(p + ".conv.0", cin, cin) + conv_unit_spec(p + ".conv.1", cin, cin)
         out += plain_conv_spec(p + ".mu_conv.0", cin, 2, 1) + plain_conv_spec(p + ".sigma_conv.0", cin, 2, 1)
     return out
 
 
-def _likelihood_spec(nf, num_classes):
+def _likelihood_spec(nf, num_classes, reversible=False):
     """Likelihood entries (phiseg.py:252-284): both ModuleLists of the first loop are registered
     before the loop, so all ups_path entries precede all post_ups_path entries."""
     root, out = "likelihood", []
     for k in range(LAT_LEVELS):
         c = nf[LAT_LEVELS - 1 - k]
+        if reversible:
+            out += rev_sequence_spec(f"{root}.likelihood_ups_path.{k}", 2, c, 2)
+            continue
         out += conv_unit_spec(f"{root}.likelihood_ups_path.{k}.convolution.0", 2, c)
         out += conv_unit_spec(f"{root}.likelihood_ups_path.{k}.convolution.1", c, c)
     for k in range(LAT_LEVELS):
@@ -60,6 +73,9 @@ def _likelihood_spec(nf, num_classes):
             out += conv_unit_spec(f"{root}.likelihood_post_ups_path.{k}.{2 * t + 1}.convolution.0", c, c)
     for i in range(LAT_LEVELS - 1):
         cin, cout = nf[i] + nf[i + 1 + LVL_DIFF], nf[i + LVL_DIFF]
+        if reversible:
+            out += rev_sequence_spec(f"{root}.likelihood_post_c_path.{i}", cin, cout, 2)
+            continue
         out += conv_unit_spec(f"{root}.likelihood_post_c_path.{i}.convolution.0", cin, cout)
         out += conv_unit_spec(f"{root}.likelihood_post_c_path.{i}.convolution.1", cout, cout)
     for k in range(LAT_LEVELS):
@@ -68,10 +84,10 @@ def _likelihood_spec(nf, num_classes):
     return out
 
 
-def phiseg_spec(input_channels, num_classes, num_filters):
+def phiseg_spec(input_channels, num_classes, num_filters, reversible=False):
     nf = list(num_filters)
-    return (_encoder_spec("posterior", input_channels + 2, nf) + _likelihood_spec(nf, num_classes)
-            + _encoder_spec("prior", input_channels, nf))
+    return (_encoder_spec("posterior", input_channels + 2, nf, reversible) + _likelihood_spec(nf, num_classes, reversible)
+            + _encoder_spec("prior", input_channels, nf, reversible))
 
 
 class PHISeg(NativeModel):
@@ -79,8 +95,7 @@ class PHISeg(NativeModel):
                  no_convs_fcomb=4, beta=10.0, image_size=(128, 128, 1), reversible=False, apply_last_layer=True,
                  exponential_weighting=True, padding=True, device=None):
         super().__init__()
-        if reversible:
-            raise NotImplementedError("reversible blocks (revtorch) are outside the native hot path")
+        self.reversible = bool(reversible)
         if len(num_filters) < RES_LEVELS or num_filters[4] != num_filters[6]:
             raise ValueError("PHISeg needs >= 7 filters with num_filters[4] == num_filters[6] (phiseg.py:131-132,258-270)")
         self.input_channels, self.num_classes, self.num_filters = input_channels, num_classes, list(num_filters)
@@ -92,7 +107,7 @@ class PHISeg(NativeModel):
         self.residual_multinoulli_loss_weight = 1.0
         self.kl_divergence_loss = self.reconstruction_loss = 0
         self.s_out_list = [None] * latent_levels
-        self._init_storage(phiseg_spec(input_channels, num_classes, num_filters), device)
+        self._init_storage(phiseg_spec(input_channels, num_classes, num_filters, self.reversible), device)
         init_default(self._ptab)
 
     # ------------------------------------------------------------------ plan construction
@@ -109,6 +124,9 @@ class PHISeg(NativeModel):
                 cat = plan.buf(f"{root}.cat{i}", 2 * nf[0] + nf[i], x.H, x.W)
                 out = cat.slice(2 * nf[0], nf[i])
                 skips[i] = cat
+            if self.reversible:
+                x = plan.rev_sequence(x, f"{root}.contracting_path.{i}.layers.{base}", nf[i], 3, conv_unit, out=out)
+                continue
             for j in range(3):
                 x = conv_unit(plan, x, f"{root}.contracting_path.{i}.layers.{base + j}", out=out if j == 2 else None)
         lats, zs = [], []
@@ -117,12 +135,18 @@ class PHISeg(NativeModel):
             if k != 0:
                 cat = skips[RES_LEVELS - 1 - k]
                 u = plan.bilinear(zs[k - 1], True, name=f"{root}.up{k}.bil")
-                u = conv_unit(plan, u, f"{root}.upsampling_path.{k - 1}.upconv_layer.0")
-                conv_unit(plan, u, f"{root}.upsampling_path.{k - 1}.upconv_layer.1", out=cat.slice(0, 2 * nf[0]))
+                if self.reversible:
+                    plan.rev_sequence(u, f"{root}.upsampling_path.{k - 1}.upconv_layer", 2 * nf[0], 2, conv_unit, out=cat.slice(0, 2 * nf[0]))
+                else:
+                    u = conv_unit(plan, u, f"{root}.upsampling_path.{k - 1}.upconv_layer.0")
+                    conv_unit(plan, u, f"{root}.upsampling_path.{k - 1}.upconv_layer.1", out=cat.slice(0, 2 * nf[0]))
                 pre = cat
             p = f"{root}.sample_z_path.{k}"
-            h = conv_unit(plan, pre, p + ".conv.0")
-            h = conv_unit(plan, h, p + ".conv.1")
+            if self.reversible:
+                h = plan.rev_sequence(pre, p + ".conv.0", pre.C, 3, conv_unit)
+            else:
+                h = conv_unit(plan, pre, p + ".conv.0")
+                h = conv_unit(plan, h, p + ".conv.1")
             mu = plan.conv_bare(h, p + ".mu_conv.0")
             ps = plan.conv_bare(h, p + ".sigma_conv.0")
             lat = plan.latent(mu, ps, eps[k], f"{root}.lat{k}", want_z=want_z, act=0)
@@ -138,8 +162,11 @@ class PHISeg(NativeModel):
         post_c = [None] * L
         for k in range(L):
             lvl = L - 1 - k
-            h = conv_unit(plan, zs[k], f"{root}.likelihood_ups_path.{k}.convolution.0")
-            h = conv_unit(plan, h, f"{root}.likelihood_ups_path.{k}.convolution.1")
+            if self.reversible:
+                h = plan.rev_sequence(zs[k], f"{root}.likelihood_ups_path.{k}", nf[lvl], 2, conv_unit)
+            else:
+                h = conv_unit(plan, zs[k], f"{root}.likelihood_ups_path.{k}.convolution.0")
+                h = conv_unit(plan, h, f"{root}.likelihood_ups_path.{k}.convolution.1")
             for t in range(LVL_DIFF):
                 h = plan.bilinear(h, True, name=f"{root}.ups{k}.bil{t}")
                 out = None
@@ -152,8 +179,11 @@ class PHISeg(NativeModel):
         for lvl in reversed(range(L - 1)):
             cat = cats[lvl]
             plan.bilinear(post_c[lvl + 1], True, out=cat.slice(nf[lvl], nf[lvl + 1 + LVL_DIFF]))
-            h = conv_unit(plan, cat, f"{root}.likelihood_post_c_path.{lvl}.convolution.0")
-            post_c[lvl] = conv_unit(plan, h, f"{root}.likelihood_post_c_path.{lvl}.convolution.1")
+            if self.reversible:
+                post_c[lvl] = plan.rev_sequence(cat, f"{root}.likelihood_post_c_path.{lvl}", nf[lvl + LVL_DIFF], 2, conv_unit)
+            else:
+                h = conv_unit(plan, cat, f"{root}.likelihood_post_c_path.{lvl}.convolution.0")
+                post_c[lvl] = conv_unit(plan, h, f"{root}.likelihood_post_c_path.{lvl}.convolution.1")
         s = [None] * L
         for k in range(L):
             lvl = L - 1 - k

@@ -36,9 +36,11 @@ def _gaussian_spec(root, in_ch, nf, latent_dim):
     return out
 
 
-def probunet_spec(input_channels, num_classes, num_filters, latent_dim, no_convs_fcomb):
+def probunet_spec(input_channels, num_classes, num_filters, latent_dim, no_convs_fcomb, reversible=False):
+    """reversible=True reaches only the U-Net backbone: the reference builds prior / posterior / fcomb without it
+    (probabilistic_unet.py:232-243)."""
     nf = list(num_filters)
-    out = unet_spec(input_channels, num_classes, nf, apply_last_layer=False, prefix="unet.")
+    out = unet_spec(input_channels, num_classes, nf, apply_last_layer=False, prefix="unet.", reversible=reversible)
     out += _gaussian_spec("prior", input_channels, nf, latent_dim)
     out += _gaussian_spec("posterior", input_channels + 2, nf, latent_dim)      # Encoder default num_classes=2 (:31,:44)
     out += conv_unit_spec("fcomb.layers.0", nf[0] + latent_dim, nf[0], k=1)
@@ -53,15 +55,14 @@ class ProbabilisticUnet(NativeModel):
     def __init__(self, input_channels=1, num_classes=1, num_filters=None, latent_levels=1, latent_dim=2, initializers=None,
                  no_convs_fcomb=4, image_size=(1, 128, 128), beta=10.0, reversible=False, device=None):
         super().__init__()
-        if reversible:
-            raise NotImplementedError("reversible blocks (revtorch) are outside the native hot path")
+        self.reversible = bool(reversible)
         self.input_channels, self.num_classes, self.num_filters = input_channels, num_classes, list(num_filters)
         self.latent_dim, self.no_convs_per_block, self.no_convs_fcomb = latent_dim, 3, no_convs_fcomb
         self.initializers = {"w": "he_normal", "b": "normal"}
         self.z_prior_sample = 0
         if self.num_filters[0] != 32:
             raise ValueError("ProbabilisticUnet.last_conv is hard-wired to 32 input channels (probabilistic_unet.py:244)")
-        self._init_storage(probunet_spec(input_channels, num_classes, self.num_filters, latent_dim, no_convs_fcomb), device)
+        self._init_storage(probunet_spec(input_channels, num_classes, self.num_filters, latent_dim, no_convs_fcomb, self.reversible), device)
         self._init_weights()
 
     def _init_weights(self):
@@ -127,7 +128,8 @@ class ProbabilisticUnet(NativeModel):
         io["p"] = plan.latent(io["p_mu"], io["p_ls"], io["p_eps0"], "prior.lat", want_z=False, act=1)
         fcat = plan.buf("fcomb.in", nf0 + L, H, W)
         io["fcat"] = fcat
-        io["features"] = build_unet_graph(plan, "unet.", io["patch"], self.num_filters, False, final_out=fcat.slice(0, nf0))
+        io["features"] = build_unet_graph(plan, "unet.", io["patch"], self.num_filters, False, final_out=fcat.slice(0, nf0),
+                                          reversible=self.reversible)
         io["last_conv"] = plan.conv_bare(io["features"], "last_conv.convolution.0", name="last_conv")
         plan.total = plan.vec("total", 1)
         if with_posterior:

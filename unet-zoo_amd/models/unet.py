@@ -10,22 +10,29 @@ import math
 import torch
 import torch.nn as nn
 
-from .._engine import NativeModel
-from .._modtree import plain_conv_spec
+from .._engine import NativeModel, conv_unit
+from .._modtree import plain_conv_spec, rev_sequence_spec
 
 
-def unet_spec(input_channels, num_classes, num_filters, apply_last_layer=True, prefix=""):
+def unet_spec(input_channels, num_classes, num_filters, apply_last_layer=True, prefix="", reversible=False):
+    """reversible=True: every DownConvBlock body is ReversibleSequence(in, out, reversible_depth=3) (unet.py:32-35)."""
     nf, out = list(num_filters), []
     for i in range(len(nf)):
         cin = input_channels if i == 0 else nf[i - 1]
         base = 0 if i == 0 else 1
+        if reversible:
+            out += rev_sequence_spec(f"{prefix}contracting_path.{i}.layers.{base}", cin, nf[i], 3)
+            continue
         for j in range(3):
             out += plain_conv_spec(f"{prefix}contracting_path.{i}.layers.{base + 2 * j}", cin if j == 0 else nf[i], nf[i], 3)
     prev = nf[-1]
     for k, i in enumerate(range(len(nf) - 2, -1, -1)):
         cin = prev + nf[i]
-        for j in range(3):
-            out += plain_conv_spec(f"{prefix}upsampling_path.{k}.conv_block.layers.{2 * j}", cin if j == 0 else nf[i], nf[i], 3)
+        if reversible:
+            out += rev_sequence_spec(f"{prefix}upsampling_path.{k}.conv_block.layers.0", cin, nf[i], 3)
+        else:
+            for j in range(3):
+                out += plain_conv_spec(f"{prefix}upsampling_path.{k}.conv_block.layers.{2 * j}", cin if j == 0 else nf[i], nf[i], 3)
         prev = nf[i]
     if apply_last_layer:
         out += plain_conv_spec(f"{prefix}last_layer", prev, num_classes, 1)
@@ -50,9 +57,13 @@ def init_unet_weights(ptab, prefix="", skip=("last_layer",)):
             nn.init.kaiming_normal_(ptab.pview(key), mode="fan_in", nonlinearity="relu")
         elif kind == "conv_b":
             nn.init.trunc_normal_(ptab.pview(key), mean=0.0, std=1e-3, a=-2e-3, b=2e-3)
+        elif kind == "bn_w":                       # BatchNorm2d of the reversible variant's Conv2D units: torch defaults
+            ptab.pview(key).fill_(1.0)
+        elif kind == "bn_rv":
+            ptab.bview(key).fill_(1.0)
 
 
-def build_unet_graph(plan, prefix, x, num_filters, apply_last_layer, final_out=None):
+def build_unet_graph(plan, prefix, x, num_filters, apply_last_layer, final_out=None, reversible=False):
     """Emit the U-Net forward (unet.py:129-157) into `plan`; returns the output View
     (logits, or the last block's features when apply_last_layer is False)."""
     nf = list(num_filters)
@@ -66,6 +77,9 @@ def build_unet_graph(plan, prefix, x, num_filters, apply_last_layer, final_out=N
             cats[i] = plan.buf(f"{prefix}cat{i}", nf[i + 1] + nf[i], x.H, x.W)
             out = cats[i].slice(nf[i + 1], nf[i])
         base = 0 if i == 0 else 1
+        if reversible:
+            x = plan.rev_sequence(x, f"{prefix}contracting_path.{i}.layers.{base}", nf[i], 3, conv_unit, out=out)
+            continue
         for j in range(3):
             x = plan.conv_relu(x, f"{prefix}contracting_path.{i}.layers.{base + 2 * j}", out=out if j == 2 else None)
     for k, i in enumerate(range(n - 2, -1, -1)):
@@ -73,6 +87,10 @@ def build_unet_graph(plan, prefix, x, num_filters, apply_last_layer, final_out=N
         plan.bilinear(x, False, out=cat.slice(0, nf[i + 1]))
         x = cat
         last_block = (i == 0)
+        if reversible:
+            o = final_out if (last_block and not apply_last_layer) else None
+            x = plan.rev_sequence(x, f"{prefix}upsampling_path.{k}.conv_block.layers.0", nf[i], 3, conv_unit, out=o)
+            continue
         for j in range(3):
             o = final_out if (last_block and j == 2 and not apply_last_layer) else None
             x = plan.conv_relu(x, f"{prefix}upsampling_path.{k}.conv_block.layers.{2 * j}", out=o)
@@ -85,34 +103,35 @@ class Unet(NativeModel):
     def __init__(self, input_channels, num_classes, num_filters, initializers=None, apply_last_layer=True, padding=True,
                  reversible=False, training=False, latent_dim=3, no_convs_fcomb=4, beta=1.0, device=None):
         super().__init__()
-        if reversible:
-            raise NotImplementedError("reversible blocks (revtorch) are outside the native hot path")
+        self.reversible = bool(reversible)
         self.input_channels, self.num_classes, self.num_filters = input_channels, num_classes, list(num_filters)
         self.padding, self.activation_maps, self.apply_last_layer = padding, [], apply_last_layer
         self.prediction = None
-        self._init_storage(unet_spec(input_channels, num_classes, num_filters, apply_last_layer), device)
+        self._init_storage(unet_spec(input_channels, num_classes, num_filters, apply_last_layer, reversible=self.reversible), device)
         init_unet_weights(self._ptab)
 
     def _build(self, N, H, W):
-        plan = self._new_plan(N, False)
+        plan = self._new_plan(N, bool(self.training) if self.reversible else False)      # only the reversible variant has BatchNorms
         plan.bn_prefixes_nbt = []
         io = {"x": plan.buf("x", self.input_channels, H, W, requires_grad=False)}
-        io["pred"] = build_unet_graph(plan, "", io["x"], self.num_filters, self.apply_last_layer)
+        io["pred"] = build_unet_graph(plan, "", io["x"], self.num_filters, self.apply_last_layer, reversible=self.reversible)
         plan.loss_phase()
         plan.total = plan.vec("total", 1)
         io["mask"] = plan.buf("loss_mask", 1, H, W, requires_grad=False)
         if self.apply_last_layer:
             plan.residual_ce([io["pred"]], io["mask"], plan.total, post_scale=1.0 / (H * W))
-        plan.finalize(want_backward=self.apply_last_layer)
+        plan.finalize(want_backward=self.apply_last_layer and (plan.bn_training or not self.reversible))
         plan.io = io
         return plan
 
     def forward(self, x, mask=None, training=True, val=False):
         self._require_gpu()
         N, _, H, W = x.shape
-        plan = self._plan((N, H, W), lambda: self._build(N, H, W))
+        plan = self._plan((N, H, W, bool(self.training) and self.reversible), lambda: self._build(N, H, W))
         plan.tensor(plan.io["x"]).copy_(x)
         self._run(plan, "fwd")
+        if self.training and self.reversible:
+            self._bump_nbt(plan)
         self._cur = plan
         out = plan.tensor(plan.io["pred"])
         if val:

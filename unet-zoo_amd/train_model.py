@@ -81,10 +81,12 @@ def load_experiment(path):
     alias = {"models": native_models, "models.phiseg": native_models.phiseg, "models.unet": native_models.unet,
              "models.probabilistic_unet": native_models.probabilistic_unet}
     data_pkg, lidc_mod, utils_mod = types.ModuleType("data"), types.ModuleType("data.lidc_data"), types.ModuleType("utils")
+    uzh_mod = types.ModuleType("data.uzh_prostate_data")            # private UZH prostate set: same loader surface, stand-in content
     lidc_mod.lidc_data = lidc_data
-    data_pkg.lidc_data = lidc_mod
+    uzh_mod.uzh_prostate_data = lidc_data
+    data_pkg.lidc_data, data_pkg.uzh_prostate_data = lidc_mod, uzh_mod
     utils_mod.normalise_image = normalise_image
-    alias.update({"data": data_pkg, "data.lidc_data": lidc_mod, "utils": utils_mod})
+    alias.update({"data": data_pkg, "data.lidc_data": lidc_mod, "data.uzh_prostate_data": uzh_mod, "utils": utils_mod})
     saved = {k: sys.modules.get(k) for k in alias}
     sys.modules.update(alias)
     try:
