@@ -291,6 +291,14 @@ int  uz_event_record(void* event, void* stream);
 int  uz_stream_wait_event(void* stream, void* event);
 int  uz_event_elapsed_ms(void* start, void* stop, float* ms_out);
 
+/* ---------------------------------------------------------------- input pipeline (data/batch_provider.py:43-67,140-271)
+ * One training batch from a dataset resident in HBM: row gather (idx), random annotator (ann), rotation, random crop + resize
+ * and flips per sample, images bilinear, labels as one-hot maps with an argmax after each resampling stage (OpenCV rules
+ * restated, utils.py:16-36).  X (M,H,W) f32, Y (M,H,W,A) u8; params (B,8) f32 = {do_rot, cos, sin, do_scale, p_x, p_y, r, flips}
+ * drawn by the host in the reference's order; outputs x (B,1,H,W) f32 and s (B,H,W) f32.                                    */
+int uz_augment_batch(const float* X, const uint8_t* Y, int H, int W, int A, const int* idx, const int* ann,
+                     const float* params, int B, int nlabels, float* x_out, float* s_out, void* stream);
+
 /* Fcomb input (probabilistic_unet.py:172-197) */
 /* z (N,L) tiled over HxW into channels of a (N,Ctot,H,W) buffer, and its backward (sum over pixels) */
 int uz_bcast_channels_fwd(const float* z, int L, float* y, int CtotY, int N, int H, int W, void* stream);

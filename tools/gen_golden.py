@@ -454,6 +454,27 @@ def phiseg_f64_case(name, filters, hw, batch, seed, n_samp=256):
     save(name, arrays, meta)
 
 
+def batch_provider_stream():
+    """Index / annotator stream of the REAL reference BatchProvider.next_batch (data/batch_provider.py:43-67,131-137) under a
+    fixed numpy seed: pins the native provider's sampling logic and its order of RNG draws.  (The augmentation draws cannot be
+    generated: the reference's _augmentation_function returns False without cv2, which this image lacks.)"""
+    from data.batch_provider import BatchProvider
+    N, A = 23, 4
+    X = np.arange(N, dtype=np.float32)[:, None, None] * np.ones((1, 4, 4), np.float32)
+    y = np.zeros((N, 4, 4, A), np.uint8)
+    for a in range(A):
+        y[..., a] = a
+    np.random.seed(1234)
+    bp = BatchProvider(X, y, np.arange(N), add_dummy_dimension=True, num_labels_per_subject=A, annotator_range=range(A))
+    rec = []
+    for _ in range(9):
+        xb, yb = bp.next_batch(5)
+        rec.append(dict(idx=[int(v) for v in xb[:, 0, 0, 0]], ann=[int(v) for v in yb[:, 0, 0]]))
+    with open(os.path.join(OUT, "batch_provider_stream.json"), "w") as f:
+        json.dump(dict(N=N, A=A, seed=1234, batch=5, batches=rec), f)
+    print("wrote batch_provider_stream")
+
+
 def op_cases():
     """G1: reference-authored arithmetic that is not a stock torch op."""
     rs = np.random.Generator(np.random.PCG64(99))
@@ -527,6 +548,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "b32":
         # BASELINE config 4 exactly (batch 32): digests only, inputs are regenerated from the seed
         phiseg_case("phiseg_full_b32_digest", [32, 64, 128, 192, 192, 192, 192], 128, 32, 1, False, 1238, store_inputs=False)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "batches":
+        batch_provider_stream()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "f64":
         b = int(sys.argv[2]) if len(sys.argv) > 2 else 32

@@ -74,7 +74,7 @@ def prototypes():
             if "*" in t:
                 return C.c_char_p if t.replace(" ", "") == "constchar*" else C.c_void_p
             base = t.replace("const", "").split()[0] if t.split() else "void"
-            return {"int": C.c_int, "size_t": C.c_size_t, "int64_t": C.c_int64, "float": C.c_float, "void": None}[base]
+            return {"int": C.c_int, "size_t": C.c_size_t, "int64_t": C.c_int64, "float": C.c_float, "void": None, "uint8_t": C.c_uint8}[base]
 
         argtypes = []
         if args and args != "void":

@@ -54,6 +54,16 @@ class SyntheticData:
         h, w = size[1], size[2]
         x, m, _ = synthetic_batch(n_train + n_val, h, w, seed=7)
         self.train = _Split(x[:n_train], m[:n_train, 0])
+        if torch.cuda.is_available():
+            # the native input pipeline (HBM-resident split, batch assembly + augmentation in one HIP kernel) also serves the
+            # synthetic stand-in, so the training loop exercises it without the LIDC files
+            from .data.batch_provider import BatchProvider
+            n_ann_t = getattr(exp_config, "num_labels_per_subject", 4)
+            lab = np.stack([np.roll(m[:n_train, 0], shift=(a, -a), axis=(1, 2)) for a in range(n_ann_t)], axis=-1).astype(np.uint8)
+            self.train = BatchProvider(x[:n_train, 0], lab, np.arange(n_train), add_dummy_dimension=True, do_augmentations=True,
+                                       augmentation_options=getattr(exp_config, "augmentation_options", None) or
+                                       dict(do_rotations=True, do_scaleaug=True, nlabels=getattr(exp_config, "n_classes", 2)),
+                                       num_labels_per_subject=n_ann_t, annotator_range=range(n_ann_t))
         # validation labels carry several annotators per image, (n, H, W, A), like the LIDC HDF5 (lidc_data_loader.py:92-110)
         n_ann = getattr(exp_config, "num_labels_per_subject", 4)
         ann = [m[n_train:, 0]]
@@ -66,6 +76,12 @@ class SyntheticData:
 
 
 def lidc_data(sys_config=None, exp_config=None):
+    """The reference's `data.lidc_data.lidc_data`: the real LIDC loader when `sys_config.data_root` points at the pickle, the
+    synthetic stand-in otherwise (no dataset ships with this repository)."""
+    root = getattr(sys_config, "data_root", None)
+    if root and os.path.exists(root):
+        from .data.lidc_data import lidc_data as real
+        return real(sys_config, exp_config)
     return SyntheticData(sys_config, exp_config)
 
 
@@ -137,7 +153,7 @@ class UNetModel:
         self.iteration = 0
 
     def train_step(self, x_b, s_b):
-        patch = torch.as_tensor(x_b, dtype=torch.float32).to(self.device)
+        patch = torch.as_tensor(x_b, dtype=torch.float32).to(self.device)          # no-ops for the device tensors of the native provider
         mask = torch.unsqueeze(torch.as_tensor(s_b, dtype=torch.float32).to(self.device), 1)
         self.mask, self.patch = mask, patch
         self.net.forward(patch, mask, training=True)
