@@ -374,24 +374,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_groups(float* __restrict__ s
         slab[(size_t)lo * n + i] = s;
     }
 }
-// stage 2: dW[co][ci][tap] = sum_g slab[g*RG][tap][co][ci]  (fixed order).  One thread per (co, ci): KK coalesced
-// read streams (lane = consecutive ci) and KK consecutive output floats per thread.
+// stage 2: dW[co][ci][tap] = sum_g slab[g*RG][tap][co][ci]  (fixed order).  One thread per (co, ci) and tap (blockIdx.y):
+// the slab reads of a wave are coalesced (lane = consecutive ci), a thread's S loads are independent of each other (issued
+// eight at a time, added in slab order), and 9x the workgroups of a per-(co, ci) sweep fill the chip - this kernel runs once
+// per layer and step, 106 times for PHiSeg.
 template <int KK>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                             int S, int RG, int Cout, int Cin) {
     const int m = Cout * Cin, n = KK * m;
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
     if (j >= m) return;
-    float s[KK];
+    const float* src = slab + (size_t)t * m + j;
+    const size_t step = (size_t)RG * n;
+    const int cnt = (S + RG - 1) / RG;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= cnt; k += 8) {
+        float v[8];
 #pragma unroll
-    for (int t = 0; t < KK; ++t) s[t] = 0.f;
-    for (int k = 0; k < S; k += RG) {
-        const float* src = slab + (size_t)k * n + j;
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * step];
 #pragma unroll
-        for (int t = 0; t < KK; ++t) s[t] += src[(size_t)t * m];
+        for (int u = 0; u < 8; ++u) s += v[u];
     }
-#pragma unroll
-    for (int t = 0; t < KK; ++t) dw[(size_t)j * KK + t] = s[t];
+    for (; k < cnt; ++k) s += src[(size_t)k * step];
+    dw[(size_t)j * KK + t] = s;
 }
 
 // db[c] = sum_{b,y,x} dy[b,c,y,x]: CSB blocks per channel write fp64 partials, then one wave per
@@ -596,8 +602,8 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         if (int rc = uz::check_launch("wgrad_reduce_groups")) return rc;
     }
     const int fgrid = uz::ceil_div(Cout * Cin, 256);
-    if (ks == 3) hipLaunchKernelGGL(wgrad_reduce_kernel<9>, dim3(fgrid), dim3(256), 0, st, p.slab, dw, Stot, RG, Cout, Cin);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(fgrid), dim3(256), 0, st, p.slab, dw, Stot, RG, Cout, Cin);
+    if (ks == 3) hipLaunchKernelGGL(wgrad_reduce_kernel<9>, dim3(fgrid, 9), dim3(256), 0, st, p.slab, dw, Stot, RG, Cout, Cin);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(fgrid, 1), dim3(256), 0, st, p.slab, dw, Stot, RG, Cout, Cin);
     if (int rc = uz::check_launch("wgrad_reduce_kernel")) return rc;
     if (db) {
         // the slab workspace is free again after the reduction above; it holds the fp64 partials

@@ -170,8 +170,10 @@ class UNetModel:
         self.net.train()
         n_it = iterations if iterations is not None else self.exp_config.iterations
         log_every = getattr(self.exp_config, "logging_frequency", 1000)
-        if self.world > 1 and hasattr(data.train, "reseed"):
-            data.train.reseed(1000003 * self.rank + 17)          # every rank draws its own shard of each global batch
+        if self.world > 1:                                       # every rank draws its own shard of each global batch
+            if hasattr(data.train, "reseed"):
+                data.train.reseed(1000003 * self.rank + 17)
+            np.random.seed(1000003 * self.rank + 17)             # the native BatchProvider samples from numpy's global RNG, like the reference
         for self.iteration in range(1, n_it):
             x_b, s_b = data.train.next_batch(self.batch_size)
             loss = self.train_step(x_b, s_b)
