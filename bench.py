@@ -34,6 +34,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")      # see unet-zoo_amd/__init__.py: must be in place before HIP initialises
 
 FILTERS7 = [32, 64, 128, 192, 192, 192, 192]
 FILTERS4 = [32, 64, 128, 192]

@@ -55,6 +55,8 @@ def run(dp, overlap=True, steps=8, timed=0):
 
 
 print("rccl version code", _ffi.lib().uz_comm_version())
+if os.environ.get("UZ_WARM_NODP"):
+    run(False, timed=3)
 if os.environ.get("UZ_DP_DIAG") or os.environ.get("UZ_DP_ONLY"):
     if os.environ.get("UZ_SIDE_STREAM"):
         side = torch.cuda.Stream()

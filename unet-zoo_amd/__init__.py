@@ -6,3 +6,12 @@ C ABI (``include/uz_api.h``) with ctypes.  PyTorch-ROCm tensors are used for sto
 There is no CPU fallback: constructing a model without the HIP library or a GPU raises.
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+# hipGraph replay of a tape with parallel branches (dependency lanes, bucket events) spreads the branches over the process's
+# hardware queues; every cross-branch edge then is a cross-queue barrier.  Measured on MI355X / ROCm 7.2 (PHiSeg step, batch 32):
+# GPU_MAX_HW_QUEUES = 2: 21.99 ms, 3: 22.02, 4 (the default): 22.42, 8: 35.2; with the overlapped data-parallel exchange 4
+# queues give anything from 21.8 to 39 ms depending on stream creation order, 2 queues a stable 22.7.  The variable is read
+# when the HIP runtime initialises (first device call), so setting it at import time is early enough.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
