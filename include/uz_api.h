@@ -209,6 +209,8 @@ int uz_add_views(const float* a, int CtotA, const float* b, int CtotB, float* y,
                  float alpha, int accumulate, const float* a_amax, const float* b_amax, float* y_amax, void* stream);
 /* slot[0] = max(slot[0], max_i |x_i|) (slot holds a non-negative float; zero it first for a plain maximum) */
 int uz_absmax(const float* x, size_t n, float* slot, void* stream);
+/* dst bound slot = max(dst, value of src bound slot): forwards a magnitude bound through ops that cannot raise it (pooling, interpolation) */
+int uz_absmax_copy(const float* src_slot, float* dst_slot, void* stream);
 int uz_scale(float* y, float alpha, size_t n, void* stream);                    /* y *= alpha   */
 /* sqrt(sum x^2) terms of utils.l2_regularisation (utils.py:93-101): one norm per tensor of a
  * table of (offset, count) pairs over the flat parameter buffer; out[i] = ||p_i||_2.       */
@@ -231,6 +233,9 @@ enum {
   UZ_OP_ADAM, UZ_OP_AXPY, UZ_OP_SCALE, UZ_OP_L2_NORMS, UZ_OP_L2_NORMS_BWD,
   UZ_OP_MEMSET, UZ_OP_COPY, UZ_OP_BCAST_CHANNELS, UZ_OP_BCAST_CHANNELS_BWD,
   UZ_OP_ABSMAX,          /* p[0] = src, p[1] = slot, n = count */
+  UZ_OP_ABSMAX_COPY,     /* p[0] = src slot, p[1] = dst slot */
+  UZ_OP_W3D_PERMUTE,     /* p = src, dst; i = Cout, Cin, mode */
+  UZ_OP_AVGPOOL3D_FWD, UZ_OP_AVGPOOL3D_BWD, UZ_OP_DEPTH_LERP_FWD, UZ_OP_DEPTH_LERP_BWD, UZ_OP_NEAREST3D_FWD, UZ_OP_NEAREST3D_BWD,
   UZ_OP_ADD_VIEWS,       /* p = a, b, y, a_amax, b_amax, y_amax; i = CtotA, CtotB, CtotY, C, N, H, W, accumulate; f[0] = alpha */
   UZ_OP_EVENT_RECORD,    /* p[0] = event (uz_event_create): marks "every earlier op this one depends on is done" */
   UZ_OP__COUNT
@@ -298,6 +303,22 @@ int  uz_event_elapsed_ms(void* start, void* stop, float* ms_out);
  * drawn by the host in the reference's order; outputs x (B,1,H,W) f32 and s (B,H,W) f32.                                    */
 int uz_augment_batch(const float* X, const uint8_t* Y, int H, int W, int A, const int* idx, const int* ann,
                      const float* params, int B, int nlabels, float* x_out, float* s_out, void* stream);
+
+/* ---------------------------------------------------------------- volumes (models/phiseg3D.py), one sample
+ * A volume is stored [D + 2][C][H][W] (zero slice before and after the D real ones) = a batch of D 2-D images.  Conv3d(3x3x3,
+ * pad 1) (phiseg3D.py:24) then is uz_conv_fwd / uz_conv_bwd_* with the depth window as 3 C input channels (pointer = slice d-1,
+ * Cin = 3 C, CinTot = C) and permuted weights: mode 0 forward [co][kd][ci][9], mode 1 data gradient [(j, co)][ci][9] (kd = 2 - j),
+ * mode 2 weight gradient back to the parameter layout [co][ci][kd][9].  BatchNorm3d / ReLU / 1x1x1 heads run their 2-D entry
+ * points over the D slices.  AvgPool3d(2, 2, ceil_mode) (phiseg3D.py:101); depth stage of F.interpolate(mode='trilinear',
+ * scale_factor=2, align_corners=True) (phiseg3D.py:146,306,376 - the in-plane stage is uz_bilinear2x_*); nearest volume resize.
+ * Pointers address slice 0 of the REAL slices; (D, H, W) are input sizes.                                                     */
+int uz_w3d_permute(const float* src, float* dst, int Cout, int Cin, int mode, void* stream);
+int uz_avgpool3d_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int D, int H, int W, void* stream);
+int uz_avgpool3d_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int D, int H, int W, int accumulate, void* stream);
+int uz_depth_lerp2x_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int D, int H, int W, void* stream);
+int uz_depth_lerp2x_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int D, int H, int W, int accumulate, void* stream);
+int uz_nearest3d_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int D, int H, int W, int f, int fz, void* stream);
+int uz_nearest3d_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int D, int H, int W, int f, int fz, int accumulate, void* stream);
 
 /* Fcomb input (probabilistic_unet.py:172-197) */
 /* z (N,L) tiled over HxW into channels of a (N,Ctot,H,W) buffer, and its backward (sum over pixels) */

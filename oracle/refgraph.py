@@ -36,16 +36,19 @@ def _bn(sd, p, y, bn_train):
 
 
 def conv_unit(sd, p, x, bn_train):
-    """Conv2D unit: Conv2d(k, pad = 1 if k == 3 else 0) -> BN -> ReLU (torchlayers.py:7-29)."""
+    """Conv2D unit: Conv2d(k, pad = 1 if k == 3 else 0) -> BN -> ReLU (torchlayers.py:7-29); with a 5-D weight the Conv3D unit
+    of models/phiseg3D.py:13-35 (Conv3d -> BatchNorm3d(eps=1e-3, momentum=0.01) -> ReLU)."""
     w = sd[p + ".convolution.0.weight"]
-    y = F.conv2d(x, w, sd[p + ".convolution.0.bias"], padding=1 if w.shape[-1] == 3 else 0)
+    conv = F.conv3d if w.dim() == 5 else F.conv2d
+    y = conv(x, w, sd[p + ".convolution.0.bias"], padding=1 if w.shape[-1] == 3 else 0)
     return F.relu(_bn(sd, p + ".convolution.1", y, bn_train))
 
 
 def conv_bare(sd, p, x):
     """Conv2D with norm=activation=nn.Identity (phiseg.py:281-284, probabilistic_unet.py:244)."""
     w = sd[p + ".convolution.0.weight"]
-    return F.conv2d(x, w, sd[p + ".convolution.0.bias"], padding=1 if w.shape[-1] == 3 else 0)
+    conv = F.conv3d if w.dim() == 5 else F.conv2d
+    return conv(x, w, sd[p + ".convolution.0.bias"], padding=1 if w.shape[-1] == 3 else 0)
 
 
 def rev_sequence(sd, p, x, bn_train):

@@ -266,3 +266,42 @@ def test_probunet_full_b32_digest():
             assert G.maxabs(rec.reshape(-1)[idx], arrays[f"dec{j}_samp"]) <= 1e-4
             assert meta["decode_margin_min"][j] > 1e-3
             assert np.array_equal(np.packbits(np.argmax(rec, axis=1).astype(np.uint8).reshape(-1)), arrays[f"dec{j}_argmax_bits"])
+
+
+@pytest.mark.parametrize("name", ["phiseg3d_small", "phiseg3d_l3"])
+def test_phiseg3d_oracle_vs_reference_modules(name):
+    """oracle/refgraph3d.py against the reference's own 3-D Posterior / prior / Likelihood modules, its loss functions and
+    autograd (fixtures from tools/gen_golden.py `3d`; the one statement the reference cannot execute is documented there)."""
+    from oracle import refgraph3d as R3
+    arrays, meta = G.load(name)
+    sd = G.leaves(oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"]))
+    L = meta["latent_levels"]
+    T = lambda k: torch.from_numpy(arrays[k])       # noqa: E731
+    eps = [T(f"eps{k}") for k in range(2 * L)]
+    out = R3.phiseg3d_forward(sd, T("patch"), T("mask_onehot"), eps, training=True, bn_train=True)
+    for l in range(L):
+        for a, b in (("post_mu", "post_mu"), ("post_sigma", "post_sigma"), ("post_z", "post_z"), ("prior_mu", "prior_mu"),
+                     ("prior_sigma", "prior_sigma"), ("s_in", "s_in")):
+            got, want = out[a][l].detach().numpy(), arrays[f"{b}{l}"]
+            assert got.shape == want.shape
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5, err_msg=f"{a}{l}")
+    total, terms = R3.phiseg3d_loss(out, T("labels"), num_classes=meta["num_classes"])
+    assert abs(float(total) - float(arrays["loss"])) <= 1e-5 * abs(float(arrays["loss"]))
+    for l in range(L):
+        assert abs(float(terms[l]) - float(arrays[f"loss:KL_divergence_loss_lvl{l}"])) <= 1e-5 * abs(float(arrays[f"loss:KL_divergence_loss_lvl{l}"])) + 1e-6
+        assert abs(float(terms[L + l]) - float(arrays[f"loss:residual_multinoulli_loss_lvl{l}"])) <= 1e-5 * float(arrays[f"loss:residual_multinoulli_loss_lvl{l}"])
+    total.backward()
+    n = 0
+    for k, v in sd.items():
+        if ("g:" + k) in arrays:
+            g = arrays["g:" + k]
+            scale = max(float(np.abs(g).max()), 1e-6)
+            assert v.grad is not None, k
+            assert float(np.abs(v.grad.numpy() - g).max()) <= 2e-4 * scale + 1e-6, k
+            n += 1
+        elif v.dtype.is_floating_point and "running_" not in k:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+    assert n > 50
+    for k in sd:
+        if "running_" in k:
+            np.testing.assert_allclose(sd[k].detach().numpy(), arrays["sd1:" + k], rtol=1e-5, atol=1e-6)

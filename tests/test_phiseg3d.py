@@ -1,0 +1,307 @@
+"""PHiSeg3D (BASELINE config 5; reference models/phiseg3D.py).  The reference's own forward cannot complete (its
+last statement, :398, raises on 5-D input) - parity is pinned on what it does execute: the fixtures tests/golden/phiseg3d_*.npz
+come from its Posterior / prior / Likelihood modules, its loss functions and autograd (tools/gen_golden.py `3d`), and
+tests/test_oracle_golden.py checks the oracle against them.  Here: the native model against those fixtures and the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from oracle import refgraph3d as R3
+import unet_zoo_amd  # noqa: F401
+from tests import _golden as G
+
+
+# ----------------------------------------------------------------------------- host side (CPU tier)
+@pytest.mark.parametrize("name", ["phiseg3d_small", "phiseg3d_l3"])
+def test_state_dict_keys_match_the_reference_model(name):
+    from unet_zoo_amd.models.phiseg3D import PHISeg3D
+    _, meta = G.load(name)
+    net = PHISeg3D(meta["input_channels"], meta["num_classes"], meta["filters"], latent_levels=meta["latent_levels"], device="cpu")
+    ours = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    ref = {k: tuple(s) for k, s, _ in meta["spec"]}                 # the real reference module's state_dict (keys, shapes)
+    assert ours == ref and list(ours) == list(ref)
+
+
+def test_plan_builds_schedules_and_rejects_what_the_reference_rejects():
+    from tests.test_host_cpu import _check_lane_schedule
+    from unet_zoo_amd.models.phiseg3D import PHISeg3D
+    arena = {}
+    for rev in (False, True):
+        net = PHISeg3D(4, 3, [8, 16, 16], latent_levels=2, reversible=rev, device="cpu")
+        plan = net._build(16, 32, 32, True, True)
+        for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
+            pairs, _ = _check_lane_schedule(plan, which, ops)
+            assert pairs > 100
+        codes = [o["code"] for o in plan.fwd_ops]
+        assert "UZ_OP_W3D_PERMUTE" in codes and "UZ_OP_AVGPOOL3D_FWD" in codes and "UZ_OP_DEPTH_LERP_FWD" in codes
+        arena[rev] = plan.summary()["arena_MB"]
+    assert arena[True] < arena[False]
+    with pytest.raises(ValueError):                                 # likelihood_post_c_path channel arithmetic (phiseg3D.py:343,372)
+        PHISeg3D(4, 3, [8, 16, 32], latent_levels=2, device="cpu")
+    net = PHISeg3D(4, 3, [8, 16, 16], latent_levels=2, device="cpu")
+    with pytest.raises(ValueError):
+        net._build(10, 32, 32, True, True)                          # 10 is not divisible by 2^(levels-1)
+    with pytest.raises(RuntimeError):                               # no CPU fallback
+        net.forward(torch.zeros(1, 4, 16, 32, 32), torch.zeros(1, 3, 16, 32, 32))
+
+
+def test_brats_experiment_file_resolves_to_the_native_model():
+    import os
+    from unet_zoo_amd import train_model as TM
+    f = "/root/reference/models/experiments/phiseg_brats.py"
+    if not os.path.isfile(f):
+        pytest.skip("reference tree not present")
+    cfg = TM.load_experiment(f)
+    from unet_zoo_amd.models.phiseg3D import PHISeg3D
+    assert cfg.model is PHISeg3D and cfg.image_size == (4, 128, 128, 128) and cfg.use_reversible is True
+    # the file's own filter list does not satisfy the reference's channel arithmetic: constructing it raises there too
+    with pytest.raises(ValueError):
+        cfg.model(cfg.input_channels, cfg.n_classes, cfg.filter_channels, latent_levels=cfg.latent_levels, device="cpu")
+
+
+# ----------------------------------------------------------------------------- device kernels vs torch
+def _g():
+    from tests import _gpu
+    return _gpu
+
+
+def _vol(t):
+    """(C, D, H, W) CPU tensor -> GPU volume [D + 2][C][H][W] with zero border slices; returns (storage, interior view)."""
+    c, d, h, w = t.shape
+    buf = torch.zeros(d + 2, c, h, w, device="cuda")
+    buf[1:d + 1] = t.permute(1, 0, 2, 3).to("cuda")
+    return buf, buf[1:d + 1]
+
+
+def _unvol(v):
+    return v.permute(1, 0, 2, 3).cpu()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,D,H,W", [(3, 6, 10, 8), (5, 7, 9, 11)])
+def test_avgpool3d_trilinear_nearest_vs_torch(C, D, H, W):
+    g = _g()
+    x = g.rnd(C, D, H, W, seed=1)
+    xr = x.clone()[None].requires_grad_(True)
+    # AvgPool3d(2, 2, ceil_mode=True)
+    yr = F.avg_pool3d(xr, 2, 2, 0, ceil_mode=True)
+    Do, Ho, Wo = yr.shape[-3:]
+    _, xv = _vol(x)
+    ybuf = torch.zeros(Do + 2, C, Ho, Wo, device="cuda")
+    g.call("uz_avgpool3d_fwd", xv, C, C, ybuf[1:], C, C, D, H, W)
+    assert g.maxabs(_unvol(ybuf[1:Do + 1]), yr[0]) <= 1e-6
+    assert float(ybuf[0].abs().max()) == 0 and float(ybuf[Do + 1].abs().max()) == 0
+    dy = g.rnd(*yr.shape[1:], seed=2)
+    yr.backward(dy[None])
+    _, dyv = _vol(dy)
+    dx = torch.full((D, C, H, W), float("nan"), device="cuda")
+    g.call("uz_avgpool3d_bwd", dyv, C, C, dx, C, C, D, H, W, 0)
+    assert g.maxabs(_unvol(dx), xr.grad[0]) <= 1e-6
+    g.call("uz_avgpool3d_bwd", dyv, C, C, dx, C, C, D, H, W, 1)
+    assert g.maxabs(_unvol(dx), 2 * xr.grad[0]) <= 2e-6
+    # trilinear x2, align_corners=True = the 2-D bilinear kernel per slice + the depth interpolation
+    xr.grad = None
+    tr = F.interpolate(xr, scale_factor=2, mode="trilinear", align_corners=True)
+    mid = torch.zeros(D + 2, C, 2 * H, 2 * W, device="cuda")
+    g.call("uz_bilinear2x_fwd", xv, C, C, mid[1:], C, C, D, H, W, 1, None, None)
+    out = torch.zeros(2 * D + 2, C, 2 * H, 2 * W, device="cuda")
+    g.call("uz_depth_lerp2x_fwd", mid[1:], C, C, out[1:], C, C, D, 2 * H, 2 * W)
+    assert g.maxabs(_unvol(out[1:2 * D + 1]), tr[0]) <= 2e-6
+    dt = g.rnd(*tr.shape[1:], seed=3)
+    tr.backward(dt[None])
+    _, dtv = _vol(dt)
+    dmid = torch.full((D, C, 2 * H, 2 * W), float("nan"), device="cuda")
+    g.call("uz_depth_lerp2x_bwd", dtv, C, C, dmid, C, C, D, 2 * H, 2 * W, 0)
+    dx2 = torch.full((D, C, H, W), float("nan"), device="cuda")
+    g.call("uz_bilinear2x_bwd", dmid, C, C, dx2, C, C, D, H, W, 1, 0)
+    assert g.maxabs(_unvol(dx2), xr.grad[0]) <= 1e-5
+    # nearest resize by integer factors
+    xr.grad = None
+    nr = F.interpolate(xr, size=[2 * D, 4 * H, 4 * W], mode="nearest")
+    nout = torch.zeros(2 * D + 2, C, 4 * H, 4 * W, device="cuda")
+    g.call("uz_nearest3d_fwd", xv, C, C, nout[1:], C, C, D, H, W, 4, 2)
+    assert g.maxabs(_unvol(nout[1:2 * D + 1]), nr[0]) == 0
+    dn = g.rnd(*nr.shape[1:], seed=4)
+    nr.backward(dn[None])
+    _, dnv = _vol(dn)
+    dx3 = torch.full((D, C, H, W), float("nan"), device="cuda")
+    g.call("uz_nearest3d_bwd", dnv, C, C, dx3, C, C, D, H, W, 4, 2, 0)
+    assert g.maxabs(_unvol(dx3), xr.grad[0]) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,D,H,W", [(4, 8, 6, 12, 10), (16, 32, 8, 16, 16), (2, 16, 4, 8, 8)])
+def test_conv3d_as_depth_window_vs_torch(Cin, Cout, D, H, W):
+    """Conv3d(3x3x3, pad 1) through the C ABI: uz_w3d_permute + uz_conv_fwd / uz_conv_bwd_weight / uz_conv_bwd_data on the
+    [D + 2][C][H][W] volume with the depth window as 3 Cin channels (include/uz_api.h, volumes section)."""
+    from unet_zoo_amd import _ffi
+    g = _g()
+    L = _ffi.lib()
+    x = g.rnd(Cin, D, H, W, seed=1)
+    w = g.rnd(Cout, Cin, 3, 3, 3, seed=2, scale=0.2)
+    b = g.rnd(Cout, seed=3)
+    xr, wr = x.clone()[None].requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, b, padding=1)
+    dy = g.rnd(Cout, D, H, W, seed=4)
+    yr.backward(dy[None])
+    xbuf, xv = _vol(x)
+    wd, bd = w.cuda(), b.cuda()
+    wp = torch.empty(Cout * Cin * 27, device="cuda")
+    g.call("uz_w3d_permute", wd, wp, Cout, Cin, 0)
+    ws_b = max(L.uz_conv_workspace(3 * Cin, Cout, D, H, W, 3), L.uz_conv_workspace(Cin, 3 * Cout, D, H, W, 3),
+               L.uz_conv_bwd_weight_workspace(3 * Cin, Cout, D, H, W, 3))
+    ws = torch.empty(ws_b // 4 + 16, device="cuda")
+    y = torch.full((D, Cout, H, W), float("nan"), device="cuda")
+    g.call("uz_conv_fwd", xbuf, 3 * Cin, Cin, wp, bd, y, Cout, Cout, D, H, W, 3, 0, None, None, None, ws, ws_b)
+    assert g.relerr(_unvol(y), yr[0]) <= 2e-5
+    # weight gradient in the window layout, permuted back to [co][ci][kd][kh][kw]
+    dybuf, dyv = _vol(dy)
+    dwp = torch.empty(Cout * Cin * 27, device="cuda")
+    g.call("uz_conv_bwd_weight", xbuf, 3 * Cin, Cin, dyv, Cout, Cout, dwp, None, D, H, W, 3, None, None, ws, ws_b)
+    dw = torch.empty(Cout, Cin, 3, 3, 3, device="cuda")
+    g.call("uz_w3d_permute", dwp, dw, Cout, Cin, 2)
+    assert g.relerr(dw, wr.grad) <= 2e-5
+    # data gradient: the dy volume read through a depth window of 3 Cout channels against the depth-flipped weights
+    wp2 = torch.empty(Cout * Cin * 27, device="cuda")
+    g.call("uz_w3d_permute", wd, wp2, Cout, Cin, 1)
+    dx = torch.full((D, Cin, H, W), float("nan"), device="cuda")
+    g.call("uz_conv_bwd_data", dybuf, 3 * Cout, Cout, wp2, dx, Cin, Cin, D, H, W, 3, 0, None, None, ws, ws_b)
+    assert g.relerr(_unvol(dx), xr.grad[0]) <= 2e-5
+
+
+# ----------------------------------------------------------------------------- model vs the reference's modules / the oracle
+def _run_native(meta, arrays, reversible=False, sd=None, training=True):
+    from unet_zoo_amd.models.phiseg3D import PHISeg3D
+    dev = torch.device("cuda", 0)
+    L = meta["latent_levels"]
+    net = PHISeg3D(meta["input_channels"], meta["num_classes"], meta["filters"], latent_levels=L, reversible=reversible,
+                   image_size=(meta["input_channels"], *meta["dhw"]))
+    net.load_state_dict(sd if sd is not None else oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"]))
+    net.train()
+    T = lambda k: torch.from_numpy(arrays[k]).to(dev)       # noqa: E731
+    s = net.forward(T("patch"), T("mask_onehot"), training=training, eps=[T(f"eps{k}") for k in range(2 * L)])
+    loss = net.loss(T("labels"))
+    return net, s, loss
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["phiseg3d_small", "phiseg3d_l3"])
+def test_native_model_vs_reference_modules(name):
+    arrays, meta = G.load(name)
+    L = meta["latent_levels"]
+    net, s, loss = _run_native(meta, arrays)
+    tol = lambda ref: 1e-4 * max(1.0, float(np.abs(ref).max()))     # noqa: E731  (north_star: within 1e-4 fp32)
+    for l in range(L):
+        for attr, key in ((net.posterior_mu, "post_mu"), (net.posterior_sigma, "post_sigma"), (net.posterior_latent_space, "post_z"),
+                          (net.prior_mu, "prior_mu"), (net.prior_sigma, "prior_sigma"), (net.s_in_list, "s_in")):
+            ref = arrays[f"{key}{l}"]
+            got = attr[l].cpu().numpy()
+            assert got.shape == ref.shape, (key, l, got.shape, ref.shape)
+            assert G.maxabs(got, ref) <= tol(ref), (key, l, G.maxabs(got, ref))
+    # the resized level logits: nearest resize of s_in to the full volume (the statement the reference cannot execute)
+    D, H, W = meta["dhw"]
+    for l in range(L):
+        want = F.interpolate(torch.from_numpy(arrays[f"s_in{l}"]), size=[D, H, W], mode="nearest").numpy()
+        assert s[l].shape == want.shape and G.maxabs(s[l].cpu().numpy(), want) <= tol(want)
+    ref_loss = float(arrays["loss"])
+    assert abs(float(loss) - ref_loss) <= 5e-5 * abs(ref_loss), (float(loss), ref_loss)
+    for l in range(L):
+        for nm in ("KL_divergence_loss_lvl%d" % l, "residual_multinoulli_loss_lvl%d" % l):
+            r = float(arrays["loss:" + nm])
+            assert abs(float(net.loss_dict[nm]) - r) <= 1e-4 * max(1.0, abs(r)), nm
+    bn_fwd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items() if "running_" in k}
+    loss.backward()
+    noise = G.bn_shadowed_biases([k for k, _, _ in meta["spec"]])
+    worst, wk, n = 0.0, None, 0
+    for k, p in net.named_parameters():
+        if ("g:" + k) not in arrays:
+            assert p.grad is None or k in meta["no_grad"] or float(p.grad.abs().max()) == 0.0, k
+            continue
+        if k in noise:
+            continue
+        ref = arrays["g:" + k]
+        err = G.maxabs(p.grad.cpu().numpy(), ref) / (float(np.abs(ref).max()) + 1e-30)
+        n += 1
+        if err > worst:
+            worst, wk = err, k
+    print(f"{name}: loss rel {abs(float(loss) - ref_loss) / abs(ref_loss):.1e}; worst gradient deviation {worst:.2e} at {wk} over {n} tensors")
+    assert n > 40 and worst <= 2e-3, (worst, wk)
+    for k, v in bn_fwd.items():
+        ref = arrays["sd1:" + k]
+        assert G.maxabs(v, ref) <= 1e-4 * max(1.0, float(np.abs(ref).max())), k
+
+
+@pytest.mark.gpu
+def test_native_reversible_and_eval_vs_oracle():
+    """reversible=True (ReversibleSequence, reversible_depth 1: phiseg3D.py:61-86) and the training=False path against the
+    oracle (revtorch is not importable: parity unpinned for the reversible variant, see oracle/refgraph.py:rev_sequence)."""
+    from unet_zoo_amd.models.phiseg3D import phiseg3d_spec
+    arrays, meta = G.load("phiseg3d_small")
+    L = meta["latent_levels"]
+    T = lambda k: torch.from_numpy(arrays[k])       # noqa: E731
+    eps = [T(f"eps{k}") for k in range(2 * L)]
+    for rev in (True, False):
+        spec = phiseg3d_spec(meta["input_channels"], meta["num_classes"], meta["filters"], L, reversible=rev)
+        sd0 = oracle.deterministic_state_dict(spec, seed=77)
+        for k, v in sd0.items():
+            if rev and k.endswith("convolution.1.weight"):
+                sd0[k] = v * 0.3
+        training = rev                                       # reversible: training graph; plain: the prior-sampling graph
+        net, s, loss = _run_native(meta, arrays, reversible=rev, sd=sd0, training=training)
+        lv = G.leaves(sd0)
+        out = R3.phiseg3d_forward(lv, T("patch"), T("mask_onehot"), eps, training=training, bn_train=True)
+        total, _ = R3.phiseg3d_loss(out, T("labels"), num_classes=meta["num_classes"])
+        assert abs(float(loss) - float(total)) <= 5e-5 * abs(float(total)), (rev, float(loss), float(total))
+        for l in range(L):
+            ref = out["s"][l].detach().numpy()
+            assert G.maxabs(s[l].cpu().numpy(), ref) <= 2e-4 * max(1.0, float(np.abs(ref).max())), (rev, l)
+        if not rev:
+            continue
+        loss.backward()
+        total.backward()
+        noise = G.bn_shadowed_biases(lv.keys())
+        worst, wk = 0.0, None
+        for k, p in net.named_parameters():
+            ref = lv[k].grad
+            if ref is None or k in noise:
+                continue
+            err = G.maxabs(p.grad.cpu().numpy(), ref.numpy()) / (float(ref.abs().max()) + 1e-30)
+            if err > worst:
+                worst, wk = err, k
+        print(f"reversible PHiSeg3D: worst gradient deviation {worst:.2e} at {wk}")
+        assert worst <= 5e-3, (worst, wk)
+
+
+@pytest.mark.gpu
+def test_native_five_level_volume_trains():
+    """BASELINE config 5's shape class at a test-sized volume: 5 resolution / 5 latent levels, 4 input channels, 3 labels,
+    hipGraph replay + fused Adam: loss matches the oracle at step 0, stays finite and decreases over a few steps."""
+    from unet_zoo_amd.models.phiseg3D import PHISeg3D, phiseg3d_spec
+    from unet_zoo_amd.optim import FusedAdam
+    dev = torch.device("cuda", 0)
+    filters, dhw, K, Cin = [8, 16, 32, 32, 32], (32, 32, 16), 3, 4
+    sd0 = oracle.deterministic_state_dict(phiseg3d_spec(Cin, K, filters, 5), seed=5)
+    shapes = R3.phiseg3d_eps_shapes(*dhw, 5, 5)
+    x, onehot, lab, eps = R3.synthetic_volume(Cin, K, dhw, 3, shapes + shapes)
+    net = PHISeg3D(Cin, K, filters, latent_levels=5, image_size=(Cin, *dhw))
+    net.load_state_dict(sd0)
+    net.train()
+    xd, od, ld = (torch.from_numpy(a).to(dev) for a in (x, onehot, lab))
+    net.forward(xd, od, training=True, eps=[torch.from_numpy(e).to(dev) for e in eps])
+    loss0 = float(net.loss(ld))
+    out = R3.phiseg3d_forward(G.leaves(sd0), torch.from_numpy(x), torch.from_numpy(onehot), [torch.from_numpy(e) for e in eps])
+    total, _ = R3.phiseg3d_loss(out, torch.from_numpy(lab), num_classes=K)
+    assert abs(loss0 - float(total)) <= 1e-4 * abs(float(total)), (loss0, float(total))
+    net.enable_graphs(True)
+    opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
+    losses = []
+    for _ in range(6):
+        net.forward(xd, od, training=True, eps=[torch.from_numpy(e).to(dev) for e in eps])
+        l = net.loss(ld)
+        opt.zero_grad()
+        l.backward()
+        opt.step()
+        losses.append(float(l))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -62,11 +62,11 @@ def kinds_for(sd):
             kind = "bn_rm"
         elif k.endswith("running_var"):
             kind = "bn_rv"
-        elif v.dim() == 4:
+        elif v.dim() >= 4:
             kind = "conv_w"
         else:
             stem = k.rsplit(".", 1)[0]
-            is_conv = sd[stem + ".weight"].dim() == 4
+            is_conv = sd[stem + ".weight"].dim() >= 4
             if is_conv:
                 kind = "conv_b"
             else:
@@ -454,6 +454,70 @@ def phiseg_f64_case(name, filters, hw, batch, seed, n_samp=256):
     save(name, arrays, meta)
 
 
+def phiseg3d_case(name, in_ch, num_classes, filters, latent_levels, dhw, seed):
+    """models/phiseg3D.py, the parts the reference can execute (see oracle/refgraph3d.py): Posterior, prior (training_prior)
+    and Likelihood modules of a real PHISeg3D instance.  Likelihood.forward's last statement (:398) raises on 5-D input; for
+    the duration of that call `interpolate(x, size=<2 elements>)` is answered with the nearest resize to the full volume (the
+    evident intent), everything else is the reference's own code - including its loss functions, fed through the attributes
+    PHISeg3D.forward would have set (:456-463), and autograd through its modules."""
+    from models.phiseg3D import PHISeg3D as Ref3D
+    import torch.nn.functional as TF
+    from oracle.refgraph3d import phiseg3d_eps_shapes, synthetic_volume
+    D, H, W = dhw
+    net = Ref3D(input_channels=in_ch, num_classes=num_classes, num_filters=filters, latent_levels=latent_levels,
+                image_size=(in_ch, D, H, W))
+    spec = kinds_for(net.state_dict())
+    net.load_state_dict(deterministic_state_dict(spec, seed=seed))
+    net.train()
+    R, L = len(filters), latent_levels
+    shapes = phiseg3d_eps_shapes(D, H, W, R, L)
+    x, onehot, lab, eps = synthetic_volume(in_ch, num_classes, dhw, 20201005, shapes + shapes)
+    xt, ot, lt = torch.from_numpy(x), torch.from_numpy(onehot), torch.from_numpy(lab)
+    s_in = {}
+    hooks = [blk.register_forward_hook(lambda m, i, o, k=k: s_in.__setitem__(k, o)) for k, blk in enumerate(net.likelihood.s_layer)]
+    orig = TF.interpolate
+
+    def resize(inp, size=None, *a, **kw):
+        if size is not None and inp.dim() == 5 and len(size) == 2:
+            return orig(inp, size=[D, H, W], mode="nearest")
+        return orig(inp, size, *a, **kw)
+    with NoiseFeeder([torch.from_numpy(e) for e in eps]):
+        pz, pmu, psig = net.posterior(xt, ot)
+        qz, qmu, qsig = net.prior(xt, training_prior=True, z_list=pz)
+    TF.interpolate = resize
+    try:
+        s = net.likelihood(pz)
+    finally:
+        TF.interpolate = orig
+    for h in hooks:
+        h.remove()
+    net.posterior_latent_space, net.posterior_mu, net.posterior_sigma = pz, pmu, psig
+    net.prior_latent_space, net.prior_mu, net.prior_sigma = qz, qmu, qsig
+    net.s_out_list = s
+    loss = net.loss(lt)
+    loss.backward()
+    arrays = {"patch": x, "mask_onehot": onehot, "labels": lab}
+    for k, e in enumerate(eps):
+        arrays[f"eps{k}"] = e
+    for l in range(L):
+        arrays[f"post_mu{l}"], arrays[f"post_sigma{l}"], arrays[f"post_z{l}"] = npf(pmu[l]), npf(psig[l]), npf(pz[l])
+        arrays[f"prior_mu{l}"], arrays[f"prior_sigma{l}"] = npf(qmu[l]), npf(qsig[l])
+        arrays[f"s_in{l}"] = npf(s_in[L - 1 - l])            # s_layer[k] serves level L-1-k (:395-397)
+    for k, v in net.loss_dict.items():
+        arrays["loss:" + k] = np.float32(float(v))
+    arrays["loss"] = np.float32(float(loss))
+    for n_, g in grads_of(net).items():
+        if g is not None:
+            arrays["g:" + n_] = g
+    sd1 = net.state_dict()
+    for k, v in sd1.items():
+        if "running_" in k:
+            arrays["sd1:" + k] = npf(v)
+    save(name, arrays, dict(model="PHISeg3D", input_channels=in_ch, num_classes=num_classes, filters=filters, latent_levels=L,
+                            dhw=list(dhw), weight_seed=seed, spec=[[k, list(s_), kd] for k, s_, kd in spec],
+                            no_grad=[n_ for n_, g in grads_of(net).items() if g is None]))
+
+
 def batch_provider_stream():
     """Index / annotator stream of the REAL reference BatchProvider.next_batch (data/batch_provider.py:43-67,131-137) under a
     fixed numpy seed: pins the native provider's sampling logic and its order of RNG draws.  (The augmentation draws cannot be
@@ -548,6 +612,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "b32":
         # BASELINE config 4 exactly (batch 32): digests only, inputs are regenerated from the seed
         phiseg_case("phiseg_full_b32_digest", [32, 64, 128, 192, 192, 192, 192], 128, 32, 1, False, 1238, store_inputs=False)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "3d":
+        phiseg3d_case("phiseg3d_small", 2, 3, [4, 8, 8], 2, (16, 16, 8), 1242)       # lvl_diff 1
+        phiseg3d_case("phiseg3d_l3", 4, 3, [8, 8, 16], 3, (8, 16, 16), 1243)         # one latent level per resolution level
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "batches":
         batch_provider_stream()

@@ -97,20 +97,22 @@ class Buf:
 
 
 class View:
-    """Channel slice [c0, c0+C) of a buffer."""
-    __slots__ = ("buf", "c0", "C")
+    """Channel slice [c0, c0+C) of a buffer, optionally restricted to the batch entries [b0, b0+nb) (volumes: the D real
+    slices between the two zero slices, see Plan.vol)."""
+    __slots__ = ("buf", "c0", "C", "b0", "nb")
 
-    def __init__(self, buf, c0=0, C=None):
+    def __init__(self, buf, c0=0, C=None, b0=0, nb=None):
         self.buf, self.c0, self.C = buf, c0, buf.C - c0 if C is None else C
+        self.b0, self.nb = b0, nb
         assert 0 <= self.c0 and self.c0 + self.C <= buf.C
 
-    N = property(lambda s: s.buf.N)
+    N = property(lambda s: s.buf.N if s.nb is None else s.nb)
     H = property(lambda s: s.buf.H)
     W = property(lambda s: s.buf.W)
     Ctot = property(lambda s: s.buf.C)
 
     def slice(self, c0, C):
-        return View(self.buf, self.c0 + c0, C)
+        return View(self.buf, self.c0 + c0, C, self.b0, self.nb)
 
     @property
     def contiguous(self):
@@ -178,7 +180,15 @@ class Plan:
             g = Buf("grad:" + v.buf.name, v.buf.N, v.buf.C, v.buf.H, v.buf.W, False)
             self.bufs.append(g)
             v.buf.gbuf = g
-        return View(v.buf.gbuf, v.c0, v.C)
+        return View(v.buf.gbuf, v.c0, v.C, v.b0, v.nb)
+
+    def vol(self, name, C, D, H, W, requires_grad=True):
+        """One volume (models/phiseg3D.py): [D + 2][C][H][W] with a zero slice on either side of the D real ones (csrc/vol.hip);
+        the returned view addresses the real slices as a batch of D images.  The arena is zero-initialised and nothing ever
+        writes the two border slices, so they ARE the depth padding of the 3x3x3 convolutions."""
+        b = Buf(name, D + 2, C, H, W, requires_grad)
+        self.bufs.append(b)
+        return View(b, 0, C, 1, D)
 
     # ------------------------------------------------------------------ magnitude bounds
     def _new_amax(self, bwd=False):
@@ -276,6 +286,23 @@ class Plan:
     def _conv_fwd(self, x, wkey, bkey, y, ks, relu, wrow0=0):
         cout = y.C
         cin = x.C
+        if len(self.ptab.shape[wkey]) == 5 and x.nb is None:
+            raise RuntimeError(f"{wkey} is a Conv3d weight but its input {x.buf.name} is not a volume")
+        if x.nb is not None and ks == 3:
+            # Conv3d(3x3x3, pad 1) on a volume = the 2-D kernel over the D slices with the depth window as 3 Cin input channels
+            # (csrc/vol.hip); the weights are permuted to [co][kd][ci][3][3] first
+            assert wrow0 == 0
+            x = self._window_input(x, wkey)
+            wp = self.vec(wkey + ":w3d_fwd", cout * cin * 27)
+            ws = self.L.uz_conv_workspace(3 * cin, cout, x.N, x.H, x.W, 3)
+            self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
+            self._newgroup()
+            self._emit(self.target, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp], i=[cout, cin, 0])
+            self._emit(self.target, "UZ_OP_CONV_FWD",
+                       p=[("win", x), wp, self.P(bkey) if bkey else None, y, ("scratch", "wgrad"), self.amax_in(x), ("amax", 0),
+                          self.amax_out(y) if relu else None],
+                       i=[3 * cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, 3, relu], n=ws)
+            return
         wextra = wrow0 * cin * ks * ks
         ws = self.L.uz_conv_workspace(cin, cout, x.N, x.H, x.W, ks)
         self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
@@ -289,6 +316,27 @@ class Plan:
         """Weight gradient (+ optional bias gradient) and, when the input carries a gradient,
         the data gradient.  gy: gradient w.r.t. the conv output (a View)."""
         cin, cout = x.C, gy.C
+        if x.nb is not None and ks == 3:                      # volume: see _conv_fwd
+            assert isinstance(gy, _ScratchView) and gy.off and db_key is None and wrow0 == 0
+            x, x_orig = self.__dict__.get("_win_of", {}).get(wkey, x), x          # the weight gradient reads the depth window
+            dwp = self.vec(wkey + ":w3d_dw", cout * cin * 27)
+            ws = self.L.uz_conv_bwd_weight_workspace(3 * cin, cout, x.N, x.H, x.W, 3)
+            self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
+            self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
+                       p=[("win", x), gy, dwp, None, ("scratch", "wgrad"), self.amax_in(x), self.amax_in(gy)],
+                       i=[3 * cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, 3], n=ws)
+            self._emit(self.bwd_ops, "UZ_OP_W3D_PERMUTE", p=[dwp, self.G(wkey)], i=[cout, cin, 2])
+            x = x_orig
+            if x.buf.requires_grad:
+                acc = self._claim(x)
+                wp2 = self.vec(wkey + ":w3d_bwd", cout * cin * 27)
+                ws2 = self.L.uz_conv_workspace(cin, 3 * cout, x.N, x.H, x.W, 3)
+                self.scratch["wgrad"] = max(self.scratch["wgrad"], ws2)
+                self._emit(self.bwd_ops, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp2], i=[cout, cin, 1])
+                self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
+                           p=[("gywin",), wp2, self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0)],
+                           i=[3 * cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, 3, acc], n=ws2)
+            return
         wextra = wrow0 * cin * ks * ks
         ws = self.L.uz_conv_bwd_weight_workspace(cin, cout, x.N, x.H, x.W, ks)
         self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
@@ -304,6 +352,22 @@ class Plan:
                        p=[gy, self.P(wkey, wextra), self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0)],
                        i=[cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, ks, acc], n=ws2)
 
+    def _window_input(self, x, wkey):
+        """The depth window of a 3x3x3 convolution addresses slices d-1, d, d+1 of its input as 3 C consecutive channels, which
+        needs the view to span its buffer (C == Ctot).  A channel slice (one half of a reversible block's tensor, the image
+        channels of the posterior's input) is first copied into a buffer of its own - pooled scratch inside reversible
+        blocks, where the backward tape recomputes it together with everything else."""
+        if x.C == x.Ctot:
+            return x
+        ctx = self.__dict__.get("_rev_ctx")
+        if ctx is not None:
+            xc = self._pool((ctx, "win" + ("F" if ".f_block." in wkey else "G")), x.C, x.H, x.W)
+        else:
+            xc = self.vol(wkey + ":win", x.C, x.N, x.H, x.W, requires_grad=False)
+        self.add_views(x, None, xc)
+        self.__dict__.setdefault("_win_of", {})[wkey] = xc
+        return xc
+
     def _gy_scratch(self, like):
         self.scratch["gy"] = max(self.scratch["gy"], like.N * like.C * like.H * like.W)
         return ("gyview", like.C)
@@ -313,10 +377,11 @@ class Plan:
         ybuf / save: caller-owned buffers for the pre-normalisation output and the saved statistics (reversible blocks share
         them); a_grad: view holding the gradient w.r.t. the unit's output instead of grad(a) (no copy)."""
         wkey, bkey = cprefix + ".weight", cprefix + ".bias"
-        cout, _, ks, _ = self.ptab.shape[wkey]
+        cout, ks = self.ptab.shape[wkey][0], self.ptab.shape[wkey][2]
         name = name or cprefix
-        y = ybuf if ybuf is not None else self.buf(name + ":y", cout, x.H, x.W)
-        a = out if out is not None else self.buf(name + ":a", cout, x.H, x.W)
+        new = (lambda nm: self.vol(nm, cout, x.N, x.H, x.W)) if x.nb is not None else (lambda nm: self.buf(nm, cout, x.H, x.W))
+        y = ybuf if ybuf is not None else new(name + ":y")
+        a = out if out is not None else new(name + ":a")
         assert a.C == cout and a.H == x.H and a.W == x.W
         save = save if save is not None else self.vec(name + ":bnsave", 2 * cout)
         self._conv_fwd(x, wkey, bkey, y, ks, 0)
@@ -335,6 +400,14 @@ class Plan:
                 raise RuntimeError("backward through eval-mode BatchNorm is not supported")
             gy = self._gy_scratch(y)
             gyv = _ScratchView(y.N, cout, y.H, y.W, amax=self._new_amax(bwd=True))
+            if x.nb is not None and ks == 3:
+                # volume: dy sits one slice into the scratch, between two zeroed border slices (the data gradient reads it
+                # through a depth window)
+                sl = cout * y.H * y.W
+                self.scratch["gy"] = max(self.scratch["gy"], (y.N + 2) * sl)
+                self._emit(self.bwd_ops, "UZ_OP_MEMSET", p=[("gypad", 0)], n=4 * sl)
+                self._emit(self.bwd_ops, "UZ_OP_MEMSET", p=[("gypad", (y.N + 1) * sl)], n=4 * sl)
+                gy, gyv.off = ("gyvol", sl), sl
             ga = a_grad if a_grad is not None else self.gview(a)
             self._emit(self.bwd_ops, "UZ_OP_BN_RELU_BWD",
                        p=[ga, y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), self.G(bkey), ("scratch", "bn"),
@@ -352,10 +425,14 @@ class Plan:
         slots = self.__dict__.setdefault("_rev_slots", {})
         k = (key, C, H, W)
         if k not in pool:
-            v = self.vec("revpool:" + "/".join(map(str, k)), C) if vec else self.buf("revpool:" + "/".join(map(str, k)), C, H, W)
+            nm = "revpool:" + "/".join(map(str, k))
+            D = self.__dict__.get("_vol_depth")
+            v = self.vec(nm, C) if vec else (self.vol(nm, C, D, H, W) if D else self.buf(nm, C, H, W))
             # all shapes of one (branch, role) share ONE region sized for the largest of them: a reversible sequence's scratch is
             # dead as soon as the next sequence of the branch starts (forward) or has been back-propagated (backward)
-            slot = slots.setdefault(key[:2], {"floats": 0, "off": None})
+            # (volumes: one region per shape - the two border slices of a volume must never be written, and regions shared by
+            # volumes of different slice sizes would put one shape's interior on another's border)
+            slot = slots.setdefault((key[:2], C, H, W) if (D and not vec) else key[:2], {"floats": 0, "off": None})
             slot["floats"] = max(slot["floats"], v.buf.numel)
             v.buf.alias = slot
             pool[k] = v
@@ -381,7 +458,10 @@ class Plan:
         branch = prefix.split(".", 1)[0]
         N, H, W, h = x.N, x.H, x.W, cout // 2
         assert cout % 2 == 0
-        seq_out = self.buf(prefix + ":revout", cout, H, W)
+        self._vol_depth = x.N if x.nb is not None else None      # volumes: pooled scratch is volume-shaped (and keyed by depth below)
+        if x.nb is not None:
+            branch = (branch, x.N)
+        seq_out = self.vol(prefix + ":revout", cout, x.N, H, W) if x.nb is not None else self.buf(prefix + ":revout", cout, H, W)
         widened = x.C != cout
         if widened:
             # the 1x1 unit's output is only the first block's input: it is recomputed in backward like every other block
@@ -410,6 +490,7 @@ class Plan:
             if not self._has_grad(seq_out):
                 return
             ycur = seq_out
+            self._vol_depth = seq_out.N if seq_out.nb is not None else None
             for i in reversed(range(depth)):
                 xin, _, bp = blocks[i]
                 xrec = self._pool((branch, "x%d" % (i & 1)), cout, H, W)       # same ping-pong pair as the forward pass
@@ -430,6 +511,8 @@ class Plan:
         """One additive-coupling block.  forward=True: y from x (forward tape).  forward=False (inside the backward tape):
         x recomputed from y into `xv`, then the gradients of F, G and dX (in place in the shared gradient buffer)."""
         N, H, W = xv.N, xv.H, xv.W
+        self._vol_depth = xv.N if xv.nb is not None else None
+        self._rev_ctx = branch
         x1, x2, y1, y2 = xv.slice(0, h), xv.slice(h, h), yv.slice(0, h), yv.slice(h, h)
         bufs = {}
         for tag in ("F", "G"):
@@ -447,6 +530,7 @@ class Plan:
             self._newgroup()
             self.add_views(x2, tG, y2)
             self._record_bwd = rec
+            self._rev_ctx = None
             return
         gy = self.gview(yv)
         gy1, gy2 = gy.slice(0, h), gy.slice(h, h)
@@ -473,6 +557,7 @@ class Plan:
                 fn()
         finally:
             self.target, self._record_bwd, self._bwd = tgt, rec, saved_bwd
+            self._rev_ctx = None
 
     def conv_relu(self, x, prefix, out=None, name=None):
         """nn.Conv2d(3, pad 1) + nn.ReLU(inplace=True) of the vanilla U-Net blocks (unet.py:25-30)."""
@@ -498,11 +583,12 @@ class Plan:
         """Plain nn.Conv2d (1x1 heads: phiseg.py:95-96,281-284; unet.py:122; probabilistic_unet.py:95).
         rows=(r0, n): use only output rows [r0, r0+n) of the parameter (mu / log-sigma halves)."""
         wkey, bkey = prefix + ".weight", prefix + ".bias"
-        cout, _, ks, _ = self.ptab.shape[wkey]
+        cout, ks = self.ptab.shape[wkey][0], self.ptab.shape[wkey][2]
         r0 = 0
         if rows is not None:
             r0, cout = rows
-        y = out if out is not None else self.buf((name or prefix) + ":y", cout, x.H, x.W)
+        y = out if out is not None else (self.vol((name or prefix) + ":y", cout, x.N, x.H, x.W) if x.nb is not None
+                                         else self.buf((name or prefix) + ":y", cout, x.H, x.W))
         self._conv_fwd(x, wkey, bkey, y, ks, 0, wrow0=r0)
 
         def bwd():
@@ -546,6 +632,60 @@ class Plan:
             pass
         return self._resample("UZ_OP_NEAREST_FWD", "UZ_OP_NEAREST_BWD", x, y, (factor,))
 
+    def avgpool3d(self, x, name):
+        """nn.AvgPool3d(2, 2, ceil_mode=True) (phiseg3D.py:101) on a volume."""
+        D, H, W = x.N, x.H, x.W
+        y = self.vol(name, x.C, (D + 1) // 2, (H + 1) // 2, (W + 1) // 2, requires_grad=x.buf.requires_grad)
+        self._newgroup()
+        self._emit(self.target, "UZ_OP_AVGPOOL3D_FWD", p=[x, y], i=[x.C, x.Ctot, y.Ctot, D, H, W])
+        if self.amax_in(x) is not None:                       # a mean of inputs: the input's bound holds (forwarded by a 1-op copy)
+            self.add_views_bound(x, y)
+
+        def bwd():
+            if not self._has_grad(y) or not x.buf.requires_grad:
+                return
+            acc = self._claim(x)
+            self._emit(self.bwd_ops, "UZ_OP_AVGPOOL3D_BWD", p=[self.gview(y), self.gview(x)], i=[x.C, y.Ctot, x.Ctot, D, H, W, acc])
+        self._push_bwd(bwd)
+        return y
+
+    def add_views_bound(self, x, y):
+        """Make y's magnitude-bound slot inherit x's (one lane of a tiny launch)."""
+        self._emit(self.target, "UZ_OP_ABSMAX_COPY", p=[self.amax_in(x), self.amax_out(y)])
+
+    def trilinear(self, x, name=None, out=None):
+        """F.interpolate(mode='trilinear', scale_factor=2, align_corners=True) (phiseg3D.py:146,306,376): the 2-D bilinear kernel
+        per slice, then linear interpolation along the depth (csrc/vol.hip) - the interpolation is separable."""
+        D, H, W = x.N, x.H, x.W
+        mid = self.vol((name or "tri") + ":inplane", x.C, D, 2 * H, 2 * W, requires_grad=x.buf.requires_grad)
+        self.bilinear(x, True, out=mid)
+        y = out if out is not None else self.vol(name, x.C, 2 * D, 2 * H, 2 * W, requires_grad=x.buf.requires_grad)
+        self._newgroup()
+        self._emit(self.target, "UZ_OP_DEPTH_LERP_FWD", p=[mid, y], i=[x.C, mid.Ctot, y.Ctot, D, 2 * H, 2 * W])
+        if self.amax_in(mid) is not None:
+            self.add_views_bound(mid, y)
+
+        def bwd():
+            if not self._has_grad(y) or not x.buf.requires_grad:
+                return
+            acc = self._claim(mid)
+            self._emit(self.bwd_ops, "UZ_OP_DEPTH_LERP_BWD", p=[self.gview(y), self.gview(mid)], i=[x.C, y.Ctot, mid.Ctot, D, 2 * H, 2 * W, acc])
+        self._push_bwd(bwd)
+        return y
+
+    def nearest3d(self, x, f, fz, name):
+        y = self.vol(name, x.C, x.N * fz, x.H * f, x.W * f, requires_grad=x.buf.requires_grad)
+        self._newgroup()
+        self._emit(self.target, "UZ_OP_NEAREST3D_FWD", p=[x, y], i=[x.C, x.Ctot, y.Ctot, x.N, x.H, x.W, f, fz])
+
+        def bwd():
+            if not self._has_grad(y) or not x.buf.requires_grad:
+                return
+            acc = self._claim(x)
+            self._emit(self.bwd_ops, "UZ_OP_NEAREST3D_BWD", p=[self.gview(y), self.gview(x)], i=[x.C, y.Ctot, x.Ctot, x.N, x.H, x.W, f, fz, acc])
+        self._push_bwd(bwd)
+        return y
+
     def spatial_mean(self, x, name):
         y = self.buf(name, x.C, 1, 1)
         self._newgroup()
@@ -588,8 +728,9 @@ class Plan:
 
     def latent(self, mu, pre, eps, name, want_z=True, act=0):
         assert mu.contiguous and pre.contiguous
-        sigma = self.buf(name + ":sigma", mu.C, mu.H, mu.W)
-        z = self.buf(name + ":z", mu.C, mu.H, mu.W) if want_z else None
+        new = (lambda nm: self.vol(nm, mu.C, mu.N, mu.H, mu.W)) if mu.nb is not None else (lambda nm: self.buf(nm, mu.C, mu.H, mu.W, N=mu.N))
+        sigma = new(name + ":sigma")
+        z = new(name + ":z") if want_z else None
         lat = Latent(mu, pre, sigma, z, eps, act)
         self._newgroup()
         self._emit(self.target, "UZ_OP_LATENT_FWD", p=[mu, pre, eps, sigma, z], i=[act], n=mu.numel)
@@ -607,6 +748,8 @@ class Plan:
     def kl(self, q, p, weight, term):
         """weight * KL_two_gauss_with_diag_cov(q || p) (phiseg.py:436-479)."""
         n, per = q.mu.N, q.mu.C * q.mu.H * q.mu.W
+        if q.mu.nb is not None:                                 # volume: ONE sample whose depth slices are stored as the batch
+            n, per = 1, q.mu.N * per
         self._newgroup()
         self._emit(self.target, "UZ_OP_KL_FWD", p=[q.mu, q.sigma, p.mu, p.sigma, term], i=[n, per], f=[weight])
 
@@ -750,10 +893,10 @@ class Plan:
         if r is None:
             return 0
         if isinstance(r, _ScratchView):
-            return self.base + 4 * self.gy_off[lane]
+            return self.base + 4 * (self.gy_off[lane] + r.off)
         if isinstance(r, View):
             assert r.buf.off is not None
-            return self.base + 4 * (r.buf.off + r.c0 * r.buf.H * r.buf.W)
+            return self.base + 4 * (r.buf.off + (r.b0 * r.buf.C + r.c0) * r.buf.H * r.buf.W)
         kind = r[0]
         if kind == "param":
             return self.ptab.pflat.data_ptr() + 4 * (self.ptab.poff[r[1]] + r[2])
@@ -773,6 +916,15 @@ class Plan:
             return self.ptrtab.data_ptr() + 8 * self._tab_off[r[1]]
         if kind == "raw":
             return int(r[1])
+        if kind == "win":                                    # depth window of a volume: starts one slice before the view
+            v = r[1]
+            return self.base + 4 * (v.buf.off + ((v.b0 - 1) * v.buf.C + v.c0) * v.buf.H * v.buf.W)
+        if kind == "gywin":                                  # depth window of the dy scratch (dy lives one slice into the scratch)
+            return self.base + 4 * self.gy_off[lane]
+        if kind == "gyvol":                                  # dy of a volume unit: the scratch's real slices start one slice in
+            return self.base + 4 * (self.gy_off[lane] + r[1])
+        if kind == "gypad":                                  # the two border slices of the dy scratch (zeroed per use)
+            return self.base + 4 * (self.gy_off[lane] + r[1])
         if kind == "amax":
             return self.base + 4 * (self.amax_off + _AMAX_FLOATS * self._amax_remap[r[1]])
         if kind == "amaxw":
@@ -832,7 +984,9 @@ class Plan:
         "UZ_OP_SUM_TERMS": (1,), "UZ_OP_SCALE": (0,), "UZ_OP_COPY": (0,), "UZ_OP_MEMSET": (0,),
         "UZ_OP_L2_NORMS": (2,), "UZ_OP_L2_NORMS_BWD": (4,),
         "UZ_OP_BCAST_CHANNELS": (1,), "UZ_OP_BCAST_CHANNELS_BWD": (1,), "UZ_OP_EVENT_RECORD": (0,), "UZ_OP_ABSMAX": (1,),
-        "UZ_OP_ADD_VIEWS": (2,),
+        "UZ_OP_ADD_VIEWS": (2,), "UZ_OP_W3D_PERMUTE": (1,), "UZ_OP_AVGPOOL3D_FWD": (1,), "UZ_OP_AVGPOOL3D_BWD": (1,),
+        "UZ_OP_DEPTH_LERP_FWD": (1,), "UZ_OP_DEPTH_LERP_BWD": (1,), "UZ_OP_NEAREST3D_FWD": (1,), "UZ_OP_NEAREST3D_BWD": (1,),
+        "UZ_OP_ABSMAX_COPY": (),
     }
 
     def _resources(self, r):
@@ -853,6 +1007,10 @@ class Plan:
             return [(("bnbuf", r[1]), 0, 1)]
         if kind == "ptrtab":
             return [x for q in self.ptr_tables[r[1]] for x in self._resources(q)]
+        if kind == "win":
+            return self._resources(r[1])
+        if kind in ("gywin", "gyvol", "gypad"):
+            return []
         if kind == "amax":
             # Bound slots are atomic-max accumulated by the same kernels that write the data they bound, so every
             # producer -> consumer order is already implied by the data buffers; only the zeroing (and the parameter-bound
@@ -1066,9 +1224,11 @@ class Plan:
 
     # ------------------------------------------------------------------ execution helpers
     def tensor(self, v):
-        """torch view (storage only) of a plan buffer slice, NCHW."""
+        """torch view (storage only) of a plan buffer slice, NCHW (volumes: the D real slices, i.e. DCHW)."""
         b = v.buf
         full = self.arena[b.off:b.off + b.numel].view(b.N, b.C, b.H, b.W)
+        if v.nb is not None:
+            full = full[v.b0:v.b0 + v.nb]
         return full[:, v.c0:v.c0 + v.C]
 
     def run(self, which, stream_ptr):
@@ -1090,3 +1250,5 @@ class _ScratchView:
         self.N, self.C, self.H, self.W, self.Ctot = N, C, H, W, C
         self.buf = None
         self.amax = amax          # magnitude-bound slot of this unit's dy
+        self.off = 0              # float offset inside the scratch (volumes: one slice, behind the zeroed border slice)
+        self.nb = None

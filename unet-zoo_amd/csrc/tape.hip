@@ -135,6 +135,22 @@ static int run_one(const uz_op& o, void* st) {
             return uz_bcast_channels_fwd(CFP(0), i[0], FP(1), i[1], i[2], i[3], i[4], st);
         case UZ_OP_BCAST_CHANNELS_BWD:
             return uz_bcast_channels_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], st);
+        case UZ_OP_ABSMAX_COPY:
+            return uz_absmax_copy(CFP(0), FP(1), st);
+        case UZ_OP_W3D_PERMUTE:
+            return uz_w3d_permute(CFP(0), FP(1), i[0], i[1], i[2], st);
+        case UZ_OP_AVGPOOL3D_FWD:
+            return uz_avgpool3d_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], st);
+        case UZ_OP_AVGPOOL3D_BWD:
+            return uz_avgpool3d_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], st);
+        case UZ_OP_DEPTH_LERP_FWD:
+            return uz_depth_lerp2x_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], st);
+        case UZ_OP_DEPTH_LERP_BWD:
+            return uz_depth_lerp2x_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], st);
+        case UZ_OP_NEAREST3D_FWD:
+            return uz_nearest3d_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], i[7], st);
+        case UZ_OP_NEAREST3D_BWD:
+            return uz_nearest3d_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], i[7], i[8], st);
         case UZ_OP_ADD_VIEWS:
             return uz_add_views(CFP(0), i[0], CFP(1), i[1], FP(2), i[2], i[3], i[4], i[5], i[6], f[0], i[7], CFP(3), CFP(4), FP(5), st);
         case UZ_OP_ABSMAX:

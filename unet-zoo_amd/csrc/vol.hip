@@ -1,0 +1,165 @@
+// Volumetric (PHiSeg3D, models/phiseg3D.py) support kernels.  A volume lives in HBM as [D + 2][C][H][W] (one sample; a zero
+// slice before and after the D real ones), i.e. a batch of D channel-major 2-D images.  With that layout
+//   * Conv3d(3x3x3, pad 1) (phiseg3D.py:24) IS a 2-D 3x3 convolution over the batch of slices whose input has 3 C channels:
+//     the slices d-1, d, d+1 are adjacent in memory, so the view (pointer = slice d-1, Cin = 3 C, batch stride = ONE slice)
+//     is the depth window, the zero slices are the depth padding, and the 2-D implicit-GEMM kernels (conv_split.hip,
+//     conv_wgrad_split.hip, conv_mfma.hip) run it unchanged with K = 27 Cin.  Only the weights need a permutation, done by the
+//     three small kernels below (forward: [co][kd][ci][3][3]; data gradient: [(j, co)][ci][3][3] with kd = 2 - j; weight
+//     gradient: back from [co][kd][ci][9] to the parameter layout [co][ci][kd][9]);
+//   * BatchNorm3d / ReLU / 1x1x1 heads / latent ops are their 2-D kernels over the batch of D slices;
+//   * AvgPool3d(2, ceil_mode) (phiseg3D.py:101) and trilinear x2 (align_corners=True: phiseg3D.py:146,306,376) are the kernels
+//     below (trilinear = the 2-D bilinear kernel per slice, then linear interpolation along the depth).
+#include "uz_common.h"
+#include "split_f16.h"
+
+namespace {
+
+__global__ void absmax_copy_k(const float* src, float* dst) { uz::amax_publish_one(uz::amax_read(src), dst, 0u); }
+
+
+// ---- weight permutations (all tiny: <= 27 * 256 * 256 floats)
+// mode 0: out[co][kd][ci][9] = w[co][ci][kd][9]                    (forward, Cin' = 3 Cin)
+// mode 1: out[j][co][ci][9]  = w[co][ci][2 - j][9]                 (data gradient: rows (j, co) = 3 Cout "output" channels)
+// mode 2: dw[co][ci][kd][9]  = src[co][kd][ci][9]                  (weight gradient back to the parameter layout)
+__global__ __launch_bounds__(256) void w3d_permute_k(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int mode) {
+    const int n = Cout * Cin * 27;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const int t = e % 9, r = e / 9;
+        if (mode == 0) { const int ci = r % Cin, r2 = r / Cin, kd = r2 % 3, co = r2 / 3; dst[e] = src[((co * Cin + ci) * 3 + kd) * 9 + t]; }
+        else if (mode == 1) { const int ci = r % Cin, r2 = r / Cin, co = r2 % Cout, j = r2 / Cout; dst[e] = src[((co * Cin + ci) * 3 + (2 - j)) * 9 + t]; }
+        else { const int kd = r % 3, r2 = r / 3, ci = r2 % Cin, co = r2 / Cin; dst[e] = src[((co * 3 + kd) * Cin + ci) * 9 + t]; }
+    }
+}
+
+// ---- AvgPool3d(kernel 2, stride 2, ceil_mode): windows clipped at the far faces divide by the in-bounds count
+__global__ __launch_bounds__(256) void avgpool3d_fwd_k(const float* __restrict__ x, int CtotX, float* __restrict__ y, int CtotY,
+                                                        int C, int D, int H, int W, int Do, int Ho, int Wo) {
+    const int od = blockIdx.z, c = blockIdx.y, n = Ho * Wo;
+    const int d0 = 2 * od, d1 = min(d0 + 2, D);
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < n; q += gridDim.x * 256) {
+        const int oy = q / Wo, ox = q - oy * Wo, y0 = 2 * oy, x0 = 2 * ox, y1 = min(y0 + 2, H), x1 = min(x0 + 2, W);
+        float acc = 0.f;
+        for (int d = d0; d < d1; ++d)
+            for (int yy = y0; yy < y1; ++yy)
+                for (int xx = x0; xx < x1; ++xx) acc += x[((size_t)d * CtotX + c) * H * W + yy * W + xx];
+        y[((size_t)od * CtotY + c) * n + q] = acc / (float)((d1 - d0) * (y1 - y0) * (x1 - x0));
+    }
+}
+__global__ __launch_bounds__(256) void avgpool3d_bwd_k(const float* __restrict__ dy, int CtotDy, float* __restrict__ dx, int CtotDx,
+                                                        int C, int D, int H, int W, int Do, int Ho, int Wo, int accumulate) {
+    const int d = blockIdx.z, c = blockIdx.y, n = H * W, od = d >> 1;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < n; q += gridDim.x * 256) {
+        const int yy = q / W, xx = q - yy * W, oy = yy >> 1, ox = xx >> 1;
+        const int cnt = (min(2 * od + 2, D) - 2 * od) * (min(2 * oy + 2, H) - 2 * oy) * (min(2 * ox + 2, W) - 2 * ox);
+        const float v = dy[((size_t)od * CtotDy + c) * Ho * Wo + oy * Wo + ox] / (float)cnt;
+        float* dst = dx + ((size_t)d * CtotDx + c) * n + q;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
+// ---- depth stage of trilinear x2, align_corners=True: y[od] = (1 - t) x[d0] + t x[d0 + 1], source = od (D - 1) / (2 D - 1)
+__device__ __forceinline__ void depth_src(int od, int D, int& d0, int& dp, float& t) {
+    const float r = (2 * D > 1) ? (float)od * ((float)(D - 1) / (float)(2 * D - 1)) : 0.f;
+    d0 = (int)r;
+    if (d0 > D - 1) d0 = D - 1;
+    dp = d0 < D - 1 ? 1 : 0;
+    t = r - (float)d0;
+}
+__global__ __launch_bounds__(256) void depth_lerp_fwd_k(const float* __restrict__ x, int CtotX, float* __restrict__ y, int CtotY,
+                                                         int C, int D, int HW) {
+    const int od = blockIdx.z, c = blockIdx.y;
+    int d0, dp; float t;
+    depth_src(od, D, d0, dp, t);
+    const float* a = x + ((size_t)d0 * CtotX + c) * HW;
+    const float* b = x + ((size_t)(d0 + dp) * CtotX + c) * HW;
+    float* o = y + ((size_t)od * CtotY + c) * HW;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < HW; q += gridDim.x * 256) o[q] = (1.f - t) * a[q] + t * b[q];
+}
+__global__ __launch_bounds__(256) void depth_lerp_bwd_k(const float* __restrict__ dy, int CtotDy, float* __restrict__ dx, int CtotDx,
+                                                         int C, int D, int HW, int accumulate) {
+    const int d = blockIdx.z, c = blockIdx.y;
+    // output slices whose footprint touches d: od in a small window around 2 d (weights recomputed exactly as in the forward)
+    float w[6]; int ods[6], nw = 0;
+    for (int od = max(0, 2 * d - 2); od <= min(2 * D - 1, 2 * d + 3); ++od) {
+        int d0, dp; float t;
+        depth_src(od, D, d0, dp, t);
+        const float ww = (d0 == d ? 1.f - t : 0.f) + (d0 + dp == d ? t : 0.f);
+        if (ww != 0.f) { w[nw] = ww; ods[nw] = od; ++nw; }
+    }
+    float* o = dx + ((size_t)d * CtotDx + c) * HW;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < HW; q += gridDim.x * 256) {
+        float acc = 0.f;
+        for (int k = 0; k < nw; ++k) acc += w[k] * dy[((size_t)ods[k] * CtotDy + c) * HW + q];
+        o[q] = accumulate ? o[q] + acc : acc;
+    }
+}
+
+// ---- nearest resize of a volume by integer factors (fz, f, f): the 3-D counterpart of phiseg.py:321 (the reference's own
+// 3-D call, phiseg3D.py:398, passes a 2-element size to a 5-D tensor and raises; this is the evident intent)
+__global__ __launch_bounds__(256) void nearest3d_fwd_k(const float* __restrict__ x, int CtotX, float* __restrict__ y, int CtotY,
+                                                        int H, int W, int f, int fz) {
+    const int od = blockIdx.z, c = blockIdx.y, Ho = H * f, Wo = W * f, n = Ho * Wo;
+    const float* s = x + ((size_t)(od / fz) * CtotX + c) * H * W;
+    float* o = y + ((size_t)od * CtotY + c) * n;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < n; q += gridDim.x * 256) { const int oy = q / Wo, ox = q - oy * Wo; o[q] = s[(oy / f) * W + ox / f]; }
+}
+__global__ __launch_bounds__(256) void nearest3d_bwd_k(const float* __restrict__ dy, int CtotDy, float* __restrict__ dx, int CtotDx,
+                                                        int H, int W, int f, int fz, int accumulate) {
+    const int d = blockIdx.z, c = blockIdx.y, Ho = H * f, Wo = W * f, n = H * W;
+    float* o = dx + ((size_t)d * CtotDx + c) * n;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < n; q += gridDim.x * 256) {
+        const int yy = q / W, xx = q - yy * W;
+        float acc = 0.f;
+        for (int k = 0; k < fz; ++k)
+            for (int i = 0; i < f; ++i)
+                for (int j = 0; j < f; ++j) acc += dy[((size_t)(d * fz + k) * CtotDy + c) * Ho * Wo + (yy * f + i) * Wo + xx * f + j];
+        o[q] = accumulate ? o[q] + acc : acc;
+    }
+}
+
+inline int gx(int n) { int g = (n + 255) / 256; return g < 1 ? 1 : (g > 64 ? 64 : g); }
+
+}  // namespace
+
+extern "C" int uz_absmax_copy(const float* src_slot, float* dst_slot, void* stream) {
+    UZ_REQUIRE(src_slot && dst_slot, "absmax_copy: null slot");
+    hipLaunchKernelGGL(absmax_copy_k, dim3(1), dim3(1), 0, uz::S(stream), src_slot, dst_slot);
+    return uz::check_launch("absmax_copy_k");
+}
+extern "C" int uz_w3d_permute(const float* src, float* dst, int Cout, int Cin, int mode, void* stream) {
+    UZ_REQUIRE(src && dst && Cout > 0 && Cin > 0 && mode >= 0 && mode <= 2, "w3d_permute: bad arguments");
+    hipLaunchKernelGGL(w3d_permute_k, dim3(gx(Cout * Cin * 27)), dim3(256), 0, uz::S(stream), src, dst, Cout, Cin, mode);
+    return uz::check_launch("w3d_permute_k");
+}
+extern "C" int uz_avgpool3d_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int D, int H, int W, void* stream) {
+    UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && D <= 65535, "avgpool3d_fwd: bad sizes");
+    const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    hipLaunchKernelGGL(avgpool3d_fwd_k, dim3(gx(Ho * Wo), C, Do), dim3(256), 0, uz::S(stream), x, CtotX, y, CtotY, C, D, H, W, Do, Ho, Wo);
+    return uz::check_launch("avgpool3d_fwd_k");
+}
+extern "C" int uz_avgpool3d_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int D, int H, int W, int accumulate, void* stream) {
+    UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && D <= 65535, "avgpool3d_bwd: bad sizes");
+    const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    hipLaunchKernelGGL(avgpool3d_bwd_k, dim3(gx(H * W), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, C, D, H, W, Do, Ho, Wo, accumulate);
+    return uz::check_launch("avgpool3d_bwd_k");
+}
+extern "C" int uz_depth_lerp2x_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int D, int H, int W, void* stream) {
+    UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && 2 * D <= 65535, "depth_lerp2x_fwd: bad sizes");
+    hipLaunchKernelGGL(depth_lerp_fwd_k, dim3(gx(H * W), C, 2 * D), dim3(256), 0, uz::S(stream), x, CtotX, y, CtotY, C, D, H * W);
+    return uz::check_launch("depth_lerp_fwd_k");
+}
+extern "C" int uz_depth_lerp2x_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int D, int H, int W, int accumulate, void* stream) {
+    UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && D <= 65535, "depth_lerp2x_bwd: bad sizes");
+    hipLaunchKernelGGL(depth_lerp_bwd_k, dim3(gx(H * W), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, C, D, H * W, accumulate);
+    return uz::check_launch("depth_lerp_bwd_k");
+}
+extern "C" int uz_nearest3d_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int D, int H, int W, int f, int fz, void* stream) {
+    UZ_REQUIRE(C > 0 && D > 0 && f >= 1 && fz >= 1 && C <= 65535 && D * fz <= 65535, "nearest3d_fwd: bad sizes");
+    hipLaunchKernelGGL(nearest3d_fwd_k, dim3(gx(H * f * W * f), C, D * fz), dim3(256), 0, uz::S(stream), x, CtotX, y, CtotY, H, W, f, fz);
+    return uz::check_launch("nearest3d_fwd_k");
+}
+extern "C" int uz_nearest3d_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int D, int H, int W, int f, int fz, int accumulate, void* stream) {
+    UZ_REQUIRE(C > 0 && D > 0 && f >= 1 && fz >= 1 && C <= 65535 && D <= 65535, "nearest3d_bwd: bad sizes");
+    hipLaunchKernelGGL(nearest3d_bwd_k, dim3(gx(H * W), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, H, W, f, fz, accumulate);
+    return uz::check_launch("nearest3d_bwd_k");
+}

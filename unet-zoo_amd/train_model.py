@@ -95,7 +95,7 @@ def load_experiment(path):
     """Execute a reference-style experiment module (train_model.py:584) against the native package."""
     from . import models as native_models
     alias = {"models": native_models, "models.phiseg": native_models.phiseg, "models.unet": native_models.unet,
-             "models.probabilistic_unet": native_models.probabilistic_unet}
+             "models.probabilistic_unet": native_models.probabilistic_unet, "models.phiseg3D": native_models.phiseg3D}
     data_pkg, lidc_mod, utils_mod = types.ModuleType("data"), types.ModuleType("data.lidc_data"), types.ModuleType("utils")
     uzh_mod = types.ModuleType("data.uzh_prostate_data")            # private UZH prostate set: same loader surface, stand-in content
     lidc_mod.lidc_data = lidc_data
