@@ -26,7 +26,9 @@ def call(name, *args):
             conv.append(a.data_ptr())
         else:
             conv.append(a)
-    rc = getattr(L, name)(*conv, stream())
+    fn = getattr(L, name)
+    assert len(conv) + 1 == len(fn.argtypes), f"{name}: {len(conv) + 1} arguments for a {len(fn.argtypes)}-argument entry point"
+    rc = fn(*conv, stream())
     _ffi.check(rc, name)
     torch.cuda.synchronize()
 

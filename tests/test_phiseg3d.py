@@ -90,44 +90,44 @@ def test_avgpool3d_trilinear_nearest_vs_torch(C, D, H, W):
     Do, Ho, Wo = yr.shape[-3:]
     _, xv = _vol(x)
     ybuf = torch.zeros(Do + 2, C, Ho, Wo, device="cuda")
-    g.call("uz_avgpool3d_fwd", xv, C, C, ybuf[1:], C, C, D, H, W)
+    g.call("uz_avgpool3d_fwd", xv, C, C, ybuf[1:], C, D, H, W)
     assert g.maxabs(_unvol(ybuf[1:Do + 1]), yr[0]) <= 1e-6
     assert float(ybuf[0].abs().max()) == 0 and float(ybuf[Do + 1].abs().max()) == 0
     dy = g.rnd(*yr.shape[1:], seed=2)
     yr.backward(dy[None])
     _, dyv = _vol(dy)
     dx = torch.full((D, C, H, W), float("nan"), device="cuda")
-    g.call("uz_avgpool3d_bwd", dyv, C, C, dx, C, C, D, H, W, 0)
+    g.call("uz_avgpool3d_bwd", dyv, C, C, dx, C, D, H, W, 0)
     assert g.maxabs(_unvol(dx), xr.grad[0]) <= 1e-6
-    g.call("uz_avgpool3d_bwd", dyv, C, C, dx, C, C, D, H, W, 1)
+    g.call("uz_avgpool3d_bwd", dyv, C, C, dx, C, D, H, W, 1)
     assert g.maxabs(_unvol(dx), 2 * xr.grad[0]) <= 2e-6
     # trilinear x2, align_corners=True = the 2-D bilinear kernel per slice + the depth interpolation
     xr.grad = None
     tr = F.interpolate(xr, scale_factor=2, mode="trilinear", align_corners=True)
     mid = torch.zeros(D + 2, C, 2 * H, 2 * W, device="cuda")
-    g.call("uz_bilinear2x_fwd", xv, C, C, mid[1:], C, C, D, H, W, 1, None, None)
+    g.call("uz_bilinear2x_fwd", xv, C, C, mid[1:], C, D, H, W, 1, None, None)
     out = torch.zeros(2 * D + 2, C, 2 * H, 2 * W, device="cuda")
-    g.call("uz_depth_lerp2x_fwd", mid[1:], C, C, out[1:], C, C, D, 2 * H, 2 * W)
+    g.call("uz_depth_lerp2x_fwd", mid[1:], C, C, out[1:], C, D, 2 * H, 2 * W)
     assert g.maxabs(_unvol(out[1:2 * D + 1]), tr[0]) <= 2e-6
     dt = g.rnd(*tr.shape[1:], seed=3)
     tr.backward(dt[None])
     _, dtv = _vol(dt)
     dmid = torch.full((D, C, 2 * H, 2 * W), float("nan"), device="cuda")
-    g.call("uz_depth_lerp2x_bwd", dtv, C, C, dmid, C, C, D, 2 * H, 2 * W, 0)
+    g.call("uz_depth_lerp2x_bwd", dtv, C, C, dmid, C, D, 2 * H, 2 * W, 0)
     dx2 = torch.full((D, C, H, W), float("nan"), device="cuda")
-    g.call("uz_bilinear2x_bwd", dmid, C, C, dx2, C, C, D, H, W, 1, 0)
+    g.call("uz_bilinear2x_bwd", dmid, C, C, dx2, C, D, H, W, 1, 0)
     assert g.maxabs(_unvol(dx2), xr.grad[0]) <= 1e-5
     # nearest resize by integer factors
     xr.grad = None
     nr = F.interpolate(xr, size=[2 * D, 4 * H, 4 * W], mode="nearest")
     nout = torch.zeros(2 * D + 2, C, 4 * H, 4 * W, device="cuda")
-    g.call("uz_nearest3d_fwd", xv, C, C, nout[1:], C, C, D, H, W, 4, 2)
+    g.call("uz_nearest3d_fwd", xv, C, C, nout[1:], C, D, H, W, 4, 2)
     assert g.maxabs(_unvol(nout[1:2 * D + 1]), nr[0]) == 0
     dn = g.rnd(*nr.shape[1:], seed=4)
     nr.backward(dn[None])
     _, dnv = _vol(dn)
     dx3 = torch.full((D, C, H, W), float("nan"), device="cuda")
-    g.call("uz_nearest3d_bwd", dnv, C, C, dx3, C, C, D, H, W, 4, 2, 0)
+    g.call("uz_nearest3d_bwd", dnv, C, C, dx3, C, D, H, W, 4, 2, 0)
     assert g.maxabs(_unvol(dx3), xr.grad[0]) <= 1e-5
 
 

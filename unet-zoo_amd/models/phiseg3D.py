@@ -162,15 +162,15 @@ class PHISeg3D(NativeModel):
         cats, post_c, s_in = {}, [None] * L, [None] * L
         for k in range(L):
             lvl = L - 1 - k
+            final = None
+            if lvl < L - 1:                 # post_z[lvl] is concatenated with the up-sampled post_c[lvl + 1] (:381)
+                cats[lvl] = plan.vol(f"{root}.cat{lvl}", nf[lvl] + nf[lvl + 1 + diff], zs[k].N << diff, zs[k].H << diff, zs[k].W << diff)
+                final = cats[lvl].slice(0, nf[lvl])
             h = self._stack(plan, zs[k], [f"{root}.likelihood_ups_path.{k}.convolution.{j}" for j in range(2)], nf[lvl], 2,
-                            rev_prefix=f"{root}.likelihood_ups_path.{k}")
+                            out=final if diff == 0 else None, rev_prefix=f"{root}.likelihood_ups_path.{k}")
             for t in range(diff):
                 h = plan.trilinear(h, name=f"{root}.ups{k}.tri{t}")
-                out = None
-                if t == diff - 1 and lvl < L - 1:
-                    cats[lvl] = plan.vol(f"{root}.cat{lvl}", nf[lvl] + nf[lvl + 1 + diff], h.N, h.H, h.W)
-                    out = cats[lvl].slice(0, nf[lvl])
-                h = conv_unit(plan, h, f"{root}.likelihood_post_ups_path.{k}.{2 * t + 1}.convolution.0", out=out)
+                h = conv_unit(plan, h, f"{root}.likelihood_post_ups_path.{k}.{2 * t + 1}.convolution.0", out=final if t == diff - 1 else None)
             if lvl == L - 1:
                 post_c[lvl] = h
         for lvl in reversed(range(L - 1)):
