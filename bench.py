@@ -5,6 +5,7 @@ at 128x128, batch 32 per GPU, fp32 in / fp32 out, on N MI355X GPUs of one node.
     python bench.py --gpus 1 --steps 20 --warmup 5                      # PHiSeg 7/5 = BASELINE.json configs[3] (headline)
     python bench.py --model unet      ...                               # configs[1]: Unet(1,2,[32,64,128,192])
     python bench.py --model probunet  ...                               # configs[2]: ProbabilisticUnet latent 6 (+ 8-sample decode)
+    python bench.py --model phiseg3d  ...                               # configs[4]: PHISeg3D 5-level, 4x128x128x64, 1 volume per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -76,6 +77,22 @@ def conv_flops(op):
     return 2.0 * n * h * w * cin * cout * ks * ks
 
 
+def conv_bytes(op):
+    """Algorithmic HBM bytes of a convolution op: input + output tensor once, weights once."""
+    d = conv_dims(op)
+    if d is None:
+        return 0.0
+    kind, cin, cout, n, h, w, ks = d
+    win = op["i"][0] == 3 * op["i"][1]                       # depth window of a volume (3 C channels over a C-channel buffer): read once
+    if win and kind in (0, 2):
+        cin_t, cout_t = cin // 3, cout
+    elif win:
+        cin_t, cout_t = cin, cout // 3
+    else:
+        cin_t, cout_t = cin, cout
+    return 4.0 * (n * h * w * (cin_t + cout_t) + cin * cout * ks * ks)
+
+
 def conv_roof(op, L):
     """Peak TFLOP/s of the pipe the library routes this op to (uz_conv_route), or None for the streaming 1x1 heads."""
     kind, cin, cout, n, h, w, ks = conv_dims(op)
@@ -104,13 +121,28 @@ def op_bytes(op):
     if c in ("UZ_OP_NEAREST_FWD", "UZ_OP_NEAREST_BWD"):
         C, N, H, W, f = i[0], i[3], i[4], i[5], i[6]
         return f4 * C * N * H * W * (1 + f * f)
+    if c in ("UZ_OP_AVGPOOL3D_FWD", "UZ_OP_AVGPOOL3D_BWD"):
+        C, D, H, W = i[0], i[3], i[4], i[5]
+        return f4 * C * D * H * W * 1.125
+    if c in ("UZ_OP_DEPTH_LERP_FWD", "UZ_OP_DEPTH_LERP_BWD"):
+        C, D, H, W = i[0], i[3], i[4], i[5]
+        return f4 * C * D * H * W * 3
+    if c in ("UZ_OP_NEAREST3D_FWD", "UZ_OP_NEAREST3D_BWD"):
+        C, D, H, W, f, fz = i[0], i[3], i[4], i[5], i[6], i[7]
+        return f4 * C * D * H * W * (1 + f * f * fz)
+    if c == "UZ_OP_ADD_VIEWS":
+        C, N, H, W = i[3], i[4], i[5], i[6]
+        return f4 * C * N * H * W * (3 if i[1] else 2)
     return 0.0
 
 
 FAMILY = {"UZ_OP_CONV_FWD": "conv_fwd", "UZ_OP_CONV_BWD_DATA": "conv_dgrad", "UZ_OP_CONV_BWD_WEIGHT": "conv_wgrad",
           "UZ_OP_BN_RELU_FWD": "bn_relu_fwd", "UZ_OP_BN_RELU_BWD": "bn_relu_bwd", "UZ_OP_RELU_BWD": "relu_bwd",
           "UZ_OP_AVGPOOL_FWD": "resample", "UZ_OP_AVGPOOL_BWD": "resample", "UZ_OP_BILINEAR_FWD": "resample",
-          "UZ_OP_BILINEAR_BWD": "resample", "UZ_OP_NEAREST_FWD": "resample", "UZ_OP_NEAREST_BWD": "resample"}
+          "UZ_OP_BILINEAR_BWD": "resample", "UZ_OP_NEAREST_FWD": "resample", "UZ_OP_NEAREST_BWD": "resample",
+          "UZ_OP_AVGPOOL3D_FWD": "resample", "UZ_OP_AVGPOOL3D_BWD": "resample", "UZ_OP_DEPTH_LERP_FWD": "resample",
+          "UZ_OP_DEPTH_LERP_BWD": "resample", "UZ_OP_NEAREST3D_FWD": "resample", "UZ_OP_NEAREST3D_BWD": "resample",
+          "UZ_OP_ADD_VIEWS": "add_copy"}
 
 
 def binding_roof(plan, L):
@@ -262,6 +294,8 @@ def cpu_baseline(model, batch, budget_s=30.0):
     cores = usable_cores()
     threads = min(cores, 32)                  # oneDNN / OpenMP stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(threads)
+    if model == "phiseg3d":
+        return cpu_baseline_3d(threads, cores, budget_s)
     spec = {"phiseg": lambda: phiseg_spec(1, 2, FILTERS7), "unet": lambda: unet_spec(1, 2, FILTERS4),
             "probunet": lambda: probunet_spec(1, 2, FILTERS7, 6, 3)}[model]()
     sd = oracle.deterministic_state_dict(spec, seed=3)
@@ -306,7 +340,42 @@ def cpu_baseline(model, batch, budget_s=30.0):
                        f"fwd+loss+bwd+Adam, {threads} threads of {cores} usable cores, {sec:.2f} s/step")
 
 
-def build(model):
+def cpu_baseline_3d(threads, cores, budget_s):
+    """PHISeg3D on the host: the CPU oracle (oracle/refgraph3d.py) on ONE volume of the benchmark's architecture.  A full
+    128x128x64 volume costs ~13 TFLOP per step - minutes on host cores - so the bounded sample is a 64x64x32 volume (1/8 of the
+    voxels, identical network) and the value is scaled to full-volume equivalents by the voxel ratio."""
+    import torch
+    import oracle
+    from oracle import refgraph3d as R3
+    from unet_zoo_amd.models.phiseg3D import phiseg3d_spec
+    sd = oracle.deterministic_state_dict(phiseg3d_spec(4, 3, FILTERS3D, 5), seed=3)
+    leaves = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running_" not in k else v.clone()) for k, v in sd.items()}
+    dhw = tuple(n // 2 for n in DHW3D)
+    shapes = R3.phiseg3d_eps_shapes(*dhw, 5, 5)
+    x, onehot, lab, eps = R3.synthetic_volume(4, 3, dhw, 100, shapes + shapes)
+    times, t_start = [], time.perf_counter()
+    for step in range(3):
+        t0 = time.perf_counter()
+        out = R3.phiseg3d_forward(leaves, torch.from_numpy(x), torch.from_numpy(onehot), [torch.from_numpy(e) for e in eps])
+        total, _ = R3.phiseg3d_loss(out, torch.from_numpy(lab), num_classes=3)
+        for v in leaves.values():
+            v.grad = None
+        total.backward()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    sec = sum(timed) / len(timed)
+    return dict(value=round(0.125 / sec, 4), unit="volumes/s", cores=threads, kind="port",
+                sample=f"CPU oracle (functional torch fp32 restatement of models/phiseg3D.py), same network on a 64x64x32 volume (1/8 of the "
+                       f"voxels; value = 1/8 volume per {sec:.2f} s, i.e. scaled to 128x128x64 equivalents), {len(timed)} timed step(s)"
+                       f"{' after 1 warm-up' if len(times) > 1 else ''}, fwd+loss+bwd (no Adam), {threads} threads of {cores} usable cores")
+
+
+def build(model, reversible=False):
+    if model == "phiseg3d":
+        from unet_zoo_amd.models.phiseg3D import PHISeg3D
+        return PHISeg3D(4, 3, FILTERS3D, latent_levels=5, image_size=(4, *DHW3D), reversible=reversible)
     from unet_zoo_amd.models.phiseg import PHISeg
     from unet_zoo_amd.models.unet import Unet
     from unet_zoo_amd.models.probabilistic_unet import ProbabilisticUnet
@@ -322,7 +391,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling); default 32 (phiseg3d: 1 volume)")
+    ap.add_argument("--reversible", action="store_true", help="phiseg3d: reversible blocks (the reference's BraTS experiment sets use_reversible)")
     ap.add_argument("--model", choices=sorted(MODELS), default="phiseg")
     ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-family HIP-event pass")
@@ -337,11 +407,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    M = MODELS[args.model]
+    M = dict(MODELS[args.model])
+    vol = args.model == "phiseg3d"
+    if args.batch is None:
+        args.batch = 1 if vol else 32
+    if vol and args.batch != 1:
+        raise SystemExit("phiseg3d runs one volume per GPU and step (BASELINE configs[4]: batch 8 on 8 GPUs)")
 
     # the fp32-MFMA-only comparison leg runs in a child process BEFORE this process initialises the GPU
     f32_leg = None
-    if world == 1 and not args.no_f32_leg and conv_math() != "f32":
+    if world == 1 and not args.no_f32_leg and conv_math() != "f32" and not vol:
         f32_leg = fp32_only_leg(args)
 
     import torch
@@ -370,7 +445,7 @@ def main():
     L = _ffi.lib()
 
     torch.manual_seed(1234)          # same initial weights on every rank (DP replicas)
-    net = build(args.model)
+    net = build(args.model, args.reversible)
     net.train()
     if world > 1:
         dist.broadcast(net._ptab.pflat, src=0)
@@ -378,12 +453,18 @@ def main():
     if not args.no_graphs:
         net.enable_graphs(True)
     opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)        # train_model.py:49
-    x, mask, _ = synthetic_batch(args.batch, 128, 128, seed=20201004 + rank)
     dev = torch.device("cuda", local_rank)
-    x, mask = torch.from_numpy(x).to(dev), torch.from_numpy(mask).to(dev)
+    if vol:
+        from unet_zoo_amd.synthetic import synthetic_volume
+        x, onehot, mask = (torch.from_numpy(a).to(dev) for a in synthetic_volume(4, 3, DHW3D, seed=20201005 + rank))
+    else:
+        x, mask, _ = synthetic_batch(args.batch, 128, 128, seed=20201004 + rank)
+        x, mask = torch.from_numpy(x).to(dev), torch.from_numpy(mask).to(dev)
 
     def step():
-        if args.model == "unet":
+        if vol:
+            net.forward(x, onehot, training=True)
+        elif args.model == "unet":
             net.forward(x)
         else:
             net.forward(x, mask, training=True)
@@ -441,12 +522,16 @@ def main():
         per_gpu = ips / world
         achieved = per_gpu * M["gflop"] / 1e3
         plan = train_plan
+        if vol:                                              # work per volume from the plan's own ops
+            M["gflop"] = sum(conv_flops(o) for ops in (plan.fwd_ops, plan.bwd_ops) for o in ops) / 1e9
+            M["gb_img"] = sum(op_bytes(o) + conv_bytes(o) for ops in (plan.fwd_ops, plan.bwd_ops) for o in ops) / 1e9
+            M["gb_step"] = 28.0 * net._ptab.n_params / 1e9          # Adam: p, g, m, v read + p, m, v written
         eff_peak, share = binding_roof(plan, L)
         roof = dict(bound="mfma", achieved=round(achieved, 3), peak=round(eff_peak, 1), unit="TFLOP/s",
                     frac=round(achieved / eff_peak, 4), traffic=None,
                     frac_vs_fp32_mfma=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), flop_share_by_pipe=share,
                     hbm_fraction=round((per_gpu * M["gb_img"] + (per_gpu / args.batch) * M["gb_step"]) / HBM_PEAK_GBS, 4),
-                    note=f"step-level, per GPU: achieved = images/s x {M['gflop']} GFLOP/image (fp32-equivalent); peak = binding roof of the "
+                    note=f"step-level, per GPU: achieved = images/s x {M['gflop']:.2f} GFLOP/image (fp32-equivalent); peak = binding roof of the "
                          "conv ops as routed: 157.3 TFLOP/s (fp32 MFMA) or 2500/3 = 833.3 TFLOP/s (split-fp16, 3 fp16 products per fp32 "
                          "product), weighted by FLOPs (harmonic); frac_vs_fp32_mfma = achieved / 157.3 as BASELINE.md section 2 defines it; "
                          "hbm_fraction uses the unfused-graph bytes and cannot exceed ~0.21 in fp32")
@@ -472,7 +557,7 @@ def main():
                      "fp32 in / fp32 out, fp32 accumulate everywhere; 3x3 layers the library routes to the split path (forward, data gradient AND "
                      "weight gradient; share in roofline.flop_share_by_pipe): operands scaled by a power of two and split into 2 fp16 pieces, 3 piece "
                      "products on the fp16 matrix pipe (error vs fp64 no larger than the fp32-MFMA kernels', tests/test_full_configs_gpu.py); other layers: fp32 MFMA")
-        line = dict(metric=M["metric"], value=round(ips, 2), unit="images/s", n_gpus=world,
+        line = dict(metric=M["metric"], value=round(ips, 3 if vol else 2), unit=M.get("unit", "images/s"), n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload=M["workload"], batch_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f"dp{world}",

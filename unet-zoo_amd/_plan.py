@@ -362,6 +362,8 @@ class Plan:
         ctx = self.__dict__.get("_rev_ctx")
         if ctx is not None:
             xc = self._pool((ctx, "win" + ("F" if ".f_block." in wkey else "G")), x.C, x.H, x.W)
+            for b0 in (0, x.N + 1):                          # pooled scratch is shared between shapes: re-zero the depth padding
+                self._emit(self.target, "UZ_OP_MEMSET", p=[View(xc.buf, 0, x.C, b0, 1)], n=4 * x.C * x.H * x.W)
         else:
             xc = self.vol(wkey + ":win", x.C, x.N, x.H, x.W, requires_grad=False)
         self.add_views(x, None, xc)
@@ -430,9 +432,9 @@ class Plan:
             v = self.vec(nm, C) if vec else (self.vol(nm, C, D, H, W) if D else self.buf(nm, C, H, W))
             # all shapes of one (branch, role) share ONE region sized for the largest of them: a reversible sequence's scratch is
             # dead as soon as the next sequence of the branch starts (forward) or has been back-propagated (backward)
-            # (volumes: one region per shape - the two border slices of a volume must never be written, and regions shared by
-            # volumes of different slice sizes would put one shape's interior on another's border)
-            slot = slots.setdefault((key[:2], C, H, W) if (D and not vec) else key[:2], {"floats": 0, "off": None})
+            # (pooled volumes therefore have no guaranteed zero border slices: _window_input clears those of the one kind of
+            # pooled volume that is read through a depth window)
+            slot = slots.setdefault(key[:2], {"floats": 0, "off": None})
             slot["floats"] = max(slot["floats"], v.buf.numel)
             v.buf.alias = slot
             pool[k] = v
