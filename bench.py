@@ -54,7 +54,13 @@ MODELS = {
     "probunet": dict(gflop=40.74, gb_img=0.736, gb_step=0.565, metric="images/sec fwd+bwd ProbU-Net(latent 6) 128x128 bs32",
                      workload="Probabilistic U-Net, filters 32-64-128-192x4, latent_dim 6, no_convs_fcomb 3, 1x128x128, "
                               "fwd+loss+bwd+Adam (BASELINE configs[2]); 8 posterior-sample decodes timed separately"),
+    # BASELINE configs[4]: one 4x128x128x64 volume per GPU ("batch 8, 8 GPUs"); work per volume is taken from the plan's own
+    # convolution ops at run time (BASELINE.md has no row for it).  fp32 storage - the bf16-storage variant is the next step.
+    "phiseg3d": dict(gflop=None, gb_img=None, gb_step=None, metric="volumes/sec fwd+bwd PHiSeg3D-5 4x128x128x64, 1 volume per GPU", unit="volumes/s",
+                     workload="PHISeg3D 5 resolution / 5 latent levels, filters 32-64-128-192-192, 4 input channels, 3 labels, one 128x128x64 "
+                              "volume per GPU, fwd+loss+bwd+Adam (BASELINE configs[4], fp32 storage)"),
 }
+FILTERS3D, DHW3D = [32, 64, 128, 192, 192], (128, 128, 64)
 
 
 def conv_dims(op):
