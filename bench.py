@@ -36,6 +36,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")      # see unet-zoo_amd/__init__.py: must be in place before HIP initialises
+os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
 
 FILTERS7 = [32, 64, 128, 192, 192, 192, 192]
 FILTERS4 = [32, 64, 128, 192]
@@ -526,12 +527,12 @@ def main():
         ms = 1e3 * elapsed / args.steps
         ips = args.batch * world * args.steps / elapsed
         per_gpu = ips / world
-        achieved = per_gpu * M["gflop"] / 1e3
         plan = train_plan
         if vol:                                              # work per volume from the plan's own ops
             M["gflop"] = sum(conv_flops(o) for ops in (plan.fwd_ops, plan.bwd_ops) for o in ops) / 1e9
             M["gb_img"] = sum(op_bytes(o) + conv_bytes(o) for ops in (plan.fwd_ops, plan.bwd_ops) for o in ops) / 1e9
             M["gb_step"] = 28.0 * net._ptab.n_params / 1e9          # Adam: p, g, m, v read + p, m, v written
+        achieved = per_gpu * M["gflop"] / 1e3
         eff_peak, share = binding_roof(plan, L)
         roof = dict(bound="mfma", achieved=round(achieved, 3), peak=round(eff_peak, 1), unit="TFLOP/s",
                     frac=round(achieved / eff_peak, 4), traffic=None,

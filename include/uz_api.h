@@ -212,6 +212,8 @@ int uz_absmax(const float* x, size_t n, float* slot, void* stream);
 /* dst bound slot = max(dst, value of src bound slot): forwards a magnitude bound through ops that cannot raise it (pooling, interpolation) */
 int uz_absmax_copy(const float* src_slot, float* dst_slot, void* stream);
 int uz_scale(float* y, float alpha, size_t n, void* stream);                    /* y *= alpha   */
+int uz_zero_f32(float* p, size_t n, void* stream);                              /* p[0..n) = 0  (kernel launch, graph-capturable) */
+int uz_copy_f32(float* dst, const float* src, size_t n, void* stream);          /* dst = src    (kernel launch, graph-capturable) */
 /* sqrt(sum x^2) terms of utils.l2_regularisation (utils.py:93-101): one norm per tensor of a
  * table of (offset, count) pairs over the flat parameter buffer; out[i] = ||p_i||_2.       */
 int uz_l2_norms(const float* flat, const int64_t* offs_counts, int n_tensors, float* out, void* stream);

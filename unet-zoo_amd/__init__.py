@@ -15,3 +15,11 @@ import os as _os
 # queues give anything from 21.8 to 39 ms depending on stream creation order, 2 queues a stable 22.7.  The variable is read
 # when the HIP runtime initialises (first device call), so setting it at import time is early enough.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+# The runtime maps a graph's branches onto DEBUG_HIP_FORCE_GRAPH_QUEUES internal streams (default 4) but creates no more of
+# them than there are hardware queues: a graph whose DAG makes it reach for the third stream then crashes inside
+# hipGraphLaunch (hip::Graph::UpdateStreams, seen with the reversible PHISeg3D backward graph at 128x128x64; 4 + 2 costs
+# nothing on the PHiSeg graph, which happens to need two).  Keep the two numbers consistent: costs 1.8 % of the PHiSeg step.
+try:
+    _os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", str(max(1, min(4, int(_os.environ["GPU_MAX_HW_QUEUES"])))))
+except ValueError:
+    pass

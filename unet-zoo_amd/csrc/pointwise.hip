@@ -398,6 +398,24 @@ extern "C" int uz_axpy(float* y, const float* x, float alpha, size_t n, void* st
     hipLaunchKernelGGL(axpy_k, dim3(vgrid(n)), dim3(256), 0, uz::S(stream), y, x, alpha, n);
     return uz::check_launch("axpy_k");
 }
+// Zero-fill / copy as KERNEL launches: under stream capture they become kernel nodes like every other op of a tape (memset /
+// memcpy nodes inside multi-branch hipGraphs crashed hipGraphLaunch on ROCm 7.2 at some sizes).
+__global__ __launch_bounds__(256) void zero_k(float* __restrict__ p, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) p[e] = 0.f;
+}
+__global__ __launch_bounds__(256) void copy_k(float* __restrict__ d, const float* __restrict__ s, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) d[e] = s[e];
+}
+extern "C" int uz_zero_f32(float* p, size_t n, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(zero_k, dim3(vgrid(n)), dim3(256), 0, uz::S(stream), p, n);
+    return uz::check_launch("zero_k");
+}
+extern "C" int uz_copy_f32(float* dst, const float* src, size_t n, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(copy_k, dim3(vgrid(n)), dim3(256), 0, uz::S(stream), dst, src, n);
+    return uz::check_launch("copy_k");
+}
 extern "C" int uz_scale(float* y, float alpha, size_t n, void* stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(scale_k, dim3(vgrid(n)), dim3(256), 0, uz::S(stream), y, alpha, n);

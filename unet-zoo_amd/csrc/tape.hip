@@ -126,11 +126,9 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_L2_NORMS_BWD:
             return uz_l2_norms_bwd(CFP(0), static_cast<const int64_t*>(p[1]), i[0], CFP(2), CFP(3), FP(4), st);
         case UZ_OP_MEMSET:
-            if (hipMemsetAsync(p[0], 0, (size_t)o.n, uz::S(st)) != hipSuccess) return uz::fail("memset failed");
-            return 0;
+            return uz_zero_f32(FP(0), (size_t)o.n / 4, st);               /* n = bytes, always whole floats */
         case UZ_OP_COPY:
-            if (hipMemcpyAsync(p[0], p[1], (size_t)o.n, hipMemcpyDeviceToDevice, uz::S(st)) != hipSuccess) return uz::fail("copy failed");
-            return 0;
+            return uz_copy_f32(FP(0), CFP(1), (size_t)o.n / 4, st);
         case UZ_OP_BCAST_CHANNELS:
             return uz_bcast_channels_fwd(CFP(0), i[0], FP(1), i[1], i[2], i[3], i[4], st);
         case UZ_OP_BCAST_CHANNELS_BWD:
