@@ -35,8 +35,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")      # see unet-zoo_amd/__init__.py: must be in place before HIP initialises
-os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")      # see unet-zoo_amd/__init__.py: must be in place before HIP initialises
+os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", os.environ["GPU_MAX_HW_QUEUES"] if os.environ["GPU_MAX_HW_QUEUES"] in ("1", "2", "3", "4") else "4")
 
 FILTERS7 = [32, 64, 128, 192, 192, 192, 192]
 FILTERS4 = [32, 64, 128, 192]

@@ -6,6 +6,7 @@ the last all-reduce.  Checks: parameters after 8 steps are BIT-IDENTICAL to a ru
 data), with overlap on and off; prints the step time of both and the exposed all-reduce time."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import unet_zoo_amd  # noqa: F401  (first: it sets the HIP queue environment, which must precede HIP initialisation)
 import torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 torch.cuda.set_device(0)

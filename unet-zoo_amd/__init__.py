@@ -14,11 +14,13 @@ import os as _os
 # GPU_MAX_HW_QUEUES = 2: 21.99 ms, 3: 22.02, 4 (the default): 22.42, 8: 35.2; with the overlapped data-parallel exchange 4
 # queues give anything from 21.8 to 39 ms depending on stream creation order, 2 queues a stable 22.7.  The variable is read
 # when the HIP runtime initialises (first device call), so setting it at import time is early enough.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 # The runtime maps a graph's branches onto DEBUG_HIP_FORCE_GRAPH_QUEUES internal streams (default 4) but creates no more of
 # them than there are hardware queues: a graph whose DAG makes it reach for the third stream then crashes inside
 # hipGraphLaunch (hip::Graph::UpdateStreams, seen with the reversible PHISeg3D backward graph at 128x128x64; 4 + 2 costs
-# nothing on the PHiSeg graph, which happens to need two).  Keep the two numbers consistent: costs 1.8 % of the PHiSeg step.
+# nothing on the PHiSeg graph, which happens to need two).  Keep the two numbers consistent.  Measured pairs (hw queues, graph
+# streams), PHiSeg step / with the overlapped data-parallel exchange: (2,2) 20.8 / 21.4 ms, (3,3) 20.2 / 21.1, (4,4) 20.7 / 34.8,
+# (2,4) 20.2 / 21.4 but unsafe -> 3 and 3.
 try:
     _os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", str(max(1, min(4, int(_os.environ["GPU_MAX_HW_QUEUES"])))))
 except ValueError:
