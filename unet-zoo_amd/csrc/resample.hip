@@ -135,46 +135,103 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const RsP p) {   // src = 
     }
 }
 
-// Banded variant for planes up to 128 high-res columns: a workgroup stages the (2 * LB + 6) high-res rows that
-// LB low-res rows can touch in LDS with coalesced float4 reads (each dy element is read from HBM ~1.2 times
-// instead of being gathered ~5 times through the vector L1) and gathers from there with the same weights.
-constexpr int LB = 16, BWMAX = 128;
-__global__ __launch_bounds__(256) void bilinear_bwd_banded_k(const RsP p) {   // src = dy (high res), dst = dx (low res)
-    __shared__ float wyT[LB * 7], wxT[BTAB * 7];
-    __shared__ __attribute__((aligned(16))) float tile[(2 * LB + 6) * BWMAX];
+// Band kernels for planes whose rows fit LDS (the layers that carry the traffic).  Bilinear interpolation is separable,
+// Y = Ry X Rx^T, hence dX = Ry^T dY Rx: a workgroup stages the high-res rows that LB low-res rows can touch (coalesced
+// float4 reads, each dY element leaves HBM ~1.2 times), reduces them along x into LDS and then along y - 2 x KT
+// multiply-adds per output instead of a KT x KT gather.  Low-res index i only receives from high-res 2i-1 .. 2i+2 (both
+// align_corners modes, any size - enumerated); the tap tables cover 2i-2 .. 2i+3 and hold exactly the forward's weights.
+constexpr int LB = 16, BWMAX = 128, KT = 6, BROWS = 2 * LB + KT - 2;
+__global__ __launch_bounds__(256) void bilinear_bwd_sep_k(const RsP p) {   // src = dy (high res), dst = dx (low res)
+    __shared__ float wyT[LB * KT];
+    __shared__ float tx[BROWS * (BWMAX / 2)];                               // dY reduced along x
     const int c = blockIdx.y, b = blockIdx.z, iy0 = blockIdx.x * LB;
     const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
     float* d = p.dst + ((size_t)b * p.CtotD + c) * p.H * p.W;
     const int nrow = min(LB, p.H - iy0);
-    const int r0 = max(0, 2 * iy0 - 2), r1 = min(p.Ho, 2 * (iy0 + nrow - 1) + 5);     // high-res rows [r0, r1)
-    for (int e = threadIdx.x; e < (nrow + p.W) * 7; e += 256) {
-        if (e < nrow * 7) { const int i = e / 7, k = e - i * 7; wyT[e] = tap_weight(2 * (iy0 + i) - 2 + k, p.Ho, p.sh, p.ac, p.H, iy0 + i); }
-        else { const int e2 = e - nrow * 7, i = e2 / 7, k = e2 - i * 7; wxT[e2] = tap_weight(2 * i - 2 + k, p.Wo, p.sw, p.ac, p.W, i); }
+    const int ob = 2 * iy0 - 2;                              // high-res row of band row 0
+    const int nb = 2 * nrow + KT - 2;                        // band rows in use
+    for (int e = threadIdx.x; e < nrow * KT; e += 256) {
+        const int i = e / KT, k = e - i * KT;
+        wyT[e] = tap_weight(2 * (iy0 + i) - 2 + k, p.Ho, p.sh, p.ac, p.H, iy0 + i);
     }
-    const int nvec = (r1 - r0) * p.Wo / 4;                  // Wo % 4 == 0 checked by the host
-    const float4* s4 = reinterpret_cast<const float4*>(s + (size_t)r0 * p.Wo);
-    for (int e = threadIdx.x; e < nvec; e += 256) reinterpret_cast<float4*>(tile)[e] = s4[e];
+    // x pass straight from HBM: the KT taps of low-res column ix are the three aligned float2 at high-res columns 2 ix - 2 ..
+    // 2 ix + 3 (a pair is entirely inside or outside the row because Wo is even); consecutive lanes read consecutive pairs,
+    // so each of the three loads of a wave is one contiguous 512-byte run and the overlap is served by the vector L1
+    // (host guarantees 256 % W == 0: a thread keeps one column, its KT weights live in registers)
+    {
+        const int ix = threadIdx.x % p.W, rstep = 256 / p.W;
+        float wx[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) wx[k] = tap_weight(2 * ix - 2 + k, p.Wo, p.sw, p.ac, p.W, ix);
+        const bool v0 = ix > 0, v2 = 2 * ix + 3 < p.Wo;          // first / last pair inside the row (the middle one always is)
+#pragma unroll 4
+        for (int r = threadIdx.x / p.W; r < nb; r += rstep) {
+            const int oy = ob + r;
+            float acc = 0.f;
+            if (oy >= 0 && oy < p.Ho) {
+                const float2* row = reinterpret_cast<const float2*>(s + (size_t)oy * p.Wo + 2 * ix - 2);
+                const float2 a = v0 ? row[0] : make_float2(0.f, 0.f), m = row[1], z = v2 ? row[2] : make_float2(0.f, 0.f);
+                acc = wx[0] * a.x + wx[1] * a.y + wx[2] * m.x + wx[3] * m.y + wx[4] * z.x + wx[5] * z.y;
+            }
+            tx[r * p.W + ix] = acc;
+        }
+    }
     __syncthreads();
     for (int q = threadIdx.x; q < nrow * p.W; q += 256) {
-        const int il = q / p.W, ix = q - il * p.W, iy = iy0 + il;
-        const int oy0 = 2 * iy - 2, ox0 = 2 * ix - 2;
+        const int il = q / p.W, ix = q - il * p.W;
+        const float* col = tx + (2 * il) * p.W + ix;
+        const float* wy = wyT + il * KT;
         float acc = 0.f;
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            const float wy = wyT[il * 7 + ky];
-            if (wy != 0.f) {                                 // zero weight <=> row outside [0, Ho) or outside the footprint
-                const float* row = tile + (oy0 + ky - r0) * p.Wo + ox0;
-                float ra = 0.f;
-#pragma unroll
-                for (int kx = 0; kx < 7; ++kx) {
-                    const float wx = wxT[ix * 7 + kx];
-                    if (wx != 0.f) ra += wx * row[kx];
-                }
-                acc += wy * ra;
-            }
-        }
-        float* dst = d + (size_t)iy * p.W + ix;
+        for (int k = 0; k < KT; ++k) acc += wy[k] * col[k * p.W];
+        float* dst = d + (size_t)(iy0 + il) * p.W + ix;
         *dst = p.accumulate ? *dst + acc : acc;
+    }
+}
+
+// Forward: a workgroup produces OB output rows of one plane from the <= OB / 2 + 2 source rows they touch (staged in LDS by
+// float4), four consecutive outputs per thread and one float4 store each; same expression as bilinear_fwd_k.
+constexpr int OB = 32, FWMAX = 128, FROWS = OB / 2 + 3;
+__global__ __launch_bounds__(256) void bilinear_fwd_band_k(const RsP p) {
+    __shared__ __attribute__((aligned(16))) float srow[FROWS * FWMAX];
+    __shared__ int xi[2 * FWMAX];
+    __shared__ float xl[2 * FWMAX];
+    forward_bound(p);
+    const int c = blockIdx.y, b = blockIdx.z, oy0 = blockIdx.x * OB;
+    const float* s = p.src + ((size_t)b * p.CtotS + c) * p.H * p.W;
+    float* d = p.dst + ((size_t)b * p.CtotD + c) * p.Ho * p.Wo;
+    const int nout = min(OB, p.Ho - oy0);
+    int first, last, ip; float l0, l1;
+    src_index(oy0, p.sh, p.ac, p.H, first, ip, l0, l1);
+    src_index(oy0 + nout - 1, p.sh, p.ac, p.H, last, ip, l0, l1);
+    last += ip;
+    for (int e = threadIdx.x; e < p.Wo; e += 256) {
+        int i0, jp; float a0, a1;
+        src_index(e, p.sw, p.ac, p.W, i0, jp, a0, a1);
+        xi[e] = i0 | (jp << 16);
+        xl[e] = a1;
+    }
+    const int w4 = p.W / 4;
+    for (int e = threadIdx.x; e < (last - first + 1) * w4; e += 256) {
+        const int r = e / w4, q = e - r * w4;
+        *reinterpret_cast<float4*>(srow + r * p.W + 4 * q) = *reinterpret_cast<const float4*>(s + (size_t)(first + r) * p.W + 4 * q);
+    }
+    __syncthreads();
+    const int o4 = p.Wo / 4;
+    for (int e = threadIdx.x; e < nout * o4; e += 256) {
+        const int r = e / o4, q = e - r * o4, oy = oy0 + r;
+        int h1, hp; float h0l, h1l;
+        src_index(oy, p.sh, p.ac, p.H, h1, hp, h0l, h1l);
+        const float* r0 = srow + (h1 - first) * p.W;
+        const float* r1 = r0 + hp * p.W;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ox = 4 * q + j, w1 = xi[ox] & 0xFFFF, wp = xi[ox] >> 16;
+            const float w1l = xl[ox], w0l = 1.f - w1l;
+            v[j] = h0l * (w0l * r0[w1] + w1l * r0[w1 + wp]) + h1l * (w0l * r1[w1] + w1l * r1[w1 + wp]);
+        }
+        *reinterpret_cast<float4*>(d + (size_t)oy * p.Wo + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -272,16 +329,21 @@ extern "C" int uz_bilinear2x_fwd(const float* x, int C, int CtotX, float* y, int
     if (int rc = check_dims("bilinear2x_fwd", C, N, H, W)) return rc;
     RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N; p.x_amax = x_amax; p.y_amax = y_amax;
     p.H = H; p.W = W; p.Ho = 2 * H; p.Wo = 2 * W; p.ac = align_corners; bil_scales(p);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (W % 4 == 0 && W <= FWMAX && H >= 4 && al16(x) && al16(y)) {     // W % 4 == 0 keeps every (image, channel) plane of both sides float4-aligned
+        hipLaunchKernelGGL(bilinear_fwd_band_k, dim3(uz::ceil_div(p.Ho, OB), C, N), dim3(256), 0, uz::S(stream), p);
+        return uz::check_launch("bilinear_fwd_band_k");
+    }
     RS_LAUNCH(bilinear_fwd_k, p.Ho * p.Wo);
 }
 extern "C" int uz_bilinear2x_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int align_corners, int accumulate, void* stream) {
     if (int rc = check_dims("bilinear2x_bwd", C, N, H, W)) return rc;
     RsP p = {}; p.src = dy; p.dst = dx; p.C = C; p.CtotS = CtotDy; p.CtotD = CtotDx; p.N = N;
     p.H = H; p.W = W; p.Ho = 2 * H; p.Wo = 2 * W; p.ac = align_corners; p.accumulate = accumulate; bil_scales(p);
-    if (p.Wo <= BWMAX && p.W <= BTAB && p.H >= 8 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (p.Ho * p.Wo) % 4 == 0) {
-        // (Ho * Wo) % 4 == 0 and a 16-byte aligned view keep every (image, channel) plane float4-aligned
-        hipLaunchKernelGGL(bilinear_bwd_banded_k, dim3(uz::ceil_div(H, LB), C, N), dim3(256), 0, uz::S(stream), p);
-        return uz::check_launch("bilinear_bwd_banded_k");
+    if (p.Wo <= BWMAX && p.H >= 4 && 256 % p.W == 0 && (reinterpret_cast<uintptr_t>(dy) & 7) == 0) {
+        // Wo is even: an 8-byte aligned view keeps every float2 of every row aligned
+        hipLaunchKernelGGL(bilinear_bwd_sep_k, dim3(uz::ceil_div(H, LB), C, N), dim3(256), 0, uz::S(stream), p);
+        return uz::check_launch("bilinear_bwd_sep_k");
     }
     RS_LAUNCH(bilinear_bwd_k, H * W);
 }
