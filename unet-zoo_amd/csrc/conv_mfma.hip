@@ -330,9 +330,22 @@ int launch_ks(const ConvP& p, int msub, int jmax, int grid, size_t smem, hipStre
 
 namespace uz {
 
+// ordered sum of the split-K slabs [ksplit][N][Mc][HW] into the output view (+ bias, accumulate, ReLU, magnitude bound)
+int splitk_reduce(const float* slab, int ksplit, const float* bias, float* y, int Mc, int McTot, int N, int HW, int relu, int accumulate,
+                  float* y_amax, hipStream_t st) {
+    const size_t n = (size_t)N * Mc * HW;
+    UZ_REQUIRE(n < (1ull << 31), "conv: split-K slab too large");
+    const bool v4 = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0;
+    int rgrid = (int)((n / (v4 ? 4 : 1) + 255) / 256);
+    if (rgrid > 2048) rgrid = 2048;
+    if (v4) hipLaunchKernelGGL(conv_splitk_reduce<4>, dim3(rgrid), dim3(256), 0, st, slab, ksplit, bias, y, Mc, McTot, N, HW, relu, accumulate, y_amax);
+    else hipLaunchKernelGGL(conv_splitk_reduce<1>, dim3(rgrid), dim3(256), 0, st, slab, ksplit, bias, y, Mc, McTot, N, HW, relu, accumulate, y_amax);
+    return check_launch("conv_splitk_reduce");
+}
+
 // x: input view (Kc channels), y: output view (Mc channels); w = PyTorch [Cout][Cin][ks][ks] parameter.
 size_t conv_workspace(int Kc, int Mc, int N, int H, int W, int ks) {
-    if (conv_split_ok(Kc, Mc, N, H, W, ks)) return conv_split_workspace(Kc, Mc, W);
+    if (conv_split_ok(Kc, Mc, N, H, W, ks)) return conv_split_workspace(Kc, Mc, N, H, W);
     const Geom g = pick_geom(N, H, W, ks / 2);
     const int cot = Mc <= 32 ? 32 : 64;
     int ksplit, cps;
@@ -349,7 +362,7 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Kc > 0 && Mc > 0, "conv: empty tensor");
     UZ_REQUIRE(H <= 4096 && W <= 4096, "conv: spatial size too large");
     // large 3x3 layers: split-bf16 matrix pipe (conv_split.hip); its packed weight image lives in the workspace
-    if (conv_split_ok(Kc, Mc, N, H, W, ks) && workspace && workspace_bytes >= conv_split_workspace(Kc, Mc, W))
+    if (conv_split_ok(Kc, Mc, N, H, W, ks) && workspace && workspace_bytes >= conv_split_workspace(Kc, Mc, N, H, W))
         return conv_split(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, dgrad, relu, accumulate, x_amax, w_amax, y_amax, workspace, st);
     const Geom g = pick_geom(N, H, W, ks / 2);
     ConvP p;
@@ -378,14 +391,7 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     if (ks == 3) rc = dgrad ? launch_ks<3, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<3, false>(p, msub, jmax, (int)grid, smem, st);
     else rc = dgrad ? launch_ks<1, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<1, false>(p, msub, jmax, (int)grid, smem, st);
     if (rc || p.ksplit == 1) return rc;
-    const size_t n = (size_t)N * Mc * H * W;
-    UZ_REQUIRE(n < (1ull << 31), "conv: split-K slab too large");
-    const bool v4 = (H * W) % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.slab) & 15) == 0;
-    int rgrid = (int)((n / (v4 ? 4 : 1) + 255) / 256);
-    if (rgrid > 2048) rgrid = 2048;
-    if (v4) hipLaunchKernelGGL(conv_splitk_reduce<4>, dim3(rgrid), dim3(256), 0, st, p.slab, p.ksplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax);
-    else hipLaunchKernelGGL(conv_splitk_reduce<1>, dim3(rgrid), dim3(256), 0, st, p.slab, p.ksplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax);
-    return check_launch("conv_splitk_reduce");
+    return splitk_reduce(p.slab, p.ksplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax, st);
 }
 
 }  // namespace uz

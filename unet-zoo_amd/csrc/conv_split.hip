@@ -46,6 +46,8 @@ struct SP {
     int relu, accumulate;
     const float* x_amax; const float* w_amax;     // device scalars: upper bounds of |x| and |w| (never null here)
     float* y_amax;                                // nullable: atomic max of |y| (bound for the next layer's split)
+    int kSplit, cps;                              // split-K: the chunk loop is shared out over kSplit workgroups, cps chunks each
+    float* slab;                                  // [kSplit][N][Cout][HW] partial sums (kSplit > 1), summed in order by splitk_reduce
 };
 
 
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 }
 
 template <int MSUB, int NTv, int TWv>
-__global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
+__global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void conv_split_kernel(const SP p) {
     using GEO = Geo<NTv, TWv>;
     constexpr int NT = GEO::NT, TW = GEO::TW, PW = GEO::PW, PSI = GEO::PSI, PSR = GEO::PSR, G = GEO::G, CE = GEO::CE;
     constexpr int COT = 32 * MSUB;
@@ -102,7 +104,9 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);
+    const int wid0 = uz::xcd_remap(blockIdx.x, gridDim.x);
+    const int part = wid0 % p.kSplit, wid = wid0 / p.kSplit;     // the parts of one tile are neighbours: they share the patch in L2
+    const int cbeg = part * p.cps, cend = min(p.nChunks, cbeg + p.cps);
     const int coT = wid % p.nCoTiles, pixT = wid / p.nCoTiles;
     const int txi = pixT % p.tilesX, t2 = pixT / p.tilesX;
     const int tyi = t2 % p.tilesY, b0 = t2 / p.tilesY;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
     const float xs = uz::split_scale(uz::amax_read(p.x_amax));
 
     // ---- per-lane output pixels (B operand columns)
-    int poff[NSUB], oidx[NSUB];
+    int poff[NSUB], oidx[NSUB], sidx[NSUB];
 #pragma unroll
     for (int n = 0; n < NSUB; ++n) {
         const int pp = wave * (32 * NSUB) + n * 32 + l31;          // pixel index inside the tile
@@ -142,6 +146,7 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
         const bool v = (y0 + ty) < p.H && (x0 + tx) < p.W;
         poff[n] = (ty * PW + tx) * 16 + h * (PPLANE / 2);           // byte offset of this lane's fragment for tap (0, 0)
         oidx[n] = v ? (b0 * p.CoutTot * p.HW + (y0 + ty) * p.W + (x0 + tx)) : -1;
+        sidx[n] = v ? (b0 * p.Cout * p.HW + (y0 + ty) * p.W + (x0 + tx)) : -1;
     }
 
     f32x16 acc[MSUB][NSUB];
@@ -220,10 +225,10 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
             if (tid + i * NT < WVEC) *reinterpret_cast<u32x4*>(Wl + 16 * (tid + i * NT)) = wq[i];
     };
 
-    const int nChunks = p.nChunks;
+    const int nChunks = cend;
 #pragma unroll
-    for (int tap = 0; tap < KK; ++tap) stage(0, tap);
-    for (int c = 0; c < nChunks; ++c) {
+    for (int tap = 0; tap < KK; ++tap) stage(cbeg, tap);
+    for (int c = cbeg; c < nChunks; ++c) {
         __syncthreads();                       // every wave has finished the MFMAs of the previous chunk
         lstore();
         __syncthreads();
@@ -260,6 +265,20 @@ __global__ __launch_bounds__(NTv) void conv_split_kernel(const SP p) {
 
     // ---- epilogue: undo the operand scales (exact), bias, optional accumulate / ReLU, coalesced NCHW stores
     const float inv_x = uz::split_inv_scale(uz::amax_read(p.x_amax)), inv_w = uz::split_inv_scale(uz::amax_read(p.w_amax));
+    if (p.kSplit > 1) {                           // partial sums only: bias / accumulate / ReLU / bound happen in the reduce
+        float* sl = p.slab + (size_t)part * p.N * p.Cout * p.HW;
+#pragma unroll
+        for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Cout)
+#pragma unroll
+                    for (int n = 0; n < NSUB; ++n)
+                        if (sidx[n] >= 0) sl[(size_t)sidx[n] + (size_t)co * p.HW] = acc[m][n][r] * inv_x * inv_w;
+            }
+        return;
+    }
     float vmax = 0.f;
 #pragma unroll
     for (int m = 0; m < MSUB; ++m) {
@@ -303,7 +322,13 @@ int launch(const SP& p, int grid, hipStream_t st) {
 // else 16 x 16 tiles (256 threads, 32-channel tiles)
 inline bool small_geo(int W) { return W <= 32; }       // measured: 16 x 16 tiles win or tie on 32 x 32 planes (128 -> 128: 91 -> 67 us), lose on 64 x 64
 inline int tile_w(int W) { return small_geo(W) ? 16 : 32; }
-inline int tile_cot(int Mc, int W) { return (small_geo(W) || Mc <= 32) ? 32 : 64; }
+// 16 x 16 tiles with 32 output channels read one LDS fragment per MFMA (LDS-read bound); with 64 channels 1.5 MFMAs per
+// fragment, at half the number of workgroups.  UZ_SMALL_COT=64 (experiment) selects the latter for layers with >= 64 channels.
+inline int small_cot() { static const int v = [] { const char* e = getenv("UZ_SMALL_COT"); return e ? atoi(e) : 32; }(); return v; }
+inline int tile_cot(int Mc, int W) {
+    if (small_geo(W)) return (small_cot() == 64 && Mc >= 64) ? 64 : 32;
+    return Mc <= 32 ? 32 : 64;
+}
 
 }  // namespace
 
@@ -331,9 +356,30 @@ bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks) {
 
 // workspace = [two fallback bound slots (x, w)] [packed weight image of one direction]
 constexpr size_t WS_HEAD = 2 * AMAX_FLOATS * sizeof(float);
-size_t conv_split_workspace(int Kc, int Mc, int W) {
+namespace {
+// Split-K for 16 x 16-tile layers that leave most CUs with one workgroup (16 x 16 planes at batch 32: 192 / 256 tiles): the
+// chunk loop is shared out over up to 4 workgroups (>= 3 chunks each, ~3 workgroups per CU) - the kernel is latency bound
+// there, more resident waves are what it lacks - and the partial sums are added in order by splitk_reduce.
+int split_parts(int Kc, int Mc, int N, int H, int W) {
+    static const int mode = [] { const char* e = getenv("UZ_SPLIT_KSPLIT"); return e ? atoi(e) : -1; }();    // experiment: 1 = off
+    if (!small_geo(W) || mode == 1) return 1;
+    const int cot = tile_cot(Mc, W), nChunks = ceil_div(Kc, CK);
+    const long long g = (long long)N * ceil_div(H, TH) * ceil_div(W, 16) * ceil_div(Mc, cot);
+    if (g >= 384) return 1;
+    int S = (int)((768 + g / 2) / g);
+    S = S > 4 ? 4 : S;
+    if (S > nChunks / 3) S = nChunks / 3;
+    return S < 1 ? 1 : S;
+}
+size_t image_bytes(int Kc, int Mc, int W) {
     const int cot = tile_cot(Mc, W);
-    return WS_HEAD + (size_t)ceil_div(Kc, CK) * ceil_div(Mc, cot) * NP * (KK * cot * CK * 2);
+    const size_t b = (size_t)ceil_div(Kc, CK) * ceil_div(Mc, cot) * NP * (KK * cot * CK * 2);
+    return (b + 255) / 256 * 256;
+}
+}  // namespace
+size_t conv_split_workspace(int Kc, int Mc, int N, int H, int W) {
+    const int S = split_parts(Kc, Mc, N, H, W);
+    return WS_HEAD + image_bytes(Kc, Mc, W) + (S > 1 ? (size_t)S * N * Mc * H * W * sizeof(float) : 0);
 }
 
 namespace {
@@ -391,15 +437,22 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     p.relu = relu; p.accumulate = accumulate;
     p.nCoTiles = ceil_div(Mc, cot);
     p.nChunks = ceil_div(Kc, CK);
-    const long long grid = (long long)p.tilesX * p.tilesY * N * p.nCoTiles;
+    p.kSplit = split_parts(Kc, Mc, N, H, W);
+    p.cps = ceil_div(p.nChunks, p.kSplit);
+    p.kSplit = ceil_div(p.nChunks, p.cps);               // no empty parts
+    p.slab = reinterpret_cast<float*>(image + image_bytes(Kc, Mc, W));
+    const long long grid = (long long)p.tilesX * p.tilesY * N * p.nCoTiles * p.kSplit;
     UZ_REQUIRE(grid < (1ll << 31), "conv_split: grid too large");
     UZ_REQUIRE((size_t)Kc * p.HW * 4 < (1ull << 32) && (size_t)McTot * p.HW * N < (1ull << 31), "conv_split: tensor too large for 32-bit offsets");
     const int rows = p.nChunks * p.nCoTiles * KK * cot;
     if (dgrad) hipLaunchKernelGGL(pack_weights_kernel<true>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
     else hipLaunchKernelGGL(pack_weights_kernel<false>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
     if (int rc = check_launch("pack_weights_kernel")) return rc;
-    if (tw == 16) return launch<1, 256, 16>(p, (int)grid, st);
-    return cot == 32 ? launch<1, 512, 32>(p, (int)grid, st) : launch<2, 512, 32>(p, (int)grid, st);
+    int rc;
+    if (tw == 16) rc = cot == 32 ? launch<1, 256, 16>(p, (int)grid, st) : launch<2, 256, 16>(p, (int)grid, st);
+    else rc = cot == 32 ? launch<1, 512, 32>(p, (int)grid, st) : launch<2, 512, 32>(p, (int)grid, st);
+    if (rc || p.kSplit == 1) return rc;
+    return splitk_reduce(p.slab, p.kSplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax, st);
 }
 
 }  // namespace uz
