@@ -45,6 +45,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA peak
 SPLIT_PRODUCTS = 3                # fp16 piece products per fp32 product in conv_split.hip / conv_wgrad_split.hip (split_f16.h)
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / SPLIT_PRODUCTS
 HBM_PEAK_GBS = 8000.0
+LARGE_OP_BYTES = 32e6
 
 # algorithmic work per image (fwd+bwd), unfused tensor bytes per image, fixed bytes per step
 MODELS = {
@@ -195,11 +196,15 @@ def profile_families(net, plan, L, reps=3):
                 e1.synchronize()
                 ms = e0.elapsed_time(e1)
                 best = ms if best is None else min(best, ms)
-            d = fam.setdefault(name, dict(ms=0.0, flops=0.0, t_roof=0.0, bytes=0.0, launches=0))
+            d = fam.setdefault(name, dict(ms=0.0, flops=0.0, t_roof=0.0, bytes=0.0, launches=0, ms_large=0.0, bytes_large=0.0, n_large=0))
             fl = conv_flops(ops[k])
             d["ms"] += best
             d["bytes"] += op_bytes(ops[k])
             d["launches"] += 1
+            if op_bytes(ops[k]) >= LARGE_OP_BYTES:            # streaming ops big enough to be bandwidth- rather than latency-bound
+                d["ms_large"] += best
+                d["bytes_large"] += op_bytes(ops[k])
+                d["n_large"] += 1
             if fl:
                 roof = conv_roof(ops[k], L)
                 if roof is not None:
@@ -554,6 +559,10 @@ def main():
                 elif d["bytes"]:
                     e["gbs"] = round(d["bytes"] / d["ms"] / 1e6, 1)
                     e["frac_of_hbm_peak"] = round(d["bytes"] / d["ms"] / 1e6 / HBM_PEAK_GBS, 4)
+                    if d["n_large"]:
+                        e["large_ops"] = dict(launches=d["n_large"], ms_per_step=round(d["ms_large"], 3), gbs=round(d["bytes_large"] / d["ms_large"] / 1e6, 1),
+                                              frac_of_hbm_peak=round(d["bytes_large"] / d["ms_large"] / 1e6 / HBM_PEAK_GBS, 4),
+                                              note=">= 32 MB of algorithmic traffic per launch; the rest of the family are latency-bound launches on the 16x16 ... 2x2 levels")
                 fams[k] = e
             dom = max((k for k in fam if fam[k]["flops"]), key=lambda k: fam[k]["ms"])
             roof["families"] = fams

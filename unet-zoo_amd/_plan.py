@@ -1233,6 +1233,17 @@ class Plan:
             full = full[v.b0:v.b0 + v.nb]
         return full[:, v.c0:v.c0 + v.C]
 
+    def span(self, views):
+        """One flat tensor covering the given whole, consecutively allocated buffers (alignment gaps included), or None when
+        they are not laid out that way: lets the host fill all of them (latent noise) with ONE launch."""
+        bufs = [v.buf for v in views]
+        if any(v.nb is not None or not v.contiguous or b.alias is not None for v, b in zip(views, bufs)):
+            return None
+        for a, b in zip(bufs, bufs[1:]):
+            if not (a.off + a.numel <= b.off <= a.off + a.numel + _ALIGN):
+                return None
+        return self.arena[bufs[0].off:bufs[-1].off + bufs[-1].numel]
+
     def run(self, which, stream_ptr):
         arr, n = self.tapes[which]
         if n:

@@ -247,8 +247,14 @@ class PHISeg(NativeModel):
         plan.tensor(io["patch"]).copy_(patch)
         plan.tensor(io["mask"]).copy_(mask.reshape(N, 1, H, W))
         if eps is None:
-            for e in io["eps"]:
-                plan.tensor(e).normal_()
+            flat = plan.__dict__.get("_eps_span", False)
+            if flat is False:
+                flat = plan._eps_span = plan.span(io["eps"])
+            if flat is not None:
+                flat.normal_()                                # the ten noise buffers are neighbours in the arena: one launch
+            else:
+                for e in io["eps"]:
+                    plan.tensor(e).normal_()
         else:
             for e, src in zip(io["eps"], eps):
                 plan.tensor(e).copy_(src)
