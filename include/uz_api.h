@@ -74,6 +74,28 @@ int uz_conv_fwd(const float* x, int Cin, int CinTot,
                 int N, int H, int W, int ks, int relu,
                 const float* x_amax, const float* w_amax, float* y_amax,
                 void* workspace, size_t workspace_bytes, void* stream);
+/* Weight images of the split path packed ONCE per step for a whole tape (instead of inside every call): the caller keeps a
+ * buffer of uz_conv_packed_bytes() per (layer, direction), describes them in a device table of 8 int64 per layer
+ * {w address, image address, Mc, Kc, wCi, uz_conv_pack_cot(), dgrad, first row} with rows counted by uz_conv_pack_rows()
+ * (Mc / Kc = output / contraction channels of the direction: forward Cout / Cin, data gradient Cin / Cout; wCi = Cin), runs
+ * uz_conv_pack_weights once (w_amax = the bound every image is scaled with) and hands each image to the *_packed calls,
+ * which are otherwise uz_conv_fwd / uz_conv_bwd_data (packed_w may be NULL: same behaviour as those).                      */
+size_t uz_conv_packed_bytes(int Cin, int Cout, int W, int dgrad);
+int uz_conv_pack_rows(int Cin, int Cout, int W, int dgrad);
+int uz_conv_pack_cot(int Cin, int Cout, int W, int dgrad);
+int uz_conv_pack_weights(const int64_t* table, int n_layers, int total_rows, const float* w_amax, void* stream);
+int uz_conv_fwd_packed(const float* x, int Cin, int CinTot,
+                       const float* w, const float* bias,
+                       float* y, int Cout, int CoutTot,
+                       int N, int H, int W, int ks, int relu,
+                       const float* x_amax, const float* w_amax, float* y_amax,
+                       void* workspace, size_t workspace_bytes, const void* packed_w, void* stream);
+int uz_conv_bwd_data_packed(const float* dy, int Cout, int CoutTot,
+                            const float* w,
+                            float* dx, int Cin, int CinTot,
+                            int N, int H, int W, int ks, int accumulate,
+                            const float* dy_amax, const float* w_amax,
+                            void* workspace, size_t workspace_bytes, const void* packed_w, void* stream);
 /* autograd of the above w.r.t. its input (aten::convolution_backward, input part):
  * dx[b,ci] (+)= sum_co sum_tap dy[b,co,.] * w[co,ci,flip(tap)]                 */
 int uz_conv_bwd_data(const float* dy, int Cout, int CoutTot,
@@ -240,6 +262,7 @@ enum {
   UZ_OP_AVGPOOL3D_FWD, UZ_OP_AVGPOOL3D_BWD, UZ_OP_DEPTH_LERP_FWD, UZ_OP_DEPTH_LERP_BWD, UZ_OP_NEAREST3D_FWD, UZ_OP_NEAREST3D_BWD,
   UZ_OP_ADD_VIEWS,       /* p = a, b, y, a_amax, b_amax, y_amax; i = CtotA, CtotB, CtotY, C, N, H, W, accumulate; f[0] = alpha */
   UZ_OP_EVENT_RECORD,    /* p[0] = event (uz_event_create): marks "every earlier op this one depends on is done" */
+  UZ_OP_PACK_WEIGHTS,    /* p[0] = table, p[1] = w_amax; i = n_layers, total_rows (uz_conv_pack_weights); CONV_FWD p[8] / CONV_BWD_DATA p[6] = image */
   UZ_OP__COUNT
 };
 typedef struct uz_op {

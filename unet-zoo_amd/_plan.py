@@ -157,6 +157,8 @@ class Plan:
         # at the head of the backward tape.
         self.n_amax, self.n_amax_fwd = 1, None
         self._amax_bwd = []                 # slot indices used by backward producers
+        self._packs = {"fwd": {}, "bwd": {}}   # pre-packed split-fp16 weight images: wkey -> geometry (see _packed)
+        self._packbuf = {}
         self.grad_buckets = []              # [(lo, hi)] float ranges of the flat gradient buffer that get a "final" event (data parallel)
         self.events = []                    # hipEvent_t handles (uz_event_create), one per gradient bucket
         self._gid = 0                       # scheduling group of the ops being emitted (see _schedule)
@@ -307,9 +309,10 @@ class Plan:
         ws = self.L.uz_conv_workspace(cin, cout, x.N, x.H, x.W, ks)
         self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
         self._newgroup()
+        packed = self._packed(wkey, cin, cout, x, False) if (ks == 3 and wrow0 == 0) else None
         self._emit(self.target, "UZ_OP_CONV_FWD",
                    p=[x, self.P(wkey, wextra), self.P(bkey, wrow0) if bkey else None, y, ("scratch", "wgrad"),
-                      self.amax_in(x), ("amax", 0), self.amax_out(y) if (relu and ks == 3) else None],
+                      self.amax_in(x), ("amax", 0), self.amax_out(y) if (relu and ks == 3) else None, packed],
                    i=[cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, ks, relu], n=ws)
 
     def _conv_bwd(self, x, wkey, gy, ks, db_key=None, wrow0=0):
@@ -348,9 +351,30 @@ class Plan:
             acc = self._claim(x)
             ws2 = self.L.uz_conv_workspace(cin, cout, x.N, x.H, x.W, ks)
             self.scratch["wgrad"] = max(self.scratch["wgrad"], ws2)
+            packed = self._packed(wkey, cin, cout, x, True) if (ks == 3 and wrow0 == 0) else None
             self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
-                       p=[gy, self.P(wkey, wextra), self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0)],
+                       p=[gy, self.P(wkey, wextra), self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0), packed],
                        i=[cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, ks, acc], n=ws2)
+
+    def _packed(self, wkey, cin, cout, x, dgrad):
+        """Reference to the pre-packed split-fp16 weight image of this layer and direction, or None when the call packs its
+        own (layers off the split path, extra tapes).  All images of a tape are packed by ONE launch at its head
+        (uz_conv_pack_weights) instead of one small launch in front of every convolution."""
+        if os.environ.get("UZ_PREPACK", "1") != "1" or self.L.uz_conv_route(1 if dgrad else 0, cin, cout, x.N, x.H, x.W, 3) != 1:
+            return None
+        if not dgrad and self.target is not self.fwd_ops and self.target is not self.bwd_ops:
+            return None                                        # extra (decode) tapes: the call packs its own image
+        which = "bwd" if dgrad else "fwd"
+        if which == "fwd" and self.target is self.bwd_ops and wkey not in self._packs["fwd"]:
+            return None                                        # (a forward convolution that only exists in the backward tape)
+        lst = self._packs[which]
+        if wkey not in lst:
+            lst[wkey] = dict(idx=len(lst), cin=cin, cout=cout, W=x.W, dgrad=int(dgrad),
+                             bytes=self.L.uz_conv_packed_bytes(cin, cout, x.W, int(dgrad)),
+                             rows=self.L.uz_conv_pack_rows(cin, cout, x.W, int(dgrad)), cot=self.L.uz_conv_pack_cot(cin, cout, x.W, int(dgrad)))
+        e = lst[wkey]
+        assert (e["cin"], e["cout"], e["W"]) == (cin, cout, x.W), f"{wkey}: one weight, two convolution shapes"
+        return ("packw", which, wkey)
 
     def _window_input(self, x, wkey):
         """The depth window of a 3x3x3 convolution addresses slices d-1, d, d+1 of its input as 3 C consecutive channels, which
@@ -832,10 +856,28 @@ class Plan:
         remap = {k: i for i, k in enumerate(fwd_slots + bwd_slots)}
         self._amax_remap, self.n_amax_fwd = remap, len(fwd_slots)
         head = self._gid = -1
+        pack_ops = {}
+        for which, lst in self._packs.items():
+            if not lst:
+                continue
+            off = rows = 0
+            refs = []
+            for wkey, e in lst.items():
+                e["off"], e["row0"] = off, rows
+                off += e["bytes"]
+                rows += e["rows"]
+                mc, kc = (e["cin"], e["cout"]) if e["dgrad"] else (e["cout"], e["cin"])
+                refs += [self.P(wkey), ("packw", which, wkey), ("raw", mc), ("raw", kc), ("raw", e["cin"]), ("raw", e["cot"]), ("raw", e["dgrad"]), ("raw", e["row0"])]
+            self._packbuf[which] = self.vec("packed_weights:" + which, off // 4)
+            pack_ops[which] = dict(code="UZ_OP_PACK_WEIGHTS", p=[self.ptr_table(refs), ("amaxw", 0), self._packbuf[which]], i=[len(lst), rows], f=[], n=0, gid=head)
+        if "bwd" in pack_ops and self.bwd_ops:
+            self.bwd_ops[:0] = [pack_ops["bwd"]]
         if self.fwd_ops:
             ops0 = []
             ops0.append(dict(code="UZ_OP_MEMSET", p=[("amaxrange", 0, self.n_amax_fwd)], i=[], f=[], n=4 * _AMAX_FLOATS * self.n_amax_fwd, gid=head))
             ops0.append(dict(code="UZ_OP_ABSMAX", p=[("pflat",), ("amaxw", 0)], i=[], f=[], n=self.ptab.n_params, gid=head))
+            if "fwd" in pack_ops:
+                ops0.append(pack_ops["fwd"])
             self.fwd_ops[:0] = ops0
         if self.bwd_ops and bwd_slots:
             self.bwd_ops[:0] = [dict(code="UZ_OP_MEMSET", p=[("amaxrange", self.n_amax_fwd, self.n_amax)], i=[], f=[],
@@ -916,6 +958,8 @@ class Plan:
             return self.base + 4 * self.gy_off[lane]
         if kind == "ptrtab":
             return self.ptrtab.data_ptr() + 8 * self._tab_off[r[1]]
+        if kind == "packw":
+            return self.base + 4 * self._packbuf[r[1]].buf.off + self._packs[r[1]][r[2]]["off"]
         if kind == "raw":
             return int(r[1])
         if kind == "win":                                    # depth window of a volume: starts one slice before the view
@@ -988,7 +1032,7 @@ class Plan:
         "UZ_OP_BCAST_CHANNELS": (1,), "UZ_OP_BCAST_CHANNELS_BWD": (1,), "UZ_OP_EVENT_RECORD": (0,), "UZ_OP_ABSMAX": (1,),
         "UZ_OP_ADD_VIEWS": (2,), "UZ_OP_W3D_PERMUTE": (1,), "UZ_OP_AVGPOOL3D_FWD": (1,), "UZ_OP_AVGPOOL3D_BWD": (1,),
         "UZ_OP_DEPTH_LERP_FWD": (1,), "UZ_OP_DEPTH_LERP_BWD": (1,), "UZ_OP_NEAREST3D_FWD": (1,), "UZ_OP_NEAREST3D_BWD": (1,),
-        "UZ_OP_ABSMAX_COPY": (),
+        "UZ_OP_ABSMAX_COPY": (), "UZ_OP_PACK_WEIGHTS": (2,),
     }
 
     def _resources(self, r):
@@ -1009,6 +1053,8 @@ class Plan:
             return [(("bnbuf", r[1]), 0, 1)]
         if kind == "ptrtab":
             return [x for q in self.ptr_tables[r[1]] for x in self._resources(q)]
+        if kind == "packw":
+            return self._resources(self._packbuf[r[1]])
         if kind == "win":
             return self._resources(r[1])
         if kind in ("gywin", "gyvol", "gypad"):

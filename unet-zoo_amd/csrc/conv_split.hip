@@ -414,10 +414,11 @@ int absmax_flat(const float* x, size_t n, float* slot, hipStream_t st) {
 // bounds that the producing kernels maintain).  y_amax (nullable): atomic max of |y| for the next consumer.
 int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
-               const float* x_amax, const float* w_amax, float* y_amax, void* workspace, hipStream_t st) {
+               const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, hipStream_t st) {
     SP p;
     float* slots = static_cast<float*>(workspace);
     char* image = static_cast<char*>(workspace) + WS_HEAD;
+    UZ_REQUIRE(!packed_w || w_amax, "conv_split: a pre-packed weight image needs the bound it was scaled with");
     if (!x_amax || !w_amax) {
         if (hipMemsetAsync(slots, 0, WS_HEAD, st) != hipSuccess) return fail("conv_split: memset failed");
         if (!x_amax) { if (int rc = absmax_view(x, Kc, KcTot, N, H * W, slots, st)) return rc; x_amax = slots; }
@@ -428,7 +429,7 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
             w_amax = slots + AMAX_FLOATS;
         }
     }
-    p.x = x; p.wp = image; p.bias = bias; p.y = y;
+    p.x = x; p.wp = packed_w ? static_cast<const char*>(packed_w) : image; p.bias = bias; p.y = y;
     p.x_amax = x_amax; p.w_amax = w_amax; p.y_amax = y_amax;
     p.N = N; p.H = H; p.W = W; p.HW = H * W;
     p.Cin = Kc; p.CinTot = KcTot; p.Cout = Mc; p.CoutTot = McTot;
@@ -445,7 +446,8 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     UZ_REQUIRE(grid < (1ll << 31), "conv_split: grid too large");
     UZ_REQUIRE((size_t)Kc * p.HW * 4 < (1ull << 32) && (size_t)McTot * p.HW * N < (1ull << 31), "conv_split: tensor too large for 32-bit offsets");
     const int rows = p.nChunks * p.nCoTiles * KK * cot;
-    if (dgrad) hipLaunchKernelGGL(pack_weights_kernel<true>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
+    if (packed_w) {}                                     // packed once per step by uz_conv_pack_weights
+    else if (dgrad) hipLaunchKernelGGL(pack_weights_kernel<true>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
     else hipLaunchKernelGGL(pack_weights_kernel<false>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
     if (int rc = check_launch("pack_weights_kernel")) return rc;
     int rc;
@@ -456,6 +458,50 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
 }
 
 }  // namespace uz
+
+namespace {
+// All weight images of a tape in ONE launch.  table: n_layers rows of 8 int64 {w (address), packed (address), Mc, Kc, wCi,
+// cot, dgrad, first row}; a workgroup finds its layer by bisection over the first-row column.
+__global__ __launch_bounds__(256) void pack_all_kernel(const long long* __restrict__ table, int n_layers, int total_rows, const float* __restrict__ w_amax) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total_rows) return;
+    int lo = 0, hi = n_layers - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)table[8 * mid + 7] <= e) lo = mid; else hi = mid - 1; }
+    const long long* t = table + 8 * lo;
+    const float* w = reinterpret_cast<const float*>(t[0]);
+    char* packed = reinterpret_cast<char*>(t[1]);
+    const int Mc = (int)t[2], Kc = (int)t[3], wCi = (int)t[4], COT = (int)t[5], dgrad = (int)t[6], r = e - (int)t[7];
+    const int nCoTiles = (Mc + COT - 1) / COT;
+    const int m = r % COT, t1 = r / COT, tap = t1 % KK, t2 = t1 / KK, coT = t2 % nCoTiles, c = t2 / nCoTiles;
+    const int mo = coT * COT + m;
+    float v[CK];
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+        const int kk = c * CK + k;
+        float x = 0.f;
+        if (mo < Mc && kk < Kc) x = dgrad ? w[((size_t)kk * wCi + mo) * KK + tap] : w[((size_t)mo * wCi + kk) * KK + tap];
+        v[k] = x;
+    }
+    const int tapL = dgrad ? KK - 1 - tap : tap;
+    const int wplane = KK * COT * CK * 2;
+    split_store16(v, uz::split_scale(uz::amax_read(w_amax)), packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * 16, wplane, wplane / 2);
+}
+}  // namespace
+
+extern "C" size_t uz_conv_packed_bytes(int Cin, int Cout, int W, int dgrad) {
+    return dgrad ? uz::image_bytes(Cout, Cin, W) : uz::image_bytes(Cin, Cout, W);
+}
+extern "C" int uz_conv_pack_rows(int Cin, int Cout, int W, int dgrad) {
+    const int Kc = dgrad ? Cout : Cin, Mc = dgrad ? Cin : Cout, cot = tile_cot(Mc, W);
+    return uz::ceil_div(Kc, CK) * uz::ceil_div(Mc, cot) * KK * cot;
+}
+extern "C" int uz_conv_pack_cot(int Cin, int Cout, int W, int dgrad) { return tile_cot(dgrad ? Cin : Cout, W); }
+extern "C" int uz_conv_pack_weights(const int64_t* table, int n_layers, int total_rows, const float* w_amax, void* stream) {
+    UZ_REQUIRE(table && w_amax && n_layers >= 0 && total_rows >= 0, "conv_pack_weights: null argument");
+    if (n_layers == 0 || total_rows == 0) return 0;
+    hipLaunchKernelGGL(pack_all_kernel, dim3(uz::ceil_div(total_rows, 256)), dim3(256), 0, uz::S(stream), reinterpret_cast<const long long*>(table), n_layers, total_rows, w_amax);
+    return uz::check_launch("pack_all_kernel");
+}
 
 extern "C" int uz_absmax(const float* x, size_t n, float* slot, void* stream) {
     UZ_REQUIRE(x && slot, "absmax: null argument");

@@ -70,9 +70,9 @@ static int run_one(const uz_op& o, void* st) {
 #define CFP(k) static_cast<const float*>(p[k])
     switch (o.code) {
         case UZ_OP_CONV_FWD:
-            return uz_conv_fwd(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(5), CFP(6), FP(7), p[4], (size_t)o.n, st);
+            return uz_conv_fwd_packed(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(5), CFP(6), FP(7), p[4], (size_t)o.n, p[8], st);
         case UZ_OP_CONV_BWD_DATA:
-            return uz_conv_bwd_data(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, st);
+            return uz_conv_bwd_data_packed(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], st);
         case UZ_OP_CONV_BWD_WEIGHT:
             return uz_conv_bwd_weight(CFP(0), i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], i[7], CFP(5), CFP(6), p[4], (size_t)o.n, st);
         case UZ_OP_BN_RELU_FWD:
@@ -125,6 +125,8 @@ static int run_one(const uz_op& o, void* st) {
             return uz_l2_norms(CFP(0), static_cast<const int64_t*>(p[1]), i[0], FP(2), st);
         case UZ_OP_L2_NORMS_BWD:
             return uz_l2_norms_bwd(CFP(0), static_cast<const int64_t*>(p[1]), i[0], CFP(2), CFP(3), FP(4), st);
+        case UZ_OP_PACK_WEIGHTS:
+            return uz_conv_pack_weights(static_cast<const int64_t*>(p[0]), i[0], i[1], CFP(1), st);
         case UZ_OP_MEMSET:
             return uz_zero_f32(FP(0), (size_t)o.n / 4, st);               /* n = bytes, always whole floats */
         case UZ_OP_COPY:
