@@ -275,6 +275,29 @@ def test_native_reversible_and_eval_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_native_reconstruct_and_sample_vs_oracle():
+    """reconstruct(z) / sample() (phiseg3D.py:443-452): the likelihood on given latent volumes + accumulate_output."""
+    arrays, meta = G.load("phiseg3d_small")
+    L = meta["latent_levels"]
+    net, s, _ = _run_native(meta, arrays, training=False)
+    net.eval()
+    sd = oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"])
+    z = [torch.randn(*arrays[f"post_z{l}"].shape, generator=torch.Generator().manual_seed(5 + l)) for l in range(L)]
+    recon, layers = net.reconstruct([t.cuda() for t in z], use_softmax=True)
+    want_s, _ = R3.likelihood3d(sd, z, bn_train=False, full_size=meta["dhw"])
+    for l in range(L):
+        assert G.maxabs(layers[l].cpu().numpy(), want_s[l].numpy()) <= 1e-4 * max(1.0, float(want_s[l].abs().max())), l
+    acc = want_s[-1].clone()
+    for l in range(L - 1):
+        acc = acc + want_s[l]
+    assert G.maxabs(recon.cpu().numpy(), torch.softmax(acc, dim=1).numpy()) <= 1e-5
+    smp = net.sample(testing=True)
+    assert smp.shape == (1, meta["num_classes"], *meta["dhw"]) and bool(torch.isfinite(smp).all())
+    with pytest.raises(NotImplementedError):
+        net.sample(testing=False)
+
+
+@pytest.mark.gpu
 def test_native_five_level_volume_trains():
     """BASELINE config 5's shape class at a test-sized volume: 5 resolution / 5 latent levels, 4 input channels, 3 labels,
     hipGraph replay + fused Adam: loss matches the oracle at step 0, stays finite and decreases over a few steps."""

@@ -186,7 +186,7 @@ class PHISeg3D(NativeModel):
             s[lvl] = plan.nearest3d(s_in[lvl], f, full[0] // s_in[lvl].N, f"{root}.s{lvl}") if f > 1 else s_in[lvl]
         return s, s_in
 
-    def _build(self, D, H, W, training, bn_training):
+    def _build(self, D, H, W, training, bn_training, decode_only=False):
         R, L, K = len(self.num_filters), self.latent_levels, self.num_classes
         if D % (1 << (R - 1)) or H % (1 << (R - 1)) or W % (1 << (R - 1)):
             raise ValueError("PHISeg3D needs every spatial size divisible by 2^(levels-1)")
@@ -194,6 +194,12 @@ class PHISeg3D(NativeModel):
         plan.bn_prefixes_nbt = []
         io = {}
         shapes = [(2, D >> (R - 1 - k), H >> (R - 1 - k), W >> (R - 1 - k)) for k in range(L)]
+        if decode_only:                                       # reconstruct() / sample(): the likelihood on given latent volumes
+            io["z_in"] = [plan.vol(f"z_in{k}", *shapes[k], requires_grad=False) for k in range(L)]
+            io["s"], io["s_in"] = self._likelihood(plan, io["z_in"], (D, H, W))
+            plan.finalize(want_backward=False)
+            plan.io = io
+            return plan
         io["eps"] = [plan.vol(f"eps{k}", *shapes[k % L], requires_grad=False) for k in range(2 * L)]
         # cat(patch, one-hot mask - 0.5) (:275-279) is staged by forward(); the prior reads its first input_channels channels
         xin = io["input"] = plan.vol("posterior.input", self.input_channels + K, D, H, W, requires_grad=False)
@@ -300,6 +306,37 @@ class PHISeg3D(NativeModel):
 
     def elbo(self, segm, reconstruct_posterior_mean=False):
         return self.loss(segm)
+
+    def sample_posterior(self):
+        """phiseg3D.py:426-433."""
+        return [m + s * torch.randn_like(s) for m, s in zip(self.posterior_mu, self.posterior_sigma)]
+
+    def sample_prior(self):
+        """phiseg3D.py:435-441."""
+        return [m + s * torch.randn_like(s) for m, s in zip(self.prior_mu, self.prior_sigma)]
+
+    def reconstruct(self, z_posterior, use_softmax=True):
+        """Decode latent volumes (finest level first) through the likelihood (phiseg3D.py:450-452)."""
+        self._require_gpu()
+        R, L = len(self.num_filters), self.latent_levels
+        _, _, d, h, w = z_posterior[0].shape
+        D, H, W = d << (R - L), h << (R - L), w << (R - L)
+        key = ("decode", D, H, W, bool(self.training))
+        plan = self._plan(key, lambda: self._build(D, H, W, False, bool(self.training), decode_only=True))
+        for lvl, z in enumerate(z_posterior):
+            plan.tensor(plan.io["z_in"][L - 1 - lvl]).copy_(self._to_slices(z))
+        self._run(plan, "fwd")
+        if self.training:
+            self._bump_nbt(plan)
+        layer_recon = [self._to_volume(plan.tensor(v)).clone() for v in plan.io["s"]]
+        return self.accumulate_output(layer_recon, use_softmax=use_softmax), layer_recon
+
+    def sample(self, testing=True):
+        """phiseg3D.py:443-448."""
+        if testing:
+            sample, _ = self.reconstruct(self.sample_prior(), use_softmax=False)
+            return sample
+        raise NotImplementedError
 
     def kl_divergence(self):
         return self.kl_divergence_loss
