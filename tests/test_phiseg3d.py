@@ -281,15 +281,17 @@ def test_native_reconstruct_and_sample_vs_oracle():
     L = meta["latent_levels"]
     net, s, _ = _run_native(meta, arrays, training=False)
     net.eval()
-    sd = oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"])
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}      # incl. the BN buffers the training-mode forward just updated
     z = [torch.randn(*arrays[f"post_z{l}"].shape, generator=torch.Generator().manual_seed(5 + l)) for l in range(L)]
     recon, layers = net.reconstruct([t.cuda() for t in z], use_softmax=True)
     want_s, _ = R3.likelihood3d(sd, z, bn_train=False, full_size=meta["dhw"])
-    for l in range(L):
-        assert G.maxabs(layers[l].cpu().numpy(), want_s[l].numpy()) <= 1e-4 * max(1.0, float(want_s[l].abs().max())), l
     acc = want_s[-1].clone()
     for l in range(L - 1):
         acc = acc + want_s[l]
+    for l in range(L):
+        # the reference accumulates IN PLACE into the coarsest level's tensor (phiseg3D.py:469-472), which it also returns
+        ref = acc if l == L - 1 else want_s[l]
+        assert G.maxabs(layers[l].cpu().numpy(), ref.numpy()) <= 1e-4 * max(1.0, float(ref.abs().max())), l
     assert G.maxabs(recon.cpu().numpy(), torch.softmax(acc, dim=1).numpy()) <= 1e-5
     smp = net.sample(testing=True)
     assert smp.shape == (1, meta["num_classes"], *meta["dhw"]) and bool(torch.isfinite(smp).all())
