@@ -58,7 +58,7 @@ def run(dp, overlap=True, steps=8, timed=0):
 print("rccl version code", _ffi.lib().uz_comm_version())
 if os.environ.get("UZ_WARM_NODP"):
     run(False, timed=3)
-if os.environ.get("UZ_DP_DIAG") or os.environ.get("UZ_DP_ONLY"):
+if os.environ.get("UZ_DP_ONLY"):
     if os.environ.get("UZ_SIDE_STREAM"):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -66,7 +66,7 @@ if os.environ.get("UZ_DP_DIAG") or os.environ.get("UZ_DP_ONLY"):
             p1, l1, ms1, ex1, nb, nev = run(True, overlap=True, timed=10)
     else:
         p1, l1, ms1, ex1, nb, nev = run(True, overlap=True, timed=10)
-    print(f"DIAG {os.environ.get('UZ_DP_DIAG')} side {os.environ.get('UZ_SIDE_STREAM')} prio {os.environ.get('UZ_DP_STREAM_PRIORITY')} lanes {os.environ.get('UZ_LANES')}: dp overlap {ms1:.3f} ms/step exposed {ex1}")
+    print(f"side {os.environ.get('UZ_SIDE_STREAM')} prio {os.environ.get('UZ_DP_STREAM_PRIORITY')} lanes {os.environ.get('UZ_LANES')}: dp overlap {ms1:.3f} ms/step exposed {ex1}")
     dist.destroy_process_group()
     sys.exit(0)
 p0, l0, ms0, _, _, _ = run(False, timed=10)

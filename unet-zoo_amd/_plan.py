@@ -984,29 +984,10 @@ class Plan:
         raise ValueError(r)
 
     def _materialize(self, ops):
-        skip = int(os.environ.get("UZ_DIAG_SKIP_SMALL", "0"))      # DIAGNOSTIC ONLY: drop ops on planes <= skip (results invalid)
-        if skip:
-            def small(o):
-                c, i = o["code"], o["i"]
-                if c.startswith("UZ_OP_CONV"):
-                    return i[5] <= skip
-                if c == "UZ_OP_BN_RELU_FWD":
-                    return i[4] <= skip
-                if c in ("UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
-                    return i[5] <= skip
-                if c.startswith("UZ_OP_AVGPOOL") or c.startswith("UZ_OP_BILINEAR"):
-                    return i[4] <= skip
-                return False
-            for o in ops:
-                if small(o):
-                    o["skip"] = True
         arr = (_ffi.uz_op * max(len(ops), 1))()
         for k, o in enumerate(ops):
             e = arr[k]
-            e.code = self.codes["UZ_OP_SCALE"] if o.get("skip") else self.codes[o["code"]]
-            if o.get("skip"):                              # a no-op in place of the skipped kernel keeps the tape / schedule shape
-                e.n = 0
-                continue
+            e.code = self.codes[o["code"]]
             assert len(o["i"]) <= 15 and len(o["f"]) <= 4 and len(o["p"]) <= 12, o["code"]
             for j, v in enumerate(o["i"]):
                 e.i[j] = v
@@ -1108,8 +1089,6 @@ class Plan:
         c, i = o["code"], o["i"]
         if c in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA", "UZ_OP_CONV_BWD_WEIGHT"):
             return i[4] * i[5] * i[6] >= 2048 and i[0] * i[2] >= 32 * 32      # measured: 512..8192 pixels all within 1 %
-        if os.environ.get("UZ_SCHED_STREAM_LIGHT") == "1" and not c.startswith("UZ_OP_CONV"):
-            return False                                   # experiment: streaming kernels may run beside a device-filling convolution
         if c in ("UZ_OP_BN_RELU_FWD", "UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
             C, N, H, W = (i[0], i[3], i[4], i[5]) if c == "UZ_OP_BN_RELU_FWD" else (i[1], i[4], i[5], i[6])
             return C * N * H * W >= 4.0e6

@@ -322,13 +322,8 @@ int launch(const SP& p, int grid, hipStream_t st) {
 // else 16 x 16 tiles (256 threads, 32-channel tiles)
 inline bool small_geo(int W) { return W <= 32; }       // measured: 16 x 16 tiles win or tie on 32 x 32 planes (128 -> 128: 91 -> 67 us), lose on 64 x 64
 inline int tile_w(int W) { return small_geo(W) ? 16 : 32; }
-// 16 x 16 tiles with 32 output channels read one LDS fragment per MFMA (LDS-read bound); with 64 channels 1.5 MFMAs per
-// fragment, at half the number of workgroups.  UZ_SMALL_COT=64 (experiment) selects the latter for layers with >= 64 channels.
-inline int small_cot() { static const int v = [] { const char* e = getenv("UZ_SMALL_COT"); return e ? atoi(e) : 32; }(); return v; }
-inline int tile_cot(int Mc, int W) {
-    if (small_geo(W)) return (small_cot() == 64 && Mc >= 64) ? 64 : 32;
-    return Mc <= 32 ? 32 : 64;
-}
+// 16 x 16 tiles carry 32 output channels (64 was measured 8 - 30 % slower: the layers that use this geometry want workgroups)
+inline int tile_cot(int Mc, int W) { return (small_geo(W) || Mc <= 32) ? 32 : 64; }
 
 }  // namespace
 
@@ -361,8 +356,7 @@ namespace {
 // chunk loop is shared out over up to 4 workgroups (>= 3 chunks each, ~3 workgroups per CU) - the kernel is latency bound
 // there, more resident waves are what it lacks - and the partial sums are added in order by splitk_reduce.
 int split_parts(int Kc, int Mc, int N, int H, int W) {
-    static const int mode = [] { const char* e = getenv("UZ_SPLIT_KSPLIT"); return e ? atoi(e) : -1; }();    // experiment: 1 = off
-    if (!small_geo(W) || mode == 1) return 1;
+    if (!small_geo(W)) return 1;
     const int cot = tile_cot(Mc, W), nChunks = ceil_div(Kc, CK);
     const long long g = (long long)N * ceil_div(H, TH) * ceil_div(W, 16) * ceil_div(Mc, cot);
     if (g >= 384) return 1;
@@ -451,7 +445,7 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     else hipLaunchKernelGGL(pack_weights_kernel<false>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
     if (int rc = check_launch("pack_weights_kernel")) return rc;
     int rc;
-    if (tw == 16) rc = cot == 32 ? launch<1, 256, 16>(p, (int)grid, st) : launch<2, 256, 16>(p, (int)grid, st);
+    if (tw == 16) rc = launch<1, 256, 16>(p, (int)grid, st);
     else rc = cot == 32 ? launch<1, 512, 32>(p, (int)grid, st) : launch<2, 512, 32>(p, (int)grid, st);
     if (rc || p.kSplit == 1) return rc;
     return splitk_reduce(p.slab, p.kSplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax, st);

@@ -195,18 +195,11 @@ class GradSync:
                 self._warned_null = True
             serial = True
         check(L.uz_event_record(self.t0, cs), "event_record")              # compute stream: backward tape done
-        diag = os.environ.get("UZ_DP_DIAG", "")
         if self.overlap and plan.events and not serial:
             for b in self.order(plan):
                 lo, hi = self.buckets[b]
-                if diag == "nocomm":
-                    continue
-                if diag == "samestream":
-                    check(L.uz_allreduce_mean_f32(self.comm, base + 4 * lo, hi - lo, cs), "allreduce")
-                    continue
                 check(L.uz_stream_wait_event(self.stream, plan.events[b]), "stream_wait_event")
-                if diag != "waitonly":
-                    check(L.uz_allreduce_mean_f32(self.comm, base + 4 * lo, hi - lo, self.stream), "allreduce")
+                check(L.uz_allreduce_mean_f32(self.comm, base + 4 * lo, hi - lo, self.stream), "allreduce")
         else:                                                                # one blocking-order all-reduce behind the whole tape
             check(L.uz_stream_wait_event(self.stream, self.t0), "stream_wait_event")
             check(L.uz_allreduce_mean_f32(self.comm, base, gflat.numel(), self.stream), "allreduce")
