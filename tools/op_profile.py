@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-op timing of one PHiSeg step (HIP events around each tape op): which layers cost what."""
+"""usage: op_profile.py [batch] [phiseg|unet|probunet].  Per-op timing of one training step (HIP events around each tape op): which layers cost what."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,11 +11,17 @@ from unet_zoo_amd.models.phiseg import PHISeg
 from unet_zoo_amd.synthetic import synthetic_batch
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-net = PHISeg(1, 2, FILTERS, image_size=(1, 128, 128)); net.train()
+MODEL = sys.argv[2] if len(sys.argv) > 2 else "phiseg"
+import bench
+net = bench.build(MODEL); net.train()
 x, m, _ = synthetic_batch(B)
 x, m = torch.from_numpy(x).cuda(), torch.from_numpy(m).cuda()
 for _ in range(2):
-    net.forward(x, m); l = net.loss(m); l.backward()
+    if MODEL == "unet":
+        net.forward(x)
+    else:
+        net.forward(x, m)
+    l = net.loss(m); l.backward()
 plan = net._cur
 L = _ffi.lib(); st = C.c_void_p(net._stream())
 rows = []

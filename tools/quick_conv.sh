@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 python -m pytest tests/test_ops_gpu.py tests/test_full_configs_gpu.py -q -x -k "conv or split" -p no:cacheprovider 2>&1 | tail -3
-for l in "224 128 128 128" "256 192 64 64" "32 32 128 128" "64 64 64 64" "128 128 32 32" "192 192 32 32" "192 192 16 16" "256 256 16 16"; do echo "== $l"; python tools/bench_conv.py $l 2>/dev/null; done
-python bench.py --steps 30 --warmup 5 --skip-cpu --no-profile --no-f32-leg 2>/dev/null | cut -c1-160
+for l in "$@"; do echo "== $l"; python tools/bench_conv.py $l 2>/dev/null; done
+for m in phiseg unet probunet; do python bench.py --model $m --steps 30 --warmup 5 --skip-cpu --no-profile --no-f32-leg 2>/dev/null | cut -c1-175; done

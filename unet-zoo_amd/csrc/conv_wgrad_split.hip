@@ -255,11 +255,14 @@ bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks) {
     if (!mode || ks != 3 || (W % 32 != 0 && W != 16)) return false;
     if (mode == 2) return true;
     const long long px = (long long)N * H * W;
-    return (Cin >= 64 && Cout >= 64 && px >= 8 * 1024) || (Cin <= 32 && Cout <= 32 && Cout >= 16 && px >= 128 * 1024);
+    const int lo = Cin < Cout ? Cin : Cout;
+    // 64-channel tiles when both sides have them; 32-channel tiles when one side is narrow (32 -> 32, and the decoder's
+    // 96 -> 32 at full resolution: 3 ci tiles - the fp32 kernel ran that layer at 79 TF/s)
+    return (Cin >= 64 && Cout >= 64 && px >= 8 * 1024) || (lo <= 32 && lo >= 16 && px >= 128 * 1024);
 }
 
 static inline int tile_w(int W) { return W == 16 ? 16 : 32; }
-static inline int chan_tile(int Cin, int Cout) { return (Cin <= 32 && Cout <= 32) ? 32 : 64; }
+static inline int chan_tile(int Cin, int Cout) { return (Cin <= 32 || Cout <= 32) ? 32 : 64; }
 
 // number of pixel splits: one (64-channel tiles, 147 KB of LDS) or two (32-channel tiles, 74 KB) workgroups per CU,
 // at most one split per pixel tile
