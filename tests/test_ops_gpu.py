@@ -38,6 +38,9 @@ CONV_CASES = [
     (3, 20, 36, 20, 16, 3),       # H not a multiple of the 4-row tile
     (2, 48, 80, 37, 96, 3),       # three 32-wide tiles per row, ragged rows, channel tiles with overhang (split kernels when forced)
     (2, 70, 33, 50, 64, 3),       # Cin, Cout with K / M tails on 64-wide planes
+    (4, 3, 32, 128, 128, 3),      # first layer of the posterior (image + 2-label one-hot): thin-input weight gradient
+    (16, 1, 40, 64, 64, 3),       # ... one input channel, two output-channel tiles (the second ragged)
+    (33, 4, 32, 64, 32, 3),       # ... four input channels, 32-wide planes, odd batch
 ]
 
 

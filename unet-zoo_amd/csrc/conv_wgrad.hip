@@ -423,6 +423,95 @@ __global__ __launch_bounds__(64) void channel_sum_final(const double* __restrict
     if (threadIdx.x == 0) db[c] = (float)s;
 }
 
+
+// ---------------------------------------------------------------- 3x3 weight gradient of the 1..4-channel input layers
+// dW[co][ci][tap] with Cin <= 4 (the first convolution of every encoder: image / image + one-hot mask) is a streaming
+// reduction over dY (N * Cout * HW * 4 bytes read once), not a GEMM: an MFMA tile would be 3 % full.  A workgroup walks
+// tiles of 2 rows x up to 128 columns of one image: dY tile [32 co][256 px] and the haloed X patch go to LDS (coalesced
+// float4 reads), thread (co, g) owns 32 consecutive pixels of the tile, slides a 3 x 3 window of X over them in registers
+// (all 32 co-lanes read the same X address: broadcast) and accumulates its 9 Cin sums; the 8 pixel groups are folded in a
+// fixed order through LDS and the workgroup writes ONE slab [tap][co][ci] - the usual ordered reduce follows.
+constexpr int THIN_CO = 32, THIN_G = 8, THIN_ROWS = 2, THIN_WMAX = 128, THIN_STRIDE = THIN_ROWS * THIN_WMAX + 1;
+template <int CIN>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(const float* __restrict__ x, int CinTot, const float* __restrict__ dy, int CoutTot, int Cout,
+                                                          float* __restrict__ slab, int N, int H, int W, int tiles_per_image, int tiles_per_wg) {
+    __shared__ __attribute__((aligned(16))) float dyL[THIN_CO * THIN_STRIDE];
+    __shared__ float xL[CIN * (THIN_ROWS + 2) * (THIN_WMAX + 2)];
+    const int tid = threadIdx.x, co = tid & 31, g = tid >> 5;
+    const int co0 = blockIdx.y * THIN_CO;
+    const int HW = H * W, PWp = W + 2;
+    const int npx = THIN_ROWS * W;                           // pixels of a tile (<= 256), W % 32 == 0 checked by the host
+    const int per = npx / THIN_G;                            // pixels per thread: a run inside one row (W >= per)
+    float acc[CIN][9];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    const int total = N * tiles_per_image;
+    const int t_lo = blockIdx.x * tiles_per_wg, t_hi = min(total, t_lo + tiles_per_wg);
+    for (int tl = t_lo; tl < t_hi; ++tl) {
+        const int b = tl / tiles_per_image, y0 = (tl - b * tiles_per_image) * THIN_ROWS;
+        __syncthreads();                                     // previous tile fully consumed
+        // dY tile: 32 co x (2 rows x W) - float4 along x
+        const int q4 = npx / 4;
+        for (int e = tid; e < THIN_CO * q4; e += 256) {
+            const int c = e / q4, q = e - c * q4, px = 4 * q, r = px / W, col = px - r * W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co0 + c < Cout && y0 + r < H) v = *reinterpret_cast<const float4*>(dy + ((size_t)b * CoutTot + co0 + c) * HW + (size_t)(y0 + r) * W + col);
+            float* d = dyL + c * THIN_STRIDE + px;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        // X patch: Cin x 4 rows x (W + 2), zero outside the image
+        for (int e = tid; e < CIN * (THIN_ROWS + 2) * PWp; e += 256) {
+            const int c = e / ((THIN_ROWS + 2) * PWp), r2 = e - c * (THIN_ROWS + 2) * PWp, r = r2 / PWp, col = r2 - r * PWp;
+            const int yy = y0 + r - 1, xx = col - 1;
+            float v = 0.f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = x[((size_t)b * CinTot + c) * HW + (size_t)yy * W + xx];
+            xL[(c * (THIN_ROWS + 2) + r) * (THIN_WMAX + 2) + col] = v;
+        }
+        __syncthreads();
+        const int p0 = g * per, r = p0 / W, c0 = p0 - r * W;
+        const float* dyrow = dyL + co * THIN_STRIDE + p0;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+            const float* xr = xL + (c * (THIN_ROWS + 2) + r) * (THIN_WMAX + 2) + c0;     // patch column of pixel column c0 - 1
+            float w0[3], w1[3], w2[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { w0[k] = xr[k * (THIN_WMAX + 2)]; w1[k] = xr[k * (THIN_WMAX + 2) + 1]; }
+            for (int i = 0; i < per; ++i) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) w2[k] = xr[k * (THIN_WMAX + 2) + i + 2];
+                const float v = dyrow[i];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    acc[c][3 * k + 0] += v * w0[k];
+                    acc[c][3 * k + 1] += v * w1[k];
+                    acc[c][3 * k + 2] += v * w2[k];
+                    w0[k] = w1[k]; w1[k] = w2[k];
+                }
+            }
+        }
+    }
+    // fold the 8 pixel groups in a fixed order, then one slab per workgroup: slab[blockIdx.x][tap][co][ci] (all co tiles)
+    __syncthreads();
+    float* red = dyL;                                        // 8 x 32 x (CIN * 9) floats <= 9216 < the dY tile
+    for (int c = 0; c < CIN; ++c)
+        for (int t = 0; t < 9; ++t) red[(g * THIN_CO + co) * (CIN * 9) + c * 9 + t] = acc[c][t];
+    __syncthreads();
+    for (int e = tid; e < THIN_CO * CIN * 9; e += 256) {
+        const int c_o = e / (CIN * 9), r2 = e - c_o * (CIN * 9), c = r2 / 9, t = r2 - c * 9;
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < THIN_G; ++k) s2 += red[(k * THIN_CO + c_o) * (CIN * 9) + r2];
+        if (co0 + c_o < Cout) slab[((size_t)blockIdx.x * 9 + t) * Cout * CIN + (size_t)(co0 + c_o) * CIN + c] = s2;
+    }
+}
+inline bool wgrad_thin_ok(int Cin, int Cout, int N, int H, int W, int ks) {
+    return ks == 3 && Cin <= 4 && W % 32 == 0 && W <= THIN_WMAX && H % THIN_ROWS == 0 && (long long)N * H * W >= 64 * 1024;
+}
+constexpr int THIN_SLABS = 512;
+inline int wgrad_thin_slabs(int N, int H) { const int t = N * (H / THIN_ROWS); return t < THIN_SLABS ? t : THIN_SLABS; }
+
 struct WGeom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB, T, S, nCoT, nCiT, WM, WN, WK, pf, fast, SW; };   // SW: slabs per pixel split
 
 WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
@@ -479,6 +568,10 @@ extern "C" size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, 
     const size_t slabs = (size_t)g.S * g.SW * ks * ks * Cout * Cin * sizeof(float);
     const size_t dbp = (size_t)Cout * CSB * sizeof(double);
     size_t need = slabs > dbp ? slabs : dbp;
+    if (wgrad_thin_ok(Cin, Cout, N, H, W, ks)) {
+        const size_t th = (size_t)wgrad_thin_slabs(N, H) * 9 * Cout * Cin * sizeof(float);
+        if (th > need) need = th;
+    }
     if (uz::wgrad_split_ok(Cin, Cout, N, H, W, ks)) {
         const size_t sp = (size_t)uz::wgrad_split_splits(Cin, Cout, N, H, W) * ks * ks * Cout * Cin * sizeof(float) + 2 * uz::AMAX_FLOATS * sizeof(float);    // + fallback bound slots
         if (sp > need) need = sp;
@@ -532,7 +625,19 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
     }
     const int grid = g.nCoT * g.nCiT * g.S;
     int Stot = g.S * g.SW;
-    const bool split_math = uz::wgrad_split_ok(Cin, Cout, N, H, W, ks);
+    const bool thin = wgrad_thin_ok(Cin, Cout, N, H, W, ks);
+    if (thin) {                                   // 1..4 input channels: streaming reduction (same slab layout, ordered reduce below)
+        const int tiles_img = H / THIN_ROWS, total = N * tiles_img;
+        Stot = wgrad_thin_slabs(N, H);
+        const int per_wg = uz::ceil_div(total, Stot);
+        Stot = uz::ceil_div(total, per_wg);
+        UZ_REQUIRE(workspace_bytes >= (size_t)Stot * 9 * Cout * Cin * sizeof(float), "conv_bwd_weight: workspace too small for the thin-input path");
+        const dim3 tg(Stot, uz::ceil_div(Cout, THIN_CO));
+#define UZ_THIN(C_) hipLaunchKernelGGL(wgrad_thin_kernel<C_>, tg, dim3(256), 0, st, x, CinTot, dy, CoutTot, Cout, p.slab, N, H, W, tiles_img, per_wg)
+        if (Cin == 1) UZ_THIN(1); else if (Cin == 2) UZ_THIN(2); else if (Cin == 3) UZ_THIN(3); else UZ_THIN(4);
+#undef UZ_THIN
+    }
+    const bool split_math = !thin && uz::wgrad_split_ok(Cin, Cout, N, H, W, ks);
     if (split_math) {                              // large layers: split-fp16 matrix pipe (conv_wgrad_split.hip), same slab layout
         Stot = uz::wgrad_split_splits(Cin, Cout, N, H, W);
         const size_t slab_bytes = (size_t)Stot * 9 * Cout * Cin * sizeof(float);
@@ -584,7 +689,7 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         else if (g.WN == 2) UZ_WG_FAST(1, 2, THF_, TW_);                             \
         else UZ_WG_FAST(1, 1, THF_, TW_);                                            \
     } while (0)
-    if (split_math) {
+    if (split_math || thin) {
     } else if (fast) {
         if (g.TW == 32 && g.TH == 4) UZ_WG_FAST_T(4, 32);
         else if (g.TW == 32) UZ_WG_FAST_T(2, 32);
