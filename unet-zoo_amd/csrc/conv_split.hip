@@ -323,7 +323,9 @@ int launch(const SP& p, int grid, hipStream_t st) {
 inline bool small_geo(int W) { return W <= 32; }       // measured: 16 x 16 tiles win or tie on 32 x 32 planes (128 -> 128: 91 -> 67 us), lose on 64 x 64
 inline int tile_w(int W) { return small_geo(W) ? 16 : 32; }
 // 16 x 16 tiles carry 32 output channels (64 was measured 8 - 30 % slower: the layers that use this geometry want workgroups)
-inline int tile_cot(int Mc, int W) { return (small_geo(W) || Mc <= 32) ? 32 : 64; }
+// ... and on the large planes when the contraction is short (Kc <= 32: two chunks, the workgroup is mostly prologue and
+// epilogue): the 32-channel kernel keeps two workgroups per CU, the 64-channel one a single one (32 -> 96 @ 128 x 128: 202 -> 185 us).
+inline int tile_cot(int Kc, int Mc, int W) { return (small_geo(W) || Mc <= 32 || Kc <= 32) ? 32 : 64; }
 
 }  // namespace
 
@@ -357,7 +359,7 @@ namespace {
 // there, more resident waves are what it lacks - and the partial sums are added in order by splitk_reduce.
 int split_parts(int Kc, int Mc, int N, int H, int W) {
     if (!small_geo(W)) return 1;
-    const int cot = tile_cot(Mc, W), nChunks = ceil_div(Kc, CK);
+    const int cot = tile_cot(Kc, Mc, W), nChunks = ceil_div(Kc, CK);
     const long long g = (long long)N * ceil_div(H, TH) * ceil_div(W, 16) * ceil_div(Mc, cot);
     if (g >= 384) return 1;
     int S = (int)((768 + g / 2) / g);
@@ -366,7 +368,7 @@ int split_parts(int Kc, int Mc, int N, int H, int W) {
     return S < 1 ? 1 : S;
 }
 size_t image_bytes(int Kc, int Mc, int W) {
-    const int cot = tile_cot(Mc, W);
+    const int cot = tile_cot(Kc, Mc, W);
     const size_t b = (size_t)ceil_div(Kc, CK) * ceil_div(Mc, cot) * NP * (KK * cot * CK * 2);
     return (b + 255) / 256 * 256;
 }
@@ -427,7 +429,7 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     p.x_amax = x_amax; p.w_amax = w_amax; p.y_amax = y_amax;
     p.N = N; p.H = H; p.W = W; p.HW = H * W;
     p.Cin = Kc; p.CinTot = KcTot; p.Cout = Mc; p.CoutTot = McTot;
-    const int tw = tile_w(W), cot = tile_cot(Mc, W);
+    const int tw = tile_w(W), cot = tile_cot(Kc, Mc, W);
     p.tilesX = ceil_div(W, tw); p.tilesY = ceil_div(H, TH);
     p.relu = relu; p.accumulate = accumulate;
     p.nCoTiles = ceil_div(Mc, cot);
@@ -486,10 +488,10 @@ extern "C" size_t uz_conv_packed_bytes(int Cin, int Cout, int W, int dgrad) {
     return dgrad ? uz::image_bytes(Cout, Cin, W) : uz::image_bytes(Cin, Cout, W);
 }
 extern "C" int uz_conv_pack_rows(int Cin, int Cout, int W, int dgrad) {
-    const int Kc = dgrad ? Cout : Cin, Mc = dgrad ? Cin : Cout, cot = tile_cot(Mc, W);
+    const int Kc = dgrad ? Cout : Cin, Mc = dgrad ? Cin : Cout, cot = tile_cot(Kc, Mc, W);
     return uz::ceil_div(Kc, CK) * uz::ceil_div(Mc, cot) * KK * cot;
 }
-extern "C" int uz_conv_pack_cot(int Cin, int Cout, int W, int dgrad) { return tile_cot(dgrad ? Cin : Cout, W); }
+extern "C" int uz_conv_pack_cot(int Cin, int Cout, int W, int dgrad) { return tile_cot(dgrad ? Cout : Cin, dgrad ? Cin : Cout, W); }
 extern "C" int uz_conv_pack_weights(const int64_t* table, int n_layers, int total_rows, const float* w_amax, void* stream) {
     UZ_REQUIRE(table && w_amax && n_layers >= 0 && total_rows >= 0, "conv_pack_weights: null argument");
     if (n_layers == 0 || total_rows == 0) return 0;
