@@ -81,8 +81,12 @@ class NativeModel(nn.Module):
             self._plans[key] = p
         return p
 
+    default_lanes = 2          # dependency lanes of the captured graphs (UZ_LANES overrides); see ProbabilisticUnet
+
     def _new_plan(self, N, bn_training):
         plan = Plan(N, self._ptab, bn_training, self.device)
+        if "UZ_LANES" not in __import__("os").environ:
+            plan.n_lanes = self.default_lanes
         dp = getattr(self, "_dp", None)
         if dp is not None and dp.overlap:
             plan.grad_buckets = list(dp.buckets)
