@@ -11,6 +11,12 @@ the reference's op graph, written functionally over a ``state_dict``-keyed
 parameter dictionary, with the latent noise eps as an explicit input.  Each
 function cites the reference file:line it restates.
 
+Second part, plain C (``oracle/uz_cpu.c`` -> ``oracle/_build/libuz_cpu.so``, built
+by ``make -C oracle`` / ``__graft_entry__.build()``): scalar ``uz_cpu_*`` twins of the
+C-ABI entry points with the SAME argument lists minus the stream,
+checked against ``torch.nn.functional`` on the CPU and used as the checker of the HIP
+kernels through identical calls (``tests/test_cpu_twins.py``).
+
 Pinning: the reference has no tests or golden vectors for this path
 (SURVEY.md section 4 / 8c), so the oracle is pinned against outputs of the
 reference itself, generated in the build container by
