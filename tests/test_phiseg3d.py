@@ -186,12 +186,26 @@ def _run_native(meta, arrays, reversible=False, sd=None, training=True):
     return net, s, loss
 
 
+@pytest.fixture
+def conv_math(request):
+    """`split`: the split-fp16 kernels (and the pre-packed depth-window weight images) on every 3x3x3 layer, also on planes the
+    default policy leaves to the fp32 kernels - the fixtures' volumes are small."""
+    from unet_zoo_amd import _ffi
+    if request.param == "split":
+        _ffi.lib().uz_set_conv_math(2)
+    yield request.param
+    _ffi.lib().uz_set_conv_math(-1)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("conv_math", ["default", "split"], indirect=True)
 @pytest.mark.parametrize("name", ["phiseg3d_small", "phiseg3d_l3"])
-def test_native_model_vs_reference_modules(name):
+def test_native_model_vs_reference_modules(name, conv_math):
     arrays, meta = G.load(name)
     L = meta["latent_levels"]
     net, s, loss = _run_native(meta, arrays)
+    if conv_math == "split":
+        assert len(net._cur._packs["fwd"]) > 10 and len(net._cur._packs["bwd"]) > 10
     tol = lambda ref: 1e-4 * max(1.0, float(np.abs(ref).max()))     # noqa: E731  (north_star: within 1e-4 fp32)
     for l in range(L):
         for attr, key in ((net.posterior_mu, "post_mu"), (net.posterior_sigma, "post_sigma"), (net.posterior_latent_space, "post_z"),

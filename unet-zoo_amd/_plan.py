@@ -295,14 +295,17 @@ class Plan:
             # (csrc/vol.hip); the weights are permuted to [co][kd][ci][3][3] first
             assert wrow0 == 0
             x = self._window_input(x, wkey)
-            wp = self.vec(wkey + ":w3d_fwd", cout * cin * 27)
             ws = self.L.uz_conv_workspace(3 * cin, cout, x.N, x.H, x.W, 3)
             self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
             self._newgroup()
-            self._emit(self.target, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp], i=[cout, cin, 0])
+            packed = self._packed(wkey, cin, cout, x, False, vol=True)
+            wp = self.P(wkey)                                  # (unused by the kernel when the image is pre-packed)
+            if packed is None:
+                wp = self.vec(wkey + ":w3d_fwd", cout * cin * 27)
+                self._emit(self.target, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp], i=[cout, cin, 0])
             self._emit(self.target, "UZ_OP_CONV_FWD",
                        p=[("win", x), wp, self.P(bkey) if bkey else None, y, ("scratch", "wgrad"), self.amax_in(x), ("amax", 0),
-                          self.amax_out(y) if relu else None],
+                          self.amax_out(y) if relu else None, packed],
                        i=[3 * cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, 3, relu], n=ws)
             return
         wextra = wrow0 * cin * ks * ks
@@ -332,12 +335,15 @@ class Plan:
             x = x_orig
             if x.buf.requires_grad:
                 acc = self._claim(x)
-                wp2 = self.vec(wkey + ":w3d_bwd", cout * cin * 27)
                 ws2 = self.L.uz_conv_workspace(cin, 3 * cout, x.N, x.H, x.W, 3)
                 self.scratch["wgrad"] = max(self.scratch["wgrad"], ws2)
-                self._emit(self.bwd_ops, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp2], i=[cout, cin, 1])
+                packed = self._packed(wkey, cin, cout, x, True, vol=True)
+                wp2 = self.P(wkey)
+                if packed is None:
+                    wp2 = self.vec(wkey + ":w3d_bwd", cout * cin * 27)
+                    self._emit(self.bwd_ops, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp2], i=[cout, cin, 1])
                 self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
-                           p=[("gywin",), wp2, self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0)],
+                           p=[("gywin",), wp2, self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0), packed],
                            i=[3 * cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, 3, acc], n=ws2)
             return
         wextra = wrow0 * cin * ks * ks
@@ -356,11 +362,14 @@ class Plan:
                        p=[gy, self.P(wkey, wextra), self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0), packed],
                        i=[cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, ks, acc], n=ws2)
 
-    def _packed(self, wkey, cin, cout, x, dgrad):
+    def _packed(self, wkey, cin, cout, x, dgrad, vol=False):
         """Reference to the pre-packed split-fp16 weight image of this layer and direction, or None when the call packs its
         own (layers off the split path, extra tapes).  All images of a tape are packed by ONE launch at its head
         (uz_conv_pack_weights) instead of one small launch in front of every convolution."""
-        if os.environ.get("UZ_PREPACK", "1") != "1" or self.L.uz_conv_route(1 if dgrad else 0, cin, cout, x.N, x.H, x.W, 3) != 1:
+        # a Conv3d runs as a 2-D convolution whose contraction side has 3 C channels (the depth window): the image is packed
+        # straight from the [Cout][Cin][3][3][3] parameter (no permutation pass)
+        gcin, gcout = (cin, 3 * cout) if (vol and dgrad) else ((3 * cin, cout) if vol else (cin, cout))
+        if os.environ.get("UZ_PREPACK", "1") != "1" or self.L.uz_conv_route(1 if dgrad else 0, gcin, gcout, x.N, x.H, x.W, 3) != 1:
             return None
         if not dgrad and self.target is not self.fwd_ops and self.target is not self.bwd_ops:
             return None                                        # extra (decode) tapes: the call packs its own image
@@ -369,9 +378,10 @@ class Plan:
             return None                                        # (a forward convolution that only exists in the backward tape)
         lst = self._packs[which]
         if wkey not in lst:
-            lst[wkey] = dict(idx=len(lst), cin=cin, cout=cout, W=x.W, dgrad=int(dgrad),
-                             bytes=self.L.uz_conv_packed_bytes(cin, cout, x.W, int(dgrad)),
-                             rows=self.L.uz_conv_pack_rows(cin, cout, x.W, int(dgrad)), cot=self.L.uz_conv_pack_cot(cin, cout, x.W, int(dgrad)))
+            lst[wkey] = dict(idx=len(lst), cin=cin, cout=cout, W=x.W, dgrad=int(dgrad), vol=int(vol),
+                             mc=gcin if dgrad else gcout, kc=gcout if dgrad else gcin,
+                             bytes=self.L.uz_conv_packed_bytes(gcin, gcout, x.W, int(dgrad)),
+                             rows=self.L.uz_conv_pack_rows(gcin, gcout, x.W, int(dgrad)), cot=self.L.uz_conv_pack_cot(gcin, gcout, x.W, int(dgrad)))
         e = lst[wkey]
         assert (e["cin"], e["cout"], e["W"]) == (cin, cout, x.W), f"{wkey}: one weight, two convolution shapes"
         return ("packw", which, wkey)
@@ -866,8 +876,8 @@ class Plan:
                 e["off"], e["row0"] = off, rows
                 off += e["bytes"]
                 rows += e["rows"]
-                mc, kc = (e["cin"], e["cout"]) if e["dgrad"] else (e["cout"], e["cin"])
-                refs += [self.P(wkey), ("packw", which, wkey), ("raw", mc), ("raw", kc), ("raw", e["cin"]), ("raw", e["cot"]), ("raw", e["dgrad"]), ("raw", e["row0"])]
+                refs += [self.P(wkey), ("packw", which, wkey), ("raw", e["mc"]), ("raw", e["kc"]), ("raw", e["cin"]), ("raw", e["cot"]),
+                         ("raw", e["dgrad"] | (e["vol"] << 1)), ("raw", e["row0"])]
             self._packbuf[which] = self.vec("packed_weights:" + which, off // 4)
             pack_ops[which] = dict(code="UZ_OP_PACK_WEIGHTS", p=[self.ptr_table(refs), ("amaxw", 0), self._packbuf[which]], i=[len(lst), rows], f=[], n=0, gid=head)
         if "bwd" in pack_ops and self.bwd_ops:

@@ -457,7 +457,9 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
 
 namespace {
 // All weight images of a tape in ONE launch.  table: n_layers rows of 8 int64 {w (address), packed (address), Mc, Kc, wCi,
-// cot, dgrad, first row}; a workgroup finds its layer by bisection over the first-row column.
+// cot, flags, first row}; a workgroup finds its layer by bisection over the first-row column.  flags bit 0 = data gradient,
+// bit 1 = Conv3d weight [Cout][Cin][3][3][3] read straight into the depth-window layout of csrc/vol.hip (forward: contraction
+// index k = kd Cin + ci; data gradient: k = j Cout + co with kd = 2 - j), wCi = the 3-D Cin.
 __global__ __launch_bounds__(256) void pack_all_kernel(const long long* __restrict__ table, int n_layers, int total_rows, const float* __restrict__ w_amax) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= total_rows) return;
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const long long* __restri
     const long long* t = table + 8 * lo;
     const float* w = reinterpret_cast<const float*>(t[0]);
     char* packed = reinterpret_cast<char*>(t[1]);
-    const int Mc = (int)t[2], Kc = (int)t[3], wCi = (int)t[4], COT = (int)t[5], dgrad = (int)t[6], r = e - (int)t[7];
+    const int Mc = (int)t[2], Kc = (int)t[3], wCi = (int)t[4], COT = (int)t[5], dgrad = (int)t[6] & 1, vol = (int)t[6] >> 1, r = e - (int)t[7];
     const int nCoTiles = (Mc + COT - 1) / COT;
     const int m = r % COT, t1 = r / COT, tap = t1 % KK, t2 = t1 / KK, coT = t2 % nCoTiles, c = t2 / nCoTiles;
     const int mo = coT * COT + m;
@@ -475,7 +477,11 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const long long* __restri
     for (int k = 0; k < CK; ++k) {
         const int kk = c * CK + k;
         float x = 0.f;
-        if (mo < Mc && kk < Kc) x = dgrad ? w[((size_t)kk * wCi + mo) * KK + tap] : w[((size_t)mo * wCi + kk) * KK + tap];
+        if (mo < Mc && kk < Kc) {
+            if (!vol) x = dgrad ? w[((size_t)kk * wCi + mo) * KK + tap] : w[((size_t)mo * wCi + kk) * KK + tap];
+            else if (!dgrad) { const int kd = kk / wCi, ci = kk - kd * wCi; x = w[(((size_t)mo * wCi + ci) * 3 + kd) * KK + tap]; }
+            else { const int C3o = Kc / 3, j = kk / C3o, co = kk - j * C3o; x = w[(((size_t)co * wCi + mo) * 3 + (2 - j)) * KK + tap]; }
+        }
         v[k] = x;
     }
     const int tapL = dgrad ? KK - 1 - tap : tap;
