@@ -268,6 +268,48 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const float* __restric
     if (y_amax) uz::amax_publish(vmax, y_amax);
 }
 
+
+// ---------------------------------------------------------------- 3x3 forward of the 1..4-channel input layers
+// The first convolution of every encoder (image / image + one-hot mask -> 32 channels at full resolution) writes 32x more than
+// it reads: a streaming kernel - one thread per output pixel keeps its 9 Cin inputs in registers and walks the output channels,
+// weights broadcast from LDS, every store a coalesced row of pixels - instead of an MFMA tile that would be 3 % full.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_thin_fwd_kernel(const float* __restrict__ x, int CinTot, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int Cout, int CoutTot, int H, int W, int relu, float* __restrict__ y_amax) {
+    extern __shared__ float wl[];                           // [Cout][CIN * 9] + [Cout] bias
+    const int HW = H * W, b = blockIdx.y;
+    for (int e = threadIdx.x; e < Cout * CIN * 9; e += 256) wl[e] = w[e];
+    for (int e = threadIdx.x; e < Cout; e += 256) wl[Cout * CIN * 9 + e] = bias ? bias[e] : 0.f;
+    __syncthreads();
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    float vmax = 0.f;
+    if (q < HW) {
+        const int yy = q / W, xx = q - yy * W;
+        float xin[CIN * 9];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int sy = yy + t / 3 - 1, sx = xx + t % 3 - 1;
+                xin[c * 9 + t] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[((size_t)b * CinTot + c) * HW + (size_t)sy * W + sx] : 0.f;
+            }
+        float* yo = y + (size_t)b * CoutTot * HW + q;
+        for (int co = 0; co < Cout; ++co) {
+            const float* wr = wl + co * CIN * 9;
+            float acc = wl[Cout * CIN * 9 + co];
+#pragma unroll
+            for (int k = 0; k < CIN * 9; ++k) acc += wr[k] * xin[k];
+            if (relu) acc = fmaxf(acc, 0.f);
+            yo[(size_t)co * HW] = acc;
+            vmax = fmaxf(vmax, fabsf(acc));
+        }
+    }
+    if (y_amax) uz::amax_publish(vmax, y_amax);
+}
+inline bool conv_thin_ok(int Cin, int Cout, int N, int H, int W, int ks) {
+    return ks == 3 && Cin <= 4 && Cout <= 256 && (long long)N * H * W >= 64 * 1024 && N <= 65535;
+}
+
 struct Geom { int TW, TH, TB, PW, PSI, PS, tilesX, tilesY, tilesB; };
 
 // Split the input-channel loop over several workgroups when the output grid alone cannot fill the
@@ -409,6 +451,14 @@ extern "C" int uz_conv_fwd_packed(const float* x, int Cin, int CinTot, const flo
     if (ks == 1 && !relu && uz::conv1x1_small_ok(Cin, Cout)) {        // 2..8-output heads: streaming VALU kernel
         const int rc = uz::conv1x1_small_fwd(x, Cin, CinTot, w, bias, y, Cout, CoutTot, N, H, W, uz::S(stream));
         if (rc != -2) return rc;
+    }
+    if (conv_thin_ok(Cin, Cout, N, H, W, ks) && !packed_w) {           // 1..4 input channels at full resolution: streaming kernel
+        const dim3 grid(uz::ceil_div(H * W, 256), N);
+        const size_t smem = (size_t)(Cout * Cin * 9 + Cout) * sizeof(float);
+#define UZ_THINF(C_) hipLaunchKernelGGL(conv_thin_fwd_kernel<C_>, grid, dim3(256), smem, uz::S(stream), x, CinTot, w, bias, y, Cout, CoutTot, H, W, relu, y_amax)
+        if (Cin == 1) UZ_THINF(1); else if (Cin == 2) UZ_THINF(2); else if (Cin == 3) UZ_THINF(3); else UZ_THINF(4);
+#undef UZ_THINF
+        return uz::check_launch("conv_thin_fwd_kernel");
     }
     return uz::conv_mfma(x, Cin, CinTot, w, Cin, bias, y, Cout, CoutTot, N, H, W, ks, 0, relu, 0, x_amax, w_amax, y_amax, workspace, workspace_bytes, packed_w, uz::S(stream));
 }

@@ -587,6 +587,9 @@ extern "C" size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, 
 // kind 0 = forward, 1 = data gradient, 2 = weight gradient; returns 0 fp32 MFMA, 1 split-fp16 MFMA, 2 streaming VALU (1x1 heads).
 extern "C" int uz_conv_route(int kind, int Cin, int Cout, int N, int H, int W, int ks) {
     if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) return 2;
+    const bool thin = ks == 3 && Cin <= 4 && (long long)N * H * W >= 64 * 1024;       // 1..4-channel input layers: streaming kernels
+    if (kind == 0 && thin && Cout <= 256 && N <= 65535) return 2;
+    if (kind == 2 && wgrad_thin_ok(Cin, Cout, N, H, W, ks)) return 2;
     if (kind == 0) return uz::conv_split_ok(Cin, Cout, N, H, W, ks) ? 1 : 0;
     if (kind == 1) return uz::conv_split_ok(Cout, Cin, N, H, W, ks) ? 1 : 0;
     return uz::wgrad_split_ok(Cin, Cout, N, H, W, ks) ? 1 : 0;
