@@ -7,6 +7,7 @@ be *constructed* without a GPU (state_dict surface, plan building - used by the 
 any attempt to execute raises: there is no CPU fallback.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -85,7 +86,7 @@ class NativeModel(nn.Module):
 
     def _new_plan(self, N, bn_training):
         plan = Plan(N, self._ptab, bn_training, self.device)
-        if "UZ_LANES" not in __import__("os").environ:
+        if "UZ_LANES" not in os.environ:
             plan.n_lanes = self.default_lanes
         dp = getattr(self, "_dp", None)
         if dp is not None and dp.overlap:
