@@ -388,3 +388,43 @@ def test_conv_split_fp16_math_on_every_conv_shape():
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_phiseg_gpu.py", "-q", "-x", "-k", "train_steps or b32_digest or fp64 or argmax"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_prepacked_weight_images_equal_in_call_packing():
+    """uz_conv_pack_weights + uz_conv_fwd_packed / uz_conv_bwd_data_packed (one pack launch for many layers) against the plain
+    entry points that pack inside the call: bit-identical results on two layers of different shapes sharing one table."""
+    from unet_zoo_amd import _ffi
+    g = _g()
+    L = _ffi.lib()
+    L.uz_set_conv_math(2)                                     # split path on these (small) shapes
+    try:
+        layers = [(2, 32, 48, 32, 32), (2, 64, 32, 16, 48)]   # N, Cin, Cout, H, W
+        ws_b = max(L.uz_conv_workspace(ci, co, n, h, w, 3) for n, ci, co, h, w in layers)
+        ws = torch.empty(ws_b // 4 + 16, device=g.dev())
+        bound = torch.zeros(256, device=g.dev())              # one bound slot for every weight, as the plans do
+        ws_all, table, rows = [], [], 0
+        data = []
+        for k, (n, ci, co, h, w) in enumerate(layers):
+            wt = g.rnd(co, ci, 3, 3, seed=10 + k, scale=0.2).to(g.dev())
+            g.call("uz_absmax", wt, wt.numel(), bound)
+            data.append((wt, g.rnd(n, ci, h, w, seed=20 + k).to(g.dev()), g.rnd(n, co, h, w, seed=30 + k).to(g.dev())))
+        for (n, ci, co, h, w), (wt, _, _) in zip(layers, data):
+            for dgrad in (0, 1):
+                img = torch.empty(L.uz_conv_packed_bytes(ci, co, w, dgrad) // 4 + 4, device=g.dev())
+                mc, kc = (ci, co) if dgrad else (co, ci)
+                table += [wt.data_ptr(), img.data_ptr(), mc, kc, ci, L.uz_conv_pack_cot(ci, co, w, dgrad), dgrad, rows]
+                rows += L.uz_conv_pack_rows(ci, co, w, dgrad)
+                ws_all.append(img)
+        tab = torch.tensor(table, dtype=torch.int64, device=g.dev())
+        g.call("uz_conv_pack_weights", tab, len(ws_all), rows, bound)
+        for k, ((n, ci, co, h, w), (wt, x, dy)) in enumerate(zip(layers, data)):
+            y0, y1 = torch.empty(n, co, h, w, device=g.dev()), torch.empty(n, co, h, w, device=g.dev())
+            g.call("uz_conv_fwd", x, ci, ci, wt, None, y0, co, co, n, h, w, 3, 0, None, bound, None, ws, ws_b)
+            g.call("uz_conv_fwd_packed", x, ci, ci, wt, None, y1, co, co, n, h, w, 3, 0, None, bound, None, ws, ws_b, ws_all[2 * k])
+            assert torch.equal(y0, y1)
+            d0, d1 = torch.empty(n, ci, h, w, device=g.dev()), torch.empty(n, ci, h, w, device=g.dev())
+            g.call("uz_conv_bwd_data", dy, co, co, wt, d0, ci, ci, n, h, w, 3, 0, None, bound, ws, ws_b)
+            g.call("uz_conv_bwd_data_packed", dy, co, co, wt, d1, ci, ci, n, h, w, 3, 0, None, bound, ws, ws_b, ws_all[2 * k + 1])
+            assert torch.equal(d0, d1)
+    finally:
+        L.uz_set_conv_math(-1)
