@@ -264,14 +264,13 @@ bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks) {
 static inline int tile_w(int W) { return W == 16 ? 16 : 32; }
 static inline int chan_tile(int Cin, int Cout) { return (Cin <= 32 || Cout <= 32) ? 32 : 64; }
 
-// number of pixel splits: one (64-channel tiles, 147 KB of LDS) or two (32-channel tiles, 74 KB) workgroups per CU,
-// at most one split per pixel tile
+// number of pixel splits: one workgroup per CU, at most one split per pixel tile
 int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
     const int ct = chan_tile(Cin, Cout);
     const int nt = ceil_div(Cout, ct) * ceil_div(Cin, ct);
     const int tw = tile_w(W);
     const int T = N * ceil_div(H, PT / tw) * (W / tw);
-    int s = (ct == 64 ? 256 : 512) / nt;
+    int s = 256 / nt;                                  // one workgroup per CU either way (the 32-channel kernel's 166 VGPRs allow no second one: 512 splits measured 6 % slower)
     if (s < 1) s = 1;
     if (s > T) s = T;
     return s;
