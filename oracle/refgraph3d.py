@@ -97,8 +97,6 @@ def likelihood3d(sd, z, bn_train, full_size=None):
     reference's own resize call raises, see the module docstring) and un-resized."""
     root = "likelihood"
     L = len(z)
-    nf_ups = [sd[f"{root}.likelihood_ups_path.{k}.convolution.0.convolution.0.weight"].shape[0]
-              if f"{root}.likelihood_ups_path.{k}.convolution.0.convolution.0.weight" in sd else None for k in range(L)]
     diff = 0
     while f"{root}.likelihood_post_ups_path.0.{2 * diff + 1}.convolution.0.convolution.0.weight" in sd:
         diff += 1
@@ -120,7 +118,6 @@ def likelihood3d(sd, z, bn_train, full_size=None):
     for k in range(L):
         s_in[-k - 1] = conv_bare(sd, f"{root}.s_layer.{k}.convolution.0", post_c[-k - 1])
         s[-k - 1] = F.interpolate(s_in[-k - 1], size=list(full_size), mode="nearest") if full_size is not None else s_in[-k - 1]
-    del nf_ups
     return s, s_in
 
 
