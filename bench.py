@@ -284,6 +284,63 @@ def fp32_only_leg(args):
         return dict(error=str(e)[:200])
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, torchrun's environment
+    contract) and relay rank 0's JSON line.  Runs BEFORE this process makes any GPU call - the children are new processes,
+    never a re-exec of a GPU-initialised one."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UZ_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for q in procs[1:]:
+        try:
+            rcs.append(q.wait(timeout=120))
+        except subprocess.TimeoutExpired:           # rank 0 is gone: a peer still waiting in a collective will never finish
+            q.kill()
+            rcs.append(q.wait())
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def dry_run(args, rank, world, global_batch):
+    """UZ_BENCH_DRY=1 (CPU test hook, never used by the driver): the launcher / rendezvous / timing / reporting skeleton of main()
+    with a sleep in place of the training step - checks that `--gpus N` really runs N ranks and reports that number."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    elapsed = time.perf_counter() - t0
+    nranks = 1
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+        nranks = dist.get_world_size()
+    if rank == 0:
+        print(json.dumps(dict(metric="dry run (no GPU work)", value=round(args.batch * world * args.steps / elapsed, 2), unit="images/s", n_gpus=world,
+                              steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True,
+                              scaling="strong" if args.strong else "weak", vs_baseline=None, dtype="none", data="none",
+                              config=dict(workload="dry run", batch_per_gpu=args.batch, global_batch=global_batch, parallelism=f"dp{world}"),
+                              dp=dict(backend="gloo", nranks=nranks, launcher="self" if os.environ.get("UZ_BENCH_SELF_LAUNCHED") else "external"))))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -413,19 +470,32 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU-oracle leg (BASELINE.md section 3: 32)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32-MFMA-only measurement (child process)")
     ap.add_argument("--no-overlap", action="store_true", help="data parallel: one blocking all-reduce after backward instead of bucketed overlap")
+    ap.add_argument("--strong", action="store_true", help="strong scaling (SURVEY 8d): the GLOBAL batch stays at --batch (default 32), "
+                                                          "each of the N GPUs takes batch / N images")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would report a GPU count that is not the number of ranks")
     M = dict(MODELS[args.model])
     vol = args.model == "phiseg3d"
     if args.batch is None:
         args.batch = 1 if vol else 32
     if vol and args.batch != 1:
         raise SystemExit("phiseg3d runs one volume per GPU and step (BASELINE configs[4]: batch 8 on 8 GPUs)")
+    global_batch = args.batch * world
+    if args.strong:
+        if vol or args.batch % world:
+            raise SystemExit(f"--strong: the global batch {args.batch} must divide over {world} GPUs (2-D models only)")
+        global_batch, args.batch = args.batch, args.batch // world
+
+    if os.environ.get("UZ_BENCH_DRY") == "1":
+        return dry_run(args, rank, world, global_batch)
 
     # the fp32-MFMA-only comparison leg runs in a child process BEFORE this process initialises the GPU
     f32_leg = None
@@ -441,12 +511,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
+        # Control plane = a gloo group on the host (unique-id hand-off, barriers, the max over ranks of the elapsed time).
+        # The ONLY RCCL communicator of the process is the one GradSync opens through the C ABI (uz_comm_init); parameters are
+        # broadcast and gradients averaged on it.  UZ_BENCH_BACKEND=gloo (test hook) moves the data plane to gloo as well.
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     if world > 1:
         # data parallel: train on a created stream - the overlapped gradient exchange needs a second stream, and the legacy
@@ -461,8 +531,10 @@ def main():
     net = build(args.model, args.reversible)
     net.train()
     if world > 1:
-        dist.broadcast(net._ptab.pflat, src=0)
-        net.set_data_parallel(True, overlap=not args.no_overlap)
+        net.set_data_parallel(True, overlap=not args.no_overlap, backend="rccl" if backend == "nccl" else "torch")
+        net._dp.broadcast_params()
+        if net._dp.backend == "rccl" and net._dp.nranks() != world:
+            raise SystemExit(f"RCCL reports {net._dp.nranks()} ranks but WORLD_SIZE={world}")
     if not args.no_graphs:
         net.enable_graphs(True)
     opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)        # train_model.py:49
@@ -502,7 +574,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss.detach())
@@ -591,17 +663,21 @@ def main():
                      "weight gradient; share in roofline.flop_share_by_pipe): operands scaled by a power of two and split into 2 fp16 pieces, 3 piece "
                      "products on the fp16 matrix pipe (error vs fp64 no larger than the fp32-MFMA kernels', tests/test_full_configs_gpu.py); other layers: fp32 MFMA")
         line = dict(metric=M["metric"], value=round(ips, 3 if vol else 2), unit=M.get("unit", "images/s"), n_gpus=world,
-                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
+                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="strong" if args.strong else "weak",
                     vs_baseline=None, dtype="f32", data="synthetic",
-                    config=dict(workload=M["workload"], batch_per_gpu=args.batch, global_batch=args.batch * world, parallelism=f"dp{world}",
+                    config=dict(workload=M["workload"], batch_per_gpu=args.batch, global_batch=global_batch, parallelism=f"dp{world}",
                                 graphs=not args.no_graphs, final_loss=final_loss, conv_math=math_note),
                     roofline=roof)
         if world > 1:
             line["config"]["allreduce"] = "bucketed, overlapped with backward" if not args.no_overlap else "one blocking all-reduce after backward"
             sync = getattr(net, "_dp", None)
             if sync is not None:
-                line["dp"] = dict(backend=sync.backend, buckets_MB=[round(4 * (hi - lo) / 1e6, 1) for lo, hi in sync.buckets],
-                                  exposed_allreduce_ms_last_step=sync.exposed_ms())
+                line["dp"] = dict(backend=sync.backend, nranks=sync.nranks(), control_plane="gloo (host): unique id, barriers, max of elapsed",
+                                  communicators=1 if sync.backend == "rccl" else 0, launcher="self" if os.environ.get("UZ_BENCH_SELF_LAUNCHED") else "external",
+                                  buckets_MB=[round(4 * (hi - lo) / 1e6, 1) for lo, hi in sync.buckets],
+                                  exposed_allreduce_ms=sync.exposed_ms())
+                if line["dp"]["nranks"] != world:
+                    raise SystemExit(f"data-parallel group reports {line['dp']['nranks']} ranks, the line says {world}")
         line.update(extra)
         if f32_leg is not None:
             line["fp32_mfma_only"] = f32_leg

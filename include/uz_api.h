@@ -233,6 +233,10 @@ int uz_add_views(const float* a, int CtotA, const float* b, int CtotB, float* y,
 int uz_absmax(const float* x, size_t n, float* slot, void* stream);
 /* dst bound slot = max(dst, value of src bound slot): forwards a magnitude bound through ops that cannot raise it (pooling, interpolation) */
 int uz_absmax_copy(const float* src_slot, float* dst_slot, void* stream);
+/* diagnostics: when buf is non-null the split-fp16 convolution kernels write 8 int64 per workgroup (first 4096 workgroups):
+ * shader-clock stamps at start / first tile staged / sum of the staging phases / main loop end / kernel end, the
+ * 100 MHz real-time counter at start and end, and the workgroup's tile count (tools/stamp_conv.py).  NULL switches it off. */
+void uz_debug_stamps(void* buf);
 int uz_scale(float* y, float alpha, size_t n, void* stream);                    /* y *= alpha   */
 int uz_zero_f32(float* p, size_t n, void* stream);                              /* p[0..n) = 0  (kernel launch, graph-capturable) */
 int uz_copy_f32(float* dst, const float* src, size_t n, void* stream);          /* dst = src    (kernel launch, graph-capturable) */

@@ -139,3 +139,33 @@ def test_device_batch_assembly_matches_the_numpy_twin():
     replay = BP.BatchProvider(X, y, np.arange(N), add_dummy_dimension=True, num_labels_per_subject=A, annotator_range=range(A))
     i2 = replay._draw_indices(8); a2, _ = replay._draw(i2)
     assert np.array_equal(xb[:, 0], X[i2]) and all(np.array_equal(sb[k], y[i2[k], ..., a2[k]]) for k in range(8))
+
+
+def _prep_worker(rank, world, port, src, pre, out_dir):
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    np.random.seed(1234 + rank)                    # an unseeded split would now differ per rank
+    d = LL.load_and_maybe_process_data(src, pre)
+    np.save(os.path.join(out_dir, f"uids{rank}.npy"), np.concatenate([np.sort(np.unique(d[tt]["uids"])) for tt in ("train", "val", "test")]))
+    assert isinstance(d["train"]["images"], np.memmap)             # really memory-mapped: one host copy per process at most
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lidc_preparation_under_two_ranks_is_done_once_and_agrees(tmp_path):
+    """every rank used to prepare at once (unseeded split, racing writes).  Now rank 0 prepares into temporary
+    names, the others wait at a barrier, and the split is seeded."""
+    import socket
+    import torch.multiprocessing as mp
+    rs = np.random.default_rng(1)
+    data = {f"s{s}_{k}": dict(image=rs.random((8, 8)).astype(np.float32), masks=[(rs.random((8, 8)) > 0.5) for _ in range(4)], series_uid=f"uid{s}")
+            for s in range(30) for k in range(2)}
+    src = tmp_path / "lidc.pickle"
+    with open(src, "wb") as f:
+        pickle.dump(data, f)
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.spawn(_prep_worker, args=(2, port, str(src), str(tmp_path / "pre"), str(tmp_path)), nprocs=2, join=True)
+    assert np.array_equal(np.load(tmp_path / "uids0.npy"), np.load(tmp_path / "uids1.npy"))
+    assert not [p for p in os.listdir(tmp_path / "pre") if ".tmp" in p]                         # temporaries renamed into place
+    assert sorted(os.listdir(tmp_path / "pre")) == sorted(f"data_lidc_{tt}_{a}.npy" for tt in ("train", "test", "val") for a in LL.ARRAYS)

@@ -130,3 +130,37 @@ def test_gradsync_buckets_world2_gloo(tmp_path):
         assert np.allclose(a[:n], ref.numpy(), atol=1e-6)
         assert np.all(a[n:] == 0.0)
     assert np.array_equal(got[0], got[1])
+
+
+# ---------------------------------------------------------------------------------------------- bench.py --gpus N without a launcher
+def _run_bench(extra_args, env_extra):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra_args, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                     # ONE JSON line, printed by rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start the ranks itself and report what the group saw (dry hook: the
+    launcher, rendezvous, barrier / max-over-ranks timing and reporting code of the real run, a sleep instead of the step)."""
+    d = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], dict(UZ_BENCH_DRY="1"))
+    assert d["n_gpus"] == 2 and d["dp"]["nranks"] == 2 and d["dp"]["launcher"] == "self"
+    assert d["config"]["global_batch"] == 64 and d["config"]["batch_per_gpu"] == 32 and d["scaling"] == "weak"
+    s = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--strong"], dict(UZ_BENCH_DRY="1"))
+    assert s["n_gpus"] == 2 and s["scaling"] == "strong" and s["config"]["global_batch"] == 32 and s["config"]["batch_per_gpu"] == 16
+
+
+def test_bench_refuses_a_gpu_count_that_is_not_the_world_size():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UZ_BENCH_DRY="1", WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()

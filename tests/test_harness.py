@@ -112,3 +112,22 @@ def test_validate_and_test_loops_match_oracle_metrics(which, tmp_path):
     assert os.path.exists(ged_file) and np.load(ged_file)["arr_0"].shape == (2 * data.test.images.shape[0],)
     os.remove(os.path.join(str(tmp_path), "t", "t", "t_best_loss.pth"))
     assert h.test(data, rounds=1) is None                                         # missing checkpoint: abort like the reference (:349-352)
+
+
+def test_cli_resolves_sys_config_from_local_and_flags(tmp_path, caplog):
+    """`train_model EXP LOCAL` ignored LOCAL and always trained on synthetic data.  LOCAL may now be a sys_config file
+    (or 'local' with an importable config package); flags override single attributes; the synthetic fallback is logged loudly."""
+    import logging
+    from unet_zoo_amd import train_model as TM
+    cfg_file = tmp_path / "my_sys.py"
+    cfg_file.write_text("data_root = '/nonexistent/data_lidc.pickle'\nlog_root = '%s'\npreproc_folder = '/x/pre'\n" % (tmp_path / "logs"))
+    c = TM.resolve_sys_config(str(cfg_file))
+    assert c.data_root == "/nonexistent/data_lidc.pickle" and c.log_root == str(tmp_path / "logs") and c.preproc_folder == "/x/pre"
+    c = TM.resolve_sys_config(str(cfg_file), data_root="/d/p.pickle", log_root="/l")
+    assert c.data_root == "/d/p.pickle" and c.log_root == "/l"
+    c = TM.resolve_sys_config("local", data_root="/d/p.pickle")                  # no config package here: flags only, preproc next to the data
+    assert c.preproc_folder == "/d/preproc" and c.log_root == "./logs"
+    exp = TM.load_experiment(os.path.join(os.path.dirname(TM.__file__), "models", "experiments", "unet.py"))
+    with caplog.at_level(logging.WARNING, logger="unet_zoo_amd"):
+        data = TM.lidc_data(TM.resolve_sys_config(str(cfg_file)), exp)
+    assert isinstance(data, TM.SyntheticData) and "SYNTHETIC" in caplog.text

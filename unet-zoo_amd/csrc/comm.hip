@@ -27,6 +27,7 @@ struct Rccl {
     int (*GetUniqueId)(ncclUniqueId*) = nullptr;
     int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(ncclComm_t, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
@@ -57,6 +58,7 @@ int load(const char* path) {
     UZ_SYM(GetUniqueId, "ncclGetUniqueId");
     UZ_SYM(CommInitRank, "ncclCommInitRank");
     UZ_SYM(CommDestroy, "ncclCommDestroy");
+    UZ_SYM(CommCount, "ncclCommCount");
     UZ_SYM(AllReduce, "ncclAllReduce");
     UZ_SYM(Broadcast, "ncclBroadcast");
     UZ_SYM(GroupStart, "ncclGroupStart");
@@ -105,7 +107,14 @@ extern "C" void uz_comm_destroy(void* comm) {
     delete c;
 }
 
-extern "C" int uz_comm_size(void* comm) { return comm ? static_cast<Comm*>(comm)->nranks : -1; }
+// the communicator's size as RCCL reports it (ncclCommCount), not the number the host asked for
+extern "C" int uz_comm_size(void* comm) {
+    Comm* c = static_cast<Comm*>(comm);
+    if (!c) return -1;
+    int n = -1;
+    if (!g.CommCount || g.CommCount(c->comm, &n) != ncclSuccess) return -1;
+    return n;
+}
 
 // In-place mean over the ranks of flat[0..count): ONE ncclAllReduce(avg, f32) enqueued on `stream` (asynchronous).
 extern "C" int uz_allreduce_mean_f32(void* comm, float* flat, size_t count, void* stream) {

@@ -48,6 +48,7 @@ struct SP {
     float* y_amax;                                // nullable: atomic max of |y| (bound for the next layer's split)
     int kSplit, cps;                              // split-K: the chunk loop is shared out over kSplit workgroups, cps chunks each
     float* slab;                                  // [kSplit][N][Cout][HW] partial sums (kSplit > 1), summed in order by splitk_reduce
+    long long* stamps;                            // diagnostics (uz_debug_stamps): 8 cycle stamps per workgroup, normally null
 };
 
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 }
 
 template <int MSUB, int NTv, int TWv>
-__global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void conv_split_kernel(const SP p) {
+__global__ __launch_bounds__(NTv, (MSUB == 2 ? (NTv == 256 ? 2 : 1) : (NTv == 256 ? 3 : 4))) void conv_split_kernel(const SP p) {
     using GEO = Geo<NTv, TWv>;
     constexpr int NT = GEO::NT, TW = GEO::TW, PW = GEO::PW, PSI = GEO::PSI, PSR = GEO::PSR, G = GEO::G, CE = GEO::CE;
     constexpr int COT = 32 * MSUB;
@@ -226,12 +227,17 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void c
     };
 
     const int nChunks = cend;
+    long long st0 = 0, st1 = 0, stl = 0, rt0 = 0;
+    if (p.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) stage(cbeg, tap);
     for (int c = cbeg; c < nChunks; ++c) {
+        long long ta = 0;
+        if (p.stamps) ta = __builtin_amdgcn_s_memtime();
         __syncthreads();                       // every wave has finished the MFMAs of the previous chunk
         lstore();
         __syncthreads();
+        if (p.stamps) { const long long tb = __builtin_amdgcn_s_memtime(); if (c == cbeg) st1 = tb; else stl += tb - ta; }
         const bool more = c + 1 < nChunks;
         const char* Al = Wl + l31 * 16 + h * (WPLANE / 2);
 #pragma unroll
@@ -263,6 +269,8 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void c
         }
     }
 
+    long long st2 = 0;
+    if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
     // ---- epilogue: undo the operand scales (exact), bias, optional accumulate / ReLU, coalesced NCHW stores
     const float inv_x = uz::split_inv_scale(uz::amax_read(p.x_amax)), inv_w = uz::split_inv_scale(uz::amax_read(p.w_amax));
     if (p.kSplit > 1) {                           // partial sums only: bias / accumulate / ReLU / bound happen in the reduce
@@ -302,6 +310,14 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void c
         }
     }
     if (p.y_amax) uz::amax_publish(vmax, p.y_amax);
+    if (p.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);          // the stores have left the wave
+        const long long st3 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && blockIdx.x < 4096) {
+            long long* o = p.stamps + 8 * blockIdx.x;
+            o[0] = st0; o[1] = st1; o[2] = stl; o[3] = st2; o[4] = st3; o[5] = rt0; o[6] = rt1; o[7] = nChunks - cbeg;
+        }
+    }
 }
 
 template <int MSUB, int NTv, int TWv>
@@ -321,6 +337,7 @@ int launch(const SP& p, int grid, hipStream_t st) {
 // tile geometry of a layer: 16 x 32 tiles (512 threads, 64- or 32-channel tiles) when the plane is wider than 32,
 // else 16 x 16 tiles (256 threads, 32-channel tiles)
 inline bool small_geo(int W) { return W <= 32; }       // measured: 16 x 16 tiles win or tie on 32 x 32 planes (128 -> 128: 91 -> 67 us), lose on 64 x 64
+inline int exp_mode() { static int m = -1; if (m < 0) { const char* e = getenv("UZ_SPLIT_EXP"); m = e ? atoi(e) : 0; } return m; }
 inline int tile_w(int W) { return small_geo(W) ? 16 : 32; }
 // 16 x 16 tiles carry 32 output channels (64 was measured 8 - 30 % slower: the layers that use this geometry want workgroups)
 // ... and on the large planes when the contraction is short (Kc <= 32: two chunks, the workgroup is mostly prologue and
@@ -330,6 +347,9 @@ inline int tile_cot(int Kc, int Mc, int W) { return (small_geo(W) || Mc <= 32 ||
 }  // namespace
 
 namespace uz {
+
+long long* debug_stamps = nullptr;
+extern "C" void uz_debug_stamps(void* buf) { debug_stamps = static_cast<long long*>(buf); }
 
 // Which layers take the split-fp16 path: 3x3, enough channels for a dense contraction and enough tiles to occupy
 // the chip.  Planes wider than 32 use 16 x 32 tiles; 32 x 32 and 16 x 16 planes use 16 x 16 tiles.
@@ -429,7 +449,9 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     p.x_amax = x_amax; p.w_amax = w_amax; p.y_amax = y_amax;
     p.N = N; p.H = H; p.W = W; p.HW = H * W;
     p.Cin = Kc; p.CinTot = KcTot; p.Cout = Mc; p.CoutTot = McTot;
-    const int tw = tile_w(W), cot = tile_cot(Kc, Mc, W);
+    const int cot = tile_cot(Kc, Mc, W);
+    const bool dual = (exp_mode() & 1) && cot == 64 && !small_geo(W);          // experiment: two independent 256-thread workgroups per CU
+    const int tw = dual ? 16 : tile_w(W);
     p.tilesX = ceil_div(W, tw); p.tilesY = ceil_div(H, TH);
     p.relu = relu; p.accumulate = accumulate;
     p.nCoTiles = ceil_div(Mc, cot);
@@ -438,6 +460,7 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     p.cps = ceil_div(p.nChunks, p.kSplit);
     p.kSplit = ceil_div(p.nChunks, p.cps);               // no empty parts
     p.slab = reinterpret_cast<float*>(image + image_bytes(Kc, Mc, W));
+    p.stamps = uz::debug_stamps;
     const long long grid = (long long)p.tilesX * p.tilesY * N * p.nCoTiles * p.kSplit;
     UZ_REQUIRE(grid < (1ll << 31), "conv_split: grid too large");
     UZ_REQUIRE((size_t)Kc * p.HW * 4 < (1ull << 32) && (size_t)McTot * p.HW * N < (1ull << 31), "conv_split: tensor too large for 32-bit offsets");
@@ -447,7 +470,8 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     else hipLaunchKernelGGL(pack_weights_kernel<false>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
     if (int rc = check_launch("pack_weights_kernel")) return rc;
     int rc;
-    if (tw == 16) rc = launch<1, 256, 16>(p, (int)grid, st);
+    if (dual) rc = launch<2, 256, 16>(p, (int)grid, st);
+    else if (tw == 16) rc = launch<1, 256, 16>(p, (int)grid, st);
     else rc = cot == 32 ? launch<1, 512, 32>(p, (int)grid, st) : launch<2, 512, 32>(p, (int)grid, st);
     if (rc || p.kSplit == 1) return rc;
     return splitk_reduce(p.slab, p.kSplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax, st);

@@ -40,6 +40,7 @@ struct WS {
     int N, H, W, HW, Cin, CinTot, Cout, CoutTot;
     int tilesX, tilesY, T, S, nCoT, nCiT;
     const float* x_amax; const float* dy_amax;          // device scalars: upper bounds of |x| and |dy|
+    long long* stamps;                                  // diagnostics (uz_debug_stamps), normally null
 };
 
 
@@ -145,11 +146,16 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
         int t = split;
+        long long st0 = 0, st1 = 0, stl = 0, rt0 = 0;
+        if (p.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
         if (t < p.T) gload(t);
         for (; t < p.T; t += p.S) {
+            long long ta = 0;
+            if (p.stamps) ta = __builtin_amdgcn_s_memtime();
             __syncthreads();                   // every wave finished the MFMAs of the previous tile
             lstore();
             __syncthreads();
+            if (p.stamps) { const long long tb = __builtin_amdgcn_s_memtime(); if (t == split) st1 = tb; else stl += tb - ta; }
             if (t + p.S < p.T) gload(t + p.S); // in flight during the MFMA loop below
 #pragma unroll
             for (int si = 0; si < PT / 16 / WK; ++si) {
@@ -194,6 +200,8 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
                 }
             }
         }
+        long long st2 = 0;
+        if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
         if constexpr (WK > 1) {
             // fold the WK pixel-quarter partial sums pairwise through LDS (fixed order ((0+2)+(1+3)), three taps per
             // round so that the dead staging area suffices); group 0 writes the slab
@@ -237,6 +245,14 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
                 const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (co < p.Cout && ci < p.Cin) out[((size_t)(TAP0 + k) * p.Cout + co) * p.Cin + ci] = acc[k][r] * inv_dy * inv_x;
             }
+        if (p.stamps) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const long long st3 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0 && blockIdx.x < 4096) {
+                long long* o = p.stamps + 8 * blockIdx.x;
+                o[0] = st0; o[1] = st1; o[2] = stl; o[3] = st2; o[4] = st3; o[5] = rt0; o[6] = rt1; o[7] = (p.T - split + p.S - 1) / p.S;
+            }
+        }
     };
     if (tg == 0) run(std::integral_constant<int, 5>{}, std::integral_constant<int, 0>{});
     else run(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
@@ -292,7 +308,7 @@ static int launch_wgrad(const WS& p, int grid, hipStream_t st) {
 int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* slab,
                 int N, int H, int W, int S, const float* x_amax, const float* dy_amax, hipStream_t st) {
     WS p;
-    p.x = x; p.dy = dy; p.slab = slab; p.x_amax = x_amax; p.dy_amax = dy_amax;
+    p.x = x; p.dy = dy; p.slab = slab; p.x_amax = x_amax; p.dy_amax = dy_amax; p.stamps = debug_stamps;
     p.N = N; p.H = H; p.W = W; p.HW = H * W; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot;
     const int tw = tile_w(W), ct = chan_tile(Cin, Cout);
     p.tilesX = W / tw; p.tilesY = ceil_div(H, PT / tw); p.T = N * p.tilesX * p.tilesY; p.S = S;

@@ -10,6 +10,7 @@ namespace uz {
 void set_error(const char* fmt, ...);
 int  fail(const char* fmt, ...);          // set_error + return -1
 int  check_launch(const char* what);      // hipGetLastError -> status
+extern long long* debug_stamps;           // diagnostics: per-workgroup cycle stamps of the split kernels (uz_debug_stamps), normally null
 int  conv_math_mode();                    // 0 fp32 MFMA only | 1 split-fp16 where it pays | 2 split-fp16 wherever eligible
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }

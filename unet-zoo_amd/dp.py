@@ -36,8 +36,10 @@ def mean_scalar(t, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t
     v = t.detach().clone().reshape(1).to(torch.float32)
+    if dist.get_backend(group) == "gloo":
+        v = v.cpu()                              # host control plane: the scheduler compares on the host anyway (one sync per step)
     dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
-    return (v / dist.get_world_size(group)).reshape(())
+    return (v / dist.get_world_size(group)).reshape(()).to(t.device)
 
 
 def shard_bounds(n, rank, world):
@@ -115,6 +117,8 @@ class GradSync:
         if backend is None:
             backend = os.environ.get("UZ_DP_BACKEND") or \
                 ("rccl" if (dist.is_initialized() and dist.get_backend(group) == "nccl") else "torch")
+        if backend not in ("rccl", "torch"):
+            raise ValueError(f"GradSync backend {backend!r}: expected 'rccl' or 'torch'")
         self.backend = backend
         self.comm = self.stream = self.done = None
         self.t0 = self.t1 = None
@@ -146,6 +150,13 @@ class GradSync:
             check(L.uz_event_create(C.byref(e), timing), "event_create")
             ev.append(e.value)
         self.done, self.t0, self.t1 = ev
+
+    def nranks(self):
+        """Ranks of the data-parallel group as the communication library itself reports them (ncclCommCount behind
+        uz_comm_size for RCCL; the process group's size for the torch test double)."""
+        if self.backend == "rccl":
+            return int(self.L.uz_comm_size(self.comm))
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def broadcast_params(self):
         """Replicas start from rank 0's parameters and BatchNorm buffers."""

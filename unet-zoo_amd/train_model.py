@@ -82,6 +82,9 @@ def lidc_data(sys_config=None, exp_config=None):
     if root and os.path.exists(root):
         from .data.lidc_data import lidc_data as real
         return real(sys_config, exp_config)
+    logging.getLogger("unet_zoo_amd").warning(
+        "!!!! LIDC data not found (sys_config.data_root = %r): training on the SYNTHETIC stand-in data set. "
+        "Pass --data-root / --preproc-folder (or a sys_config module via LOCAL) to train on LIDC-IDRI.", root)
     return SyntheticData(sys_config, exp_config)
 
 
@@ -125,8 +128,11 @@ class UNetModel:
     def __init__(self, exp_config, logger=None, tensorboard=False, log_root="./logs"):
         # one process per GPU: bind this rank to cuda:LOCAL_RANK *before* any buffer is allocated (the model, the
         # optimiser state and the RCCL communicator must all live on the same device)
-        self.rank, self.local_rank, self.world = dp.init_from_env()
+        # Control plane (unique-id hand-off, barriers, the scheduler's mean loss) = a gloo group on the host; the ONE RCCL
+        # communicator of the process is opened through the C ABI by dp.GradSync (uz_comm_init).
+        self.rank, self.local_rank, self.world = dp.init_from_env(backend="gloo")
         if self.world > 1 and torch.cuda.is_available():
+            torch.cuda.set_device(self.local_rank)
             torch.cuda.set_stream(torch.cuda.Stream())      # overlapped gradient exchange needs a created (non-default) stream
         kwargs = dict(input_channels=exp_config.input_channels, num_classes=exp_config.n_classes,
                       num_filters=exp_config.filter_channels, latent_levels=exp_config.latent_levels,
@@ -145,9 +151,8 @@ class UNetModel:
         self.optimizer = FusedAdam(self.net, lr=1e-3, weight_decay=1e-5)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", min_lr=1e-4, patience=50000)
         if self.world > 1:
-            dp.broadcast_(self.net._ptab.pflat)
-            dp.broadcast_(self.net._ptab.bflat)
-            self.net.set_data_parallel(True)
+            self.net.set_data_parallel(True, backend="rccl" if torch.cuda.is_available() and os.environ.get("UZ_DP_BACKEND", "rccl") == "rccl" else "torch")
+            self.net._dp.broadcast_params()
         self.log_root = log_root
         self.tot_loss = self.kl_loss = self.reconstruction_loss = 0
         self.iteration = 0
@@ -312,19 +317,58 @@ class UNetModel:
         return path
 
 
+def resolve_sys_config(local, data_root=None, preproc_folder=None, log_root=None):
+    """The reference picks `config.local_config` or `config.system` from the LOCAL argument (train_model.py:577-581) and hands
+    the module to the data loader and to test().  Here LOCAL may be 'local' / anything else (-> `config.local_config` /
+    `config.system` when such a package is importable, as in a checkout of the reference) or the path of a Python file with
+    the same attributes; --data-root / --preproc-folder / --log-root (or UZ_DATA_ROOT / UZ_PREPROC_FOLDER / UZ_LOG_ROOT)
+    override single attributes.  Missing attributes default to None / './logs'."""
+    cfg = types.SimpleNamespace(data_root=None, preproc_folder=None, log_root="./logs")
+    mod = None
+    if local and os.path.isfile(local):
+        spec = importlib.util.spec_from_file_location("uz_sys_config", local)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    else:
+        try:
+            mod = importlib.import_module("config.local_config" if local == "local" else "config.system")
+        except ImportError:
+            mod = None
+    if mod is not None:
+        for k, v in vars(mod).items():
+            if not k.startswith("_"):
+                setattr(cfg, k, v)
+    for attr, val, env in (("data_root", data_root, "UZ_DATA_ROOT"), ("preproc_folder", preproc_folder, "UZ_PREPROC_FOLDER"),
+                           ("log_root", log_root, "UZ_LOG_ROOT")):
+        val = val or os.environ.get(env)
+        if val:
+            setattr(cfg, attr, val)
+    if cfg.data_root and not cfg.preproc_folder:
+        cfg.preproc_folder = os.path.join(os.path.dirname(os.path.abspath(cfg.data_root)), "preproc")
+    return cfg
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Script for training (native MI355X path)")
     ap.add_argument("EXP_PATH", type=str, help="Path to experiment config file")
-    ap.add_argument("LOCAL", type=str, help="Is this script run on the local machine or the BIWI cluster?")
+    ap.add_argument("LOCAL", type=str, help="'local' / cluster name as in the reference (imports config.local_config / config.system when "
+                                            "present), or the path of a sys_config Python file")
     ap.add_argument("dummy", type=str, nargs="?", default="dummy", help="(unused, kept for CLI compatibility)")
     ap.add_argument("--iterations", type=int, default=None)
+    ap.add_argument("--data-root", default=None, help="sys_config.data_root: the LIDC pickle (data_lidc.pickle)")
+    ap.add_argument("--preproc-folder", default=None, help="sys_config.preproc_folder: where the prepared splits are cached")
+    ap.add_argument("--log-root", default=None, help="sys_config.log_root: checkpoints land in <log_root>/<log_dir_name>/<experiment_name>")
+    ap.add_argument("--test", action="store_true", help="run UNetModel.test on the best-loss checkpoint after training (train_model.py:333-475)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s")
+    sys_config = resolve_sys_config(args.LOCAL, args.data_root, args.preproc_folder, args.log_root)
     exp_config = load_experiment(args.EXP_PATH)
-    model = UNetModel(exp_config)
-    data = exp_config.data_loader(None, exp_config) if hasattr(exp_config, "data_loader") else SyntheticData(None, exp_config)
+    model = UNetModel(exp_config, log_root=sys_config.log_root)
+    data = exp_config.data_loader(sys_config=sys_config, exp_config=exp_config) if hasattr(exp_config, "data_loader") else lidc_data(sys_config, exp_config)
     model.train(data, iterations=args.iterations)
     print(model.save_model("last"))
+    if args.test:
+        model.test(data, sys_config=sys_config)
 
 
 if __name__ == "__main__":
