@@ -233,6 +233,11 @@ int uz_add_views(const float* a, int CtotA, const float* b, int CtotB, float* y,
 int uz_absmax(const float* x, size_t n, float* slot, void* stream);
 /* dst bound slot = max(dst, value of src bound slot): forwards a magnitude bound through ops that cannot raise it (pooling, interpolation) */
 int uz_absmax_copy(const float* src_slot, float* dst_slot, void* stream);
+/* Device flag word of the split-fp16 convolution path.  The kernels scale every operand by a power of two taken from an upper
+ * bound of its tensor's magnitudes; a bound that is too small by more than 4x (a stale parameter bound, a wrong bound passed to a
+ * stand-alone call) would overflow fp16.  Such values are CLAMPED to the largest finite fp16 (the result is wrong but never inf /
+ * NaN) and a bit is raised here: 1 = activation, 2 = weight, 4 = output gradient.  Synchronises the stream; clear != 0 resets. */
+int uz_device_flags(int* out, int clear, void* stream);
 /* diagnostics: when buf is non-null the split-fp16 convolution kernels write 8 int64 per workgroup (first 4096 workgroups):
  * shader-clock stamps at start / first tile staged / sum of the staging phases / main loop end / kernel end, the
  * 100 MHz real-time counter at start and end, and the workgroup's tile count (tools/stamp_conv.py).  NULL switches it off. */

@@ -1,0 +1,245 @@
+"""The split-fp16 convolution path under adversarial operands, through the C ABI.
+
+Error model.  An operand element a of a tensor with magnitude bound A is represented by two fp16 pieces with
+|error| <= max(2^-22 |a|, 2^-38 A); a product a b is formed from three piece products (the dropped one is <= 2^-22 |a b|) and
+accumulated in fp32.  For an output element y_i = sum_k a_k b_k this gives
+
+    |y_i - exact_i|  <=  E_i  =  4 * 2^-22 * sum_k |a_k b_k|  +  2^-38 * (A * sum_k |b_k| + B * sum_k |a_k|)  +  fp32 accumulation
+
+The first term is 16 units of fp32's own rounding scale u_i = 2^-24 sum_k |a_k b_k| (a worst case; measured: below the fp32-MFMA
+kernel's error); the second only matters when a tensor's maximum exceeds its typical magnitude by more than ~2^14 - the tests below
+put one 2^10 x and one 2^20 x outlier into an operand and check the bound element by element.  Bounds that are too SMALL (stale /
+wrong bound passed by the caller) must never produce inf / NaN: the pieces are clamped and uz_device_flags reports it."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+N, CIN, COUT, H, W = 8, 64, 64, 64, 64
+
+
+def _g():
+    from tests import _gpu
+    return _gpu
+
+
+def _lib():
+    from unet_zoo_amd import _ffi
+    return _ffi.lib()
+
+
+def _slot(v):
+    t = torch.zeros(256, device=_g().dev())
+    t[0] = float(v)
+    return t
+
+
+def _flags(clear=True):
+    out = C.c_int(0)
+    from unet_zoo_amd import _ffi
+    _ffi.check(_lib().uz_device_flags(C.byref(out), 1 if clear else 0, _g().stream()), "device_flags")
+    return out.value
+
+
+def _ws(cin=CIN, cout=COUT, n=N, h=H, w=W):
+    L = _lib()
+    nb = max(L.uz_conv_workspace(cin, cout, n, h, w, 3), L.uz_conv_bwd_weight_workspace(cin, cout, n, h, w, 3))
+    return torch.empty(nb // 4 + 64, device=_g().dev()), nb
+
+
+def _run_all(x, w, dy, xa=None, wa=None, dya=None, shape=None):
+    """forward, data gradient, weight gradient of a 3x3 layer through the C ABI with explicit bounds (None = measured by the call)."""
+    g = _g()
+    n, cin, h, wd = x.shape
+    cout = w.shape[0]
+    ws, nb = _ws(cin, cout, n, h, wd)
+    xd, wdv, dyd = x.to(g.dev()), w.to(g.dev()), dy.to(g.dev())
+    y = torch.empty(n, cout, h, wd, device=g.dev()); dx = torch.empty_like(xd); dw = torch.empty_like(wdv)
+    g.call("uz_conv_fwd", xd, cin, cin, wdv, None, y, cout, cout, n, h, wd, 3, 0, xa, wa, None, ws, nb)
+    g.call("uz_conv_bwd_data", dyd, cout, cout, wdv, dx, cin, cin, n, h, wd, 3, 0, dya, wa, ws, nb)
+    g.call("uz_conv_bwd_weight", xd, cin, cin, dyd, cout, cout, dw, None, n, h, wd, 3, xa, dya, ws, nb)
+    return y.cpu(), dx.cpu(), dw.cpu()
+
+
+def _exact(x, w, dy):
+    """fp64 results and the sums of absolute products (the rounding scale of every output element)."""
+    x64, w64, dy64 = x.double(), w.double(), dy.double()
+    y = F.conv2d(x64, w64, padding=1)
+    dx = F.conv_transpose2d(dy64, w64, padding=1)
+    dw = torch.nn.grad.conv2d_weight(x64, w64.shape, dy64, padding=1)
+    ya = F.conv2d(x64.abs(), w64.abs(), padding=1)
+    dxa = F.conv_transpose2d(dy64.abs(), w64.abs(), padding=1)
+    dwa = torch.nn.grad.conv2d_weight(x64.abs(), w64.shape, dy64.abs(), padding=1)
+    # sums of |a| and |b| alone over each output's contraction (second term of the bound)
+    one_w, one_x, one_dy = torch.ones_like(w64), torch.ones_like(x64), torch.ones_like(dy64)
+    terms = dict(
+        y=(ya, F.conv2d(x64.abs(), one_w, padding=1), F.conv2d(one_x, w64.abs(), padding=1)),
+        dx=(dxa, F.conv_transpose2d(dy64.abs(), one_w, padding=1), F.conv_transpose2d(one_dy, w64.abs(), padding=1)),
+        dw=(dwa, torch.nn.grad.conv2d_weight(x64.abs(), w64.shape, one_dy, padding=1), torch.nn.grad.conv2d_weight(one_x, w64.shape, dy64.abs(), padding=1)))
+    return dict(y=y, dx=dx, dw=dw), terms
+
+
+def _bound(sum_ab, sum_a, sum_b, amax_a, amax_b):
+    return 5.0 * 2.0 ** -22 * sum_ab + 2.0 ** -37 * (amax_a * sum_b + amax_b * sum_a) + 1e-30
+
+
+def _check(got, exact, terms, amax):
+    """every element within the documented bound; returns the worst error in units of fp32's own rounding scale 2^-24 sum|ab|"""
+    worst = {}
+    for k, (a_name, b_name) in dict(y=("x", "w"), dx=("dy", "w"), dw=("x", "dy")).items():
+        sab, sa, sb = terms[k]
+        err = (got[k].double() - exact[k]).abs()
+        bound = _bound(sab, sa, sb, amax[a_name], amax[b_name])
+        assert torch.isfinite(got[k]).all(), k
+        bad = err > bound
+        assert not bad.any(), f"{k}: {int(bad.sum())} elements beyond the split-fp16 error bound (worst ratio {float((err / bound).max()):.2f})"
+        worst[k] = float((err / (2.0 ** -24 * sab + 1e-300)).max())
+    return worst
+
+
+def _operands(seed, outlier=None):
+    g = _g()
+    x = g.rnd(N, CIN, H, W, seed=seed).relu_()                 # post-ReLU activations: half zeros, heavy right tail
+    w = g.rnd(COUT, CIN, 3, 3, seed=seed + 1, scale=0.05)
+    dy = g.rnd(N, COUT, H, W, seed=seed + 2, scale=1e-3)
+    if outlier:
+        x[1, 3, 17, 29] = float(x.max()) * outlier
+        dy[2, 5, 40, 11] = float(dy.abs().max()) * outlier
+        w[7, 9, 1, 1] = float(w.abs().max()) * min(outlier, 2.0 ** 10)
+    return x, w, dy
+
+
+@pytest.mark.parametrize("outlier", [None, 2.0 ** 10, 2.0 ** 20])
+def test_split_error_stays_within_its_bound_with_outliers(outlier):
+    L = _lib()
+    assert L.uz_conv_route(0, CIN, COUT, N, H, W, 3) == 1 and L.uz_conv_route(2, CIN, COUT, N, H, W, 3) == 1, "layer must take the split path"
+    x, w, dy = _operands(11, outlier)
+    exact, terms = _exact(x, w, dy)
+    amax = dict(x=float(x.abs().max()), w=float(w.abs().max()), dy=float(dy.abs().max()))
+    _flags()
+    y, dx, dw = _run_all(x, w, dy)                               # bounds measured by the calls themselves
+    worst = _check(dict(y=y, dx=dx, dw=dw), exact, terms, amax)
+    assert _flags() == 0
+    # the same through tight caller-supplied bounds and through loose ones (x 2^8: any bound within 2^10 keeps the accuracy)
+    for slack in (1.0, 256.0):
+        y2, dx2, dw2 = _run_all(x, w, dy, _slot(amax["x"] * slack), _slot(amax["w"] * slack), _slot(amax["dy"] * slack))
+        _check(dict(y=y2, dx=dx2, dw=dw2), exact, terms, {k: v * slack for k, v in amax.items()})
+    assert _flags() == 0
+    # against the fp32-MFMA kernels on the same operands, per element in units of fp32's own rounding scale
+    try:
+        L.uz_set_conv_math(0)
+        yf, dxf, dwf = _run_all(x, w, dy)
+    finally:
+        L.uz_set_conv_math(-1)
+    worst_f32 = {k: float(((v.double() - exact[k]).abs() / (2.0 ** -24 * terms[k][0] + 1e-300)).max()) for k, v in dict(y=yf, dx=dxf, dw=dwf).items()}
+    print(f"outlier {outlier}: worst error / (2^-24 sum|ab|): split {worst}  fp32-MFMA {worst_f32}")
+    if outlier is None:
+        # well-scaled operands: the split is no worse than the fp32 MFMA kernel (up to 2x slack for different summation orders)
+        for k in worst:
+            assert worst[k] <= 2.0 * worst_f32[k] + 4.0, (k, worst, worst_f32)
+    if outlier == 2.0 ** 10:
+        for k in worst:                                          # a 2^10 outlier costs nothing either (both pieces stay normal down to 2^-17 of the bound)
+            assert worst[k] <= 4.0 * worst_f32[k] + 8.0, (k, worst, worst_f32)
+
+
+def test_zero_and_tiny_operands():
+    g = _g()
+    x, w, dy = _operands(21)
+    zero_x, zero_dy = torch.zeros_like(x), torch.zeros_like(dy)
+    _flags()
+    y, dx, dw = _run_all(zero_x, w, dy)
+    assert (y == 0).all() and (dw == 0).all() and torch.isfinite(dx).all()
+    y, dx, dw = _run_all(x, w, zero_dy)
+    assert (dx == 0).all() and (dw == 0).all() and torch.isfinite(y).all()
+    y, dx, dw = _run_all(x, torch.zeros_like(w), dy)
+    assert (y == 0).all() and (dx == 0).all() and torch.isfinite(dw).all()
+    # magnitudes at the bottom of the normal range (and one subnormal): finite, and right relative to the tensor's scale
+    tiny = x * 1e-36
+    tiny[0, 0, 0, 0] = 1e-41
+    exact, terms = _exact(tiny, w, dy)
+    y, dx, dw = _run_all(tiny, w, dy)
+    assert torch.isfinite(y).all() and torch.isfinite(dw).all()
+    assert float((y.double() - exact["y"]).abs().max()) <= 1e-5 * float(exact["y"].abs().max())
+    assert float((dw.double() - exact["dw"]).abs().max()) <= 1e-5 * float(exact["dw"].abs().max())
+    assert _flags() == 0
+
+
+def test_a_bound_that_is_too_small_clamps_and_raises_the_flag_never_inf():
+    x, w, dy = _operands(31)
+    amax = dict(x=float(x.abs().max()), w=float(w.abs().max()), dy=float(dy.abs().max()))
+    _flags()
+    # activation bound 64 x too small: values above 1/16 of the true maximum exceed fp16 after scaling
+    y, dx, dw = _run_all(x, w, dy, _slot(amax["x"] / 64), _slot(amax["w"]), _slot(amax["dy"]))
+    assert torch.isfinite(y).all() and torch.isfinite(dw).all() and torch.isfinite(dx).all()
+    assert _flags() & 1, "activation bound violation must be reported"
+    # weight bound too small (what a stale parameter bound looks like after the weights grew)
+    y, dx, dw = _run_all(x, w, dy, _slot(amax["x"]), _slot(amax["w"] / 64), _slot(amax["dy"]))
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all()
+    assert _flags() & 2, "weight bound violation must be reported"
+    # output-gradient bound too small
+    y, dx, dw = _run_all(x, w, dy, _slot(amax["x"]), _slot(amax["w"]), _slot(amax["dy"] / 64))
+    assert torch.isfinite(dx).all() and torch.isfinite(dw).all()
+    assert _flags() & 4, "gradient bound violation must be reported"
+    # a bound that is too small by less than 4x is harmless: exact same accuracy, no flag
+    exact, terms = _exact(x, w, dy)
+    y, dx, dw = _run_all(x, w, dy, _slot(amax["x"] / 3), _slot(amax["w"] / 3), _slot(amax["dy"] / 3))
+    _check(dict(y=y, dx=dx, dw=dw), exact, terms, amax)
+    assert _flags() == 0
+
+
+def test_unnormalised_unet_activations_after_real_training_steps():
+    """the vanilla U-Net has no normalisation, so its activations are whatever training makes them.  Train the
+    native model for 50 steps, then push the real post-ReLU activations of the first two levels (recomputed on the CPU from the
+    trained weights) through the split kernels: error per element against fp64, in units of fp32's own rounding scale, next to the
+    fp32-MFMA kernel's; and the max / rms ratio of those tensors (the quantity the split's error bound depends on)."""
+    import unet_zoo_amd  # noqa: F401
+    from unet_zoo_amd.models.unet import Unet
+    from unet_zoo_amd.optim import FusedAdam
+    from unet_zoo_amd.synthetic import synthetic_batch
+    g = _g()
+    torch.manual_seed(5)
+    net = Unet(1, 2, [32, 64, 128, 192])
+    net.train()
+    opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
+    for step in range(50):
+        xb, mb, _ = synthetic_batch(8, 128, 128, seed=100 + step)
+        xb, mb = torch.from_numpy(xb).to(g.dev()), torch.from_numpy(mb).to(g.dev())
+        net.forward(xb)
+        loss = net.loss(mb)
+        opt.zero_grad(); loss.backward(); opt.step()
+    assert net.check_bounds() == 0, "a producer-maintained magnitude bound was violated during training"
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    xb, _, _ = synthetic_batch(8, 128, 128, seed=999)
+    a = torch.from_numpy(xb)
+    acts = {}
+    for li in (0, 2, 4):
+        a = F.relu(F.conv2d(a, sd[f"contracting_path.0.layers.{li}.weight"], sd[f"contracting_path.0.layers.{li}.bias"], padding=1))
+    a = F.avg_pool2d(a, 2, 2, ceil_mode=True)
+    acts["32->64 @64x64"] = (a, sd["contracting_path.1.layers.1.weight"])
+    a = F.relu(F.conv2d(a, sd["contracting_path.1.layers.1.weight"], sd["contracting_path.1.layers.1.bias"], padding=1))
+    acts["64->64 @64x64"] = (a, sd["contracting_path.1.layers.3.weight"])
+    L = _lib()
+    for name, (x, w) in acts.items():
+        n, cin, h, wd = x.shape
+        cout = w.shape[0]
+        assert L.uz_conv_route(0, cin, cout, n, h, wd, 3) == 1, name
+        ratio = float(x.abs().max() / x.pow(2).mean().sqrt())
+        dy = g.rnd(n, cout, h, wd, seed=3, scale=1e-3)
+        exact, terms = _exact(x, w, dy)
+        amax = dict(x=float(x.abs().max()), w=float(w.abs().max()), dy=float(dy.abs().max()))
+        y, dx, dw = _run_all(x, w, dy)
+        worst = _check(dict(y=y, dx=dx, dw=dw), exact, terms, amax)
+        try:
+            L.uz_set_conv_math(0)
+            yf, _, dwf = _run_all(x, w, dy)
+        finally:
+            L.uz_set_conv_math(-1)
+        wf = float(((yf.double() - exact["y"]).abs() / (2.0 ** -24 * terms["y"][0] + 1e-300)).max())
+        print(f"{name}: max/rms {ratio:.1f}; worst error / fp32 rounding scale: split {worst['y']:.2f}, fp32-MFMA {wf:.2f}")
+        assert ratio < 2.0 ** 12                                 # far from the 2^14 where the bound's second term would start to matter
+        assert worst["y"] <= 2.0 * wf + 4.0
+    assert _flags() == 0

@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+python -m pytest tests/test_ops_gpu.py tests/test_full_configs_gpu.py tests/test_cpu_twins.py -q -x -k "conv or split or twin" -p no:cacheprovider 2>&1 | tail -3
+for l in "224 128 128 128" "128 128 128 128" "256 192 64 64" "32 32 128 128" "64 64 64 64" "192 192 32 32" "256 256 16 16"; do
+  echo "== $l"; python tools/bench_conv.py $l 2>&1 | tail -3
+done
+python bench.py --steps 30 --warmup 5 --skip-cpu --no-profile --no-f32-leg 2>/dev/null | cut -c1-175
+python bench.py --steps 30 --warmup 5 --skip-cpu --no-profile --no-f32-leg 2>/dev/null | cut -c1-175

@@ -70,6 +70,15 @@ class NativeModel(nn.Module):
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def check_bounds(self, clear=True):
+        """Device flag word of the split-fp16 convolution path (uz_device_flags): 0 when every tensor stayed within the
+        magnitude bound its consumer was given; bit 1 / 2 / 4 = an activation / weight / gradient exceeded its bound by more
+        than 4x and was clamped (results wrong but finite).  Synchronises the stream - call it per epoch, not per step."""
+        self._require_gpu()
+        out = C.c_int(0)
+        _ffi.check(_ffi.lib().uz_device_flags(C.byref(out), 1 if clear else 0, C.c_void_p(self._stream())), "device_flags")
+        return out.value
+
     def _require_gpu(self):
         if self.device.type != "cuda":
             raise _ffi.UzError("no GPU visible: the native path has no CPU fallback (model was built in structure-only mode)")

@@ -889,6 +889,14 @@ class Plan:
             if "fwd" in pack_ops:
                 ops0.append(pack_ops["fwd"])
             self.fwd_ops[:0] = ops0
+        # Extra forward-only tapes (decode) run long after the forward tape that measured the parameter bound in slot 0 -
+        # behind an optimiser step or a load_state_dict the bound may be stale, and a bound more than 4x too small overflows the
+        # fp16 pieces.  A tape with a convolution on the split path therefore re-measures the bound at its own head.
+        for name, ops in self.extra_ops.items():
+            if any(o["code"] == "UZ_OP_CONV_FWD" and o["i"][7] == 3 and
+                   self.L.uz_conv_route(0, o["i"][0], o["i"][2], o["i"][4], o["i"][5], o["i"][6], 3) == 1 for o in ops):
+                ops[:0] = [dict(code="UZ_OP_MEMSET", p=[("amaxrange", 0, 1)], i=[], f=[], n=4 * _AMAX_FLOATS, gid=head),
+                           dict(code="UZ_OP_ABSMAX", p=[("pflat",), ("amaxw", 0)], i=[], f=[], n=self.ptab.n_params, gid=head)]
         if self.bwd_ops and bwd_slots:
             self.bwd_ops[:0] = [dict(code="UZ_OP_MEMSET", p=[("amaxrange", self.n_amax_fwd, self.n_amax)], i=[], f=[],
                                      n=4 * _AMAX_FLOATS * (self.n_amax - self.n_amax_fwd), gid=head)]

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "uz_common.h"
+#include <type_traits>
 #include "split_f16.h"
 
 namespace {
@@ -49,6 +50,7 @@ struct SP {
     int kSplit, cps;                              // split-K: the chunk loop is shared out over kSplit workgroups, cps chunks each
     float* slab;                                  // [kSplit][N][Cout][HW] partial sums (kSplit > 1), summed in order by splitk_reduce
     long long* stamps;                            // diagnostics (uz_debug_stamps): 8 cycle stamps per workgroup, normally null
+    int* flags;                                   // device flag word (bound violations), nullable
 };
 
 
@@ -57,10 +59,15 @@ struct SP {
 // 64 lanes of a fragment read (one ds_read_b128) cover two contiguous 512-byte runs - conflict free; with whole 32-byte
 // rows every second 16-lane group of the read collided on its banks (2-way).
 // 16 fp32 values (one row of 16 channels), scaled -> fp16 pieces at dst + plane * plane_stride + half * half_stride (bytes)
-__device__ __forceinline__ void split_store16(const float (&v)[CK], float scale, char* dst, int plane_stride, int half_stride) {
+__device__ __forceinline__ void split_store16(const float (&v)[CK], float scale, char* dst, int plane_stride, int half_stride, int* flags = nullptr) {
     unsigned p1[8], p2[8];
+    bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) split2(v[2 * i] * scale, v[2 * i + 1] * scale, p1[i], p2[i]);
+    for (int i = 0; i < 8; ++i) {
+        bad |= uz::bound_violated(v[2 * i] * scale, v[2 * i + 1] * scale);
+        split2(v[2 * i] * scale, v[2 * i + 1] * scale, p1[i], p2[i]);
+    }
+    if (bad && flags) atomicOr(flags, uz::FLAG_W_BOUND);
     *reinterpret_cast<u32x4*>(dst) = u32x4{p1[0], p1[1], p1[2], p1[3]};
     *reinterpret_cast<u32x4*>(dst + half_stride) = u32x4{p1[4], p1[5], p1[6], p1[7]};
     *reinterpret_cast<u32x4*>(dst + plane_stride) = u32x4{p2[0], p2[1], p2[2], p2[3]};
@@ -71,7 +78,7 @@ __device__ __forceinline__ void split_store16(const float (&v)[CK], float scale,
 // packed[chunk][coTile][plane 2][k half 2][tap 9][co COT][8 k] fp16, scaled by split_scale(*w_amax).  One thread per (chunk, coTile, tap, co) row.
 template <bool DGRAD>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, char* __restrict__ packed, const float* __restrict__ w_amax,
-                                                           int Mc, int Kc, int wCi, int nChunks, int nCoTiles, int COT) {
+                                                           int Mc, int Kc, int wCi, int nChunks, int nCoTiles, int COT, int* flags) {
     const int rows = nChunks * nCoTiles * KK * COT;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= rows) return;
@@ -87,11 +94,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
     const int tapL = DGRAD ? KK - 1 - tap : tap;
     const int wplane = KK * COT * CK * 2;
-    split_store16(v, uz::split_scale(uz::amax_read(w_amax)), packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * 16, wplane, wplane / 2);
+    split_store16(v, uz::split_scale(uz::amax_read(w_amax)), packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * 16, wplane, wplane / 2, flags);
 }
 
 template <int MSUB, int NTv, int TWv>
-__global__ __launch_bounds__(NTv, (MSUB == 2 ? (NTv == 256 ? 2 : 1) : (NTv == 256 ? 3 : 4))) void conv_split_kernel(const SP p) {
+__global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void conv_split_kernel(const SP p) {
     using GEO = Geo<NTv, TWv>;
     constexpr int NT = GEO::NT, TW = GEO::TW, PW = GEO::PW, PSI = GEO::PSI, PSR = GEO::PSR, G = GEO::G, CE = GEO::CE;
     constexpr int COT = 32 * MSUB;
@@ -139,15 +146,12 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? (NTv == 256 ? 2 : 1) : (NTv == 25
     const float xs = uz::split_scale(uz::amax_read(p.x_amax));
 
     // ---- per-lane output pixels (B operand columns)
-    int poff[NSUB], oidx[NSUB], sidx[NSUB];
+    int poff[NSUB];
 #pragma unroll
     for (int n = 0; n < NSUB; ++n) {
         const int pp = wave * (32 * NSUB) + n * 32 + l31;          // pixel index inside the tile
         const int tx = pp & (TW - 1), ty = pp / TW;
-        const bool v = (y0 + ty) < p.H && (x0 + tx) < p.W;
         poff[n] = (ty * PW + tx) * 16 + h * (PPLANE / 2);           // byte offset of this lane's fragment for tap (0, 0)
-        oidx[n] = v ? (b0 * p.CoutTot * p.HW + (y0 + ty) * p.W + (x0 + tx)) : -1;
-        sidx[n] = v ? (b0 * p.Cout * p.HW + (y0 + ty) * p.W + (x0 + tx)) : -1;
     }
 
     f32x16 acc[MSUB][NSUB];
@@ -231,6 +235,17 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? (NTv == 256 ? 2 : 1) : (NTv == 25
     if (p.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) stage(cbeg, tap);
+    if (p.flags) {                                 // bound check on the first chunk's patch (the clamp in split2 covers every chunk)
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < CK; k += 2) bad |= uz::bound_violated(pr[k] * xs, pr[k + 1] * xs);
+        if (bad) atomicOr(p.flags, uz::FLAG_X_BOUND);
+    }
+    // A 64-channel tile whose upper 32 channels lie beyond Cout (Cout = 224 = 3 x 64 + 32: the data gradient of the heaviest
+    // layer) skips that half's MFMAs, fragment reads and epilogue pass: 12.5 % of that launch's matrix work were zeros.
+    const bool half_tile = MSUB == 2 && p.Cout - co0 <= 32;
+    auto main_loop = [&](auto ms_c) __attribute__((always_inline)) {
+    constexpr int MS = decltype(ms_c)::value;
     for (int c = cbeg; c < nChunks; ++c) {
         long long ta = 0;
         if (p.stamps) ta = __builtin_amdgcn_s_memtime();
@@ -243,9 +258,9 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? (NTv == 256 ? 2 : 1) : (NTv == 25
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             const int tapoff = ((tap / 3) * PW + (tap % 3)) * 16;
-            f16x8 a[MSUB][NP], b[NSUB][NP];
+            f16x8 a[MS][NP], b[NSUB][NP];
 #pragma unroll
-            for (int m = 0; m < MSUB; ++m)
+            for (int m = 0; m < MS; ++m)
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
                     a[m][q] = *reinterpret_cast<const f16x8*>(Al + q * WPLANE + (tap * COT + m * 32) * 16);
@@ -257,7 +272,7 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? (NTv == 256 ? 2 : 1) : (NTv == 25
             if (more) stage(c + 1, tap);
             // smallest products first
 #pragma unroll
-            for (int m = 0; m < MSUB; ++m)
+            for (int m = 0; m < MS; ++m)
 #pragma unroll
                 for (int n = 0; n < NSUB; ++n) {
                     f32x16 t = acc[m][n];
@@ -268,48 +283,86 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? (NTv == 256 ? 2 : 1) : (NTv == 25
                 }
         }
     }
+    };
+    if (half_tile) main_loop(std::integral_constant<int, 1>{});
+    else main_loop(std::integral_constant<int, MSUB>{});
 
     long long st2 = 0;
     if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
-    // ---- epilogue: undo the operand scales (exact), bias, optional accumulate / ReLU, coalesced NCHW stores
+    // ---- epilogue: undo the operand scales (exact), bias, optional accumulate / ReLU, NCHW stores.
+    // An accumulator register holds ONE pixel of a channel per lane, so storing from registers costs a 4-byte store instruction per
+    // value (measured with the cycle stamps: 24 k of a workgroup's 105 - 160 k cycles, every CU's store queue full while the
+    // matrix pipe idles).  Instead the tile goes through the (now dead) staging LDS, 8 * GP channels x all pixels per pass, and
+    // comes back as float4 rows: a quarter of the store instructions, each wave writing whole 128-byte lines.
     const float inv_x = uz::split_inv_scale(uz::amax_read(p.x_amax)), inv_w = uz::split_inv_scale(uz::amax_read(p.w_amax));
-    if (p.kSplit > 1) {                           // partial sums only: bias / accumulate / ReLU / bound happen in the reduce
-        float* sl = p.slab + (size_t)part * p.N * p.Cout * p.HW;
-#pragma unroll
-        for (int m = 0; m < MSUB; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (co < p.Cout)
-#pragma unroll
-                    for (int n = 0; n < NSUB; ++n)
-                        if (sidx[n] >= 0) sl[(size_t)sidx[n] + (size_t)co * p.HW] = acc[m][n][r] * inv_x * inv_w;
-            }
-        return;
-    }
+    const float inv = inv_x * inv_w;
+    constexpr int LDS_BYTES = NP * WPLANE + NP * PPLANE;
+    constexpr int GP = (32 * NT * 4 <= LDS_BYTES) ? 4 : ((16 * NT * 4 <= LDS_BYTES) ? 2 : 1);    // channel groups of 8 per pass
+    constexpr int ROWF = NT + 4;                         // floats per channel row (one pixel per thread, + 16 B: rows start on different banks)
+    static_assert(8 * GP * ROWF * 4 <= LDS_BYTES, "epilogue staging must fit the main loop's LDS");
+    constexpr int Q = NT / 4;                            // float4 per channel row
+    float* El = reinterpret_cast<float*>(lds);
+    const bool split = p.kSplit > 1;                     // partial sums only: bias / accumulate / ReLU / bound happen in the reduce
+    float* const obase = split ? p.slab + (size_t)part * p.N * p.Cout * p.HW + (size_t)b0 * p.Cout * p.HW
+                               : p.y + (size_t)b0 * p.CoutTot * p.HW;
+    const bool vec = (p.W & 3) == 0 && (reinterpret_cast<uintptr_t>(obase) & 15) == 0;
+    const int c4 = tid % Q, rsub = tid / Q;              // this thread's float4 column and row phase (rows rsub, rsub + 4, ...)
+    const int px = 4 * c4, ty = px / TW, tx = px % TW;
+    const int oy = y0 + ty, ox = x0 + tx;
+    const bool rowok = oy < p.H && ox < p.W;
     float vmax = 0.f;
 #pragma unroll
     for (int m = 0; m < MSUB; ++m) {
+        if (m == 1 && half_tile) break;                  // workgroup-uniform
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (co < p.Cout) {
-                const float bv = p.bias ? p.bias[co] : 0.f;
+        for (int g0 = 0; g0 < 4; g0 += GP) {
+            __syncthreads();                             // main loop / previous pass done with this LDS
 #pragma unroll
-                for (int n = 0; n < NSUB; ++n) {
-                    if (oidx[n] >= 0) {
-                        float* dst = p.y + (size_t)oidx[n] + (size_t)co * p.HW;
-                        float v = acc[m][n][r] * inv_x * inv_w + bv;
-                        if (p.accumulate) v += *dst;
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        *dst = v;
-                        vmax = fmaxf(vmax, fabsf(v));
+            for (int g = 0; g < GP; ++g)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int n = 0; n < NSUB; ++n)
+                        El[(g * 8 + rr + 4 * h) * ROWF + wave * (32 * NSUB) + n * 32 + l31] = acc[m][n][(g0 + g) * 4 + rr];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2 * GP; ++j) {
+                const int row = 4 * j + rsub;            // 0 .. 8 GP - 1
+                const int co = co0 + m * 32 + g0 * 8 + row;
+                if (co < p.Cout && rowok) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(El + row * ROWF + px);
+                    float* dst = obase + (size_t)co * p.HW + (size_t)oy * p.W + ox;
+                    if (split) {
+                        v *= inv;
+                    } else {
+                        const float bv = p.bias ? p.bias[co] : 0.f;
+                        v = v * inv + bv;
+                    }
+                    if (vec) {
+                        if (!split) {
+                            if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+                            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                        }
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (ox + e < p.W) {
+                                float t = v[e];
+                                if (!split) {
+                                    if (p.accumulate) t += dst[e];
+                                    if (p.relu) t = fmaxf(t, 0.f);
+                                    vmax = fmaxf(vmax, fabsf(t));
+                                }
+                                dst[e] = t;
+                            }
                     }
                 }
             }
         }
     }
-    if (p.y_amax) uz::amax_publish(vmax, p.y_amax);
+    if (!split && p.y_amax) uz::amax_publish(vmax, p.y_amax);
     if (p.stamps) {
         __builtin_amdgcn_s_waitcnt(0);          // the stores have left the wave
         const long long st3 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
@@ -337,7 +390,6 @@ int launch(const SP& p, int grid, hipStream_t st) {
 // tile geometry of a layer: 16 x 32 tiles (512 threads, 64- or 32-channel tiles) when the plane is wider than 32,
 // else 16 x 16 tiles (256 threads, 32-channel tiles)
 inline bool small_geo(int W) { return W <= 32; }       // measured: 16 x 16 tiles win or tie on 32 x 32 planes (128 -> 128: 91 -> 67 us), lose on 64 x 64
-inline int exp_mode() { static int m = -1; if (m < 0) { const char* e = getenv("UZ_SPLIT_EXP"); m = e ? atoi(e) : 0; } return m; }
 inline int tile_w(int W) { return small_geo(W) ? 16 : 32; }
 // 16 x 16 tiles carry 32 output channels (64 was measured 8 - 30 % slower: the layers that use this geometry want workgroups)
 // ... and on the large planes when the contraction is short (Kc <= 32: two chunks, the workgroup is mostly prologue and
@@ -350,6 +402,28 @@ namespace uz {
 
 long long* debug_stamps = nullptr;
 extern "C" void uz_debug_stamps(void* buf) { debug_stamps = static_cast<long long*>(buf); }
+
+// Device flag word: bit FLAG_X_BOUND / FLAG_DY_BOUND = an activation / gradient tensor exceeded the magnitude bound a split-fp16
+// kernel was given by more than 4x, bit FLAG_W_BOUND = a weight did (the values were clamped: results are wrong but finite).
+int* dev_flags_ptr() {
+    static int* ptr = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        if (hipMalloc(&ptr, sizeof(int)) != hipSuccess || hipMemset(ptr, 0, sizeof(int)) != hipSuccess) ptr = nullptr;
+    }
+    return ptr;
+}
+extern "C" int uz_device_flags(int* out, int clear, void* stream) {
+    UZ_REQUIRE(out, "device_flags: null output");
+    int* d = dev_flags_ptr();
+    *out = 0;
+    if (!d) return 0;
+    if (hipStreamSynchronize(S(stream)) != hipSuccess) return fail("device_flags: stream synchronize failed");
+    if (hipMemcpy(out, d, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail("device_flags: copy failed");
+    if (clear && *out && hipMemset(d, 0, sizeof(int)) != hipSuccess) return fail("device_flags: clear failed");
+    return 0;
+}
 
 // Which layers take the split-fp16 path: 3x3, enough channels for a dense contraction and enough tiles to occupy
 // the chip.  Planes wider than 32 use 16 x 32 tiles; 32 x 32 and 16 x 16 planes use 16 x 16 tiles.
@@ -449,9 +523,7 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     p.x_amax = x_amax; p.w_amax = w_amax; p.y_amax = y_amax;
     p.N = N; p.H = H; p.W = W; p.HW = H * W;
     p.Cin = Kc; p.CinTot = KcTot; p.Cout = Mc; p.CoutTot = McTot;
-    const int cot = tile_cot(Kc, Mc, W);
-    const bool dual = (exp_mode() & 1) && cot == 64 && !small_geo(W);          // experiment: two independent 256-thread workgroups per CU
-    const int tw = dual ? 16 : tile_w(W);
+    const int tw = tile_w(W), cot = tile_cot(Kc, Mc, W);
     p.tilesX = ceil_div(W, tw); p.tilesY = ceil_div(H, TH);
     p.relu = relu; p.accumulate = accumulate;
     p.nCoTiles = ceil_div(Mc, cot);
@@ -461,17 +533,18 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     p.kSplit = ceil_div(p.nChunks, p.cps);               // no empty parts
     p.slab = reinterpret_cast<float*>(image + image_bytes(Kc, Mc, W));
     p.stamps = uz::debug_stamps;
+    p.flags = dev_flags_ptr();
     const long long grid = (long long)p.tilesX * p.tilesY * N * p.nCoTiles * p.kSplit;
     UZ_REQUIRE(grid < (1ll << 31), "conv_split: grid too large");
-    UZ_REQUIRE((size_t)Kc * p.HW * 4 < (1ull << 32) && (size_t)McTot * p.HW * N < (1ull << 31), "conv_split: tensor too large for 32-bit offsets");
+    // per-image buffer resources and 64-bit output addressing: only ONE image's input view has to fit 32-bit byte offsets
+    UZ_REQUIRE((size_t)Kc * p.HW * 4 < (1ull << 32), "conv_split: one image's input view exceeds 4 GB");
     const int rows = p.nChunks * p.nCoTiles * KK * cot;
     if (packed_w) {}                                     // packed once per step by uz_conv_pack_weights
-    else if (dgrad) hipLaunchKernelGGL(pack_weights_kernel<true>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
-    else hipLaunchKernelGGL(pack_weights_kernel<false>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot);
+    else if (dgrad) hipLaunchKernelGGL(pack_weights_kernel<true>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot, p.flags);
+    else hipLaunchKernelGGL(pack_weights_kernel<false>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot, p.flags);
     if (int rc = check_launch("pack_weights_kernel")) return rc;
     int rc;
-    if (dual) rc = launch<2, 256, 16>(p, (int)grid, st);
-    else if (tw == 16) rc = launch<1, 256, 16>(p, (int)grid, st);
+    if (tw == 16) rc = launch<1, 256, 16>(p, (int)grid, st);
     else rc = cot == 32 ? launch<1, 512, 32>(p, (int)grid, st) : launch<2, 512, 32>(p, (int)grid, st);
     if (rc || p.kSplit == 1) return rc;
     return splitk_reduce(p.slab, p.kSplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax, st);
@@ -484,7 +557,7 @@ namespace {
 // cot, flags, first row}; a workgroup finds its layer by bisection over the first-row column.  flags bit 0 = data gradient,
 // bit 1 = Conv3d weight [Cout][Cin][3][3][3] read straight into the depth-window layout of csrc/vol.hip (forward: contraction
 // index k = kd Cin + ci; data gradient: k = j Cout + co with kd = 2 - j), wCi = the 3-D Cin.
-__global__ __launch_bounds__(256) void pack_all_kernel(const long long* __restrict__ table, int n_layers, int total_rows, const float* __restrict__ w_amax) {
+__global__ __launch_bounds__(256) void pack_all_kernel(const long long* __restrict__ table, int n_layers, int total_rows, const float* __restrict__ w_amax, int* flags) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= total_rows) return;
     int lo = 0, hi = n_layers - 1;
@@ -510,7 +583,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const long long* __restri
     }
     const int tapL = dgrad ? KK - 1 - tap : tap;
     const int wplane = KK * COT * CK * 2;
-    split_store16(v, uz::split_scale(uz::amax_read(w_amax)), packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * 16, wplane, wplane / 2);
+    split_store16(v, uz::split_scale(uz::amax_read(w_amax)), packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * 16, wplane, wplane / 2, flags);
 }
 }  // namespace
 
@@ -525,7 +598,7 @@ extern "C" int uz_conv_pack_cot(int Cin, int Cout, int W, int dgrad) { return ti
 extern "C" int uz_conv_pack_weights(const int64_t* table, int n_layers, int total_rows, const float* w_amax, void* stream) {
     UZ_REQUIRE(table && w_amax && n_layers >= 0 && total_rows >= 0, "conv_pack_weights: null argument");
     if (n_layers == 0 || total_rows == 0) return 0;
-    hipLaunchKernelGGL(pack_all_kernel, dim3(uz::ceil_div(total_rows, 256)), dim3(256), 0, uz::S(stream), reinterpret_cast<const long long*>(table), n_layers, total_rows, w_amax);
+    hipLaunchKernelGGL(pack_all_kernel, dim3(uz::ceil_div(total_rows, 256)), dim3(256), 0, uz::S(stream), reinterpret_cast<const long long*>(table), n_layers, total_rows, w_amax, uz::dev_flags_ptr());
     return uz::check_launch("pack_all_kernel");
 }
 

@@ -537,7 +537,10 @@ WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
     g.nCoT = uz::ceil_div(Cout, 32 * g.WM);
     g.nCiT = uz::ceil_div(Cin, 32 * g.WN);
     g.pf = (32 * g.WN * g.PS <= 18 * 512) ? 1 : 0;
-    g.fast = halo == 1 && g.TB == 1 &&
+    // the fast kernels address a whole tensor through one buffer resource (32-bit byte offsets): tensors of 2^30 elements
+    // or more take the generic kernel (64-bit pointers)
+    const bool huge = (size_t)N * Cin * H * W >= (1ull << 30) || (size_t)N * Cout * H * W >= (1ull << 30);
+    g.fast = halo == 1 && g.TB == 1 && !huge &&
              ((g.TW == 32 && (g.TH == 2 || g.TH == 4)) || (g.TW == 16 && g.TH == 4) || (g.TW == 8 && g.TH == 8));
     g.SW = g.fast ? 1 : g.WK;                 // the fast kernels fold their WK partial sums in LDS
     // pixel splits S: small cost model instead of a fixed target.  More splits = more workgroups in flight
@@ -640,7 +643,11 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         if (Cin == 1) UZ_THIN(1); else if (Cin == 2) UZ_THIN(2); else if (Cin == 3) UZ_THIN(3); else UZ_THIN(4);
 #undef UZ_THIN
     }
-    const bool split_math = !thin && uz::wgrad_split_ok(Cin, Cout, N, H, W, ks);
+    // The split-fp16 and the fast fp32 kernels address a whole tensor through one buffer resource (32-bit byte offsets): tensors
+    // of 2^30 elements or more take the generic fp32 kernel (64-bit pointers) instead of failing.
+    const bool huge = (size_t)N * CinTot * H * W >= (1ull << 30) || (size_t)N * CoutTot * H * W >= (1ull << 30);
+    UZ_REQUIRE(!(huge && g.fast), "conv_bwd_weight: a channel-slice view of a buffer of 2^30 elements or more is not supported by the tiled kernels");
+    const bool split_math = !thin && !huge && uz::wgrad_split_ok(Cin, Cout, N, H, W, ks);
     if (split_math) {                              // large layers: split-fp16 matrix pipe (conv_wgrad_split.hip), same slab layout
         Stot = uz::wgrad_split_splits(Cin, Cout, N, H, W);
         const size_t slab_bytes = (size_t)Stot * 9 * Cout * Cin * sizeof(float);

@@ -30,8 +30,8 @@ constexpr int XCH = 496;                                 // bytes per ci of one 
 template <int TWv> struct WGeo {
     static constexpr int TW = TWv, TH = PT / TWv;
     static constexpr int XROW = (TWv + 8) * 2;           // bytes per patch row: TW + 2 pixels, padded to a 16-byte multiple (80 / 48)
-    static constexpr int PAIRS_ROW = (TWv + 2) / 2;      // 17 / 9 pixel pairs per patch row
-    static constexpr int XPAIRS = (TH + 2) * PAIRS_ROW;  // 102 / 90 per ci
+    static constexpr int QROWX = TWv / 4;                // staging slots per patch row: TW / 4 quads (4 pixels) + one pair (the last two pixels)
+    static constexpr int PROWS = TH + 2;
     static_assert((TH + 2) * XROW + 16 == XCH, "patch image per channel");
 };
 
@@ -41,6 +41,7 @@ struct WS {
     int tilesX, tilesY, T, S, nCoT, nCiT;
     const float* x_amax; const float* dy_amax;          // device scalars: upper bounds of |x| and |dy|
     long long* stamps;                                  // diagnostics (uz_debug_stamps), normally null
+    int* flags;                                         // device flag word (bound violations), nullable
 };
 
 
@@ -49,12 +50,13 @@ struct WS {
 template <int TWv, int CT>
 __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
     using GEO = WGeo<TWv>;
-    constexpr int TW = GEO::TW, TH = GEO::TH, XROW = GEO::XROW, PAIRS_ROW = GEO::PAIRS_ROW, XPAIRS = GEO::XPAIRS;
+    constexpr int TW = GEO::TW, TH = GEO::TH, XROW = GEO::XROW, QROWX = GEO::QROWX, PROWS = GEO::PROWS;
     constexpr int QROW = TW / 4, SROW = TW / 16;          // float4 quads / 16-pixel k-steps per tile row
     constexpr int COT = CT, CIT = CT, WK = CT == 64 ? 1 : 4;
     constexpr int DYPLANE = COT * DYROW, XPLANE = CIT * XCH;
     constexpr int DYSLOTS = COT * PT / 4 / NT;            // float4 per thread: 4 / 2
-    constexpr int XSLOTS = (CIT * XPAIRS + NT - 1) / NT;
+    constexpr int XQSLOTS = (CIT * PROWS * QROWX + NT - 1) / NT;     // quads per thread: 6 / 5 (64 channels), 3 (32 channels)
+    constexpr int XPSLOTS = (CIT * PROWS + NT - 1) / NT;             // pairs per thread: 1 / 2
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dYl = lds;
     char* Xl = lds + NP * DYPLANE;
@@ -83,33 +85,55 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
     // dY: float4 e = tid + i * 512 -> co = e / 32, quad q = e % 32 (row q / QROW, columns 4 (q % QROW) ..); the
     // per-slot offsets are recomputed per tile (a handful of integer ops) rather than held in registers
     f32x4 dreg[DYSLOTS];
-    float xreg[XSLOTS][2];
-    auto gload = [&](int t) __attribute__((always_inline)) {
+    f32x4 xq[XQSLOTS];
+    float xp[XPSLOTS][2];
+    // The loads of the next tile are issued in NPARTS portions, one per k-step of the MFMA loop (part < 0: all at once, prologue):
+    // issued as one block behind the barrier, their address arithmetic (a few hundred VALU instructions per wave) kept BOTH waves
+    // of every SIMD off the matrix pipe at the start of each tile (cycle stamps: 15 k cycles per tile against 6.9 k of MFMAs).
+    constexpr int NPARTS = PT / 16 / WK;
+    auto gload = [&](int t, int part) __attribute__((always_inline)) {
         const int txi = t % p.tilesX, t2 = t / p.tilesX;
         const int x0 = txi * TW, y0 = (t2 % p.tilesY) * TH, b0 = t2 / p.tilesY;
         const unsigned dbase = 4u * (unsigned)((b0 * p.CoutTot + co0) * p.HW + y0 * p.W + x0);
 #pragma unroll
         for (int i = 0; i < DYSLOTS; ++i) {
+            if (part >= 0 && i % NPARTS != part % NPARTS) continue;
             const int e = tid + i * NT, co = e >> 5, q = e & 31, row = q / QROW, c4 = (q % QROW) * 4;
             const unsigned m = ((y0 + row) < p.H && (co0 + co) < p.Cout) ? 0u : 0xFFFFFFFFu;      // all-ones: the range check returns 0
             dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (dbase + 4u * (unsigned)(co * p.HW + row * p.W + c4)) | m, 0, 0));
         }
+        // X patch: a quad slot is 4 consecutive patch pixels of one row (patch pixels 4 q .. 4 q + 3 = image columns x0 - 1 + 4 q ..):
+        // one 16-byte load (dword aligned; a wave's lanes read one contiguous run) whose LDS image is one aligned 8-byte store per
+        // plane; the last two pixels of every row are pair slots.  Quads and pairs have their own slot indices, so every lane of a
+        // wave executes the same instructions.  A quarter of the load / store instructions and address arithmetic of pair-only staging.
         const int xbase = (b0 * p.CinTot + ci0) * p.HW + y0 * p.W + x0;
 #pragma unroll
-        for (int i = 0; i < XSLOTS; ++i) {
+        for (int i = 0; i < XQSLOTS; ++i) {
+            if (part >= 0 && (i + DYSLOTS) % NPARTS != part % NPARTS) continue;
             const int e = tid + i * NT;
-            const int ci = e / XPAIRS, rem = e - ci * XPAIRS, prow = rem / PAIRS_ROW, pj = rem - prow * PAIRS_ROW;
-            const int yy = y0 + prow - 1, xx = x0 + 2 * pj - 1;
-            const bool rowok = e < CIT * XPAIRS && (ci0 + ci) < p.Cin && yy >= 0 && yy < p.H;
-            const int off = xbase + ci * p.HW + (prow - 1) * p.W + 2 * pj - 1;
-            const unsigned o0 = (rowok && xx >= 0 && xx < p.W) ? 4u * (unsigned)off : 0xFFFFFFFFu;
-            const unsigned o1 = (rowok && xx + 1 < p.W) ? 4u * (unsigned)(off + 1) : 0xFFFFFFFFu;
-            xreg[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, o0, 0, 0));
-            xreg[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, o1, 0, 0));
+            const int q = e % QROWX, r = e / QROWX, ci = r / PROWS, prow = r - ci * PROWS;
+            const int yy = y0 + prow - 1;
+            const bool rowok = e < CIT * PROWS * QROWX && (ci0 + ci) < p.Cin && yy >= 0 && yy < p.H;
+            const int sh = (q == 0 && x0 == 0) ? 1 : 0;           // image column -1: load columns 0..3 and shift (never reads before the row)
+            const int off = xbase + ci * p.HW + (prow - 1) * p.W + 4 * q - 1 + sh;
+            // (the shift itself happens in lstore: a use of the loaded value here would wait for the load inside the MFMA loop)
+            xq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxx, rowok ? 4u * (unsigned)off : 0xFFFFFFFFu, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < XPSLOTS; ++i) {
+            if (part >= 0 && (i + DYSLOTS + XQSLOTS) % NPARTS != part % NPARTS) continue;
+            const int e = tid + i * NT;
+            const int ci = e / PROWS, prow = e - ci * PROWS;
+            const int yy = y0 + prow - 1;
+            const bool rowok = e < CIT * PROWS && (ci0 + ci) < p.Cin && yy >= 0 && yy < p.H;
+            const int off = xbase + ci * p.HW + (prow - 1) * p.W + TW - 1;        // image columns x0 + TW - 1 (inside the image) and x0 + TW
+            xp[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, rowok ? 4u * (unsigned)off : 0xFFFFFFFFu, 0, 0));
+            xp[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (rowok && x0 + TW < p.W) ? 4u * (unsigned)(off + 1) : 0xFFFFFFFFu, 0, 0));
         }
     };
     const float sdy = uz::split_scale(uz::amax_read(p.dy_amax)), sx = uz::split_scale(uz::amax_read(p.x_amax));
-    auto lstore = [&]() __attribute__((always_inline)) {
+    auto lstore = [&](int t) __attribute__((always_inline)) {
+        const bool left_edge = t % p.tilesX == 0;               // tile column 0: the quads with q == 0 were loaded one column to the right
 #pragma unroll
         for (int i = 0; i < DYSLOTS; ++i) {
             unsigned a1, a2, b1, b2;
@@ -121,13 +145,27 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             *reinterpret_cast<uint2*>(d + DYPLANE) = make_uint2(a2, b2);
         }
 #pragma unroll
-        for (int i = 0; i < XSLOTS; ++i) {
+        for (int i = 0; i < XQSLOTS; ++i) {
             const int e = tid + i * NT;
-            if (e < CIT * XPAIRS) {
-                const int ci = e / XPAIRS, rem = e - ci * XPAIRS, prow = rem / PAIRS_ROW, pj = rem - prow * PAIRS_ROW;
+            if (e < CIT * PROWS * QROWX) {
+                const int q = e % QROWX, r = e / QROWX, ci = r / PROWS, prow = r - ci * PROWS;
+                unsigned a1, a2, b1, b2;
+                const f32x4 v = (left_edge && q == 0) ? f32x4{0.f, xq[i][0], xq[i][1], xq[i][2]} : xq[i];
+                split2(v[0] * sx, v[1] * sx, a1, a2);
+                split2(v[2] * sx, v[3] * sx, b1, b2);
+                char* d = Xl + ci * XCH + prow * XROW + q * 8;
+                *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2*>(d + XPLANE) = make_uint2(a2, b2);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < XPSLOTS; ++i) {
+            const int e = tid + i * NT;
+            if (e < CIT * PROWS) {
+                const int ci = e / PROWS, prow = e - ci * PROWS;
                 unsigned a1, a2;
-                split2(xreg[i][0] * sx, xreg[i][1] * sx, a1, a2);
-                char* d = Xl + ci * XCH + prow * XROW + pj * 4;
+                split2(xp[i][0] * sx, xp[i][1] * sx, a1, a2);
+                char* d = Xl + ci * XCH + prow * XROW + QROWX * 8;
                 *reinterpret_cast<unsigned*>(d) = a1;
                 *reinterpret_cast<unsigned*>(d + XPLANE) = a2;
             }
@@ -148,17 +186,27 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         int t = split;
         long long st0 = 0, st1 = 0, stl = 0, rt0 = 0;
         if (p.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-        if (t < p.T) gload(t);
+        if (t < p.T) gload(t, -1);
+        if (p.flags && t < p.T) {                       // bound check on the first tile (the clamp in split2 covers every tile)
+            bool bx = false, bd = false;
+#pragma unroll
+            for (int i = 0; i < DYSLOTS; ++i) bd |= uz::bound_violated(dreg[i][0] * sdy, dreg[i][1] * sdy) | uz::bound_violated(dreg[i][2] * sdy, dreg[i][3] * sdy);
+#pragma unroll
+            for (int i = 0; i < XQSLOTS; ++i) bx |= uz::bound_violated(xq[i][0] * sx, xq[i][1] * sx) | uz::bound_violated(xq[i][2] * sx, xq[i][3] * sx);
+            if (bd) atomicOr(p.flags, uz::FLAG_DY_BOUND);
+            if (bx) atomicOr(p.flags, uz::FLAG_X_BOUND);
+        }
         for (; t < p.T; t += p.S) {
             long long ta = 0;
             if (p.stamps) ta = __builtin_amdgcn_s_memtime();
             __syncthreads();                   // every wave finished the MFMAs of the previous tile
-            lstore();
+            lstore(t);
             __syncthreads();
             if (p.stamps) { const long long tb = __builtin_amdgcn_s_memtime(); if (t == split) st1 = tb; else stl += tb - ta; }
-            if (t + p.S < p.T) gload(t + p.S); // in flight during the MFMA loop below
+            const bool more = t + p.S < p.T;
 #pragma unroll
             for (int si = 0; si < PT / 16 / WK; ++si) {
+                if (more) gload(t + p.S, si);               // a portion of the next tile's loads per k-step, in flight during the MFMAs
                 const int s = si * WK + wk;                 // WK == 1: compile-time; WK == 4: wave-uniform
                 const int srow = s / SROW, scol = (s % SROW) * 16;
                 f16x8 a[NP];
@@ -308,12 +356,12 @@ static int launch_wgrad(const WS& p, int grid, hipStream_t st) {
 int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* slab,
                 int N, int H, int W, int S, const float* x_amax, const float* dy_amax, hipStream_t st) {
     WS p;
-    p.x = x; p.dy = dy; p.slab = slab; p.x_amax = x_amax; p.dy_amax = dy_amax; p.stamps = debug_stamps;
+    p.x = x; p.dy = dy; p.slab = slab; p.x_amax = x_amax; p.dy_amax = dy_amax; p.stamps = debug_stamps; p.flags = dev_flags_ptr();
     p.N = N; p.H = H; p.W = W; p.HW = H * W; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot;
     const int tw = tile_w(W), ct = chan_tile(Cin, Cout);
     p.tilesX = W / tw; p.tilesY = ceil_div(H, PT / tw); p.T = N * p.tilesX * p.tilesY; p.S = S;
     p.nCoT = ceil_div(Cout, ct); p.nCiT = ceil_div(Cin, ct);
-    UZ_REQUIRE((size_t)N * CinTot * p.HW < (1ull << 30) && (size_t)N * CoutTot * p.HW < (1ull << 30), "wgrad_split: tensor too large for 32-bit offsets");
+    UZ_REQUIRE((size_t)N * CinTot * p.HW < (1ull << 30) && (size_t)N * CoutTot * p.HW < (1ull << 30), "wgrad_split: tensor too large for 32-bit offsets (the dispatcher routes such tensors to the fp32 kernel)");
     const int grid = p.nCoT * p.nCiT * S;
     if (ct == 32) return tw == 16 ? launch_wgrad<16, 32>(p, grid, st) : launch_wgrad<32, 32>(p, grid, st);
     return tw == 16 ? launch_wgrad<16, 64>(p, grid, st) : launch_wgrad<32, 64>(p, grid, st);

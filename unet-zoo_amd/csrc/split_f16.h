@@ -34,8 +34,19 @@ __device__ __forceinline__ float split_inv_scale(float amax) {
     return __builtin_bit_cast(float, (unsigned)(254 - se) << 23);           // 2^-(se - 127)
 }
 
+// Largest finite fp16.  A scaled value beyond it can only come from a magnitude bound that is more than 4x too small (stale or
+// wrong bound handed in through the C ABI): it is clamped, so that the matrix pipe never sees an infinity (inf - inf = NaN
+// would poison a whole output tile), and reported through the device flag word (uz_device_flags) where a kernel checks it.
+constexpr float F16_MAX = 65504.f;
+// bits of the device flag word
+enum { FLAG_X_BOUND = 1, FLAG_W_BOUND = 2, FLAG_DY_BOUND = 4 };
+extern int* dev_flags_ptr();                    // conv_split.hip: lazily allocated device word (nullptr when allocation failed)
+__device__ __forceinline__ bool bound_violated(float v0, float v1) { return fabsf(v0) > F16_MAX || fabsf(v1) > F16_MAX; }
+
 // splits two (already scaled) values at once; p1 / p2 hold the pieces of (v0, v1) as packed fp16 pairs (v0 in the low half)
 __device__ __forceinline__ void split2(float v0, float v1, unsigned& p1, unsigned& p2) {
+    v0 = __builtin_amdgcn_fmed3f(v0, -F16_MAX, F16_MAX);
+    v1 = __builtin_amdgcn_fmed3f(v1, -F16_MAX, F16_MAX);
     const f32x2 a = {v0, v1};
     const f16x2 h1 = __builtin_convertvector(a, f16x2);                     // round to nearest even
     const f32x2 b = __builtin_convertvector(h1, f32x2);
