@@ -115,7 +115,7 @@ def op_bytes(op):
     f4 = 4.0
     if c == "UZ_OP_BN_RELU_FWD":
         C, N, H, W, training = i[0], i[3], i[4], i[5], i[6]
-        big = N * H * W > 8192
+        big = N * H * W > 8192 and not (len(i) > 8 and i[8])        # i[8] > 0: statistics come from the convolution's epilogue partials
         return f4 * C * N * H * W * ((3 if big else 2) if training else 2)
     if c in ("UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
         C, N, H, W = i[1], i[4], i[5], i[6]

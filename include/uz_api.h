@@ -90,6 +90,15 @@ int uz_conv_fwd_packed(const float* x, int Cin, int CinTot,
                        int N, int H, int W, int ks, int relu,
                        const float* x_amax, const float* w_amax, float* y_amax,
                        void* workspace, size_t workspace_bytes, const void* packed_w, void* stream);
+/* Forward convolution that also reduces the BatchNorm statistics of its output while the tile is in registers
+ * (torchlayers.py:18-21: every Conv2d of a Conv2D unit feeds a BatchNorm2d): bn_partials (nullable) receives
+ * uz_conv_bn_partials(...) x Cout x 4 floats for uz_bn_relu_fwd_pre.  uz_conv_bn_partials returns 0 for shapes whose kernel
+ * cannot do this (off the split-fp16 path, split-K); relu must be 0 with bn_partials.                                     */
+int uz_conv_bn_partials(int Cin, int Cout, int N, int H, int W, int ks);
+int uz_conv_fwd_bnstats(const float* x, int Cin, int CinTot, const float* w, const float* bias,
+                        float* y, int Cout, int CoutTot, int N, int H, int W, int ks, int relu,
+                        const float* x_amax, const float* w_amax, float* y_amax,
+                        void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials, void* stream);
 int uz_conv_bwd_data_packed(const float* dy, int Cout, int CoutTot,
                             const float* w,
                             float* dx, int Cin, int CinTot,
@@ -128,6 +137,14 @@ int uz_bn_relu_fwd(const float* y, int C, int CtotY,
                    float* a, int CtotA,
                    int N, int H, int W, float eps, float momentum, int training, int relu,
                    float* a_amax, void* workspace, void* stream);
+/* The same with the batch statistics taken from the partials the producing convolution wrote in its epilogue
+ * (uz_conv_fwd_bnstats): conv_partials = [n_partials][C][4] floats {sum, sum of squares, max, max of the negated}; NULL / 0 =
+ * uz_bn_relu_fwd.  Training mode, N*H*W > 4096 only.                                                                     */
+int uz_bn_relu_fwd_pre(const float* y, int C, int CtotY, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float* save_mean_rstd,
+                       float* a, int CtotA, int N, int H, int W, float eps, float momentum,
+                       int training, int relu, float* a_amax, void* workspace,
+                       const float* conv_partials, int n_partials, void* stream);
 /* native_batch_norm_backward + threshold_backward: da -> dy, dgamma, dbeta, and the
  * conv-bias gradient dbias = sum dy (nullable).  dy may alias da.               */
 int uz_bn_relu_bwd(const float* da, int CtotDa,
@@ -233,6 +250,12 @@ int uz_add_views(const float* a, int CtotA, const float* b, int CtotB, float* y,
 int uz_absmax(const float* x, size_t n, float* slot, void* stream);
 /* dst bound slot = max(dst, value of src bound slot): forwards a magnitude bound through ops that cannot raise it (pooling, interpolation) */
 int uz_absmax_copy(const float* src_slot, float* dst_slot, void* stream);
+/* Latent noise eps ~ N(0, 1) (phiseg.py:104 torch.randn_like, probabilistic_unet.py:276 rsample) on the device: Philox4x32-10 +
+ * Box-Muller keyed by rng_state = {seed, offset} (two uint64 in DEVICE memory; offset counts 4-float blocks).  uz_step_counters
+ * runs behind it: counters[idx[k]] += 1 for the BatchNorm batch counters (num_batches_tracked) of the pass and
+ * rng_state.offset += advance - so a replayed launch never repeats a draw.  (uint64_t parameters are passed as pointers / int64.) */
+int uz_randn_fill(float* dst, size_t n, const void* rng_state, void* stream);
+int uz_step_counters(int64_t* counters, const int64_t* idx, int n_idx, void* rng_state, int64_t advance, void* stream);
 /* Device flag word of the split-fp16 convolution path.  The kernels scale every operand by a power of two taken from an upper
  * bound of its tensor's magnitudes; a bound that is too small by more than 4x (a stale parameter bound, a wrong bound passed to a
  * stand-alone call) would overflow fp16.  Such values are CLAMPED to the largest finite fp16 (the result is wrong but never inf /

@@ -160,6 +160,82 @@ def test_bn_relu_fwd_bwd(N, C, H, W, relu):
     assert g.maxabs(abuf[:, 2:], ae) <= 2e-5
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(8, 64, 64, 64, 64),        # 16 x 32 tiles, 64-channel tiles
+                                            (4, 40, 224, 64, 96),       # Cout = 3 x 64 + 32: the half tile; K tail
+                                            (4, 64, 96, 37, 70),        # ragged planes: partial tiles contribute only their valid pixels
+                                            (32, 128, 96, 32, 32),      # 16 x 16 tiles (one wave per channel row)
+                                            (2, 32, 32, 128, 128)])     # 32-channel tiles
+def test_conv_with_fused_bn_statistics(N, Cin, Cout, H, W):
+    """uz_conv_fwd_bnstats + uz_bn_relu_fwd_pre == Conv2d -> BatchNorm2d(train) -> ReLU (torchlayers.py:18-21): the convolution's
+    epilogue leaves per-tile partial statistics, the BatchNorm finalises them instead of re-reading y."""
+    g = _g()
+    from unet_zoo_amd import _ffi
+    L = _ffi.lib()
+    npart = L.uz_conv_bn_partials(Cin, Cout, N, H, W, 3)
+    if L.uz_get_conv_math() == 0:
+        assert npart == 0
+        pytest.skip("fp32-MFMA mode: no fused statistics")
+    assert npart > 0, "shape must support fused statistics"
+    x = g.rnd(N, Cin, H, W, seed=1)
+    w = g.rnd(Cout, Cin, 3, 3, seed=2, scale=0.1)
+    b = g.rnd(Cout, seed=3)
+    gamma, beta = g.rnd(Cout, seed=6).abs() + 0.5, g.rnd(Cout, seed=7) * 0.3
+    rm, rv = g.rnd(Cout, seed=8) * 0.1, g.rnd(Cout, seed=9).abs() + 0.5
+    yr = F.conv2d(x, w, b, padding=1)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    ar = F.relu(F.batch_norm(yr, rm_r, rv_r, gamma, beta, training=True, momentum=0.01, eps=1e-3))
+    wsb = L.uz_conv_workspace(Cin, Cout, N, H, W, 3)
+    ws = torch.empty(wsb // 4 + 16, device=g.dev())
+    ybuf = torch.full((N, Cout + 3, H, W), float("nan"), device=g.dev())
+    yv = ybuf[:, 1:]
+    part = torch.full((npart * Cout * 4,), float("nan"), device=g.dev())
+    g.call("uz_conv_fwd_bnstats", x.to(g.dev()), Cin, Cin, w.to(g.dev()), b.to(g.dev()), yv, Cout, Cout + 3, N, H, W, 3, 0, None, None, None, ws, wsb, None, part)
+    assert g.relerr(ybuf[:, 1:1 + Cout], yr) <= TOL
+    assert torch.isfinite(part.view(npart, Cout, 4)[:, :, :2]).all()
+    pr = part.view(npart, Cout, 4).cpu().double()
+    assert float((pr[:, :, 0].sum(0) - yr.double().sum((0, 2, 3))).abs().max()) <= 1e-5 * float(yr.abs().sum((0, 2, 3)).max())
+    assert float((pr[:, :, 2].max(0).values - yr.amax((0, 2, 3)).double()).abs().max()) <= 1e-5 * float(yr.abs().max())
+    bws = torch.empty(L.uz_bn_workspace(Cout, N, H, W) // 4 + 16, device=g.dev())
+    a = torch.empty(N, Cout, H, W, device=g.dev())
+    save = torch.empty(2 * Cout, device=g.dev())
+    rmd, rvd = rm.to(g.dev()), rv.to(g.dev())
+    slot = torch.zeros(256, device=g.dev())
+    g.call("uz_bn_relu_fwd_pre", yv, Cout, Cout + 3, gamma.to(g.dev()), beta.to(g.dev()), rmd, rvd, save, a, Cout, N, H, W, 1e-3, 0.01, 1, 1, slot, bws, part, npart)
+    assert g.maxabs(a, ar) <= 3e-5
+    assert g.maxabs(rmd, rm_r) <= 1e-6 and g.maxabs(rvd, rv_r) <= 1e-5
+    assert float(slot.max()) >= float(ar.max()) * (1 - 1e-5) and float(slot.max()) <= float(ar.max()) * 1.001     # exact range from the partial maxima
+    # the same statistics as the stand-alone pass
+    save2 = torch.empty(2 * Cout, device=g.dev())
+    g.call("uz_bn_relu_fwd", yv, Cout, Cout + 3, gamma.to(g.dev()), beta.to(g.dev()), rm.to(g.dev()), rv.to(g.dev()), save2, a, Cout, N, H, W, 1e-3, 0.01, 1, 1, None, bws)
+    assert g.relerr(save, save2) <= 2e-6
+
+
+def test_device_normal_stream_and_step_counters():
+    """uz_randn_fill / uz_step_counters replace normal_() / index_add_ in the step (no ATen compute between the tape launches):
+    standard normal moments, no repetition across launches, repeatable for a seed, ragged sizes, counters bumped exactly once."""
+    g = _g()
+    n = 1 << 20
+    st = torch.tensor([12345, 0], dtype=torch.int64, device=g.dev())
+    a, b = torch.empty(n, device=g.dev()), torch.empty(n, device=g.dev())
+    g.call("uz_randn_fill", a, n, st)
+    g.call("uz_step_counters", None, None, 0, st, (n + 3) // 4)
+    g.call("uz_randn_fill", b, n, st)
+    assert int(st[1]) == n // 4
+    x = a.double().cpu()
+    assert abs(float(x.mean())) < 4e-3 and abs(float(x.std()) - 1) < 4e-3
+    assert abs(float((x ** 3).mean())) < 2e-2 and abs(float((x ** 4).mean()) - 3) < 5e-2 and float(x.abs().max()) < 6.5
+    assert abs(float((a * b).mean())) < 4e-3 and not torch.equal(a, b)                 # the next launch continues the stream
+    st2 = torch.tensor([12345, 0], dtype=torch.int64, device=g.dev())
+    c = torch.full((n + 3,), float("nan"), device=g.dev())
+    g.call("uz_randn_fill", c, n + 1, st2)                                                # ragged count: the tail stays untouched
+    assert torch.equal(c[:n], a) and torch.isfinite(c[n]) and torch.isnan(c[n + 1:]).all()
+    cnt = torch.zeros(7, dtype=torch.int64, device=g.dev())
+    idx = torch.tensor([5, 0, 3], dtype=torch.int64, device=g.dev())
+    g.call("uz_step_counters", cnt, idx, 3, None, 0)
+    g.call("uz_step_counters", cnt, idx, 3, None, 0)
+    assert cnt.tolist() == [2, 0, 0, 2, 0, 2, 0]
+
+
 def test_relu_bwd():
     g = _g()
     from unet_zoo_amd import _ffi

@@ -92,11 +92,17 @@ class NativeModel(nn.Module):
         return p
 
     default_lanes = 2          # dependency lanes of the captured graphs (UZ_LANES overrides); see ProbabilisticUnet
+    # Planes (N*H*W pixels) up to which a layer's weight gradient becomes a scheduling group of its own (Plan._decouple_wgrad;
+    # UZ_DECOUPLE_WGRAD overrides).  Measured A/B on one MI355X: PHiSeg 19.49 -> 19.26 ms with 8192 (the deep levels' backward
+    # chains no longer carry the weight gradients), Probabilistic U-Net 11.33 -> 11.66 ms (three lanes already interleave its
+    # chains) - so it is a per-model default.
+    decouple_wgrad_px = 0
 
     def _new_plan(self, N, bn_training):
         plan = Plan(N, self._ptab, bn_training, self.device)
         if "UZ_LANES" not in os.environ:
             plan.n_lanes = self.default_lanes
+        plan.decouple_wgrad_px = self.decouple_wgrad_px
         dp = getattr(self, "_dp", None)
         if dp is not None and dp.overlap:
             plan.grad_buckets = list(dp.buckets)
@@ -218,13 +224,35 @@ class NativeModel(nn.Module):
         return _TapeLoss.apply(self._anchor, self, plan)
 
     def _bump_nbt(self, plan, which="bn_prefixes_nbt"):
+        """num_batches_tracked += 1 for every BatchNorm the pass ran (uz_step_counters: one tiny launch of our own, no ATen
+        index_add_ in the step)."""
         idx = plan.__dict__.get("_nbt_idx_" + which)
         if idx is None:
             ks = [self._ptab.nbt_keys.index(k) for k in plan.__dict__.get(which, [])]
             idx = torch.tensor(ks, dtype=torch.int64, device=self.device)
             plan.__dict__["_nbt_idx_" + which] = idx
         if idx.numel():
-            self._ptab.nbt.index_add_(0, idx, torch.ones_like(idx))
+            _ffi.check(_ffi.lib().uz_step_counters(self._ptab.nbt.data_ptr(), idx.data_ptr(), idx.numel(), None, 0, C.c_void_p(self._stream())),
+                       "step_counters")
+
+    def _rng_state(self):
+        """{seed, offset} of the device-side latent-noise stream (uz_randn_fill): seeded from torch's default generator when
+        first used, so torch.manual_seed(...) before the first draw makes runs repeatable."""
+        st = self.__dict__.get("_rng_state_t")
+        if st is None:
+            st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=self.device)
+            object.__setattr__(self, "_rng_state_t", st)
+        return st
+
+    def _fill_normal(self, t):
+        """t.normal_() without ATen: Philox / Box-Muller on the device, the stream offset advanced behind the fill."""
+        assert t.dtype == torch.float32
+        if not t.is_contiguous():                       # (padded volume views): draw into a dense scratch, then move
+            return t.copy_(self._fill_normal(torch.empty(t.shape, dtype=torch.float32, device=t.device)))
+        L, st, s = _ffi.lib(), self._rng_state(), C.c_void_p(self._stream())
+        _ffi.check(L.uz_randn_fill(t.data_ptr(), t.numel(), st.data_ptr(), s), "randn_fill")
+        _ffi.check(L.uz_step_counters(None, None, 0, st.data_ptr(), (t.numel() + 3) // 4, s), "step_counters")
+        return t
 
 
 def conv_unit(plan, x, prefix, out=None, relu=True, recompute=False, **kw):

@@ -163,6 +163,7 @@ class Plan:
         self.events = []                    # hipEvent_t handles (uz_event_create), one per gradient bucket
         self._gid = 0                       # scheduling group of the ops being emitted (see _schedule)
         self.n_lanes = max(1, min(int(os.environ.get("UZ_LANES", "2")), 8))
+        self.decouple_wgrad_px = 0           # NativeModel.decouple_wgrad_px: planes (N*H*W) up to which weight gradients get a group of their own
 
     def _newgroup(self):
         self._gid += 1
@@ -285,7 +286,7 @@ class Plan:
         self._bwd_tail.append(tail)
 
     # ------------------------------------------------------------------ convolution family
-    def _conv_fwd(self, x, wkey, bkey, y, ks, relu, wrow0=0):
+    def _conv_fwd(self, x, wkey, bkey, y, ks, relu, wrow0=0, bn_partials=None):
         cout = y.C
         cin = x.C
         if len(self.ptab.shape[wkey]) == 5 and x.nb is None:
@@ -315,7 +316,7 @@ class Plan:
         packed = self._packed(wkey, cin, cout, x, False) if (ks == 3 and wrow0 == 0) else None
         self._emit(self.target, "UZ_OP_CONV_FWD",
                    p=[x, self.P(wkey, wextra), self.P(bkey, wrow0) if bkey else None, y, ("scratch", "wgrad"),
-                      self.amax_in(x), ("amax", 0), self.amax_out(y) if (relu and ks == 3) else None, packed],
+                      self.amax_in(x), ("amax", 0), self.amax_out(y) if (relu and ks == 3) else None, packed, bn_partials],
                    i=[cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, ks, relu], n=ws)
 
     def _conv_bwd(self, x, wkey, gy, ks, db_key=None, wrow0=0):
@@ -349,10 +350,19 @@ class Plan:
         wextra = wrow0 * cin * ks * ks
         ws = self.L.uz_conv_bwd_weight_workspace(cin, cout, x.N, x.H, x.W, ks)
         self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
-        self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
-                   p=[x, gy, self.G(wkey, wextra), self.G(db_key, wrow0) if db_key else None, ("scratch", "wgrad"),
-                      self.amax_in(x), self.amax_in(gy)],
-                   i=[cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, ks], n=ws)
+
+        def emit_wgrad():
+            self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
+                       p=[x, gy, self.G(wkey, wextra), self.G(db_key, wrow0) if db_key else None, ("scratch", "wgrad"),
+                          self.amax_in(x), self.amax_in(gy)],
+                       i=[cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, ks], n=ws)
+        # dy in a buffer of its own (small planes): the data gradient - the only thing the next layer's backward waits for -
+        # goes first and the weight gradient becomes a scheduling group of its own, so that the latency-bound chains of the deep
+        # levels (BatchNorm backward -> data gradient -> next BatchNorm backward) no longer carry the weight gradients and their
+        # slab reductions; those fill the other dependency lane instead.
+        decoupled = isinstance(gy, _ScratchView) and gy.view is not None
+        if not decoupled:
+            emit_wgrad()
         if x.buf.requires_grad:
             acc = self._claim(x)
             ws2 = self.L.uz_conv_workspace(cin, cout, x.N, x.H, x.W, ks)
@@ -361,6 +371,9 @@ class Plan:
             self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
                        p=[gy, self.P(wkey, wextra), self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0), packed],
                        i=[cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, ks, acc], n=ws2)
+        if decoupled:
+            self._newgroup()
+            emit_wgrad()
 
     def _packed(self, wkey, cin, cout, x, dgrad, vol=False):
         """Reference to the pre-packed split-fp16 weight image of this layer and direction, or None when the call packs its
@@ -404,6 +417,12 @@ class Plan:
         self.__dict__.setdefault("_win_of", {})[wkey] = xc
         return xc
 
+    def _decouple_wgrad(self, x, ks):
+        """Weight gradient as a scheduling group of its own (needs dy in a real buffer instead of the lane scratch): on the
+        latency-bound planes only - at and above 32 x 32 (batch 32) every kernel of a layer's backward fills the chip anyway."""
+        lim = int(os.environ.get("UZ_DECOUPLE_WGRAD", str(self.decouple_wgrad_px)))
+        return x.nb is None and ks == 3 and self.n_lanes > 1 and x.N * x.H * x.W <= lim and not self.__dict__.get("_in_rev", False)
+
     def _gy_scratch(self, like):
         self.scratch["gy"] = max(self.scratch["gy"], like.N * like.C * like.H * like.W)
         return ("gyview", like.C)
@@ -420,14 +439,21 @@ class Plan:
         a = out if out is not None else new(name + ":a")
         assert a.C == cout and a.H == x.H and a.W == x.W
         save = save if save is not None else self.vec(name + ":bnsave", 2 * cout)
-        self._conv_fwd(x, wkey, bkey, y, ks, 0)
+        # BatchNorm statistics in the convolution's epilogue (torchlayers.py:18-21: every Conv2d of a unit feeds a BatchNorm2d):
+        # where the forward kernel supports it, it leaves per-tile {sum, sum of squares, max, max(-y)} partials and the
+        # BatchNorm finalises them instead of streaming y a second time
+        npart = 0
+        if self.bn_training and x.nb is None and os.environ.get("UZ_BN_FUSE_STATS", "1") == "1" and x.N * x.H * x.W > 4096:
+            npart = self.L.uz_conv_bn_partials(x.C, cout, x.N, x.H, x.W, ks)
+        bnpart = self.vec(name + ":bnpart", 4 * cout * npart) if npart else None
+        self._conv_fwd(x, wkey, bkey, y, ks, 0, bn_partials=bnpart)
         bnws = self.L.uz_bn_workspace(cout, x.N, x.H, x.W)
         self.scratch["bn"] = max(self.scratch["bn"], bnws)
         gam, bet = bprefix + ".weight", bprefix + ".bias"
         self._emit(self.target, "UZ_OP_BN_RELU_FWD",
                    p=[y, self.P(gam), self.P(bet), self.B(bprefix + ".running_mean"), self.B(bprefix + ".running_var"),
-                      save, a, ("scratch", "bn"), self.amax_out(a)],
-                   i=[cout, y.Ctot, a.Ctot, x.N, x.H, x.W, int(self.bn_training), int(relu)], f=[BN_EPS, BN_MOMENTUM])
+                      save, a, ("scratch", "bn"), self.amax_out(a), bnpart],
+                   i=[cout, y.Ctot, a.Ctot, x.N, x.H, x.W, int(self.bn_training), int(relu), npart], f=[BN_EPS, BN_MOMENTUM])
 
         def bwd():
             if a_grad is None and not self._has_grad(a):
@@ -436,6 +462,9 @@ class Plan:
                 raise RuntimeError("backward through eval-mode BatchNorm is not supported")
             gy = self._gy_scratch(y)
             gyv = _ScratchView(y.N, cout, y.H, y.W, amax=self._new_amax(bwd=True))
+            if self._decouple_wgrad(x, ks) and ybuf is None and a_grad is None:
+                gyv.view = self.buf(name + ":dy", cout, y.H, y.W, N=y.N, requires_grad=False)
+                gy = gyv
             if x.nb is not None and ks == 3:
                 # volume: dy sits one slice into the scratch, between two zeroed border slices (the data gradient reads it
                 # through a depth window)
@@ -955,6 +984,8 @@ class Plan:
         if r is None:
             return 0
         if isinstance(r, _ScratchView):
+            if r.view is not None:
+                return self._resolve(r.view, lane)
             return self.base + 4 * (self.gy_off[lane] + r.off)
         if isinstance(r, View):
             assert r.buf.off is not None
@@ -1020,7 +1051,7 @@ class Plan:
     # Which p[] slots an op writes (every other slot is read).  Scratch slots are private to a
     # group and parameters are read-only inside a tape, so neither creates a dependency.
     _WRITES = {
-        "UZ_OP_CONV_FWD": (3,), "UZ_OP_CONV_BWD_DATA": (2,), "UZ_OP_CONV_BWD_WEIGHT": (2, 3),
+        "UZ_OP_CONV_FWD": (3, 9), "UZ_OP_CONV_BWD_DATA": (2,), "UZ_OP_CONV_BWD_WEIGHT": (2, 3),
         "UZ_OP_BN_RELU_FWD": (3, 4, 5, 6), "UZ_OP_BN_RELU_BWD": (5, 6, 7, 8), "UZ_OP_RELU_BWD": (2, 3),
         "UZ_OP_AVGPOOL_FWD": (1,), "UZ_OP_AVGPOOL_BWD": (1,), "UZ_OP_BILINEAR_FWD": (1,), "UZ_OP_BILINEAR_BWD": (1,),
         "UZ_OP_NEAREST_FWD": (1,), "UZ_OP_NEAREST_BWD": (1,), "UZ_OP_SPATIAL_MEAN_FWD": (1,), "UZ_OP_SPATIAL_MEAN_BWD": (1,),
@@ -1036,6 +1067,8 @@ class Plan:
 
     def _resources(self, r):
         """Dependency-relevant resources behind one pointer ref: (space, lo, hi) half-open ranges."""
+        if isinstance(r, _ScratchView) and r.view is not None:
+            return self._resources(r.view)
         if r is None or isinstance(r, _ScratchView):
             return []
         if isinstance(r, View):
@@ -1308,3 +1341,4 @@ class _ScratchView:
         self.amax = amax          # magnitude-bound slot of this unit's dy
         self.off = 0              # float offset inside the scratch (volumes: one slice, behind the zeroed border slice)
         self.nb = None
+        self.view = None          # a buffer of its own instead of the lane's scratch (decoupled weight gradients, see _conv_bwd)

@@ -29,6 +29,8 @@ struct BnP {
     int nb, ngrp;                                      // reduction kernels: images per workgroup, number of image groups
     float eps, momentum;
     int training, relu;
+    int pre;                                           // training statistics already in save[] (finalised from the convolution's partials)
+    const float* cpart; int ncpart;                    // the producing convolution's per-tile partials {sum, sum sq, max, max(-y)} [ncpart][C]
     float* amax;                                       // nullable: atomic max of |out| (bound for a following split-fp16 convolution)
 };
 
@@ -114,13 +116,52 @@ __device__ __forceinline__ void channel_totals(const BnP& p, int c, double* red,
     t0 = red[0]; t1 = red[1];
 }
 
+// Statistics from the partials the convolution's epilogue wrote while the tile was still in registers (conv_split.hip): one
+// workgroup per channel adds them in a fixed order in fp64 and publishes mean / rstd, the running statistics and the output
+// bound - the streaming statistics pass over y (a third of the forward BatchNorm traffic) disappears.
+__global__ __launch_bounds__(256) void bn_finalize_conv_partials(const BnP p) {
+    __shared__ double sm[8];
+    __shared__ float smf[8];
+    const int c = blockIdx.x;
+    double v2[2] = {0.0, 0.0};
+    float vmx = -INFINITY, vmn = -INFINITY;
+    for (int i = threadIdx.x; i < p.ncpart; i += 256) {
+        const float4 q = *reinterpret_cast<const float4*>(p.cpart + ((size_t)i * p.C + c) * 4);
+        v2[0] += (double)q.x; v2[1] += (double)q.y;
+        vmx = fmaxf(vmx, q.z); vmn = fmaxf(vmn, q.w);
+    }
+    uz::block_sum_d<2>(v2, sm);
+    block_max2(vmx, vmn, smf);
+    if (threadIdx.x == 0) {
+        const double n = (double)p.N * p.HW;
+        const double m = v2[0] / n;
+        double var = v2[1] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        p.save[c] = mean;
+        p.save[p.C + c] = rstd;
+        if (p.rmean) {
+            const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+            p.rmean[c] = (float)((1.0 - p.momentum) * p.rmean[c] + p.momentum * m);
+            p.rvar[c] = (float)((1.0 - p.momentum) * p.rvar[c] + p.momentum * unb);
+        }
+        if (p.amax) {
+            const float g = p.gamma ? p.gamma[c] : 1.f, bb = p.beta ? p.beta[c] : 0.f;
+            const float alpha = g * rstd, beta_ = bb - mean * alpha;
+            const float floor0 = p.relu ? 0.f : -INFINITY;
+            const float e0 = fmaxf(fmaf(vmx, alpha, beta_), floor0), e1 = fmaxf(fmaf(-vmn, alpha, beta_), floor0);
+            uz::amax_publish_one(fmaxf(fabsf(e0), fabsf(e1)), p.amax, (unsigned)c);
+        }
+    }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
     __shared__ double red[2];
     __shared__ float redf[2];
     const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
     float alpha, beta_, mean, rstd;
-    if (p.training) {
+    if (p.training && !p.pre) {
         double s, ss;
         channel_totals(p, c, red, s, ss, redf);
         const double n = (double)p.N * p.HW;
@@ -444,7 +485,17 @@ extern "C" int uz_bn_relu_fwd(const float* y, int C, int CtotY, const float* gam
                               float* running_mean, float* running_var, float* save_mean_rstd,
                               float* a, int CtotA, int N, int H, int W, float eps, float momentum,
                               int training, int relu, float* a_amax, void* workspace, void* stream) {
+    return uz_bn_relu_fwd_pre(y, C, CtotY, gamma, beta, running_mean, running_var, save_mean_rstd, a, CtotA, N, H, W, eps, momentum,
+                              training, relu, a_amax, workspace, nullptr, 0, stream);
+}
+
+extern "C" int uz_bn_relu_fwd_pre(const float* y, int C, int CtotY, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float* save_mean_rstd,
+                                  float* a, int CtotA, int N, int H, int W, float eps, float momentum,
+                                  int training, int relu, float* a_amax, void* workspace,
+                                  const float* conv_partials, int n_partials, void* stream) {
     UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_fwd: empty tensor");
+    UZ_REQUIRE(!conv_partials || (training && n_partials > 0 && (size_t)N * H * W > SMALL_LIMIT), "bn_relu_fwd: convolution partials only serve the training-mode large-plane path");
     UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_fwd: N or C exceeds grid limits");
     UZ_REQUIRE(!training || save_mean_rstd, "bn_relu_fwd: training needs save_mean_rstd");
     UZ_REQUIRE(training || (running_mean && running_var), "bn_relu_fwd: eval needs running statistics");
@@ -463,7 +514,11 @@ extern "C" int uz_bn_relu_fwd(const float* y, int C, int CtotY, const float* gam
     const dim3 grid(p.parts, C, N);
     reduction_groups(p);
     const dim3 rgrid(p.parts, C, p.ngrp);
-    if (training) {
+    if (training && conv_partials) {
+        p.pre = 1; p.cpart = conv_partials; p.ncpart = n_partials;
+        hipLaunchKernelGGL(bn_finalize_conv_partials, dim3(C), dim3(256), 0, st, p);
+        if (int rc = uz::check_launch("bn_finalize_conv_partials")) return rc;
+    } else if (training) {
         UZ_REQUIRE(workspace, "bn_relu_fwd: workspace required");
         carve(p, workspace);
         if (vec) hipLaunchKernelGGL(bn_stats_partial<true>, rgrid, dim3(256), 0, st, p);

@@ -399,14 +399,15 @@ size_t conv_workspace(int Kc, int Mc, int N, int H, int W, int ks) {
 int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
               float* y, int Mc, int McTot, int N, int H, int W, int ks, int dgrad, int relu, int accumulate,
               const float* x_amax, const float* w_amax, float* y_amax,
-              void* workspace, size_t workspace_bytes, const void* packed_w, hipStream_t st) {
+              void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials, hipStream_t st) {
     UZ_REQUIRE(ks == 1 || ks == 3, "conv: kernel size %d unsupported (1 or 3)", ks);
     UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Kc > 0 && Mc > 0, "conv: empty tensor");
     UZ_REQUIRE(H <= 4096 && W <= 4096, "conv: spatial size too large");
     // large 3x3 layers: split-bf16 matrix pipe (conv_split.hip); its packed weight image lives in the workspace
     if (conv_split_ok(Kc, Mc, N, H, W, ks) && workspace && workspace_bytes >= conv_split_workspace(Kc, Mc, N, H, W))
-        return conv_split(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, dgrad, relu, accumulate, x_amax, w_amax, y_amax, workspace, packed_w, st);
+        return conv_split(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, dgrad, relu, accumulate, x_amax, w_amax, y_amax, workspace, packed_w, bn_partials, st);
     UZ_REQUIRE(!packed_w, "conv: a pre-packed weight image was supplied for a layer that does not take the split path");
+    UZ_REQUIRE(!bn_partials, "conv: fused BatchNorm statistics were requested for a layer that does not take the split path (uz_conv_bn_partials() == 0)");
     const Geom g = pick_geom(N, H, W, ks / 2);
     ConvP p;
     p.x = x; p.w = w; p.bias = bias; p.y = y;
@@ -444,10 +445,15 @@ extern "C" size_t uz_conv_workspace(int Cin, int Cout, int N, int H, int W, int 
     return a > b ? a : b;
 }
 
-extern "C" int uz_conv_fwd_packed(const float* x, int Cin, int CinTot, const float* w, const float* bias,
-                                  float* y, int Cout, int CoutTot, int N, int H, int W, int ks, int relu,
-                                  const float* x_amax, const float* w_amax, float* y_amax,
-                                  void* workspace, size_t workspace_bytes, const void* packed_w, void* stream) {
+extern "C" int uz_conv_bn_partials(int Cin, int Cout, int N, int H, int W, int ks) {
+    if (ks != 3 || conv_thin_ok(Cin, Cout, N, H, W, ks)) return 0;
+    return uz::conv_split_bn_partials(Cin, Cout, N, H, W);
+}
+extern "C" int uz_conv_fwd_bnstats(const float* x, int Cin, int CinTot, const float* w, const float* bias,
+                                   float* y, int Cout, int CoutTot, int N, int H, int W, int ks, int relu,
+                                   const float* x_amax, const float* w_amax, float* y_amax,
+                                   void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials, void* stream) {
+    UZ_REQUIRE(!bn_partials || uz_conv_bn_partials(Cin, Cout, N, H, W, ks) > 0, "conv_fwd_bnstats: this shape writes no fused statistics (uz_conv_bn_partials() == 0)");
     if (ks == 1 && !relu && uz::conv1x1_small_ok(Cin, Cout)) {        // 2..8-output heads: streaming VALU kernel
         const int rc = uz::conv1x1_small_fwd(x, Cin, CinTot, w, bias, y, Cout, CoutTot, N, H, W, uz::S(stream));
         if (rc != -2) return rc;
@@ -460,7 +466,13 @@ extern "C" int uz_conv_fwd_packed(const float* x, int Cin, int CinTot, const flo
 #undef UZ_THINF
         return uz::check_launch("conv_thin_fwd_kernel");
     }
-    return uz::conv_mfma(x, Cin, CinTot, w, Cin, bias, y, Cout, CoutTot, N, H, W, ks, 0, relu, 0, x_amax, w_amax, y_amax, workspace, workspace_bytes, packed_w, uz::S(stream));
+    return uz::conv_mfma(x, Cin, CinTot, w, Cin, bias, y, Cout, CoutTot, N, H, W, ks, 0, relu, 0, x_amax, w_amax, y_amax, workspace, workspace_bytes, packed_w, bn_partials, uz::S(stream));
+}
+extern "C" int uz_conv_fwd_packed(const float* x, int Cin, int CinTot, const float* w, const float* bias,
+                                  float* y, int Cout, int CoutTot, int N, int H, int W, int ks, int relu,
+                                  const float* x_amax, const float* w_amax, float* y_amax,
+                                  void* workspace, size_t workspace_bytes, const void* packed_w, void* stream) {
+    return uz_conv_fwd_bnstats(x, Cin, CinTot, w, bias, y, Cout, CoutTot, N, H, W, ks, relu, x_amax, w_amax, y_amax, workspace, workspace_bytes, packed_w, nullptr, stream);
 }
 extern "C" int uz_conv_fwd(const float* x, int Cin, int CinTot, const float* w, const float* bias,
                            float* y, int Cout, int CoutTot, int N, int H, int W, int ks, int relu,
@@ -477,7 +489,7 @@ extern "C" int uz_conv_bwd_data_packed(const float* dy, int Cout, int CoutTot, c
         const int rc = uz::conv1x1_small_bwd_data(dy, Cout, CoutTot, w, dx, Cin, CinTot, N, H, W, accumulate, uz::S(stream));
         if (rc != -2) return rc;
     }
-    return uz::conv_mfma(dy, Cout, CoutTot, w, Cin, nullptr, dx, Cin, CinTot, N, H, W, ks, 1, 0, accumulate, dy_amax, w_amax, nullptr, workspace, workspace_bytes, packed_w, uz::S(stream));
+    return uz::conv_mfma(dy, Cout, CoutTot, w, Cin, nullptr, dx, Cin, CinTot, N, H, W, ks, 1, 0, accumulate, dy_amax, w_amax, nullptr, workspace, workspace_bytes, packed_w, nullptr, uz::S(stream));
 }
 extern "C" int uz_conv_bwd_data(const float* dy, int Cout, int CoutTot, const float* w,
                                 float* dx, int Cin, int CinTot, int N, int H, int W, int ks, int accumulate,

@@ -51,6 +51,7 @@ struct SP {
     float* slab;                                  // [kSplit][N][Cout][HW] partial sums (kSplit > 1), summed in order by splitk_reduce
     long long* stamps;                            // diagnostics (uz_debug_stamps): 8 cycle stamps per workgroup, normally null
     int* flags;                                   // device flag word (bound violations), nullable
+    float* bnpart;                                // nullable: per-(pixel tile, row half, channel) {sum, sum of squares, max, max of negated} of y
 };
 
 
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 }
 
 template <int MSUB, int NTv, int TWv>
-__global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void conv_split_kernel(const SP p) {
+__device__ __forceinline__ void conv_split_body(const SP& p) {
     using GEO = Geo<NTv, TWv>;
     constexpr int NT = GEO::NT, TW = GEO::TW, PW = GEO::PW, PSI = GEO::PSI, PSR = GEO::PSR, G = GEO::G, CE = GEO::CE;
     constexpr int COT = 32 * MSUB;
@@ -244,8 +245,7 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void c
     // A 64-channel tile whose upper 32 channels lie beyond Cout (Cout = 224 = 3 x 64 + 32: the data gradient of the heaviest
     // layer) skips that half's MFMAs, fragment reads and epilogue pass: 12.5 % of that launch's matrix work were zeros.
     const bool half_tile = MSUB == 2 && p.Cout - co0 <= 32;
-    auto main_loop = [&](auto ms_c) __attribute__((always_inline)) {
-    constexpr int MS = decltype(ms_c)::value;
+    constexpr int MS = MSUB;
     for (int c = cbeg; c < nChunks; ++c) {
         long long ta = 0;
         if (p.stamps) ta = __builtin_amdgcn_s_memtime();
@@ -272,7 +272,8 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void c
             if (more) stage(c + 1, tap);
             // smallest products first
 #pragma unroll
-            for (int m = 0; m < MS; ++m)
+            for (int m = 0; m < MS; ++m) {
+                if (m == 1 && half_tile) continue;           // workgroup-uniform: a scalar branch around six MFMAs
 #pragma unroll
                 for (int n = 0; n < NSUB; ++n) {
                     f32x16 t = acc[m][n];
@@ -281,11 +282,9 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void c
                     t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], b[n][0], t, 0, 0, 0);
                     acc[m][n] = t;
                 }
+            }
         }
     }
-    };
-    if (half_tile) main_loop(std::integral_constant<int, 1>{});
-    else main_loop(std::integral_constant<int, MSUB>{});
 
     long long st2 = 0;
     if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
@@ -329,6 +328,7 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void c
             for (int j = 0; j < 2 * GP; ++j) {
                 const int row = 4 * j + rsub;            // 0 .. 8 GP - 1
                 const int co = co0 + m * 32 + g0 * 8 + row;
+                f32x4 st4 = {0.f, 0.f, -INFINITY, -INFINITY};     // BatchNorm partials of this thread's four pixels: sum, sum of squares, max, max(-y)
                 if (co < p.Cout && rowok) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(El + row * ROWF + px);
                     float* dst = obase + (size_t)co * p.HW + (size_t)oy * p.W + ox;
@@ -345,6 +345,8 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void c
                             vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                         }
                         *reinterpret_cast<f32x4*>(dst) = v;
+                        st4 = f32x4{(v.x + v.y) + (v.z + v.w), (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w),
+                                    fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), fmaxf(fmaxf(-v.x, -v.y), fmaxf(-v.z, -v.w))};
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -356,8 +358,20 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void c
                                     vmax = fmaxf(vmax, fabsf(t));
                                 }
                                 dst[e] = t;
+                                st4 = f32x4{st4.x + t, st4.y + t * t, fmaxf(st4.z, t), fmaxf(st4.w, -t)};
                             }
                     }
+                }
+                if (p.bnpart) {
+                    // BatchNorm statistics of the tile while it is in registers (torchlayers.py:18-21: every Conv2d feeds a BatchNorm2d):
+                    // the 64 lanes of a wave hold 256 pixels of ONE channel row; wave reduce, lane 0 writes the partial.
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        st4.x += __shfl_xor(st4.x, o, 64); st4.y += __shfl_xor(st4.y, o, 64);
+                        st4.z = fmaxf(st4.z, __shfl_xor(st4.z, o, 64)); st4.w = fmaxf(st4.w, __shfl_xor(st4.w, o, 64));
+                    }
+                    if (lane == 0 && co < p.Cout)
+                        *reinterpret_cast<f32x4*>(p.bnpart + ((size_t)(pixT * (Q / 64) + c4 / 64) * p.Cout + co) * 4) = st4;
                 }
             }
         }
@@ -373,11 +387,25 @@ __global__ __launch_bounds__(NTv, (MSUB == 2 ? 1 : (NTv == 256 ? 3 : 4))) void c
     }
 }
 
+// The three instances as kernels of their own (attributes take literal constants only).  The 64-channel kernel is capped at
+// UZ_SPLIT64_VGPRS registers: with 2 waves per SIMD that leaves room on every CU for the waves of a streaming kernel
+// (BatchNorm, resampling) from the other dependency lane to run BESIDE the matrix work instead of in its gaps.
+#ifndef UZ_SPLIT64_VGPRS
+#define UZ_SPLIT64_VGPRS 256
+#endif
+template <int MSUB, int NTv, int TWv> struct SplitKernel;
+__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(UZ_SPLIT64_VGPRS))) void conv_split_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32>(p); }
+__global__ __launch_bounds__(512, 4) void conv_split_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32>(p); }
+__global__ __launch_bounds__(256, 3) void conv_split_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16>(p); }
+template <> struct SplitKernel<2, 512, 32> { static constexpr auto fn = conv_split_kernel_2_512_32; };
+template <> struct SplitKernel<1, 512, 32> { static constexpr auto fn = conv_split_kernel_1_512_32; };
+template <> struct SplitKernel<1, 256, 16> { static constexpr auto fn = conv_split_kernel_1_256_16; };
+
 template <int MSUB, int NTv, int TWv>
 int launch(const SP& p, int grid, hipStream_t st) {
     constexpr size_t smem = NP * (size_t)(KK * 32 * MSUB * CK * 2) + NP * (size_t)(Geo<NTv, TWv>::PSR * CK * 2);
     static bool attr_done = false;
-    auto kern = conv_split_kernel<MSUB, NTv, TWv>;
+    auto kern = SplitKernel<MSUB, NTv, TWv>::fn;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return uz::fail("conv_split: cannot raise dynamic LDS limit");
@@ -467,6 +495,13 @@ size_t image_bytes(int Kc, int Mc, int W) {
     return (b + 255) / 256 * 256;
 }
 }  // namespace
+// Number of per-channel statistics partials a forward launch with fused BatchNorm statistics writes (0: this shape does not
+// support them - off the split path, or its chunk loop is split over workgroups and the partial sums are only added later).
+int conv_split_bn_partials(int Kc, int Mc, int N, int H, int W) {
+    if (!conv_split_ok(Kc, Mc, N, H, W, 3) || split_parts(Kc, Mc, N, H, W) != 1) return 0;
+    const int tw = tile_w(W), nt = tw == 16 ? 256 : 512;
+    return N * ceil_div(H, TH) * ceil_div(W, tw) * (nt / 4 / 64);
+}
 size_t conv_split_workspace(int Kc, int Mc, int N, int H, int W) {
     const int S = split_parts(Kc, Mc, N, H, W);
     return WS_HEAD + image_bytes(Kc, Mc, W) + (S > 1 ? (size_t)S * N * Mc * H * W * sizeof(float) : 0);
@@ -504,7 +539,7 @@ int absmax_flat(const float* x, size_t n, float* slot, hipStream_t st) {
 // bounds that the producing kernels maintain).  y_amax (nullable): atomic max of |y| for the next consumer.
 int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
-               const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, hipStream_t st) {
+               const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, float* bn_partials, hipStream_t st) {
     SP p;
     float* slots = static_cast<float*>(workspace);
     char* image = static_cast<char*>(workspace) + WS_HEAD;
@@ -531,9 +566,11 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     p.kSplit = split_parts(Kc, Mc, N, H, W);
     p.cps = ceil_div(p.nChunks, p.kSplit);
     p.kSplit = ceil_div(p.nChunks, p.cps);               // no empty parts
+    UZ_REQUIRE(!bn_partials || (p.kSplit == 1 && !relu && !accumulate && !dgrad), "conv_split: fused BatchNorm statistics need an unsplit plain forward convolution");
     p.slab = reinterpret_cast<float*>(image + image_bytes(Kc, Mc, W));
     p.stamps = uz::debug_stamps;
     p.flags = dev_flags_ptr();
+    p.bnpart = bn_partials;
     const long long grid = (long long)p.tilesX * p.tilesY * N * p.nCoTiles * p.kSplit;
     UZ_REQUIRE(grid < (1ll << 31), "conv_split: grid too large");
     // per-image buffer resources and 64-bit output addressing: only ONE image's input view has to fit 32-bit byte offsets

@@ -465,3 +465,61 @@ extern "C" int uz_l2_norms_bwd(const float* flat, const int64_t* offs_counts, in
     hipLaunchKernelGGL(l2_norms_bwd_k, dim3(n_tensors), dim3(1024), 0, uz::S(stream), flat, offs_counts, norms, scale, grad_flat);
     return uz::check_launch("l2_norms_bwd_k");
 }
+
+// ---------------------------------------------------------------- latent noise and step counters
+// eps ~ N(0, 1) for the reparameterised samples (phiseg.py:104 `torch.randn_like`, probabilistic_unet.py rsample): counter-based
+// Philox4x32-10 + Box-Muller, one 128-bit counter per four outputs.  The stream is (seed, offset) in device memory, so a captured
+// or replayed launch draws fresh numbers every time: uz_step_counters advances the offset behind the fill (and counts the
+// BatchNorm batches, num_batches_tracked, in the same launch).  The reference draws on the host generator; no two devices share
+// a random stream, so the draw ORDER is not part of the contract - determinism for a given seed is.
+namespace {
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__global__ __launch_bounds__(256) void randn_fill_k(float* __restrict__ dst, size_t n, const unsigned long long* __restrict__ state) {
+    const unsigned long long seed = state[0], base = state[1];
+    const size_t quads = (n + 3) / 4;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (size_t)gridDim.x * 256) {
+        const unsigned long long ctr = base + q;
+        unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), 0x5A5A5A5Au, 0u};
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        float o[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);        // (0, 1): 24 bits, never 0
+            const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float r = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            o[2 * h] = r * cs; o[2 * h + 1] = r * sn;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * q + e < n) dst[4 * q + e] = o[e];
+    }
+}
+__global__ __launch_bounds__(256) void step_counters_k(long long* __restrict__ counters, const long long* __restrict__ idx, int n_idx,
+                                                       unsigned long long* __restrict__ rng_state, unsigned long long advance) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n_idx) counters[idx[e]] += 1;                 // indices are distinct (one BatchNorm each)
+    if (e == 0 && rng_state) rng_state[1] += advance;
+}
+}  // namespace
+extern "C" int uz_randn_fill(float* dst, size_t n, const void* rng_state, void* stream) {
+    UZ_REQUIRE(dst && rng_state, "randn_fill: null argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(randn_fill_k, dim3(vgrid((n + 3) / 4)), dim3(256), 0, uz::S(stream), dst, n, reinterpret_cast<const unsigned long long*>(rng_state));
+    return uz::check_launch("randn_fill_k");
+}
+extern "C" int uz_step_counters(int64_t* counters, const int64_t* idx, int n_idx, void* rng_state, int64_t advance, void* stream) {
+    UZ_REQUIRE(n_idx >= 0 && (n_idx == 0 || (counters && idx)), "step_counters: null argument");
+    if (n_idx == 0 && !rng_state) return 0;
+    hipLaunchKernelGGL(step_counters_k, dim3(uz::ceil_div(n_idx > 0 ? n_idx : 1, 256)), dim3(256), 0, uz::S(stream),
+                       reinterpret_cast<long long*>(counters), reinterpret_cast<const long long*>(idx), n_idx,
+                       reinterpret_cast<unsigned long long*>(rng_state), (unsigned long long)advance);
+    return uz::check_launch("step_counters_k");
+}

@@ -62,7 +62,8 @@ int splitk_reduce(const float* slab, int ksplit, const float* bias, float* y, in
                   float* y_amax, hipStream_t st);      // conv_mfma.hip
 int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
-               const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, hipStream_t st);
+               const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, float* bn_partials, hipStream_t st);
+int conv_split_bn_partials(int Kc, int Mc, int N, int H, int W);
 
 // conv_wgrad_split.hip: 3x3 weight gradient on the fp16 matrix pipe with two-piece split operands
 bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks);

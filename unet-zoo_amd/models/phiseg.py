@@ -91,6 +91,8 @@ def phiseg_spec(input_channels, num_classes, num_filters, reversible=False):
 
 
 class PHISeg(NativeModel):
+    decouple_wgrad_px = 8192       # see NativeModel.decouple_wgrad_px: the 16 x 16 ... 2 x 2 levels at batch 32
+
     def __init__(self, input_channels, num_classes, num_filters, latent_levels=5, latent_dim=2, initializers=None,
                  no_convs_fcomb=4, beta=10.0, image_size=(128, 128, 1), reversible=False, apply_last_layer=True,
                  exponential_weighting=True, padding=True, device=None):
@@ -251,10 +253,10 @@ class PHISeg(NativeModel):
             if flat is False:
                 flat = plan._eps_span = plan.span(io["eps"])
             if flat is not None:
-                flat.normal_()                                # the ten noise buffers are neighbours in the arena: one launch
+                self._fill_normal(flat)                       # the ten noise buffers are neighbours in the arena: one launch
             else:
                 for e in io["eps"]:
-                    plan.tensor(e).normal_()
+                    self._fill_normal(plan.tensor(e))
         else:
             for e, src in zip(io["eps"], eps):
                 plan.tensor(e).copy_(src)

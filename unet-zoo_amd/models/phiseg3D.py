@@ -254,7 +254,7 @@ class PHISeg3D(NativeModel):
         T(io["input"].slice(self.input_channels, K)).copy_(onehot - 0.5)
         for k, e in enumerate(io["eps"]):
             if eps is None:
-                T(e).normal_()
+                self._fill_normal(T(e))
             else:
                 T(e).copy_(self._to_slices(eps[k]))
         self._run(plan, "fwd")

@@ -230,7 +230,7 @@ class ProbabilisticUnet(NativeModel):
         N, _, H, W = T(plan.io["loss_mask"]).shape
         T(plan.io["loss_mask"]).copy_(mask.reshape(N, 1, H, W))
         if eps is None:
-            T(plan.io["eps"]).normal_()
+            self._fill_normal(T(plan.io["eps"]))
         else:
             T(plan.io["eps"]).copy_(eps.reshape(N, self.latent_dim, 1, 1))
         if torch.is_grad_enabled() and plan.tapes["bwd"][1]:
