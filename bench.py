@@ -250,6 +250,16 @@ def dominant_kernel_live(net, plan, L, heaviest, reps=20):
                peak_note=("dense fp16 MFMA peak 2500 TFLOP/s / 3 piece products per fp32 product" if split else "fp32 MFMA peak"))
     if split:
         out["fp16_mfma_tflops"] = round(SPLIT_PRODUCTS * flops / ms / 1e9, 1)
+    try:                                                    # round 3: per-layer dispatch table (tools/prof_layers.sh), keyed on layer and direction
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r3_layer_table.json")))
+        for row in tab["layers"]:
+            if (row["kind"], row["cin"], row["cout"], row["n"], row["h"], row["w"], row["ks"]) == (kind, cin, cout, n, h, w, ks):
+                out.update(traffic=row["hbm_bytes"], traffic_source="profiles/r3_layer_table.json", kernel=row["dominant_kernel"],
+                           profiled=dict(avg_launch_us=row["avg_launch_us"], mfma_busy_fraction=row["mfma_busy_fraction"],
+                                         traffic_over_algorithmic=row["traffic_over_algorithmic"]))
+                return out
+    except Exception:
+        pass
     for prof in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))

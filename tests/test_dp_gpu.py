@@ -27,3 +27,36 @@ def test_rccl_backend_world_size_one_step():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_world1_check.py")], cwd=root, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "nccl world 1: ms/step" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def _bench(args, env_extra):
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_from_one_command_on_one_device():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its own ranks (fresh processes, before any
+    GPU call in the parent), rank 0 prints ONE line whose n_gpus is what the data-parallel group itself reports.  On the
+    one-GPU test box both ranks share cuda:0 and the data plane is gloo (RCCL refuses two ranks per device); on an 8-GPU node the
+    same command without the two test variables runs one rank per GPU over RCCL."""
+    common = ["--steps", "3", "--warmup", "2", "--skip-cpu", "--no-profile", "--no-f32-leg"]
+    hook = dict(UZ_BENCH_SINGLE_DEVICE="1", UZ_BENCH_BACKEND="gloo")
+    d = _bench(["--gpus", "2", "--batch", "4"] + common, hook)
+    assert d["n_gpus"] == 2 and d["dp"]["nranks"] == 2 and d["dp"]["launcher"] == "self" and d["dp"]["backend"] == "torch"
+    assert d["config"]["global_batch"] == 8 and d["config"]["batch_per_gpu"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    s = _bench(["--gpus", "2", "--batch", "8", "--strong"] + common, hook)
+    assert s["n_gpus"] == 2 and s["scaling"] == "strong" and s["config"]["global_batch"] == 8 and s["config"]["batch_per_gpu"] == 4
+
+
+def test_bench_world_size_one_uses_the_single_rccl_communicator():
+    """The product's data plane at world size 1 through bench.py's own bootstrap: gloo control plane, ONE RCCL communicator
+    behind the C ABI, its size as ncclCommCount reports it."""
+    d = _bench(["--gpus", "1", "--batch", "4", "--steps", "3", "--warmup", "2", "--skip-cpu", "--no-profile", "--no-f32-leg"], {})
+    assert d["n_gpus"] == 1 and "dp" not in d

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Per-layer dispatch workload for rocprofv3 (kernel trace and the three PMC passes of tools/prof_layers.sh).
+
+Builds the benchmark's PHiSeg plan, runs two training steps so that every buffer, bound slot and packed weight image holds real
+values, picks the TOP heaviest convolution ops of the forward / backward tapes (ranked by a HIP-event timing of each op alone) and
+then launches, per op:   one MARKER kernel (uz_axpy on one float - a kernel name that occurs nowhere else in this workload),
+followed by REPS launches of exactly that tape op (uz_run_tape on a 1-op tape: the product's own call, its real views, bounds and
+pre-packed weights).  The dispatch stream is therefore   marker, op0 x REPS, marker, op1 x REPS, ...   and tools/layer_table.py
+cuts the trace / counter CSVs at the markers - keyed on dispatch ORDER, not on grid size or kernel name.
+Segment 0 is the FETCH_SIZE calibration (uz_absmax over a known byte count: one coalesced dword per lane).
+usage: layer_profile.py <ops.json> [top] [reps]"""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from bench import conv_dims, conv_flops, conv_bytes, conv_roof
+from unet_zoo_amd import _ffi
+from unet_zoo_amd.synthetic import synthetic_batch
+
+out_path = sys.argv[1]
+TOP = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+MODEL = os.environ.get("UZ_PROFILE_MODEL", "phiseg")
+B = 32
+net = bench.build(MODEL); net.train()
+x, m, _ = synthetic_batch(B)
+x, m = torch.from_numpy(x).cuda(), torch.from_numpy(m).cuda()
+for _ in range(2):
+    net.forward(x) if MODEL == "unet" else net.forward(x, m)
+    net.loss(m).backward()
+torch.cuda.synchronize()
+plan = net._cur
+L = _ffi.lib()
+st = C.c_void_p(net._stream())
+
+
+def one_op(which, k):
+    arr, _n = plan.tapes[which]
+    return (type(arr[0]) * 1)(arr[k])
+
+
+cands = []
+fixed = os.environ.get("UZ_PROFILE_OPS")            # the PMC passes profile exactly the op list the trace pass ranked
+if fixed and os.path.exists(fixed):
+    top = [(o["isolated_ms_hip_events"], o["tape"], o["index"]) for o in json.load(open(fixed))["ops"]]
+for which, ops in ((("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)) if not (fixed and os.path.exists(fixed)) else ()):
+    for k, o in enumerate(ops):
+        if conv_dims(o) is None:
+            continue
+        tape = one_op(which, k)
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); _ffi.check(L.uz_run_tape(tape, 1, st), "op"); e1.record(); e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        cands.append((best, which, k))
+if cands:
+    cands.sort(reverse=True)
+    top = cands[:TOP]
+
+marker_buf = torch.zeros(4, device="cuda")
+cal = torch.randn(64 * 1024 * 1024, device="cuda")                  # 256 MB calibration read
+slot = torch.zeros(256, device="cuda")
+meta = dict(model=MODEL, batch=B, reps=REPS, marker="axpy_k", calibration=dict(kernel="absmax_view_kernel", known_read_bytes=cal.numel() * 4), ops=[])
+torch.cuda.synchronize()
+
+
+def marker():
+    _ffi.check(L.uz_axpy(marker_buf.data_ptr(), marker_buf.data_ptr(), C.c_float(0.0), 1, st), "marker")
+
+
+marker()
+for _ in range(REPS):
+    _ffi.check(L.uz_absmax(cal.data_ptr(), cal.numel(), slot.data_ptr(), st), "calibration")
+for ms, which, k in top:
+    o = (plan.fwd_ops if which == "fwd" else plan.bwd_ops)[k]
+    kind, cin, cout, n, h, w, ks = conv_dims(o)
+    roof = conv_roof(o, L)
+    meta["ops"].append(dict(tape=which, index=k, op={0: "forward", 1: "data gradient", 2: "weight gradient"}[kind], kind=kind,
+                            layer=f"{ks}x{ks} {cin}->{cout} @ {n}x{h}x{w}", cin=cin, cout=cout, n=n, h=h, w=w, ks=ks,
+                            flops=conv_flops(o), algorithmic_bytes=conv_bytes(o), roof_tflops=roof, isolated_ms_hip_events=round(ms, 4)))
+    tape = one_op(which, k)
+    marker()
+    for _ in range(REPS):
+        _ffi.check(L.uz_run_tape(tape, 1, st), "op")
+marker()
+torch.cuda.synchronize()
+json.dump(meta, open(out_path, "w"), indent=1)
+print("profiled", len(top), "ops; heaviest", meta["ops"][0]["layer"], meta["ops"][0]["op"], meta["ops"][0]["isolated_ms_hip_events"], "ms")

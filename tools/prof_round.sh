@@ -2,7 +2,7 @@
 # passes on the dominant layer.  Summaries land in gpurun_out/; the ones to be judged are copied to profiles/ by hand.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-R=${1:-2}
+R=${1:-3}
 rm -rf gpurun_out/prof_graph gpurun_out/prof_eager gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_graph -- python bench.py --steps 10 --warmup 5 --skip-cpu --no-profile --no-f32-leg > gpurun_out/prof_graph_line.json 2> gpurun_out/prof_graph.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_eager -- python bench.py --steps 10 --warmup 5 --skip-cpu --no-profile --no-f32-leg --no-graphs > gpurun_out/prof_eager_line.json 2> gpurun_out/prof_eager.err
