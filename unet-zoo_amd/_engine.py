@@ -186,6 +186,15 @@ class NativeModel(nn.Module):
         self._dp_group = group
         self._dp = dp.GradSync(self, None if group is True else group, backend=backend, overlap=overlap)
         self._plans.clear()                # plans built before this call carry no bucket events
+        self._drop_graphs()
+
+    def _drop_graphs(self):
+        """Destroy the captured hipGraphExec handles (they hold device allocations) instead of just forgetting them."""
+        L = _ffi.lib() if self._graphs else None
+        for segs in self._graphs.values():
+            for handle, _ev in segs:
+                if handle is not None:
+                    L.uz_graph_destroy(handle)
         self._graphs.clear()
 
     def _run_backward(self, plan, gout):

@@ -282,7 +282,9 @@ class Plan:
             sc = self.vec("l2_scale", 1)
             self._emit(self.bwd_ops, "UZ_OP_COPY", p=[sc, self.loss_scale], n=4)
             self._emit(self.bwd_ops, "UZ_OP_SCALE", p=[sc], f=[coeff], n=1)
-            self._emit(self.bwd_ops, "UZ_OP_L2_NORMS_BWD", p=[("pflat",), tab, norms, sc, ("gflat",)], i=[n])
+            # the write set is the listed tensors' gradient ranges only: with the whole flat buffer declared, every
+            # gradient bucket's "final" marker waited for this op and the data-parallel overlap collapsed to one exchange
+            self._emit(self.bwd_ops, "UZ_OP_L2_NORMS_BWD", p=[("pflat",), tab, norms, sc, ("gflat_keys", tuple(keys))], i=[n])
         self._bwd_tail.append(tail)
 
     # ------------------------------------------------------------------ convolution family
@@ -999,7 +1001,7 @@ class Plan:
             return self.ptab.bflat.data_ptr() + 4 * self.ptab.boff[r[1]]
         if kind == "pflat":
             return self.ptab.pflat.data_ptr()
-        if kind == "gflat":
+        if kind in ("gflat", "gflat_keys"):
             return self.ptab.gflat.data_ptr()
         if kind == "scratch":
             return self.base + 4 * self.scratch_off[lane][r[1]]
@@ -1081,6 +1083,8 @@ class Plan:
             return [(("gflat",), lo, lo + _numel(self.ptab.shape[r[1]]))]
         if kind == "gflat":
             return [(("gflat",), 0, 1 << 62)]
+        if kind == "gflat_keys":
+            return [(("gflat",), self.ptab.poff[k], self.ptab.poff[k] + _numel(self.ptab.shape[k])) for k in r[1]]
         if kind == "buffer":
             return [(("bnbuf", r[1]), 0, 1)]
         if kind == "ptrtab":
