@@ -39,7 +39,7 @@ for k in fetch:
     if "FETCH_SIZE" not in fetch[k]:
         continue
     fb, wb = int(fetch[k]["FETCH_SIZE"] * KB * f), int(write.get(k, {}).get("WRITE_SIZE", 0) * KB)
-    if k.startswith("conv_split_kernel<2"):
+    if k.startswith("conv_split_kernel<2") or k.startswith("conv_split_kernel_2_512_32"):
         name, alg = "conv_split_kernel<2> f16 (forward)", alg_x + alg_w + alg_y
         note = "mean over the forward and data-gradient launches of the layer (same kernel, same algorithmic bytes)"
     elif k.startswith("wgrad_split_kernel<32"):
