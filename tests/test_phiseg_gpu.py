@@ -164,6 +164,7 @@ def test_phiseg_full_size_digest_vs_reference_golden(fixture):
     s = net.forward(x, mask, training=True, eps=eps)
     loss = net.loss(mask)
     loss.backward()
+    assert net.check_bounds() == 0          # every magnitude bound a split-fp16 kernel was handed covered its tensor (uz_device_flags)
     st = meta["steps"][0]
     assert abs(float(loss) - st["loss"]) <= 2e-5 * abs(st["loss"])
     idx = arrays["s_idx"]
@@ -250,6 +251,7 @@ def test_phiseg_b32_gradients_vs_fp64_reference():
     s = net.forward(x, mask, training=True, eps=eps)
     loss = net.loss(mask)
     loss.backward()
+    assert net.check_bounds() == 0
     assert abs(float(loss) - meta["loss64"]) <= 2e-5 * abs(meta["loss64"])
     idx = arrays["s_idx"]
     for l in range(5):

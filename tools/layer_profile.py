@@ -43,6 +43,20 @@ def one_op(which, k):
     return (type(arr[0]) * 1)(arr[k])
 
 
+def run_group_prefix(which, k):
+    """The ops of the same scheduling group in front of op k, once: a backward convolution reads its layer's dy from the lane's
+    SCRATCH, which after a full step holds some other layer's dy (values beyond this op's magnitude bound: clamped, flagged, and
+    not what the op sees in a step).  Re-running the BatchNorm backward of the group puts the right tensor there."""
+    ops = plan.fwd_ops if which == "fwd" else plan.bwd_ops
+    arr, _n = plan.tapes[which]
+    j = k
+    while j > 0 and ops[j - 1]["gid"] == ops[k]["gid"]:
+        j -= 1
+    if j < k:
+        sub = (type(arr[0]) * (k - j))(*[arr[i] for i in range(j, k)])
+        _ffi.check(L.uz_run_tape(sub, k - j, st), "group prefix")
+
+
 cands = []
 fixed = os.environ.get("UZ_PROFILE_OPS")            # the PMC passes profile exactly the op list the trace pass ranked
 if fixed and os.path.exists(fixed):
@@ -52,6 +66,7 @@ for which, ops in ((("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)) if not (fixed 
         if conv_dims(o) is None:
             continue
         tape = one_op(which, k)
+        run_group_prefix(which, k)
         best = 1e9
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -84,6 +99,7 @@ for ms, which, k in top:
                             layer=f"{ks}x{ks} {cin}->{cout} @ {n}x{h}x{w}", cin=cin, cout=cout, n=n, h=h, w=w, ks=ks,
                             flops=conv_flops(o), algorithmic_bytes=conv_bytes(o), roof_tflops=roof, isolated_ms_hip_events=round(ms, 4)))
     tape = one_op(which, k)
+    run_group_prefix(which, k)
     marker()
     for _ in range(REPS):
         _ffi.check(L.uz_run_tape(tape, 1, st), "op")
