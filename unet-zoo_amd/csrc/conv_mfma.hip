@@ -386,8 +386,8 @@ int splitk_reduce(const float* slab, int ksplit, const float* bias, float* y, in
 }
 
 // x: input view (Kc channels), y: output view (Mc channels); w = PyTorch [Cout][Cin][ks][ks] parameter.
-size_t conv_workspace(int Kc, int Mc, int N, int H, int W, int ks) {
-    if (conv_split_ok(Kc, Mc, N, H, W, ks)) return conv_split_workspace(Kc, Mc, N, H, W);
+size_t conv_workspace(int Kc, int Mc, int N, int H, int W, int ks, int dgrad) {
+    if (conv_split_ok(Kc, Mc, N, H, W, ks, dgrad)) return conv_split_workspace(Kc, Mc, N, H, W);
     const Geom g = pick_geom(N, H, W, ks / 2);
     const int cot = Mc <= 32 ? 32 : 64;
     int ksplit, cps;
@@ -404,7 +404,7 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Kc > 0 && Mc > 0, "conv: empty tensor");
     UZ_REQUIRE(H <= 4096 && W <= 4096, "conv: spatial size too large");
     // large 3x3 layers: split-bf16 matrix pipe (conv_split.hip); its packed weight image lives in the workspace
-    if (conv_split_ok(Kc, Mc, N, H, W, ks) && workspace && workspace_bytes >= conv_split_workspace(Kc, Mc, N, H, W))
+    if (conv_split_ok(Kc, Mc, N, H, W, ks, dgrad) && workspace && workspace_bytes >= conv_split_workspace(Kc, Mc, N, H, W))
         return conv_split(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, dgrad, relu, accumulate, x_amax, w_amax, y_amax, workspace, packed_w, bn_partials, st);
     UZ_REQUIRE(!packed_w, "conv: a pre-packed weight image was supplied for a layer that does not take the split path");
     UZ_REQUIRE(!bn_partials, "conv: fused BatchNorm statistics were requested for a layer that does not take the split path (uz_conv_bn_partials() == 0)");
@@ -441,7 +441,7 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
 }  // namespace uz
 
 extern "C" size_t uz_conv_workspace(int Cin, int Cout, int N, int H, int W, int ks) {
-    const size_t a = uz::conv_workspace(Cin, Cout, N, H, W, ks), b = uz::conv_workspace(Cout, Cin, N, H, W, ks);
+    const size_t a = uz::conv_workspace(Cin, Cout, N, H, W, ks, 0), b = uz::conv_workspace(Cout, Cin, N, H, W, ks, 1);
     return a > b ? a : b;
 }
 

@@ -455,7 +455,7 @@ extern "C" int uz_device_flags(int* out, int clear, void* stream) {
 
 // Which layers take the split-fp16 path: 3x3, enough channels for a dense contraction and enough tiles to occupy
 // the chip.  Planes wider than 32 use 16 x 32 tiles; 32 x 32 and 16 x 16 planes use 16 x 16 tiles.
-bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks) {
+bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks, int /*dgrad: same policy for both directions (tiny planes forward-only was measured slower)*/) {
     // UZ_CONV_MATH: "f32" = fp32 MFMA only; "split" = split-fp16 on every 3x3 shape (tests); default = where it pays
     const int mode = conv_math_mode();
     if (!mode || ks != 3) return false;
@@ -498,7 +498,7 @@ size_t image_bytes(int Kc, int Mc, int W) {
 // Number of per-channel statistics partials a forward launch with fused BatchNorm statistics writes (0: this shape does not
 // support them - off the split path, or its chunk loop is split over workgroups and the partial sums are only added later).
 int conv_split_bn_partials(int Kc, int Mc, int N, int H, int W) {
-    if (!conv_split_ok(Kc, Mc, N, H, W, 3) || split_parts(Kc, Mc, N, H, W) != 1) return 0;
+    if (!conv_split_ok(Kc, Mc, N, H, W, 3, 0) || split_parts(Kc, Mc, N, H, W) != 1) return 0;
     const int tw = tile_w(W), nt = tw == 16 ? 256 : 512;
     return N * ceil_div(H, TH) * ceil_div(W, tw) * (nt / 4 / 64);
 }

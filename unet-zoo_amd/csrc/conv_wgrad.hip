@@ -593,8 +593,8 @@ extern "C" int uz_conv_route(int kind, int Cin, int Cout, int N, int H, int W, i
     const bool thin = ks == 3 && Cin <= 4 && (long long)N * H * W >= 64 * 1024;       // 1..4-channel input layers: streaming kernels
     if (kind == 0 && thin && Cout <= 256 && N <= 65535) return 2;
     if (kind == 2 && wgrad_thin_ok(Cin, Cout, N, H, W, ks)) return 2;
-    if (kind == 0) return uz::conv_split_ok(Cin, Cout, N, H, W, ks) ? 1 : 0;
-    if (kind == 1) return uz::conv_split_ok(Cout, Cin, N, H, W, ks) ? 1 : 0;
+    if (kind == 0) return uz::conv_split_ok(Cin, Cout, N, H, W, ks, 0) ? 1 : 0;
+    if (kind == 1) return uz::conv_split_ok(Cout, Cin, N, H, W, ks, 1) ? 1 : 0;
     return uz::wgrad_split_ok(Cin, Cout, N, H, W, ks) ? 1 : 0;
 }
 

@@ -56,7 +56,7 @@ __device__ __forceinline__ void block_sum_d(double (&v)[NV], double* smem /* >= 
 }
 
 // conv_split.hip: 3x3 forward / data gradient on the fp16 matrix pipe with two-piece split operands (fp32-accurate)
-bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks);
+bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks, int dgrad);
 size_t conv_split_workspace(int Kc, int Mc, int N, int H, int W);
 int splitk_reduce(const float* slab, int ksplit, const float* bias, float* y, int Mc, int McTot, int N, int HW, int relu, int accumulate,
                   float* y_amax, hipStream_t st);      // conv_mfma.hip
