@@ -106,7 +106,8 @@ def conv_roof(op, L):
     """Peak TFLOP/s of the pipe the library routes this op to (uz_conv_route), or None for the streaming 1x1 heads."""
     kind, cin, cout, n, h, w, ks = conv_dims(op)
     r = L.uz_conv_route(kind, cin, cout, n, h, w, ks)
-    return {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_SPLIT_TFLOPS, 2: None}[r]
+    split_roof = PEAK_F16_MFMA_TFLOPS if L.uz_get_conv_math() == 3 else PEAK_SPLIT_TFLOPS      # bf16 mode: one product per MAC
+    return {0: PEAK_F32_MFMA_TFLOPS, 1: split_roof, 2: None}[r]
 
 
 def op_bytes(op):
@@ -254,9 +255,14 @@ def dominant_kernel_live(net, plan, L, heaviest, reps=20):
                layer=f"{ks}x{ks} {cin}->{cout} @ {n}x{h}x{w}", flops_per_launch=flops, avg_launch_ms=round(ms, 4),
                achieved=round(flops / ms / 1e9, 2), peak=round(roof, 1), unit="TFLOP/s", frac=round(flops / ms / 1e9 / roof, 4),
                algorithmic_bytes=alg_bytes, traffic=None,
-               peak_note=("dense fp16 MFMA peak 2500 TFLOP/s / 3 piece products per fp32 product" if split else "fp32 MFMA peak"))
+               peak_note=("dense bf16 MFMA peak 2500 TFLOP/s, one product per MAC (UZ_CONV_MATH=bf16)" if roof == PEAK_F16_MFMA_TFLOPS else
+                          "dense fp16 MFMA peak 2500 TFLOP/s / 3 piece products per fp32 product" if split else "fp32 MFMA peak"))
     if split:
-        out["fp16_mfma_tflops"] = round(SPLIT_PRODUCTS * flops / ms / 1e9, 1)
+        out["fp16_mfma_tflops"] = round((1 if roof == PEAK_F16_MFMA_TFLOPS else SPLIT_PRODUCTS) * flops / ms / 1e9, 1)
+    if roof == PEAK_F16_MFMA_TFLOPS:
+        # one product per MAC puts these layers on the memory side of the ridge for narrow channel counts: report the HBM view too
+        out["hbm_view"] = dict(achieved_gbs=round(alg_bytes / ms / 1e6, 1), peak_gbs=HBM_PEAK_GBS, frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                               note="algorithmic bytes (fp32 storage: input + output tensor once) / launch duration against 8 TB/s")
     try:                                                    # round 3: per-layer dispatch table (tools/prof_layers.sh), keyed on layer and direction
         tab = json.load(open(os.path.join(ROOT, "profiles", "r3_layer_table.json")))
         for row in tab["layers"]:
@@ -487,10 +493,17 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU-oracle leg (BASELINE.md section 3: 32)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32-MFMA-only measurement (child process)")
     ap.add_argument("--no-overlap", action="store_true", help="data parallel: one blocking all-reduce after backward instead of bucketed overlap")
+    ap.add_argument("--conv-math", choices=["default", "f32", "split", "bf16"], default=None,
+                    help="arithmetic of the large 3x3 convolutions (= UZ_CONV_MATH): default = fp32-accurate fp16 split; bf16 = one bf16 piece per "
+                         "operand, fp32 accumulation.  phiseg3d defaults to bf16 (BASELINE configs[4] is quoted in bf16), everything else to default")
     ap.add_argument("--strong", action="store_true", help="strong scaling (SURVEY 8d): the GLOBAL batch stays at --batch (default 32), "
                                                           "each of the N GPUs takes batch / N images")
     args = ap.parse_args()
 
+    if args.conv_math is None and args.model == "phiseg3d" and "UZ_CONV_MATH" not in os.environ:
+        args.conv_math = "bf16"
+    if args.conv_math and args.conv_math != "default":
+        os.environ["UZ_CONV_MATH"] = args.conv_math          # read by the library when it first routes a convolution; inherited by the ranks
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
@@ -676,12 +689,15 @@ def main():
             except Exception as e:                          # never lose the headline line to the per-family pass
                 roof["families_error"] = str(e)[:200]
         math_note = ("fp32 MFMA only (UZ_CONV_MATH=f32)" if conv_math() == "f32" else
+                     "bf16 ARITHMETIC in the large 3x3(x3) convolutions (UZ_CONV_MATH=bf16): operands rounded to bf16 (round to nearest even) while they "
+                     "are staged, one v_mfma_f32_32x32x16_bf16 product per MAC, fp32 accumulation; activations, gradients and BatchNorm statistics are "
+                     "STORED in fp32 (bf16 storage is not built); small planes and 1x1 heads stay on the fp32 kernels" if conv_math() == "bf16" else
                      "fp32 in / fp32 out, fp32 accumulate everywhere; 3x3 layers the library routes to the split path (forward, data gradient AND "
                      "weight gradient; share in roofline.flop_share_by_pipe): operands scaled by a power of two and split into 2 fp16 pieces, 3 piece "
                      "products on the fp16 matrix pipe (error vs fp64 no larger than the fp32-MFMA kernels', tests/test_full_configs_gpu.py); other layers: fp32 MFMA")
         line = dict(metric=M["metric"], value=round(ips, 3 if vol else 2), unit=M.get("unit", "images/s"), n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="strong" if args.strong else "weak",
-                    vs_baseline=None, dtype="f32", data="synthetic",
+                    vs_baseline=None, dtype="bf16 arithmetic / f32 storage" if conv_math() == "bf16" else "f32", data="synthetic",
                     config=dict(workload=M["workload"], batch_per_gpu=args.batch, global_batch=global_batch, parallelism=f"dp{world}",
                                 graphs=not args.no_graphs, final_loss=final_loss, conv_math=math_note),
                     roofline=roof)

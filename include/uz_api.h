@@ -55,8 +55,10 @@ int         uz_device_info(int* n_cu, char* name, int name_cap);
  * workspace of uz_conv_workspace() bytes the input-channel loop is split over workgroups and summed
  * in a fixed order (bitwise reproducible); workspace may be NULL (no split, slower, same result up
  * to summation order).                                                                          */
-/* run-time override of UZ_CONV_MATH for tests / diagnostics: -1 = environment, 0 = f32, 1 = default policy, 2 = split on
- * every eligible shape.  Workspace sizes depend on the mode: query them after switching.  Not thread safe.            */
+/* run-time override of UZ_CONV_MATH for tests / diagnostics: -1 = environment, 0 = f32, 1 = default policy (fp32-accurate fp16
+ * split where it pays), 2 = split on every eligible shape, 3 = bf16: the layers of mode 1 with one bf16 piece per operand and one
+ * MFMA product, fp32 accumulation (bf16 arithmetic, fp32 storage; BASELINE configs[4] is quoted in bf16).  Workspace sizes depend
+ * on the mode: query them after switching.  Not thread safe.                                                            */
 int uz_set_conv_math(int mode);
 int uz_get_conv_math(void);
 /* kernel family a call takes under the current mode: kind 0 fwd / 1 bwd_data / 2 bwd_weight -> 0 fp32 MFMA, 1 split-fp16 MFMA,

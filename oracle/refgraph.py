@@ -35,11 +35,24 @@ def _bn(sd, p, y, bn_train):
                         training=bn_train, momentum=BN_MOMENTUM, eps=BN_EPS)
 
 
+# Test hook for the bf16 arithmetic mode of the native convolutions (UZ_CONV_MATH=bf16, BASELINE config 5): a callable
+# (x, w) -> bool; where it returns True both operands are rounded to bf16 (round to nearest even) before the fp32 convolution -
+# exactly what the single-piece kernels multiply (products of two bf16 values are exact in fp32, accumulation is fp32).
+CONV_OPERAND_ROUNDING = None
+
+
+def _maybe_round(x, w):
+    if CONV_OPERAND_ROUNDING is not None and CONV_OPERAND_ROUNDING(x, w):
+        return x.to(torch.bfloat16).to(torch.float32), w.to(torch.bfloat16).to(torch.float32)
+    return x, w
+
+
 def conv_unit(sd, p, x, bn_train):
     """Conv2D unit: Conv2d(k, pad = 1 if k == 3 else 0) -> BN -> ReLU (torchlayers.py:7-29); with a 5-D weight the Conv3D unit
     of models/phiseg3D.py:13-35 (Conv3d -> BatchNorm3d(eps=1e-3, momentum=0.01) -> ReLU)."""
     w = sd[p + ".convolution.0.weight"]
     conv = F.conv3d if w.dim() == 5 else F.conv2d
+    x, w = _maybe_round(x, w)
     y = conv(x, w, sd[p + ".convolution.0.bias"], padding=1 if w.shape[-1] == 3 else 0)
     return F.relu(_bn(sd, p + ".convolution.1", y, bn_train))
 
@@ -48,6 +61,7 @@ def conv_bare(sd, p, x):
     """Conv2D with norm=activation=nn.Identity (phiseg.py:281-284, probabilistic_unet.py:244)."""
     w = sd[p + ".convolution.0.weight"]
     conv = F.conv3d if w.dim() == 5 else F.conv2d
+    x, w = _maybe_round(x, w)
     return conv(x, w, sd[p + ".convolution.0.bias"], padding=1 if w.shape[-1] == 3 else 0)
 
 

@@ -504,3 +504,43 @@ def test_prepacked_weight_images_equal_in_call_packing():
             assert torch.equal(d0, d1)
     finally:
         L.uz_set_conv_math(-1)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(8, 64, 64, 64, 64), (4, 40, 224, 64, 96), (32, 128, 96, 32, 32), (2, 32, 32, 128, 128), (4, 64, 96, 37, 70)])
+def test_conv_bf16_arithmetic_mode(N, Cin, Cout, H, W):
+    """UZ_CONV_MATH=bf16 (uz_set_conv_math(3); BASELINE config 5 "bf16"): the layers of the split path with ONE bf16 piece per
+    operand and one MFMA product, fp32 accumulation.  Reference = fp32 torch convolutions of the bf16-ROUNDED operands (a product
+    of two bf16 values is exact in fp32), so the gate is summation order only: 2e-5 of the largest magnitude - and the
+    difference to the un-rounded fp32 result is the expected 2^-9-per-operand rounding (checked to be there, and small)."""
+    g = _g()
+    from unet_zoo_amd import _ffi
+    L = _ffi.lib()
+    x = g.rnd(N, Cin, H, W, seed=1)
+    w = g.rnd(Cout, Cin, 3, 3, seed=2, scale=0.1)
+    b = g.rnd(Cout, seed=3)
+    dy = g.rnd(N, Cout, H, W, seed=4)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    xr, wr = rb(x).requires_grad_(True), rb(w).requires_grad_(True)
+    yr = F.conv2d(xr, wr, b, padding=1)
+    y32 = F.conv2d(x, w, b, padding=1)
+    dx_ref = F.conv_transpose2d(rb(dy), rb(w), padding=1)                         # the data gradient rounds dy and w (when it takes this path)
+    dx_ref32 = F.conv_transpose2d(dy, w, padding=1)
+    dw_ref = torch.nn.grad.conv2d_weight(rb(x), w.shape, rb(dy), padding=1)      # the weight gradient rounds x and dy (when it takes this path)
+    dw_ref32 = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1)
+    wsb = max(L.uz_conv_workspace(Cin, Cout, N, H, W, 3), L.uz_conv_bwd_weight_workspace(Cin, Cout, N, H, W, 3))
+    ws = torch.empty(wsb // 4 + 64, device=g.dev())
+    xd, wd, bd, dyd = x.to(g.dev()), w.to(g.dev()), b.to(g.dev()), dy.to(g.dev())
+    y = torch.empty(N, Cout, H, W, device=g.dev()); dx = torch.empty_like(xd); dw = torch.empty_like(wd)
+    try:
+        L.uz_set_conv_math(3)
+        assert L.uz_conv_route(0, Cin, Cout, N, H, W, 3) == 1
+        dgrad_bf16 = L.uz_conv_route(1, Cin, Cout, N, H, W, 3) == 1          # each direction is routed by its own shape
+        wgrad_bf16 = L.uz_conv_route(2, Cin, Cout, N, H, W, 3) == 1          # narrow layers keep their weight gradient on the fp32 kernels
+        g.call("uz_conv_fwd", xd, Cin, Cin, wd, bd, y, Cout, Cout, N, H, W, 3, 0, None, None, None, ws, wsb)
+        g.call("uz_conv_bwd_data", dyd, Cout, Cout, wd, dx, Cin, Cin, N, H, W, 3, 0, None, None, ws, wsb)
+        g.call("uz_conv_bwd_weight", xd, Cin, Cin, dyd, Cout, Cout, dw, None, N, H, W, 3, None, None, ws, wsb)
+    finally:
+        L.uz_set_conv_math(-1)
+    assert g.relerr(y, yr) <= TOL and g.relerr(dx, dx_ref if dgrad_bf16 else dx_ref32) <= TOL and g.relerr(dw, dw_ref if wgrad_bf16 else dw_ref32) <= 5e-5
+    dev32 = g.relerr(y, y32)
+    assert 1e-5 < dev32 < 2e-2, dev32            # it IS bf16 arithmetic (not the fp32-accurate split), and no worse than bf16 should be

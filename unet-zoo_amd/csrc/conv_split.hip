@@ -26,7 +26,26 @@ namespace {
 using uz::f32x16; using uz::f32x4; using uz::f16x8; using uz::u32x4; using uz::split2;
 
 
-constexpr int CK = 16, NSUB = 2, KK = 9, TH = 16, NP = 2;      // NP fp16 planes per operand
+constexpr int CK = 16, NSUB = 2, KK = 9, TH = 16;
+// NP = planes per operand: 2 = fp32-accurate split (two fp16 pieces, three products), 1 = ONE bf16 piece and one product per
+// (a, b) pair - bf16 arithmetic with fp32 accumulation (UZ_CONV_MATH=bf16: BASELINE config 5, PHiSeg3D "bf16"); bf16 keeps fp32's
+// exponent range, so that mode needs neither operand scales nor magnitude bounds.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+template <int NP> __device__ __forceinline__ void pieces(float v0, float v1, unsigned (&out)[NP]) {
+    if constexpr (NP == 2) split2(v0, v1, out[0], out[1]);
+    else out[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(uz::f32x2{v0, v1}, bf16x2));      // v_cvt_pk_bf16_f32, round to nearest even
+}
+template <int NP> __device__ __forceinline__ f32x16 mma(f32x16 t, const u32x4 (&a)[NP], const u32x4 (&b)[NP]) {
+    if constexpr (NP == 2) {                       // smallest products first
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), t, 0, 0, 0);
+    } else {
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), t, 0, 0, 0);
+    }
+    return t;
+}
 // Two tile geometries share the kernel: 512 threads on 16 x 32 pixels (planes at least 32 wide) and 256 threads
 // on 16 x 16 pixels (one 16 x 16 plane per workgroup, 32 output channels, 60 KB of LDS -> two workgroups per CU).
 template <int NTv, int TWv> struct Geo {
@@ -60,24 +79,26 @@ struct SP {
 // 64 lanes of a fragment read (one ds_read_b128) cover two contiguous 512-byte runs - conflict free; with whole 32-byte
 // rows every second 16-lane group of the read collided on its banks (2-way).
 // 16 fp32 values (one row of 16 channels), scaled -> fp16 pieces at dst + plane * plane_stride + half * half_stride (bytes)
+template <int NP>
 __device__ __forceinline__ void split_store16(const float (&v)[CK], float scale, char* dst, int plane_stride, int half_stride, int* flags = nullptr) {
-    unsigned p1[8], p2[8];
+    unsigned pc[8][NP];
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        bad |= uz::bound_violated(v[2 * i] * scale, v[2 * i + 1] * scale);
-        split2(v[2 * i] * scale, v[2 * i + 1] * scale, p1[i], p2[i]);
+        if (NP == 2) bad |= uz::bound_violated(v[2 * i] * scale, v[2 * i + 1] * scale);
+        pieces<NP>(v[2 * i] * scale, v[2 * i + 1] * scale, pc[i]);
     }
     if (bad && flags) atomicOr(flags, uz::FLAG_W_BOUND);
-    *reinterpret_cast<u32x4*>(dst) = u32x4{p1[0], p1[1], p1[2], p1[3]};
-    *reinterpret_cast<u32x4*>(dst + half_stride) = u32x4{p1[4], p1[5], p1[6], p1[7]};
-    *reinterpret_cast<u32x4*>(dst + plane_stride) = u32x4{p2[0], p2[1], p2[2], p2[3]};
-    *reinterpret_cast<u32x4*>(dst + plane_stride + half_stride) = u32x4{p2[4], p2[5], p2[6], p2[7]};
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        *reinterpret_cast<u32x4*>(dst + q * plane_stride) = u32x4{pc[0][q], pc[1][q], pc[2][q], pc[3][q]};
+        *reinterpret_cast<u32x4*>(dst + q * plane_stride + half_stride) = u32x4{pc[4][q], pc[5][q], pc[6][q], pc[7][q]};
+    }
 }
 
 // Weight panel of one layer and direction, split once per call into the kernel's LDS image:
 // packed[chunk][coTile][plane 2][k half 2][tap 9][co COT][8 k] fp16, scaled by split_scale(*w_amax).  One thread per (chunk, coTile, tap, co) row.
-template <bool DGRAD>
+template <bool DGRAD, int NP>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, char* __restrict__ packed, const float* __restrict__ w_amax,
                                                            int Mc, int Kc, int wCi, int nChunks, int nCoTiles, int COT, int* flags) {
     const int rows = nChunks * nCoTiles * KK * COT;
@@ -95,11 +116,20 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
     const int tapL = DGRAD ? KK - 1 - tap : tap;
     const int wplane = KK * COT * CK * 2;
-    split_store16(v, uz::split_scale(uz::amax_read(w_amax)), packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * 16, wplane, wplane / 2, flags);
+    split_store16<NP>(v, NP == 2 ? uz::split_scale(uz::amax_read(w_amax)) : 1.f, packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * 16, wplane, wplane / 2, flags);
 }
 
-template <int MSUB, int NTv, int TWv>
+// dynamic LDS of an instance: the staging images of the main loop, or (single-plane mode) the 16 channel rows x all pixels the
+// epilogue passes through it, whichever is larger
+template <int MSUB, int NTv, int TWv, int NP>
+constexpr int lds_bytes() {
+    const int main_loop = NP * (KK * 32 * MSUB * CK * 2) + NP * (Geo<NTv, TWv>::PSR * CK * 2);
+    const int epilogue = 16 * (NTv + 4) * 4;
+    return main_loop > epilogue ? main_loop : epilogue;
+}
+template <int MSUB, int NTv, int TWv, int NP>
 __device__ __forceinline__ void conv_split_body(const SP& p) {
+    using uz::u32x4;
     using GEO = Geo<NTv, TWv>;
     constexpr int NT = GEO::NT, TW = GEO::TW, PW = GEO::PW, PSI = GEO::PSI, PSR = GEO::PSR, G = GEO::G, CE = GEO::CE;
     constexpr int COT = 32 * MSUB;
@@ -144,7 +174,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     const int prow1 = NT + tid / G, q4 = tid & (G - 1);
     const unsigned xstep = 4u * (unsigned)p.HW;
     const unsigned wblock = (unsigned)NP * WPLANE;
-    const float xs = uz::split_scale(uz::amax_read(p.x_amax));
+    const float xs = NP == 2 ? uz::split_scale(uz::amax_read(p.x_amax)) : 1.f;
 
     // ---- per-lane output pixels (B operand columns)
     int poff[NSUB];
@@ -203,12 +233,20 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
             if (tap == 8) { for (int i = 5; i < WREGS; ++i) weight_load(c, i); }
             if (tap < 8) {
                 const int i0 = 2 * (tap - 4);
-                split2(pr[2 * i0] * xs, pr[2 * i0 + 1] * xs, pk[0][i0], pk[1][i0]);
-                split2(pr[2 * i0 + 2] * xs, pr[2 * i0 + 3] * xs, pk[0][i0 + 1], pk[1][i0 + 1]);
+                unsigned t0[NP], t1[NP];
+                pieces<NP>(pr[2 * i0] * xs, pr[2 * i0 + 1] * xs, t0);
+                pieces<NP>(pr[2 * i0 + 2] * xs, pr[2 * i0 + 3] * xs, t1);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { pk[q][i0] = t0[q]; pk[q][i0 + 1] = t1[q]; }
             }
             if (tap == 4) {
 #pragma unroll
-                for (int i = 0; i < CE / 2; ++i) split2(pr1[2 * i] * xs, pr1[2 * i + 1] * xs, pk1[0][i], pk1[1][i]);
+                for (int i = 0; i < CE / 2; ++i) {
+                    unsigned t0[NP];
+                    pieces<NP>(pr1[2 * i] * xs, pr1[2 * i + 1] * xs, t0);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) pk1[q][i] = t0[q];
+                }
             }
         }
     };
@@ -236,7 +274,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     if (p.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) stage(cbeg, tap);
-    if (p.flags) {                                 // bound check on the first chunk's patch (the clamp in split2 covers every chunk)
+    if (NP == 2 && p.flags) {                      // bound check on the first chunk's patch (the clamp in split2 covers every chunk)
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < CK; k += 2) bad |= uz::bound_violated(pr[k] * xs, pr[k + 1] * xs);
@@ -258,30 +296,24 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             const int tapoff = ((tap / 3) * PW + (tap % 3)) * 16;
-            f16x8 a[MS][NP], b[NSUB][NP];
+            u32x4 a[MS][NP], b[NSUB][NP];
 #pragma unroll
             for (int m = 0; m < MS; ++m)
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    a[m][q] = *reinterpret_cast<const f16x8*>(Al + q * WPLANE + (tap * COT + m * 32) * 16);
+                    a[m][q] = *reinterpret_cast<const u32x4*>(Al + q * WPLANE + (tap * COT + m * 32) * 16);
 #pragma unroll
             for (int n = 0; n < NSUB; ++n)
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    b[n][q] = *reinterpret_cast<const f16x8*>(Pl + q * PPLANE + poff[n] + tapoff);
+                    b[n][q] = *reinterpret_cast<const u32x4*>(Pl + q * PPLANE + poff[n] + tapoff);
             if (more) stage(c + 1, tap);
             // smallest products first
 #pragma unroll
             for (int m = 0; m < MS; ++m) {
                 if (m == 1 && half_tile) continue;           // workgroup-uniform: a scalar branch around six MFMAs
 #pragma unroll
-                for (int n = 0; n < NSUB; ++n) {
-                    f32x16 t = acc[m][n];
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][1], b[n][0], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], b[n][1], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], b[n][0], t, 0, 0, 0);
-                    acc[m][n] = t;
-                }
+                for (int n = 0; n < NSUB; ++n) acc[m][n] = mma<NP>(acc[m][n], a[m], b[n]);
             }
         }
     }
@@ -293,9 +325,8 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     // value (measured with the cycle stamps: 24 k of a workgroup's 105 - 160 k cycles, every CU's store queue full while the
     // matrix pipe idles).  Instead the tile goes through the (now dead) staging LDS, 8 * GP channels x all pixels per pass, and
     // comes back as float4 rows: a quarter of the store instructions, each wave writing whole 128-byte lines.
-    const float inv_x = uz::split_inv_scale(uz::amax_read(p.x_amax)), inv_w = uz::split_inv_scale(uz::amax_read(p.w_amax));
-    const float inv = inv_x * inv_w;
-    constexpr int LDS_BYTES = NP * WPLANE + NP * PPLANE;
+    const float inv = NP == 2 ? uz::split_inv_scale(uz::amax_read(p.x_amax)) * uz::split_inv_scale(uz::amax_read(p.w_amax)) : 1.f;
+    constexpr int LDS_BYTES = lds_bytes<MSUB, NTv, TWv, NP>();
     constexpr int GP = (32 * NT * 4 <= LDS_BYTES) ? 4 : ((16 * NT * 4 <= LDS_BYTES) ? 2 : 1);    // channel groups of 8 per pass
     constexpr int ROWF = NT + 4;                         // floats per channel row (one pixel per thread, + 16 B: rows start on different banks)
     static_assert(8 * GP * ROWF * 4 <= LDS_BYTES, "epilogue staging must fit the main loop's LDS");
@@ -387,25 +418,27 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     }
 }
 
-// The three instances as kernels of their own (attributes take literal constants only).  The 64-channel kernel is capped at
-// UZ_SPLIT64_VGPRS registers: with 2 waves per SIMD that leaves room on every CU for the waves of a streaming kernel
-// (BatchNorm, resampling) from the other dependency lane to run BESIDE the matrix work instead of in its gaps.
-#ifndef UZ_SPLIT64_VGPRS
-#define UZ_SPLIT64_VGPRS 256
-#endif
-template <int MSUB, int NTv, int TWv> struct SplitKernel;
-__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_num_vgpr(UZ_SPLIT64_VGPRS))) void conv_split_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32>(p); }
-__global__ __launch_bounds__(512, 4) void conv_split_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32>(p); }
-__global__ __launch_bounds__(256, 3) void conv_split_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16>(p); }
-template <> struct SplitKernel<2, 512, 32> { static constexpr auto fn = conv_split_kernel_2_512_32; };
-template <> struct SplitKernel<1, 512, 32> { static constexpr auto fn = conv_split_kernel_1_512_32; };
-template <> struct SplitKernel<1, 256, 16> { static constexpr auto fn = conv_split_kernel_1_256_16; };
+// The instances as kernels of their own (attributes take literal constants only; names show up in profiles): three tile
+// geometries x {split-fp16 (fp32-accurate), single-piece bf16}.
+template <int MSUB, int NTv, int TWv, int NP> struct SplitKernel;
+__global__ __launch_bounds__(512, 1) void conv_split_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32, 2>(p); }
+__global__ __launch_bounds__(512, 4) void conv_split_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32, 2>(p); }
+__global__ __launch_bounds__(256, 3) void conv_split_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16, 2>(p); }
+__global__ __launch_bounds__(512, 1) void conv_bf16_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32, 1>(p); }
+__global__ __launch_bounds__(512, 4) void conv_bf16_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32, 1>(p); }
+__global__ __launch_bounds__(256, 3) void conv_bf16_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16, 1>(p); }
+template <> struct SplitKernel<2, 512, 32, 2> { static constexpr auto fn = conv_split_kernel_2_512_32; };
+template <> struct SplitKernel<1, 512, 32, 2> { static constexpr auto fn = conv_split_kernel_1_512_32; };
+template <> struct SplitKernel<1, 256, 16, 2> { static constexpr auto fn = conv_split_kernel_1_256_16; };
+template <> struct SplitKernel<2, 512, 32, 1> { static constexpr auto fn = conv_bf16_kernel_2_512_32; };
+template <> struct SplitKernel<1, 512, 32, 1> { static constexpr auto fn = conv_bf16_kernel_1_512_32; };
+template <> struct SplitKernel<1, 256, 16, 1> { static constexpr auto fn = conv_bf16_kernel_1_256_16; };
 
-template <int MSUB, int NTv, int TWv>
+template <int MSUB, int NTv, int TWv, int NP>
 int launch(const SP& p, int grid, hipStream_t st) {
-    constexpr size_t smem = NP * (size_t)(KK * 32 * MSUB * CK * 2) + NP * (size_t)(Geo<NTv, TWv>::PSR * CK * 2);
+    constexpr size_t smem = lds_bytes<MSUB, NTv, TWv, NP>();
     static bool attr_done = false;
-    auto kern = SplitKernel<MSUB, NTv, TWv>::fn;
+    auto kern = SplitKernel<MSUB, NTv, TWv, NP>::fn;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return uz::fail("conv_split: cannot raise dynamic LDS limit");
@@ -428,6 +461,8 @@ inline int tile_cot(int Kc, int Mc, int W) { return (small_geo(W) || Mc <= 32 ||
 
 namespace uz {
 
+// planes per operand under the current math mode: 1 = bf16 (UZ_CONV_MATH=bf16), 2 = fp32-accurate fp16 split
+int conv_np() { return conv_math_mode() == 3 ? 1 : 2; }
 long long* debug_stamps = nullptr;
 extern "C" void uz_debug_stamps(void* buf) { debug_stamps = static_cast<long long*>(buf); }
 
@@ -491,7 +526,7 @@ int split_parts(int Kc, int Mc, int N, int H, int W) {
 }
 size_t image_bytes(int Kc, int Mc, int W) {
     const int cot = tile_cot(Kc, Mc, W);
-    const size_t b = (size_t)ceil_div(Kc, CK) * ceil_div(Mc, cot) * NP * (KK * cot * CK * 2);
+    const size_t b = (size_t)ceil_div(Kc, CK) * ceil_div(Mc, cot) * 2 * (KK * cot * CK * 2);      // sized for two planes in either mode
     return (b + 255) / 256 * 256;
 }
 }  // namespace
@@ -543,8 +578,9 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     SP p;
     float* slots = static_cast<float*>(workspace);
     char* image = static_cast<char*>(workspace) + WS_HEAD;
-    UZ_REQUIRE(!packed_w || w_amax, "conv_split: a pre-packed weight image needs the bound it was scaled with");
-    if (!x_amax || !w_amax) {
+    const int np = conv_np();                            // 1: bf16 single-piece operands (no scales, no bounds)
+    UZ_REQUIRE(np == 1 || !packed_w || w_amax, "conv_split: a pre-packed weight image needs the bound it was scaled with");
+    if (np == 2 && (!x_amax || !w_amax)) {
         if (hipMemsetAsync(slots, 0, WS_HEAD, st) != hipSuccess) return fail("conv_split: memset failed");
         if (!x_amax) { if (int rc = absmax_view(x, Kc, KcTot, N, H * W, slots, st)) return rc; x_amax = slots; }
         if (!w_amax) {
@@ -577,12 +613,22 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     UZ_REQUIRE((size_t)Kc * p.HW * 4 < (1ull << 32), "conv_split: one image's input view exceeds 4 GB");
     const int rows = p.nChunks * p.nCoTiles * KK * cot;
     if (packed_w) {}                                     // packed once per step by uz_conv_pack_weights
-    else if (dgrad) hipLaunchKernelGGL(pack_weights_kernel<true>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot, p.flags);
-    else hipLaunchKernelGGL(pack_weights_kernel<false>, dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot, p.flags);
+    else if (np == 2) {
+        if (dgrad) hipLaunchKernelGGL((pack_weights_kernel<true, 2>), dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot, p.flags);
+        else hipLaunchKernelGGL((pack_weights_kernel<false, 2>), dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot, p.flags);
+    } else {
+        if (dgrad) hipLaunchKernelGGL((pack_weights_kernel<true, 1>), dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot, p.flags);
+        else hipLaunchKernelGGL((pack_weights_kernel<false, 1>), dim3(ceil_div(rows, 256)), dim3(256), 0, st, w, image, w_amax, Mc, Kc, wCi, p.nChunks, p.nCoTiles, cot, p.flags);
+    }
     if (int rc = check_launch("pack_weights_kernel")) return rc;
     int rc;
-    if (tw == 16) rc = launch<1, 256, 16>(p, (int)grid, st);
-    else rc = cot == 32 ? launch<1, 512, 32>(p, (int)grid, st) : launch<2, 512, 32>(p, (int)grid, st);
+    if (np == 2) {
+        if (tw == 16) rc = launch<1, 256, 16, 2>(p, (int)grid, st);
+        else rc = cot == 32 ? launch<1, 512, 32, 2>(p, (int)grid, st) : launch<2, 512, 32, 2>(p, (int)grid, st);
+    } else {
+        if (tw == 16) rc = launch<1, 256, 16, 1>(p, (int)grid, st);
+        else rc = cot == 32 ? launch<1, 512, 32, 1>(p, (int)grid, st) : launch<2, 512, 32, 1>(p, (int)grid, st);
+    }
     if (rc || p.kSplit == 1) return rc;
     return splitk_reduce(p.slab, p.kSplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax, st);
 }
@@ -594,6 +640,7 @@ namespace {
 // cot, flags, first row}; a workgroup finds its layer by bisection over the first-row column.  flags bit 0 = data gradient,
 // bit 1 = Conv3d weight [Cout][Cin][3][3][3] read straight into the depth-window layout of csrc/vol.hip (forward: contraction
 // index k = kd Cin + ci; data gradient: k = j Cout + co with kd = 2 - j), wCi = the 3-D Cin.
+template <int NP>
 __global__ __launch_bounds__(256) void pack_all_kernel(const long long* __restrict__ table, int n_layers, int total_rows, const float* __restrict__ w_amax, int* flags) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= total_rows) return;
@@ -620,7 +667,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const long long* __restri
     }
     const int tapL = dgrad ? KK - 1 - tap : tap;
     const int wplane = KK * COT * CK * 2;
-    split_store16(v, uz::split_scale(uz::amax_read(w_amax)), packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * 16, wplane, wplane / 2, flags);
+    split_store16<NP>(v, NP == 2 ? uz::split_scale(uz::amax_read(w_amax)) : 1.f, packed + (size_t)(c * nCoTiles + coT) * NP * wplane + (tapL * COT + m) * 16, wplane, wplane / 2, flags);
 }
 }  // namespace
 
@@ -635,7 +682,8 @@ extern "C" int uz_conv_pack_cot(int Cin, int Cout, int W, int dgrad) { return ti
 extern "C" int uz_conv_pack_weights(const int64_t* table, int n_layers, int total_rows, const float* w_amax, void* stream) {
     UZ_REQUIRE(table && w_amax && n_layers >= 0 && total_rows >= 0, "conv_pack_weights: null argument");
     if (n_layers == 0 || total_rows == 0) return 0;
-    hipLaunchKernelGGL(pack_all_kernel, dim3(uz::ceil_div(total_rows, 256)), dim3(256), 0, uz::S(stream), reinterpret_cast<const long long*>(table), n_layers, total_rows, w_amax, uz::dev_flags_ptr());
+    if (uz::conv_np() == 2) hipLaunchKernelGGL(pack_all_kernel<2>, dim3(uz::ceil_div(total_rows, 256)), dim3(256), 0, uz::S(stream), reinterpret_cast<const long long*>(table), n_layers, total_rows, w_amax, uz::dev_flags_ptr());
+    else hipLaunchKernelGGL(pack_all_kernel<1>, dim3(uz::ceil_div(total_rows, 256)), dim3(256), 0, uz::S(stream), reinterpret_cast<const long long*>(table), n_layers, total_rows, w_amax, uz::dev_flags_ptr());
     return uz::check_launch("pack_all_kernel");
 }
 

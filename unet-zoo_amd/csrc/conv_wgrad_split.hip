@@ -23,7 +23,24 @@ namespace {
 using uz::f32x16; using uz::f32x4; using uz::f16x8; using uz::u32x4; using uz::split2;
 
 
-constexpr int NT = 512, PT = 128, NP = 2;                // 128 pixels per tile, NP fp16 planes per operand
+constexpr int NT = 512, PT = 128;                        // 128 pixels per tile
+// NP = planes per operand: 2 = fp32-accurate fp16 split (three products), 1 = one bf16 piece, one product (UZ_CONV_MATH=bf16)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+template <int NP> __device__ __forceinline__ void pieces(float v0, float v1, unsigned (&out)[NP]) {
+    if constexpr (NP == 2) split2(v0, v1, out[0], out[1]);
+    else out[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(uz::f32x2{v0, v1}, bf16x2));
+}
+template <int NP> __device__ __forceinline__ f32x16 mma(f32x16 t, const u32x4 (&a)[NP], const u32x4 (&b)[NP]) {
+    if constexpr (NP == 2) {
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), t, 0, 0, 0);
+    } else {
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), t, 0, 0, 0);
+    }
+    return t;
+}
 constexpr int DYROW = PT * 2 + 16;                       // bytes per co row of one dY plane (272: 16-byte aligned, skewed banks)
 constexpr int XCH = 496;                                 // bytes per ci of one X plane: 6 rows x 80 B or 10 rows x 48 B, + 16
 // tile geometry: 4 rows x 32 columns (planes whose width is a multiple of 32) or 8 rows x 16 columns (16-wide planes)
@@ -47,7 +64,7 @@ struct WS {
 
 // CT = channel tile on both sides: 64 (waves = co half x ci half x tap group) or 32 (waves = pixel quarter x tap
 // group; the four pixel quarters are folded through LDS at the end; 74 KB of LDS -> two workgroups per CU)
-template <int TWv, int CT>
+template <int TWv, int CT, int NP>
 __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
     using GEO = WGeo<TWv>;
     constexpr int TW = GEO::TW, TH = GEO::TH, XROW = GEO::XROW, QROWX = GEO::QROWX, PROWS = GEO::PROWS;
@@ -131,31 +148,31 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             xp[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (rowok && x0 + TW < p.W) ? 4u * (unsigned)(off + 1) : 0xFFFFFFFFu, 0, 0));
         }
     };
-    const float sdy = uz::split_scale(uz::amax_read(p.dy_amax)), sx = uz::split_scale(uz::amax_read(p.x_amax));
+    const float sdy = NP == 2 ? uz::split_scale(uz::amax_read(p.dy_amax)) : 1.f, sx = NP == 2 ? uz::split_scale(uz::amax_read(p.x_amax)) : 1.f;
     auto lstore = [&](int t) __attribute__((always_inline)) {
         const bool left_edge = t % p.tilesX == 0;               // tile column 0: the quads with q == 0 were loaded one column to the right
 #pragma unroll
         for (int i = 0; i < DYSLOTS; ++i) {
-            unsigned a1, a2, b1, b2;
-            split2(dreg[i][0] * sdy, dreg[i][1] * sdy, a1, a2);
-            split2(dreg[i][2] * sdy, dreg[i][3] * sdy, b1, b2);
+            unsigned pa[NP], pb[NP];
+            pieces<NP>(dreg[i][0] * sdy, dreg[i][1] * sdy, pa);
+            pieces<NP>(dreg[i][2] * sdy, dreg[i][3] * sdy, pb);
             const int e = tid + i * NT, co = e >> 5, q = e & 31;
             char* d = dYl + co * DYROW + ((q / QROW) * TW + (q % QROW) * 4) * 2;
-            *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
-            *reinterpret_cast<uint2*>(d + DYPLANE) = make_uint2(a2, b2);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * DYPLANE) = make_uint2(pa[pl], pb[pl]);
         }
 #pragma unroll
         for (int i = 0; i < XQSLOTS; ++i) {
             const int e = tid + i * NT;
             if (e < CIT * PROWS * QROWX) {
                 const int q = e % QROWX, r = e / QROWX, ci = r / PROWS, prow = r - ci * PROWS;
-                unsigned a1, a2, b1, b2;
+                unsigned pa[NP], pb[NP];
                 const f32x4 v = (left_edge && q == 0) ? f32x4{0.f, xq[i][0], xq[i][1], xq[i][2]} : xq[i];
-                split2(v[0] * sx, v[1] * sx, a1, a2);
-                split2(v[2] * sx, v[3] * sx, b1, b2);
+                pieces<NP>(v[0] * sx, v[1] * sx, pa);
+                pieces<NP>(v[2] * sx, v[3] * sx, pb);
                 char* d = Xl + ci * XCH + prow * XROW + q * 8;
-                *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
-                *reinterpret_cast<uint2*>(d + XPLANE) = make_uint2(a2, b2);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * XPLANE) = make_uint2(pa[pl], pb[pl]);
             }
         }
 #pragma unroll
@@ -163,11 +180,11 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             const int e = tid + i * NT;
             if (e < CIT * PROWS) {
                 const int ci = e / PROWS, prow = e - ci * PROWS;
-                unsigned a1, a2;
-                split2(xp[i][0] * sx, xp[i][1] * sx, a1, a2);
+                unsigned pa[NP];
+                pieces<NP>(xp[i][0] * sx, xp[i][1] * sx, pa);
                 char* d = Xl + ci * XCH + prow * XROW + QROWX * 8;
-                *reinterpret_cast<unsigned*>(d) = a1;
-                *reinterpret_cast<unsigned*>(d + XPLANE) = a2;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<unsigned*>(d + pl * XPLANE) = pa[pl];
             }
         }
     };
@@ -187,7 +204,7 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         long long st0 = 0, st1 = 0, stl = 0, rt0 = 0;
         if (p.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
         if (t < p.T) gload(t, -1);
-        if (p.flags && t < p.T) {                       // bound check on the first tile (the clamp in split2 covers every tile)
+        if (NP == 2 && p.flags && t < p.T) {            // bound check on the first tile (the clamp in split2 covers every tile)
             bool bx = false, bd = false;
 #pragma unroll
             for (int i = 0; i < DYSLOTS; ++i) bd |= uz::bound_violated(dreg[i][0] * sdy, dreg[i][1] * sdy) | uz::bound_violated(dreg[i][2] * sdy, dreg[i][3] * sdy);
@@ -209,9 +226,9 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
                 if (more) gload(t + p.S, si);               // a portion of the next tile's loads per k-step, in flight during the MFMAs
                 const int s = si * WK + wk;                 // WK == 1: compile-time; WK == 4: wave-uniform
                 const int srow = s / SROW, scol = (s % SROW) * 16;
-                f16x8 a[NP];
+                u32x4 a[NP];
 #pragma unroll
-                for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const f16x8*>(Ab + q * DYPLANE + (srow * TW + scol) * 2);
+                for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const u32x4*>(Ab + q * DYPLANE + (srow * TW + scol) * 2);
                 // B fragments: per patch row d and plane q five dwords (b128 + b32); the three dx variants of a row are
                 // formed right before their MFMAs (dx = 0: dwords 0..3, dx = 2: dwords 1..4, dx = 1: v_alignbit of
                 // neighbours) so that only one row's raw dwords and one shifted triple are live at a time
@@ -230,19 +247,16 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
                         constexpr int dummy = 0; (void)dummy;
                         const int tap = (DY0 + d) * 3 + dx, k = tap - TAP0;
                         if (k >= 0 && k < NTAP) {
-                            f16x8 b[NP];
+                            u32x4 b[NP];
 #pragma unroll
                             for (int q = 0; q < NP; ++q) {
-                                if (dx == 0) b[q] = __builtin_bit_cast(f16x8, v[q]);
-                                else if (dx == 2) b[q] = __builtin_bit_cast(f16x8, u32x4{v[q].y, v[q].z, v[q].w, v4[q]});
-                                else b[q] = __builtin_bit_cast(f16x8, u32x4{__builtin_amdgcn_alignbit(v[q].y, v[q].x, 16), __builtin_amdgcn_alignbit(v[q].z, v[q].y, 16),
-                                                                             __builtin_amdgcn_alignbit(v[q].w, v[q].z, 16), __builtin_amdgcn_alignbit(v4[q], v[q].w, 16)});
+                                if (dx == 0) b[q] = v[q];
+                                else if (dx == 2) b[q] = u32x4{v[q].y, v[q].z, v[q].w, v4[q]};
+                                else b[q] = u32x4{__builtin_amdgcn_alignbit(v[q].y, v[q].x, 16), __builtin_amdgcn_alignbit(v[q].z, v[q].y, 16),
+                                                  __builtin_amdgcn_alignbit(v[q].w, v[q].z, 16), __builtin_amdgcn_alignbit(v4[q], v[q].w, 16)};
                             }
-                            f32x16 acc_k = acc[k < 0 ? 0 : (k >= NTAP ? NTAP - 1 : k)];
-                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc_k, 0, 0, 0);
-                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc_k, 0, 0, 0);
-                            acc_k = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc_k, 0, 0, 0);
-                            acc[k < 0 ? 0 : (k >= NTAP ? NTAP - 1 : k)] = acc_k;
+                            const int kc = k < 0 ? 0 : (k >= NTAP ? NTAP - 1 : k);      // (folds: the loops are fully unrolled)
+                            acc[kc] = mma<NP>(acc[kc], a, b);
                         }
                     }
                 }
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         }
         float* out = p.slab + (size_t)split * 9 * p.Cout * p.Cin;
         const int ci = ci0 + wn * 32 + l31;
-        const float inv_dy = uz::split_inv_scale(uz::amax_read(p.dy_amax)), inv_x = uz::split_inv_scale(uz::amax_read(p.x_amax));      // exact powers of two
+        const float inv_dy = NP == 2 ? uz::split_inv_scale(uz::amax_read(p.dy_amax)) : 1.f, inv_x = NP == 2 ? uz::split_inv_scale(uz::amax_read(p.x_amax)) : 1.f;      // exact powers of two
 #pragma unroll
         for (int k = 0; k < NTAP; ++k)
 #pragma unroll
@@ -340,17 +354,23 @@ int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
     return s;
 }
 
-template <int TWv, int CT>
-static int launch_wgrad(const WS& p, int grid, hipStream_t st) {
-    constexpr size_t smem = NP * (size_t)(CT * DYROW) + NP * (size_t)(CT * XCH);
+template <int TWv, int CT, int NP>
+static int launch_wgrad_np(const WS& p, int grid, hipStream_t st) {
+    // (the 32-channel kernel folds its pixel quarters through this LDS at the end: three taps x 16 x 64 floats per wave pair)
+    constexpr size_t stage = NP * (size_t)(CT * DYROW) + NP * (size_t)(CT * XCH), fold = CT == 32 ? (size_t)4 * 3 * 16 * 64 * 4 : 0;
+    constexpr size_t smem = stage > fold ? stage : fold;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<TWv, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<TWv, CT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return fail("wgrad_split: cannot raise dynamic LDS limit");
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad_split_kernel<TWv, CT>), dim3(grid), dim3(NT), smem, st, p);
+    hipLaunchKernelGGL((wgrad_split_kernel<TWv, CT, NP>), dim3(grid), dim3(NT), smem, st, p);
     return check_launch("wgrad_split_kernel");
+}
+template <int TWv, int CT>
+static int launch_wgrad(const WS& p, int grid, hipStream_t st) {
+    return conv_np() == 2 ? launch_wgrad_np<TWv, CT, 2>(p, grid, st) : launch_wgrad_np<TWv, CT, 1>(p, grid, st);
 }
 
 int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* slab,

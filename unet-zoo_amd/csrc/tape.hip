@@ -31,19 +31,20 @@ int check_launch(const char* what) {
     return 0;
 }
 
-// 0 = fp32 MFMA only, 1 = split-bf16 where it pays (default), 2 = split-bf16 on every eligible 3x3 shape.
-// Process default from UZ_CONV_MATH (f32 | split), overridable at run time through uz_set_conv_math (tests, diagnostics).
+// 0 = fp32 MFMA only, 1 = split-fp16 where it pays (default), 2 = split-fp16 on every eligible 3x3 shape, 3 = bf16: the layers of
+// mode 1 with ONE bf16 piece per operand and one product (bf16 arithmetic, fp32 accumulation - BASELINE config 5).
+// Process default from UZ_CONV_MATH (f32 | split | bf16), overridable at run time through uz_set_conv_math (tests, diagnostics).
 static int g_conv_math = -1;
 int conv_math_mode() {
     if (g_conv_math >= 0) return g_conv_math;
-    static const int env = [] { const char* e = getenv("UZ_CONV_MATH"); return !e ? 1 : !strcmp(e, "f32") ? 0 : !strcmp(e, "split") ? 2 : 1; }();
+    static const int env = [] { const char* e = getenv("UZ_CONV_MATH"); return !e ? 1 : !strcmp(e, "f32") ? 0 : !strcmp(e, "split") ? 2 : !strcmp(e, "bf16") ? 3 : 1; }();
     return env;
 }
 
 }  // namespace uz
 
 extern "C" int uz_set_conv_math(int mode) {
-    if (mode < -1 || mode > 2) return uz::fail("set_conv_math: mode %d not in -1..2", mode);
+    if (mode < -1 || mode > 3) return uz::fail("set_conv_math: mode %d not in -1..3", mode);
     uz::g_conv_math = mode;
     return 0;
 }

@@ -11,7 +11,8 @@ void set_error(const char* fmt, ...);
 int  fail(const char* fmt, ...);          // set_error + return -1
 int  check_launch(const char* what);      // hipGetLastError -> status
 extern long long* debug_stamps;           // diagnostics: per-workgroup cycle stamps of the split kernels (uz_debug_stamps), normally null
-int  conv_math_mode();                    // 0 fp32 MFMA only | 1 split-fp16 where it pays | 2 split-fp16 wherever eligible
+int  conv_math_mode();                    // 0 fp32 MFMA only | 1 split-fp16 where it pays | 2 split-fp16 wherever eligible | 3 bf16 (one piece, one product) where 1 would split
+int  conv_np();                           // operand planes of the split kernels under the current mode: 2 (fp16 split) or 1 (bf16)
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
