@@ -305,3 +305,46 @@ def test_phiseg3d_oracle_vs_reference_modules(name):
     for k in sd:
         if "running_" in k:
             np.testing.assert_allclose(sd[k].detach().numpy(), arrays["sd1:" + k], rtol=1e-5, atol=1e-6)
+
+
+def test_oracle3d_matches_the_reference_fp32_leg_of_the_bf16_fixture():
+    """The fp32 leg of tests/golden/phiseg3d_bf16 (reference modules on a 32 x 64 x 64 volume, filters 32-32-64) pins the 3-D
+    oracle at a size where the native library uses its matrix-pipe kernels; with operand rounding switched on for every 3x3x3
+    layer the oracle lands between the reference's fp32 and bf16 runs (closer to fp32 than the reference's own bf16 run)."""
+    from oracle import refgraph as RG
+    from oracle import refgraph3d as R3
+    from oracle.refgraph3d import phiseg3d_eps_shapes, synthetic_volume
+    arrays, meta = G.load("phiseg3d_bf16")
+    D, H, W = meta["dhw"]
+    Lv = meta["latent_levels"]
+    shapes = phiseg3d_eps_shapes(D, H, W, len(meta["filters"]), Lv)
+    x, onehot, lab, eps = synthetic_volume(meta["input_channels"], meta["num_classes"], (D, H, W), meta["input_seed"], shapes + shapes)
+    sd = oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"])
+    args = (torch.from_numpy(x), torch.from_numpy(onehot), [torch.from_numpy(e) for e in eps])
+    st = meta["logit_stride"]
+
+    def gaps(out):
+        g32 = gbf = 0.0
+        for l in range(Lv):
+            for name, t in (("post_mu", out["post_mu"][l]), ("post_sigma", out["post_sigma"][l]), ("prior_mu", out["prior_mu"][l]),
+                            ("prior_sigma", out["prior_sigma"][l]), ("s_in", out["s_in"][l])):
+                got = t.detach().numpy().reshape(-1)[::st]
+                rf, rb = arrays[f"fp32:{name}{l}"], arrays[f"bf16:{name}{l}"]
+                rng = float(np.abs(rf).max())
+                g32, gbf = max(g32, G.maxabs(got, rf) / rng), max(gbf, G.maxabs(got, rb) / rng)
+        return g32, gbf
+    with torch.no_grad():
+        out = R3.phiseg3d_forward(G.leaves(sd), *args)
+        total, _ = R3.phiseg3d_loss(out, torch.from_numpy(lab), num_classes=meta["num_classes"])
+    g32, _ = gaps(out)
+    assert g32 <= 1e-4, g32
+    assert abs(float(total) - float(arrays["fp32:loss"])) <= 2e-5 * abs(float(arrays["fp32:loss"]))
+    RG.CONV_OPERAND_ROUNDING = lambda xx, ww: ww.dim() == 5 and ww.shape[-1] == 3
+    try:
+        with torch.no_grad():
+            out_r = R3.phiseg3d_forward(G.leaves(oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"])), *args)
+    finally:
+        RG.CONV_OPERAND_ROUNDING = None
+    r32, rbf = gaps(out_r)
+    ref_gap = max(G.maxabs(arrays[f"bf16:s_in{l}"], arrays[f"fp32:s_in{l}"]) / float(np.abs(arrays[f"fp32:s_in{l}"]).max()) for l in range(Lv))
+    assert 1e-5 < r32 <= 1.2 * ref_gap and rbf <= 4e-2, (r32, rbf, ref_gap)

@@ -456,3 +456,45 @@ def test_bf16_arithmetic_mode_against_the_operand_rounding_oracle():
         assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     finally:
         L.uz_set_conv_math(-1)
+
+
+@pytest.mark.gpu
+def test_bf16_mode_against_the_reference_modules_run_in_bf16():
+    """tests/golden/phiseg3d_bf16.*: the reference's Posterior / prior / Likelihood modules run under
+    torch.autocast('cpu', torch.bfloat16) (and in fp32) on a 32 x 64 x 64 volume, filters 32-32-64 - large enough that the
+    library routes the 3x3x3 layers to the matrix-pipe kernels (tools/gen_golden.py 3d_bf16; every 7th element stored).
+    Gate (stated): the reference's own bf16 run differs from its fp32 run by up to 3 % of a tensor's range (it also rounds every
+    convolution OUTPUT to bf16: measured 3.6 %); the native bf16 arithmetic mode keeps outputs in fp32, so it must be CLOSER to the
+    reference's fp32 tensors than the reference's own bf16 run is (measured 2.1 %), and - two independent bf16 perturbations of one
+    fp32 result - within 6 % of the reference's bf16 tensors (measured 4.6 %); loss within 1e-3 of both."""
+    from unet_zoo_amd import _ffi
+    from oracle.refgraph3d import phiseg3d_eps_shapes, synthetic_volume
+    arrays, meta = G.load("phiseg3d_bf16")
+    L, Lv = _ffi.lib(), meta["latent_levels"]
+    D, H, W = meta["dhw"]
+    shapes = phiseg3d_eps_shapes(D, H, W, len(meta["filters"]), Lv)
+    x, onehot, lab, eps = synthetic_volume(meta["input_channels"], meta["num_classes"], (D, H, W), meta["input_seed"], shapes + shapes)
+    inputs = dict(patch=x, mask_onehot=onehot, labels=lab, **{f"eps{k}": e for k, e in enumerate(eps)})
+    try:
+        L.uz_set_conv_math(3)
+        net, s, loss = _run_native(meta, inputs)
+        n_bf16 = sum(1 for o in net._cur.fwd_ops if o["code"] == "UZ_OP_CONV_FWD" and o["i"][7] == 3 and
+                     L.uz_conv_route(0, o["i"][0], o["i"][2], o["i"][4], o["i"][5], o["i"][6], 3) == 1)
+        assert n_bf16 >= 10, n_bf16                                   # the mode is really exercised
+    finally:
+        L.uz_set_conv_math(-1)
+    st = meta["logit_stride"]
+    worst_vs_bf16 = worst_vs_f32 = ref_gap = 0.0
+    for l in range(Lv):
+        for attr, key in ((net.posterior_mu, "post_mu"), (net.posterior_sigma, "post_sigma"), (net.prior_mu, "prior_mu"),
+                          (net.prior_sigma, "prior_sigma"), (net.s_in_list, "s_in")):
+            got = attr[l].cpu().numpy().reshape(-1)[::st]
+            rb, rf = arrays[f"bf16:{key}{l}"], arrays[f"fp32:{key}{l}"]
+            rng = float(np.abs(rf).max())
+            worst_vs_bf16 = max(worst_vs_bf16, G.maxabs(got, rb) / rng)
+            worst_vs_f32 = max(worst_vs_f32, G.maxabs(got, rf) / rng)
+            ref_gap = max(ref_gap, G.maxabs(rb, rf) / rng)
+    print(f"native bf16 mode vs reference-bf16 {worst_vs_bf16:.3e}, vs reference-fp32 {worst_vs_f32:.3e}; reference bf16 vs its fp32 {ref_gap:.3e}")
+    assert worst_vs_bf16 <= 6e-2 and worst_vs_f32 <= ref_gap
+    lf, lb = float(arrays["fp32:loss"]), float(arrays["bf16:loss"])
+    assert abs(float(loss) - lf) <= 1e-3 * abs(lf) and abs(float(loss) - lb) <= 1e-3 * abs(lb), (float(loss), lf, lb)

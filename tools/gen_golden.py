@@ -518,6 +518,68 @@ def phiseg3d_case(name, in_ch, num_classes, filters, latent_levels, dhw, seed):
                             no_grad=[n_ for n_, g in grads_of(net).items() if g is None]))
 
 
+def phiseg3d_bf16_case(name, in_ch, num_classes, filters, latent_levels, dhw, seed):
+    """The reference's 3-D modules run IN BF16 the way PyTorch runs a model in bf16 with fp32 master weights:
+    torch.autocast('cpu', dtype=torch.bfloat16) around Posterior / prior / Likelihood of a real PHISeg3D instance (Conv3d in bf16
+    with bf16 outputs; whatever autocast keeps in fp32 stays fp32).  Fixture for the native bf16 ARITHMETIC mode
+    (UZ_CONV_MATH=bf16: bf16 products, fp32 accumulation, fp32 storage): the two differ by the rounding of every conv OUTPUT to bf16
+    on the reference side, so the gate is loose and stated in the test; the tight pin of that mode is the operand-rounding oracle.
+    Digests only: every 7th element of the latent statistics and of the level logits."""
+    from models.phiseg3D import PHISeg3D as Ref3D
+    import torch.nn.functional as TF
+    from oracle.refgraph3d import phiseg3d_eps_shapes, synthetic_volume
+    D, H, W = dhw
+    net = Ref3D(input_channels=in_ch, num_classes=num_classes, num_filters=filters, latent_levels=latent_levels, image_size=(in_ch, D, H, W))
+    spec = kinds_for(net.state_dict())
+    net.load_state_dict(deterministic_state_dict(spec, seed=seed))
+    net.train()
+    R, L = len(filters), latent_levels
+    shapes = phiseg3d_eps_shapes(D, H, W, R, L)
+    x, onehot, lab, eps = synthetic_volume(in_ch, num_classes, dhw, 20201006, shapes + shapes)
+    xt, ot, lt = torch.from_numpy(x), torch.from_numpy(onehot), torch.from_numpy(lab)
+    s_in = {}
+    hooks = [blk.register_forward_hook(lambda m, i, o, k=k: s_in.__setitem__(k, o)) for k, blk in enumerate(net.likelihood.s_layer)]
+    orig = TF.interpolate
+
+    def resize(inp, size=None, *a, **kw):
+        if size is not None and inp.dim() == 5 and len(size) == 2:
+            return orig(inp, size=[D, H, W], mode="nearest")
+        return orig(inp, size, *a, **kw)
+    out = {}
+    for mode in ("fp32", "bf16"):
+        # fresh running statistics for each run (train-mode BatchNorm updates them)
+        net.load_state_dict(deterministic_state_dict(spec, seed=seed))
+        ctx = torch.autocast("cpu", dtype=torch.bfloat16) if mode == "bf16" else torch.autocast("cpu", enabled=False)
+        with torch.no_grad(), ctx:
+            with NoiseFeeder([torch.from_numpy(e) for e in eps]):
+                pz, pmu, psig = net.posterior(xt, ot)
+                qz, qmu, qsig = net.prior(xt, training_prior=True, z_list=pz)
+            TF.interpolate = resize
+            try:
+                s = net.likelihood(pz)
+            finally:
+                TF.interpolate = orig
+        net.posterior_latent_space, net.posterior_mu, net.posterior_sigma = [t.float() for t in pz], [t.float() for t in pmu], [t.float() for t in psig]
+        net.prior_latent_space, net.prior_mu, net.prior_sigma = [t.float() for t in qz], [t.float() for t in qmu], [t.float() for t in qsig]
+        net.s_out_list = [t.float() for t in s]
+        with torch.no_grad():
+            loss = net.loss(lt)
+        out[mode] = dict(pmu=pmu, psig=psig, qmu=qmu, qsig=qsig, s_in=dict(s_in), loss=float(loss))
+    for h in hooks:
+        h.remove()
+    arrays = {}
+    for mode, o in out.items():
+        for l in range(L):
+            sub = lambda t: npf(t.float()).reshape(-1)[::7].copy()          # every 7th element, flat
+            arrays[f"{mode}:post_mu{l}"], arrays[f"{mode}:post_sigma{l}"] = sub(o["pmu"][l]), sub(o["psig"][l])
+            arrays[f"{mode}:prior_mu{l}"], arrays[f"{mode}:prior_sigma{l}"] = sub(o["qmu"][l]), sub(o["qsig"][l])
+            arrays[f"{mode}:s_in{l}"] = sub(o["s_in"][L - 1 - l])
+        arrays[f"{mode}:loss"] = np.float32(o["loss"])
+    save(name, arrays, dict(model="PHISeg3D", input_channels=in_ch, num_classes=num_classes, filters=filters, latent_levels=L, dhw=list(dhw),
+                            weight_seed=seed, input_seed=20201006, logit_stride=7, spec=[[k, list(s_), kd] for k, s_, kd in spec],
+                            how="reference Posterior / prior / Likelihood under torch.autocast('cpu', torch.bfloat16) and in fp32, no_grad"))
+
+
 def batch_provider_stream():
     """Index / annotator stream of the REAL reference BatchProvider.next_batch (data/batch_provider.py:43-67,131-137) under a
     fixed numpy seed: pins the native provider's sampling logic and its order of RNG draws.  (The augmentation draws cannot be
@@ -616,6 +678,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "3d":
         phiseg3d_case("phiseg3d_small", 2, 3, [4, 8, 8], 2, (16, 16, 8), 1242)       # lvl_diff 1
         phiseg3d_case("phiseg3d_l3", 4, 3, [8, 8, 16], 3, (8, 16, 16), 1243)         # one latent level per resolution level
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "3d_bf16":
+        # large enough for the library to route its convolutions to the matrix-pipe kernels (32+ channels on 64-wide planes)
+        phiseg3d_bf16_case("phiseg3d_bf16", 4, 3, [32, 32, 64], 3, (32, 64, 64), 1244)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "batches":
         batch_provider_stream()
