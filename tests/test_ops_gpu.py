@@ -527,12 +527,12 @@ def test_conv_bf16_arithmetic_mode(N, Cin, Cout, H, W):
     dx_ref32 = F.conv_transpose2d(dy, w, padding=1)
     dw_ref = torch.nn.grad.conv2d_weight(rb(x), w.shape, rb(dy), padding=1)      # the weight gradient rounds x and dy (when it takes this path)
     dw_ref32 = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1)
-    wsb = max(L.uz_conv_workspace(Cin, Cout, N, H, W, 3), L.uz_conv_bwd_weight_workspace(Cin, Cout, N, H, W, 3))
-    ws = torch.empty(wsb // 4 + 64, device=g.dev())
     xd, wd, bd, dyd = x.to(g.dev()), w.to(g.dev()), b.to(g.dev()), dy.to(g.dev())
     y = torch.empty(N, Cout, H, W, device=g.dev()); dx = torch.empty_like(xd); dw = torch.empty_like(wd)
     try:
         L.uz_set_conv_math(3)
+        wsb = max(L.uz_conv_workspace(Cin, Cout, N, H, W, 3), L.uz_conv_bwd_weight_workspace(Cin, Cout, N, H, W, 3))   # sizes depend on the mode
+        ws = torch.empty(wsb // 4 + 64, device=g.dev())
         assert L.uz_conv_route(0, Cin, Cout, N, H, W, 3) == 1
         dgrad_bf16 = L.uz_conv_route(1, Cin, Cout, N, H, W, 3) == 1          # each direction is routed by its own shape
         wgrad_bf16 = L.uz_conv_route(2, Cin, Cout, N, H, W, 3) == 1          # narrow layers keep their weight gradient on the fp32 kernels

@@ -13,6 +13,7 @@ done
 python bench.py --model phiseg3d --conv-math default --steps 10 --warmup 3 --skip-cpu --no-profile > gpurun_out/bench_phiseg3d_f32split.json 2>/dev/null; cut -c1-200 gpurun_out/bench_phiseg3d_f32split.json
 python bench.py --conv-math bf16 --steps 20 --warmup 5 --skip-cpu --no-profile --no-f32-leg > gpurun_out/bench_phiseg_bf16math.json 2>/dev/null; cut -c1-200 gpurun_out/bench_phiseg_bf16math.json
 python bench.py --model phiseg3d --reversible --steps 10 --warmup 3 --skip-cpu --no-profile > gpurun_out/bench_phiseg3d_rev.json 2> gpurun_out/bench_phiseg3d_rev.err; cut -c1-200 gpurun_out/bench_phiseg3d_rev.json
+python bench.py --model unet --cpu-batch 4 --steps 5 --warmup 2 --no-f32-leg --no-profile > gpurun_out/bench_unet_cpu_b4.json 2>/dev/null; python -c "import json; d=json.loads(open('gpurun_out/bench_unet_cpu_b4.json').read().strip().splitlines()[-1]); print('config 1 (Unet-4 B=4 CPU oracle on this box):', d['cpu_baseline'])"
 UZ_BENCH_SINGLE_DEVICE=1 UZ_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --skip-cpu --no-profile --no-f32-leg > gpurun_out/bench_2ranks_one_device.json 2> gpurun_out/bench_2ranks.err; cut -c1-250 gpurun_out/bench_2ranks_one_device.json
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29577 python tools/nccl_world1_check.py > gpurun_out/nccl_world1.log 2>&1; echo "nccl rc=$?"; tail -4 gpurun_out/nccl_world1.log
 bash tools/prof_round.sh 3 > gpurun_out/prof_round.log 2>&1; tail -5 gpurun_out/prof_round.log

@@ -5,8 +5,9 @@ Builds the benchmark's PHiSeg plan, runs two training steps so that every buffer
 values, picks the TOP heaviest convolution ops of the forward / backward tapes (ranked by a HIP-event timing of each op alone) and
 then launches, per op:   one MARKER kernel (uz_axpy on one float - a kernel name that occurs nowhere else in this workload),
 followed by REPS launches of exactly that tape op (uz_run_tape on a 1-op tape: the product's own call, its real views, bounds and
-pre-packed weights).  The dispatch stream is therefore   marker, op0 x REPS, marker, op1 x REPS, ...   and tools/layer_table.py
-cuts the trace / counter CSVs at the markers - keyed on dispatch ORDER, not on grid size or kernel name.
+pre-packed weights) and a closing MARKER.  The dispatch stream is therefore   marker, op0 x REPS, marker, [prefix of op1], marker,
+op1 x REPS, marker, ...   and tools/layer_table.py cuts the trace / counter CSVs at the marker PAIRS - keyed on dispatch ORDER, not
+on grid size or kernel name.
 Segment 0 is the FETCH_SIZE calibration (uz_absmax over a known byte count: one coalesced dword per lane).
 usage: layer_profile.py <ops.json> [top] [reps]"""
 import ctypes as C
@@ -67,6 +68,7 @@ for which, ops in ((("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)) if not (fixed 
             continue
         tape = one_op(which, k)
         run_group_prefix(which, k)
+        _ffi.check(L.uz_run_tape(tape, 1, st), "op")        # untimed first launch (kernel attribute calls, code object residency)
         best = 1e9
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -78,7 +80,8 @@ if cands:
     top = cands[:TOP]
 
 marker_buf = torch.zeros(4, device="cuda")
-cal = torch.randn(64 * 1024 * 1024, device="cuda")                  # 256 MB calibration read
+cal = torch.randn(256 * 1024 * 1024, device="cuda")                 # 1 GiB calibration read: four times the Infinity Cache, so no repetition finds it resident
+flush = torch.empty(128 * 1024 * 1024, device="cuda") if os.environ.get("UZ_PROFILE_FLUSH") == "1" else None      # 512 MiB
 slot = torch.zeros(256, device="cuda")
 meta = dict(model=MODEL, batch=B, reps=REPS, marker="axpy_k", calibration=dict(kernel="absmax_view_kernel", known_read_bytes=cal.numel() * 4), ops=[])
 torch.cuda.synchronize()
@@ -88,9 +91,20 @@ def marker():
     _ffi.check(L.uz_axpy(marker_buf.data_ptr(), marker_buf.data_ptr(), C.c_float(0.0), 1, st), "marker")
 
 
+def cold():
+    """PMC passes only (UZ_PROFILE_FLUSH=1): overwrite 512 MiB between two launches, so that every launch starts with none of its
+    operands in the 256 MiB Infinity Cache - the traffic then is what the kernel pulls from HBM when nothing helps it (an upper
+    bound of the in-step figure; FETCH_SIZE shrinks by a third when the same operands are re-read from the cache, measured on the
+    calibration kernel).  The flush kernel (zero_k) is excluded from the per-op sums by name."""
+    if flush is not None:
+        _ffi.check(L.uz_zero_f32(flush.data_ptr(), flush.numel(), st), "flush")
+
+
 marker()
 for _ in range(REPS):
+    cold()
     _ffi.check(L.uz_absmax(cal.data_ptr(), cal.numel(), slot.data_ptr(), st), "calibration")
+marker()
 for ms, which, k in top:
     o = (plan.fwd_ops if which == "fwd" else plan.bwd_ops)[k]
     kind, cin, cout, n, h, w, ks = conv_dims(o)
@@ -102,8 +116,9 @@ for ms, which, k in top:
     run_group_prefix(which, k)
     marker()
     for _ in range(REPS):
+        cold()
         _ffi.check(L.uz_run_tape(tape, 1, st), "op")
-marker()
+    marker()                                             # a segment is [marker, launches, marker]: the next op's group prefix stays outside
 torch.cuda.synchronize()
 json.dump(meta, open(out_path, "w"), indent=1)
 print("profiled", len(top), "ops; heaviest", meta["ops"][0]["layer"], meta["ops"][0]["op"], meta["ops"][0]["isolated_ms_hip_events"], "ms")

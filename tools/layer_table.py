@@ -3,12 +3,12 @@
 
 usage: layer_table.py <ops.json> <kernel_trace_dir> <pmc_fetch_dir> <pmc_write_dir> <pmc_mfma_dir> <out.json>
 
-The dispatch stream of the workload is   marker, calibration x R, marker, op0 x R, marker, op1 x R, ..., marker   (marker =
-axpy_k).  Every CSV is ordered by dispatch and cut at the LAST len(ops) + 2 markers, so a row of the table is "what the product
+The dispatch stream of the workload is   marker, calibration x R, marker, ..., marker, op_i x R, marker, ...   (marker = axpy_k).
+Every CSV is ordered by dispatch and cut at the LAST 2 (len(ops) + 1) markers, taken in pairs, so a row of the table is "what the product
 launches for that layer and direction" - all kernels of the op (weight packing, the convolution, its slab reductions) - keyed on
 dispatch order.  Durations come from the kernel trace (no counters active); FETCH_SIZE / WRITE_SIZE / MFMA-busy from their own
 passes (MI355X_MICROARCH.md: FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2 - they cannot share a pass; gfx950 tallies 128-B read
-requests at 64 B, hence the calibration factor measured on a known 256 MB read in segment 0)."""
+requests at 64 B, hence the calibration factor measured on a known 1 GiB read in segment 0)."""
 import csv, glob, json, re, sys, collections
 
 meta = json.load(open(sys.argv[1]))
@@ -23,9 +23,11 @@ def short(n):
 def segments(rows, name_key, order_key):
     rows = sorted(rows, key=order_key)
     marks = [i for i, r in enumerate(rows) if short(r[name_key]).startswith(meta["marker"])]
-    assert len(marks) >= K + 2, f"{len(marks)} markers, need {K + 2}"
-    marks = marks[-(K + 2):]
-    return [rows[a + 1:b] for a, b in zip(marks, marks[1:])]
+    assert len(marks) >= 2 * (K + 1), f"{len(marks)} markers, need {2 * (K + 1)}"
+    marks = marks[-2 * (K + 1):]
+    # segments are marker PAIRS (what runs between two pairs is the next op's group prefix); zero_k = the cache flush between
+    # launches of the PMC passes (tools/layer_profile.py:cold)
+    return [[r for r in rows[a + 1:b] if not short(r[name_key]).startswith("zero_k")] for a, b in zip(marks[0::2], marks[1::2])]
 
 
 def trace_rows():

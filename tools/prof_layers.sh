@@ -7,6 +7,7 @@ O=gpurun_out/layers
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python tools/layer_profile.py $O/ops.json $TOP $REPS > $O/trace.log 2>&1
 export UZ_PROFILE_OPS=$GRAFT_REPO_ROOT/$O/ops.json
+export UZ_PROFILE_FLUSH=1      # PMC passes: every launch starts with a cold Infinity Cache (tools/layer_profile.py:cold)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python tools/layer_profile.py $O/ops_fetch.json $TOP $REPS > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python tools/layer_profile.py $O/ops_write.json $TOP $REPS > $O/write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -- python tools/layer_profile.py $O/ops_mfma.json $TOP $REPS > $O/mfma.log 2>&1
