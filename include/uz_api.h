@@ -117,7 +117,9 @@ int uz_conv_bwd_data(const float* dy, int Cout, int CoutTot,
                      void* workspace, size_t workspace_bytes, void* stream);
 /* autograd w.r.t. the weight: dw[co,ci,tap] = sum_{b,y,x} dy * x_shifted.
  * Deterministic split-K: partial slabs in `workspace` (uz_conv_bwd_weight_workspace
- * bytes), then an ordered reduction.  db (nullable) = sum_{b,y,x} dy.           */
+ * bytes), then an ordered reduction.  db (nullable) = sum_{b,y,x} dy.
+ * Depth window (Cin == 3 * CinTot, ks 3: a Conv3d run over D slices, see the volume section): dw is written in the Conv3d
+ * parameter layout [Cout][CinTot][3][3][3] (contraction channel k = kd * CinTot + ci), no separate permutation needed.   */
 size_t uz_conv_bwd_weight_workspace(int Cin, int Cout, int N, int H, int W, int ks);
 int uz_conv_bwd_weight(const float* x, int Cin, int CinTot,
                        const float* dy, int Cout, int CoutTot,

@@ -158,10 +158,10 @@ def test_conv3d_as_depth_window_vs_torch(Cin, Cout, D, H, W):
     assert g.relerr(_unvol(y), yr[0]) <= 2e-5
     # weight gradient in the window layout, permuted back to [co][ci][kd][kh][kw]
     dybuf, dyv = _vol(dy)
-    dwp = torch.empty(Cout * Cin * 27, device="cuda")
-    g.call("uz_conv_bwd_weight", xbuf, 3 * Cin, Cin, dyv, Cout, Cout, dwp, None, D, H, W, 3, None, None, ws, ws_b)
+    # a depth-window call (3 Cin view channels over a Cin-channel buffer) leaves its gradient in the Conv3d parameter layout
+    # [Cout][Cin][3][3][3] itself: the slab reduction permutes on the way out (round 3; it used to need uz_w3d_permute mode 2)
     dw = torch.empty(Cout, Cin, 3, 3, 3, device="cuda")
-    g.call("uz_w3d_permute", dwp, dw, Cout, Cin, 2)
+    g.call("uz_conv_bwd_weight", xbuf, 3 * Cin, Cin, dyv, Cout, Cout, dw, None, D, H, W, 3, None, None, ws, ws_b)
     assert g.relerr(dw, wr.grad) <= 2e-5
     # data gradient: the dy volume read through a depth window of 3 Cout channels against the depth-flipped weights
     wp2 = torch.empty(Cout * Cin * 27, device="cuda")

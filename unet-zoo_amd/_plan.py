@@ -162,6 +162,7 @@ class Plan:
         self.grad_buckets = []              # [(lo, hi)] float ranges of the flat gradient buffer that get a "final" event (data parallel)
         self.events = []                    # hipEvent_t handles (uz_event_create), one per gradient bucket
         self._gid = 0                       # scheduling group of the ops being emitted (see _schedule)
+        self._gyz = {}                       # zero-bordered dy scratch classes of volume units: (slices, floats per slice) -> floats
         self.n_lanes = max(1, min(int(os.environ.get("UZ_LANES", "2")), 8))
         self.decouple_wgrad_px = 0           # NativeModel.decouple_wgrad_px: planes (N*H*W) up to which weight gradients get a group of their own
 
@@ -328,13 +329,13 @@ class Plan:
         if x.nb is not None and ks == 3:                      # volume: see _conv_fwd
             assert isinstance(gy, _ScratchView) and gy.off and db_key is None and wrow0 == 0
             x, x_orig = self.__dict__.get("_win_of", {}).get(wkey, x), x          # the weight gradient reads the depth window
-            dwp = self.vec(wkey + ":w3d_dw", cout * cin * 27)
             ws = self.L.uz_conv_bwd_weight_workspace(3 * cin, cout, x.N, x.H, x.W, 3)
             self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
+            # (a depth-window call - 3 C view channels over a C-channel buffer - writes the Conv3d gradient layout itself:
+            # uz_conv_bwd_weight's slab reduction does the [co][kd][ci] -> [co][ci][kd] permutation on the way out)
             self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
-                       p=[("win", x), gy, dwp, None, ("scratch", "wgrad"), self.amax_in(x), self.amax_in(gy)],
+                       p=[("win", x), gy, self.G(wkey), None, ("scratch", "wgrad"), self.amax_in(x), self.amax_in(gy)],
                        i=[3 * cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, 3], n=ws)
-            self._emit(self.bwd_ops, "UZ_OP_W3D_PERMUTE", p=[dwp, self.G(wkey)], i=[cout, cin, 2])
             x = x_orig
             if x.buf.requires_grad:
                 acc = self._claim(x)
@@ -346,7 +347,7 @@ class Plan:
                     wp2 = self.vec(wkey + ":w3d_bwd", cout * cin * 27)
                     self._emit(self.bwd_ops, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp2], i=[cout, cin, 1])
                 self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
-                           p=[("gywin",), wp2, self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0), packed],
+                           p=[("gywin", gy.zkey), wp2, self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0), packed],
                            i=[3 * cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, 3, acc], n=ws2)
             return
         wextra = wrow0 * cin * ks * ks
@@ -470,11 +471,12 @@ class Plan:
             if x.nb is not None and ks == 3:
                 # volume: dy sits one slice into the scratch, between two zeroed border slices (the data gradient reads it
                 # through a depth window)
+                # ... in a scratch region of its own per (slices, slice size): the arena is zero-initialised and only the interior
+                # slices are ever written, so the two border slices stay zero without a memset per layer and step
                 sl = cout * y.H * y.W
-                self.scratch["gy"] = max(self.scratch["gy"], (y.N + 2) * sl)
-                self._emit(self.bwd_ops, "UZ_OP_MEMSET", p=[("gypad", 0)], n=4 * sl)
-                self._emit(self.bwd_ops, "UZ_OP_MEMSET", p=[("gypad", (y.N + 1) * sl)], n=4 * sl)
-                gy, gyv.off = ("gyvol", sl), sl
+                gyv.zkey = (y.N, sl)
+                self._gyz[gyv.zkey] = (y.N + 2) * sl
+                gy, gyv.off = ("gyvol", gyv.zkey), sl
             ga = a_grad if a_grad is not None else self.gview(a)
             self._emit(self.bwd_ops, "UZ_OP_BN_RELU_BWD",
                        p=[ga, y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), self.G(bkey), ("scratch", "bn"),
@@ -943,10 +945,15 @@ class Plan:
             b.off = off
             off += -(-b.numel // _ALIGN) * _ALIGN
         # scratch regions are private to a scheduling group, so every capture lane gets its own copy
-        self.gy_off, self.scratch_off = [], []
+        self.gy_off, self.scratch_off, self.gyz_off = [], [], []
         for _ in range(self.n_lanes):
             self.gy_off.append(off)
             off += -(-self.scratch["gy"] // _ALIGN) * _ALIGN
+            zo = {}
+            for key, fl in self._gyz.items():
+                zo[key] = off
+                off += -(-fl // _ALIGN) * _ALIGN
+            self.gyz_off.append(zo)
             so = {}
             for k in ("bn", "wgrad", "ce"):
                 so[k] = off
@@ -988,6 +995,8 @@ class Plan:
         if isinstance(r, _ScratchView):
             if r.view is not None:
                 return self._resolve(r.view, lane)
+            if r.zkey is not None:
+                return self.base + 4 * (self.gyz_off[lane][r.zkey] + r.off)
             return self.base + 4 * (self.gy_off[lane] + r.off)
         if isinstance(r, View):
             assert r.buf.off is not None
@@ -1016,12 +1025,10 @@ class Plan:
         if kind == "win":                                    # depth window of a volume: starts one slice before the view
             v = r[1]
             return self.base + 4 * (v.buf.off + ((v.b0 - 1) * v.buf.C + v.c0) * v.buf.H * v.buf.W)
-        if kind == "gywin":                                  # depth window of the dy scratch (dy lives one slice into the scratch)
-            return self.base + 4 * self.gy_off[lane]
-        if kind == "gyvol":                                  # dy of a volume unit: the scratch's real slices start one slice in
-            return self.base + 4 * (self.gy_off[lane] + r[1])
-        if kind == "gypad":                                  # the two border slices of the dy scratch (zeroed per use)
-            return self.base + 4 * (self.gy_off[lane] + r[1])
+        if kind == "gywin":                                  # depth window of a volume unit's dy scratch (dy lives one slice into it)
+            return self.base + 4 * self.gyz_off[lane][r[1]]
+        if kind == "gyvol":                                  # dy of a volume unit: the real slices start one slice in
+            return self.base + 4 * (self.gyz_off[lane][r[1]] + r[1][1])
         if kind == "amax":
             return self.base + 4 * (self.amax_off + _AMAX_FLOATS * self._amax_remap[r[1]])
         if kind == "amaxw":
@@ -1093,7 +1100,7 @@ class Plan:
             return self._resources(self._packbuf[r[1]])
         if kind == "win":
             return self._resources(r[1])
-        if kind in ("gywin", "gyvol", "gypad"):
+        if kind in ("gywin", "gyvol"):
             return []
         if kind == "amax":
             # Bound slots are atomic-max accumulated by the same kernels that write the data they bound, so every
@@ -1346,3 +1353,4 @@ class _ScratchView:
         self.off = 0              # float offset inside the scratch (volumes: one slice, behind the zeroed border slice)
         self.nb = None
         self.view = None          # a buffer of its own instead of the lane's scratch (decoupled weight gradients, see _conv_bwd)
+        self.zkey = None          # volume units: the zero-bordered scratch class (slices, floats per slice) this dy lives in

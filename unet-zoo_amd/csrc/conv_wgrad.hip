@@ -378,9 +378,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_groups(float* __restrict__ s
 // the slab reads of a wave are coalesced (lane = consecutive ci), a thread's S loads are independent of each other (issued
 // eight at a time, added in slab order), and 9x the workgroups of a per-(co, ci) sweep fill the chip - this kernel runs once
 // per layer and step, 106 times for PHiSeg.
+// volC > 0: the layer is a Conv3d run as a depth window (Cin = 3 volC contraction channels, k = kd volC + ci): the sum goes
+// straight into the PyTorch [Cout][volC][3][3][3] gradient layout (no separate permutation launch).
 template <int KK>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                            int S, int RG, int Cout, int Cin) {
+                                                            int S, int RG, int Cout, int Cin, int volC) {
     const int m = Cout * Cin, n = KK * m;
     const int j = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
     if (j >= m) return;
@@ -397,7 +399,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (int u = 0; u < 8; ++u) s += v[u];
     }
     for (; k < cnt; ++k) s += src[(size_t)k * step];
-    dw[(size_t)j * KK + t] = s;
+    if (volC > 0) {
+        const int co = j / Cin, kc = j - co * Cin, kd = kc / volC, ci = kc - kd * volC;
+        dw[(((size_t)co * volC + ci) * 3 + kd) * KK + t] = s;
+    } else {
+        dw[(size_t)j * KK + t] = s;
+    }
 }
 
 // db[c] = sum_{b,y,x} dy[b,c,y,x]: CSB blocks per channel write fp64 partials, then one wave per
@@ -717,8 +724,11 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
         if (int rc = uz::check_launch("wgrad_reduce_groups")) return rc;
     }
     const int fgrid = uz::ceil_div(Cout * Cin, 256);
-    if (ks == 3) hipLaunchKernelGGL(wgrad_reduce_kernel<9>, dim3(fgrid, 9), dim3(256), 0, st, p.slab, dw, Stot, RG, Cout, Cin);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(fgrid, 1), dim3(256), 0, st, p.slab, dw, Stot, RG, Cout, Cin);
+    // a depth window (csrc/vol.hip: Conv3d = the 2-D kernel over D slices with 3 C contraction channels on a C-channel buffer) is the
+    // only call with more view channels than the buffer has: its gradient leaves in the Conv3d parameter layout
+    const int volC = (ks == 3 && Cin == 3 * CinTot) ? CinTot : 0;
+    if (ks == 3) hipLaunchKernelGGL(wgrad_reduce_kernel<9>, dim3(fgrid, 9), dim3(256), 0, st, p.slab, dw, Stot, RG, Cout, Cin, volC);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(fgrid, 1), dim3(256), 0, st, p.slab, dw, Stot, RG, Cout, Cin, 0);
     if (int rc = uz::check_launch("wgrad_reduce_kernel")) return rc;
     if (db) {
         // the slab workspace is free again after the reduction above; it holds the fp64 partials

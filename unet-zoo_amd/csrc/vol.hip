@@ -45,6 +45,23 @@ __global__ __launch_bounds__(256) void avgpool3d_fwd_k(const float* __restrict__
         y[((size_t)od * CtotY + c) * n + q] = acc / (float)((d1 - d0) * (y1 - y0) * (x1 - x0));
     }
 }
+// W % 4 == 0 (and 16-byte aligned views): a thread turns up to 2 x 2 float4 loads into one float2 of outputs
+__global__ __launch_bounds__(256) void avgpool3d_fwd_v4(const float* __restrict__ x, int CtotX, float* __restrict__ y, int CtotY,
+                                                         int C, int D, int H, int W, int Do, int Ho, int Wo) {
+    const int od = blockIdx.z, c = blockIdx.y, W4 = W / 4, n2 = Ho * W4;
+    const int d0 = 2 * od, d1 = min(d0 + 2, D);
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < n2; q += gridDim.x * 256) {
+        const int oy = q / W4, j = q - oy * W4, y0 = 2 * oy, y1 = min(y0 + 2, H);
+        float a0 = 0.f, a1 = 0.f;
+        for (int d = d0; d < d1; ++d)
+            for (int yy = y0; yy < y1; ++yy) {
+                const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)d * CtotX + c) * H * W + (size_t)yy * W + 4 * j);
+                a0 += v.x + v.y; a1 += v.z + v.w;
+            }
+        const float inv = 1.f / (float)((d1 - d0) * (y1 - y0) * 2);
+        *reinterpret_cast<float2*>(y + ((size_t)od * CtotY + c) * Ho * Wo + (size_t)oy * Wo + 2 * j) = make_float2(a0 * inv, a1 * inv);
+    }
+}
 __global__ __launch_bounds__(256) void avgpool3d_bwd_k(const float* __restrict__ dy, int CtotDy, float* __restrict__ dx, int CtotDx,
                                                         int C, int D, int H, int W, int Do, int Ho, int Wo, int accumulate) {
     const int d = blockIdx.z, c = blockIdx.y, n = H * W, od = d >> 1;
@@ -54,6 +71,20 @@ __global__ __launch_bounds__(256) void avgpool3d_bwd_k(const float* __restrict__
         const float v = dy[((size_t)od * CtotDy + c) * Ho * Wo + oy * Wo + ox] / (float)cnt;
         float* dst = dx + ((size_t)d * CtotDx + c) * n + q;
         *dst = accumulate ? *dst + v : v;
+    }
+}
+__global__ __launch_bounds__(256) void avgpool3d_bwd_v4(const float* __restrict__ dy, int CtotDy, float* __restrict__ dx, int CtotDx,
+                                                         int C, int D, int H, int W, int Do, int Ho, int Wo, int accumulate) {
+    const int d = blockIdx.z, c = blockIdx.y, W4 = W / 4, n4 = H * W4, od = d >> 1;
+    const int cd = min(2 * od + 2, D) - 2 * od;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < n4; q += gridDim.x * 256) {
+        const int yy = q / W4, j = q - yy * W4, oy = yy >> 1;
+        const float inv = 1.f / (float)(cd * (min(2 * oy + 2, H) - 2 * oy) * 2);
+        const float2 g = *reinterpret_cast<const float2*>(dy + ((size_t)od * CtotDy + c) * Ho * Wo + (size_t)oy * Wo + 2 * j);
+        float4* dst = reinterpret_cast<float4*>(dx + ((size_t)d * CtotDx + c) * H * W + (size_t)yy * W + 4 * j);
+        float4 v = make_float4(g.x * inv, g.x * inv, g.y * inv, g.y * inv);
+        if (accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *dst = v;
     }
 }
 
@@ -74,6 +105,41 @@ __global__ __launch_bounds__(256) void depth_lerp_fwd_k(const float* __restrict_
     const float* b = x + ((size_t)(d0 + dp) * CtotX + c) * HW;
     float* o = y + ((size_t)od * CtotY + c) * HW;
     for (int q = blockIdx.x * 256 + threadIdx.x; q < HW; q += gridDim.x * 256) o[q] = (1.f - t) * a[q] + t * b[q];
+}
+__global__ __launch_bounds__(256) void depth_lerp_fwd_v4(const float* __restrict__ x, int CtotX, float* __restrict__ y, int CtotY,
+                                                          int C, int D, int HW) {
+    const int od = blockIdx.z, c = blockIdx.y;
+    int d0, dp; float t;
+    depth_src(od, D, d0, dp, t);
+    const float4* a = reinterpret_cast<const float4*>(x + ((size_t)d0 * CtotX + c) * HW);
+    const float4* b = reinterpret_cast<const float4*>(x + ((size_t)(d0 + dp) * CtotX + c) * HW);
+    float4* o = reinterpret_cast<float4*>(y + ((size_t)od * CtotY + c) * HW);
+    const float s = 1.f - t;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < HW / 4; q += gridDim.x * 256) {
+        const float4 u = a[q], v = b[q];
+        o[q] = make_float4(s * u.x + t * v.x, s * u.y + t * v.y, s * u.z + t * v.z, s * u.w + t * v.w);
+    }
+}
+__global__ __launch_bounds__(256) void depth_lerp_bwd_v4(const float* __restrict__ dy, int CtotDy, float* __restrict__ dx, int CtotDx,
+                                                          int C, int D, int HW, int accumulate) {
+    const int d = blockIdx.z, c = blockIdx.y;
+    float w[6]; int ods[6], nw = 0;
+    for (int od = max(0, 2 * d - 2); od <= min(2 * D - 1, 2 * d + 3); ++od) {
+        int d0, dp; float t;
+        depth_src(od, D, d0, dp, t);
+        const float ww = (d0 == d ? 1.f - t : 0.f) + (d0 + dp == d ? t : 0.f);
+        if (ww != 0.f) { w[nw] = ww; ods[nw] = od; ++nw; }
+    }
+    float4* o = reinterpret_cast<float4*>(dx + ((size_t)d * CtotDx + c) * HW);
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < HW / 4; q += gridDim.x * 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nw; ++k) {
+            const float4 g = reinterpret_cast<const float4*>(dy + ((size_t)ods[k] * CtotDy + c) * HW)[q];
+            acc.x += w[k] * g.x; acc.y += w[k] * g.y; acc.z += w[k] * g.z; acc.w += w[k] * g.w;
+        }
+        if (accumulate) { const float4 p = o[q]; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+        o[q] = acc;
+    }
 }
 __global__ __launch_bounds__(256) void depth_lerp_bwd_k(const float* __restrict__ dy, int CtotDy, float* __restrict__ dx, int CtotDx,
                                                          int C, int D, int HW, int accumulate) {
@@ -118,6 +184,7 @@ __global__ __launch_bounds__(256) void nearest3d_bwd_k(const float* __restrict__
 }
 
 inline int gx(int n) { int g = (n + 255) / 256; return g < 1 ? 1 : (g > 64 ? 64 : g); }
+inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
@@ -134,23 +201,35 @@ extern "C" int uz_w3d_permute(const float* src, float* dst, int Cout, int Cin, i
 extern "C" int uz_avgpool3d_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int D, int H, int W, void* stream) {
     UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && D <= 65535, "avgpool3d_fwd: bad sizes");
     const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    hipLaunchKernelGGL(avgpool3d_fwd_k, dim3(gx(Ho * Wo), C, Do), dim3(256), 0, uz::S(stream), x, CtotX, y, CtotY, C, D, H, W, Do, Ho, Wo);
+    if (W % 4 == 0 && a16(x) && a16(y) && (H * W) % 4 == 0 && (Ho * Wo) % 2 == 0)
+        hipLaunchKernelGGL(avgpool3d_fwd_v4, dim3(gx(Ho * W / 4), C, Do), dim3(256), 0, uz::S(stream), x, CtotX, y, CtotY, C, D, H, W, Do, Ho, Wo);
+    else
+        hipLaunchKernelGGL(avgpool3d_fwd_k, dim3(gx(Ho * Wo), C, Do), dim3(256), 0, uz::S(stream), x, CtotX, y, CtotY, C, D, H, W, Do, Ho, Wo);
     return uz::check_launch("avgpool3d_fwd_k");
 }
 extern "C" int uz_avgpool3d_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int D, int H, int W, int accumulate, void* stream) {
     UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && D <= 65535, "avgpool3d_bwd: bad sizes");
     const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    hipLaunchKernelGGL(avgpool3d_bwd_k, dim3(gx(H * W), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, C, D, H, W, Do, Ho, Wo, accumulate);
+    if (W % 4 == 0 && a16(dx) && a16(dy) && (Ho * Wo) % 2 == 0)
+        hipLaunchKernelGGL(avgpool3d_bwd_v4, dim3(gx(H * W / 4), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, C, D, H, W, Do, Ho, Wo, accumulate);
+    else
+        hipLaunchKernelGGL(avgpool3d_bwd_k, dim3(gx(H * W), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, C, D, H, W, Do, Ho, Wo, accumulate);
     return uz::check_launch("avgpool3d_bwd_k");
 }
 extern "C" int uz_depth_lerp2x_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int D, int H, int W, void* stream) {
     UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && 2 * D <= 65535, "depth_lerp2x_fwd: bad sizes");
-    hipLaunchKernelGGL(depth_lerp_fwd_k, dim3(gx(H * W), C, 2 * D), dim3(256), 0, uz::S(stream), x, CtotX, y, CtotY, C, D, H * W);
+    if ((H * W) % 4 == 0 && a16(x) && a16(y))
+        hipLaunchKernelGGL(depth_lerp_fwd_v4, dim3(gx(H * W / 4), C, 2 * D), dim3(256), 0, uz::S(stream), x, CtotX, y, CtotY, C, D, H * W);
+    else
+        hipLaunchKernelGGL(depth_lerp_fwd_k, dim3(gx(H * W), C, 2 * D), dim3(256), 0, uz::S(stream), x, CtotX, y, CtotY, C, D, H * W);
     return uz::check_launch("depth_lerp_fwd_k");
 }
 extern "C" int uz_depth_lerp2x_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int D, int H, int W, int accumulate, void* stream) {
     UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && D <= 65535, "depth_lerp2x_bwd: bad sizes");
-    hipLaunchKernelGGL(depth_lerp_bwd_k, dim3(gx(H * W), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, C, D, H * W, accumulate);
+    if ((H * W) % 4 == 0 && a16(dx) && a16(dy))
+        hipLaunchKernelGGL(depth_lerp_bwd_v4, dim3(gx(H * W / 4), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, C, D, H * W, accumulate);
+    else
+        hipLaunchKernelGGL(depth_lerp_bwd_k, dim3(gx(H * W), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, C, D, H * W, accumulate);
     return uz::check_launch("depth_lerp_bwd_k");
 }
 extern "C" int uz_nearest3d_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int D, int H, int W, int f, int fz, void* stream) {
