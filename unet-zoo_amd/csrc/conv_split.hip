@@ -137,6 +137,12 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     constexpr int PPLANE = PSR * CK * 2;                 // bytes per patch plane
     constexpr int WVEC = NP * WPLANE / 16;               // 16-byte vectors of one packed weight block (2304 / 1152)
     constexpr int WREGS = (WVEC + NT - 1) / NT;          // per thread
+    constexpr bool DEEP = TWv == 16;                     // patch loads two chunks ahead (see stage_deep)
+    constexpr bool PREF = TWv == 16;                     // fragment reads one tap ahead of the MFMAs
+#ifndef UZ_UNCOND_TW
+#define UZ_UNCOND_TW 16
+#endif
+    constexpr bool UNCOND = TWv <= UZ_UNCOND_TW;         // stage the (non-existent) chunk after the last one too
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Wl = lds;
     char* Pl = lds + NP * WPLANE;
@@ -224,6 +230,23 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
         const unsigned off = v < WVEC ? (unsigned)(c * p.nCoTiles + coT) * wblock + 16u * (unsigned)v : 0xFFFFFFFFu;
         wq[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
     };
+    auto convert = [&](int j) {              // split / round the values of k 4j .. 4j + 3 (j = 0 also the shared-row share)
+        const int i0 = 2 * j;
+        unsigned t0[NP], t1[NP];
+        pieces<NP>(pr[2 * i0] * xs, pr[2 * i0 + 1] * xs, t0);
+        pieces<NP>(pr[2 * i0 + 2] * xs, pr[2 * i0 + 3] * xs, t1);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { pk[q][i0] = t0[q]; pk[q][i0 + 1] = t1[q]; }
+        if (j == 0) {
+#pragma unroll
+            for (int i = 0; i < CE / 2; ++i) {
+                unsigned t2[NP];
+                pieces<NP>(pr1[2 * i] * xs, pr1[2 * i + 1] * xs, t2);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) pk1[q][i] = t2[q];
+            }
+        }
+    };
     auto stage = [&](int c, int tap) {
         if (tap < 4) {
             patch_loads(c, 2 * tap); patch_loads(c, 2 * tap + 1);
@@ -231,23 +254,23 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
         } else {
             if (tap - 4 < WREGS) weight_load(c, tap - 4);
             if (tap == 8) { for (int i = 5; i < WREGS; ++i) weight_load(c, i); }
-            if (tap < 8) {
-                const int i0 = 2 * (tap - 4);
-                unsigned t0[NP], t1[NP];
-                pieces<NP>(pr[2 * i0] * xs, pr[2 * i0 + 1] * xs, t0);
-                pieces<NP>(pr[2 * i0 + 2] * xs, pr[2 * i0 + 3] * xs, t1);
+            if (tap < 8) convert(tap - 4);
+        }
+    };
+    // DEEP (the 16 x 16-pixel geometry: few workgroups, one to three waves per SIMD, so nothing else covers a load's latency):
+    // the patch values are fetched TWO chunks ahead - taps 5..8 of chunk c issue the loads of chunk c + 2 into the raw registers
+    // that taps 0..3 have just converted (chunk c + 1); the packed weights (L2 resident, short latency) stay one chunk ahead and
+    // are issued first (tap 4) so that the in-order wait before the LDS writes does not include the patch loads.
+    auto stage_deep = [&](int c, int tap, bool more, bool more2) {
+        if (tap < 4) { if (more) convert(tap); }
+        else if (tap == 4) {
+            if (more) {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) { pk[q][i0] = t0[q]; pk[q][i0 + 1] = t1[q]; }
+                for (int i = 0; i < WREGS; ++i) weight_load(c + 1, i);
             }
-            if (tap == 4) {
-#pragma unroll
-                for (int i = 0; i < CE / 2; ++i) {
-                    unsigned t0[NP];
-                    pieces<NP>(pr1[2 * i] * xs, pr1[2 * i + 1] * xs, t0);
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) pk1[q][i] = t0[q];
-                }
-            }
+        } else if (more2) {
+            patch_loads(c + 2, 2 * (tap - 5)); patch_loads(c + 2, 2 * (tap - 5) + 1);
+            if (tap == 5) shared_row_loads(c + 2);
         }
     };
     auto lstore = [&]() {
@@ -284,6 +307,10 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     // layer) skips that half's MFMAs, fragment reads and epilogue pass: 12.5 % of that launch's matrix work were zeros.
     const bool half_tile = MSUB == 2 && p.Cout - co0 <= 32;
     constexpr int MS = MSUB;
+    if (DEEP && cbeg + 1 < cend) {
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) stage(cbeg + 1, tap);       // the raw registers are free again: chunk cbeg is converted
+    }
     for (int c = cbeg; c < nChunks; ++c) {
         long long ta = 0;
         if (p.stamps) ta = __builtin_amdgcn_s_memtime();
@@ -293,27 +320,50 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
         if (p.stamps) { const long long tb = __builtin_amdgcn_s_memtime(); if (c == cbeg) st1 = tb; else stl += tb - ta; }
         const bool more = c + 1 < nChunks;
         const char* Al = Wl + l31 * 16 + h * (WPLANE / 2);
-#pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
+        // Fragment reads run one tap ahead of the MFMAs (PREF: the 16 x 16-pixel geometry, where one to three waves per SIMD do not
+        // cover a ds_read's latency between themselves); the first tap of a chunk has to wait for the barrier above.
+        u32x4 a[PREF ? 2 : 1][MS][NP], b[PREF ? 2 : 1][NSUB][NP];
+        auto frag_loads = [&](int tap, int buf) {
             const int tapoff = ((tap / 3) * PW + (tap % 3)) * 16;
-            u32x4 a[MS][NP], b[NSUB][NP];
 #pragma unroll
             for (int m = 0; m < MS; ++m)
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    a[m][q] = *reinterpret_cast<const u32x4*>(Al + q * WPLANE + (tap * COT + m * 32) * 16);
+                    a[buf][m][q] = *reinterpret_cast<const u32x4*>(Al + q * WPLANE + (tap * COT + m * 32) * 16);
 #pragma unroll
             for (int n = 0; n < NSUB; ++n)
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    b[n][q] = *reinterpret_cast<const u32x4*>(Pl + q * PPLANE + poff[n] + tapoff);
-            if (more) stage(c + 1, tap);
+                    b[buf][n][q] = *reinterpret_cast<const u32x4*>(Pl + q * PPLANE + poff[n] + tapoff);
+        };
+        if (PREF) frag_loads(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int cur = PREF ? (tap & 1) : 0;
+            if (!PREF) frag_loads(tap, 0);
+            else if (tap + 1 < KK) frag_loads(tap + 1, cur ^ 1);
+            // Unconditional (a branch here would fence the instruction scheduler: the staging VALU block ran with the matrix pipe
+            // idle): past the last chunk the K-tail masks of the loads turn them into range-checked no-ops returning 0.
+            if (DEEP) stage_deep(c, tap, UNCOND || more, UNCOND || c + 2 < nChunks);
+            else if (UNCOND || more) stage(c + 1, tap);
             // smallest products first
 #pragma unroll
             for (int m = 0; m < MS; ++m) {
                 if (m == 1 && half_tile) continue;           // workgroup-uniform: a scalar branch around six MFMAs
 #pragma unroll
-                for (int n = 0; n < NSUB; ++n) acc[m][n] = mma<NP>(acc[m][n], a[m], b[n]);
+                for (int n = 0; n < NSUB; ++n) acc[m][n] = mma<NP>(acc[m][n], a[cur][m], b[cur][n]);
+            }
+            if (UNCOND) {
+                // one wave per SIMD: nobody else fills the gaps, so the staging VALU / memory instructions of this tap are
+                // asked to sit BETWEEN its MFMAs (in program order behind them they would run with the matrix pipe idle)
+#pragma unroll
+                for (int i = 0; i < MS * NSUB * (NP == 2 ? 3 : 1); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);           // ... and the next tap's work stays behind this tap's MFMAs
             }
         }
     }
@@ -423,7 +473,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 template <int MSUB, int NTv, int TWv, int NP> struct SplitKernel;
 __global__ __launch_bounds__(512, 1) void conv_split_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32, 2>(p); }
 __global__ __launch_bounds__(512, 4) void conv_split_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32, 2>(p); }
-__global__ __launch_bounds__(256, 3) void conv_split_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16, 2>(p); }
+__global__ __launch_bounds__(256, 2) void conv_split_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16, 2>(p); }
 __global__ __launch_bounds__(512, 1) void conv_bf16_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32, 1>(p); }
 __global__ __launch_bounds__(512, 4) void conv_bf16_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32, 1>(p); }
 __global__ __launch_bounds__(256, 3) void conv_bf16_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16, 1>(p); }
@@ -518,9 +568,11 @@ int split_parts(int Kc, int Mc, int N, int H, int W) {
     if (!small_geo(W)) return 1;
     const int cot = tile_cot(Kc, Mc, W), nChunks = ceil_div(Kc, CK);
     const long long g = (long long)N * ceil_div(H, TH) * ceil_div(W, 16) * ceil_div(Mc, cot);
-    if (g >= 384) return 1;
+    static const int gmin = getenv("UZ_SPLITK_GRID") ? atoi(getenv("UZ_SPLITK_GRID")) : 160;
+    if (g >= gmin) return 1;                      // most CUs have a workgroup: a longer chunk loop beats slabs + a reduce launch
     int S = (int)((768 + g / 2) / g);
-    S = S > 4 ? 4 : S;
+    static const int smax = getenv("UZ_SPLITK_MAX") ? atoi(getenv("UZ_SPLITK_MAX")) : 4;
+    S = S > smax ? smax : S;
     if (S > nChunks / 3) S = nChunks / 3;
     return S < 1 ? 1 : S;
 }
