@@ -332,6 +332,15 @@ void pick_split(long long base_grid, int nChunks, int msub, int kk, double out_b
     }
 }
 
+// 32- or 64-channel tiles.  64 halves the operand reads per MFMA, but on the 4 x 4 and 2 x 2 planes even one chunk per workgroup
+// leaves most CUs idle (6 tiles x 12 chunks = 72 workgroups): there 32-channel tiles double the workgroups and halve the chain.
+int pick_msub(int Mc, long long pixel_tiles, int nChunks) {
+    if (Mc <= 32) return 1;
+    static const bool off = getenv("UZ_MSUB_SMALL") && atoi(getenv("UZ_MSUB_SMALL")) == 0;
+    if (off) return 2;
+    return pixel_tiles * uz::ceil_div(Mc, 64) * nChunks < 256 ? 1 : 2;
+}
+
 Geom pick_geom(int N, int H, int W, int halo) {
     Geom g;
     g.TW = W >= 32 ? 32 : uz::pow2_ceil(W);
@@ -389,7 +398,7 @@ int splitk_reduce(const float* slab, int ksplit, const float* bias, float* y, in
 size_t conv_workspace(int Kc, int Mc, int N, int H, int W, int ks, int dgrad) {
     if (conv_split_ok(Kc, Mc, N, H, W, ks, dgrad)) return conv_split_workspace(Kc, Mc, N, H, W);
     const Geom g = pick_geom(N, H, W, ks / 2);
-    const int cot = Mc <= 32 ? 32 : 64;
+    const int cot = 32 * pick_msub(Mc, (long long)g.tilesX * g.tilesY * g.tilesB, ceil_div(Kc, CK));
     int ksplit, cps;
     pick_split((long long)g.tilesX * g.tilesY * g.tilesB * ceil_div(Mc, cot), ceil_div(Kc, CK), cot / 32, ks * ks,
                (double)N * Mc * H * W * sizeof(float), ksplit, cps);
@@ -417,7 +426,7 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     p.tilesX = g.tilesX; p.tilesY = g.tilesY;
     p.PW = g.PW; p.PSI = g.PSI; p.PS = g.PS;
     p.relu = relu; p.accumulate = accumulate; p.y_amax = y_amax;
-    const int msub = Mc <= 32 ? 1 : 2;
+    const int msub = pick_msub(Mc, (long long)g.tilesX * g.tilesY * g.tilesB, ceil_div(Kc, CK));
     const int cot = 32 * msub;
     p.nCoTiles = ceil_div(Mc, cot);
     const int jmax = g.PS <= 512 ? 2 : 4;
