@@ -256,3 +256,41 @@ def test_unnormalised_unet_activations_after_real_training_steps():
         assert ratio < 2.0 ** 12                                 # far from the 2^14 where the bound's second term would start to matter
         assert worst["y"] <= 2.0 * wf + 4.0
     assert _flags() == 0
+
+
+def test_guard_bounds_falls_back_to_fp32_arithmetic_and_the_step_can_be_repeated():
+    """The engine's safety net (Native.guard_bounds, used by train_model.train_step before the optimizer touches the parameters):
+    a raised device flag -> RuntimeWarning, process switched to the fp32-MFMA kernels, plans and graphs rebuilt; the repeated
+    step gives the fp32 mode's gradients."""
+    _need_split()
+    import unet_zoo_amd  # noqa: F401
+    from unet_zoo_amd.models.unet import Unet
+    from unet_zoo_amd.synthetic import synthetic_batch
+    g, L = _g(), _lib()
+    torch.manual_seed(7)
+    net = Unet(1, 2, [32, 64, 128, 192])
+    net.train(); net.enable_graphs(True)
+    xb, mb, _ = synthetic_batch(8, 128, 128, seed=3)
+    xb, mb = torch.from_numpy(xb).to(g.dev()), torch.from_numpy(mb).to(g.dev())
+
+    def step():
+        net.zero_grad()
+        net.forward(xb); loss = net.loss(mb); loss.backward()
+        return float(loss.detach()), net._ptab.gflat.clone()
+    try:
+        l_split, g_split = step()
+        assert net.guard_bounds() == 0 and L.uz_get_conv_math() != 0
+        # raise the activation flag the way a stale bound would: one raw call with a bound 64 x too small
+        x, w, dy = _operands(41)
+        _run_all(x, w, dy, _slot(float(x.abs().max()) / 64), _slot(float(w.abs().max())), _slot(float(dy.abs().max())))
+        with pytest.warns(RuntimeWarning, match="falling back to fp32"):
+            assert net.guard_bounds() & 1
+        assert L.uz_get_conv_math() == 0 and not net._plans and not net._graphs
+        l_f32, g_f32 = step()                                   # the repeated step: fp32 MFMA kernels
+        assert net.guard_bounds() == 0
+        assert all(L.uz_conv_route(k, 64, 64, 8, 64, 64, 3) == 0 for k in range(3))
+        assert abs(l_f32 - l_split) <= 1e-5 * abs(l_split)
+        den = float(g_f32.abs().max())
+        assert float((g_f32 - g_split).abs().max()) <= 2e-4 * den      # two fp32-accurate evaluations of the same step
+    finally:
+        L.uz_set_conv_math(-1)

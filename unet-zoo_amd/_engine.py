@@ -79,6 +79,21 @@ class NativeModel(nn.Module):
         _ffi.check(_ffi.lib().uz_device_flags(C.byref(out), 1 if clear else 0, C.c_void_p(self._stream())), "device_flags")
         return out.value
 
+    def guard_bounds(self):
+        """check_bounds() + the safety net behind it: if any split-fp16 kernel saw a tensor beyond its magnitude bound (values were
+        clamped: finite, but wrong), warn, switch the PROCESS to the fp32-MFMA kernels (uz_set_conv_math(0): no bounds, no scales)
+        and drop this model's plans and graphs so that the next forward is rebuilt on them.  Returns the flag word; a caller that
+        gets non-zero repeats the step it just ran (train_model.py does).  Costs one stream synchronisation."""
+        flags = self.check_bounds()
+        if flags:
+            import warnings
+            warnings.warn(f"split-fp16 convolution path: magnitude bound exceeded (flags {flags:#x}: 1 activation, 2 weight, 4 gradient) - "
+                          "falling back to fp32 MFMA arithmetic for the rest of this process", RuntimeWarning)
+            _ffi.check(_ffi.lib().uz_set_conv_math(0), "set_conv_math")
+            self._plans.clear()
+            self._drop_graphs()
+        return flags
+
     def _require_gpu(self):
         if self.device.type != "cuda":
             raise _ffi.UzError("no GPU visible: the native path has no CPU fallback (model was built in structure-only mode)")

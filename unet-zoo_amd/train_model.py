@@ -168,6 +168,13 @@ class UNetModel:
         self.kl_loss += getattr(self.net, "kl_divergence_loss", 0)
         self.optimizer.zero_grad()
         self.loss.backward()
+        if hasattr(self.net, "guard_bounds") and self.net.guard_bounds():
+            # a split-fp16 kernel clamped a tensor (never expected: the bounds are maintained by the producing kernels) - the
+            # engine has switched to fp32 MFMA arithmetic; repeat this batch there before the parameters are touched
+            self.net.forward(patch, mask, training=True)
+            self.loss = self.net.loss(mask)
+            self.optimizer.zero_grad()
+            self.loss.backward()
         self.optimizer.step()
         return self.loss
 
