@@ -144,28 +144,31 @@ constexpr int LB = 16, BWMAX = 128, KT = 6, BROWS = 2 * LB + KT - 2;
 __global__ __launch_bounds__(256) void bilinear_bwd_sep_k(const RsP p) {   // src = dy (high res), dst = dx (low res)
     __shared__ float wyT[LB * KT];
     __shared__ float tx[BROWS * (BWMAX / 2)];                               // dY reduced along x
-    const int c = blockIdx.y, b = blockIdx.z, iy0 = blockIdx.x * LB;
+    const int c = blockIdx.y, b = blockIdx.z;
     const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
     float* d = p.dst + ((size_t)b * p.CtotD + c) * p.H * p.W;
-    const int nrow = min(LB, p.H - iy0);
-    const int ob = 2 * iy0 - 2;                              // high-res row of band row 0
-    const int nb = 2 * nrow + KT - 2;                        // band rows in use
-    for (int e = threadIdx.x; e < nrow * KT; e += 256) {
-        const int i = e / KT, k = e - i * KT;
-        wyT[e] = tap_weight(2 * (iy0 + i) - 2 + k, p.Ho, p.sh, p.ac, p.H, iy0 + i);
-    }
     // x pass straight from HBM: the KT taps of low-res column ix are the three aligned float2 at high-res columns 2 ix - 2 ..
     // 2 ix + 3 (a pair is entirely inside or outside the row because Wo is even); consecutive lanes read consecutive pairs,
     // so each of the three loads of a wave is one contiguous 512-byte run and the overlap is served by the vector L1
-    // (host guarantees 256 % W == 0: a thread keeps one column, its KT weights live in registers)
-    {
-        const int ix = threadIdx.x % p.W, rstep = 256 / p.W;
-        float wx[KT];
+    // (host guarantees 256 % W == 0: a thread keeps one column, its KT weights live in registers).
+    // A workgroup walks ALL bands of its plane (grid.x = 1): the column weights, the index arithmetic (W is a run-time value:
+    // every / and % is a ~40-instruction sequence) and the launch overhead are paid once per plane, not once per 16 rows -
+    // at 17 KB of input per band they were most of the kernel.
+    const int ix = threadIdx.x % p.W, rstep = 256 / p.W, r0 = threadIdx.x / p.W;
+    float wx[KT];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) wx[k] = tap_weight(2 * ix - 2 + k, p.Wo, p.sw, p.ac, p.W, ix);
-        const bool v0 = ix > 0, v2 = 2 * ix + 3 < p.Wo;          // first / last pair inside the row (the middle one always is)
+    for (int k = 0; k < KT; ++k) wx[k] = tap_weight(2 * ix - 2 + k, p.Wo, p.sw, p.ac, p.W, ix);
+    const bool v0 = ix > 0, v2 = 2 * ix + 3 < p.Wo;              // first / last pair inside the row (the middle one always is)
+    for (int iy0 = blockIdx.x * LB; iy0 < p.H; iy0 += gridDim.x * LB) {
+        const int nrow = min(LB, p.H - iy0);
+        const int ob = 2 * iy0 - 2;                              // high-res row of band row 0
+        const int nb = 2 * nrow + KT - 2;                        // band rows in use
+        for (int e = threadIdx.x; e < nrow * KT; e += 256) {
+            const int i = e / KT, k = e - i * KT;
+            wyT[e] = tap_weight(2 * (iy0 + i) - 2 + k, p.Ho, p.sh, p.ac, p.H, iy0 + i);
+        }
 #pragma unroll 4
-        for (int r = threadIdx.x / p.W; r < nb; r += rstep) {
+        for (int r = r0; r < nb; r += rstep) {
             const int oy = ob + r;
             float acc = 0.f;
             if (oy >= 0 && oy < p.Ho) {
@@ -175,74 +178,17 @@ __global__ __launch_bounds__(256) void bilinear_bwd_sep_k(const RsP p) {   // sr
             }
             tx[r * p.W + ix] = acc;
         }
-    }
-    __syncthreads();
-    for (int q = threadIdx.x; q < nrow * p.W; q += 256) {
-        const int il = q / p.W, ix = q - il * p.W;
-        const float* col = tx + (2 * il) * p.W + ix;
-        const float* wy = wyT + il * KT;
-        float acc = 0.f;
+        __syncthreads();
+        for (int il = r0; il < nrow; il += rstep) {               // same (row group, column) split as the x pass: no divisions
+            const float* col = tx + (2 * il) * p.W + ix;
+            const float* wy = wyT + il * KT;
+            float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < KT; ++k) acc += wy[k] * col[k * p.W];
-        float* dst = d + (size_t)(iy0 + il) * p.W + ix;
-        *dst = p.accumulate ? *dst + acc : acc;
-    }
-}
-
-// Same reduction with the band staged in LDS first: every dY row leaves HBM as whole aligned float4 (one contiguous 1 KB run per
-// wave instruction, each element fetched once) instead of three overlapping float2 per lane; the x pass then reads its three
-// pairs from LDS (consecutive lanes, consecutive 8-byte words: conflict free).  Needs 16-byte aligned rows (Wo % 4 == 0).
-__global__ __launch_bounds__(256) void bilinear_bwd_band_k(const RsP p) {  // src = dy (high res), dst = dx (low res)
-    __shared__ float wyT[LB * KT];
-    __shared__ __attribute__((aligned(16))) float raw[BROWS * (BWMAX + 4)];   // row = [2 zero floats | Wo values | 2 zero floats]
-    __shared__ float tx[BROWS * (BWMAX / 2)];
-    const int c = blockIdx.y, b = blockIdx.z, iy0 = blockIdx.x * LB;
-    const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
-    float* d = p.dst + ((size_t)b * p.CtotD + c) * p.H * p.W;
-    const int nrow = min(LB, p.H - iy0);
-    const int ob = 2 * iy0 - 2;
-    const int nb = 2 * nrow + KT - 2;
-    const int RS = p.Wo + 4;                                  // LDS row stride: the pairs left / right of the row are zeros
-    for (int e = threadIdx.x; e < nrow * KT; e += 256) {
-        const int i = e / KT, k = e - i * KT;
-        wyT[e] = tap_weight(2 * (iy0 + i) - 2 + k, p.Ho, p.sh, p.ac, p.H, iy0 + i);
-    }
-    const int o4 = p.Wo / 4;
-    for (int e = threadIdx.x; e < nb * (o4 + 1); e += 256) {
-        const int r = e / (o4 + 1), q = e - r * (o4 + 1), oy = ob + r;
-        if (q == o4) {                                        // the row's two border pairs
-            *reinterpret_cast<float2*>(raw + r * RS) = make_float2(0.f, 0.f);
-            *reinterpret_cast<float2*>(raw + r * RS + 2 + p.Wo) = make_float2(0.f, 0.f);
-        } else {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oy >= 0 && oy < p.Ho) v = *reinterpret_cast<const float4*>(s + (size_t)oy * p.Wo + 4 * q);
-            float* dst = raw + r * RS + 2 + 4 * q;            // 8-byte aligned (RS and the offset are even)
-            *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
-            *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+            for (int k = 0; k < KT; ++k) acc += wy[k] * col[k * p.W];
+            float* dst = d + (size_t)(iy0 + il) * p.W + ix;
+            *dst = p.accumulate ? *dst + acc : acc;
         }
-    }
-    __syncthreads();
-    {
-        const int ix = threadIdx.x % p.W, rstep = 256 / p.W;
-        float wx[KT];
-#pragma unroll
-        for (int k = 0; k < KT; ++k) wx[k] = tap_weight(2 * ix - 2 + k, p.Wo, p.sw, p.ac, p.W, ix);
-        for (int r = threadIdx.x / p.W; r < nb; r += rstep) {
-            const float2* row = reinterpret_cast<const float2*>(raw + r * RS + 2 * ix);      // high-res columns 2 ix - 2 .. 2 ix + 3
-            const float2 a = row[0], m = row[1], z = row[2];
-            tx[r * p.W + ix] = wx[0] * a.x + wx[1] * a.y + wx[2] * m.x + wx[3] * m.y + wx[4] * z.x + wx[5] * z.y;
-        }
-    }
-    __syncthreads();
-    for (int q = threadIdx.x; q < nrow * p.W; q += 256) {
-        const int il = q / p.W, ix = q - il * p.W;
-        const float* col = tx + (2 * il) * p.W + ix;
-        const float* wy = wyT + il * KT;
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < KT; ++k) acc += wy[k] * col[k * p.W];
-        float* dst = d + (size_t)(iy0 + il) * p.W + ix;
-        *dst = p.accumulate ? *dst + acc : acc;
+        __syncthreads();                                          // tx / wyT are rewritten by the next band
     }
 }
 
@@ -399,12 +345,8 @@ extern "C" int uz_bilinear2x_bwd(const float* dy, int C, int CtotDy, float* dx, 
     p.H = H; p.W = W; p.Ho = 2 * H; p.Wo = 2 * W; p.ac = align_corners; p.accumulate = accumulate; bil_scales(p);
     if (p.Wo <= BWMAX && p.H >= 4 && 256 % p.W == 0 && (reinterpret_cast<uintptr_t>(dy) & 7) == 0) {
         // Wo is even: an 8-byte aligned view keeps every float2 of every row aligned
-        static const bool band = !(getenv("UZ_BILINEAR_BWD_BAND") && atoi(getenv("UZ_BILINEAR_BWD_BAND")) == 0);
-        if (band && p.Wo % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && ((size_t)p.Ho * p.Wo) % 4 == 0) {
-            hipLaunchKernelGGL(bilinear_bwd_band_k, dim3(uz::ceil_div(H, LB), C, N), dim3(256), 0, uz::S(stream), p);
-            return uz::check_launch("bilinear_bwd_band_k");
-        }
-        hipLaunchKernelGGL(bilinear_bwd_sep_k, dim3(uz::ceil_div(H, LB), C, N), dim3(256), 0, uz::S(stream), p);
+        // enough planes to fill the chip: one workgroup per plane walks its bands (2.8 -> 3.3 TB/s on 192 ch 64^2 -> 128^2, 3.1 -> 3.75 on 32^2)
+        hipLaunchKernelGGL(bilinear_bwd_sep_k, dim3((long long)C * N >= 2048 ? 1 : uz::ceil_div(H, LB), C, N), dim3(256), 0, uz::S(stream), p);
         return uz::check_launch("bilinear_bwd_sep_k");
     }
     RS_LAUNCH(bilinear_bwd_k, H * W);
