@@ -149,6 +149,19 @@ int uz_bn_relu_fwd_pre(const float* y, int C, int CtotY, const float* gamma, con
                        float* a, int CtotA, int N, int H, int W, float eps, float momentum,
                        int training, int relu, float* a_amax, void* workspace,
                        const float* conv_partials, int n_partials, void* stream);
+/* Small planes (N*H*W <= 4096: the 8x8 ... 2x2 levels), where a Conv2D unit (torchlayers.py:7-29) is a chain of short launches:
+ * the convolution's split-K reduce folded into the BatchNorm.  uz_conv_splitk_parts() = number of partial-sum slabs the fp32 forward
+ * kernel produces for a shape when given its workspace (1: unsplit or another kernel family - not foldable); uz_conv_fwd_slabs runs
+ * that kernel only and leaves [parts][N][Cout][H*W] floats at the start of `workspace` (>= uz_conv_workspace()); uz_bn_relu_fwd_slabs
+ * then forms y = conv_bias + slabs (slab order: bit-identical to uz_conv_fwd), WRITES y (the backward pass reads it) and does what
+ * uz_bn_relu_fwd does.                                                                                                    */
+int uz_conv_splitk_parts(int Cin, int Cout, int N, int H, int W, int ks);
+int uz_conv_fwd_slabs(const float* x, int Cin, int CinTot, const float* w, int Cout, int N, int H, int W, int ks,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int uz_bn_relu_fwd_slabs(const float* slabs, int n_slabs, const float* conv_bias, float* y, int C, int CtotY,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, float* save_mean_rstd,
+                         float* a, int CtotA, int N, int H, int W, float eps, float momentum,
+                         int training, int relu, float* a_amax, void* stream);
 /* native_batch_norm_backward + threshold_backward: da -> dy, dgamma, dbeta, and the
  * conv-bias gradient dbias = sum dy (nullable).  dy may alias da.               */
 int uz_bn_relu_bwd(const float* da, int CtotDa,

@@ -210,6 +210,58 @@ def test_conv_with_fused_bn_statistics(N, Cin, Cout, H, W):
     assert g.relerr(save, save2) <= 2e-6
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks,training", [(32, 192, 192, 8, 8, 3, 1), (32, 192, 192, 4, 4, 3, 1), (32, 256, 256, 2, 2, 3, 1),
+                                                       (32, 2, 64, 4, 4, 3, 1), (32, 192, 192, 8, 8, 3, 0), (7, 70, 50, 5, 3, 3, 1)])
+def test_conv_reduce_folded_into_small_plane_batchnorm(N, Cin, Cout, H, W, ks, training):
+    """uz_conv_fwd_slabs + uz_bn_relu_fwd_slabs (the 8x8 ... 2x2 levels: the convolution's split-K reduce folded into the
+    one-workgroup-per-channel BatchNorm) == uz_conv_fwd + uz_bn_relu_fwd BIT FOR BIT (same slab order), and both == the torch unit
+    Conv2d -> BatchNorm2d -> ReLU (torchlayers.py:7-29); y views with foreign channels on both sides stay untouched."""
+    g = _g()
+    from unet_zoo_amd import _ffi
+    L = _ffi.lib()
+    parts = L.uz_conv_splitk_parts(Cin, Cout, N, H, W, ks)
+    if parts <= 1:
+        pytest.skip("this shape's chunk loop is not split on this build")
+    dev = g.dev()
+    x = g.rnd(N, Cin, H, W, seed=1)
+    w = g.rnd(Cout, Cin, ks, ks, seed=2, scale=0.1)
+    b = g.rnd(Cout, seed=3)
+    gamma, beta = g.rnd(Cout, seed=6).abs() + 0.5, g.rnd(Cout, seed=7) * 0.3
+    rm, rv = g.rnd(Cout, seed=8) * 0.1, g.rnd(Cout, seed=9).abs() + 0.5
+    yr = F.conv2d(x, w, b, padding=ks // 2)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    ar = F.relu(F.batch_norm(yr, rm_r, rv_r, gamma, beta, training=bool(training), momentum=0.01, eps=1e-3))
+    wsb = L.uz_conv_workspace(Cin, Cout, N, H, W, ks)
+    assert wsb >= parts * N * Cout * H * W * 4
+    xd, wd, bd, gd, btd = x.to(dev), w.to(dev), b.to(dev), gamma.to(dev), beta.to(dev)
+    out = {}
+    for folded in (0, 1):
+        ws = torch.full((wsb // 4 + 16,), float("nan"), device=dev)
+        ybuf = torch.full((N, Cout + 3, H, W), 7.0, device=dev)
+        yv = ybuf[:, 1:]
+        a = torch.empty(N, Cout, H, W, device=dev)
+        save = torch.zeros(2 * Cout, device=dev)
+        rmd, rvd = rm.to(dev), rv.to(dev)
+        slot = torch.zeros(256, device=dev)
+        if folded:
+            g.call("uz_conv_fwd_slabs", xd, Cin, Cin, wd, Cout, N, H, W, ks, ws, wsb)
+            assert bool((ybuf == 7.0).all()), "the slabs-only convolution must not touch y"
+            g.call("uz_bn_relu_fwd_slabs", ws, parts, bd, yv, Cout, Cout + 3, gd, btd, rmd, rvd, save, a, Cout, N, H, W, 1e-3, 0.01, training, 1, slot)
+        else:
+            bws = torch.empty(L.uz_bn_workspace(Cout, N, H, W) // 4 + 16, device=dev)
+            g.call("uz_conv_fwd", xd, Cin, Cin, wd, bd, yv, Cout, Cout + 3, N, H, W, ks, 0, None, None, None, ws, wsb)
+            g.call("uz_bn_relu_fwd", yv, Cout, Cout + 3, gd, btd, rmd, rvd, save, a, Cout, N, H, W, 1e-3, 0.01, training, 1, slot, bws)
+        assert bool((ybuf[:, 0] == 7.0).all()) and bool((ybuf[:, Cout + 1:] == 7.0).all())
+        out[folded] = (ybuf[:, 1:1 + Cout].clone(), a, save, rmd, rvd, slot.max())
+    for u, v in zip(out[0], out[1]):
+        assert torch.equal(u, v), "folded and stand-alone paths must agree bit for bit"
+    y, a = out[1][0], out[1][1]
+    assert g.relerr(y, yr) <= TOL
+    assert g.maxabs(a, ar) <= 3e-5 * max(1.0, float(ar.abs().max()))
+    if training:
+        assert g.maxabs(out[1][3], rm_r) <= 1e-6 and g.maxabs(out[1][4], rv_r) <= 1e-5
+
+
 def test_device_normal_stream_and_step_counters():
     """uz_randn_fill / uz_step_counters replace normal_() / index_add_ in the step (no ATen compute between the tape launches):
     standard normal moments, no repetition across launches, repeatable for a seed, ragged sizes, counters bumped exactly once."""

@@ -289,7 +289,7 @@ class Plan:
         self._bwd_tail.append(tail)
 
     # ------------------------------------------------------------------ convolution family
-    def _conv_fwd(self, x, wkey, bkey, y, ks, relu, wrow0=0, bn_partials=None):
+    def _conv_fwd(self, x, wkey, bkey, y, ks, relu, wrow0=0, bn_partials=None, slabs_only=False):
         cout = y.C
         cin = x.C
         if len(self.ptab.shape[wkey]) == 5 and x.nb is None:
@@ -320,7 +320,7 @@ class Plan:
         self._emit(self.target, "UZ_OP_CONV_FWD",
                    p=[x, self.P(wkey, wextra), self.P(bkey, wrow0) if bkey else None, y, ("scratch", "wgrad"),
                       self.amax_in(x), ("amax", 0), self.amax_out(y) if (relu and ks == 3) else None, packed, bn_partials],
-                   i=[cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, ks, relu], n=ws)
+                   i=[cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, ks, relu, int(slabs_only)], n=ws)
 
     def _conv_bwd(self, x, wkey, gy, ks, db_key=None, wrow0=0):
         """Weight gradient (+ optional bias gradient) and, when the input carries a gradient,
@@ -449,14 +449,22 @@ class Plan:
         if self.bn_training and x.nb is None and os.environ.get("UZ_BN_FUSE_STATS", "1") == "1" and x.N * x.H * x.W > 4096:
             npart = self.L.uz_conv_bn_partials(x.C, cout, x.N, x.H, x.W, ks)
         bnpart = self.vec(name + ":bnpart", 4 * cout * npart) if npart else None
-        self._conv_fwd(x, wkey, bkey, y, ks, 0, bn_partials=bnpart)
+        # Small planes (the 8x8 ... 2x2 levels: a unit is conv -> split-K reduce -> BatchNorm, 5 - 30 us each, on the step's critical
+        # chains): the convolution stops after its main kernel and the one-workgroup-per-channel BatchNorm adds the slabs itself -
+        # one launch and one pass over y less per unit, bit-identical values (include/uz_api.h: uz_conv_fwd_slabs)
+        nslab = 0
+        if x.nb is None and x.N * x.H * x.W <= 4096 and os.environ.get("UZ_BN_FOLD_REDUCE", "1") == "1":
+            nslab = self.L.uz_conv_splitk_parts(x.C, cout, x.N, x.H, x.W, ks)
+            nslab = nslab if nslab > 1 else 0
+        self._conv_fwd(x, wkey, bkey, y, ks, 0, bn_partials=bnpart, slabs_only=nslab > 0)
         bnws = self.L.uz_bn_workspace(cout, x.N, x.H, x.W)
         self.scratch["bn"] = max(self.scratch["bn"], bnws)
         gam, bet = bprefix + ".weight", bprefix + ".bias"
         self._emit(self.target, "UZ_OP_BN_RELU_FWD",
                    p=[y, self.P(gam), self.P(bet), self.B(bprefix + ".running_mean"), self.B(bprefix + ".running_var"),
-                      save, a, ("scratch", "bn"), self.amax_out(a), bnpart],
-                   i=[cout, y.Ctot, a.Ctot, x.N, x.H, x.W, int(self.bn_training), int(relu), npart], f=[BN_EPS, BN_MOMENTUM])
+                      save, a, ("scratch", "bn"), self.amax_out(a), bnpart,
+                      ("scratch", "wgrad") if nslab else None, (self.P(bkey) if bkey else None) if nslab else None],
+                   i=[cout, y.Ctot, a.Ctot, x.N, x.H, x.W, int(self.bn_training), int(relu), npart, nslab], f=[BN_EPS, BN_MOMENTUM])
 
         def bwd():
             if a_grad is None and not self._has_grad(a):

@@ -31,6 +31,7 @@ struct BnP {
     int training, relu;
     int pre;                                           // training statistics already in save[] (finalised from the convolution's partials)
     const float* cpart; int ncpart;                    // the producing convolution's per-tile partials {sum, sum sq, max, max(-y)} [ncpart][C]
+    const float* slab; int nslab; const float* cbias; float* ywr;     // small path: y := conv bias + sum of the split-K slabs (uz_bn_relu_fwd_slabs)
     float* amax;                                       // nullable: atomic max of |out| (bound for a following split-fp16 convolution)
 };
 
@@ -219,18 +220,53 @@ __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
 }
 
 // ------------------------------------------------------------------ forward, small path (one WG / channel)
+constexpr int EPT = SMALL_LIMIT / 256;      // elements per thread on the small path: a channel's whole batch lives in registers
 __global__ __launch_bounds__(256) void bn_fused_small_fwd(const BnP p) {
     __shared__ double sm[8];
     __shared__ float bc[2];
     const int c = blockIdx.x;
     const int total = p.N * p.HW;
+    // One trip to memory: the channel's N*HW <= 4096 values are loaded once (all loads of a thread in flight together), the
+    // statistics and the normalised output are formed from registers.  (Three dependent passes over global memory made this
+    // launch 8 - 14 us on the 8x8 ... 2x2 levels, whose chains are the step's exposed latency.)
+    float v[EPT];
+    int bq[EPT];                               // image index << 12 | pixel (both < 4096 here)
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        const int b = i / p.HW;
+        bq[j] = (b << 12) | (i - b * p.HW);
+    }
+    if (p.slab) {
+        // The producing convolution left its split-K partial sums [nslab][N][C][HW]: finish it here (bias + slabs in slab order =
+        // conv_splitk_reduce's arithmetic, bit for bit) instead of in a launch of its own; y is written for the backward pass.
+        const size_t n = (size_t)p.N * p.C * p.HW;
+        const float bv = p.cbias ? p.cbias[c] : 0.f;
+        const float* __restrict__ slab = p.slab;
+        float* __restrict__ ywr = p.ywr;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) v[j] = bv;
+        for (int k = 0; k < p.nslab; ++k) {
+            float t[EPT];
+#pragma unroll
+            for (int j = 0; j < EPT; ++j)
+                t[j] = threadIdx.x + 256 * j < total ? slab[(size_t)k * n + ((size_t)(bq[j] >> 12) * p.C + c) * p.HW + (bq[j] & 4095)] : 0.f;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) v[j] += t[j];
+        }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j)
+            if (threadIdx.x + 256 * j < total) ywr[((size_t)(bq[j] >> 12) * p.CtotY + c) * p.HW + (bq[j] & 4095)] = v[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j)
+            v[j] = threadIdx.x + 256 * j < total ? p.y[((size_t)(bq[j] >> 12) * p.CtotY + c) * p.HW + (bq[j] & 4095)] : 0.f;
+    }
     if (p.training) {
         double v2[2] = {0.0, 0.0};
-        for (int i = threadIdx.x; i < total; i += 256) {
-            const int b = i / p.HW, q = i - b * p.HW;
-            const double v = p.y[((size_t)b * p.CtotY + c) * p.HW + q];
-            v2[0] += v; v2[1] += v * v;
-        }
+#pragma unroll
+        for (int j = 0; j < EPT; ++j)
+            if (threadIdx.x + 256 * j < total) { const double d = v[j]; v2[0] += d; v2[1] += d * d; }
         uz::block_sum_d<2>(v2, sm);
         if (threadIdx.x == 0) {
             const double n = (double)total;
@@ -258,12 +294,13 @@ __global__ __launch_bounds__(256) void bn_fused_small_fwd(const BnP p) {
     }
     const float floor_ = p.relu ? 0.f : -INFINITY;
     float vmax = 0.f;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int b = i / p.HW, q = i - b * p.HW;
-        const float v = fmaxf(fmaf(p.y[((size_t)b * p.CtotY + c) * p.HW + q], alpha, beta_), floor_);
-        p.out[((size_t)b * p.CtotOut + c) * p.HW + q] = v;
-        vmax = fmaxf(vmax, fabsf(v));
-    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (threadIdx.x + 256 * j < total) {
+            const float r = fmaxf(fmaf(v[j], alpha, beta_), floor_);
+            p.out[((size_t)(bq[j] >> 12) * p.CtotOut + c) * p.HW + (bq[j] & 4095)] = r;
+            vmax = fmaxf(vmax, fabsf(r));
+        }
     if (p.amax) uz::amax_publish(vmax, p.amax);
 }
 
@@ -378,14 +415,30 @@ __global__ __launch_bounds__(256) void bn_fused_small_bwd(const BnP p) {
     const int total = p.N * p.HW;
     float alpha, beta_, mean, rstd;
     alpha_beta(p, c, alpha, beta_, mean, rstd);
+    // register-resident like the forward: y and da are read once
+    float dz[EPT], xh[EPT];
+    int bq[EPT];
     double v2[2] = {0.0, 0.0};
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int b = i / p.HW, q = i - b * p.HW;
-        const float yv = p.y[((size_t)b * p.CtotY + c) * p.HW + q];
-        const float dv = p.da[((size_t)b * p.CtotDa + c) * p.HW + q];
-        const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
-        v2[0] += dz; v2[1] += (double)(dz * ((yv - mean) * rstd));
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        const int b = i / p.HW;
+        bq[j] = (b << 12) | (i - b * p.HW);
     }
+    float yv[EPT], dv[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const bool ok = threadIdx.x + 256 * j < total;
+        yv[j] = ok ? p.y[((size_t)(bq[j] >> 12) * p.CtotY + c) * p.HW + (bq[j] & 4095)] : 0.f;
+        dv[j] = ok ? p.da[((size_t)(bq[j] >> 12) * p.CtotDa + c) * p.HW + (bq[j] & 4095)] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (threadIdx.x + 256 * j < total) {
+            dz[j] = (!p.relu || fmaf(yv[j], alpha, beta_) > 0.f) ? dv[j] : 0.f;
+            xh[j] = (yv[j] - mean) * rstd;
+            v2[0] += dz[j]; v2[1] += (double)(dz[j] * xh[j]);
+        }
     uz::block_sum_d<2>(v2, sm);
     if (threadIdx.x == 0) {
         if (p.dbeta) p.dbeta[c] = (float)v2[0];
@@ -396,16 +449,14 @@ __global__ __launch_bounds__(256) void bn_fused_small_bwd(const BnP p) {
     const float m1 = bc[0], m2 = bc[1];
     double sd[1] = {0.0};
     float vmax = 0.f;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int b = i / p.HW, q = i - b * p.HW;
-        const float yv = p.y[((size_t)b * p.CtotY + c) * p.HW + q];
-        const float dv = p.da[((size_t)b * p.CtotDa + c) * p.HW + q];
-        const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
-        const float r = alpha * (dz - m1 - ((yv - mean) * rstd) * m2);
-        p.out[((size_t)b * p.CtotOut + c) * p.HW + q] = r;
-        sd[0] += r;
-        vmax = fmaxf(vmax, fabsf(r));
-    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (threadIdx.x + 256 * j < total) {
+            const float r = alpha * (dz[j] - m1 - xh[j] * m2);
+            p.out[((size_t)(bq[j] >> 12) * p.CtotOut + c) * p.HW + (bq[j] & 4095)] = r;
+            sd[0] += r;
+            vmax = fmaxf(vmax, fabsf(r));
+        }
     if (p.amax) uz::amax_publish(vmax, p.amax);
     if (p.dbias) {
         uz::block_sum_d<1>(sd, sm);
@@ -489,11 +540,11 @@ extern "C" int uz_bn_relu_fwd(const float* y, int C, int CtotY, const float* gam
                               training, relu, a_amax, workspace, nullptr, 0, stream);
 }
 
-extern "C" int uz_bn_relu_fwd_pre(const float* y, int C, int CtotY, const float* gamma, const float* beta,
-                                  float* running_mean, float* running_var, float* save_mean_rstd,
-                                  float* a, int CtotA, int N, int H, int W, float eps, float momentum,
-                                  int training, int relu, float* a_amax, void* workspace,
-                                  const float* conv_partials, int n_partials, void* stream) {
+static int bn_relu_fwd_impl(const float* y, int C, int CtotY, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float* save_mean_rstd,
+                            float* a, int CtotA, int N, int H, int W, float eps, float momentum,
+                            int training, int relu, float* a_amax, void* workspace,
+                            const float* conv_partials, int n_partials, const float* slabs, int n_slabs, const float* conv_bias, void* stream) {
     UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_fwd: empty tensor");
     UZ_REQUIRE(!conv_partials || (training && n_partials > 0 && (size_t)N * H * W > SMALL_LIMIT), "bn_relu_fwd: convolution partials only serve the training-mode large-plane path");
     UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_fwd: N or C exceeds grid limits");
@@ -506,7 +557,9 @@ extern "C" int uz_bn_relu_fwd_pre(const float* y, int C, int CtotY, const float*
     p.out = a; p.C = C; p.CtotY = CtotY; p.CtotOut = CtotA; p.N = N; p.HW = H * W;
     p.parts = uz::ceil_div(p.HW, CHUNK);
     p.eps = eps; p.momentum = momentum; p.training = training; p.relu = relu; p.amax = a_amax;
+    UZ_REQUIRE(!slabs || (n_slabs > 1 && (size_t)N * p.HW <= SMALL_LIMIT), "bn_relu_fwd_slabs: split-K slabs only serve the small-plane path (N*H*W <= 4096)");
     if ((size_t)N * p.HW <= SMALL_LIMIT) {
+        p.slab = slabs; p.nslab = n_slabs; p.cbias = conv_bias; p.ywr = const_cast<float*>(y);
         hipLaunchKernelGGL(bn_fused_small_fwd, dim3(C), dim3(256), 0, st, p);
         return uz::check_launch("bn_fused_small_fwd");
     }
@@ -528,6 +581,26 @@ extern "C" int uz_bn_relu_fwd_pre(const float* y, int C, int CtotY, const float*
     if (vec) hipLaunchKernelGGL(bn_apply<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(bn_apply<false>, grid, dim3(256), 0, st, p);
     return uz::check_launch("bn_apply");
+}
+
+extern "C" int uz_bn_relu_fwd_pre(const float* y, int C, int CtotY, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float* save_mean_rstd,
+                                  float* a, int CtotA, int N, int H, int W, float eps, float momentum,
+                                  int training, int relu, float* a_amax, void* workspace,
+                                  const float* conv_partials, int n_partials, void* stream) {
+    return bn_relu_fwd_impl(y, C, CtotY, gamma, beta, running_mean, running_var, save_mean_rstd, a, CtotA, N, H, W, eps, momentum,
+                            training, relu, a_amax, workspace, conv_partials, n_partials, nullptr, 0, nullptr, stream);
+}
+// Conv2d (split-K, fp32 kernel) + BatchNorm + ReLU on the small planes with the convolution's reduce folded in: `slabs` are the
+// n_slabs partial-sum tensors [n_slabs][N][C][H*W] uz_conv_fwd_slabs left in its workspace, conv_bias the convolution's bias
+// (nullable); y (written here: conv output, read by the backward pass) = bias + slabs in order.  N*H*W <= 4096.
+extern "C" int uz_bn_relu_fwd_slabs(const float* slabs, int n_slabs, const float* conv_bias, float* y, int C, int CtotY,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var, float* save_mean_rstd,
+                                    float* a, int CtotA, int N, int H, int W, float eps, float momentum,
+                                    int training, int relu, float* a_amax, void* stream) {
+    UZ_REQUIRE(slabs && n_slabs > 1 && y, "bn_relu_fwd_slabs: needs at least two slabs and the output view");
+    return bn_relu_fwd_impl(y, C, CtotY, gamma, beta, running_mean, running_var, save_mean_rstd, a, CtotA, N, H, W, eps, momentum,
+                            training, relu, a_amax, nullptr, nullptr, 0, slabs, n_slabs, conv_bias, stream);
 }
 
 extern "C" int uz_bn_relu_bwd(const float* da, int CtotDa, const float* y, int C, int CtotY,

@@ -405,14 +405,38 @@ size_t conv_workspace(int Kc, int Mc, int N, int H, int W, int ks, int dgrad) {
     return ksplit > 1 ? (size_t)ksplit * N * Mc * H * W * sizeof(float) : 0;
 }
 
+// slabs_only: stop after the split-K main kernel and leave the partial sums [ksplit][N][Mc][HW] at the start of the workspace
+// (the caller's BatchNorm adds them, uz_bn_relu_fwd_slabs); only legal where conv_splitk_parts() > 1.
+static int conv_mfma_impl(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
+              float* y, int Mc, int McTot, int N, int H, int W, int ks, int dgrad, int relu, int accumulate,
+              const float* x_amax, const float* w_amax, float* y_amax,
+              void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials, hipStream_t st, bool slabs_only);
 int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
               float* y, int Mc, int McTot, int N, int H, int W, int ks, int dgrad, int relu, int accumulate,
               const float* x_amax, const float* w_amax, float* y_amax,
               void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials, hipStream_t st) {
+    return conv_mfma_impl(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, ks, dgrad, relu, accumulate, x_amax, w_amax, y_amax,
+                          workspace, workspace_bytes, packed_w, bn_partials, st, false);
+}
+// split count of the fp32 forward kernel for this shape when it is given its workspace (1: unsplit, or another kernel family)
+int conv_splitk_parts(int Kc, int Mc, int N, int H, int W, int ks) {
+    if (conv_split_ok(Kc, Mc, N, H, W, ks, 0)) return 1;
+    const Geom g = pick_geom(N, H, W, ks / 2);
+    const long long tiles = (long long)g.tilesX * g.tilesY * g.tilesB;
+    const int msub = pick_msub(Mc, tiles, ceil_div(Kc, CK));
+    int ksplit, cps;
+    pick_split(tiles * ceil_div(Mc, 32 * msub), ceil_div(Kc, CK), msub, ks * ks, (double)N * Mc * H * W * sizeof(float), ksplit, cps);
+    return ksplit;
+}
+static int conv_mfma_impl(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
+              float* y, int Mc, int McTot, int N, int H, int W, int ks, int dgrad, int relu, int accumulate,
+              const float* x_amax, const float* w_amax, float* y_amax,
+              void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials, hipStream_t st, bool slabs_only) {
     UZ_REQUIRE(ks == 1 || ks == 3, "conv: kernel size %d unsupported (1 or 3)", ks);
     UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Kc > 0 && Mc > 0, "conv: empty tensor");
     UZ_REQUIRE(H <= 4096 && W <= 4096, "conv: spatial size too large");
     // large 3x3 layers: split-bf16 matrix pipe (conv_split.hip); its packed weight image lives in the workspace
+    UZ_REQUIRE(!slabs_only || (!dgrad && !conv_split_ok(Kc, Mc, N, H, W, ks, 0)), "conv_fwd_slabs: this shape does not run the split-K fp32 kernel");
     if (conv_split_ok(Kc, Mc, N, H, W, ks, dgrad) && workspace && workspace_bytes >= conv_split_workspace(Kc, Mc, N, H, W))
         return conv_split(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, dgrad, relu, accumulate, x_amax, w_amax, y_amax, workspace, packed_w, bn_partials, st);
     UZ_REQUIRE(!packed_w, "conv: a pre-packed weight image was supplied for a layer that does not take the split path");
@@ -436,6 +460,7 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     pick_split(base_grid, ceil_div(Kc, CK), msub, kk, (double)N * Mc * H * W * sizeof(float), p.ksplit, p.cps);
     const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * N * Mc * H * W * sizeof(float) : 0;
     if (p.ksplit > 1 && (!workspace || workspace_bytes < need)) { p.ksplit = 1; p.cps = ceil_div(Kc, CK); }   // no workspace: stay unsplit
+    UZ_REQUIRE(!slabs_only || p.ksplit > 1, "conv_fwd_slabs: the chunk loop of this shape is not split (uz_conv_splitk_parts() == 1) or the workspace is too small");
     p.slab = static_cast<float*>(workspace);
     if (p.ksplit > 1) p.y_amax = nullptr;               // split-K: the reduce kernel sees the final values
     const long long grid = base_grid * p.ksplit;
@@ -443,11 +468,24 @@ int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const 
     int rc;
     if (ks == 3) rc = dgrad ? launch_ks<3, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<3, false>(p, msub, jmax, (int)grid, smem, st);
     else rc = dgrad ? launch_ks<1, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<1, false>(p, msub, jmax, (int)grid, smem, st);
-    if (rc || p.ksplit == 1) return rc;
+    if (rc || p.ksplit == 1 || slabs_only) return rc;
     return splitk_reduce(p.slab, p.ksplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax, st);
 }
 
 }  // namespace uz
+
+extern "C" int uz_conv_splitk_parts(int Cin, int Cout, int N, int H, int W, int ks) {
+    if ((ks != 1 && ks != 3) || Cin <= 0 || Cout <= 0 || N <= 0 || H <= 0 || W <= 0) return 1;
+    if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) return 1;
+    if (conv_thin_ok(Cin, Cout, N, H, W, ks)) return 1;
+    return uz::conv_splitk_parts(Cin, Cout, N, H, W, ks);
+}
+extern "C" int uz_conv_fwd_slabs(const float* x, int Cin, int CinTot, const float* w, int Cout, int N, int H, int W, int ks,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    UZ_REQUIRE(uz_conv_splitk_parts(Cin, Cout, N, H, W, ks) > 1, "conv_fwd_slabs: uz_conv_splitk_parts() == 1 for this shape");
+    return uz::conv_mfma_impl(x, Cin, CinTot, w, Cin, nullptr, nullptr, Cout, Cout, N, H, W, ks, 0, 0, 0, nullptr, nullptr, nullptr,
+                              workspace, workspace_bytes, nullptr, nullptr, uz::S(stream), true);
+}
 
 extern "C" size_t uz_conv_workspace(int Cin, int Cout, int N, int H, int W, int ks) {
     const size_t a = uz::conv_workspace(Cin, Cout, N, H, W, ks, 0), b = uz::conv_workspace(Cout, Cin, N, H, W, ks, 1);

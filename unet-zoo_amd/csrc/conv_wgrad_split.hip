@@ -207,9 +207,9 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         if (NP == 2 && p.flags && t < p.T) {            // bound check on the first tile (the clamp in split2 covers every tile)
             bool bx = false, bd = false;
 #pragma unroll
-            for (int i = 0; i < DYSLOTS; ++i) bd |= uz::bound_violated(dreg[i][0] * sdy, dreg[i][1] * sdy) | uz::bound_violated(dreg[i][2] * sdy, dreg[i][3] * sdy);
+            for (int i = 0; i < DYSLOTS; ++i) { bd |= uz::bound_violated(dreg[i][0] * sdy, dreg[i][1] * sdy); bd |= uz::bound_violated(dreg[i][2] * sdy, dreg[i][3] * sdy); }
 #pragma unroll
-            for (int i = 0; i < XQSLOTS; ++i) bx |= uz::bound_violated(xq[i][0] * sx, xq[i][1] * sx) | uz::bound_violated(xq[i][2] * sx, xq[i][3] * sx);
+            for (int i = 0; i < XQSLOTS; ++i) { bx |= uz::bound_violated(xq[i][0] * sx, xq[i][1] * sx); bx |= uz::bound_violated(xq[i][2] * sx, xq[i][3] * sx); }
             if (bd) atomicOr(p.flags, uz::FLAG_DY_BOUND);
             if (bx) atomicOr(p.flags, uz::FLAG_X_BOUND);
         }

@@ -71,12 +71,14 @@ static int run_one(const uz_op& o, void* st) {
 #define CFP(k) static_cast<const float*>(p[k])
     switch (o.code) {
         case UZ_OP_CONV_FWD:
+            if (i[9]) return uz_conv_fwd_slabs(CFP(0), i[0], i[1], CFP(1), i[2], i[4], i[5], i[6], i[7], p[4], (size_t)o.n, st);      // the unit's BatchNorm adds the slabs
             return uz_conv_fwd_bnstats(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(5), CFP(6), FP(7), p[4], (size_t)o.n, p[8], FP(9), st);
         case UZ_OP_CONV_BWD_DATA:
             return uz_conv_bwd_data_packed(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], st);
         case UZ_OP_CONV_BWD_WEIGHT:
             return uz_conv_bwd_weight(CFP(0), i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], i[7], CFP(5), CFP(6), p[4], (size_t)o.n, st);
         case UZ_OP_BN_RELU_FWD:
+            if (i[9] > 1) return uz_bn_relu_fwd_slabs(CFP(10), i[9], CFP(11), FP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], FP(8), st);
             return uz_bn_relu_fwd_pre(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], FP(8), p[7], CFP(9), i[8], st);
         case UZ_OP_BN_RELU_BWD:
             return uz_bn_relu_bwd(CFP(0), i[0], CFP(1), i[1], i[2], CFP(2), CFP(3), CFP(4), FP(5), i[3], FP(6), FP(7), FP(8), i[4], i[5], i[6], i[7], FP(10), p[9], st);
