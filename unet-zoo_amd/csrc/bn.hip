@@ -10,6 +10,7 @@
 //    second read of the <= 32 KB channel comes from L1/L2).
 // Statistics are accumulated in fp64 so that E[y^2]-E[y]^2 carries no cancellation error into the
 // 30+ stacked normalisations of PHiSeg.
+#include <type_traits>
 #include "uz_common.h"
 #include "split_f16.h"
 
@@ -246,14 +247,35 @@ __global__ __launch_bounds__(256) void bn_fused_small_fwd(const BnP p) {
         float* __restrict__ ywr = p.ywr;
 #pragma unroll
         for (int j = 0; j < EPT; ++j) v[j] = bv;
-        for (int k = 0; k < p.nslab; ++k) {
-            float t[EPT];
+        // four slabs' loads in flight per round (the rounds are dependent trips to L2 / HBM: 12 slabs one at a time made this launch
+        // 20 us); added in slab order.  E = elements per thread in use, as a compile-time bound (8 / 2 / 1 on 8x8 / 4x4 / 2x2 at batch 32)
+        auto add_slabs = [&](auto Ec) {
+            constexpr int E = decltype(Ec)::value, U = E <= 8 ? 4 : 1;
+            int k = 0;
+            for (; k + U <= p.nslab; k += U) {
+                float t[U][E];
 #pragma unroll
-            for (int j = 0; j < EPT; ++j)
-                t[j] = threadIdx.x + 256 * j < total ? slab[(size_t)k * n + ((size_t)(bq[j] >> 12) * p.C + c) * p.HW + (bq[j] & 4095)] : 0.f;
+                for (int kk = 0; kk < U; ++kk)
 #pragma unroll
-            for (int j = 0; j < EPT; ++j) v[j] += t[j];
-        }
+                    for (int j = 0; j < E; ++j)
+                        t[kk][j] = threadIdx.x + 256 * j < total ? slab[(size_t)(k + kk) * n + ((size_t)(bq[j] >> 12) * p.C + c) * p.HW + (bq[j] & 4095)] : 0.f;
+#pragma unroll
+                for (int kk = 0; kk < U; ++kk)
+#pragma unroll
+                    for (int j = 0; j < E; ++j) v[j] += t[kk][j];
+            }
+            for (; k < p.nslab; ++k) {
+                float t[E];
+#pragma unroll
+                for (int j = 0; j < E; ++j)
+                    t[j] = threadIdx.x + 256 * j < total ? slab[(size_t)k * n + ((size_t)(bq[j] >> 12) * p.C + c) * p.HW + (bq[j] & 4095)] : 0.f;
+#pragma unroll
+                for (int j = 0; j < E; ++j) v[j] += t[j];
+            }
+        };
+        if (total <= 2 * 256) add_slabs(std::integral_constant<int, 2>{});
+        else if (total <= 8 * 256) add_slabs(std::integral_constant<int, 8>{});
+        else add_slabs(std::integral_constant<int, EPT>{});
 #pragma unroll
         for (int j = 0; j < EPT; ++j)
             if (threadIdx.x + 256 * j < total) ywr[((size_t)(bq[j] >> 12) * p.CtotY + c) * p.HW + (bq[j] & 4095)] = v[j];
