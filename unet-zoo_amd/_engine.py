@@ -112,12 +112,14 @@ class NativeModel(nn.Module):
     # chains no longer carry the weight gradients), Probabilistic U-Net 11.33 -> 11.66 ms (three lanes already interleave its
     # chains) - so it is a per-model default.
     decouple_wgrad_px = 0
+    decouple_wgrad_prefixes = ()      # sub-networks (parameter-name prefixes) whose weight gradients are decoupled at every size
 
     def _new_plan(self, N, bn_training):
         plan = Plan(N, self._ptab, bn_training, self.device)
         if "UZ_LANES" not in os.environ:
             plan.n_lanes = self.default_lanes
         plan.decouple_wgrad_px = self.decouple_wgrad_px
+        plan.decouple_wgrad_prefixes = tuple(self.decouple_wgrad_prefixes)
         dp = getattr(self, "_dp", None)
         if dp is not None and dp.overlap:
             plan.grad_buckets = list(dp.buckets)

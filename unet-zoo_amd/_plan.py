@@ -165,6 +165,7 @@ class Plan:
         self._gyz = {}                       # zero-bordered dy scratch classes of volume units: (slices, floats per slice) -> floats
         self.n_lanes = max(1, min(int(os.environ.get("UZ_LANES", "2")), 8))
         self.decouple_wgrad_px = 0           # NativeModel.decouple_wgrad_px: planes (N*H*W) up to which weight gradients get a group of their own
+        self.decouple_wgrad_prefixes = ()    # NativeModel.decouple_wgrad_prefixes
 
     def _newgroup(self):
         self._gid += 1
@@ -420,11 +421,17 @@ class Plan:
         self.__dict__.setdefault("_win_of", {})[wkey] = xc
         return xc
 
-    def _decouple_wgrad(self, x, ks):
+    def _decouple_wgrad(self, x, ks, name=""):
         """Weight gradient as a scheduling group of its own (needs dy in a real buffer instead of the lane scratch): on the
-        latency-bound planes only - at and above 32 x 32 (batch 32) every kernel of a layer's backward fills the chip anyway."""
+        latency-bound planes (decouple_wgrad_px) and in the sub-networks named by decouple_wgrad_prefixes - chains whose backward
+        has no independent partner chain for the second lane, so the weight gradient of layer L runs beside BatchNorm backward +
+        data gradient of layer L - 1 (PHiSeg's likelihood: +1 %; its posterior / prior nets: -0.5 ... -1 %, they already pair up)."""
+        if x.nb is not None or ks != 3 or self.n_lanes <= 1 or self.__dict__.get("_in_rev", False):
+            return False
         lim = int(os.environ.get("UZ_DECOUPLE_WGRAD", str(self.decouple_wgrad_px)))
-        return x.nb is None and ks == 3 and self.n_lanes > 1 and x.N * x.H * x.W <= lim and not self.__dict__.get("_in_rev", False)
+        pref = os.environ.get("UZ_DECOUPLE_PREFIX")
+        pref = tuple(q for q in pref.split(",") if q) if pref is not None else tuple(self.__dict__.get("decouple_wgrad_prefixes", ()))
+        return x.N * x.H * x.W <= lim or any(name.startswith(q) for q in pref)
 
     def _gy_scratch(self, like):
         self.scratch["gy"] = max(self.scratch["gy"], like.N * like.C * like.H * like.W)
@@ -473,7 +480,7 @@ class Plan:
                 raise RuntimeError("backward through eval-mode BatchNorm is not supported")
             gy = self._gy_scratch(y)
             gyv = _ScratchView(y.N, cout, y.H, y.W, amax=self._new_amax(bwd=True))
-            if self._decouple_wgrad(x, ks) and ybuf is None and a_grad is None:
+            if self._decouple_wgrad(x, ks, cprefix) and ybuf is None and a_grad is None:
                 gyv.view = self.buf(name + ":dy", cout, y.H, y.W, N=y.N, requires_grad=False)
                 gy = gyv
             if x.nb is not None and ks == 3:
