@@ -321,16 +321,28 @@ def launch_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UZ_BENCH_SELF_LAUNCHED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    for q in procs[1:]:
-        try:
-            rcs.append(q.wait(timeout=120))
-        except subprocess.TimeoutExpired:           # rank 0 is gone: a peer still waiting in a collective will never finish
-            q.kill()
-            rcs.append(q.wait())
-    sys.stdout.write(out)
+    # rank 0's stdout is drained by a thread while every rank is watched: a rank that dies (RCCL init, out of memory) leaves its
+    # peers waiting in a collective forever - then the survivors are killed and the failure is reported instead of a hang
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(q.poll() is None for q in procs):
+        for r, q in enumerate(procs):
+            if q.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.2)
+    if failed is not None:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    rcs = [q.wait() for q in procs]
+    reader.join(timeout=10)
+    sys.stdout.write("".join(c for c in chunks if c))
     sys.stdout.flush()
+    if failed is not None:
+        print(f"bench.py: rank {failed} exited with code {rcs[failed]}; the other ranks were stopped", file=sys.stderr)
     return max(abs(rc) for rc in rcs)
 
 
@@ -339,6 +351,8 @@ def dry_run(args, rank, world, global_batch):
     with a sleep in place of the training step - checks that `--gpus N` really runs N ranks and reports that number."""
     import torch
     import torch.distributed as dist
+    if os.environ.get("UZ_BENCH_DRY_FAIL_RANK") == str(rank):      # test hook: a rank that dies before the rendezvous
+        sys.exit(3)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -164,3 +164,19 @@ def test_bench_refuses_a_gpu_count_that_is_not_the_world_size():
     env = dict(os.environ, UZ_BENCH_DRY="1", WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_launcher_stops_the_survivors_when_a_rank_dies():
+    """A rank that exits before the rendezvous would leave rank 0 waiting for it forever: the self-launcher must notice, stop the
+    other ranks and fail (non-zero exit, message on stderr) instead of hanging until the driver's timeout."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(UZ_BENCH_DRY="1", UZ_BENCH_DRY_FAIL_RANK="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "rank 1 exited with code 3" in r.stderr, (r.returncode, r.stderr[-400:])
+    assert time.time() - t0 < 200
