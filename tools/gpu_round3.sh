@@ -23,3 +23,4 @@ F=$(ls gpurun_out/kt_graph/*/*kernel_trace.csv | head -1)
 python tools/timeline.py $F gpurun_out/r3_timeline_graph.json | head -20
 gzip -c $F > gpurun_out/r3_kernel_trace_graph.csv.gz; rm -rf gpurun_out/kt_graph
 bash tools/prof_layers.sh 3 20 20 > gpurun_out/prof_layers.log 2>&1; tail -24 gpurun_out/prof_layers.log | cut -c1-230
+python tools/soak_train.py 300 > gpurun_out/r3_soak_300_steps.log 2>&1; tail -3 gpurun_out/r3_soak_300_steps.log
