@@ -41,6 +41,8 @@ CONV_CASES = [
     (4, 3, 32, 128, 128, 3),      # first layer of the posterior (image + 2-label one-hot): thin-input weight gradient
     (16, 1, 40, 64, 64, 3),       # ... one input channel, two output-channel tiles (the second ragged)
     (33, 4, 32, 64, 32, 3),       # ... four input channels, 32-wide planes, odd batch
+    (40, 72, 80, 24, 28, 3),      # 16 x 16-pixel geometry UNSPLIT (>= 160 tiles: unconditional staging past the last chunk), K tail of 8, ragged tiles
+    (3, 72, 80, 24, 28, 3),       # ... the same layer with 36 tiles: chunk loop split over workgroups (slabs + ordered reduce)
 ]
 
 
