@@ -555,7 +555,10 @@ bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks, int /*dgrad: sam
     }
     if (W >= 16 && H >= 16 && Kc >= 32 && Mc >= 32) {       // 16 x 16 tiles, 32 output channels per workgroup, two workgroups per CU
         const long long grid = (long long)N * ((H + TH - 1) / TH) * ((W + 15) / 16) * ((Mc + 31) / 32);
-        return grid >= 128;
+        // 40 tiles (was 128): with the chunk loop shared out over up to four workgroups even 48 tiles beat the fp32 kernel 2x
+        // (576 -> 192 @ 8 x 16 x 16: 62 -> 33 us); PHiSeg at 8 / 16 images per GPU +3 % / +1.4 %, batch 32 unchanged (192 tiles)
+        static const int gmin16 = getenv("UZ_SPLIT16_GRID") ? atoi(getenv("UZ_SPLIT16_GRID")) : 40;
+        return grid >= gmin16;
     }
     return false;
 }
