@@ -549,7 +549,9 @@ bool conv_split_ok(int Kc, int Mc, int N, int H, int W, int ks, int /*dgrad: sam
     if (!small_geo(W)) {
         // fewer than 32 output channels only on big tensors (the 2-channel latent gradients of a volume: a 32-wide tile that is 6 % full
         // still beats the fp32 pipe 3x there: 0.96 -> 0.3 ms at 192 -> 2 @ 128 x 128 x 64)
-        if (H < 16 || Kc < 16 || (Mc < 32 && (long long)N * H * W < 262144)) return false;
+        // fewer than 16 input channels (one zero-padded chunk) likewise on big tensors only: 12 -> 32 @ 128 x 128 x 64 forward 132 -> 44 us
+        static const int kcmin = getenv("UZ_SPLIT_KCMIN") ? atoi(getenv("UZ_SPLIT_KCMIN")) : 5;
+        if (H < 16 || (Kc < 16 && (Kc < kcmin || (long long)N * H * W < 262144)) || (Mc < 32 && (long long)N * H * W < 262144)) return false;
         const long long grid = (long long)N * ((H + TH - 1) / TH) * ((W + 31) / 32) * ((Mc + 63) / 64);
         return grid >= min_grid;
     }

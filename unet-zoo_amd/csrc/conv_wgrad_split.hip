@@ -338,7 +338,12 @@ bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks) {
     const int lo = Cin < Cout ? Cin : Cout;
     // 64-channel tiles when both sides have them; 32-channel tiles when one side is narrow (32 -> 32, and the decoder's
     // 96 -> 32 at full resolution: 3 ci tiles - the fp32 kernel ran that layer at 79 TF/s)
-    return (Cin >= 64 && Cout >= 64 && px >= 8 * 1024) || (lo <= 32 && lo >= 16 && px >= 128 * 1024);
+    // late round 3 (the volume path's shapes): 64-channel tiles from 2 048 pixels on (768 -> 256 @ 8 x 16 x 16: 99 -> 35 us) and, on
+    // tensors of >= 512 k pixels, a narrow side down to 5 channels (the depth window of the 4-channel image / 2-channel latent input:
+    // 12 -> 32 and 6 -> 64 @ 128 x 128 x 64: 227 -> 69 and 376 -> 118 us; a 32-wide tile a fifth full still beats the fp32 pipe)
+    static const int pxmin = getenv("UZ_WGS_PXMIN") ? atoi(getenv("UZ_WGS_PXMIN")) : 2 * 1024;
+    static const int lomin = getenv("UZ_WGS_LOMIN") ? atoi(getenv("UZ_WGS_LOMIN")) : 5;
+    return (Cin >= 64 && Cout >= 64 && px >= pxmin) || (lo <= 32 && lo >= 16 && px >= 128 * 1024) || (lo < 16 && lo >= lomin && px >= 512 * 1024);
 }
 
 static inline int tile_w(int W) { return W == 16 ? 16 : 32; }
