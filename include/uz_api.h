@@ -222,6 +222,10 @@ int uz_latent_sample_bwd(const float* dmu, const float* dsigma, const float* dz,
  * fwd writes loss_out[0] (single block, ordered); bwd writes the four gradients * scale. */
 int uz_kl_fwd(const float* mu0, const float* s0, const float* mu1, const float* s1,
               int N, int per_sample, float weight, float* loss_out, void* stream);
+/* uz_kl_fwd with a scratch of >= 512 bytes (nullable): tensors beyond 128 k elements (a volume's full-resolution latent level is ONE
+ * sample of 2 M elements) are summed by up to 64 workgroups + an ordered final pass instead of one workgroup. */
+int uz_kl_fwd_ws(const float* mu0, const float* s0, const float* mu1, const float* s1, int N, int per_sample, float weight,
+                 float* loss_out, void* workspace, void* stream);
 int uz_kl_bwd(const float* mu0, const float* s0, const float* mu1, const float* s1,
               int N, int per_sample, float weight, const float* loss_scale,
               float* dmu0, float* ds0, float* dmu1, float* ds1, void* stream);

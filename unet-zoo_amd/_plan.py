@@ -835,7 +835,8 @@ class Plan:
         if q.mu.nb is not None:                                 # volume: ONE sample whose depth slices are stored as the batch
             n, per = 1, q.mu.N * per
         self._newgroup()
-        self._emit(self.target, "UZ_OP_KL_FWD", p=[q.mu, q.sigma, p.mu, p.sigma, term], i=[n, per], f=[weight])
+        self.scratch["bn"] = max(self.scratch["bn"], 512)
+        self._emit(self.target, "UZ_OP_KL_FWD", p=[q.mu, q.sigma, p.mu, p.sigma, term, ("scratch", "bn")], i=[n, per], f=[weight])
 
         def bwd():
             for lat, tag in ((q, "q"), (p, "p")):

@@ -103,6 +103,35 @@ __global__ __launch_bounds__(1024) void kl_fwd_k(const float* __restrict__ mu0, 
         out[0] = (float)((double)weight * 0.5 * s / N);
     }
 }
+// Large tensors (a volume's full-resolution latent level: 2 M elements in ONE sample - 1.3 ms in the single workgroup above): the
+// same ordered fp64 sum in two stages - G workgroups over fixed contiguous ranges, then one thread over the G partials.
+__global__ __launch_bounds__(1024) void kl_fwd_part_k(const float* __restrict__ mu0, const float* __restrict__ s0, const float* __restrict__ mu1,
+                                                       const float* __restrict__ s1, int total, int chunk, double* __restrict__ part) {
+    __shared__ double sm[16];
+    const int lo = blockIdx.x * chunk, hi = min(total, lo + chunk);
+    double v = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+        const float a0 = s0[i], a1 = s1[i];
+        const float s0fs = a0 * a0, s1fs = a1 * a0;
+        const float d = mu1[i] - mu0[i];
+        v += (s0fs + d * d) / (s1fs + 1e-10f) + logf(s1fs + 1e-10f) - logf(s0fs + 1e-10f) - 1.f;
+    }
+    v = uz::wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += sm[w];
+        part[blockIdx.x] = s;
+    }
+}
+__global__ __launch_bounds__(64) void kl_fwd_final_k(const double* __restrict__ part, int G, int N, float weight, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int g = 0; g < G; ++g) s += part[g];
+        out[0] = (float)((double)weight * 0.5 * s / N);
+    }
+}
 __global__ __launch_bounds__(256) void kl_bwd_k(const float* __restrict__ mu0, const float* __restrict__ s0, const float* __restrict__ mu1,
                                                  const float* __restrict__ s1, int total, float k, const float* __restrict__ scale,
                                                  float* __restrict__ dmu0, float* __restrict__ ds0, float* __restrict__ dmu1, float* __restrict__ ds1) {
@@ -163,12 +192,15 @@ __global__ __launch_bounds__(256) void ce_fwd_k(const CeP p) {
         for (int l = 0; l < MAXL; ++l) o[l] = acc_l[l];
     }
 }
-__global__ __launch_bounds__(64) void ce_finalize_k(const CeP p) {
-    const int l = threadIdx.x;
+// one wave per level: lane j adds partials j, j + 64, ... in order, then a fixed butterfly (a volume has 4 096 partials per level:
+// the former one-thread-per-level loop took 150 us of the loss tape)
+__global__ __launch_bounds__(64 * MAXL) void ce_finalize_k(const CeP p) {
+    const int l = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (l >= p.L) return;
     double s = 0.0;
-    for (int i = 0; i < p.nblk; ++i) s += p.part[(size_t)i * MAXL + l];
-    p.out[l] = (float)(s / p.N);
+    for (int i = lane; i < p.nblk; i += 64) s += p.part[(size_t)i * MAXL + l];
+    s = uz::wave_sum_d(s);
+    if (lane == 0) p.out[l] = (float)(s / p.N);
 }
 template <int K>
 __global__ __launch_bounds__(256) void ce_bwd_k(const CeP p) {
@@ -344,6 +376,22 @@ extern "C" int uz_kl_fwd(const float* mu0, const float* s0, const float* mu1, co
     hipLaunchKernelGGL(kl_fwd_k, dim3(1), dim3(1024), 0, uz::S(stream), mu0, s0, mu1, s1, N * per_sample, N, weight, loss_out);
     return uz::check_launch("kl_fwd_k");
 }
+extern "C" int uz_kl_fwd_ws(const float* mu0, const float* s0, const float* mu1, const float* s1, int N, int per_sample, float weight,
+                            float* loss_out, void* workspace, void* stream) {
+    UZ_REQUIRE(N > 0 && per_sample > 0, "kl_fwd: empty tensor");
+    const long long total = (long long)N * per_sample;
+    UZ_REQUIRE(total < (1ll << 31), "kl_fwd: tensor too large");
+    if (!workspace || total <= 131072) return uz_kl_fwd(mu0, s0, mu1, s1, N, per_sample, weight, loss_out, stream);
+    const int chunk = 65536;
+    int G = (int)((total + chunk - 1) / chunk);
+    const int ck = G > 64 ? (int)(((total + 63) / 64 + 1023) / 1024 * 1024) : chunk;      // at most 64 partials (512 bytes of workspace)
+    G = (int)((total + ck - 1) / ck);
+    double* part = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(kl_fwd_part_k, dim3(G), dim3(1024), 0, uz::S(stream), mu0, s0, mu1, s1, (int)total, ck, part);
+    if (int rc = uz::check_launch("kl_fwd_part_k")) return rc;
+    hipLaunchKernelGGL(kl_fwd_final_k, dim3(1), dim3(64), 0, uz::S(stream), part, G, N, weight, loss_out);
+    return uz::check_launch("kl_fwd_final_k");
+}
 extern "C" int uz_kl_bwd(const float* mu0, const float* s0, const float* mu1, const float* s1, int N, int per_sample, float weight,
                          const float* loss_scale, float* dmu0, float* ds0, float* dmu1, float* ds1, void* stream) {
     UZ_REQUIRE(N > 0 && per_sample > 0, "kl_bwd: empty tensor");
@@ -372,7 +420,7 @@ extern "C" int uz_residual_ce_fwd(const float* const* s_ptrs, int L, int K, cons
     else if (K == 3) hipLaunchKernelGGL(ce_fwd_k<3>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(ce_fwd_k<4>, grid, dim3(256), 0, st, p);
     if (int rc = uz::check_launch("ce_fwd_k")) return rc;
-    hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(64 * MAXL), 0, st, p);
     return uz::check_launch("ce_finalize_k");
 }
 extern "C" int uz_residual_ce_bwd(const float* const* s_ptrs, float* const* ds_ptrs, int L, int K, const float* mask, int N, int H, int W,

@@ -107,7 +107,7 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_LATENT_BWD:
             return uz_latent_sample_bwd(CFP(0), CFP(1), CFP(2), CFP(3), CFP(4), FP(5), FP(6), (size_t)o.n, i[0], st);
         case UZ_OP_KL_FWD:
-            return uz_kl_fwd(CFP(0), CFP(1), CFP(2), CFP(3), i[0], i[1], f[0], FP(4), st);
+            return uz_kl_fwd_ws(CFP(0), CFP(1), CFP(2), CFP(3), i[0], i[1], f[0], FP(4), p[5], st);
         case UZ_OP_KL_BWD:
             return uz_kl_bwd(CFP(0), CFP(1), CFP(2), CFP(3), i[0], i[1], f[0], CFP(4), FP(5), FP(6), FP(7), FP(8), st);
         case UZ_OP_CE_FWD:
