@@ -241,8 +241,14 @@ class Plan:
         return all(any(a <= c < b for a, b in regs) for c in range(v.c0, v.c0 + v.C))
 
     # ------------------------------------------------------------------ op emission
-    def _emit(self, lst, code, p=(), i=(), f=(), n=0):
-        lst.append(dict(code=code, p=list(p), i=[int(x) for x in i], f=[float(x) for x in f], n=int(n), gid=self._gid))
+    def _emit(self, lst, code, p=(), i=(), f=(), n=0, detached=False):
+        """detached: a scheduling group of its own, whatever is emitted around it (parameter-only preparation ops: they are ready at
+        the head of the tape and must not sit in a layer's chain)."""
+        gid = self._gid
+        if detached:
+            self._detached = getattr(self, "_detached", 0) + 1
+            gid = ("detached", self._detached)
+        lst.append(dict(code=code, p=list(p), i=[int(x) for x in i], f=[float(x) for x in f], n=int(n), gid=gid))
 
     def P(self, key, extra=0):
         return ("param", key, extra)
@@ -307,7 +313,7 @@ class Plan:
             wp = self.P(wkey)                                  # (unused by the kernel when the image is pre-packed)
             if packed is None:
                 wp = self.vec(wkey + ":w3d_fwd", cout * cin * 27)
-                self._emit(self.target, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp], i=[cout, cin, 0])
+                self._emit(self.target, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp], i=[cout, cin, 0], detached=True)
             self._emit(self.target, "UZ_OP_CONV_FWD",
                        p=[("win", x), wp, self.P(bkey) if bkey else None, y, ("scratch", "wgrad"), self.amax_in(x), ("amax", 0),
                           self.amax_out(y) if relu else None, packed],
@@ -346,7 +352,9 @@ class Plan:
                 wp2 = self.P(wkey)
                 if packed is None:
                     wp2 = self.vec(wkey + ":w3d_bwd", cout * cin * 27)
-                    self._emit(self.bwd_ops, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp2], i=[cout, cin, 1])
+                    # the data gradient's weight layout is prepared in the FORWARD tape (same parameters: the optimiser only steps
+                    # behind the backward tape), as a group of its own - not in the layer's backward chain
+                    self._emit(self.fwd_ops, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp2], i=[cout, cin, 1], detached=True)
                 self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
                            p=[("gywin", gy.zkey), wp2, self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0), packed],
                            i=[3 * cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, 3, acc], n=ws2)
