@@ -316,7 +316,7 @@ class Plan:
                 self._emit(self.target, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp], i=[cout, cin, 0], detached=True)
             self._emit(self.target, "UZ_OP_CONV_FWD",
                        p=[("win", x), wp, self.P(bkey) if bkey else None, y, ("scratch", "wgrad"), self.amax_in(x), ("amax", 0),
-                          self.amax_out(y) if relu else None, packed],
+                          self.amax_out(y) if relu else None, packed, bn_partials],
                        i=[3 * cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, 3, relu], n=ws)
             return
         wextra = wrow0 * cin * ks * ks
@@ -461,8 +461,10 @@ class Plan:
         # where the forward kernel supports it, it leaves per-tile {sum, sum of squares, max, max(-y)} partials and the
         # BatchNorm finalises them instead of streaming y a second time
         npart = 0
-        if self.bn_training and x.nb is None and os.environ.get("UZ_BN_FUSE_STATS", "1") == "1" and x.N * x.H * x.W > 4096:
-            npart = self.L.uz_conv_bn_partials(x.C, cout, x.N, x.H, x.W, ks)
+        if self.bn_training and os.environ.get("UZ_BN_FUSE_STATS", "1") == "1" and x.N * x.H * x.W > 4096 and \
+                (x.nb is None or (ks == 3 and os.environ.get("UZ_BN_FUSE_STATS_VOL", "1") == "1")):
+            # (a volume's Conv3d is the 2-D kernel over its slices with the depth window as 3 Cin input channels: same epilogue)
+            npart = self.L.uz_conv_bn_partials(x.C if x.nb is None else 3 * x.C, cout, x.N, x.H, x.W, ks)
         bnpart = self.vec(name + ":bnpart", 4 * cout * npart) if npart else None
         # Small planes (the 8x8 ... 2x2 levels: a unit is conv -> split-K reduce -> BatchNorm, 5 - 30 us each, on the step's critical
         # chains): the convolution stops after its main kernel and the one-workgroup-per-channel BatchNorm adds the slabs itself -
