@@ -129,6 +129,18 @@ def test_avgpool3d_trilinear_nearest_vs_torch(C, D, H, W):
     dx3 = torch.full((D, C, H, W), float("nan"), device="cuda")
     g.call("uz_nearest3d_bwd", dnv, C, C, dx3, C, D, H, W, 4, 2, 0)
     assert g.maxabs(_unvol(dx3), xr.grad[0]) <= 1e-5
+    # large factors (>= 64 children per element: one wave per element sums them), overwrite and accumulate
+    for f, fz in ((4, 4), (8, 8)):
+        xr.grad = None
+        nr = F.interpolate(xr, size=[fz * D, f * H, f * W], mode="nearest")
+        dn = g.rnd(*nr.shape[1:], seed=5)
+        nr.backward(dn[None])
+        _, dnv = _vol(dn)
+        dx4 = torch.full((D, C, H, W), float("nan"), device="cuda")
+        g.call("uz_nearest3d_bwd", dnv, C, C, dx4, C, D, H, W, f, fz, 0)
+        assert g.maxabs(_unvol(dx4), xr.grad[0]) <= 1e-5 * f * f * fz
+        g.call("uz_nearest3d_bwd", dnv, C, C, dx4, C, D, H, W, f, fz, 1)
+        assert g.maxabs(_unvol(dx4), 2 * xr.grad[0]) <= 2e-5 * f * f * fz
 
 
 @pytest.mark.gpu

@@ -183,6 +183,28 @@ __global__ __launch_bounds__(256) void nearest3d_bwd_k(const float* __restrict__
     }
 }
 
+// Large factors (the deep levels' logits resized to the full volume: 16 x 16 x 16 = 4 096 children per element of an 8 x 8 x 4
+// tensor): one WAVE per low-resolution element - lanes stride over the children (x fastest: coalesced runs of f floats), ordered
+// butterfly at the end - instead of one thread walking 4 096 strided values (397 us for 768 threads' worth of work).
+__global__ __launch_bounds__(256) void nearest3d_bwd_wave_k(const float* __restrict__ dy, int CtotDy, float* __restrict__ dx, int CtotDx,
+                                                             int H, int W, int f, int fz, int accumulate) {
+    const int d = blockIdx.z, c = blockIdx.y, Ho = H * f, Wo = W * f, n = H * W;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= n) return;
+    const int yy = q / W, xx = q - yy * W, m = f * f * fz;
+    float acc = 0.f;
+    for (int e = lane; e < m; e += 64) {
+        const int j = e % f, r = e / f, i = r % f, k = r / f;
+        acc += dy[((size_t)(d * fz + k) * CtotDy + c) * Ho * Wo + (size_t)(yy * f + i) * Wo + xx * f + j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+        float* o = dx + ((size_t)d * CtotDx + c) * n + q;
+        *o = accumulate ? *o + acc : acc;
+    }
+}
+
 inline int gx(int n) { int g = (n + 255) / 256; return g < 1 ? 1 : (g > 64 ? 64 : g); }
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -239,6 +261,9 @@ extern "C" int uz_nearest3d_fwd(const float* x, int C, int CtotX, float* y, int 
 }
 extern "C" int uz_nearest3d_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int D, int H, int W, int f, int fz, int accumulate, void* stream) {
     UZ_REQUIRE(C > 0 && D > 0 && f >= 1 && fz >= 1 && C <= 65535 && D <= 65535, "nearest3d_bwd: bad sizes");
-    hipLaunchKernelGGL(nearest3d_bwd_k, dim3(gx(H * W), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, H, W, f, fz, accumulate);
+    if (f * f * fz >= 64 && (H * W + 3) / 4 <= 65535)
+        hipLaunchKernelGGL(nearest3d_bwd_wave_k, dim3((H * W + 3) / 4, C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, H, W, f, fz, accumulate);
+    else
+        hipLaunchKernelGGL(nearest3d_bwd_k, dim3(gx(H * W), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, H, W, f, fz, accumulate);
     return uz::check_launch("nearest3d_bwd_k");
 }
