@@ -43,6 +43,8 @@ CONV_CASES = [
     (33, 4, 32, 64, 32, 3),       # ... four input channels, 32-wide planes, odd batch
     (40, 72, 80, 24, 28, 3),      # 16 x 16-pixel geometry UNSPLIT (>= 160 tiles: unconditional staging past the last chunk), K tail of 8, ragged tiles
     (3, 72, 80, 24, 28, 3),       # ... the same layer with 36 tiles: chunk loop split over workgroups (slabs + ordered reduce)
+    (16, 3, 40, 128, 128, 3),     # big tensor, data gradient with 3 output channels: split kernel on a 32-wide tile (routing of the volume path's shapes)
+    (32, 12, 32, 128, 128, 3),    # big tensor, 12 input channels (one zero-padded chunk) forward, narrow-side (12) split weight gradient
 ]
 
 
