@@ -115,6 +115,17 @@ int uz_conv_bwd_data(const float* dy, int Cout, int CoutTot,
                      int N, int H, int W, int ks, int accumulate,
                      const float* dy_amax, const float* w_amax,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* Data gradient with the ReLU backward of the unit that produced A folded in (vanilla U-Net blocks, unet.py:25-30: Conv -> ReLU ->
+ * Conv): dx = (a > 0) ? conv_T(dy, w) (+ dx) : 0 - i.e. dx leaves as the gradient w.r.t. that unit's convolution output, no
+ * separate uz_relu_bwd pass.  partials: uz_conv_bwd_relu_partials() x Cin x 4 floats whose .x components uz_chan_sum_partials adds
+ * up to the unit's bias gradient; dx_amax: bound slot of dx.  uz_conv_bwd_relu_partials() == 0: shape not supported (off the
+ * split path or split-K) - use uz_conv_bwd_data + uz_relu_bwd. */
+int uz_conv_bwd_relu_partials(int Cin, int Cout, int N, int H, int W, int ks);
+int uz_conv_bwd_data_relu(const float* dy, int Cout, int CoutTot, const float* w, float* dx, int Cin, int CinTot,
+                          int N, int H, int W, int ks, int accumulate, const float* dy_amax, const float* w_amax,
+                          void* workspace, size_t workspace_bytes, const void* packed_w,
+                          const float* a, int aCtot, float* partials, float* dx_amax, void* stream);
+int uz_chan_sum_partials(const float* partials, int n_rows, int C, float* out, void* stream);
 /* autograd w.r.t. the weight: dw[co,ci,tap] = sum_{b,y,x} dy * x_shifted.
  * Deterministic split-K: partial slabs in `workspace` (uz_conv_bwd_weight_workspace
  * bytes), then an ordered reduction.  db (nullable) = sum_{b,y,x} dy.
@@ -316,6 +327,7 @@ enum {
   UZ_OP_ADD_VIEWS,       /* p = a, b, y, a_amax, b_amax, y_amax; i = CtotA, CtotB, CtotY, C, N, H, W, accumulate; f[0] = alpha */
   UZ_OP_EVENT_RECORD,    /* p[0] = event (uz_event_create): marks "every earlier op this one depends on is done" */
   UZ_OP_PACK_WEIGHTS,    /* p[0] = table, p[1] = w_amax; i = n_layers, total_rows (uz_conv_pack_weights); CONV_FWD p[8] / CONV_BWD_DATA p[6] = image */
+  UZ_OP_CHAN_SUM_PARTIALS, /* p = partials, out; i = n_rows, C (uz_chan_sum_partials); CONV_BWD_DATA p[7] = a (folded ReLU backward), p[8] = partials, p[9] = dx bound; i[9] = CtotA */
   UZ_OP__COUNT
 };
 typedef struct uz_op {

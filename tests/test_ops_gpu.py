@@ -97,11 +97,54 @@ def test_conv_fwd_bwd(N, Cin, Cout, H, W, ks):
     dw = torch.full_like(wd, float("nan"))
     db = torch.full_like(bd, float("nan"))
     g.call("uz_conv_bwd_weight", xv, Cin, Cin + 5, dyd, Cout, Cout, dw, db, N, H, W, ks, None, None, ws, ws_bytes)
-    assert g.relerr(dw, wr.grad) <= TOL
-    assert g.relerr(db, br.grad) <= TOL
+    # a weight gradient is a sum over N*H*W pixels: beyond ~64 k of them the fp32 torch reference itself (whose summation order
+    # depends on its thread count) carries more rounding than TOL - the gate grows with sqrt(K) there (2.3e-5 seen at K = 524 k)
+    tol_k = TOL * max(1.0, (N * H * W / 65536.0) ** 0.5)
+    assert g.relerr(dw, wr.grad) <= tol_k
+    assert g.relerr(db, br.grad) <= tol_k
     dw2 = torch.empty_like(dw)
     g.call("uz_conv_bwd_weight", xv, Cin, Cin + 5, dyd, Cout, Cout, dw2, None, N, H, W, ks, None, None, ws, ws_bytes)
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(8, 64, 64, 64, 64), (4, 32, 96, 128, 128), (32, 128, 128, 32, 32), (6, 48, 80, 37, 70)])
+def test_data_gradient_with_folded_relu_backward(N, Cin, Cout, H, W):
+    """uz_conv_bwd_data_relu: the ReLU backward of the unit that produced A (vanilla U-Net blocks, unet.py:25-30: Conv -> ReLU -> Conv)
+    in the epilogue of the data gradient that writes dA - dx = (a > 0) ? conv_T(dy, w) (+ dx) : 0, the bias-gradient partials and the
+    bound of dx.  Against conv_transpose2d + threshold_backward, overwrite and accumulate, through channel-slice views."""
+    g = _g()
+    from unet_zoo_amd import _ffi
+    L = _ffi.lib()
+    npart = L.uz_conv_bwd_relu_partials(Cin, Cout, N, H, W, 3)
+    if npart == 0:
+        pytest.skip("shape off the split path in this math mode")
+    dev = g.dev()
+    dy = g.rnd(N, Cout, H, W, seed=21)
+    w = g.rnd(Cout, Cin, 3, 3, seed=22, scale=0.1)
+    a = torch.relu(g.rnd(N, Cin, H, W, seed=23))                      # the producing unit's activation: about half zeros
+    prev = g.rnd(N, Cin, H, W, seed=24)
+    full = F.conv_transpose2d(dy, w, padding=1)
+    mask = (a > 0).float()
+    abuf = torch.full((N, Cin + 2, H, W), -1.0, device=dev); abuf[:, 1:1 + Cin] = a.to(dev)
+    dxbuf = torch.full((N, Cin + 3, H, W), 5.0, device=dev)
+    wsb = L.uz_conv_workspace(Cin, Cout, N, H, W, 3)
+    ws = torch.empty(wsb // 4 + 64, device=dev)
+    part = torch.full((npart * Cin * 4,), float("nan"), device=dev)
+    slot = torch.zeros(256, device=dev)
+    for acc in (0, 1):
+        ref = (full + (prev if acc else 0)) * mask
+        if acc:
+            dxbuf[:, 2:2 + Cin] = prev.to(dev)
+        slot.zero_()
+        g.call("uz_conv_bwd_data_relu", dy.to(dev), Cout, Cout, w.to(dev), dxbuf[:, 2:], Cin, Cin + 3, N, H, W, 3, acc, None, None, ws, wsb, None,
+               abuf[:, 1:], Cin + 2, part, slot)
+        assert g.relerr(dxbuf[:, 2:2 + Cin], ref) <= TOL
+        assert bool((dxbuf[:, :2] == 5.0).all()) and bool((dxbuf[:, 2 + Cin:] == 5.0).all())
+        db = torch.empty(Cin, device=dev)
+        g.call("uz_chan_sum_partials", part, npart, Cin, db)
+        dbr = ref.sum((0, 2, 3))
+        assert g.maxabs(db, dbr) <= 2e-5 * float(ref.abs().sum((0, 2, 3)).max())
+        assert float(slot.max()) >= float(ref.abs().max()) * (1 - 1e-5) and float(slot.max()) <= float(ref.abs().max()) * 1.001
 
 
 def test_conv_full_size_linearity():

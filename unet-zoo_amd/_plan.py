@@ -83,13 +83,14 @@ class ParamTable:
 
 
 class Buf:
-    __slots__ = ("name", "N", "C", "H", "W", "off", "gbuf", "requires_grad", "amax", "amax_cov", "alias")
+    __slots__ = ("name", "N", "C", "H", "W", "off", "gbuf", "requires_grad", "amax", "amax_cov", "alias", "relu")
 
     def __init__(self, name, N, C, H, W, requires_grad=True):
         self.name, self.N, self.C, self.H, self.W = name, int(N), int(C), int(H), int(W)
         self.off, self.gbuf, self.requires_grad = None, None, requires_grad
         self.amax, self.amax_cov = None, []      # magnitude-bound slot and the channel ranges whose producers maintain it
         self.alias = None                        # pooled scratch: several differently shaped Bufs share one arena region
+        self.relu = None                         # set by Plan.conv_relu: {(c0, C): state} of Conv -> ReLU units writing into this buffer
 
     @property
     def numel(self):
@@ -166,6 +167,7 @@ class Plan:
         self.n_lanes = max(1, min(int(os.environ.get("UZ_LANES", "2")), 8))
         self.decouple_wgrad_px = 0           # NativeModel.decouple_wgrad_px: planes (N*H*W) up to which weight gradients get a group of their own
         self.decouple_wgrad_prefixes = ()    # NativeModel.decouple_wgrad_prefixes
+        self._nclaims = {}                   # backward writers seen per buffer (conv_relu's folded ReLU backward checks it was the last one)
 
     def _newgroup(self):
         self._gid += 1
@@ -227,6 +229,7 @@ class Plan:
     def _claim(self, v):
         """Returns the accumulate flag for a backward write to grad(v) and records the region."""
         regs = self._ginit.setdefault(v.buf, [])
+        self._nclaims[v.buf] = self._nclaims.get(v.buf, 0) + 1
         lo, hi = v.c0, v.c0 + v.C
         covered = [c for c in range(lo, hi) if any(a <= c < b for a, b in regs)]
         if len(covered) == hi - lo:
@@ -380,9 +383,21 @@ class Plan:
             ws2 = self.L.uz_conv_workspace(cin, cout, x.N, x.H, x.W, ks)
             self.scratch["wgrad"] = max(self.scratch["wgrad"], ws2)
             packed = self._packed(wkey, cin, cout, x, True) if (ks == 3 and wrow0 == 0) else None
+            # x is the output of a Conv -> ReLU unit (vanilla U-Net blocks) and this data gradient is the last writer of its
+            # gradient: fold that unit's ReLU backward into the epilogue (mask, bias-gradient partials, bound) - the unit then
+            # uses grad(x) in place as its dy instead of running uz_relu_bwd over it (conv_relu.bwd checks "last writer")
+            fold = None
+            st = (x.buf.relu or {}).get((x.c0, x.C)) if x.nb is None else None
+            if st is not None and ks == 3 and wrow0 == 0 and os.environ.get("UZ_FOLD_RELU_BWD", "1") == "1" \
+                    and not self.__dict__.get("_in_rev", False):
+                npart = self.L.uz_conv_bwd_relu_partials(cin, cout, x.N, x.H, x.W, ks)
+                if npart > 0:
+                    fold = st["fold"] = dict(part=self.vec(x.buf.name + f":dbpart{x.c0}", 4 * cin * npart), npart=npart,
+                                             amax=self.amax_out(self.gview(x)), claims=self._nclaims[x.buf])
             self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
-                       p=[gy, self.P(wkey, wextra), self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0), packed],
-                       i=[cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, ks, acc], n=ws2)
+                       p=[gy, self.P(wkey, wextra), self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0), packed]
+                         + ([x, fold["part"], fold["amax"]] if fold else []),
+                       i=[cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, ks, acc] + ([x.Ctot] if fold else []), n=ws2)
         if decoupled:
             self._newgroup()
             emit_wgrad()
@@ -660,9 +675,21 @@ class Plan:
         a = out if out is not None else self.buf((name or prefix) + ":a", cout, x.H, x.W)
         self._conv_fwd(x, wkey, bkey, a, ks, 1)
         self.scratch["bn"] = max(self.scratch["bn"], self.L.uz_bn_workspace(cout, x.N, x.H, x.W))
+        if a.buf.relu is None:
+            a.buf.relu = {}
+        state = a.buf.relu[(a.c0, a.C)] = {}
 
         def bwd():
             if not self._has_grad(a):
+                return
+            fold = state.get("fold")
+            if fold is not None:
+                # the data gradient that wrote grad(a) last already applied this unit's ReLU mask (see _conv_bwd)
+                if self._nclaims.get(a.buf, 0) != fold["claims"]:
+                    raise RuntimeError(f"{prefix}: a later writer of grad({a.buf.name}) follows the data gradient that folded the ReLU "
+                                       "backward - set UZ_FOLD_RELU_BWD=0 for this model")
+                self._emit(self.bwd_ops, "UZ_OP_CHAN_SUM_PARTIALS", p=[fold["part"], self.G(bkey)], i=[fold["npart"], cout])
+                self._conv_bwd(x, wkey, self.gview(a), ks)
                 return
             gy = self._gy_scratch(a)
             gyv = _ScratchView(a.N, cout, a.H, a.W, amax=self._new_amax(bwd=True))
@@ -1086,7 +1113,7 @@ class Plan:
     # Which p[] slots an op writes (every other slot is read).  Scratch slots are private to a
     # group and parameters are read-only inside a tape, so neither creates a dependency.
     _WRITES = {
-        "UZ_OP_CONV_FWD": (3, 9), "UZ_OP_CONV_BWD_DATA": (2,), "UZ_OP_CONV_BWD_WEIGHT": (2, 3),
+        "UZ_OP_CONV_FWD": (3, 9), "UZ_OP_CONV_BWD_DATA": (2, 8, 9), "UZ_OP_CONV_BWD_WEIGHT": (2, 3),
         "UZ_OP_BN_RELU_FWD": (3, 4, 5, 6), "UZ_OP_BN_RELU_BWD": (5, 6, 7, 8), "UZ_OP_RELU_BWD": (2, 3),
         "UZ_OP_AVGPOOL_FWD": (1,), "UZ_OP_AVGPOOL_BWD": (1,), "UZ_OP_BILINEAR_FWD": (1,), "UZ_OP_BILINEAR_BWD": (1,),
         "UZ_OP_NEAREST_FWD": (1,), "UZ_OP_NEAREST_BWD": (1,), "UZ_OP_SPATIAL_MEAN_FWD": (1,), "UZ_OP_SPATIAL_MEAN_BWD": (1,),
@@ -1097,7 +1124,7 @@ class Plan:
         "UZ_OP_BCAST_CHANNELS": (1,), "UZ_OP_BCAST_CHANNELS_BWD": (1,), "UZ_OP_EVENT_RECORD": (0,), "UZ_OP_ABSMAX": (1,),
         "UZ_OP_ADD_VIEWS": (2,), "UZ_OP_W3D_PERMUTE": (1,), "UZ_OP_AVGPOOL3D_FWD": (1,), "UZ_OP_AVGPOOL3D_BWD": (1,),
         "UZ_OP_DEPTH_LERP_FWD": (1,), "UZ_OP_DEPTH_LERP_BWD": (1,), "UZ_OP_NEAREST3D_FWD": (1,), "UZ_OP_NEAREST3D_BWD": (1,),
-        "UZ_OP_ABSMAX_COPY": (), "UZ_OP_PACK_WEIGHTS": (2,),
+        "UZ_OP_ABSMAX_COPY": (), "UZ_OP_PACK_WEIGHTS": (2,), "UZ_OP_CHAN_SUM_PARTIALS": (1,),
     }
 
     def _resources(self, r):

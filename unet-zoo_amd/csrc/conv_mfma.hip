@@ -538,6 +538,36 @@ extern "C" int uz_conv_bwd_data_packed(const float* dy, int Cout, int CoutTot, c
     }
     return uz::conv_mfma(dy, Cout, CoutTot, w, Cin, nullptr, dx, Cin, CinTot, N, H, W, ks, 1, 0, accumulate, dy_amax, w_amax, nullptr, workspace, workspace_bytes, packed_w, nullptr, uz::S(stream));
 }
+// ---- ReLU backward folded into the data gradient that produces dA (vanilla U-Net blocks: Conv -> ReLU -> Conv, unet.py:25-30)
+namespace {
+// dbias[c] = sum over the partial rows of partials[row][c].x (ordered, fp64), one wave per channel
+__global__ __launch_bounds__(256) void chan_sum_partials_k(const float* __restrict__ part, int nrows, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int i = lane; i < nrows; i += 64) s += (double)part[((size_t)i * C + c) * 4];
+    s = uz::wave_sum_d(s);
+    if (lane == 0) out[c] = (float)s;
+}
+}  // namespace
+extern "C" int uz_conv_bwd_relu_partials(int Cin, int Cout, int N, int H, int W, int ks) {
+    if (ks != 3 || !uz::conv_split_ok(Cout, Cin, N, H, W, ks, 1)) return 0;
+    return uz::conv_split_bn_partials(Cout, Cin, N, H, W);          // 0 when the chunk loop is split over workgroups
+}
+extern "C" int uz_conv_bwd_data_relu(const float* dy, int Cout, int CoutTot, const float* w, float* dx, int Cin, int CinTot,
+                                     int N, int H, int W, int ks, int accumulate, const float* dy_amax, const float* w_amax,
+                                     void* workspace, size_t workspace_bytes, const void* packed_w,
+                                     const float* a, int aCtot, float* partials, float* dx_amax, void* stream) {
+    UZ_REQUIRE(uz_conv_bwd_relu_partials(Cin, Cout, N, H, W, ks) > 0, "conv_bwd_data_relu: this shape does not support the folded ReLU backward (uz_conv_bwd_relu_partials() == 0)");
+    UZ_REQUIRE(workspace && workspace_bytes >= uz::conv_split_workspace(Cout, Cin, N, H, W), "conv_bwd_data_relu: workspace too small");
+    return uz::conv_split_dgrad_relu(dy, Cout, CoutTot, w, Cin, dx, Cin, CinTot, N, H, W, accumulate, dy_amax, w_amax, dx_amax, workspace, packed_w,
+                                     a, aCtot, partials, uz::S(stream));
+}
+extern "C" int uz_chan_sum_partials(const float* partials, int n_rows, int C, float* out, void* stream) {
+    UZ_REQUIRE(partials && out && n_rows > 0 && C > 0, "chan_sum_partials: bad arguments");
+    hipLaunchKernelGGL(chan_sum_partials_k, dim3(uz::ceil_div(C, 4)), dim3(256), 0, uz::S(stream), partials, n_rows, C, out);
+    return uz::check_launch("chan_sum_partials_k");
+}
 extern "C" int uz_conv_bwd_data(const float* dy, int Cout, int CoutTot, const float* w,
                                 float* dx, int Cin, int CinTot, int N, int H, int W, int ks, int accumulate,
                                 const float* dy_amax, const float* w_amax,

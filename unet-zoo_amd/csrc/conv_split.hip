@@ -67,6 +67,7 @@ struct SP {
     const float* x_amax; const float* w_amax;     // device scalars: upper bounds of |x| and |w| (never null here)
     float* y_amax;                                // nullable: atomic max of |y| (bound for the next layer's split)
     int kSplit, cps;                              // split-K: the chunk loop is shared out over kSplit workgroups, cps chunks each
+    const float* mask; int maskCtot;              // data gradient with the producer's ReLU mask folded in: y = (mask > 0) ? y : 0 (view of Cout channels)
     float* slab;                                  // [kSplit][N][Cout][HW] partial sums (kSplit > 1), summed in order by splitk_reduce
     long long* stamps;                            // diagnostics (uz_debug_stamps): 8 cycle stamps per workgroup, normally null
     int* flags;                                   // device flag word (bound violations), nullable
@@ -127,7 +128,7 @@ constexpr int lds_bytes() {
     const int epilogue = 16 * (NTv + 4) * 4;
     return main_loop > epilogue ? main_loop : epilogue;
 }
-template <int MSUB, int NTv, int TWv, int NP>
+template <int MSUB, int NTv, int TWv, int NP, bool MK = false>      // MK: the folded ReLU-backward mask (kernels of their own: +12 VGPRs)
 __device__ __forceinline__ void conv_split_body(const SP& p) {
     using uz::u32x4;
     using GEO = Geo<NTv, TWv>;
@@ -385,7 +386,8 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     const bool split = p.kSplit > 1;                     // partial sums only: bias / accumulate / ReLU / bound happen in the reduce
     float* const obase = split ? p.slab + (size_t)part * p.N * p.Cout * p.HW + (size_t)b0 * p.Cout * p.HW
                                : p.y + (size_t)b0 * p.CoutTot * p.HW;
-    const bool vec = (p.W & 3) == 0 && (reinterpret_cast<uintptr_t>(obase) & 15) == 0;
+    const float* const mbase = (MK && p.mask) ? p.mask + (size_t)b0 * p.maskCtot * p.HW : nullptr;
+    const bool vec = (p.W & 3) == 0 && (reinterpret_cast<uintptr_t>(obase) & 15) == 0 && (reinterpret_cast<uintptr_t>(mbase) & 15) == 0;
     const int c4 = tid % Q, rsub = tid / Q;              // this thread's float4 column and row phase (rows rsub, rsub + 4, ...)
     const int px = 4 * c4, ty = px / TW, tx = px % TW;
     const int oy = y0 + ty, ox = x0 + tx;
@@ -422,6 +424,10 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
                     if (vec) {
                         if (!split) {
                             if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+                            if (MK && mbase) {               // ReLU backward of the producing unit (unet.py:25-30), behind the last accumulation
+                                const f32x4 mk = *reinterpret_cast<const f32x4*>(mbase + (dst - obase));
+                                v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                            }
                             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                             vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                         }
@@ -435,6 +441,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
                                 float t = v[e];
                                 if (!split) {
                                     if (p.accumulate) t += dst[e];
+                                    if (MK && mbase) t = mbase[(dst - obase) + e] > 0.f ? t : 0.f;
                                     if (p.relu) t = fmaxf(t, 0.f);
                                     vmax = fmaxf(vmax, fabsf(t));
                                 }
@@ -477,6 +484,19 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel_1_256_16(const SP p)
 __global__ __launch_bounds__(512, 1) void conv_bf16_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32, 1>(p); }
 __global__ __launch_bounds__(512, 4) void conv_bf16_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32, 1>(p); }
 __global__ __launch_bounds__(256, 3) void conv_bf16_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16, 1>(p); }
+__global__ __launch_bounds__(512, 1) void conv_split_relu_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32, 2, true>(p); }
+__global__ __launch_bounds__(512, 4) void conv_split_relu_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32, 2, true>(p); }
+__global__ __launch_bounds__(256, 2) void conv_split_relu_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16, 2, true>(p); }
+__global__ __launch_bounds__(512, 1) void conv_bf16_relu_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32, 1, true>(p); }
+__global__ __launch_bounds__(512, 4) void conv_bf16_relu_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32, 1, true>(p); }
+__global__ __launch_bounds__(256, 3) void conv_bf16_relu_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16, 1, true>(p); }
+template <int MSUB, int NTv, int TWv, int NP> struct SplitReluKernel;
+template <> struct SplitReluKernel<2, 512, 32, 2> { static constexpr auto fn = conv_split_relu_kernel_2_512_32; };
+template <> struct SplitReluKernel<1, 512, 32, 2> { static constexpr auto fn = conv_split_relu_kernel_1_512_32; };
+template <> struct SplitReluKernel<1, 256, 16, 2> { static constexpr auto fn = conv_split_relu_kernel_1_256_16; };
+template <> struct SplitReluKernel<2, 512, 32, 1> { static constexpr auto fn = conv_bf16_relu_kernel_2_512_32; };
+template <> struct SplitReluKernel<1, 512, 32, 1> { static constexpr auto fn = conv_bf16_relu_kernel_1_512_32; };
+template <> struct SplitReluKernel<1, 256, 16, 1> { static constexpr auto fn = conv_bf16_relu_kernel_1_256_16; };
 template <> struct SplitKernel<2, 512, 32, 2> { static constexpr auto fn = conv_split_kernel_2_512_32; };
 template <> struct SplitKernel<1, 512, 32, 2> { static constexpr auto fn = conv_split_kernel_1_512_32; };
 template <> struct SplitKernel<1, 256, 16, 2> { static constexpr auto fn = conv_split_kernel_1_256_16; };
@@ -487,12 +507,13 @@ template <> struct SplitKernel<1, 256, 16, 1> { static constexpr auto fn = conv_
 template <int MSUB, int NTv, int TWv, int NP>
 int launch(const SP& p, int grid, hipStream_t st) {
     constexpr size_t smem = lds_bytes<MSUB, NTv, TWv, NP>();
-    static bool attr_done = false;
-    auto kern = SplitKernel<MSUB, NTv, TWv, NP>::fn;
-    if (!attr_done) {
+    static bool attr_done[2] = {false, false};
+    const int mk = p.mask != nullptr;
+    auto kern = mk ? SplitReluKernel<MSUB, NTv, TWv, NP>::fn : SplitKernel<MSUB, NTv, TWv, NP>::fn;
+    if (!attr_done[mk]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return uz::fail("conv_split: cannot raise dynamic LDS limit");
-        attr_done = true;
+        attr_done[mk] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTv), smem, st, p);
     return uz::check_launch("conv_split_kernel");
@@ -631,10 +652,33 @@ int absmax_flat(const float* x, size_t n, float* slot, hipStream_t st) {
 // x_amax / w_amax: device scalars bounding |x| and |w| (any upper bound within ~2^10 of the true maximum keeps full
 // accuracy); NULL = measure here (one extra pass over the tensor: the stand-alone C-ABI path, the model plans pass
 // bounds that the producing kernels maintain).  y_amax (nullable): atomic max of |y| for the next consumer.
+static int conv_split_impl(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
+               float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
+               const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, float* bn_partials, hipStream_t st,
+               const float* relu_mask, int maskCtot);
 int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
                const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, float* bn_partials, hipStream_t st) {
+    return conv_split_impl(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, dgrad, relu, accumulate, x_amax, w_amax, y_amax, workspace, packed_w,
+                           bn_partials, st, nullptr, 0);
+}
+// Data gradient with the ReLU backward of the unit that PRODUCED its output's forward twin folded into the epilogue (vanilla U-Net
+// blocks, unet.py:25-30: Conv -> ReLU with no normalisation in between): dx = (a > 0) ? conv_T(dy, w) [+ dx] : 0, where `a` is that
+// unit's activation (a view of Mc channels); partials (nullable) receive the per-(tile, channel) sums of dx for the unit's bias
+// gradient in the layout of conv_split_bn_partials(); dx_amax receives max |dx|.  Unsplit chunk loops only.
+int conv_split_dgrad_relu(const float* dy, int Kc, int KcTot, const float* w, int wCi, float* dx, int Mc, int McTot, int N, int H, int W, int accumulate,
+                          const float* dy_amax, const float* w_amax, float* dx_amax, void* workspace, const void* packed_w,
+                          const float* a, int aCtot, float* partials, hipStream_t st) {
+    UZ_REQUIRE(a, "conv_dgrad_relu: needs the producer's activation");
+    return conv_split_impl(dy, Kc, KcTot, w, wCi, nullptr, dx, Mc, McTot, N, H, W, 1, 0, accumulate, dy_amax, w_amax, dx_amax, workspace, packed_w,
+                           partials, st, a, aCtot);
+}
+static int conv_split_impl(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
+               float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
+               const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, float* bn_partials, hipStream_t st,
+               const float* relu_mask, int maskCtot) {
     SP p;
+    p.mask = relu_mask; p.maskCtot = maskCtot;
     float* slots = static_cast<float*>(workspace);
     char* image = static_cast<char*>(workspace) + WS_HEAD;
     const int np = conv_np();                            // 1: bf16 single-piece operands (no scales, no bounds)
@@ -661,7 +705,8 @@ int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const
     p.kSplit = split_parts(Kc, Mc, N, H, W);
     p.cps = ceil_div(p.nChunks, p.kSplit);
     p.kSplit = ceil_div(p.nChunks, p.cps);               // no empty parts
-    UZ_REQUIRE(!bn_partials || (p.kSplit == 1 && !relu && !accumulate && !dgrad), "conv_split: fused BatchNorm statistics need an unsplit plain forward convolution");
+    UZ_REQUIRE(!bn_partials || (p.kSplit == 1 && !relu && ((!accumulate && !dgrad) || relu_mask)), "conv_split: fused BatchNorm statistics need an unsplit plain forward convolution");
+    UZ_REQUIRE(!relu_mask || (p.kSplit == 1 && dgrad), "conv_split: the folded ReLU backward needs an unsplit data gradient");
     p.slab = reinterpret_cast<float*>(image + image_bytes(Kc, Mc, W));
     p.stamps = uz::debug_stamps;
     p.flags = dev_flags_ptr();

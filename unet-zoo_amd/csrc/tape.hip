@@ -74,6 +74,7 @@ static int run_one(const uz_op& o, void* st) {
             if (i[9]) return uz_conv_fwd_slabs(CFP(0), i[0], i[1], CFP(1), i[2], i[4], i[5], i[6], i[7], p[4], (size_t)o.n, st);      // the unit's BatchNorm adds the slabs
             return uz_conv_fwd_bnstats(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(5), CFP(6), FP(7), p[4], (size_t)o.n, p[8], FP(9), st);
         case UZ_OP_CONV_BWD_DATA:
+            if (p[7]) return uz_conv_bwd_data_relu(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], CFP(7), i[9], FP(8), FP(9), st);
             return uz_conv_bwd_data_packed(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], st);
         case UZ_OP_CONV_BWD_WEIGHT:
             return uz_conv_bwd_weight(CFP(0), i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], i[7], CFP(5), CFP(6), p[4], (size_t)o.n, st);
@@ -128,6 +129,8 @@ static int run_one(const uz_op& o, void* st) {
             return uz_l2_norms(CFP(0), static_cast<const int64_t*>(p[1]), i[0], FP(2), st);
         case UZ_OP_L2_NORMS_BWD:
             return uz_l2_norms_bwd(CFP(0), static_cast<const int64_t*>(p[1]), i[0], CFP(2), CFP(3), FP(4), st);
+        case UZ_OP_CHAN_SUM_PARTIALS:
+            return uz_chan_sum_partials(CFP(0), i[0], i[1], FP(1), st);
         case UZ_OP_PACK_WEIGHTS:
             return uz_conv_pack_weights(static_cast<const int64_t*>(p[0]), i[0], i[1], CFP(1), st);
         case UZ_OP_MEMSET:

@@ -64,6 +64,9 @@ int splitk_reduce(const float* slab, int ksplit, const float* bias, float* y, in
 int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
                const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, float* bn_partials, hipStream_t st);
+int conv_split_dgrad_relu(const float* dy, int Kc, int KcTot, const float* w, int wCi, float* dx, int Mc, int McTot, int N, int H, int W, int accumulate,
+                          const float* dy_amax, const float* w_amax, float* dx_amax, void* workspace, const void* packed_w,
+                          const float* a, int aCtot, float* partials, hipStream_t st);   // conv_split.hip
 int conv_split_bn_partials(int Kc, int Mc, int N, int H, int W);
 
 // conv_wgrad_split.hip: 3x3 weight gradient on the fp16 matrix pipe with two-piece split operands
