@@ -24,3 +24,9 @@ python tools/timeline.py $F gpurun_out/r3_timeline_graph.json | head -20
 gzip -c $F > gpurun_out/r3_kernel_trace_graph.csv.gz; rm -rf gpurun_out/kt_graph
 bash tools/prof_layers.sh 3 20 20 > gpurun_out/prof_layers.log 2>&1; tail -24 gpurun_out/prof_layers.log | cut -c1-230
 python tools/soak_train.py 300 > gpurun_out/r3_soak_300_steps.log 2>&1; tail -3 gpurun_out/r3_soak_300_steps.log
+# kernel statistics of the other three models' bench runs (profiles/r3_bench_kernel_stats_graph_<model>.csv)
+for m in unet probunet phiseg3d; do
+  rm -rf gpurun_out/prof_$m
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$m -- python bench.py --model $m --steps 10 --warmup 5 --skip-cpu --no-profile --no-f32-leg > gpurun_out/prof_${m}_line.json 2>/dev/null
+  cp $(ls gpurun_out/prof_$m/*/*kernel_stats.csv | head -1) gpurun_out/r3_bench_kernel_stats_graph_$m.csv; rm -rf gpurun_out/prof_$m
+done
