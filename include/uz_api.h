@@ -126,6 +126,15 @@ int uz_conv_bwd_data_relu(const float* dy, int Cout, int CoutTot, const float* w
                           void* workspace, size_t workspace_bytes, const void* packed_w,
                           const float* a, int aCtot, float* partials, float* dx_amax, void* stream);
 int uz_chan_sum_partials(const float* partials, int n_rows, int C, float* out, void* stream);
+/* The same fold for the OTHER last writers of a unit's dA: the backward of the pooling / interpolation that consumed A (the third
+ * unit of every U-Net block).  partials: uz_resample_bwd_relu_rows(kind, C, N, H, W) x C doubles (kind 0 = avgpool2 with H x W the
+ * high-resolution plane, 1 = bilinear2x with H x W the low-resolution plane), summed by uz_chan_sum_partials_d. */
+int uz_resample_bwd_relu_rows(int kind, int C, int N, int H, int W);
+int uz_avgpool2_bwd_relu(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int accumulate,
+                         const float* a, int CtotA, double* partials, float* dx_amax, void* stream);
+int uz_bilinear2x_bwd_relu(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int align_corners, int accumulate,
+                           const float* a, int CtotA, double* partials, float* dx_amax, void* stream);
+int uz_chan_sum_partials_d(const double* partials, int n_rows, int C, float* out, void* stream);
 /* autograd w.r.t. the weight: dw[co,ci,tap] = sum_{b,y,x} dy * x_shifted.
  * Deterministic split-K: partial slabs in `workspace` (uz_conv_bwd_weight_workspace
  * bytes), then an ordered reduction.  db (nullable) = sum_{b,y,x} dy.

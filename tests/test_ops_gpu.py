@@ -147,6 +147,42 @@ def test_data_gradient_with_folded_relu_backward(N, Cin, Cout, H, W):
         assert float(slot.max()) >= float(ref.abs().max()) * (1 - 1e-5) and float(slot.max()) <= float(ref.abs().max()) * 1.001
 
 
+@pytest.mark.parametrize("kind,N,C,H,W", [(0, 4, 32, 64, 64), (0, 3, 5, 33, 17), (1, 4, 32, 32, 32), (1, 2, 6, 20, 12), (1, 40, 64, 16, 16)])
+def test_pool_and_interpolation_backward_with_folded_relu(kind, N, C, H, W):
+    """uz_avgpool2_bwd_relu / uz_bilinear2x_bwd_relu: the backward of the pooling / interpolation that consumed a Conv -> ReLU unit's
+    output A (vanilla U-Net blocks) as the last writer of dA applies the unit's mask, leaves its bias-gradient partials and the bound
+    of dA.  Against torch autograd of relu -> pool / interpolate, accumulate on, channel-slice views.  (H, W): plane of A."""
+    g = _g()
+    from unet_zoo_amd import _ffi
+    L = _ffi.lib()
+    dev = g.dev()
+    pre = g.rnd(N, C, H, W, seed=31).requires_grad_(True)
+    a = torch.relu(pre)
+    y = F.avg_pool2d(a, 2, 2, ceil_mode=True) if kind == 0 else F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True)
+    dy = g.rnd(*y.shape, seed=32)
+    prev = g.rnd(N, C, H, W, seed=33)                                 # an earlier writer of dA
+    y.backward(dy)
+    full = pre.grad                                                   # = mask * upstream
+    mask = (a > 0).float().detach()
+    ref = full + prev * mask
+    rows = L.uz_resample_bwd_relu_rows(kind, C, N, H, W) if kind == 0 else L.uz_resample_bwd_relu_rows(kind, C, N, H, W)
+    part = torch.full((rows * C,), float("nan"), dtype=torch.float64, device=dev)
+    abuf = torch.full((N, C + 2, H, W), -1.0, device=dev); abuf[:, 1:1 + C] = a.detach().to(dev)
+    dxbuf = torch.full((N, C + 3, H, W), 5.0, device=dev); dxbuf[:, 2:2 + C] = prev.to(dev)
+    slot = torch.zeros(256, device=dev)
+    dyd = dy.to(dev)
+    if kind == 0:
+        g.call("uz_avgpool2_bwd_relu", dyd, C, C, dxbuf[:, 2:], C + 3, N, H, W, 1, abuf[:, 1:], C + 2, part, slot)
+    else:
+        g.call("uz_bilinear2x_bwd_relu", dyd, C, C, dxbuf[:, 2:], C + 3, N, H, W, 1, 1, abuf[:, 1:], C + 2, part, slot)
+    assert g.maxabs(dxbuf[:, 2:2 + C], ref) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    assert bool((dxbuf[:, :2] == 5.0).all()) and bool((dxbuf[:, 2 + C:] == 5.0).all())
+    db = torch.empty(C, device=dev)
+    g.call("uz_chan_sum_partials_d", part, rows, C, db)
+    assert g.maxabs(db, ref.sum((0, 2, 3))) <= 1e-5 * float(ref.abs().sum((0, 2, 3)).max())
+    assert float(slot.max()) >= float(ref.abs().max()) * (1 - 1e-5) and float(slot.max()) <= float(ref.abs().max()) * 1.001
+
+
 def test_conv_full_size_linearity():
     """BASELINE-size layer (224->128 @128x128, the heaviest PHiSeg conv): too big for a CPU oracle in
     seconds at batch 32, so check size-independent properties: linearity in the input and agreement

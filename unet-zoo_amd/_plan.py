@@ -688,7 +688,7 @@ class Plan:
                 if self._nclaims.get(a.buf, 0) != fold["claims"]:
                     raise RuntimeError(f"{prefix}: a later writer of grad({a.buf.name}) follows the data gradient that folded the ReLU "
                                        "backward - set UZ_FOLD_RELU_BWD=0 for this model")
-                self._emit(self.bwd_ops, "UZ_OP_CHAN_SUM_PARTIALS", p=[fold["part"], self.G(bkey)], i=[fold["npart"], cout])
+                self._emit(self.bwd_ops, "UZ_OP_CHAN_SUM_PARTIALS", p=[fold["part"], self.G(bkey)], i=[fold["npart"], cout, fold.get("dbl", 0)])
                 self._conv_bwd(x, wkey, self.gview(a), ks)
                 return
             gy = self._gy_scratch(a)
@@ -733,8 +733,17 @@ class Plan:
             if not self._has_grad(y) or not x.buf.requires_grad:
                 return
             acc = self._claim(x)
-            self._emit(self.bwd_ops, bcode, p=[self.gview(y), self.gview(x)],
-                       i=[x.C, y.Ctot, x.Ctot, x.N, x.H, x.W, *extra_i, acc])
+            # x is the output of a Conv -> ReLU unit and this pooling / interpolation backward is the last writer of its gradient
+            # (the third unit of every vanilla U-Net block): fold that unit's ReLU backward in, like _conv_bwd does
+            fold = None
+            st = (x.buf.relu or {}).get((x.c0, x.C)) if x.nb is None else None
+            if st is not None and bcode in ("UZ_OP_AVGPOOL_BWD", "UZ_OP_BILINEAR_BWD") and not self.__dict__.get("_in_rev", False) \
+                    and os.environ.get("UZ_FOLD_RELU_BWD", "1") == "1":
+                rows = self.L.uz_resample_bwd_relu_rows(0 if bcode == "UZ_OP_AVGPOOL_BWD" else 1, x.C, x.N, x.H, x.W)
+                fold = st["fold"] = dict(part=self.vec(x.buf.name + f":dbpart{x.c0}", 2 * rows * x.C), npart=rows, dbl=1,
+                                         amax=self.amax_out(self.gview(x)), claims=self._nclaims[x.buf])
+            self._emit(self.bwd_ops, bcode, p=[self.gview(y), self.gview(x)] + ([x, fold["part"], fold["amax"]] if fold else []),
+                       i=[x.C, y.Ctot, x.Ctot, x.N, x.H, x.W, *extra_i, acc] + ([x.Ctot] if fold else []))
         self._push_bwd(bwd)
         return y
 
@@ -1115,7 +1124,7 @@ class Plan:
     _WRITES = {
         "UZ_OP_CONV_FWD": (3, 9), "UZ_OP_CONV_BWD_DATA": (2, 8, 9), "UZ_OP_CONV_BWD_WEIGHT": (2, 3),
         "UZ_OP_BN_RELU_FWD": (3, 4, 5, 6), "UZ_OP_BN_RELU_BWD": (5, 6, 7, 8), "UZ_OP_RELU_BWD": (2, 3),
-        "UZ_OP_AVGPOOL_FWD": (1,), "UZ_OP_AVGPOOL_BWD": (1,), "UZ_OP_BILINEAR_FWD": (1,), "UZ_OP_BILINEAR_BWD": (1,),
+        "UZ_OP_AVGPOOL_FWD": (1,), "UZ_OP_AVGPOOL_BWD": (1, 3, 4), "UZ_OP_BILINEAR_FWD": (1,), "UZ_OP_BILINEAR_BWD": (1, 3, 4),
         "UZ_OP_NEAREST_FWD": (1,), "UZ_OP_NEAREST_BWD": (1,), "UZ_OP_SPATIAL_MEAN_FWD": (1,), "UZ_OP_SPATIAL_MEAN_BWD": (1,),
         "UZ_OP_POSTERIOR_INPUT": (2,), "UZ_OP_LATENT_FWD": (3, 4), "UZ_OP_LATENT_BWD": (5, 6),
         "UZ_OP_KL_FWD": (4,), "UZ_OP_KL_BWD": (5, 6, 7, 8), "UZ_OP_CE_FWD": (2,), "UZ_OP_CE_BWD": (1,),

@@ -625,6 +625,11 @@ extern "C" int uz_bn_relu_fwd_slabs(const float* slabs, int n_slabs, const float
                             training, relu, a_amax, nullptr, nullptr, 0, slabs, n_slabs, conv_bias, stream);
 }
 
+extern "C" int uz_chan_sum_partials_d(const double* partials, int n_rows, int C, float* out, void* stream) {
+    UZ_REQUIRE(partials && out && n_rows > 0 && C > 0, "chan_sum_partials_d: bad arguments");
+    hipLaunchKernelGGL(chan_partial_sum, dim3(uz::ceil_div(C, 4)), dim3(256), 0, uz::S(stream), partials, n_rows, C, out);
+    return uz::check_launch("chan_partial_sum");
+}
 extern "C" int uz_bn_relu_bwd(const float* da, int CtotDa, const float* y, int C, int CtotY,
                               const float* gamma, const float* beta, const float* save_mean_rstd,
                               float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,

@@ -18,7 +18,24 @@ struct RsP {
     int ac, factor, accumulate;
     float sh, sw;
     const float* x_amax; float* y_amax;   // forward pooling / interpolation are convex combinations: |y| <= bound of |x|
+    // backward kernels, optional: dst is the gradient w.r.t. the OUTPUT A of a Conv -> ReLU unit (vanilla U-Net blocks) and this launch
+    // is its last writer - apply the unit's ReLU mask (a > 0), leave per-workgroup sums for its bias gradient, publish max |dst|
+    const float* mask; int CtotM; double* part; float* m_amax;
 };
+struct ReluFold { float sd = 0.f, vmax = 0.f; };
+__device__ __forceinline__ float fold_value(const RsP& p, const float* mplane, int q, float v, ReluFold& f) {
+    if (p.mask) { v = mplane[q] > 0.f ? v : 0.f; f.sd += v; f.vmax = fmaxf(f.vmax, fabsf(v)); }
+    return v;
+}
+// (every thread of the workgroup calls this: it contains barriers) partial row = image * gridDim.x + blockIdx.x
+__device__ __forceinline__ void fold_finish(const RsP& p, int c, int b, const ReluFold& f) {
+    if (!p.mask) return;
+    __shared__ double fsm[4];
+    double v1[1] = {(double)f.sd};
+    uz::block_sum_d<1>(v1, fsm);
+    if (threadIdx.x == 0) p.part[((size_t)b * gridDim.x + blockIdx.x) * p.C + c] = v1[0];
+    if (p.m_amax) uz::amax_publish(f.vmax, p.m_amax);
+}
 
 // the output bound of a pooling / interpolation pass is its input's bound (one lane of the grid forwards it)
 __device__ __forceinline__ void forward_bound(const RsP& p) {
@@ -49,13 +66,16 @@ __global__ __launch_bounds__(256) void avgpool_bwd_k(const RsP p) {   // src = d
     const float* s = p.src + ((size_t)b * p.CtotS + c) * p.H * p.W;
     float* d = p.dst + ((size_t)b * p.CtotD + c) * p.Ho * p.Wo;
     const int n = p.Ho * p.Wo;
+    const float* mp = p.mask ? p.mask + ((size_t)b * p.CtotM + c) * n : nullptr;
+    ReluFold f;
     for (int q = blockIdx.x * PCH + threadIdx.x; q < min(n, (int)(blockIdx.x + 1) * PCH); q += 256) {
         const int y = q / p.Wo, x = q - y * p.Wo;
         const int oy = y >> 1, ox = x >> 1;
         const int cnt = (min(2 * oy + 2, p.Ho) - 2 * oy) * (min(2 * ox + 2, p.Wo) - 2 * ox);
         const float v = s[oy * p.W + ox] / (float)cnt;
-        d[q] = p.accumulate ? d[q] + v : v;
+        d[q] = fold_value(p, mp, q, p.accumulate ? d[q] + v : v, f);
     }
+    fold_finish(p, c, b, f);
 }
 
 // ---------------------------------------------------------------- bilinear x2
@@ -102,6 +122,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const RsP p) {   // src = 
     const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
     float* d = p.dst + ((size_t)b * p.CtotD + c) * p.H * p.W;
     const int n = p.H * p.W;
+    const float* mpl = p.mask ? p.mask + ((size_t)b * p.CtotM + c) * n : nullptr;
+    ReluFold fo;
     const bool tab = p.H <= BTAB && p.W <= BTAB;
     if (tab) {
         for (int e = threadIdx.x; e < (p.H + p.W) * 7; e += 256) {
@@ -131,8 +153,9 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const RsP p) {   // src = 
                 acc += wy[ky] * ra;
             }
         }
-        d[q] = p.accumulate ? d[q] + acc : acc;
+        d[q] = fold_value(p, mpl, q, p.accumulate ? d[q] + acc : acc, fo);
     }
+    fold_finish(p, c, b, fo);
 }
 
 // Band kernels for planes whose rows fit LDS (the layers that carry the traffic).  Bilinear interpolation is separable,
@@ -147,6 +170,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_sep_k(const RsP p) {   // sr
     const int c = blockIdx.y, b = blockIdx.z;
     const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
     float* d = p.dst + ((size_t)b * p.CtotD + c) * p.H * p.W;
+    const float* mpl = p.mask ? p.mask + ((size_t)b * p.CtotM + c) * p.H * p.W : nullptr;
+    ReluFold fo;
     // x pass straight from HBM: the KT taps of low-res column ix are the three aligned float2 at high-res columns 2 ix - 2 ..
     // 2 ix + 3 (a pair is entirely inside or outside the row because Wo is even); consecutive lanes read consecutive pairs,
     // so each of the three loads of a wave is one contiguous 512-byte run and the overlap is served by the vector L1
@@ -186,10 +211,11 @@ __global__ __launch_bounds__(256) void bilinear_bwd_sep_k(const RsP p) {   // sr
 #pragma unroll
             for (int k = 0; k < KT; ++k) acc += wy[k] * col[k * p.W];
             float* dst = d + (size_t)(iy0 + il) * p.W + ix;
-            *dst = p.accumulate ? *dst + acc : acc;
+            *dst = fold_value(p, mpl, (iy0 + il) * p.W + ix, p.accumulate ? *dst + acc : acc, fo);
         }
         __syncthreads();                                          // tx / wyT are rewritten by the next band
     }
+    fold_finish(p, c, b, fo);
 }
 
 // Forward: a workgroup produces OB output rows of one plane from the <= OB / 2 + 2 source rows they touch (staged in LDS by
@@ -317,11 +343,29 @@ extern "C" int uz_avgpool2_fwd(const float* x, int C, int CtotX, float* y, int C
     p.Ho = H; p.Wo = W; p.H = (H + 1) / 2; p.W = (W + 1) / 2;
     RS_LAUNCH(avgpool_fwd_k, p.H * p.W);
 }
-extern "C" int uz_avgpool2_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int accumulate, void* stream) {
+static int avgpool2_bwd_impl(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int accumulate,
+                             const float* a, int CtotA, double* part, float* dx_amax, void* stream) {
     if (int rc = check_dims("avgpool2_bwd", C, N, H, W)) return rc;
     RsP p = {}; p.src = dy; p.dst = dx; p.C = C; p.CtotS = CtotDy; p.CtotD = CtotDx; p.N = N;
     p.Ho = H; p.Wo = W; p.H = (H + 1) / 2; p.W = (W + 1) / 2; p.accumulate = accumulate;
+    p.mask = a; p.CtotM = CtotA; p.part = part; p.m_amax = dx_amax;
     RS_LAUNCH(avgpool_bwd_k, H * W);
+}
+extern "C" int uz_avgpool2_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int accumulate, void* stream) {
+    return avgpool2_bwd_impl(dy, C, CtotDy, dx, CtotDx, N, H, W, accumulate, nullptr, 0, nullptr, nullptr, stream);
+}
+// the grid's x extent of the backward kernels = partial rows per image of the *_bwd_relu entry points (kind 0: avgpool2, H x W = the
+// HIGH-resolution plane; kind 1: bilinear2x, H x W = the LOW-resolution plane)
+static int resample_bwd_gx(int kind, int C, int N, int H, int W) {
+    if (kind == 0) return uz::ceil_div(H * W, PCH);
+    if (2 * W <= BWMAX && H >= 4 && 256 % W == 0) return (long long)C * N >= 2048 ? 1 : uz::ceil_div(H, LB);
+    return uz::ceil_div(H * W, PCH);
+}
+extern "C" int uz_resample_bwd_relu_rows(int kind, int C, int N, int H, int W) { return N * resample_bwd_gx(kind, C, N, H, W); }
+extern "C" int uz_avgpool2_bwd_relu(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int accumulate,
+                                    const float* a, int CtotA, double* partials, float* dx_amax, void* stream) {
+    UZ_REQUIRE(a && partials, "avgpool2_bwd_relu: needs the activation and the partial-sum rows");
+    return avgpool2_bwd_impl(dy, C, CtotDy, dx, CtotDx, N, H, W, accumulate, a, CtotA, partials, dx_amax, stream);
 }
 static void bil_scales(RsP& p) {
     if (p.ac) { p.sh = p.Ho > 1 ? (float)(p.H - 1) / (float)(p.Ho - 1) : 0.f; p.sw = p.Wo > 1 ? (float)(p.W - 1) / (float)(p.Wo - 1) : 0.f; }
@@ -339,10 +383,23 @@ extern "C" int uz_bilinear2x_fwd(const float* x, int C, int CtotX, float* y, int
     }
     RS_LAUNCH(bilinear_fwd_k, p.Ho * p.Wo);
 }
+static int bilinear2x_bwd_impl(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int align_corners, int accumulate,
+                               const float* a, int CtotA, double* part, float* dx_amax, void* stream);
 extern "C" int uz_bilinear2x_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int align_corners, int accumulate, void* stream) {
+    return bilinear2x_bwd_impl(dy, C, CtotDy, dx, CtotDx, N, H, W, align_corners, accumulate, nullptr, 0, nullptr, nullptr, stream);
+}
+extern "C" int uz_bilinear2x_bwd_relu(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int align_corners, int accumulate,
+                                      const float* a, int CtotA, double* partials, float* dx_amax, void* stream) {
+    UZ_REQUIRE(a && partials, "bilinear2x_bwd_relu: needs the activation and the partial-sum rows");
+    UZ_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 7) == 0, "bilinear2x_bwd_relu: dy must be 8-byte aligned");      // (keeps the kernel choice = uz_resample_bwd_relu_rows)
+    return bilinear2x_bwd_impl(dy, C, CtotDy, dx, CtotDx, N, H, W, align_corners, accumulate, a, CtotA, partials, dx_amax, stream);
+}
+static int bilinear2x_bwd_impl(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int align_corners, int accumulate,
+                               const float* a, int CtotA, double* part, float* dx_amax, void* stream) {
     if (int rc = check_dims("bilinear2x_bwd", C, N, H, W)) return rc;
     RsP p = {}; p.src = dy; p.dst = dx; p.C = C; p.CtotS = CtotDy; p.CtotD = CtotDx; p.N = N;
     p.H = H; p.W = W; p.Ho = 2 * H; p.Wo = 2 * W; p.ac = align_corners; p.accumulate = accumulate; bil_scales(p);
+    p.mask = a; p.CtotM = CtotA; p.part = part; p.m_amax = dx_amax;
     if (p.Wo <= BWMAX && p.H >= 4 && 256 % p.W == 0 && (reinterpret_cast<uintptr_t>(dy) & 7) == 0) {
         // Wo is even: an 8-byte aligned view keeps every float2 of every row aligned
         // enough planes to fill the chip: one workgroup per plane walks its bands (2.8 -> 3.3 TB/s on 192 ch 64^2 -> 128^2, 3.1 -> 3.75 on 32^2)

@@ -88,10 +88,12 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_AVGPOOL_FWD:
             return uz_avgpool2_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], CFP(2), FP(3), st);
         case UZ_OP_AVGPOOL_BWD:
+            if (p[2]) return uz_avgpool2_bwd_relu(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], CFP(2), i[7], static_cast<double*>(p[3]), FP(4), st);
             return uz_avgpool2_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], st);
         case UZ_OP_BILINEAR_FWD:
             return uz_bilinear2x_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], CFP(2), FP(3), st);
         case UZ_OP_BILINEAR_BWD:
+            if (p[2]) return uz_bilinear2x_bwd_relu(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], i[7], CFP(2), i[8], static_cast<double*>(p[3]), FP(4), st);
             return uz_bilinear2x_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], i[7], st);
         case UZ_OP_NEAREST_FWD:
             return uz_nearest_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], st);
@@ -130,7 +132,7 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_L2_NORMS_BWD:
             return uz_l2_norms_bwd(CFP(0), static_cast<const int64_t*>(p[1]), i[0], CFP(2), CFP(3), FP(4), st);
         case UZ_OP_CHAN_SUM_PARTIALS:
-            return uz_chan_sum_partials(CFP(0), i[0], i[1], FP(1), st);
+            return i[2] ? uz_chan_sum_partials_d(static_cast<const double*>(p[0]), i[0], i[1], FP(1), st) : uz_chan_sum_partials(CFP(0), i[0], i[1], FP(1), st);
         case UZ_OP_PACK_WEIGHTS:
             return uz_conv_pack_weights(static_cast<const int64_t*>(p[0]), i[0], i[1], CFP(1), st);
         case UZ_OP_MEMSET:
