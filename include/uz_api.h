@@ -135,6 +135,8 @@ int uz_avgpool2_bwd_relu(const float* dy, int C, int CtotDy, float* dx, int Ctot
 int uz_bilinear2x_bwd_relu(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int align_corners, int accumulate,
                            const float* a, int CtotA, double* partials, float* dx_amax, void* stream);
 int uz_chan_sum_partials_d(const double* partials, int n_rows, int C, float* out, void* stream);
+/* every bias gradient of a tape in one launch: table = n_entries rows of 5 int64 {partials pointer, out pointer, n_rows, C, partials are double} */
+int uz_chan_sum_table(const int64_t* table, int n_entries, int max_channels, void* stream);
 /* autograd w.r.t. the weight: dw[co,ci,tap] = sum_{b,y,x} dy * x_shifted.
  * Deterministic split-K: partial slabs in `workspace` (uz_conv_bwd_weight_workspace
  * bytes), then an ordered reduction.  db (nullable) = sum_{b,y,x} dy.
@@ -336,6 +338,7 @@ enum {
   UZ_OP_ADD_VIEWS,       /* p = a, b, y, a_amax, b_amax, y_amax; i = CtotA, CtotB, CtotY, C, N, H, W, accumulate; f[0] = alpha */
   UZ_OP_EVENT_RECORD,    /* p[0] = event (uz_event_create): marks "every earlier op this one depends on is done" */
   UZ_OP_PACK_WEIGHTS,    /* p[0] = table, p[1] = w_amax; i = n_layers, total_rows (uz_conv_pack_weights); CONV_FWD p[8] / CONV_BWD_DATA p[6] = image */
+  UZ_OP_CHAN_SUM_TABLE,    /* p[0] = table (uz_chan_sum_table), p[1] = the gradient regions it writes; i = n_entries, max_channels */
   UZ_OP_CHAN_SUM_PARTIALS, /* p = partials, out; i = n_rows, C (uz_chan_sum_partials); CONV_BWD_DATA p[7] = a (folded ReLU backward), p[8] = partials, p[9] = dx bound; i[9] = CtotA */
   UZ_OP__COUNT
 };

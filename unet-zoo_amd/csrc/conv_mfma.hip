@@ -550,6 +550,30 @@ __global__ __launch_bounds__(256) void chan_sum_partials_k(const float* __restri
     if (lane == 0) out[c] = (float)s;
 }
 }  // namespace
+namespace {
+// all bias gradients of a tape in ONE launch: table rows {partials, out, n_rows, C, is_double}; blockIdx.y = row, one wave per channel
+__global__ __launch_bounds__(256) void chan_sum_table_k(const long long* __restrict__ table) {
+    const long long* e = table + 5 * blockIdx.y;
+    const int nrows = (int)e[2], C = (int)e[3];
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0;
+    if (e[4]) {
+        const double* part = reinterpret_cast<const double*>(e[0]);
+        for (int i = lane; i < nrows; i += 64) s += part[(size_t)i * C + c];
+    } else {
+        const float* part = reinterpret_cast<const float*>(e[0]);
+        for (int i = lane; i < nrows; i += 64) s += (double)part[((size_t)i * C + c) * 4];
+    }
+    s = uz::wave_sum_d(s);
+    if (lane == 0) reinterpret_cast<float*>(e[1])[c] = (float)s;
+}
+}  // namespace
+extern "C" int uz_chan_sum_table(const int64_t* table, int n_entries, int max_channels, void* stream) {
+    UZ_REQUIRE(table && n_entries > 0 && n_entries <= 65535 && max_channels > 0, "chan_sum_table: bad arguments");
+    hipLaunchKernelGGL(chan_sum_table_k, dim3(uz::ceil_div(max_channels, 4), n_entries), dim3(256), 0, uz::S(stream), reinterpret_cast<const long long*>(table));
+    return uz::check_launch("chan_sum_table_k");
+}
 extern "C" int uz_conv_bwd_relu_partials(int Cin, int Cout, int N, int H, int W, int ks) {
     if (ks != 3 || !uz::conv_split_ok(Cout, Cin, N, H, W, ks, 1)) return 0;
     return uz::conv_split_bn_partials(Cout, Cin, N, H, W);          // 0 when the chunk loop is split over workgroups

@@ -131,6 +131,8 @@ static int run_one(const uz_op& o, void* st) {
             return uz_l2_norms(CFP(0), static_cast<const int64_t*>(p[1]), i[0], FP(2), st);
         case UZ_OP_L2_NORMS_BWD:
             return uz_l2_norms_bwd(CFP(0), static_cast<const int64_t*>(p[1]), i[0], CFP(2), CFP(3), FP(4), st);
+        case UZ_OP_CHAN_SUM_TABLE:
+            return uz_chan_sum_table(static_cast<const int64_t*>(p[0]), i[0], i[1], st);
         case UZ_OP_CHAN_SUM_PARTIALS:
             return i[2] ? uz_chan_sum_partials_d(static_cast<const double*>(p[0]), i[0], i[1], FP(1), st) : uz_chan_sum_partials(CFP(0), i[0], i[1], FP(1), st);
         case UZ_OP_PACK_WEIGHTS:
