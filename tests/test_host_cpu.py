@@ -184,3 +184,25 @@ def test_initialisers_match_reference_moments(which):
             w = v.detach().double().reshape(v.shape[0], -1)
             gm = w @ w.t() if w.shape[0] <= w.shape[1] else w.t() @ w
             assert float((gm - torch.eye(gm.shape[0], dtype=torch.float64)).abs().max()) <= 1e-5, k
+
+
+def test_unet_plan_folds_the_relu_backward_into_the_last_writer_of_dA(monkeypatch):
+    """Plan-level view of the folded ReLU backward: in the vanilla U-Net at BASELINE size every Conv -> ReLU unit
+    whose dA is last written by a split-path data gradient, a pooling or an interpolation backward loses its uz_relu_bwd op; the bias
+    gradients come from ONE table-driven launch - or from one launch per unit under data parallelism, where a bucket's gradients must
+    be final when its all-reduce starts; UZ_FOLD_RELU_BWD=0 restores the plain tape.  The lane schedule stays dependency-correct."""
+    from unet_zoo_amd.models.unet import Unet
+    count = lambda plan, code: sum(o["code"] == code for o in plan.bwd_ops)
+    net = Unet(1, 2, [32, 64, 128, 192], device="cpu")
+    plan = net._build(32, 128, 128)
+    n_units = sum(o["code"] == "UZ_OP_CONV_FWD" and o["i"][8] == 1 for o in plan.fwd_ops)          # convolutions with the fused forward ReLU
+    assert n_units == 21
+    assert count(plan, "UZ_OP_RELU_BWD") == 1 and count(plan, "UZ_OP_CHAN_SUM_TABLE") == 1 and count(plan, "UZ_OP_CHAN_SUM_PARTIALS") == 0
+    folded = [o for o in plan.bwd_ops if o["code"] in ("UZ_OP_CONV_BWD_DATA", "UZ_OP_AVGPOOL_BWD", "UZ_OP_BILINEAR_BWD") and len(o["p"]) > 7 - 5 * (o["code"] != "UZ_OP_CONV_BWD_DATA")]
+    assert len(folded) == 20
+    monkeypatch.setenv("UZ_LANES", "2")
+    plan2 = Unet(1, 2, [32, 64, 128, 192], device="cpu")._build(32, 128, 128)
+    _check_lane_schedule(plan2, "bwd", plan2.bwd_ops)
+    monkeypatch.setenv("UZ_FOLD_RELU_BWD", "0")
+    plain = Unet(1, 2, [32, 64, 128, 192], device="cpu")._build(32, 128, 128)
+    assert count(plain, "UZ_OP_RELU_BWD") == 21 and count(plain, "UZ_OP_CHAN_SUM_TABLE") == 0
