@@ -310,30 +310,39 @@ def fp32_only_leg(args):
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, torchrun's environment
     contract) and relay rank 0's JSON line.  Runs BEFORE this process makes any GPU call - the children are new processes,
-    never a re-exec of a GPU-initialised one."""
+    never a re-exec of a GPU-initialised one.
+
+    Every rank is watched: one that dies (RCCL init, out of memory) leaves its peers waiting in a collective forever, and one
+    that hangs INSIDE ncclCommInitRank / a collective never exits at all.  So (a) a non-zero exit stops the survivors at once,
+    (b) a wall-clock deadline (UZ_BENCH_DEADLINE_S, default 900 s; the driver's own default run finishes in well under a minute
+    per GPU count) stops everything when rank 0 has not finished by then - in both cases the command exits non-zero with every
+    rank's exit code and the tail of its stderr in the message instead of hanging until the caller's timeout."""
     import socket
+    import tempfile
+    import threading
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    deadline_s = float(os.environ.get("UZ_BENCH_DEADLINE_S", "900"))
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UZ_BENCH_SELF_LAUNCHED="1")
+        ef = tempfile.TemporaryFile(mode="w+", prefix=f"uz_bench_rank{r}_")      # every rank's stderr is kept (a file: no pipe to fill up)
+        errs.append(ef)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    # rank 0's stdout is drained by a thread while every rank is watched: a rank that dies (RCCL init, out of memory) leaves its
-    # peers waiting in a collective forever - then the survivors are killed and the failure is reported instead of a hang
-    import threading
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=ef, text=True))
     chunks = []
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
-    failed = None
-    while failed is None and any(q.poll() is None for q in procs):
+    failed, timed_out, t0 = None, False, time.monotonic()
+    while failed is None and not timed_out and any(q.poll() is None for q in procs):
         for r, q in enumerate(procs):
             if q.poll() not in (None, 0):
                 failed = r
+        timed_out = time.monotonic() - t0 > deadline_s
         time.sleep(0.2)
-    if failed is not None:
+    if failed is not None or timed_out:
         for q in procs:
             if q.poll() is None:
                 q.kill()
@@ -341,9 +350,22 @@ def launch_ranks(n, argv):
     reader.join(timeout=10)
     sys.stdout.write("".join(c for c in chunks if c))
     sys.stdout.flush()
-    if failed is not None:
-        print(f"bench.py: rank {failed} exited with code {rcs[failed]}; the other ranks were stopped", file=sys.stderr)
-    return max(abs(rc) for rc in rcs)
+
+    def tail(f, lines=12):
+        f.seek(0)
+        return "".join(f.readlines()[-lines:])
+    if failed is not None or timed_out:
+        what = (f"rank {failed} exited with code {rcs[failed]}; the other ranks were stopped" if failed is not None
+                else f"no result after {deadline_s:.0f} s (UZ_BENCH_DEADLINE_S): every rank was stopped")
+        print(f"bench.py: {what}", file=sys.stderr)
+        for r, f in enumerate(errs):
+            t = tail(f)
+            print(f"---- rank {r}: exit code {rcs[r]}, stderr tail:\n{t if t else '(empty)'}", file=sys.stderr)
+    else:
+        sys.stderr.write(tail(errs[0], 50))                  # rank 0's own diagnostics (warnings) are passed through
+    for f in errs:
+        f.close()
+    return 1 if timed_out else max(abs(rc) for rc in rcs)
 
 
 def dry_run(args, rank, world, global_batch):
@@ -352,7 +374,11 @@ def dry_run(args, rank, world, global_batch):
     import torch
     import torch.distributed as dist
     if os.environ.get("UZ_BENCH_DRY_FAIL_RANK") == str(rank):      # test hook: a rank that dies before the rendezvous
+        print(f"dry run: rank {rank} fails on purpose", file=sys.stderr)
         sys.exit(3)
+    if os.environ.get("UZ_BENCH_DRY_HANG_RANK") == str(rank):      # test hook: a rank stuck before the rendezvous (as inside ncclCommInitRank)
+        print(f"dry run: rank {rank} hangs on purpose", file=sys.stderr, flush=True)
+        time.sleep(3600)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)

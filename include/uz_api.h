@@ -199,6 +199,54 @@ int uz_relu_bwd(const float* da, int CtotDa, const float* a, int C, int CtotA,
                 float* dy, int CtotDy, float* dbias,
                 int N, int H, int W, float* dy_amax, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------- split storage + folded BatchNorm backward (round 4)
+ * Conv2D unit = Conv2d -> BatchNorm2d -> ReLU (torchlayers.py:18-21), 106 of them per PHiSeg step.  Two things the producer of
+ * a tensor can do for the matrix kernels that consume it:
+ *
+ * Split storage.  A tensor whose bound is known BEFORE its first element is written (BatchNorm forward: exact output range from
+ * the statistics; BatchNorm backward: analytic bound; pooling / interpolation: the input's bound) may be stored as one 32-bit
+ * word per element holding the two fp16 pieces of v * s (low half h1 = fp16(v s), high half h2 = fp16(v s - h1), s = the power of
+ * two the split kernels derive from the bound slot) - the operand pieces the consuming convolution would otherwise form from the
+ * fp32 value in its staging (scale, clamp, two conversions, subtract, convert per element).  Same bytes, same values
+ * (h1 + h2 = v s to 2^-22); the `out_packed` producers below write it, the `*_packed` flags of the convolution calls read it.
+ * A concat buffer with two producers carries two bounds: channels [0, seg_channels) were scaled from x_amax, the rest from
+ * x_amax2 (seg_channels a multiple of 16; 0 = one bound).  uz_pack_split / uz_unpack_split convert whole tensors (tests, tools).
+ *
+ * Folded backward reduction.  The data gradient that writes dA of a unit LAST can apply the unit's ReLU mask (alpha y + beta' > 0)
+ * and leave the unit's BatchNorm-backward sums {sum dz, sum dz x_hat, max |dz|, max |x_hat|} per (tile, channel) in its epilogue
+ * (bn_y = the unit's pre-normalisation output, bn_save = the 4 C floats uz_bn_relu_fwd_ex saved); uz_bn_relu_bwd_ex then runs a
+ * one-workgroup-per-channel finalise instead of the reduction pass over dA and y.  uz_conv_bwd_relu_partials() gives the number of
+ * partial rows (0: shape not supported).                                                                                       */
+int uz_pack_split(const float* x, float* packed, size_t n, const float* amax, void* stream);
+int uz_unpack_split(const float* packed, float* x, size_t n, const float* amax, void* stream);
+int uz_bn_relu_fwd_ex(const float* y, int C, int CtotY, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float* save_mean_rstd_ab,
+                      float* a, int CtotA, int N, int H, int W, float eps, float momentum,
+                      int training, int relu, float* a_amax, void* workspace,
+                      const float* conv_partials, int n_partials, int out_packed, void* stream);
+int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, int C, int CtotY,
+                      const float* gamma, const float* beta, const float* save_mean_rstd,
+                      float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
+                      int N, int H, int W, int relu, float* dy_amax, void* workspace,
+                      const float* conv_partials, int n_partials, int out_packed, void* stream);
+int uz_avgpool2_fwd_ex(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W,
+                       const float* x_amax, float* y_amax, int out_packed, void* stream);
+int uz_bilinear2x_fwd_ex(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W, int align_corners,
+                         const float* x_amax, float* y_amax, int out_packed, void* stream);
+int uz_conv_fwd_ex(const float* x, int Cin, int CinTot, const float* w, const float* bias,
+                   float* y, int Cout, int CoutTot, int N, int H, int W, int ks, int relu,
+                   const float* x_amax, const float* w_amax, float* y_amax,
+                   void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials,
+                   int x_packed, const float* x_amax2, int seg_channels, void* stream);
+int uz_conv_bwd_data_ex(const float* dy, int Cout, int CoutTot, const float* w, float* dx, int Cin, int CinTot,
+                        int N, int H, int W, int ks, int accumulate, const float* dy_amax, const float* w_amax,
+                        void* workspace, size_t workspace_bytes, const void* packed_w, int dy_packed,
+                        const float* bn_y, int bn_yCtot, const float* bn_save, int bn_relu, float* bn_partials, void* stream);
+int uz_conv_bwd_weight_ex(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
+                          float* dw, float* db, int N, int H, int W, int ks,
+                          const float* x_amax, const float* dy_amax, void* workspace, size_t workspace_bytes,
+                          int x_packed, const float* x_amax2, int seg_channels, int dy_packed, void* stream);
+
 /* ---------------------------------------------------------------- resampling
  * nn.AvgPool2d(2, 2, padding=0, ceil_mode=True): phiseg.py:23, unet.py:22,
  * probabilistic_unet.py:56.  Ho = ceil(H/2); partial windows divide by the

@@ -180,3 +180,20 @@ def test_bench_launcher_stops_the_survivors_when_a_rank_dies():
                        capture_output=True, text=True, timeout=240)
     assert r.returncode != 0 and "rank 1 exited with code 3" in r.stderr, (r.returncode, r.stderr[-400:])
     assert time.time() - t0 < 200
+
+
+def test_bench_launcher_deadline_stops_a_hung_rank():
+    """A rank stuck inside communicator set-up never exits: the launcher's wall-clock deadline (UZ_BENCH_DEADLINE_S) must stop every
+    rank and fail with each rank's exit code and stderr tail instead of waiting for the caller's timeout."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(UZ_BENCH_DRY="1", UZ_BENCH_DRY_HANG_RANK="1", UZ_BENCH_DEADLINE_S="20")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "no result after 20 s" in r.stderr and "rank 1 hangs on purpose" in r.stderr and "---- rank 0" in r.stderr, r.stderr[-600:]
+    assert time.time() - t0 < 120

@@ -1,0 +1,256 @@
+"""Round-4 entry points of the Conv2D unit (Conv2d -> BatchNorm2d -> ReLU, reference torchlayers.py:18-21) through the C ABI:
+
+  * split storage - a producer that knows its tensor's bound beforehand (BatchNorm apply forward / backward, pooling, bilinear
+    interpolation) writes each element as the two fp16 pieces of its scaled value; the split-fp16 convolutions read that directly;
+  * the BatchNorm-backward reduction folded into the epilogue of the data gradient that writes dA.
+
+Every case is checked against the SAME chain through the fp32-storage entry points (must agree to the split's own 2^-22) and against
+a plain torch fp32 reference of the unit (gate 3e-5 of the largest magnitude, the convolution gate of test_ops_gpu.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _g():
+    from tests import _gpu
+    return _gpu
+
+
+def _lib():
+    from unet_zoo_amd import _ffi
+    return _ffi.lib()
+
+
+def _need_split():
+    if _lib().uz_get_conv_math() in (0, 3):
+        pytest.skip("split storage is the two-piece fp16 format: not used in the fp32-only / bf16 math modes")
+
+
+def _slot(v=0.0):
+    t = torch.zeros(256, device=_g().dev())
+    t[0] = v
+    return t
+
+
+def _unpack(packed, slot):
+    g = _g()
+    out = torch.empty_like(packed)
+    g.call("uz_unpack_split", packed.contiguous(), out, packed.numel(), slot)
+    return out
+
+
+def test_pack_unpack_roundtrip():
+    g = _g()
+    x = g.rnd(3, 7, 33, 20, seed=4) * 3.0
+    x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1e-6, -2.5e-7])
+    xd = x.to(g.dev())
+    slot = _slot(float(x.abs().max()))
+    pk = torch.empty_like(xd)
+    g.call("uz_pack_split", xd, pk, xd.numel(), slot)
+    back = _unpack(pk, slot)
+    amax = float(x.abs().max())
+    err = (back.cpu().double() - x.double()).abs()
+    assert float((err - (2.0 ** -22) * x.double().abs()).max()) <= 2.0 ** -38 * amax       # |r| <= 2^-22 |v| (+ the fp16 subnormal floor)
+    assert float(back[0, 0, 0, 0]) == 0.0 and float(back[0, 0, 0, 1]) == 0.0
+    # packing what was unpacked reproduces the value (h1 + h2 is exactly representable in fp32)
+    pk2 = torch.empty_like(xd)
+    g.call("uz_pack_split", back, pk2, xd.numel(), slot)
+    assert torch.equal(_unpack(pk2, slot), back)
+
+
+UNIT_CASES = [(8, 64, 96, 64, 64), (32, 64, 64, 32, 32), (4, 96, 64, 37, 64), (2, 32, 32, 128, 128)]
+
+
+@pytest.mark.parametrize("N,C1,C2,H,W", UNIT_CASES)
+def test_two_units_forward_and_weight_gradient_with_split_storage(N, C1, C2, H, W):
+    """conv1 (+ statistics in the epilogue) -> BatchNorm apply writing split storage -> conv2 forward and weight gradient reading it."""
+    _need_split()
+    g, L = _g(), _lib()
+    C0 = 40
+    if L.uz_conv_route(0, C1, C2, N, H, W, 3) != 1 or L.uz_conv_route(2, C1, C2, N, H, W, 3) != 1 or L.uz_conv_bn_partials(C0, C1, N, H, W, 3) <= 0:
+        pytest.skip("shape off the split path in this math mode")
+    x = g.rnd(N, C0, H, W, seed=1)
+    w1, b1 = g.rnd(C1, C0, 3, 3, seed=2, scale=0.1), g.rnd(C1, seed=3)
+    w2, b2 = g.rnd(C2, C1, 3, 3, seed=4, scale=0.1), g.rnd(C2, seed=5)
+    gamma, beta = g.rnd(C1, seed=6).abs() + 0.5, g.rnd(C1, seed=7) * 0.3
+    dy2 = g.rnd(N, C2, H, W, seed=8)
+    # torch reference
+    y1r = F.conv2d(x, w1, b1, padding=1)
+    a1r = F.relu(F.batch_norm(y1r, None, None, gamma, beta, training=True, eps=1e-3)).requires_grad_(True)
+    w2r = w2.clone().requires_grad_(True)
+    y2r = F.conv2d(a1r, w2r, b2, padding=1)
+    y2r.backward(dy2)
+    d = g.dev()
+    xd, w1d, b1d, w2d, b2d, gd, bd, dy2d = (t.to(d) for t in (x, w1, b1, w2, b2, gamma, beta, dy2))
+    npart = L.uz_conv_bn_partials(C0, C1, N, H, W, 3)
+    wsb = max(L.uz_conv_workspace(C0, C1, N, H, W, 3), L.uz_conv_workspace(C1, C2, N, H, W, 3), L.uz_conv_bwd_weight_workspace(C1, C2, N, H, W, 3))
+    ws = torch.empty(wsb // 4 + 64, device=d)
+    bws = torch.empty(L.uz_bn_workspace(C1, N, H, W) // 4 + 16, device=d)
+    y1 = torch.empty(N, C1, H, W, device=d)
+    part = torch.empty(npart * C1 * 4, device=d)
+    g.call("uz_conv_fwd_bnstats", xd, C0, C0, w1d, b1d, y1, C1, C1, N, H, W, 3, 0, None, None, None, ws, wsb, None, part)
+    res = {}
+    for packed in (0, 1):
+        a1 = torch.full((N, C1, H, W), float("nan"), device=d)
+        save = torch.full((4 * C1,), float("nan"), device=d)
+        slot = _slot()
+        g.call("uz_bn_relu_fwd_ex", y1, C1, C1, gd, bd, None, None, save, a1, C1, N, H, W, 1e-3, 0.01, 1, 1, slot, bws, part, npart, packed)
+        y2 = torch.empty(N, C2, H, W, device=d)
+        g.call("uz_conv_fwd_ex", a1, C1, C1, w2d, b2d, y2, C2, C2, N, H, W, 3, 0, slot, None, None, ws, wsb, None, None, packed, None, 0)
+        dw2 = torch.empty(C2, C1, 3, 3, device=d)
+        g.call("uz_conv_bwd_weight_ex", a1, C1, C1, dy2d, C2, C2, dw2, None, N, H, W, 3, slot, None, ws, wsb, packed, None, 0, 0)
+        res[packed] = (a1, y2, dw2, slot, save)
+    a_f32, y2_f32, dw_f32, slot0, save0 = res[0]
+    a_pk, y2_pk, dw_pk, slot1, save1 = res[1]
+    assert torch.equal(slot0, slot1)                                   # same exact bound either way
+    assert torch.isfinite(save1).all()                                # mean, rstd, alpha, beta'
+    alpha = gamma.double() * save1[C1:2 * C1].cpu().double()
+    assert float((save1[2 * C1:3 * C1].cpu().double() - alpha).abs().max()) <= 1e-6 * float(alpha.abs().max())
+    # the stored words decode to the fp32 activation within the split's 2^-22
+    dec = _unpack(a_pk, slot1)
+    amax = float(a_f32.abs().max())
+    assert float((dec - a_f32).abs().max()) <= 2.0 ** -21 * amax
+    assert g.maxabs(dec, a1r) <= 3e-5 * max(1.0, amax)
+    # consumers: the same operand pieces (up to ties of the first rounding) -> the same results
+    assert g.relerr(y2_pk, y2_f32) <= 2e-6 and g.relerr(dw_pk, dw_f32) <= 2e-6
+    assert g.relerr(y2_pk, y2r) <= 3e-5 and g.relerr(dw_pk, w2r.grad) <= 3e-5
+
+
+def test_concat_buffer_with_two_scale_segments():
+    """A concat buffer written by two producers, each scaling from its own bound (phiseg.py:315: torch.cat of the up-sampled coarse
+    features and the level's own): BatchNorm apply into channels [0, 32), bilinear interpolation into [32, 80) with a 64 x larger
+    magnitude; the consuming convolution switches scales at channel 32 (forward: accumulators rescaled at the chunk boundary;
+    weight gradient: per input channel)."""
+    _need_split()
+    g, L = _g(), _lib()
+    N, CA, CB, C2, H, W = 8, 32, 48, 64, 64, 64
+    C = CA + CB
+    if L.uz_conv_route(0, C, C2, N, H, W, 3) != 1 or L.uz_conv_route(2, C, C2, N, H, W, 3) != 1:
+        pytest.skip("shape off the split path in this math mode")
+    d = g.dev()
+    C0 = 32
+    x = g.rnd(N, C0, H, W, seed=11)
+    w1 = g.rnd(CA, C0, 3, 3, seed=12, scale=0.1)
+    gamma, beta = g.rnd(CA, seed=13).abs() + 0.5, g.rnd(CA, seed=14) * 0.3
+    low = g.rnd(N, CB, H // 2, W // 2, seed=15) * 64.0
+    w2, dy2 = g.rnd(C2, C, 3, 3, seed=16, scale=0.05), g.rnd(N, C2, H, W, seed=17)
+    y1r = F.conv2d(x, w1, None, padding=1)
+    ar = F.relu(F.batch_norm(y1r, None, None, gamma, beta, training=True, eps=1e-3))
+    upr = F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=True)
+    catr = torch.cat([ar, upr], 1).requires_grad_(True)
+    w2r = w2.clone().requires_grad_(True)
+    y2r = F.conv2d(catr, w2r, None, padding=1)
+    y2r.backward(dy2)
+
+    npart = L.uz_conv_bn_partials(C0, CA, N, H, W, 3)
+    assert npart > 0
+    wsb = max(L.uz_conv_workspace(C0, CA, N, H, W, 3), L.uz_conv_workspace(C, C2, N, H, W, 3), L.uz_conv_bwd_weight_workspace(C, C2, N, H, W, 3))
+    ws = torch.empty(wsb // 4 + 64, device=d)
+    bws = torch.empty(L.uz_bn_workspace(CA, N, H, W) // 4 + 16, device=d)
+    y1 = torch.empty(N, CA, H, W, device=d)
+    part = torch.empty(npart * CA * 4, device=d)
+    g.call("uz_conv_fwd_bnstats", x.to(d), C0, C0, w1.to(d), None, y1, CA, CA, N, H, W, 3, 0, None, None, None, ws, wsb, None, part)
+    cat = torch.full((N, C, H, W), float("nan"), device=d)
+    save = torch.empty(4 * CA, device=d)
+    sA, sB, sLow = _slot(), _slot(), _slot(float(low.abs().max()))
+    g.call("uz_bn_relu_fwd_ex", y1, CA, CA, gamma.to(d), beta.to(d), None, None, save, cat, C, N, H, W, 1e-3, 0.01, 1, 1, sA, bws, part, npart, 1)
+    g.call("uz_bilinear2x_fwd_ex", low.to(d), CB, CB, cat[:, CA:], C, N, H // 2, W // 2, 1, sLow, sB, 1)
+    assert float(sB.max()) == float(sLow.max()) and float(sB.max()) > 16 * float(sA.max())
+    decA = _unpack(cat[:, :CA].contiguous(), sA)
+    decB = _unpack(cat[:, CA:].contiguous(), sB)
+    assert g.maxabs(decA, ar) <= 3e-5 * float(ar.abs().max()) and g.maxabs(decB, upr) <= 3e-5 * float(upr.abs().max())
+    y2 = torch.empty(N, C2, H, W, device=d)
+    g.call("uz_conv_fwd_ex", cat, C, C, w2.to(d), None, y2, C2, C2, N, H, W, 3, 0, sA, None, None, ws, wsb, None, None, 1, sB, CA)
+    dw2 = torch.empty(C2, C, 3, 3, device=d)
+    g.call("uz_conv_bwd_weight_ex", cat, C, C, dy2.to(d), C2, C2, dw2, None, N, H, W, 3, sA, None, ws, wsb, 1, sB, CA, 0)
+    assert g.relerr(y2, y2r) <= 3e-5
+    # per input-channel block: the small-magnitude segment keeps its own precision
+    for lo, hi in ((0, CA), (CA, C)):
+        assert g.relerr(dw2[:, lo:hi], w2r.grad[:, lo:hi]) <= 3e-5
+    # the fp32-storage path on the decoded concat gives the same numbers
+    catf = torch.cat([decA, decB], 1).contiguous()
+    y2f = torch.empty_like(y2)
+    g.call("uz_conv_fwd", catf, C, C, w2.to(d), None, y2f, C2, C2, N, H, W, 3, 0, None, None, None, ws, wsb)
+    assert g.relerr(y2, y2f) <= 5e-6
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (33, 36)])
+def test_pooling_writes_split_storage(H, W):
+    _need_split()
+    g = _g()
+    N, C = 4, 6
+    x = g.rnd(N, C, H, W, seed=21) * 5
+    ref = F.avg_pool2d(x, 2, 2, ceil_mode=True)
+    d = g.dev()
+    sx, sy = _slot(float(x.abs().max())), _slot()
+    y = torch.empty(N, C, (H + 1) // 2, (W + 1) // 2, device=d)
+    g.call("uz_avgpool2_fwd_ex", x.to(d), C, C, y, C, N, H, W, sx, sy, 1)
+    assert float(sy.max()) == float(sx.max())
+    assert g.maxabs(_unpack(y, sy), ref) <= 2.0 ** -21 * float(x.abs().max())
+
+
+@pytest.mark.parametrize("N,C1,C2,H,W", UNIT_CASES)
+def test_unit_backward_with_folded_reduction_and_split_storage(N, C1, C2, H, W):
+    """Backward of unit 1 (Conv -> BN -> ReLU) behind unit 2's data gradient: the data gradient masks dA with unit 1's ReLU and leaves
+    the BatchNorm-backward sums in its epilogue (uz_conv_bwd_data_ex), uz_bn_relu_bwd_ex finalises them and writes dy as split
+    storage, unit 1's weight / data gradients read it - against the un-fused fp32-storage chain and torch autograd."""
+    _need_split()
+    g, L = _g(), _lib()
+    C0 = 64
+    rows = L.uz_conv_bwd_relu_partials(C1, C2, N, H, W, 3)
+    if rows <= 0 or L.uz_conv_route(2, C0, C1, N, H, W, 3) != 1 or L.uz_conv_route(1, C0, C1, N, H, W, 3) != 1 or L.uz_conv_bn_partials(C0, C1, N, H, W, 3) <= 0:
+        pytest.skip("shape off the split path in this math mode")
+    d = g.dev()
+    x = g.rnd(N, C0, H, W, seed=31)
+    w1, w2 = g.rnd(C1, C0, 3, 3, seed=32, scale=0.1), g.rnd(C2, C1, 3, 3, seed=33, scale=0.1)
+    gamma, beta = g.rnd(C1, seed=34).abs() + 0.5, g.rnd(C1, seed=35) * 0.3
+    dy2 = g.rnd(N, C2, H, W, seed=36)
+    xr, w1r = x.clone().requires_grad_(True), w1.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y1r = F.conv2d(xr, w1r, None, padding=1)
+    a1r = F.relu(F.batch_norm(y1r, None, None, gr, br, training=True, eps=1e-3))
+    F.conv2d(a1r, w2, None, padding=1).backward(dy2)
+
+    xd, w1d, w2d, gd, bd, dy2d = (t.to(d) for t in (x, w1, w2, gamma, beta, dy2))
+    npart = L.uz_conv_bn_partials(C0, C1, N, H, W, 3)
+    wsb = max(L.uz_conv_workspace(C0, C1, N, H, W, 3), L.uz_conv_workspace(C1, C2, N, H, W, 3), L.uz_conv_bwd_weight_workspace(C0, C1, N, H, W, 3))
+    ws = torch.empty(wsb // 4 + 64, device=d)
+    bws = torch.empty(L.uz_bn_workspace(C1, N, H, W) // 4 + 16, device=d)
+    y1 = torch.empty(N, C1, H, W, device=d)
+    part = torch.empty(npart * C1 * 4, device=d)
+    g.call("uz_conv_fwd_bnstats", xd, C0, C0, w1d, None, y1, C1, C1, N, H, W, 3, 0, None, None, None, ws, wsb, None, part)
+    a1 = torch.empty(N, C1, H, W, device=d)
+    save = torch.empty(4 * C1, device=d)
+    g.call("uz_bn_relu_fwd_ex", y1, C1, C1, gd, bd, None, None, save, a1, C1, N, H, W, 1e-3, 0.01, 1, 1, _slot(), bws, part, npart, 0)
+    sdy2 = _slot(float(dy2.abs().max()))
+    out = {}
+    for fused in (0, 1):
+        dA = torch.full((N, C1, H, W), float("nan"), device=d)
+        bpart = torch.full((rows * C1 * 4,), float("nan"), device=d)
+        if fused:
+            g.call("uz_conv_bwd_data_ex", dy2d, C2, C2, w2d, dA, C1, C1, N, H, W, 3, 0, sdy2, None, ws, wsb, None, 0, y1, C1, save, 1, bpart)
+        else:
+            g.call("uz_conv_bwd_data", dy2d, C2, C2, w2d, dA, C1, C1, N, H, W, 3, 0, sdy2, None, ws, wsb)
+        dy1 = torch.full((N, C1, H, W), float("nan"), device=d)
+        dgm, dbt, dbias = (torch.empty(C1, device=d) for _ in range(3))
+        sdy1 = _slot()
+        g.call("uz_bn_relu_bwd_ex", dA, C1, y1, C1, C1, gd, bd, save, dy1, C1, dgm, dbt, dbias, N, H, W, 1, sdy1, bws, bpart if fused else None, rows if fused else 0, fused)
+        dw1 = torch.empty(C1, C0, 3, 3, device=d)
+        g.call("uz_conv_bwd_weight_ex", xd, C0, C0, dy1, C1, C1, dw1, None, N, H, W, 3, None, sdy1, ws, wsb, 0, None, 0, fused)
+        dx = torch.empty(N, C0, H, W, device=d)
+        g.call("uz_conv_bwd_data_ex", dy1, C1, C1, w1d, dx, C0, C0, N, H, W, 3, 0, sdy1, None, ws, wsb, None, fused, None, 0, None, 0, None)
+        out[fused] = (dA, dy1, dgm, dbt, dw1, dx, sdy1)
+    dA0, dy0, dg0, db0, dw0, dx0, s0 = out[0]
+    dA1, dy1p, dg1, db1, dw1_, dx1, s1 = out[1]
+    mask = (a1 > 0).float()
+    assert g.maxabs(dA1, dA0 * mask) <= 1e-6 * float(dA0.abs().max())                 # the folded launch stores dz = dA * [a > 0]
+    dec = _unpack(dy1p, s1)
+    assert float(s1.max()) >= float(dy0.abs().max()) * (1 - 1e-6)                     # the analytic bound covers the tensor
+    assert g.maxabs(dec, dy0) <= 3e-6 * float(dy0.abs().max())
+    assert g.relerr(dg1, dg0) <= 2e-5 and g.relerr(db1, db0) <= 2e-5
+    assert g.relerr(dw1_, dw0) <= 5e-6 and g.relerr(dx1, dx0) <= 5e-6
+    # ... and all of it against autograd
+    assert g.relerr(dw1_, w1r.grad) <= 5e-5 and g.relerr(dx1, xr.grad) <= 5e-5
+    assert g.relerr(dg1, gr.grad) <= 1e-4 and g.relerr(db1, br.grad) <= 1e-4

@@ -69,6 +69,11 @@ if os.environ.get("UZ_DP_ONLY"):
     print(f"side {os.environ.get('UZ_SIDE_STREAM')} prio {os.environ.get('UZ_DP_STREAM_PRIORITY')} lanes {os.environ.get('UZ_LANES')}: dp overlap {ms1:.3f} ms/step exposed {ex1}")
     dist.destroy_process_group()
     sys.exit(0)
+if os.environ.get("UZ_SERIAL_ONLY"):      # the serial exchange alone in a fresh process (is its 32 ms the exchange, or being the third model of the process?)
+    p2, l2, ms2, ex2, _, _ = run(True, overlap=False, timed=10)
+    print(f"serial only (first and only model of the process): dp serial {ms2:.3f} ms/step, exposed {ex2:.3f} ms")
+    dist.destroy_process_group()
+    sys.exit(0)
 p0, l0, ms0, _, _, _ = run(False, timed=10)
 p1, l1, ms1, ex1, nb, nev = run(True, overlap=True, timed=10)
 p2, l2, ms2, ex2, _, _ = run(True, overlap=False, timed=10)

@@ -17,6 +17,14 @@ from ._modtree import attach
 from ._plan import ParamTable, Plan
 
 
+def set_conv_math(mode):
+    """uz_set_conv_math (0 fp32 MFMA | 1 default | 2 split everywhere | 3 bf16 | -1 back to UZ_CONV_MATH).  The mode is
+    process-global and every plan of every live model was built for the mode in force at the time (routing, workspace and
+    packed-image sizes, folded ops): NativeModel._plan compares the library's current mode with the one its plans were built
+    under and drops plans and graphs when they differ - whoever flipped the switch."""
+    _ffi.check(_ffi.lib().uz_set_conv_math(int(mode)), "set_conv_math")
+
+
 def default_device():
     return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
@@ -81,18 +89,43 @@ class NativeModel(nn.Module):
 
     def guard_bounds(self):
         """check_bounds() + the safety net behind it: if any split-fp16 kernel saw a tensor beyond its magnitude bound (values were
-        clamped: finite, but wrong), warn, switch the PROCESS to the fp32-MFMA kernels (uz_set_conv_math(0): no bounds, no scales)
-        and drop this model's plans and graphs so that the next forward is rebuilt on them.  Returns the flag word; a caller that
-        gets non-zero repeats the step it just ran (train_model.py does).  Costs one stream synchronisation."""
+        clamped: finite, but wrong), warn, switch the PROCESS to the fp32-MFMA kernels (set_conv_math(0): no bounds, no scales;
+        every live model drops its plans and graphs).  Under data parallelism the decision is COLLECTIVE - the flag words are
+        OR-ed over the ranks on the host control plane, so either every rank falls back and repeats the step or none does (a
+        rank acting alone would issue a second set of all-reduces that pair with its peers' next step).  Returns the flag word;
+        a caller that gets non-zero repeats the step it just ran from the state snapshot_step() saved (train_model.py does).
+        Costs one stream synchronisation: meant for loops that synchronise per step anyway (the reference's scheduler does)."""
         flags = self.check_bounds()
+        if getattr(self, "_dp", None) is not None:
+            from . import dp
+            agree = 0
+            for bit in (1, 2, 4):
+                agree |= bit if dp.max_int(1 if flags & bit else 0, self._dp.group) else 0
+            flags = agree
         if flags:
             import warnings
             warnings.warn(f"split-fp16 convolution path: magnitude bound exceeded (flags {flags:#x}: 1 activation, 2 weight, 4 gradient) - "
                           "falling back to fp32 MFMA arithmetic for the rest of this process", RuntimeWarning)
-            _ffi.check(_ffi.lib().uz_set_conv_math(0), "set_conv_math")
-            self._plans.clear()
+            set_conv_math(0)
+            self._plans.clear()              # (other live models notice the new mode in their next _plan() lookup)
             self._drop_graphs()
         return flags
+
+    def snapshot_step(self):
+        """State a repeated step must start from: BatchNorm running statistics, batch counters and the position of the
+        latent-noise stream (a few KB, device-to-device, no synchronisation)."""
+        snap = (self._ptab.bflat.clone(), self._ptab.nbt.clone(), self._rng_state().clone())
+        object.__setattr__(self, "_step_snapshot", snap)
+
+    def restore_step(self):
+        """Undo what the forward pass since snapshot_step() did to the BatchNorm buffers / counters and rewind the noise stream,
+        so that the repeated step draws the SAME eps and updates the running statistics once."""
+        snap = self.__dict__.get("_step_snapshot")
+        if snap is None:
+            raise RuntimeError("restore_step() without snapshot_step()")
+        self._ptab.bflat.copy_(snap[0])
+        self._ptab.nbt.copy_(snap[1])
+        self._rng_state().copy_(snap[2])
 
     def _require_gpu(self):
         if self.device.type != "cuda":
@@ -100,6 +133,12 @@ class NativeModel(nn.Module):
 
     # ------------------------------------------------------------------ plans
     def _plan(self, key, builder):
+        mode = _ffi.lib().uz_get_conv_math()
+        if self._plans and self.__dict__.get("_plans_mode", mode) != mode:      # the process switched its convolution math mode
+            self._plans.clear()
+            self._drop_graphs()
+            self._cur = None
+        self.__dict__["_plans_mode"] = mode
         p = self._plans.get(key)
         if p is None:
             p = builder()

@@ -9,7 +9,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuz_hip.so")
+# UZ_LIB: an experiment build of the same library (csrc/Makefile VARIANT=...); never a different implementation
+LIB_PATH = os.environ.get("UZ_LIB") or os.path.join(_HERE, "libuz_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "uz_api.h")
 
 _lib = None

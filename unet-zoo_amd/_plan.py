@@ -83,7 +83,7 @@ class ParamTable:
 
 
 class Buf:
-    __slots__ = ("name", "N", "C", "H", "W", "off", "gbuf", "requires_grad", "amax", "amax_cov", "alias", "relu")
+    __slots__ = ("name", "N", "C", "H", "W", "off", "gbuf", "requires_grad", "amax", "amax_cov", "alias", "relu", "packed")
 
     def __init__(self, name, N, C, H, W, requires_grad=True):
         self.name, self.N, self.C, self.H, self.W = name, int(N), int(C), int(H), int(W)
@@ -91,6 +91,7 @@ class Buf:
         self.amax, self.amax_cov = None, []      # magnitude-bound slot and the channel ranges whose producers maintain it
         self.alias = None                        # pooled scratch: several differently shaped Bufs share one arena region
         self.relu = None                         # set by Plan.conv_relu: {(c0, C): state} of Conv -> ReLU units writing into this buffer
+        self.packed = False                      # kept in split storage (Plan._round4_passes): Plan.tensor() of it is NOT fp32 values
 
     @property
     def numel(self):
@@ -252,7 +253,9 @@ class Plan:
         if detached:
             self._detached = getattr(self, "_detached", 0) + 1
             gid = ("detached", self._detached)
-        lst.append(dict(code=code, p=list(p), i=[int(x) for x in i], f=[float(x) for x in f], n=int(n), gid=gid))
+        op = dict(code=code, p=list(p), i=[int(x) for x in i], f=[float(x) for x in f], n=int(n), gid=gid)
+        lst.append(op)
+        return op
 
     def P(self, key, extra=0):
         return ("param", key, extra)
@@ -333,9 +336,11 @@ class Plan:
                       self.amax_in(x), ("amax", 0), self.amax_out(y) if (relu and ks == 3) else None, packed, bn_partials],
                    i=[cin, x.Ctot, cout, y.Ctot, x.N, x.H, x.W, ks, relu, int(slabs_only)], n=ws)
 
-    def _conv_bwd(self, x, wkey, gy, ks, db_key=None, wrow0=0):
+    def _conv_bwd(self, x, wkey, gy, ks, db_key=None, wrow0=0, rec=None):
         """Weight gradient (+ optional bias gradient) and, when the input carries a gradient,
-        the data gradient.  gy: gradient w.r.t. the conv output (a View)."""
+        the data gradient.  gy: gradient w.r.t. the conv output (a View).  rec (dict): receives the emitted 2-D ops
+        ("wgrad", "dgrad") for the round-4 passes of finalize()."""
+        rec = rec if rec is not None else {}
         cin, cout = x.C, gy.C
         if x.nb is not None and ks == 3:                      # volume: see _conv_fwd
             assert isinstance(gy, _ScratchView) and gy.off and db_key is None and wrow0 == 0
@@ -368,10 +373,10 @@ class Plan:
         self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
 
         def emit_wgrad():
-            self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
-                       p=[x, gy, self.G(wkey, wextra), self.G(db_key, wrow0) if db_key else None, ("scratch", "wgrad"),
-                          self.amax_in(x), self.amax_in(gy)],
-                       i=[cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, ks], n=ws)
+            rec["wgrad"] = self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
+                                      p=[x, gy, self.G(wkey, wextra), self.G(db_key, wrow0) if db_key else None, ("scratch", "wgrad"),
+                                         self.amax_in(x), self.amax_in(gy)],
+                                      i=[cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, ks], n=ws)
         # dy in a buffer of its own (small planes): the data gradient - the only thing the next layer's backward waits for -
         # goes first and the weight gradient becomes a scheduling group of its own, so that the latency-bound chains of the deep
         # levels (BatchNorm backward -> data gradient -> next BatchNorm backward) no longer carry the weight gradients and their
@@ -395,10 +400,10 @@ class Plan:
                 if npart > 0:
                     fold = st["fold"] = dict(part=self.vec(x.buf.name + f":dbpart{x.c0}", 4 * cin * npart), npart=npart,
                                              amax=self.amax_out(self.gview(x)), claims=self._nclaims[x.buf])
-            self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
+            rec["dgrad"] = self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
                        p=[gy, self.P(wkey, wextra), self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0), packed]
                          + ([x, fold["part"], fold["amax"]] if fold else []),
-                       i=[cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, ks, acc] + ([x.Ctot] if fold else []), n=ws2)
+                       i=[cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, ks, acc] + ([x.Ctot, 1] if fold else []), n=ws2)
         if decoupled:
             self._newgroup()
             emit_wgrad()
@@ -472,7 +477,9 @@ class Plan:
         y = ybuf if ybuf is not None else new(name + ":y")
         a = out if out is not None else new(name + ":a")
         assert a.C == cout and a.H == x.H and a.W == x.W
-        save = save if save is not None else self.vec(name + ":bnsave", 2 * cout)
+        # (4 C floats: mean, rstd and - where the statistics come from the convolution's partials - alpha, beta' for a data gradient
+        # that folds this unit's backward reduction, see _round4_passes)
+        save = save if save is not None else self.vec(name + ":bnsave", 4 * cout)
         # BatchNorm statistics in the convolution's epilogue (torchlayers.py:18-21: every Conv2d of a unit feeds a BatchNorm2d):
         # where the forward kernel supports it, it leaves per-tile {sum, sum of squares, max, max(-y)} partials and the
         # BatchNorm finalises them instead of streaming y a second time
@@ -493,11 +500,19 @@ class Plan:
         bnws = self.L.uz_bn_workspace(cout, x.N, x.H, x.W)
         self.scratch["bn"] = max(self.scratch["bn"], bnws)
         gam, bet = bprefix + ".weight", bprefix + ".bias"
-        self._emit(self.target, "UZ_OP_BN_RELU_FWD",
+        # unit record for the round-4 passes (finalize -> _round4_passes); units inside reversible sequences (shared scratch,
+        # recomputation inside the backward tape) and volume units stay as they are
+        plain = ybuf is None and a_grad is None and x.nb is None and self.__dict__.get("_rev_ctx") is None and self.target is self.fwd_ops
+        unit = dict(name=name, y=y, a=a, save=save, relu=int(relu), npart=npart, C=cout, N=x.N, H=x.H, W=x.W) if plain else None
+        if unit is not None:
+            self.__dict__.setdefault("_units", []).append(unit)
+        op_fwd = self._emit(self.target, "UZ_OP_BN_RELU_FWD",
                    p=[y, self.P(gam), self.P(bet), self.B(bprefix + ".running_mean"), self.B(bprefix + ".running_var"),
                       save, a, ("scratch", "bn"), self.amax_out(a), bnpart,
                       ("scratch", "wgrad") if nslab else None, (self.P(bkey) if bkey else None) if nslab else None],
                    i=[cout, y.Ctot, a.Ctot, x.N, x.H, x.W, int(self.bn_training), int(relu), npart, nslab], f=[BN_EPS, BN_MOMENTUM])
+        if unit is not None:
+            unit["bn_fwd"] = op_fwd
 
         def bwd():
             if a_grad is None and not self._has_grad(a):
@@ -519,11 +534,14 @@ class Plan:
                 self._gyz[gyv.zkey] = (y.N + 2) * sl
                 gy, gyv.off = ("gyvol", gyv.zkey), sl
             ga = a_grad if a_grad is not None else self.gview(a)
-            self._emit(self.bwd_ops, "UZ_OP_BN_RELU_BWD",
-                       p=[ga, y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), self.G(bkey), ("scratch", "bn"),
-                          ("amax", gyv.amax)],
-                       i=[ga.Ctot, cout, y.Ctot, cout, x.N, x.H, x.W, int(relu)])
-            self._conv_bwd(x, wkey, gyv, ks)
+            op_bwd = self._emit(self.bwd_ops, "UZ_OP_BN_RELU_BWD",
+                                p=[ga, y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), self.G(bkey), ("scratch", "bn"),
+                                   ("amax", gyv.amax)],
+                                i=[ga.Ctot, cout, y.Ctot, cout, x.N, x.H, x.W, int(relu)])
+            rec = {}
+            self._conv_bwd(x, wkey, gyv, ks, rec=rec)
+            if unit is not None:
+                unit.update(bn_bwd=op_bwd, ga=ga, ks=ks, cin=x.C, wgrad=rec.get("wgrad"), dgrad=rec.get("dgrad"))
         self._push_bwd(bwd)
         return a
 
@@ -627,7 +645,7 @@ class Plan:
         bufs = {}
         for tag in ("F", "G"):
             ybuf, abuf = self._pool((branch, tag + "y"), h, H, W), self._pool((branch, tag + "a"), h, H, W)
-            save = self._pool((branch, tag + "s"), 2 * h, 1, 1, vec=True)
+            save = self._pool((branch, tag + "s"), 4 * h, 1, 1, vec=True)
             for b in (ybuf, abuf):
                 self._ginit.pop(b.buf, None)
             bufs[tag] = (ybuf, abuf, save)
@@ -936,6 +954,172 @@ class Plan:
         self.ptr_tables.append(refs)
         return ("ptrtab", len(self.ptr_tables) - 1)
 
+    # ------------------------------------------------------------------ round-4 passes over the emitted ops
+    # p[] slots through which an op may WRITE / READ a buffer that is kept in split storage (csrc/split_f16.h: one word per element
+    # holding the two fp16 pieces of the scaled value - what the split-fp16 convolutions otherwise form in their staging)
+    _PACK_WRITERS = {"UZ_OP_BN_RELU_FWD": (6, 8), "UZ_OP_BILINEAR_FWD": (1, 3), "UZ_OP_AVGPOOL_FWD": (1, 3)}     # (view slot, bound slot)
+    _PACK_READERS = {"UZ_OP_CONV_FWD": 0, "UZ_OP_CONV_BWD_WEIGHT": 0}
+
+    def _round4_passes(self):
+        """Plan-time rewrites on the Conv2D units (torchlayers.py:18-21) of the large planes, all decided from the emitted ops:
+          1. folded backward reduction - where the ONLY writer of a unit's dA is an unsplit split-path data gradient, that launch masks
+             dA with the unit's ReLU and leaves the BatchNorm-backward sums in its epilogue; the unit's backward runs a per-channel
+             finalise instead of the reduction pass over dA and y (UZ_FOLD_BN_BWD=0 switches it off);
+          2. dY in split storage - where both consumers of a unit's dy (its weight and data gradient) run on the split path, the
+             BatchNorm-backward apply pass writes the operand pieces instead of fp32 values (UZ_PACK_DY=0);
+          3. activations in split storage - a buffer written only by BatchNorm-apply / pooling / interpolation launches that know
+             their bound beforehand and read only by split-path convolutions (forward + weight gradient) is kept as operand pieces;
+             a concat buffer's (at most two) producers each scale from a slot of their own (UZ_PACK_ACT=0).
+        Returns a summary dict (also kept as self.round4)."""
+        info = dict(folded=0, dy_packed=0, act_packed=0, act_views=0)
+        self.round4 = info
+        units = [u for u in self.__dict__.get("_units", []) if "bn_bwd" in u or "bn_fwd" in u]
+        if self.L.uz_get_conv_math() in (0, 3) or not self.bn_training:
+            return info                              # fp32-only / bf16 modes have no two-piece operands
+        env = lambda k: os.environ.get(k, "1") == "1"
+        large = lambda u: u["N"] * u["H"] * u["W"] > 4096 and (u["H"] * u["W"]) % 4 == 0
+        all_ops = [("fwd", self.fwd_ops), ("loss", self.loss_ops), ("bwd", self.bwd_ops)] + list(self.extra_ops.items())
+
+        def touches(r, buf):
+            if isinstance(r, View):
+                return r.buf is buf
+            if isinstance(r, _ScratchView):
+                return r.view is not None and r.view.buf is buf
+            if isinstance(r, tuple) and r and r[0] in ("win",):
+                return r[1].buf is buf
+            return False
+        tabbed = {id(q.buf) for t in self.ptr_tables for q in t if isinstance(q, View)}
+        # ---- 1. folded backward reduction
+        if env("UZ_FOLD_BN_BWD") and self.bwd_ops:
+            for u in units:
+                B = u.get("bn_bwd")
+                if B is None or not large(u) or u["npart"] <= 0:
+                    continue
+                ga = u["ga"]
+                if not isinstance(ga, View) or ga.nb is not None or id(ga.buf) in tabbed:
+                    continue
+                writers, readers = [], []
+                for tape, ops in all_ops:
+                    for o in ops:
+                        wr = self._WRITES[o["code"]]
+                        for j, r in enumerate(o["p"]):
+                            if touches(r, ga.buf) and isinstance(r, View) and r.c0 < ga.c0 + ga.C and ga.c0 < r.c0 + r.C:
+                                (writers if j in wr else readers).append((o, j, r))
+                if len(writers) != 1 or len(readers) != 1 or readers[0][0] is not B:
+                    continue
+                W, j, r = writers[0]
+                if W["code"] != "UZ_OP_CONV_BWD_DATA" or j != 2 or (r.c0, r.C, r.nb) != (ga.c0, ga.C, None) or len(W["p"]) != 7 or W["i"][8] != 0 or W["i"][7] != 3:
+                    continue
+                cout_w, cin_w, N, H, Wd = W["i"][0], W["i"][2], W["i"][4], W["i"][5], W["i"][6]
+                rows = self.L.uz_conv_bwd_relu_partials(cin_w, cout_w, N, H, Wd, 3)
+                if rows <= 0 or cin_w != u["C"]:
+                    continue
+                part = self.vec(u["name"] + ":bwdpart", 4 * u["C"] * rows)
+                y = u["y"]
+                W["p"] = W["p"][:7] + [y, part, None, u["save"]]
+                W["i"] = W["i"][:9] + [y.Ctot, 2, 0, u["relu"]]
+                B["p"] = B["p"][:11] + [part]
+                B["i"] = B["i"][:8] + [rows, 0]
+                info["folded"] += 1
+        # ---- 2. dY in split storage
+        if env("UZ_PACK_DY") and self.bwd_ops:
+            for u in units:
+                B, wg, dg = u.get("bn_bwd"), u.get("wgrad"), u.get("dgrad")
+                if B is None or wg is None or not large(u) or u["ks"] != 3 or u["W"] % 4:
+                    continue
+                if self.L.uz_conv_route(2, u["cin"], u["C"], u["N"], u["H"], u["W"], 3) != 1:
+                    continue
+                if dg is not None and (self.L.uz_conv_route(1, u["cin"], u["C"], u["N"], u["H"], u["W"], 3) != 1 or dg["i"][10:11] == [1]):
+                    continue
+                B["i"] = (B["i"] + [0, 0])[:10]
+                B["i"][9] = 1
+                B["p"] = (B["p"] + [None])[:12]
+                wg["i"] = (wg["i"] + [0, 0, 0])[:11]
+                wg["i"][10] = 1
+                wg["p"] = (wg["p"] + [None])[:8]
+                if dg is not None:
+                    dg["i"] = (dg["i"] + [0, 0, 0, 0])[:13]
+                    dg["i"][11] = 1
+                    dg["p"] = (dg["p"] + [None] * 4)[:11]
+                info["dy_packed"] += 1
+        # ---- 3. activations in split storage
+        if env("UZ_PACK_ACT") and not self.extra_ops:
+            named = {id(v.buf) for v in self.named.values() if isinstance(v, View)}
+            for b in self.bufs:
+                if b.alias is not None or id(b) in tabbed or id(b) in named or (b.H * b.W) % 4 or b.N * b.H * b.W <= 4096:
+                    continue
+                wr_list, rd_list, ok = [], [], True
+                for tape, ops in all_ops:
+                    for o in ops:
+                        for j, r in enumerate(o["p"]):
+                            if not touches(r, b):
+                                continue
+                            c = o["code"]
+                            if not isinstance(r, View) or r.nb is not None:
+                                ok = False
+                            elif c in self._PACK_WRITERS and j == self._PACK_WRITERS[c][0]:
+                                if c == "UZ_OP_BN_RELU_FWD" and not (o["i"][6] and o["i"][8] > 0 and o["i"][9] == 0):
+                                    ok = False               # needs the bound before the apply pass: statistics from the convolution's partials
+                                if c != "UZ_OP_BN_RELU_FWD" and o["p"][2] is None:
+                                    ok = False               # pooling / interpolation forward their INPUT's bound
+                                wr_list.append((o, r))
+                            elif c in self._PACK_READERS and j == self._PACK_READERS[c]:
+                                i = o["i"]
+                                kind = 0 if c == "UZ_OP_CONV_FWD" else 2
+                                if i[7] != 3 or self.L.uz_conv_route(kind, i[0], i[2], i[4], i[5], i[6], 3) != 1 or (kind == 0 and i[9]):
+                                    ok = False
+                                rd_list.append((o, r))
+                            else:
+                                ok = False
+                if not ok or not wr_list or not rd_list:
+                    continue
+                wr_list.sort(key=lambda t: t[1].c0)
+                segs = [(r.c0, r.c0 + r.C) for _, r in wr_list]
+                if any(a[1] > b2[0] for a, b2 in zip(segs, segs[1:])):
+                    continue                                 # overlapping producers
+                plan_rd = []
+                for o, r in rd_list:
+                    cov = [sg for sg in segs if sg[0] < r.c0 + r.C and r.c0 < sg[1]]
+                    tiled = cov and cov[0][0] <= r.c0 and cov[-1][1] >= r.c0 + r.C and all(a[1] == b2[0] for a, b2 in zip(cov, cov[1:]))
+                    if not tiled or len(cov) > 2 or (len(cov) == 2 and (cov[1][0] - r.c0) % 16):
+                        ok = False
+                        break
+                    plan_rd.append((o, r, cov))
+                if not ok:
+                    continue
+                slot_of = {}
+                for o, r in wr_list:
+                    vi, bi = self._PACK_WRITERS[o["code"]]
+                    slot = slot_of[(r.c0, r.c0 + r.C)] = ("amax", self._new_amax())
+                    o["p"][bi] = slot
+                    if o["code"] == "UZ_OP_BN_RELU_FWD":
+                        o["i"] = (o["i"] + [0])[:11]
+                        o["i"][10] = 1
+                    elif o["code"] == "UZ_OP_BILINEAR_FWD":
+                        o["i"] = (o["i"] + [0])[:8]
+                        o["i"][7] = 1
+                    else:
+                        o["i"] = (o["i"] + [0])[:7]
+                        o["i"][6] = 1
+                for o, r, cov in plan_rd:
+                    s1 = slot_of[cov[0]]
+                    s2 = slot_of[cov[1]] if len(cov) == 2 else None
+                    seg = cov[1][0] - r.c0 if len(cov) == 2 else 0
+                    if o["code"] == "UZ_OP_CONV_FWD":
+                        o["p"] = (o["p"] + [None])[:11]
+                        o["p"][5], o["p"][10] = s1, s2
+                        o["i"] = (o["i"] + [0, 0])[:12]
+                        o["i"][10], o["i"][11] = 1, seg
+                    else:
+                        o["p"] = (o["p"] + [None])[:8]
+                        o["p"][5], o["p"][7] = s1, s2
+                        o["i"] = (o["i"] + [0, 0, 0])[:11]
+                        o["i"][8], o["i"][9] = 1, seg
+                b.packed = True
+                info["act_packed"] += 1
+                info["act_views"] += len(wr_list)
+        return info
+
     # ------------------------------------------------------------------ finalisation
     def finalize(self, want_backward=True):
         assert not self.finalized
@@ -965,6 +1149,7 @@ class Plan:
                 self._newgroup()
                 self._emit(self.bwd_ops, "UZ_OP_EVENT_RECORD", p=[("event", b), ("gflat_range", lo, hi)])
         self._bwd = []
+        self._round4_passes()
         # magnitude-bound slots: zero the forward-side slots and measure the parameter bound at the head of the forward tape,
         # zero the backward-side slots at the head of the backward tape (group 0 of each tape: everything else depends on it)
         self.n_amax_fwd = self.n_amax

@@ -34,6 +34,9 @@ struct BnP {
     const float* cpart; int ncpart;                    // the producing convolution's per-tile partials {sum, sum sq, max, max(-y)} [ncpart][C]
     const float* slab; int nslab; const float* cbias; float* ywr;     // small path: y := conv bias + sum of the split-K slabs (uz_bn_relu_fwd_slabs)
     float* amax;                                       // nullable: atomic max of |out| (bound for a following split-fp16 convolution)
+    int save4;                                         // save[] holds 4 C floats: mean, rstd and (written by the finalise kernel) alpha = gamma rstd, beta' = beta - mean alpha
+    int out_packed;                                    // out is written as split storage (split_f16.h: two fp16 pieces of v * split_scale(*amax) per word)
+    float* chanf;                                      // backward, finalised: [C] m1 = mean(dz), [C] m2 = mean(dz x_hat)
 };
 
 // block-wide maxima of two floats (blockDim.x == 256); result valid in thread 0
@@ -147,6 +150,11 @@ __global__ __launch_bounds__(256) void bn_finalize_conv_partials(const BnP p) {
             p.rmean[c] = (float)((1.0 - p.momentum) * p.rmean[c] + p.momentum * m);
             p.rvar[c] = (float)((1.0 - p.momentum) * p.rvar[c] + p.momentum * unb);
         }
+        if (p.save4) {       // the affine map of this channel, as alpha_beta() forms it: consumers (a data gradient folding this unit's backward reduction) read it from here
+            const float g = p.gamma ? p.gamma[c] : 1.f, bb = p.beta ? p.beta[c] : 0.f;
+            p.save[2 * p.C + c] = g * rstd;
+            p.save[3 * p.C + c] = bb - mean * (g * rstd);
+        }
         if (p.amax) {
             const float g = p.gamma ? p.gamma[c] : 1.f, bb = p.beta ? p.beta[c] : 0.f;
             const float alpha = g * rstd, beta_ = bb - mean * alpha;
@@ -157,13 +165,13 @@ __global__ __launch_bounds__(256) void bn_finalize_conv_partials(const BnP p) {
     }
 }
 
-template <bool VEC>
+template <bool VEC, bool PK = false>
 __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
     __shared__ double red[2];
     __shared__ float redf[2];
     const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
     float alpha, beta_, mean, rstd;
-    if (p.training && !p.pre) {
+    if (!PK && p.training && !p.pre) {
         double s, ss;
         channel_totals(p, c, red, s, ss, redf);
         const double n = (double)p.N * p.HW;
@@ -200,6 +208,21 @@ __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
     const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
     const float floor_ = p.relu ? 0.f : -INFINITY;
     float vmax = 0.f;
+    if (PK) {
+        // split storage: the finalise launch in front of this one published the tensor's exact bound, so every workgroup derives
+        // the same scale and the words it writes are the operand pieces the consuming convolution would have formed itself
+        const float s = uz::split_scale(uz::amax_read(p.amax));
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+            const float4 v = s4[i];
+            uint4 o;
+            o.x = uz::pack_split(fmaxf(fmaf(v.x, alpha, beta_), floor_), s); o.y = uz::pack_split(fmaxf(fmaf(v.y, alpha, beta_), floor_), s);
+            o.z = uz::pack_split(fmaxf(fmaf(v.z, alpha, beta_), floor_), s); o.w = uz::pack_split(fmaxf(fmaf(v.w, alpha, beta_), floor_), s);
+            d4[i] = o;
+        }
+        return;
+    }
     if (VEC) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
         float4* d4 = reinterpret_cast<float4*>(dst);
@@ -369,7 +392,45 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_partial(const BnP p) {
     }
 }
 
-template <bool VEC>
+// Backward statistics as a launch of their own (one workgroup per channel, fixed order, fp64): from the fp64 partials of
+// bn_bwd_reduce_partial, or from the float4 partials {sum dz, sum dz x_hat, max |dz|, max |x_hat|} that the data gradient which
+// wrote dA last left in its epilogue (conv_split.hip, MK == 2: the reduction pass over dA and y disappears).  Publishes dgamma, dbeta,
+// m1, m2 and the bound of dy - BEFORE the apply pass starts, which is what lets that pass write split storage.
+__global__ __launch_bounds__(256) void bn_bwd_finalize(const BnP p) {
+    __shared__ double sm[8];
+    __shared__ float smf[8];
+    const int c = blockIdx.x;
+    double v2[2] = {0.0, 0.0};
+    float mdz = 0.f, mxh = 0.f;
+    if (p.cpart) {
+        for (int i = threadIdx.x; i < p.ncpart; i += 256) {
+            const float4 q = *reinterpret_cast<const float4*>(p.cpart + ((size_t)i * p.C + c) * 4);
+            v2[0] += (double)q.x; v2[1] += (double)q.y;
+            mdz = fmaxf(mdz, q.z); mxh = fmaxf(mxh, q.w);
+        }
+    } else {
+        const int P = p.ngrp * p.parts;
+        for (int i = threadIdx.x; i < P; i += 256) {
+            const double* o = p.part + ((size_t)i * p.C + c) * 2;
+            v2[0] += o[0]; v2[1] += o[1];
+            mdz = fmaxf(mdz, p.mm[((size_t)i * p.C + c) * 2]); mxh = fmaxf(mxh, p.mm[((size_t)i * p.C + c) * 2 + 1]);
+        }
+    }
+    uz::block_sum_d<2>(v2, sm);
+    block_max2(mdz, mxh, smf);
+    if (threadIdx.x == 0) {
+        float alpha, beta_, mean, rstd;
+        alpha_beta(p, c, alpha, beta_, mean, rstd);
+        const double n = (double)p.N * p.HW;
+        const float m1 = (float)(v2[0] / n), m2 = (float)(v2[1] / n);
+        p.chanf[c] = m1; p.chanf[p.C + c] = m2;
+        if (p.dbeta) p.dbeta[c] = (float)v2[0];
+        if (p.dgamma) p.dgamma[c] = (float)v2[1];
+        if (p.amax) uz::amax_publish_one(fabsf(alpha) * (mdz + fabsf(m1) + mxh * fabsf(m2)), p.amax, (unsigned)c);
+    }
+}
+
+template <bool VEC, bool PRE = false, bool PK = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const BnP p) {
     __shared__ double sm[4];
     __shared__ double red[2];
@@ -377,10 +438,54 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnP p) {
     const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
     float alpha, beta_, mean, rstd;
     alpha_beta(p, c, alpha, beta_, mean, rstd);
+    float m1, m2;
+    if (PRE) {
+        m1 = p.chanf[c]; m2 = p.chanf[p.C + c];
+        const float* ys = p.y + ((size_t)b * p.CtotY + c) * p.HW;
+        const float* ds = p.da + ((size_t)b * p.CtotDa + c) * p.HW;
+        const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
+        float sd = 0.f;
+        auto one = [&](float yv, float dv) -> float {
+            const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
+            const float r = alpha * (dz - m1 - ((yv - mean) * rstd) * m2);
+            sd += r;
+            return r;
+        };
+        const float4* y4 = reinterpret_cast<const float4*>(ys);
+        const float4* d4 = reinterpret_cast<const float4*>(ds);
+        if (PK) {
+            const float s = uz::split_scale(uz::amax_read(p.amax));
+            uint4* o4 = reinterpret_cast<uint4*>(p.out + ((size_t)b * p.CtotOut + c) * p.HW);
+            for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+                const float4 yv = y4[i], dv = d4[i];
+                uint4 o;
+                o.x = uz::pack_split(one(yv.x, dv.x), s); o.y = uz::pack_split(one(yv.y, dv.y), s);
+                o.z = uz::pack_split(one(yv.z, dv.z), s); o.w = uz::pack_split(one(yv.w, dv.w), s);
+                o4[i] = o;
+            }
+        } else if (VEC) {
+            float4* o4 = reinterpret_cast<float4*>(p.out + ((size_t)b * p.CtotOut + c) * p.HW);
+            for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+                const float4 yv = y4[i], dv = d4[i];
+                float4 r;
+                r.x = one(yv.x, dv.x); r.y = one(yv.y, dv.y); r.z = one(yv.z, dv.z); r.w = one(yv.w, dv.w);
+                o4[i] = r;
+            }
+        } else {
+            float* dst = p.out + ((size_t)b * p.CtotOut + c) * p.HW;
+            for (int i = lo + threadIdx.x; i < hi; i += 256) dst[i] = one(ys[i], ds[i]);
+        }
+        if (p.dbias) {
+            double v1[1] = {(double)sd};
+            uz::block_sum_d<1>(v1, sm);
+            if (threadIdx.x == 0) p.part2[(size_t)(b * p.parts + part) * p.C + c] = v1[0];
+        }
+        return;
+    }
     double s1, s2;
     channel_totals(p, c, red, s1, s2, redf);
     const double n = (double)p.N * p.HW;
-    const float m1 = (float)(s1 / n), m2 = (float)(s2 / n);
+    m1 = (float)(s1 / n); m2 = (float)(s2 / n);
     if (b == 0 && part == 0 && threadIdx.x == 0) {
         if (p.dbeta) p.dbeta[c] = (float)s1;
         if (p.dgamma) p.dgamma[c] = (float)s2;
@@ -566,8 +671,11 @@ static int bn_relu_fwd_impl(const float* y, int C, int CtotY, const float* gamma
                             float* running_mean, float* running_var, float* save_mean_rstd,
                             float* a, int CtotA, int N, int H, int W, float eps, float momentum,
                             int training, int relu, float* a_amax, void* workspace,
-                            const float* conv_partials, int n_partials, const float* slabs, int n_slabs, const float* conv_bias, void* stream) {
+                            const float* conv_partials, int n_partials, const float* slabs, int n_slabs, const float* conv_bias, void* stream,
+                            int save4 = 0, int out_packed = 0) {
     UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_fwd: empty tensor");
+    UZ_REQUIRE(!out_packed || (training && conv_partials && a_amax && (size_t)N * H * W > SMALL_LIMIT),
+               "bn_relu_fwd_ex: split storage needs the output's bound before the apply pass - training mode, statistics from the convolution's partials, a bound slot");
     UZ_REQUIRE(!conv_partials || (training && n_partials > 0 && (size_t)N * H * W > SMALL_LIMIT), "bn_relu_fwd: convolution partials only serve the training-mode large-plane path");
     UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_fwd: N or C exceeds grid limits");
     UZ_REQUIRE(!training || save_mean_rstd, "bn_relu_fwd: training needs save_mean_rstd");
@@ -579,6 +687,7 @@ static int bn_relu_fwd_impl(const float* y, int C, int CtotY, const float* gamma
     p.out = a; p.C = C; p.CtotY = CtotY; p.CtotOut = CtotA; p.N = N; p.HW = H * W;
     p.parts = uz::ceil_div(p.HW, CHUNK);
     p.eps = eps; p.momentum = momentum; p.training = training; p.relu = relu; p.amax = a_amax;
+    p.save4 = save4; p.out_packed = out_packed;
     UZ_REQUIRE(!slabs || (n_slabs > 1 && (size_t)N * p.HW <= SMALL_LIMIT), "bn_relu_fwd_slabs: split-K slabs only serve the small-plane path (N*H*W <= 4096)");
     if ((size_t)N * p.HW <= SMALL_LIMIT) {
         p.slab = slabs; p.nslab = n_slabs; p.cbias = conv_bias; p.ywr = const_cast<float*>(y);
@@ -600,7 +709,10 @@ static int bn_relu_fwd_impl(const float* y, int C, int CtotY, const float* gamma
         else hipLaunchKernelGGL(bn_stats_partial<false>, rgrid, dim3(256), 0, st, p);
         if (int rc = uz::check_launch("bn_stats_partial")) return rc;
     }
-    if (vec) hipLaunchKernelGGL(bn_apply<true>, grid, dim3(256), 0, st, p);
+    if (out_packed) {
+        UZ_REQUIRE(vec, "bn_relu_fwd_ex: split storage needs H*W %% 4 == 0 and 16-byte aligned views");
+        hipLaunchKernelGGL((bn_apply<true, true>), grid, dim3(256), 0, st, p);
+    } else if (vec) hipLaunchKernelGGL(bn_apply<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(bn_apply<false>, grid, dim3(256), 0, st, p);
     return uz::check_launch("bn_apply");
 }
@@ -612,6 +724,17 @@ extern "C" int uz_bn_relu_fwd_pre(const float* y, int C, int CtotY, const float*
                                   const float* conv_partials, int n_partials, void* stream) {
     return bn_relu_fwd_impl(y, C, CtotY, gamma, beta, running_mean, running_var, save_mean_rstd, a, CtotA, N, H, W, eps, momentum,
                             training, relu, a_amax, workspace, conv_partials, n_partials, nullptr, 0, nullptr, stream);
+}
+// uz_bn_relu_fwd_pre with (a) save_mean_rstd_ab holding 4 C floats - mean, rstd, and alpha = gamma rstd, beta' = beta - mean alpha,
+// written where the statistics come from the convolution's partials (a data gradient that folds this unit's backward reduction reads
+// them, uz_conv_bwd_data_bn) - and (b) out_packed: `a` is written as split storage (include/uz_api.h, "Split storage").
+extern "C" int uz_bn_relu_fwd_ex(const float* y, int C, int CtotY, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float* save_mean_rstd_ab,
+                                 float* a, int CtotA, int N, int H, int W, float eps, float momentum,
+                                 int training, int relu, float* a_amax, void* workspace,
+                                 const float* conv_partials, int n_partials, int out_packed, void* stream) {
+    return bn_relu_fwd_impl(y, C, CtotY, gamma, beta, running_mean, running_var, save_mean_rstd_ab, a, CtotA, N, H, W, eps, momentum,
+                            training, relu, a_amax, workspace, conv_partials, n_partials, nullptr, 0, nullptr, stream, 1, out_packed);
 }
 // Conv2d (split-K, fp32 kernel) + BatchNorm + ReLU on the small planes with the convolution's reduce folded in: `slabs` are the
 // n_slabs partial-sum tensors [n_slabs][N][C][H*W] uz_conv_fwd_slabs left in its workspace, conv_bias the convolution's bias
@@ -634,7 +757,22 @@ extern "C" int uz_bn_relu_bwd(const float* da, int CtotDa, const float* y, int C
                               const float* gamma, const float* beta, const float* save_mean_rstd,
                               float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
                               int N, int H, int W, int relu, float* dy_amax, void* workspace, void* stream) {
+    return uz_bn_relu_bwd_ex(da, CtotDa, y, C, CtotY, gamma, beta, save_mean_rstd, dy, CtotDy, dgamma, dbeta, dbias, N, H, W, relu, dy_amax, workspace,
+                             nullptr, 0, 0, stream);
+}
+// uz_bn_relu_bwd with (a) conv_partials: n_partials rows [C][4] of {sum dz, sum dz x_hat, max |dz|, max |x_hat|} left by the data
+// gradient that wrote dA last (uz_conv_bwd_data_bn; dA then already carries the ReLU mask) - the reduction pass over dA and y is
+// replaced by a one-workgroup-per-channel finalise - and (b) out_packed: dy is written as split storage (needs dy_amax; the
+// finalise launch publishes the bound before the apply pass starts).  Large planes only (N*H*W > 4096).
+extern "C" int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, int C, int CtotY,
+                                 const float* gamma, const float* beta, const float* save_mean_rstd,
+                                 float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
+                                 int N, int H, int W, int relu, float* dy_amax, void* workspace,
+                                 const float* conv_partials, int n_partials, int out_packed, void* stream) {
     UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_bwd: empty tensor");
+    UZ_REQUIRE(!(conv_partials || out_packed) || (size_t)N * H * W > SMALL_LIMIT, "bn_relu_bwd_ex: folded statistics / split storage only serve the large-plane path");
+    UZ_REQUIRE(!conv_partials || n_partials > 0, "bn_relu_bwd_ex: conv_partials without rows");
+    UZ_REQUIRE(!out_packed || dy_amax, "bn_relu_bwd_ex: split storage needs the bound slot");
     UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_bwd: N or C exceeds grid limits");
     UZ_REQUIRE(save_mean_rstd, "bn_relu_bwd: needs the saved batch statistics");
     hipStream_t st = uz::S(stream);
@@ -654,10 +792,23 @@ extern "C" int uz_bn_relu_bwd(const float* da, int CtotDa, const float* y, int C
     const dim3 grid(p.parts, C, N);
     reduction_groups(p);
     const dim3 rgrid(p.parts, C, p.ngrp);
-    if (vec) hipLaunchKernelGGL(bn_bwd_reduce_partial<true>, rgrid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(bn_bwd_reduce_partial<false>, rgrid, dim3(256), 0, st, p);
-    if (int rc = uz::check_launch("bn_bwd_reduce_partial")) return rc;
-    if (vec) hipLaunchKernelGGL(bn_bwd_apply<true>, grid, dim3(256), 0, st, p);
+    const bool pre = conv_partials || out_packed;
+    p.cpart = conv_partials; p.ncpart = n_partials; p.out_packed = out_packed;
+    p.chanf = reinterpret_cast<float*>(p.chan);
+    if (!conv_partials) {
+        if (vec) hipLaunchKernelGGL(bn_bwd_reduce_partial<true>, rgrid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(bn_bwd_reduce_partial<false>, rgrid, dim3(256), 0, st, p);
+        if (int rc = uz::check_launch("bn_bwd_reduce_partial")) return rc;
+    }
+    if (pre) {
+        hipLaunchKernelGGL(bn_bwd_finalize, dim3(C), dim3(256), 0, st, p);
+        if (int rc = uz::check_launch("bn_bwd_finalize")) return rc;
+        if (out_packed) {
+            UZ_REQUIRE(vec, "bn_relu_bwd_ex: split storage needs H*W %% 4 == 0 and 16-byte aligned views");
+            hipLaunchKernelGGL((bn_bwd_apply<true, true, true>), grid, dim3(256), 0, st, p);
+        } else if (vec) hipLaunchKernelGGL((bn_bwd_apply<true, true, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((bn_bwd_apply<false, true, false>), grid, dim3(256), 0, st, p);
+    } else if (vec) hipLaunchKernelGGL(bn_bwd_apply<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(bn_bwd_apply<false>, grid, dim3(256), 0, st, p);
     if (int rc = uz::check_launch("bn_bwd_apply")) return rc;
     if (dbias) {

@@ -528,6 +528,40 @@ extern "C" int uz_conv_fwd(const float* x, int Cin, int CinTot, const float* w, 
     return uz_conv_fwd_packed(x, Cin, CinTot, w, bias, y, Cout, CoutTot, N, H, W, ks, relu, x_amax, w_amax, y_amax, workspace, workspace_bytes, nullptr, stream);
 }
 
+// Round 4 (include/uz_api.h, "split storage + folded BatchNorm backward").  Without options these are uz_conv_fwd_bnstats /
+// uz_conv_bwd_data_packed; with them the call must take the split-fp16 path (uz_conv_route() == 1) - nothing else reads split storage.
+extern "C" int uz_conv_fwd_ex(const float* x, int Cin, int CinTot, const float* w, const float* bias,
+                              float* y, int Cout, int CoutTot, int N, int H, int W, int ks, int relu,
+                              const float* x_amax, const float* w_amax, float* y_amax,
+                              void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials,
+                              int x_packed, const float* x_amax2, int seg_channels, void* stream) {
+    if (!x_packed)
+        return uz_conv_fwd_bnstats(x, Cin, CinTot, w, bias, y, Cout, CoutTot, N, H, W, ks, relu, x_amax, w_amax, y_amax, workspace, workspace_bytes, packed_w, bn_partials, stream);
+    UZ_REQUIRE(ks == 3 && uz_conv_route(0, Cin, Cout, N, H, W, ks) == 1 && uz::conv_np() == 2, "conv_fwd_ex: input in split storage, but this shape / math mode does not take the split-fp16 path");
+    UZ_REQUIRE(workspace && workspace_bytes >= uz::conv_split_workspace(Cin, Cout, N, H, W), "conv_fwd_ex: workspace too small");
+    UZ_REQUIRE(!bn_partials || uz_conv_bn_partials(Cin, Cout, N, H, W, ks) > 0, "conv_fwd_ex: this shape writes no fused statistics (uz_conv_bn_partials() == 0)");
+    uz::SplitOpts o;
+    o.x_packed = 1; o.x_amax2 = x_amax2; o.seg_channels = seg_channels;
+    return uz::conv_split_ex(x, Cin, CinTot, w, Cin, bias, y, Cout, CoutTot, N, H, W, 0, relu, 0, x_amax, w_amax, y_amax, workspace, packed_w, bn_partials, uz::S(stream), o);
+}
+extern "C" int uz_conv_bwd_data_ex(const float* dy, int Cout, int CoutTot, const float* w, float* dx, int Cin, int CinTot,
+                                   int N, int H, int W, int ks, int accumulate, const float* dy_amax, const float* w_amax,
+                                   void* workspace, size_t workspace_bytes, const void* packed_w, int dy_packed,
+                                   const float* bn_y, int bn_yCtot, const float* bn_save, int bn_relu, float* bn_partials, void* stream) {
+    if (!dy_packed && !bn_y)
+        return uz_conv_bwd_data_packed(dy, Cout, CoutTot, w, dx, Cin, CinTot, N, H, W, ks, accumulate, dy_amax, w_amax, workspace, workspace_bytes, packed_w, stream);
+    UZ_REQUIRE(ks == 3 && uz_conv_route(1, Cin, Cout, N, H, W, ks) == 1 && uz::conv_np() == 2, "conv_bwd_data_ex: split storage / folded reduction, but this shape / math mode does not take the split-fp16 path");
+    UZ_REQUIRE(workspace && workspace_bytes >= uz::conv_split_workspace(Cout, Cin, N, H, W), "conv_bwd_data_ex: workspace too small");
+    uz::SplitOpts o;
+    o.x_packed = dy_packed;
+    if (bn_y) {
+        UZ_REQUIRE(bn_save && bn_partials && !accumulate && uz_conv_bwd_relu_partials(Cin, Cout, N, H, W, ks) > 0,
+                   "conv_bwd_data_ex: the folded BatchNorm reduction needs the statistics table, the partial rows, an overwriting unsplit launch");
+        o.mk = 2; o.mask = bn_y; o.maskCtot = bn_yCtot; o.mk_save = bn_save; o.mk_relu = bn_relu;
+    }
+    return uz::conv_split_ex(dy, Cout, CoutTot, w, Cin, nullptr, dx, Cin, CinTot, N, H, W, 1, 0, accumulate, dy_amax, w_amax, nullptr, workspace, packed_w,
+                             bn_y ? bn_partials : nullptr, uz::S(stream), o);
+}
 extern "C" int uz_conv_bwd_data_packed(const float* dy, int Cout, int CoutTot, const float* w,
                                        float* dx, int Cin, int CinTot, int N, int H, int W, int ks, int accumulate,
                                        const float* dy_amax, const float* w_amax,

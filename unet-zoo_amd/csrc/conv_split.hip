@@ -68,6 +68,13 @@ struct SP {
     float* y_amax;                                // nullable: atomic max of |y| (bound for the next layer's split)
     int kSplit, cps;                              // split-K: the chunk loop is shared out over kSplit workgroups, cps chunks each
     const float* mask; int maskCtot;              // data gradient with the producer's ReLU mask folded in: y = (mask > 0) ? y : 0 (view of Cout channels)
+    // MK == 2: the producer is a Conv -> BatchNorm -> ReLU unit (torchlayers.py:18-21); mask = its pre-normalisation output, mk_save =
+    // its [4][Cout] {mean, rstd, alpha, beta'} table: the epilogue masks with alpha y + beta' > 0 and leaves the unit's backward
+    // reduction {sum dz, sum dz x_hat, max |dz|, max |x_hat|} per (tile, channel) in bnpart
+    const float* mk_save; int mk_relu;
+    // XPK: the first segc chunks of the input were scaled from x_amax, the rest from x_amax2 (a concat buffer's two producers);
+    // segc <= 0 or >= nChunks: one bound
+    const float* x_amax2; int segc;
     float* slab;                                  // [kSplit][N][Cout][HW] partial sums (kSplit > 1), summed in order by splitk_reduce
     long long* stamps;                            // diagnostics (uz_debug_stamps): 8 cycle stamps per workgroup, normally null
     int* flags;                                   // device flag word (bound violations), nullable
@@ -128,8 +135,10 @@ constexpr int lds_bytes() {
     const int epilogue = 16 * (NTv + 4) * 4;
     return main_loop > epilogue ? main_loop : epilogue;
 }
-template <int MSUB, int NTv, int TWv, int NP, bool MK = false>      // MK: the folded ReLU-backward mask (kernels of their own: +12 VGPRs)
+// MK: 1 = the folded ReLU-backward mask (kernels of their own: +12 VGPRs), 2 = the folded BatchNorm-backward reduction; XPK = input in split storage
+template <int MSUB, int NTv, int TWv, int NP, int MK = 0, bool XPK = false>
 __device__ __forceinline__ void conv_split_body(const SP& p) {
+    static_assert(!XPK || NP == 2, "split storage is the two-piece fp16 format");
     using uz::u32x4;
     using GEO = Geo<NTv, TWv>;
     constexpr int NT = GEO::NT, TW = GEO::TW, PW = GEO::PW, PSI = GEO::PSI, PSR = GEO::PSR, G = GEO::G, CE = GEO::CE;
@@ -181,7 +190,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     const int prow1 = NT + tid / G, q4 = tid & (G - 1);
     const unsigned xstep = 4u * (unsigned)p.HW;
     const unsigned wblock = (unsigned)NP * WPLANE;
-    const float xs = NP == 2 ? uz::split_scale(uz::amax_read(p.x_amax)) : 1.f;
+    const float xs = (NP == 2 && !XPK) ? uz::split_scale(uz::amax_read(p.x_amax)) : 1.f;
 
     // ---- per-lane output pixels (B operand columns)
     int poff[NSUB];
@@ -231,18 +240,24 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
         const unsigned off = v < WVEC ? (unsigned)(c * p.nCoTiles + coT) * wblock + 16u * (unsigned)v : 0xFFFFFFFFu;
         wq[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
     };
+    // XPK: the input arrives as split storage (split_f16.h) - every word already holds the two fp16 pieces of its scaled value,
+    // staging is two byte permutes per pair instead of scale / clamp / convert / subtract / convert
+    auto pair_pieces = [&](float v0, float v1, unsigned (&out)[NP]) {
+        if constexpr (XPK) uz::packed_pair(__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), out[0], out[1]);
+        else pieces<NP>(v0 * xs, v1 * xs, out);
+    };
     auto convert = [&](int j) {              // split / round the values of k 4j .. 4j + 3 (j = 0 also the shared-row share)
         const int i0 = 2 * j;
         unsigned t0[NP], t1[NP];
-        pieces<NP>(pr[2 * i0] * xs, pr[2 * i0 + 1] * xs, t0);
-        pieces<NP>(pr[2 * i0 + 2] * xs, pr[2 * i0 + 3] * xs, t1);
+        pair_pieces(pr[2 * i0], pr[2 * i0 + 1], t0);
+        pair_pieces(pr[2 * i0 + 2], pr[2 * i0 + 3], t1);
 #pragma unroll
         for (int q = 0; q < NP; ++q) { pk[q][i0] = t0[q]; pk[q][i0 + 1] = t1[q]; }
         if (j == 0) {
 #pragma unroll
             for (int i = 0; i < CE / 2; ++i) {
                 unsigned t2[NP];
-                pieces<NP>(pr1[2 * i] * xs, pr1[2 * i + 1] * xs, t2);
+                pair_pieces(pr1[2 * i], pr1[2 * i + 1], t2);
 #pragma unroll
                 for (int q = 0; q < NP; ++q) pk1[q][i] = t2[q];
             }
@@ -298,7 +313,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     if (p.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) stage(cbeg, tap);
-    if (NP == 2 && p.flags) {                      // bound check on the first chunk's patch (the clamp in split2 covers every chunk)
+    if (NP == 2 && !XPK && p.flags) {              // bound check on the first chunk's patch (the clamp in split2 covers every chunk)
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < CK; k += 2) bad |= uz::bound_violated(pr[k] * xs, pr[k + 1] * xs);
@@ -315,6 +330,14 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     for (int c = cbeg; c < nChunks; ++c) {
         long long ta = 0;
         if (p.stamps) ta = __builtin_amdgcn_s_memtime();
+        if (XPK && c == p.segc && c > cbeg) {
+            // the input's second segment was scaled from another bound: bring the sums so far into its units (a power of two: exact)
+            const float ratio = uz::split_scale(uz::amax_read(p.x_amax2)) * uz::split_inv_scale(uz::amax_read(p.x_amax));
+#pragma unroll
+            for (int m = 0; m < MSUB; ++m)
+#pragma unroll
+                for (int n = 0; n < NSUB; ++n) acc[m][n] *= ratio;
+        }
         __syncthreads();                       // every wave has finished the MFMAs of the previous chunk
         lstore();
         __syncthreads();
@@ -376,7 +399,8 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     // value (measured with the cycle stamps: 24 k of a workgroup's 105 - 160 k cycles, every CU's store queue full while the
     // matrix pipe idles).  Instead the tile goes through the (now dead) staging LDS, 8 * GP channels x all pixels per pass, and
     // comes back as float4 rows: a quarter of the store instructions, each wave writing whole 128-byte lines.
-    const float inv = NP == 2 ? uz::split_inv_scale(uz::amax_read(p.x_amax)) * uz::split_inv_scale(uz::amax_read(p.w_amax)) : 1.f;
+    const float* const xa_last = (XPK && p.segc > 0 && nChunks > p.segc) ? p.x_amax2 : p.x_amax;      // the bound the LAST chunk of this part was scaled from
+    const float inv = NP == 2 ? uz::split_inv_scale(uz::amax_read(xa_last)) * uz::split_inv_scale(uz::amax_read(p.w_amax)) : 1.f;
     constexpr int LDS_BYTES = lds_bytes<MSUB, NTv, TWv, NP>();
     constexpr int GP = (32 * NT * 4 <= LDS_BYTES) ? 4 : ((16 * NT * 4 <= LDS_BYTES) ? 2 : 1);    // channel groups of 8 per pass
     constexpr int ROWF = NT + 4;                         // floats per channel row (one pixel per thread, + 16 B: rows start on different banks)
@@ -386,7 +410,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     const bool split = p.kSplit > 1;                     // partial sums only: bias / accumulate / ReLU / bound happen in the reduce
     float* const obase = split ? p.slab + (size_t)part * p.N * p.Cout * p.HW + (size_t)b0 * p.Cout * p.HW
                                : p.y + (size_t)b0 * p.CoutTot * p.HW;
-    const float* const mbase = (MK && p.mask) ? p.mask + (size_t)b0 * p.maskCtot * p.HW : nullptr;
+    const float* const mbase = (MK != 0 && p.mask) ? p.mask + (size_t)b0 * p.maskCtot * p.HW : nullptr;
     const bool vec = (p.W & 3) == 0 && (reinterpret_cast<uintptr_t>(obase) & 15) == 0 && (reinterpret_cast<uintptr_t>(mbase) & 15) == 0;
     const int c4 = tid % Q, rsub = tid / Q;              // this thread's float4 column and row phase (rows rsub, rsub + 4, ...)
     const int px = 4 * c4, ty = px / TW, tx = px % TW;
@@ -398,6 +422,22 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
         if (m == 1 && half_tile) break;                  // workgroup-uniform
 #pragma unroll
         for (int g0 = 0; g0 < 4; g0 += GP) {
+            // What the rows of this pass read from memory - the tensor they accumulate onto, the producing unit's activation (MK) -
+            // is requested BEFORE the tile goes through LDS: fetched row by row inside the loop below, every row waited for its
+            // own load with one workgroup per CU to hide it (folded data gradient of 128 -> 128 @ 128 x 128: 451 -> 630 us)
+            f32x4 pre_acc[2 * GP], pre_mk[2 * GP];
+            const bool pre_a = vec && !split && p.accumulate, pre_m = vec && !split && MK != 0 && mbase;
+            if (pre_a || pre_m) {
+#pragma unroll
+                for (int j = 0; j < 2 * GP; ++j) {
+                    const int co = co0 + m * 32 + g0 * 8 + 4 * j + rsub;
+                    if (co < p.Cout && rowok) {
+                        const size_t off = (size_t)co * p.HW + (size_t)oy * p.W + ox;
+                        if (pre_a) pre_acc[j] = *reinterpret_cast<const f32x4*>(obase + off);
+                        if (pre_m) pre_mk[j] = *reinterpret_cast<const f32x4*>(mbase + off);
+                    }
+                }
+            }
             __syncthreads();                             // main loop / previous pass done with this LDS
 #pragma unroll
             for (int g = 0; g < GP; ++g)
@@ -422,18 +462,31 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
                         v = v * inv + bv;
                     }
                     if (vec) {
+                        f32x4 xh = {0.f, 0.f, 0.f, 0.f};
                         if (!split) {
-                            if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-                            if (MK && mbase) {               // ReLU backward of the producing unit (unet.py:25-30), behind the last accumulation
-                                const f32x4 mk = *reinterpret_cast<const f32x4*>(mbase + (dst - obase));
+                            if (p.accumulate) v += pre_acc[j];
+                            if (MK == 1 && mbase) {          // ReLU backward of the producing unit (unet.py:25-30), behind the last accumulation
+                                const f32x4 mk = pre_mk[j];
                                 v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                            }
+                            if (MK == 2 && mbase) {          // ReLU mask of the producing Conv -> BatchNorm -> ReLU unit and its normalised activation
+                                const f32x4 yy = pre_mk[j];
+                                const float mean = p.mk_save[co], rstd = p.mk_save[p.Cout + co], al = p.mk_save[2 * p.Cout + co], be = p.mk_save[3 * p.Cout + co];
+                                if (p.mk_relu) {
+                                    v.x = fmaf(yy.x, al, be) > 0.f ? v.x : 0.f; v.y = fmaf(yy.y, al, be) > 0.f ? v.y : 0.f;
+                                    v.z = fmaf(yy.z, al, be) > 0.f ? v.z : 0.f; v.w = fmaf(yy.w, al, be) > 0.f ? v.w : 0.f;
+                                }
+                                xh = f32x4{(yy.x - mean) * rstd, (yy.y - mean) * rstd, (yy.z - mean) * rstd, (yy.w - mean) * rstd};
                             }
                             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                             vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                         }
                         *reinterpret_cast<f32x4*>(dst) = v;
-                        st4 = f32x4{(v.x + v.y) + (v.z + v.w), (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w),
-                                    fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), fmaxf(fmaxf(-v.x, -v.y), fmaxf(-v.z, -v.w))};
+                        if (MK == 2) st4 = f32x4{(v.x + v.y) + (v.z + v.w), (v.x * xh.x + v.y * xh.y) + (v.z * xh.z + v.w * xh.w),
+                                                 fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))),
+                                                 fmaxf(fmaxf(fabsf(xh.x), fabsf(xh.y)), fmaxf(fabsf(xh.z), fabsf(xh.w)))};
+                        else st4 = f32x4{(v.x + v.y) + (v.z + v.w), (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w),
+                                         fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), fmaxf(fmaxf(-v.x, -v.y), fmaxf(-v.z, -v.w))};
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -441,9 +494,17 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
                                 float t = v[e];
                                 if (!split) {
                                     if (p.accumulate) t += dst[e];
-                                    if (MK && mbase) t = mbase[(dst - obase) + e] > 0.f ? t : 0.f;
+                                    if (MK == 1 && mbase) t = mbase[(dst - obase) + e] > 0.f ? t : 0.f;
                                     if (p.relu) t = fmaxf(t, 0.f);
                                     vmax = fmaxf(vmax, fabsf(t));
+                                }
+                                if (MK == 2 && mbase) {
+                                    const float yy = mbase[(dst - obase) + e];
+                                    if (p.mk_relu) t = fmaf(yy, p.mk_save[2 * p.Cout + co], p.mk_save[3 * p.Cout + co]) > 0.f ? t : 0.f;
+                                    const float xh1 = (yy - p.mk_save[co]) * p.mk_save[p.Cout + co];
+                                    dst[e] = t;
+                                    st4 = f32x4{st4.x + t, st4.y + t * xh1, fmaxf(st4.z, fabsf(t)), fmaxf(st4.w, fabsf(xh1))};
+                                    continue;
                                 }
                                 dst[e] = t;
                                 st4 = f32x4{st4.x + t, st4.y + t * t, fmaxf(st4.z, t), fmaxf(st4.w, -t)};
@@ -476,47 +537,62 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 }
 
 // The instances as kernels of their own (attributes take literal constants only; names show up in profiles): three tile
-// geometries x {split-fp16 (fp32-accurate), single-piece bf16}.
-template <int MSUB, int NTv, int TWv, int NP> struct SplitKernel;
-__global__ __launch_bounds__(512, 1) void conv_split_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32, 2>(p); }
-__global__ __launch_bounds__(512, 4) void conv_split_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32, 2>(p); }
-__global__ __launch_bounds__(256, 2) void conv_split_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16, 2>(p); }
-__global__ __launch_bounds__(512, 1) void conv_bf16_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32, 1>(p); }
-__global__ __launch_bounds__(512, 4) void conv_bf16_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32, 1>(p); }
-__global__ __launch_bounds__(256, 3) void conv_bf16_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16, 1>(p); }
-__global__ __launch_bounds__(512, 1) void conv_split_relu_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32, 2, true>(p); }
-__global__ __launch_bounds__(512, 4) void conv_split_relu_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32, 2, true>(p); }
-__global__ __launch_bounds__(256, 2) void conv_split_relu_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16, 2, true>(p); }
-__global__ __launch_bounds__(512, 1) void conv_bf16_relu_kernel_2_512_32(const SP p) { conv_split_body<2, 512, 32, 1, true>(p); }
-__global__ __launch_bounds__(512, 4) void conv_bf16_relu_kernel_1_512_32(const SP p) { conv_split_body<1, 512, 32, 1, true>(p); }
-__global__ __launch_bounds__(256, 3) void conv_bf16_relu_kernel_1_256_16(const SP p) { conv_split_body<1, 256, 16, 1, true>(p); }
-template <int MSUB, int NTv, int TWv, int NP> struct SplitReluKernel;
-template <> struct SplitReluKernel<2, 512, 32, 2> { static constexpr auto fn = conv_split_relu_kernel_2_512_32; };
-template <> struct SplitReluKernel<1, 512, 32, 2> { static constexpr auto fn = conv_split_relu_kernel_1_512_32; };
-template <> struct SplitReluKernel<1, 256, 16, 2> { static constexpr auto fn = conv_split_relu_kernel_1_256_16; };
-template <> struct SplitReluKernel<2, 512, 32, 1> { static constexpr auto fn = conv_bf16_relu_kernel_2_512_32; };
-template <> struct SplitReluKernel<1, 512, 32, 1> { static constexpr auto fn = conv_bf16_relu_kernel_1_512_32; };
-template <> struct SplitReluKernel<1, 256, 16, 1> { static constexpr auto fn = conv_bf16_relu_kernel_1_256_16; };
-template <> struct SplitKernel<2, 512, 32, 2> { static constexpr auto fn = conv_split_kernel_2_512_32; };
-template <> struct SplitKernel<1, 512, 32, 2> { static constexpr auto fn = conv_split_kernel_1_512_32; };
-template <> struct SplitKernel<1, 256, 16, 2> { static constexpr auto fn = conv_split_kernel_1_256_16; };
-template <> struct SplitKernel<2, 512, 32, 1> { static constexpr auto fn = conv_bf16_kernel_2_512_32; };
-template <> struct SplitKernel<1, 512, 32, 1> { static constexpr auto fn = conv_bf16_kernel_1_512_32; };
-template <> struct SplitKernel<1, 256, 16, 1> { static constexpr auto fn = conv_bf16_kernel_1_256_16; };
+// geometries x {split-fp16 (fp32-accurate), single-piece bf16} x epilogue {plain, folded ReLU backward, folded BatchNorm-backward
+// reduction} x input {fp32, split storage}.
+template <int MSUB, int NTv, int TWv, int NP, int MK, bool XPK> struct SplitKernel;
+#define UZ_SPLIT_KERNEL(name, MSUB_, NT_, TW_, NP_, MK_, XPK_, OCC_)                                                     \
+    __global__ __launch_bounds__(NT_, OCC_) void name(const SP p) { conv_split_body<MSUB_, NT_, TW_, NP_, MK_, XPK_>(p); } \
+    template <> struct SplitKernel<MSUB_, NT_, TW_, NP_, MK_, XPK_> { static constexpr auto fn = name; };
+UZ_SPLIT_KERNEL(conv_split_kernel_2_512_32, 2, 512, 32, 2, 0, false, 1)
+UZ_SPLIT_KERNEL(conv_split_kernel_1_512_32, 1, 512, 32, 2, 0, false, 4)
+UZ_SPLIT_KERNEL(conv_split_kernel_1_256_16, 1, 256, 16, 2, 0, false, 2)
+UZ_SPLIT_KERNEL(conv_bf16_kernel_2_512_32, 2, 512, 32, 1, 0, false, 1)
+UZ_SPLIT_KERNEL(conv_bf16_kernel_1_512_32, 1, 512, 32, 1, 0, false, 4)
+UZ_SPLIT_KERNEL(conv_bf16_kernel_1_256_16, 1, 256, 16, 1, 0, false, 3)
+UZ_SPLIT_KERNEL(conv_split_relu_kernel_2_512_32, 2, 512, 32, 2, 1, false, 1)
+UZ_SPLIT_KERNEL(conv_split_relu_kernel_1_512_32, 1, 512, 32, 2, 1, false, 4)
+UZ_SPLIT_KERNEL(conv_split_relu_kernel_1_256_16, 1, 256, 16, 2, 1, false, 2)
+UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_2_512_32, 2, 512, 32, 1, 1, false, 1)
+UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_1_512_32, 1, 512, 32, 1, 1, false, 4)
+UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_1_256_16, 1, 256, 16, 1, 1, false, 3)
+// round 4: input in split storage (conv_splitp_*), BatchNorm-backward reduction in the data gradient's epilogue (*_bn_*)
+UZ_SPLIT_KERNEL(conv_splitp_kernel_2_512_32, 2, 512, 32, 2, 0, true, 1)
+UZ_SPLIT_KERNEL(conv_splitp_kernel_1_512_32, 1, 512, 32, 2, 0, true, 4)
+UZ_SPLIT_KERNEL(conv_splitp_kernel_1_256_16, 1, 256, 16, 2, 0, true, 2)
+UZ_SPLIT_KERNEL(conv_split_bn_kernel_2_512_32, 2, 512, 32, 2, 2, false, 1)
+UZ_SPLIT_KERNEL(conv_split_bn_kernel_1_512_32, 1, 512, 32, 2, 2, false, 4)
+UZ_SPLIT_KERNEL(conv_split_bn_kernel_1_256_16, 1, 256, 16, 2, 2, false, 2)
+UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_2_512_32, 2, 512, 32, 2, 2, true, 1)
+UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_512_32, 1, 512, 32, 2, 2, true, 4)
+UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_256_16, 1, 256, 16, 2, 2, true, 2)
+#undef UZ_SPLIT_KERNEL
 
-template <int MSUB, int NTv, int TWv, int NP>
-int launch(const SP& p, int grid, hipStream_t st) {
+template <int MSUB, int NTv, int TWv, int NP, int MK, bool XPK>
+int launch_one(const SP& p, int grid, hipStream_t st) {
     constexpr size_t smem = lds_bytes<MSUB, NTv, TWv, NP>();
-    static bool attr_done[2] = {false, false};
-    const int mk = p.mask != nullptr;
-    auto kern = mk ? SplitReluKernel<MSUB, NTv, TWv, NP>::fn : SplitKernel<MSUB, NTv, TWv, NP>::fn;
-    if (!attr_done[mk]) {
+    static bool attr_done = false;
+    auto kern = SplitKernel<MSUB, NTv, TWv, NP, MK, XPK>::fn;
+    if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return uz::fail("conv_split: cannot raise dynamic LDS limit");
-        attr_done[mk] = true;
+        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTv), smem, st, p);
     return uz::check_launch("conv_split_kernel");
+}
+// mk: 0 plain, 1 folded ReLU backward, 2 folded BatchNorm-backward reduction; xpk: input in split storage (two-piece mode only)
+template <int MSUB, int NTv, int TWv, int NP>
+int launch(const SP& p, int grid, hipStream_t st, int mk, int xpk) {
+    if constexpr (NP == 2) {
+        if (xpk) {
+            if (mk == 1) return uz::fail("conv_split: the folded ReLU backward takes an fp32 gradient");
+            return mk == 2 ? launch_one<MSUB, NTv, TWv, 2, 2, true>(p, grid, st) : launch_one<MSUB, NTv, TWv, 2, 0, true>(p, grid, st);
+        }
+        if (mk == 2) return launch_one<MSUB, NTv, TWv, 2, 2, false>(p, grid, st);
+    } else {
+        if (xpk || mk == 2) return uz::fail("conv_split: split storage / the folded BatchNorm reduction need the two-piece fp16 mode");
+    }
+    return mk == 1 ? launch_one<MSUB, NTv, TWv, NP, 1, false>(p, grid, st) : launch_one<MSUB, NTv, TWv, NP, 0, false>(p, grid, st);
 }
 
 // tile geometry of a layer: 16 x 32 tiles (512 threads, 64- or 32-channel tiles) when the plane is wider than 32,
@@ -655,12 +731,21 @@ int absmax_flat(const float* x, size_t n, float* slot, hipStream_t st) {
 static int conv_split_impl(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
                const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, float* bn_partials, hipStream_t st,
-               const float* relu_mask, int maskCtot);
+               const SplitOpts& o);
 int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
                const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, float* bn_partials, hipStream_t st) {
     return conv_split_impl(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, dgrad, relu, accumulate, x_amax, w_amax, y_amax, workspace, packed_w,
-                           bn_partials, st, nullptr, 0);
+                           bn_partials, st, SplitOpts());
+}
+// ... with the round-4 options (uz_common.h, SplitOpts): input in split storage with up to two scale segments, and / or the
+// BatchNorm-backward reduction of the unit that produced the data gradient's output folded into the epilogue
+int conv_split_ex(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
+                  float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
+                  const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, float* bn_partials, hipStream_t st,
+                  const SplitOpts& o) {
+    return conv_split_impl(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, dgrad, relu, accumulate, x_amax, w_amax, y_amax, workspace, packed_w,
+                           bn_partials, st, o);
 }
 // Data gradient with the ReLU backward of the unit that PRODUCED its output's forward twin folded into the epilogue (vanilla U-Net
 // blocks, unet.py:25-30: Conv -> ReLU with no normalisation in between): dx = (a > 0) ? conv_T(dy, w) [+ dx] : 0, where `a` is that
@@ -670,19 +755,28 @@ int conv_split_dgrad_relu(const float* dy, int Kc, int KcTot, const float* w, in
                           const float* dy_amax, const float* w_amax, float* dx_amax, void* workspace, const void* packed_w,
                           const float* a, int aCtot, float* partials, hipStream_t st) {
     UZ_REQUIRE(a, "conv_dgrad_relu: needs the producer's activation");
+    SplitOpts o;
+    o.mk = 1; o.mask = a; o.maskCtot = aCtot;
     return conv_split_impl(dy, Kc, KcTot, w, wCi, nullptr, dx, Mc, McTot, N, H, W, 1, 0, accumulate, dy_amax, w_amax, dx_amax, workspace, packed_w,
-                           partials, st, a, aCtot);
+                           partials, st, o);
 }
 static int conv_split_impl(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
                const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, float* bn_partials, hipStream_t st,
-               const float* relu_mask, int maskCtot) {
+               const SplitOpts& o) {
+    const float* relu_mask = o.mask;
     SP p;
-    p.mask = relu_mask; p.maskCtot = maskCtot;
+    p.mask = o.mask; p.maskCtot = o.maskCtot; p.mk_save = o.mk_save; p.mk_relu = o.mk_relu;
     float* slots = static_cast<float*>(workspace);
     char* image = static_cast<char*>(workspace) + WS_HEAD;
     const int np = conv_np();                            // 1: bf16 single-piece operands (no scales, no bounds)
     UZ_REQUIRE(np == 1 || !packed_w || w_amax, "conv_split: a pre-packed weight image needs the bound it was scaled with");
+    UZ_REQUIRE(!o.x_packed || (np == 2 && x_amax), "conv_split: input in split storage needs the two-piece mode and the bound it was scaled from");
+    UZ_REQUIRE(!o.x_packed || o.seg_channels == 0 || (o.x_amax2 && o.seg_channels % CK == 0 && o.seg_channels < Kc),
+               "conv_split: the second scale segment must start on a multiple of 16 channels inside the view and carry its bound");
+    UZ_REQUIRE(o.mk != 2 || (o.mask && o.mk_save && dgrad && bn_partials), "conv_split: the folded BatchNorm reduction needs y, the statistics table and the partial rows");
+    p.x_amax2 = o.x_packed && o.seg_channels > 0 ? o.x_amax2 : nullptr;
+    p.segc = p.x_amax2 ? o.seg_channels / CK : -1;
     if (np == 2 && (!x_amax || !w_amax)) {
         if (hipMemsetAsync(slots, 0, WS_HEAD, st) != hipSuccess) return fail("conv_split: memset failed");
         if (!x_amax) { if (int rc = absmax_view(x, Kc, KcTot, N, H * W, slots, st)) return rc; x_amax = slots; }
@@ -706,7 +800,7 @@ static int conv_split_impl(const float* x, int Kc, int KcTot, const float* w, in
     p.cps = ceil_div(p.nChunks, p.kSplit);
     p.kSplit = ceil_div(p.nChunks, p.cps);               // no empty parts
     UZ_REQUIRE(!bn_partials || (p.kSplit == 1 && !relu && ((!accumulate && !dgrad) || relu_mask)), "conv_split: fused BatchNorm statistics need an unsplit plain forward convolution");
-    UZ_REQUIRE(!relu_mask || (p.kSplit == 1 && dgrad), "conv_split: the folded ReLU backward needs an unsplit data gradient");
+    UZ_REQUIRE(!relu_mask || (p.kSplit == 1 && dgrad), "conv_split: the folded ReLU / BatchNorm backward needs an unsplit data gradient");
     p.slab = reinterpret_cast<float*>(image + image_bytes(Kc, Mc, W));
     p.stamps = uz::debug_stamps;
     p.flags = dev_flags_ptr();
@@ -727,11 +821,11 @@ static int conv_split_impl(const float* x, int Kc, int KcTot, const float* w, in
     if (int rc = check_launch("pack_weights_kernel")) return rc;
     int rc;
     if (np == 2) {
-        if (tw == 16) rc = launch<1, 256, 16, 2>(p, (int)grid, st);
-        else rc = cot == 32 ? launch<1, 512, 32, 2>(p, (int)grid, st) : launch<2, 512, 32, 2>(p, (int)grid, st);
+        if (tw == 16) rc = launch<1, 256, 16, 2>(p, (int)grid, st, o.mk, o.x_packed);
+        else rc = cot == 32 ? launch<1, 512, 32, 2>(p, (int)grid, st, o.mk, o.x_packed) : launch<2, 512, 32, 2>(p, (int)grid, st, o.mk, o.x_packed);
     } else {
-        if (tw == 16) rc = launch<1, 256, 16, 1>(p, (int)grid, st);
-        else rc = cot == 32 ? launch<1, 512, 32, 1>(p, (int)grid, st) : launch<2, 512, 32, 1>(p, (int)grid, st);
+        if (tw == 16) rc = launch<1, 256, 16, 1>(p, (int)grid, st, o.mk, o.x_packed);
+        else rc = cot == 32 ? launch<1, 512, 32, 1>(p, (int)grid, st, o.mk, o.x_packed) : launch<2, 512, 32, 1>(p, (int)grid, st, o.mk, o.x_packed);
     }
     if (rc || p.kSplit == 1) return rc;
     return splitk_reduce(p.slab, p.kSplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax, st);

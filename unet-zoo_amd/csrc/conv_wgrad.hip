@@ -609,7 +609,19 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
                                   float* dw, float* db, int N, int H, int W, int ks,
                                   const float* x_amax, const float* dy_amax,
                                   void* workspace, size_t workspace_bytes, void* stream) {
+    return uz_conv_bwd_weight_ex(x, Cin, CinTot, dy, Cout, CoutTot, dw, db, N, H, W, ks, x_amax, dy_amax, workspace, workspace_bytes, 0, nullptr, 0, 0, stream);
+}
+// ... with either operand in split storage (include/uz_api.h, round 4): only on the split-fp16 path, bias gradient not available
+// (db reads dy as fp32).
+extern "C" int uz_conv_bwd_weight_ex(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
+                                     float* dw, float* db, int N, int H, int W, int ks,
+                                     const float* x_amax, const float* dy_amax, void* workspace, size_t workspace_bytes,
+                                     int x_packed, const float* x_amax2, int seg_channels, int dy_packed, void* stream) {
     UZ_REQUIRE(ks == 1 || ks == 3, "conv_bwd_weight: kernel size %d unsupported", ks);
+    const bool any_packed = x_packed || dy_packed;
+    UZ_REQUIRE(!any_packed || (uz_conv_route(2, Cin, Cout, N, H, W, ks) == 1 && uz::conv_np() == 2 && !(dy_packed && db)),
+               "conv_bwd_weight_ex: an operand in split storage, but this shape / math mode does not take the split-fp16 path (or a bias gradient was requested)");
+    UZ_REQUIRE((!x_packed || x_amax) && (!dy_packed || dy_amax), "conv_bwd_weight_ex: an operand in split storage needs the bound it was scaled from");
     UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_bwd_weight: empty tensor");
     UZ_REQUIRE(H < 1024 && W < 1024, "conv_bwd_weight: spatial size too large");
     if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) {                 // 2..8-output heads: streaming VALU kernel
@@ -655,6 +667,7 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
     const bool huge = (size_t)N * CinTot * H * W >= (1ull << 30) || (size_t)N * CoutTot * H * W >= (1ull << 30);
     UZ_REQUIRE(!(huge && g.fast), "conv_bwd_weight: a channel-slice view of a buffer of 2^30 elements or more is not supported by the tiled kernels");
     const bool split_math = !thin && !huge && uz::wgrad_split_ok(Cin, Cout, N, H, W, ks);
+    UZ_REQUIRE(!any_packed || split_math, "conv_bwd_weight_ex: split storage on a call that left the split-fp16 path");
     if (split_math) {                              // large layers: split-fp16 matrix pipe (conv_wgrad_split.hip), same slab layout
         Stot = uz::wgrad_split_splits(Cin, Cout, N, H, W);
         const size_t slab_bytes = (size_t)Stot * 9 * Cout * Cin * sizeof(float);
@@ -666,7 +679,7 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
             if (!x_amax) { if (int rc = uz::absmax_view(x, Cin, CinTot, N, H * W, slots, st)) return rc; x_amax = slots; }
             if (!dy_amax) { if (int rc = uz::absmax_view(dy, Cout, CoutTot, N, H * W, slots + uz::AMAX_FLOATS, st)) return rc; dy_amax = slots + uz::AMAX_FLOATS; }
         }
-        if (int rc = uz::wgrad_split(x, Cin, CinTot, dy, Cout, CoutTot, p.slab, N, H, W, Stot, x_amax, dy_amax, st)) return rc;
+        if (int rc = uz::wgrad_split(x, Cin, CinTot, dy, Cout, CoutTot, p.slab, N, H, W, Stot, x_amax, dy_amax, st, x_packed, x_amax2, seg_channels, dy_packed)) return rc;
     }
 #define UZ_WG_LAUNCH(KS_, WM_, WN_, PF_)                                                                         \
     do {                                                                                                         \

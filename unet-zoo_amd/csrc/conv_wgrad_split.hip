@@ -57,6 +57,7 @@ struct WS {
     int N, H, W, HW, Cin, CinTot, Cout, CoutTot;
     int tilesX, tilesY, T, S, nCoT, nCiT;
     const float* x_amax; const float* dy_amax;          // device scalars: upper bounds of |x| and |dy|
+    const float* x_amax2; int seg_channels;             // XPK: input channels from seg_channels on were scaled from x_amax2 (a concat buffer's second producer); null: one bound
     long long* stamps;                                  // diagnostics (uz_debug_stamps), normally null
     int* flags;                                         // device flag word (bound violations), nullable
 };
@@ -64,8 +65,9 @@ struct WS {
 
 // CT = channel tile on both sides: 64 (waves = co half x ci half x tap group) or 32 (waves = pixel quarter x tap
 // group; the four pixel quarters are folded through LDS at the end; 74 KB of LDS -> two workgroups per CU)
-template <int TWv, int CT, int NP>
+template <int TWv, int CT, int NP, bool XPK = false, bool DPK = false>
 __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
+    static_assert(NP == 2 || (!XPK && !DPK), "split storage is the two-piece fp16 format");
     using GEO = WGeo<TWv>;
     constexpr int TW = GEO::TW, TH = GEO::TH, XROW = GEO::XROW, QROWX = GEO::QROWX, PROWS = GEO::PROWS;
     constexpr int QROW = TW / 4, SROW = TW / 16;          // float4 quads / 16-pixel k-steps per tile row
@@ -149,13 +151,22 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         }
     };
     const float sdy = NP == 2 ? uz::split_scale(uz::amax_read(p.dy_amax)) : 1.f, sx = NP == 2 ? uz::split_scale(uz::amax_read(p.x_amax)) : 1.f;
+    // XPK / DPK: X / dY arrive as split storage (split_f16.h): every word already holds the two fp16 pieces of its scaled value
+    auto xpieces = [&](float v0, float v1, unsigned (&out)[NP]) __attribute__((always_inline)) {
+        if constexpr (XPK) uz::packed_pair(__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), out[0], out[1]);
+        else pieces<NP>(v0 * sx, v1 * sx, out);
+    };
+    auto dpieces = [&](float v0, float v1, unsigned (&out)[NP]) __attribute__((always_inline)) {
+        if constexpr (DPK) uz::packed_pair(__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), out[0], out[1]);
+        else pieces<NP>(v0 * sdy, v1 * sdy, out);
+    };
     auto lstore = [&](int t) __attribute__((always_inline)) {
         const bool left_edge = t % p.tilesX == 0;               // tile column 0: the quads with q == 0 were loaded one column to the right
 #pragma unroll
         for (int i = 0; i < DYSLOTS; ++i) {
             unsigned pa[NP], pb[NP];
-            pieces<NP>(dreg[i][0] * sdy, dreg[i][1] * sdy, pa);
-            pieces<NP>(dreg[i][2] * sdy, dreg[i][3] * sdy, pb);
+            dpieces(dreg[i][0], dreg[i][1], pa);
+            dpieces(dreg[i][2], dreg[i][3], pb);
             const int e = tid + i * NT, co = e >> 5, q = e & 31;
             char* d = dYl + co * DYROW + ((q / QROW) * TW + (q % QROW) * 4) * 2;
 #pragma unroll
@@ -168,8 +179,8 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
                 const int q = e % QROWX, r = e / QROWX, ci = r / PROWS, prow = r - ci * PROWS;
                 unsigned pa[NP], pb[NP];
                 const f32x4 v = (left_edge && q == 0) ? f32x4{0.f, xq[i][0], xq[i][1], xq[i][2]} : xq[i];
-                pieces<NP>(v[0] * sx, v[1] * sx, pa);
-                pieces<NP>(v[2] * sx, v[3] * sx, pb);
+                xpieces(v[0], v[1], pa);
+                xpieces(v[2], v[3], pb);
                 char* d = Xl + ci * XCH + prow * XROW + q * 8;
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * XPLANE) = make_uint2(pa[pl], pb[pl]);
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             if (e < CIT * PROWS) {
                 const int ci = e / PROWS, prow = e - ci * PROWS;
                 unsigned pa[NP];
-                pieces<NP>(xp[i][0] * sx, xp[i][1] * sx, pa);
+                xpieces(xp[i][0], xp[i][1], pa);
                 char* d = Xl + ci * XCH + prow * XROW + QROWX * 8;
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<unsigned*>(d + pl * XPLANE) = pa[pl];
@@ -206,10 +217,14 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         if (t < p.T) gload(t, -1);
         if (NP == 2 && p.flags && t < p.T) {            // bound check on the first tile (the clamp in split2 covers every tile)
             bool bx = false, bd = false;
+            if (!DPK) {
 #pragma unroll
-            for (int i = 0; i < DYSLOTS; ++i) { bd |= uz::bound_violated(dreg[i][0] * sdy, dreg[i][1] * sdy); bd |= uz::bound_violated(dreg[i][2] * sdy, dreg[i][3] * sdy); }
+                for (int i = 0; i < DYSLOTS; ++i) { bd |= uz::bound_violated(dreg[i][0] * sdy, dreg[i][1] * sdy); bd |= uz::bound_violated(dreg[i][2] * sdy, dreg[i][3] * sdy); }
+            }
+            if (!XPK) {
 #pragma unroll
-            for (int i = 0; i < XQSLOTS; ++i) { bx |= uz::bound_violated(xq[i][0] * sx, xq[i][1] * sx); bx |= uz::bound_violated(xq[i][2] * sx, xq[i][3] * sx); }
+                for (int i = 0; i < XQSLOTS; ++i) { bx |= uz::bound_violated(xq[i][0] * sx, xq[i][1] * sx); bx |= uz::bound_violated(xq[i][2] * sx, xq[i][3] * sx); }
+            }
             if (bd) atomicOr(p.flags, uz::FLAG_DY_BOUND);
             if (bx) atomicOr(p.flags, uz::FLAG_X_BOUND);
         }
@@ -301,7 +316,9 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         }
         float* out = p.slab + (size_t)split * 9 * p.Cout * p.Cin;
         const int ci = ci0 + wn * 32 + l31;
-        const float inv_dy = NP == 2 ? uz::split_inv_scale(uz::amax_read(p.dy_amax)) : 1.f, inv_x = NP == 2 ? uz::split_inv_scale(uz::amax_read(p.x_amax)) : 1.f;      // exact powers of two
+        // exact powers of two; with two-segment split storage the input scale is a property of the column (ci) - K is pixels here
+        const float inv_dy = NP == 2 ? uz::split_inv_scale(uz::amax_read(p.dy_amax)) : 1.f;
+        const float inv_x = NP == 2 ? uz::split_inv_scale(uz::amax_read((XPK && p.x_amax2 && ci >= p.seg_channels) ? p.x_amax2 : p.x_amax)) : 1.f;
 #pragma unroll
         for (int k = 0; k < NTAP; ++k)
 #pragma unroll
@@ -361,28 +378,36 @@ int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
     return s;
 }
 
-template <int TWv, int CT, int NP>
+template <int TWv, int CT, int NP, bool XPK = false, bool DPK = false>
 static int launch_wgrad_np(const WS& p, int grid, hipStream_t st) {
     // (the 32-channel kernel folds its pixel quarters through this LDS at the end: three taps x 16 x 64 floats per wave pair)
     constexpr size_t stage = NP * (size_t)(CT * DYROW) + NP * (size_t)(CT * XCH), fold = CT == 32 ? (size_t)4 * 3 * 16 * 64 * 4 : 0;
     constexpr size_t smem = stage > fold ? stage : fold;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<TWv, CT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<TWv, CT, NP, XPK, DPK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return fail("wgrad_split: cannot raise dynamic LDS limit");
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad_split_kernel<TWv, CT, NP>), dim3(grid), dim3(NT), smem, st, p);
+    hipLaunchKernelGGL((wgrad_split_kernel<TWv, CT, NP, XPK, DPK>), dim3(grid), dim3(NT), smem, st, p);
     return check_launch("wgrad_split_kernel");
 }
 template <int TWv, int CT>
-static int launch_wgrad(const WS& p, int grid, hipStream_t st) {
-    return conv_np() == 2 ? launch_wgrad_np<TWv, CT, 2>(p, grid, st) : launch_wgrad_np<TWv, CT, 1>(p, grid, st);
+static int launch_wgrad(const WS& p, int grid, hipStream_t st, int xpk, int dpk) {
+    if (conv_np() != 2) {
+        if (xpk || dpk) return fail("wgrad_split: split storage needs the two-piece fp16 mode");
+        return launch_wgrad_np<TWv, CT, 1>(p, grid, st);
+    }
+    if (xpk) return dpk ? launch_wgrad_np<TWv, CT, 2, true, true>(p, grid, st) : launch_wgrad_np<TWv, CT, 2, true, false>(p, grid, st);
+    return dpk ? launch_wgrad_np<TWv, CT, 2, false, true>(p, grid, st) : launch_wgrad_np<TWv, CT, 2, false, false>(p, grid, st);
 }
 
 int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* slab,
-                int N, int H, int W, int S, const float* x_amax, const float* dy_amax, hipStream_t st) {
+                int N, int H, int W, int S, const float* x_amax, const float* dy_amax, hipStream_t st,
+                int x_packed, const float* x_amax2, int seg_channels, int dy_packed) {
     WS p;
+    p.x_amax2 = (x_packed && seg_channels > 0) ? x_amax2 : nullptr; p.seg_channels = seg_channels;
+    UZ_REQUIRE(!x_packed || seg_channels == 0 || (x_amax2 && seg_channels < Cin), "wgrad_split: the second scale segment needs its bound");
     p.x = x; p.dy = dy; p.slab = slab; p.x_amax = x_amax; p.dy_amax = dy_amax; p.stamps = debug_stamps; p.flags = dev_flags_ptr();
     p.N = N; p.H = H; p.W = W; p.HW = H * W; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot;
     const int tw = tile_w(W), ct = chan_tile(Cin, Cout);
@@ -390,8 +415,8 @@ int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, 
     p.nCoT = ceil_div(Cout, ct); p.nCiT = ceil_div(Cin, ct);
     UZ_REQUIRE((size_t)N * CinTot * p.HW < (1ull << 30) && (size_t)N * CoutTot * p.HW < (1ull << 30), "wgrad_split: tensor too large for 32-bit offsets (the dispatcher routes such tensors to the fp32 kernel)");
     const int grid = p.nCoT * p.nCiT * S;
-    if (ct == 32) return tw == 16 ? launch_wgrad<16, 32>(p, grid, st) : launch_wgrad<32, 32>(p, grid, st);
-    return tw == 16 ? launch_wgrad<16, 64>(p, grid, st) : launch_wgrad<32, 64>(p, grid, st);
+    if (ct == 32) return tw == 16 ? launch_wgrad<16, 32>(p, grid, st, x_packed, dy_packed) : launch_wgrad<32, 32>(p, grid, st, x_packed, dy_packed);
+    return tw == 16 ? launch_wgrad<16, 64>(p, grid, st, x_packed, dy_packed) : launch_wgrad<32, 64>(p, grid, st, x_packed, dy_packed);
 }
 
 }  // namespace uz

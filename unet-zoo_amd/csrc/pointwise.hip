@@ -487,6 +487,31 @@ __global__ __launch_bounds__(256) void zero_k(float* __restrict__ p, size_t n) {
 __global__ __launch_bounds__(256) void copy_k(float* __restrict__ d, const float* __restrict__ s, size_t n) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) d[e] = s[e];
 }
+// ---- split storage <-> fp32 (include/uz_api.h, round 4; tests and tools - the model plans never convert whole tensors)
+namespace {
+__global__ __launch_bounds__(256) void pack_split_k(const float* __restrict__ x, unsigned* __restrict__ out, size_t n, const float* __restrict__ amax) {
+    const float s = uz::split_scale(uz::amax_read(amax));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = uz::pack_split(x[i], s);
+}
+__global__ __launch_bounds__(256) void unpack_split_k(const unsigned* __restrict__ in, float* __restrict__ x, size_t n, const float* __restrict__ amax) {
+    const float inv = uz::split_inv_scale(uz::amax_read(amax));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = uz::unpack_split(in[i], inv);
+}
+inline int stream_grid(size_t n) { size_t g = (n + 256 * 8 - 1) / (256 * 8); return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+}  // namespace
+extern "C" int uz_pack_split(const float* x, float* packed, size_t n, const float* amax, void* stream) {
+    UZ_REQUIRE(x && packed && amax, "pack_split: null argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pack_split_k, dim3(stream_grid(n)), dim3(256), 0, uz::S(stream), x, reinterpret_cast<unsigned*>(packed), n, amax);
+    return uz::check_launch("pack_split_k");
+}
+extern "C" int uz_unpack_split(const float* packed, float* x, size_t n, const float* amax, void* stream) {
+    UZ_REQUIRE(x && packed && amax, "unpack_split: null argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(unpack_split_k, dim3(stream_grid(n)), dim3(256), 0, uz::S(stream), reinterpret_cast<const unsigned*>(packed), x, n, amax);
+    return uz::check_launch("unpack_split_k");
+}
+
 extern "C" int uz_zero_f32(float* p, size_t n, void* stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(zero_k, dim3(vgrid(n)), dim3(256), 0, uz::S(stream), p, n);

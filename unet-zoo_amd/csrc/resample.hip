@@ -18,6 +18,7 @@ struct RsP {
     int ac, factor, accumulate;
     float sh, sw;
     const float* x_amax; float* y_amax;   // forward pooling / interpolation are convex combinations: |y| <= bound of |x|
+    int pack;                             // forward pooling / interpolation: write dst as split storage scaled from *x_amax (split_f16.h)
     // backward kernels, optional: dst is the gradient w.r.t. the OUTPUT A of a Conv -> ReLU unit (vanilla U-Net blocks) and this launch
     // is its last writer - apply the unit's ReLU mask (a > 0), leave per-workgroup sums for its bias gradient, publish max |dst|
     const float* mask; int CtotM; double* part; float* m_amax;
@@ -37,6 +38,11 @@ __device__ __forceinline__ void fold_finish(const RsP& p, int c, int b, const Re
     if (p.m_amax) uz::amax_publish(f.vmax, p.m_amax);
 }
 
+// output value as stored: the fp32 value, or (split storage) the word holding its two fp16 pieces
+__device__ __forceinline__ float out_word(const RsP& p, float v, float s) {
+    return p.pack ? __builtin_bit_cast(float, uz::pack_split(v, s)) : v;
+}
+__device__ __forceinline__ float pack_scale(const RsP& p) { return p.pack ? uz::split_scale(uz::amax_read(p.x_amax)) : 1.f; }
 // the output bound of a pooling / interpolation pass is its input's bound (one lane of the grid forwards it)
 __device__ __forceinline__ void forward_bound(const RsP& p) {
     if (p.y_amax && p.x_amax && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
@@ -51,6 +57,7 @@ __global__ __launch_bounds__(256) void avgpool_fwd_k(const RsP p) {
     const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
     float* d = p.dst + ((size_t)b * p.CtotD + c) * p.H * p.W;
     const int n = p.H * p.W;
+    const float ps = pack_scale(p);
     for (int q = blockIdx.x * PCH + threadIdx.x; q < min(n, (int)(blockIdx.x + 1) * PCH); q += 256) {
         const int oy = q / p.W, ox = q - oy * p.W;
         const int y0 = 2 * oy, x0 = 2 * ox;
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(256) void avgpool_fwd_k(const RsP p) {
         float acc = 0.f;
         for (int yy = y0; yy < y1; ++yy)
             for (int xx = x0; xx < x1; ++xx) acc += s[yy * p.Wo + xx];
-        d[q] = acc / (float)((y1 - y0) * (x1 - x0));
+        d[q] = out_word(p, acc / (float)((y1 - y0) * (x1 - x0)), ps);
     }
 }
 __global__ __launch_bounds__(256) void avgpool_bwd_k(const RsP p) {   // src = dy (low res), dst = dx (high res)
@@ -95,6 +102,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_k(const RsP p) {
     const float* s = p.src + ((size_t)b * p.CtotS + c) * p.H * p.W;
     float* d = p.dst + ((size_t)b * p.CtotD + c) * p.Ho * p.Wo;
     const int n = p.Ho * p.Wo;
+    const float ps = pack_scale(p);
     for (int q = blockIdx.x * PCH + threadIdx.x; q < min(n, (int)(blockIdx.x + 1) * PCH); q += 256) {
         const int oy = q / p.Wo, ox = q - oy * p.Wo;
         int h1, hp, w1, wp; float h0l, h1l, w0l, w1l;
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_k(const RsP p) {
         src_index(ox, p.sw, p.ac, p.W, w1, wp, w0l, w1l);
         const float* r0 = s + h1 * p.W + w1;
         const float* r1 = r0 + hp * p.W;
-        d[q] = h0l * (w0l * r0[0] + w1l * r0[wp]) + h1l * (w0l * r1[0] + w1l * r1[wp]);
+        d[q] = out_word(p, h0l * (w0l * r0[0] + w1l * r0[wp]) + h1l * (w0l * r1[0] + w1l * r1[wp]), ps);
     }
 }
 // gather form of upsample_bilinear2d_backward: every low-res pixel sums the <= 7x7 high-res pixels
@@ -247,6 +255,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_band_k(const RsP p) {
     }
     __syncthreads();
     const int o4 = p.Wo / 4;
+    const float ps = pack_scale(p);
     for (int e = threadIdx.x; e < nout * o4; e += 256) {
         const int r = e / o4, q = e - r * o4, oy = oy0 + r;
         int h1, hp; float h0l, h1l;
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_band_k(const RsP p) {
             const float w1l = xl[ox], w0l = 1.f - w1l;
             v[j] = h0l * (w0l * r0[w1] + w1l * r0[w1 + wp]) + h1l * (w0l * r1[w1] + w1l * r1[w1 + wp]);
         }
-        *reinterpret_cast<float4*>(d + (size_t)oy * p.Wo + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(d + (size_t)oy * p.Wo + 4 * q) = make_float4(out_word(p, v[0], ps), out_word(p, v[1], ps), out_word(p, v[2], ps), out_word(p, v[3], ps));
     }
 }
 
@@ -338,8 +347,13 @@ int check_dims(const char* op, int C, int N, int H, int W) {
 
 extern "C" int uz_avgpool2_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W,
                                const float* x_amax, float* y_amax, void* stream) {
+    return uz_avgpool2_fwd_ex(x, C, CtotX, y, CtotY, N, H, W, x_amax, y_amax, 0, stream);
+}
+extern "C" int uz_avgpool2_fwd_ex(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W,
+                                  const float* x_amax, float* y_amax, int out_packed, void* stream) {
     if (int rc = check_dims("avgpool2_fwd", C, N, H, W)) return rc;
-    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N; p.x_amax = x_amax; p.y_amax = y_amax;
+    UZ_REQUIRE(!out_packed || (x_amax && y_amax), "avgpool2_fwd_ex: split storage needs the input's bound and the output's slot");
+    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N; p.x_amax = x_amax; p.y_amax = y_amax; p.pack = out_packed;
     p.Ho = H; p.Wo = W; p.H = (H + 1) / 2; p.W = (W + 1) / 2;
     RS_LAUNCH(avgpool_fwd_k, p.H * p.W);
 }
@@ -373,8 +387,13 @@ static void bil_scales(RsP& p) {
 }
 extern "C" int uz_bilinear2x_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W, int align_corners,
                                  const float* x_amax, float* y_amax, void* stream) {
+    return uz_bilinear2x_fwd_ex(x, C, CtotX, y, CtotY, N, H, W, align_corners, x_amax, y_amax, 0, stream);
+}
+extern "C" int uz_bilinear2x_fwd_ex(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W, int align_corners,
+                                    const float* x_amax, float* y_amax, int out_packed, void* stream) {
     if (int rc = check_dims("bilinear2x_fwd", C, N, H, W)) return rc;
-    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N; p.x_amax = x_amax; p.y_amax = y_amax;
+    UZ_REQUIRE(!out_packed || (x_amax && y_amax), "bilinear2x_fwd_ex: split storage needs the input's bound and the output's slot");
+    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N; p.x_amax = x_amax; p.y_amax = y_amax; p.pack = out_packed;
     p.H = H; p.W = W; p.Ho = 2 * H; p.Wo = 2 * W; p.ac = align_corners; bil_scales(p);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (W % 4 == 0 && W <= FWMAX && H >= 4 && al16(x) && al16(y)) {     // W % 4 == 0 keeps every (image, channel) plane of both sides float4-aligned

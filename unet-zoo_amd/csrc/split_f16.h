@@ -56,6 +56,28 @@ __device__ __forceinline__ void split2(float v0, float v1, unsigned& p1, unsigne
     p2 = __builtin_bit_cast(unsigned, h2);
 }
 
+// ---- split storage ("packed" operands, round 4).  A producer that knows its tensor's bound before it writes the first element
+// (BatchNorm forward: the exact output range follows from the statistics; BatchNorm backward: the analytic bound; pooling and
+// interpolation: their input's bound) stores every element as ONE 32-bit word holding the two fp16 pieces of v * s
+// (low half = h1, high half = h2, s = split_scale(bound)) instead of the fp32 value.  Same bytes; the consuming matrix kernels
+// stage the word as it is (two byte permutes per pair of elements instead of scale / clamp / convert / subtract / convert), and
+// h1 + h2 reproduces v * s to 2^-22 - exactly the operand the consumer would have formed from the fp32 value itself.
+__device__ __forceinline__ unsigned pack_split(float v, float s) {
+    const float t = v * s;
+    const _Float16 h1 = (_Float16)t;                                        // round to nearest even
+    const _Float16 h2 = (_Float16)(t - (float)h1);                          // the subtraction is exact
+    return (unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
+}
+__device__ __forceinline__ float unpack_split(unsigned w, float inv_s) {
+    const _Float16 h1 = __builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)), h2 = __builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+    return ((float)h1 + (float)h2) * inv_s;
+}
+// two packed words (elements k, k + 1) -> the pair's h1 plane word and h2 plane word (element k in the low half)
+__device__ __forceinline__ void packed_pair(unsigned w0, unsigned w1, unsigned& p1, unsigned& p2) {
+    p1 = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+    p2 = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+}
+
 // ---- magnitude-bound slots.  A slot is AMAX_SUB sub-slots AMAX_STRIDE floats (64 bytes) apart; its value is the maximum
 // over the sub-slots.  Same-address float atomics serialise at the memory side (MI355X_MICROARCH.md, Global float atomics:
 // every workgroup into one row is 14x slower), so producers (a) spread their updates over the sub-slots and (b) read the

@@ -72,26 +72,36 @@ static int run_one(const uz_op& o, void* st) {
     switch (o.code) {
         case UZ_OP_CONV_FWD:
             if (i[9]) return uz_conv_fwd_slabs(CFP(0), i[0], i[1], CFP(1), i[2], i[4], i[5], i[6], i[7], p[4], (size_t)o.n, st);      // the unit's BatchNorm adds the slabs
-            return uz_conv_fwd_bnstats(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(5), CFP(6), FP(7), p[4], (size_t)o.n, p[8], FP(9), st);
+            // i[10] = input in split storage, p[10] / i[11] = bound and first channel of its second scale segment
+            return uz_conv_fwd_ex(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(5), CFP(6), FP(7), p[4], (size_t)o.n, p[8], FP(9),
+                                  i[10], CFP(10), i[11], st);
         case UZ_OP_CONV_BWD_DATA:
-            if (p[7]) return uz_conv_bwd_data_relu(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], CFP(7), i[9], FP(8), FP(9), st);
-            return uz_conv_bwd_data_packed(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], st);
+            // i[10]: fold of the unit that produced the output's forward twin - 1 ReLU mask (p[7] = its activation), 2 BatchNorm-backward
+            // reduction (p[7] = its pre-normalisation output, p[10] = its statistics table, i[12] = its relu flag); i[11] = dy in split storage
+            if (i[10] == 1) return uz_conv_bwd_data_relu(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], CFP(7), i[9], FP(8), FP(9), st);
+            return uz_conv_bwd_data_ex(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], i[11],
+                                       i[10] == 2 ? CFP(7) : nullptr, i[9], CFP(10), i[12], FP(8), st);
         case UZ_OP_CONV_BWD_WEIGHT:
-            return uz_conv_bwd_weight(CFP(0), i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], i[7], CFP(5), CFP(6), p[4], (size_t)o.n, st);
+            // i[8] = x in split storage, p[7] / i[9] = second scale segment of x, i[10] = dy in split storage
+            return uz_conv_bwd_weight_ex(CFP(0), i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], i[7], CFP(5), CFP(6), p[4], (size_t)o.n,
+                                         i[8], CFP(7), i[9], i[10], st);
         case UZ_OP_BN_RELU_FWD:
             if (i[9] > 1) return uz_bn_relu_fwd_slabs(CFP(10), i[9], CFP(11), FP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], FP(8), st);
-            return uz_bn_relu_fwd_pre(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], FP(8), p[7], CFP(9), i[8], st);
+            // (save holds 4 C floats in plans; i[10] = write the activation as split storage)
+            return uz_bn_relu_fwd_ex(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], FP(8), p[7], CFP(9), i[8], i[10], st);
         case UZ_OP_BN_RELU_BWD:
-            return uz_bn_relu_bwd(CFP(0), i[0], CFP(1), i[1], i[2], CFP(2), CFP(3), CFP(4), FP(5), i[3], FP(6), FP(7), FP(8), i[4], i[5], i[6], i[7], FP(10), p[9], st);
+            // p[11] / i[8] = reduction partials left by the data gradient that wrote dA last, i[9] = write dy as split storage
+            return uz_bn_relu_bwd_ex(CFP(0), i[0], CFP(1), i[1], i[2], CFP(2), CFP(3), CFP(4), FP(5), i[3], FP(6), FP(7), FP(8), i[4], i[5], i[6], i[7], FP(10), p[9],
+                                     CFP(11), i[8], i[9], st);
         case UZ_OP_RELU_BWD:
             return uz_relu_bwd(CFP(0), i[0], CFP(1), i[1], i[2], FP(2), i[3], FP(3), i[4], i[5], i[6], FP(5), p[4], st);
         case UZ_OP_AVGPOOL_FWD:
-            return uz_avgpool2_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], CFP(2), FP(3), st);
+            return uz_avgpool2_fwd_ex(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], CFP(2), FP(3), i[6], st);
         case UZ_OP_AVGPOOL_BWD:
             if (p[2]) return uz_avgpool2_bwd_relu(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], CFP(2), i[7], static_cast<double*>(p[3]), FP(4), st);
             return uz_avgpool2_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], st);
         case UZ_OP_BILINEAR_FWD:
-            return uz_bilinear2x_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], CFP(2), FP(3), st);
+            return uz_bilinear2x_fwd_ex(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], CFP(2), FP(3), i[7], st);
         case UZ_OP_BILINEAR_BWD:
             if (p[2]) return uz_bilinear2x_bwd_relu(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], i[7], CFP(2), i[8], static_cast<double*>(p[3]), FP(4), st);
             return uz_bilinear2x_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], i[7], st);

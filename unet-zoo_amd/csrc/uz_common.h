@@ -64,6 +64,20 @@ int splitk_reduce(const float* slab, int ksplit, const float* bias, float* y, in
 int conv_split(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
                const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, float* bn_partials, hipStream_t st);
+// round-4 options of the split path
+struct SplitOpts {
+    int x_packed = 0;                       // the input operand (x, or dy for a data gradient) is split storage (split_f16.h)
+    const float* x_amax2 = nullptr;         // ... whose channels from seg_channels on were scaled from this bound instead of x_amax
+    int seg_channels = 0;
+    int mk = 0;                             // epilogue: 0 plain, 1 ReLU mask of the producing unit (mask = its activation), 2 BatchNorm-backward reduction
+    const float* mask = nullptr; int maskCtot = 0;
+    const float* mk_save = nullptr;         // mk == 2: [4][C] {mean, rstd, alpha, beta'} of the producing unit (uz_bn_relu_fwd_ex)
+    int mk_relu = 1;
+};
+int conv_split_ex(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
+                  float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
+                  const float* x_amax, const float* w_amax, float* y_amax, void* workspace, const void* packed_w, float* bn_partials, hipStream_t st,
+                  const SplitOpts& o);
 int conv_split_dgrad_relu(const float* dy, int Kc, int KcTot, const float* w, int wCi, float* dx, int Mc, int McTot, int N, int H, int W, int accumulate,
                           const float* dy_amax, const float* w_amax, float* dx_amax, void* workspace, const void* packed_w,
                           const float* a, int aCtot, float* partials, hipStream_t st);   // conv_split.hip
@@ -73,7 +87,8 @@ int conv_split_bn_partials(int Kc, int Mc, int N, int H, int W);
 bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks);
 int wgrad_split_splits(int Cin, int Cout, int N, int H, int W);
 int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* slab,
-                int N, int H, int W, int S, const float* x_amax, const float* dy_amax, hipStream_t st);
+                int N, int H, int W, int S, const float* x_amax, const float* dy_amax, hipStream_t st,
+                int x_packed = 0, const float* x_amax2 = nullptr, int seg_channels = 0, int dy_packed = 0);      // *_packed: operand in split storage
 
 // conv1x1_small.hip: streaming VALU kernels for 1x1 convolutions with <= 8 outputs (-2 = shape not covered)
 bool conv1x1_small_ok(int Cin, int Cout);

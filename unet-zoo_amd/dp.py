@@ -1,9 +1,16 @@
-"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm).
+"""Data-parallel plumbing: one process per GPU.
 
-The hot path shards by samples: every rank holds a full replica, runs forward/backward on its own
-images and the only exchange is ONE sum-all-reduce of the flat fp32 gradient buffer per step
-(98 MB for PHiSeg 7/5), scaled by 1/world_size - identical to the full-batch mean-loss gradient
-for equal shard sizes (BatchNorm statistics stay per replica, as in DDP).  SURVEY.md 8e.
+The hot path shards by samples: every rank holds a full replica and runs forward / backward on its own images; the only
+data-path exchange is the average of the flat fp32 gradient buffer (98 MB for PHiSeg 7/5), identical to the full-batch
+mean-loss gradient for equal shard sizes (BatchNorm statistics stay per replica, as in DDP).
+
+Two planes:
+  * control plane - a gloo process group on the HOST (init_from_env): the RCCL unique-id hand-off, barriers, the maximum over
+    ranks of the timed region, the scheduler's mean loss (mean_scalar) and collective decisions (max_int);
+  * data plane - ONE RCCL communicator per process, opened through the C ABI (uz_comm_init, csrc/comm.hip) by GradSync:
+    parameters are broadcast and gradients averaged on it, bucket by bucket (one bucket per sub-network), each bucket as soon
+    as the backward tape has finished it, on a communication stream beside the remaining backward kernels.
+    backend="torch" swaps the data plane for torch.distributed collectives (the gloo test double of the CPU tier).
 """
 import os
 
@@ -40,6 +47,18 @@ def mean_scalar(t, group=None):
         v = v.cpu()                              # host control plane: the scheduler compares on the host anyway (one sync per step)
     dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
     return (v / dist.get_world_size(group)).reshape(()).to(t.device)
+
+
+def max_int(v, group=None):
+    """Maximum of a host integer over the ranks (identity for a single process): collective decisions - e.g. "did ANY rank see
+    a violated magnitude bound" - must come out the same everywhere, or the ranks' collectives stop pairing up."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return int(v)
+    t = torch.tensor([int(v)], dtype=torch.int64)
+    if dist.get_backend(group) != "gloo":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
 
 
 def shard_bounds(n, rank, world):

@@ -161,20 +161,25 @@ class UNetModel:
         patch = torch.as_tensor(x_b, dtype=torch.float32).to(self.device)          # no-ops for the device tensors of the native provider
         mask = torch.unsqueeze(torch.as_tensor(s_b, dtype=torch.float32).to(self.device), 1)
         self.mask, self.patch = mask, patch
+        guarded = hasattr(self.net, "guard_bounds")
+        if guarded:
+            self.net.snapshot_step()
         self.net.forward(patch, mask, training=True)
         self.loss = self.net.loss(mask)
-        self.tot_loss += self.loss.detach()
-        self.reconstruction_loss += getattr(self.net, "reconstruction_loss", 0)
-        self.kl_loss += getattr(self.net, "kl_divergence_loss", 0)
         self.optimizer.zero_grad()
         self.loss.backward()
-        if hasattr(self.net, "guard_bounds") and self.net.guard_bounds():
+        if guarded and self.net.guard_bounds():
             # a split-fp16 kernel clamped a tensor (never expected: the bounds are maintained by the producing kernels) - the
-            # engine has switched to fp32 MFMA arithmetic; repeat this batch there before the parameters are touched
+            # engine has switched to fp32 MFMA arithmetic on EVERY rank (the decision is collective); repeat this batch there
+            # before the parameters are touched: same eps, BatchNorm buffers and counters rewound, so it is the same step
+            self.net.restore_step()
             self.net.forward(patch, mask, training=True)
             self.loss = self.net.loss(mask)
             self.optimizer.zero_grad()
             self.loss.backward()
+        self.tot_loss += self.loss.detach()
+        self.reconstruction_loss += getattr(self.net, "reconstruction_loss", 0)
+        self.kl_loss += getattr(self.net, "kl_divergence_loss", 0)
         self.optimizer.step()
         return self.loss
 
