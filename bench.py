@@ -748,7 +748,7 @@ def main():
                 line["dp"] = dict(backend=sync.backend, nranks=sync.nranks(), control_plane="gloo (host): unique id, barriers, max of elapsed",
                                   communicators=1 if sync.backend == "rccl" else 0, launcher="self" if os.environ.get("UZ_BENCH_SELF_LAUNCHED") else "external",
                                   buckets_MB=[round(4 * (hi - lo) / 1e6, 1) for lo, hi in sync.buckets],
-                                  exposed_allreduce_ms=sync.exposed_ms())
+                                  exposed_allreduce_ms=sync.exposed_ms(), exposed_allreduce_ms_per_bucket=sync.exposed_ms_per_bucket())
                 if line["dp"]["nranks"] != world:
                     raise SystemExit(f"data-parallel group reports {line['dp']['nranks']} ranks, the line says {world}")
         line.update(extra)

@@ -228,7 +228,9 @@ int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, int C, int Ct
                       const float* gamma, const float* beta, const float* save_mean_rstd,
                       float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
                       int N, int H, int W, int relu, float* dy_amax, void* workspace,
-                      const float* conv_partials, int n_partials, int out_packed, void* stream);
+                      const float* conv_partials, int n_partials, int out_packed, double* dbias_partials, void* stream);
+int uz_bn_bwd_fused_limit(int H, int W);         /* N*H*W up to which uz_bn_relu_bwd(_ex) is one launch with the channel's batch on chip: no out_packed / dbias_partials there */
+int uz_bn_bwd_dbias_rows(int N, int H, int W);   /* rows of dbias_partials ([rows][C] doubles, summed by uz_chan_sum_table); 0: small-plane path */
 int uz_avgpool2_fwd_ex(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W,
                        const float* x_amax, float* y_amax, int out_packed, void* stream);
 int uz_bilinear2x_fwd_ex(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W, int align_corners,
@@ -245,7 +247,14 @@ int uz_conv_bwd_data_ex(const float* dy, int Cout, int CoutTot, const float* w, 
 int uz_conv_bwd_weight_ex(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
                           float* dw, float* db, int N, int H, int W, int ks,
                           const float* x_amax, const float* dy_amax, void* workspace, size_t workspace_bytes,
-                          int x_packed, const float* x_amax2, int seg_channels, int dy_packed, void* stream);
+                          int x_packed, const float* x_amax2, int seg_channels, int dy_packed, float* slabs_out, void* stream);
+/* Weight-gradient slab reductions of many layers in ONE launch.  slabs_out (above, nullable): the call leaves its
+ * uz_conv_bwd_weight_slabs() x ks*ks x Cout x Cin partial sums there instead of reducing them into dw; uz_wgrad_reduce_table adds
+ * them later - table rows of 8 int64 {slabs, dw, S, Cout, Cin, ks*ks, first block, 0}, blocks counted by uz_wgrad_reduce_blocks().
+ * Same order of additions as the in-call reduction (bitwise the same dw).                                                        */
+int uz_conv_bwd_weight_slabs(int Cin, int Cout, int N, int H, int W, int ks);
+int uz_wgrad_reduce_blocks(int Cin, int Cout, int ks);
+int uz_wgrad_reduce_table(const int64_t* table, int n_layers, int total_blocks, void* stream);
 
 /* ---------------------------------------------------------------- resampling
  * nn.AvgPool2d(2, 2, padding=0, ceil_mode=True): phiseg.py:23, unet.py:22,
@@ -387,6 +396,7 @@ enum {
   UZ_OP_EVENT_RECORD,    /* p[0] = event (uz_event_create): marks "every earlier op this one depends on is done" */
   UZ_OP_PACK_WEIGHTS,    /* p[0] = table, p[1] = w_amax; i = n_layers, total_rows (uz_conv_pack_weights); CONV_FWD p[8] / CONV_BWD_DATA p[6] = image */
   UZ_OP_CHAN_SUM_TABLE,    /* p[0] = table (uz_chan_sum_table), p[1] = the gradient regions it writes; i = n_entries, max_channels */
+  UZ_OP_WGRAD_REDUCE_TABLE, /* p[0] = table (uz_wgrad_reduce_table), p[1] = the gradient regions it writes; i = n_layers, total_blocks */
   UZ_OP_CHAN_SUM_PARTIALS, /* p = partials, out; i = n_rows, C (uz_chan_sum_partials); CONV_BWD_DATA p[7] = a (folded ReLU backward), p[8] = partials, p[9] = dx bound; i[9] = CtotA */
   UZ_OP__COUNT
 };

@@ -55,7 +55,9 @@ def test_unet_full_b32_vs_reference_digest():
     conf = np.unpackbits(arrays["argmax_conf_bits"]).astype(bool)
     got = np.argmax(p, axis=1).astype(np.uint8).reshape(-1)
     ref = np.unpackbits(arrays["argmax_bits"])
-    assert conf.sum() >= conf.size - 200
+    # the pixels the fixture leaves out of the bit-exact comparison are exactly the ones it recorded as near ties (reference margin
+    # below 2e-4) - a count the generator stored, not an allowance
+    assert int(conf.size - conf.sum()) == meta["n_near_ties"]
     assert np.array_equal(got[conf], ref[conf])                   # bit-exact label map wherever the margin decides it
     print(f"unet b32: loss rel {abs(float(loss) - st['loss']) / st['loss']:.1e}, worst grad-norm dev {worst:.1e}, "
           f"{int((got != ref).sum())} of {meta['n_near_ties']} near-tie pixels differ")

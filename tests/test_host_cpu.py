@@ -206,3 +206,102 @@ def test_unet_plan_folds_the_relu_backward_into_the_last_writer_of_dA(monkeypatc
     monkeypatch.setenv("UZ_FOLD_RELU_BWD", "0")
     plain = Unet(1, 2, [32, 64, 128, 192], device="cpu")._build(32, 128, 128)
     assert count(plain, "UZ_OP_RELU_BWD") == 21 and count(plain, "UZ_OP_CHAN_SUM_TABLE") == 0
+
+
+def test_phiseg_plan_round4_passes(monkeypatch):
+    """Plan-level view of split storage at the BASELINE size (Plan._round4_passes): every buffer kept as operand
+    pieces is written only by launches that know their bound beforehand (BatchNorm apply with the convolution's statistics, pooling,
+    interpolation) and read only by split-path convolutions; a concat buffer's two producers own one bound slot each and the
+    forward consumer switches scales on a 16-channel boundary; dy is packed exactly where the unit's backward is not the
+    one-launch kernel; the deferred conv-bias sums are one table-driven launch; the switches restore the plain tape."""
+    from unet_zoo_amd import _ffi
+    from unet_zoo_amd._plan import View
+    from unet_zoo_amd.models.phiseg import PHISeg
+    L = _ffi.lib()
+    if L.uz_get_conv_math() in (0, 3):
+        pytest.skip("two-piece operands only exist in the default / split math modes")
+    net = PHISeg(1, 2, [32, 64, 128, 192, 192, 192, 192], device="cpu")
+    net.train()
+    plan = net._build(32, 128, 128, True, True)
+    info = plan.round4
+    assert info["act_packed"] >= 30 and info["folded"] == 0
+    packed = [b for b in plan.bufs if b.packed]
+    assert len(packed) == info["act_packed"]
+    named = {id(v.buf) for k, v in plan.io.items() if isinstance(v, View)}
+    all_ops = plan.fwd_ops + plan.loss_ops + plan.bwd_ops
+    for b in packed:
+        assert id(b) not in named
+        slots = set()
+        for o in all_ops:
+            for j, r in enumerate(o["p"]):
+                if not (isinstance(r, View) and r.buf is b):
+                    continue
+                c, i = o["code"], o["i"]
+                if c == "UZ_OP_BN_RELU_FWD":
+                    assert j == 6 and i[10] == 1 and i[8] > 0 and o["p"][8] is not None
+                    slots.add(o["p"][8])
+                elif c in ("UZ_OP_BILINEAR_FWD", "UZ_OP_AVGPOOL_FWD"):
+                    assert j == 1 and i[7 if c == "UZ_OP_BILINEAR_FWD" else 6] == 1 and o["p"][2] is not None
+                    slots.add(o["p"][3])
+                elif c == "UZ_OP_CONV_FWD":
+                    assert j == 0 and i[10] == 1 and L.uz_conv_route(0, i[0], i[2], i[4], i[5], i[6], 3) == 1
+                    assert i[11] % 16 == 0 and (i[11] == 0) == (o["p"][10] is None)
+                    assert o["p"][5] in slots and (o["p"][10] is None or o["p"][10] in slots)
+                elif c == "UZ_OP_CONV_BWD_WEIGHT":
+                    assert j == 0 and i[8] == 1 and L.uz_conv_route(2, i[0], i[2], i[4], i[5], i[6], 3) == 1
+                else:
+                    raise AssertionError(f"{c} touches the packed buffer {b.name}")
+    # the heaviest layer (3 x 3, 224 -> 128 @ 128 x 128) reads its concat input as two segments: 32 channels from the BatchNorm apply, 192 from the interpolation
+    big = [o for o in plan.fwd_ops if o["code"] == "UZ_OP_CONV_FWD" and o["i"][:3] == [224, 224, 128]]
+    assert len(big) == 1 and big[0]["i"][10:12] == [1, 32]
+    # dy: packed where the backward is the three-launch large-plane path, fp32 where it is one launch with the channel's batch on chip
+    for o in plan.bwd_ops:
+        if o["code"] == "UZ_OP_BN_RELU_BWD":
+            i = o["i"]
+            npx, fused = i[4] * i[5] * i[6], L.uz_bn_bwd_fused_limit(i[5], i[6])
+            assert not (i[9] and npx <= fused)                        # dy is packed only on the three-launch path (bound known before the apply pass)
+            assert (i[10] == 1) == (npx > fused)                      # conv-bias partial rows only on the three-launch path
+    n3 = sum(o["code"] == "UZ_OP_BN_RELU_BWD" and o["i"][10] == 1 for o in plan.bwd_ops)
+    assert 10 <= info["dy_packed"] <= n3
+    assert sum(o["code"] == "UZ_OP_CHAN_SUM_TABLE" for o in plan.bwd_ops) == (1 if n3 else 0)
+    # weight-gradient slab reductions: one table-driven launch for all 3 x 3 layers, none inside the layers' own ops
+    tab = [o for o in plan.bwd_ops if o["code"] == "UZ_OP_WGRAD_REDUCE_TABLE"]
+    wg = [o for o in plan.bwd_ops if o["code"] == "UZ_OP_CONV_BWD_WEIGHT" and o["i"][7] == 3]
+    assert len(tab) == 1 and tab[0]["i"][0] == len(wg) == 106 and all(o["i"][11] == 1 and o["p"][8] is not None for o in wg)
+    monkeypatch.setenv("UZ_LANES", "2")
+    plan2 = PHISeg(1, 2, [32, 64, 128, 192, 192, 192, 192], device="cpu")
+    plan2.train()
+    plan2 = plan2._build(32, 128, 128, True, True)
+    _check_lane_schedule(plan2, "bwd", plan2.bwd_ops)
+    _check_lane_schedule(plan2, "fwd", plan2.fwd_ops)
+    for k in ("UZ_PACK_ACT", "UZ_PACK_DY", "UZ_DBIAS_TABLE", "UZ_WGRAD_TABLE"):
+        monkeypatch.setenv(k, "0")
+    net3 = PHISeg(1, 2, [32, 64, 128, 192, 192, 192, 192], device="cpu")
+    net3.train()
+    plain = net3._build(32, 128, 128, True, True)
+    assert plain.round4 == dict(folded=0, dy_packed=0, act_packed=0, act_views=0) and not any(b.packed for b in plain.bufs)
+    assert sum(o["code"] in ("UZ_OP_CHAN_SUM_TABLE", "UZ_OP_WGRAD_REDUCE_TABLE") for o in plain.bwd_ops) == 0
+
+
+def test_default_routing_keeps_small_planes_off_the_split_path():
+    """The split path's error is bounded relative to the TENSOR's maximum (2^-22 |a|max |b|), not per element: on tiny planes
+    whose gradients mix channels of very different magnitude that is coarser than fp32's per-element rounding (the one gradient
+    gate that fails with UZ_CONV_MATH=split forced everywhere sits on the 8 x 8 ... 2 x 2 levels of a batch-2 fixture - VERDICT r3
+    item 6c).  The DEFAULT policy therefore never routes a plane below 16 x 16 to it, whatever the channel counts or the batch:
+    uz_conv_route is the single place that decides, and this pins it."""
+    L = _ffi.lib()
+    mode = L.uz_get_conv_math()
+    try:
+        assert L.uz_set_conv_math(1) == 0
+        for kind in (0, 1, 2):
+            for h, w in ((2, 2), (4, 4), (8, 8), (8, 16), (16, 8), (12, 12), (15, 64)):
+                for cin, cout in ((32, 32), (64, 64), (192, 192), (256, 256), (768, 256), (2, 192), (192, 2)):
+                    for n in (1, 2, 32, 256, 4096):
+                        assert L.uz_conv_route(kind, cin, cout, n, h, w, 3) != 1, (kind, cin, cout, n, h, w)
+        # ... and 1 x 1 kernels never take it
+        assert all(L.uz_conv_route(k, 192, 192, 32, 64, 64, 1) != 1 for k in (0, 1, 2))
+        # the large planes of the BASELINE configs do
+        assert all(L.uz_conv_route(k, 224, 128, 32, 128, 128, 3) == 1 for k in (0, 1, 2))
+        assert L.uz_set_conv_math(0) == 0 and all(L.uz_conv_route(k, 224, 128, 32, 128, 128, 3) == 0 for k in (0, 1, 2))
+    finally:
+        L.uz_set_conv_math(-1 if os.environ.get("UZ_CONV_MATH") is None else mode)

@@ -361,8 +361,8 @@ def test_native_five_level_volume_trains():
 @pytest.mark.gpu
 def test_baseline_config5_architecture_at_full_volume_size():
     """BASELINE.json configs[4] at its real size: PHISeg3D 5 resolution / 5 latent levels, filters 32-64-128-192-192, 4 input
-    channels, 3 labels, one 128 x 128 x 64 volume per GPU (fp32 storage - the bf16 variant the config names is not built, see
-    DESIGN.md section 8).  (a) The same network and weights on a 64 x 64 x 32 sub-volume against the CPU oracle (the full
+    channels, 3 labels, one 128 x 128 x 64 volume per GPU, default math (the bf16 arithmetic the config names: next-but-one test;
+    storage is fp32 in both).  (a) The same network and weights on a 64 x 64 x 32 sub-volume against the CPU oracle (the full
     volume costs the oracle minutes): loss within 1e-4 relative, level logits within 1e-4 of their range.  (b) At full size:
     three hipGraph-replayed training steps, loss finite and decreasing, no violated magnitude bound."""
     from unet_zoo_amd.models.phiseg3D import PHISeg3D, phiseg3d_spec
@@ -468,6 +468,62 @@ def test_bf16_arithmetic_mode_against_the_operand_rounding_oracle():
         assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     finally:
         L.uz_set_conv_math(-1)
+
+
+@pytest.mark.gpu
+def test_baseline_config5_full_volume_in_bf16_mode():
+    """BASELINE.json configs[4] as it is quoted - bf16 - AT ITS REAL SIZE (the bf16 mode was only run at 64 x 64 x 32):
+    PHISeg3D 5 / 5 levels, filters 32-64-128-192-192, 4 x 128 x 128 x 64, uz_set_conv_math(3) (one bf16 piece per operand, one MFMA
+    product, fp32 accumulation; storage stays fp32 - DESIGN.md section 8).  The CPU oracle needs minutes for this volume, so the
+    reference point is the SAME network through the fp32-accurate split mode on the device (that path is pinned against the oracle
+    on the 64 x 64 x 32 sub-volume above): first-step loss within 2 % (the price of bf16 arithmetic, measured at 64 x 64 x 32
+    against the oracle: < 2 %), level logits within 5 % of their range, and three replayed training steps finite and decreasing."""
+    from unet_zoo_amd import _ffi
+    from unet_zoo_amd.models.phiseg3D import PHISeg3D, phiseg3d_spec
+    from unet_zoo_amd.optim import FusedAdam
+    L = _ffi.lib()
+    if L.uz_get_conv_math() == 0:
+        pytest.skip("fp32-only run")
+    dev = torch.device("cuda", 0)
+    filters, K, Cin, dhw = [32, 64, 128, 192, 192], 3, 4, (128, 128, 64)
+    sd0 = oracle.deterministic_state_dict(phiseg3d_spec(Cin, K, filters, 5), seed=11)
+    shapes = R3.phiseg3d_eps_shapes(*dhw, 5, 5)
+    x, onehot, lab, eps = R3.synthetic_volume(Cin, K, dhw, 9, shapes + shapes)
+    xd, od, ld = (torch.from_numpy(a).to(dev) for a in (x, onehot, lab))
+    epsd = [torch.from_numpy(e).to(dev) for e in eps]
+    res = {}
+    try:
+        for mode in (1, 3):
+            L.uz_set_conv_math(mode)
+            net = PHISeg3D(Cin, K, filters, latent_levels=5, image_size=(Cin, *dhw))
+            net.load_state_dict(sd0)
+            net.train()
+            s = net.forward(xd, od, training=True, eps=epsd)
+            res[mode] = (float(net.loss(ld)), [t.clone() for t in s])
+            if mode == 3:
+                n_bf16 = sum(1 for o in net._cur.fwd_ops if o["code"] == "UZ_OP_CONV_FWD" and o["i"][7] == 3 and
+                             L.uz_conv_route(0, o["i"][0], o["i"][2], o["i"][4], o["i"][5], o["i"][6], 3) == 1)
+                assert n_bf16 >= 20                                   # the volume's 3 x 3 x 3 convolutions really run on the one-piece kernels
+                net.enable_graphs(True)
+                opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
+                losses = []
+                for _ in range(4):
+                    net.forward(xd, od, training=True, eps=epsd)
+                    l = net.loss(ld)
+                    opt.zero_grad(); l.backward(); opt.step()
+                    losses.append(float(l))
+                assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+            del net
+            torch.cuda.empty_cache()
+    finally:
+        L.uz_set_conv_math(-1)
+    (l_ref, s_ref), (l_bf, s_bf) = res[1], res[3]
+    rel = abs(l_bf - l_ref) / abs(l_ref)
+    print(f"config 5 at full size: loss fp32-accurate split {l_ref:.6g}, bf16 arithmetic {l_bf:.6g} (rel {rel:.2e})")
+    assert 1e-8 < rel < 2e-2, (l_ref, l_bf)
+    for a, b in zip(s_ref, s_bf):
+        rng = float(a.max() - a.min())
+        assert float((a - b).abs().max()) <= 5e-2 * max(rng, 1e-3)
 
 
 @pytest.mark.gpu

@@ -100,7 +100,7 @@ def test_two_units_forward_and_weight_gradient_with_split_storage(N, C1, C2, H, 
         y2 = torch.empty(N, C2, H, W, device=d)
         g.call("uz_conv_fwd_ex", a1, C1, C1, w2d, b2d, y2, C2, C2, N, H, W, 3, 0, slot, None, None, ws, wsb, None, None, packed, None, 0)
         dw2 = torch.empty(C2, C1, 3, 3, device=d)
-        g.call("uz_conv_bwd_weight_ex", a1, C1, C1, dy2d, C2, C2, dw2, None, N, H, W, 3, slot, None, ws, wsb, packed, None, 0, 0)
+        g.call("uz_conv_bwd_weight_ex", a1, C1, C1, dy2d, C2, C2, dw2, None, N, H, W, 3, slot, None, ws, wsb, packed, None, 0, 0, None)
         res[packed] = (a1, y2, dw2, slot, save)
     a_f32, y2_f32, dw_f32, slot0, save0 = res[0]
     a_pk, y2_pk, dw_pk, slot1, save1 = res[1]
@@ -164,7 +164,7 @@ def test_concat_buffer_with_two_scale_segments():
     y2 = torch.empty(N, C2, H, W, device=d)
     g.call("uz_conv_fwd_ex", cat, C, C, w2.to(d), None, y2, C2, C2, N, H, W, 3, 0, sA, None, None, ws, wsb, None, None, 1, sB, CA)
     dw2 = torch.empty(C2, C, 3, 3, device=d)
-    g.call("uz_conv_bwd_weight_ex", cat, C, C, dy2.to(d), C2, C2, dw2, None, N, H, W, 3, sA, None, ws, wsb, 1, sB, CA, 0)
+    g.call("uz_conv_bwd_weight_ex", cat, C, C, dy2.to(d), C2, C2, dw2, None, N, H, W, 3, sA, None, ws, wsb, 1, sB, CA, 0, None)
     assert g.relerr(y2, y2r) <= 3e-5
     # per input-channel block: the small-magnitude segment keeps its own precision
     for lo, hi in ((0, CA), (CA, C)):
@@ -236,9 +236,9 @@ def test_unit_backward_with_folded_reduction_and_split_storage(N, C1, C2, H, W):
         dy1 = torch.full((N, C1, H, W), float("nan"), device=d)
         dgm, dbt, dbias = (torch.empty(C1, device=d) for _ in range(3))
         sdy1 = _slot()
-        g.call("uz_bn_relu_bwd_ex", dA, C1, y1, C1, C1, gd, bd, save, dy1, C1, dgm, dbt, dbias, N, H, W, 1, sdy1, bws, bpart if fused else None, rows if fused else 0, fused)
+        g.call("uz_bn_relu_bwd_ex", dA, C1, y1, C1, C1, gd, bd, save, dy1, C1, dgm, dbt, dbias, N, H, W, 1, sdy1, bws, bpart if fused else None, rows if fused else 0, fused, None)
         dw1 = torch.empty(C1, C0, 3, 3, device=d)
-        g.call("uz_conv_bwd_weight_ex", xd, C0, C0, dy1, C1, C1, dw1, None, N, H, W, 3, None, sdy1, ws, wsb, 0, None, 0, fused)
+        g.call("uz_conv_bwd_weight_ex", xd, C0, C0, dy1, C1, C1, dw1, None, N, H, W, 3, None, sdy1, ws, wsb, 0, None, 0, fused, None)
         dx = torch.empty(N, C0, H, W, device=d)
         g.call("uz_conv_bwd_data_ex", dy1, C1, C1, w1d, dx, C0, C0, N, H, W, 3, 0, sdy1, None, ws, wsb, None, fused, None, 0, None, 0, None)
         out[fused] = (dA, dy1, dgm, dbt, dw1, dx, sdy1)
@@ -254,3 +254,58 @@ def test_unit_backward_with_folded_reduction_and_split_storage(N, C1, C2, H, W):
     # ... and all of it against autograd
     assert g.relerr(dw1_, w1r.grad) <= 5e-5 and g.relerr(dx1, xr.grad) <= 5e-5
     assert g.relerr(dg1, gr.grad) <= 1e-4 and g.relerr(db1, br.grad) <= 1e-4
+
+
+def test_deferred_conv_bias_sums():
+    """uz_bn_relu_bwd_ex(dbias_partials) + uz_chan_sum_table == the conv-bias gradient uz_bn_relu_bwd sums in a launch of its own
+    (the plans add all units' rows in ONE launch at the end of the backward tape)."""
+    g, L = _g(), _lib()
+    N, C, H, W = 3, 5, 128, 128
+    assert N * H * W > L.uz_bn_bwd_fused_limit(H, W)
+    d = g.dev()
+    y, da = (g.rnd(N, C, H, W, seed=41) * 2 + 0.3).to(d), g.rnd(N, C, H, W, seed=42).to(d)
+    gamma, beta = (g.rnd(C, seed=43).abs() + 0.5).to(d), (g.rnd(C, seed=44) * 0.3).to(d)
+    ws = torch.empty(L.uz_bn_workspace(C, N, H, W) // 4 + 16, device=d)
+    save = torch.empty(2 * C, device=d)
+    a = torch.empty(N, C, H, W, device=d)
+    g.call("uz_bn_relu_fwd", y, C, C, gamma, beta, None, None, save, a, C, N, H, W, 1e-3, 0.01, 1, 1, None, ws)
+    dy0, dy1 = torch.empty_like(y), torch.empty_like(y)
+    dg0, db0, dbias0, dg1, db1, dbias1 = (torch.empty(C, device=d) for _ in range(6))
+    g.call("uz_bn_relu_bwd", da, C, y, C, C, gamma, beta, save, dy0, C, dg0, db0, dbias0, N, H, W, 1, None, ws)
+    rows = L.uz_bn_bwd_dbias_rows(N, H, W)
+    assert rows > 0
+    part = torch.full((rows * C,), float("nan"), dtype=torch.float64, device=d)
+    g.call("uz_bn_relu_bwd_ex", da, C, y, C, C, gamma, beta, save, dy1, C, dg1, db1, None, N, H, W, 1, None, ws, None, 0, 0, part)
+    table = torch.tensor([part.data_ptr(), dbias1.data_ptr(), rows, C, 1], dtype=torch.int64, device=d)
+    g.call("uz_chan_sum_table", table, 1, C)
+    assert torch.equal(dy0, dy1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert torch.equal(dbias0, dbias1)
+
+
+def test_weight_gradient_slabs_reduced_by_the_table_launch():
+    """uz_conv_bwd_weight_ex(slabs_out) + uz_wgrad_reduce_table == uz_conv_bwd_weight BIT FOR BIT (same order of additions), for
+    two layers of different kernel families sharing one table launch: a split-path layer (S > 64: two-stage order) and an
+    fp32 small-plane layer."""
+    g, L = _g(), _lib()
+    d = g.dev()
+    cases = [(8, 64, 64, 64, 64), (32, 48, 40, 8, 8)]
+    rows, blk, keep = [], 0, []
+    for k, (N, Cin, Cout, H, W) in enumerate(cases):
+        x, dy = g.rnd(N, Cin, H, W, seed=60 + k).to(d), g.rnd(N, Cout, H, W, seed=70 + k).to(d)
+        wsb = L.uz_conv_bwd_weight_workspace(Cin, Cout, N, H, W, 3)
+        ws = torch.empty(wsb // 4 + 64, device=d)
+        dw0 = torch.empty(Cout, Cin, 3, 3, device=d)
+        g.call("uz_conv_bwd_weight", x, Cin, Cin, dy, Cout, Cout, dw0, None, N, H, W, 3, None, None, ws, wsb)
+        S = L.uz_conv_bwd_weight_slabs(Cin, Cout, N, H, W, 3)
+        assert S > 0
+        slabs = torch.full((S * 9 * Cout * Cin,), float("nan"), device=d)
+        dw1 = torch.full_like(dw0, float("nan"))
+        g.call("uz_conv_bwd_weight_ex", x, Cin, Cin, dy, Cout, Cout, dw1, None, N, H, W, 3, None, None, ws, wsb, 0, None, 0, 0, slabs)
+        assert torch.isnan(dw1).all()                      # the call stopped behind its main kernel
+        rows += [slabs.data_ptr(), dw1.data_ptr(), S, Cout, Cin, 9, blk, 0]
+        blk += L.uz_wgrad_reduce_blocks(Cin, Cout, 3)
+        keep.append((dw0, dw1, slabs, S))
+    table = torch.tensor(rows, dtype=torch.int64, device=d)
+    g.call("uz_wgrad_reduce_table", table, len(cases), blk)
+    for dw0, dw1, _, S in keep:
+        assert torch.equal(dw0, dw1), S

@@ -36,5 +36,5 @@ for pk in (0, 1):
     X, DY = (xp, dyp) if pk else (x, dy)
     f = t(lambda: _ffi.check(L.uz_conv_fwd_ex(P(X), Cin, Cin, P(w), None, P(y), Cout, Cout, N, H, W, 3, 0, P(xa), P(wa), None, P(ws), wsb, None, None, pk, None, 0, st), "fwd"))
     d = t(lambda: _ffi.check(L.uz_conv_bwd_data_ex(P(DY), Cout, Cout, P(w), P(dx), Cin, Cin, N, H, W, 3, 0, P(dya), P(wa), P(ws), wsb, None, pk, None, 0, None, 0, None, st), "dgrad"))
-    g = t(lambda: _ffi.check(L.uz_conv_bwd_weight_ex(P(x if not pk else xp), Cin, Cin, P(DY), Cout, Cout, P(dw), None, N, H, W, 3, P(xa), P(dya), P(ws), wsb, pk, None, 0, pk, st), "wgrad"))
+    g = t(lambda: _ffi.check(L.uz_conv_bwd_weight_ex(P(x if not pk else xp), Cin, Cin, P(DY), Cout, Cout, P(dw), None, N, H, W, 3, P(xa), P(dya), P(ws), wsb, pk, None, 0, pk, None, st), "wgrad"))
     print(f"{'packed' if pk else 'fp32  '}  fwd {f*1e3:8.1f} us {fl/f/1e9:6.1f} TF/s | dgrad {d*1e3:8.1f} us {fl/d/1e9:6.1f} | wgrad {g*1e3:8.1f} us {fl/g/1e9:6.1f}")

@@ -217,6 +217,50 @@ def phiseg_case(name, filters, hw, batch, n_steps, store_full, seed, store_input
     save(name, arrays, meta)
 
 
+def phiseg_traj_case(name, filters, hw, batch, n_steps, seed, n_samp=8):
+    """Train-step contract AT THE HEADLINE SIZE: n_steps x [forward, loss, zero_grad, backward,
+    Adam(lr 1e-3, wd 1e-5)] of the real reference from the deterministic state_dict; per step the loss terms and - behind the
+    optimiser step - digests of every parameter and BatchNorm buffer (L2 norm + n_samp sampled entries).  Inputs and noise are
+    regenerated from the seeds (synthetic_batch(seed = 20201004 + step))."""
+    net = PHISeg(input_channels=1, num_classes=2, num_filters=filters, latent_levels=5, image_size=(1, hw, hw))
+    spec = kinds_for(net.state_dict())
+    sd0 = deterministic_state_dict(spec, seed=seed)
+    net.load_state_dict(sd0)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)   # train_model.py:49
+    shapes = phiseg_eps_shapes(batch, hw, hw)
+    rs = np.random.Generator(np.random.PCG64(11))
+    picks = {k: rs.integers(0, int(np.prod(sh)) if len(sh) else 1, size=min(n_samp, max(1, int(np.prod(sh))))) for k, sh, kd in spec if kd != "bn_nbt"}
+    arrays = {"pick:" + k: v for k, v in picks.items()}
+    meta = dict(model="PHISeg", filters=filters, hw=hw, batch=batch, weight_seed=seed, lr=1e-3, weight_decay=1e-5,
+                spec=[[k, list(sh), kd] for k, sh, kd in spec], steps=[])
+    for step in range(n_steps):
+        x, mask, eps = synthetic_batch(batch, hw, hw, seed=20201004 + step, eps_shapes=shapes + shapes)
+        xt, mt = torch.from_numpy(x), torch.from_numpy(mask)
+        with NoiseFeeder(eps) as nf:
+            net.forward(xt, mt, training=True)
+            assert nf.used == 10
+        loss = net.loss(mt)
+        opt.zero_grad()
+        loss.backward()
+        st = dict(loss=float(loss), loss_dict={k: float(v) for k, v in net.loss_dict.items()},
+                  none_grads=[k for k, p in net.named_parameters() if p.grad is None])
+        opt.step()
+        sd = net.state_dict()
+        norms = {}
+        for k, sh, kd in spec:
+            if kd == "bn_nbt":
+                continue
+            v = npf(sd[k]).reshape(-1)
+            norms[k] = float(np.sqrt((v.astype(np.float64) ** 2).sum()))
+            arrays[f"step{step}:" + k] = v[picks[k]]
+        st["norms"] = norms
+        st["nbt"] = int(sd[[k for k, _, kd in spec if kd == "bn_nbt"][0]])
+        meta["steps"].append(st)
+        print(f"step {step}: loss {float(loss):.6f}", flush=True)
+    save(name, arrays, meta)
+
+
 def unet_case(name, filters, batch, n_steps, seed):
     hw = 128                                                           # Unet.loss hard-codes 128 (unet.py:163)
     net = Unet(1, 2, filters)
@@ -674,6 +718,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "b32":
         # BASELINE config 4 exactly (batch 32): digests only, inputs are regenerated from the seed
         phiseg_case("phiseg_full_b32_digest", [32, 64, 128, 192, 192, 192, 192], 128, 32, 1, False, 1238, store_inputs=False)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "b32traj":
+        # BASELINE config 4, three training steps: losses, post-step parameter / buffer digests
+        phiseg_traj_case("phiseg_full_b32_traj", [32, 64, 128, 192, 192, 192, 192], 128, 32, 3, 1238)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "3d":
         phiseg3d_case("phiseg3d_small", 2, 3, [4, 8, 8], 2, (16, 16, 8), 1242)       # lvl_diff 1

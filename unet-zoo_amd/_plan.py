@@ -373,10 +373,20 @@ class Plan:
         self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
 
         def emit_wgrad():
+            # Slab reductions: outside data-parallel runs (where a bucket's gradients must be final when its all-reduce starts) a
+            # 3 x 3 layer leaves its partial-sum slabs in a buffer of its own and ONE table-driven launch at the end of the tape adds
+            # the slabs of every layer (UZ_OP_WGRAD_REDUCE_TABLE) - PHiSeg: 106 + 27 small reduction launches less per step
+            nslab = 0
+            if ks == 3 and db_key is None and wrow0 == 0 and not self.grad_buckets and os.environ.get("UZ_WGRAD_TABLE", "1") == "1" \
+                    and not self.__dict__.get("_in_rev", False) and self.__dict__.get("_rev_ctx") is None:
+                nslab = self.L.uz_conv_bwd_weight_slabs(cin, cout, x.N, x.H, x.W, ks)
+            slabbuf = self.vec(wkey + ":wslabs", nslab * ks * ks * cout * cin) if nslab else None
             rec["wgrad"] = self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
                                       p=[x, gy, self.G(wkey, wextra), self.G(db_key, wrow0) if db_key else None, ("scratch", "wgrad"),
-                                         self.amax_in(x), self.amax_in(gy)],
-                                      i=[cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, ks], n=ws)
+                                         self.amax_in(x), self.amax_in(gy), None, slabbuf],
+                                      i=[cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, ks, 0, 0, 0, 1 if nslab else 0], n=ws)
+            if nslab:
+                self.__dict__.setdefault("_wgrad_jobs", []).append((slabbuf, wkey, nslab, cout, cin, ks * ks))
         # dy in a buffer of its own (small planes): the data gradient - the only thing the next layer's backward waits for -
         # goes first and the weight gradient becomes a scheduling group of its own, so that the latency-bound chains of the deep
         # levels (BatchNorm backward -> data gradient -> next BatchNorm backward) no longer carry the weight gradients and their
@@ -534,10 +544,17 @@ class Plan:
                 self._gyz[gyv.zkey] = (y.N + 2) * sl
                 gy, gyv.off = ("gyvol", gyv.zkey), sl
             ga = a_grad if a_grad is not None else self.gview(a)
+            # conv-bias gradient (the sum of dy: analytically zero behind a training-mode BatchNorm, the reference returns its
+            # rounding noise and so do we): outside data-parallel runs the large-plane units leave their per-workgroup sums in rows of
+            # their own and ONE table-driven launch at the end of the tape adds them - a summation launch less in every unit's chain
+            dbrows = self.L.uz_bn_bwd_dbias_rows(x.N, x.H, x.W) if (plain and not self.grad_buckets and os.environ.get("UZ_DBIAS_TABLE", "1") == "1") else 0
+            dbpart = self.vec(name + ":dbrows", 2 * dbrows * cout) if dbrows else None
             op_bwd = self._emit(self.bwd_ops, "UZ_OP_BN_RELU_BWD",
-                                p=[ga, y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), self.G(bkey), ("scratch", "bn"),
+                                p=[ga, y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), dbpart if dbrows else self.G(bkey), ("scratch", "bn"),
                                    ("amax", gyv.amax)],
-                                i=[ga.Ctot, cout, y.Ctot, cout, x.N, x.H, x.W, int(relu)])
+                                i=[ga.Ctot, cout, y.Ctot, cout, x.N, x.H, x.W, int(relu), 0, 0, 1 if dbrows else 0])
+            if dbrows:
+                self._dbias_jobs.append((dbpart, bkey, dbrows, cout, 1))
             rec = {}
             self._conv_bwd(x, wkey, gyv, ks, rec=rec)
             if unit is not None:
@@ -990,7 +1007,10 @@ class Plan:
             return False
         tabbed = {id(q.buf) for t in self.ptr_tables for q in t if isinstance(q, View)}
         # ---- 1. folded backward reduction
-        if env("UZ_FOLD_BN_BWD") and self.bwd_ops:
+        # (off by default: measured on MI355X the epilogue's extra read of y is exposed - the 64-channel-tile kernel keeps ONE
+        #  workgroup per CU, so its memory phase overlaps nothing: data gradient of 128 -> 128 @ 128 x 128 451 -> 573 us against
+        #  269 -> 170 us for the unit's BatchNorm backward; step +-0)
+        if os.environ.get("UZ_FOLD_BN_BWD", "0") == "1" and self.bwd_ops:
             for u in units:
                 B = u.get("bn_bwd")
                 if B is None or not large(u) or u["npart"] <= 0:
@@ -1019,7 +1039,7 @@ class Plan:
                 W["p"] = W["p"][:7] + [y, part, None, u["save"]]
                 W["i"] = W["i"][:9] + [y.Ctot, 2, 0, u["relu"]]
                 B["p"] = B["p"][:11] + [part]
-                B["i"] = B["i"][:8] + [rows, 0]
+                B["i"][8] = rows
                 info["folded"] += 1
         # ---- 2. dY in split storage
         if env("UZ_PACK_DY") and self.bwd_ops:
@@ -1027,16 +1047,15 @@ class Plan:
                 B, wg, dg = u.get("bn_bwd"), u.get("wgrad"), u.get("dgrad")
                 if B is None or wg is None or not large(u) or u["ks"] != 3 or u["W"] % 4:
                     continue
+                if u["N"] * u["H"] * u["W"] <= self.L.uz_bn_bwd_fused_limit(u["H"], u["W"]):
+                    continue                         # one-launch backward (channel's batch on chip): no tensor-wide bound before the first write
                 if self.L.uz_conv_route(2, u["cin"], u["C"], u["N"], u["H"], u["W"], 3) != 1:
                     continue
                 if dg is not None and (self.L.uz_conv_route(1, u["cin"], u["C"], u["N"], u["H"], u["W"], 3) != 1 or dg["i"][10:11] == [1]):
                     continue
-                B["i"] = (B["i"] + [0, 0])[:10]
                 B["i"][9] = 1
                 B["p"] = (B["p"] + [None])[:12]
-                wg["i"] = (wg["i"] + [0, 0, 0])[:11]
                 wg["i"][10] = 1
-                wg["p"] = (wg["p"] + [None])[:8]
                 if dg is not None:
                     dg["i"] = (dg["i"] + [0, 0, 0, 0])[:13]
                     dg["i"][11] = 1
@@ -1111,9 +1130,7 @@ class Plan:
                         o["i"] = (o["i"] + [0, 0])[:12]
                         o["i"][10], o["i"][11] = 1, seg
                     else:
-                        o["p"] = (o["p"] + [None])[:8]
                         o["p"][5], o["p"][7] = s1, s2
-                        o["i"] = (o["i"] + [0, 0, 0])[:11]
                         o["i"][8], o["i"][9] = 1, seg
                 b.packed = True
                 info["act_packed"] += 1
@@ -1142,6 +1159,16 @@ class Plan:
                            p=[self.ptr_table(refs), ("gflat_keys", tuple(j[1] for j in self._dbias_jobs))],
                            i=[len(self._dbias_jobs), max(j[3] for j in self._dbias_jobs)])
                 self._dbias_jobs = []
+            jobs = self.__dict__.get("_wgrad_jobs", [])
+            if jobs:
+                refs, blk = [], 0
+                for slabbuf, wkey, nslab, co, ci, kk in jobs:
+                    refs += [slabbuf, self.G(wkey), ("raw", nslab), ("raw", co), ("raw", ci), ("raw", kk), ("raw", blk), ("raw", 0)]
+                    blk += self.L.uz_wgrad_reduce_blocks(ci, co, 3 if kk == 9 else 1)
+                self._newgroup()
+                self._emit(self.bwd_ops, "UZ_OP_WGRAD_REDUCE_TABLE",
+                           p=[self.ptr_table(refs), ("gflat_keys", tuple(j[1] for j in jobs))], i=[len(jobs), blk])
+                self._wgrad_jobs = []
             # data parallel: one event per gradient bucket, recorded as soon as every writer of that slice of the flat
             # gradient buffer is done (the scheduler hoists the marker to that point of the DAG); the communication
             # stream waits for it and all-reduces the bucket beside the rest of the backward tape
@@ -1320,7 +1347,7 @@ class Plan:
     # Which p[] slots an op writes (every other slot is read).  Scratch slots are private to a
     # group and parameters are read-only inside a tape, so neither creates a dependency.
     _WRITES = {
-        "UZ_OP_CONV_FWD": (3, 9), "UZ_OP_CONV_BWD_DATA": (2, 8, 9), "UZ_OP_CONV_BWD_WEIGHT": (2, 3),
+        "UZ_OP_CONV_FWD": (3, 9), "UZ_OP_CONV_BWD_DATA": (2, 8, 9), "UZ_OP_CONV_BWD_WEIGHT": (2, 3, 8),
         "UZ_OP_BN_RELU_FWD": (3, 4, 5, 6), "UZ_OP_BN_RELU_BWD": (5, 6, 7, 8), "UZ_OP_RELU_BWD": (2, 3),
         "UZ_OP_AVGPOOL_FWD": (1,), "UZ_OP_AVGPOOL_BWD": (1, 3, 4), "UZ_OP_BILINEAR_FWD": (1,), "UZ_OP_BILINEAR_BWD": (1, 3, 4),
         "UZ_OP_NEAREST_FWD": (1,), "UZ_OP_NEAREST_BWD": (1,), "UZ_OP_SPATIAL_MEAN_FWD": (1,), "UZ_OP_SPATIAL_MEAN_BWD": (1,),
@@ -1331,7 +1358,7 @@ class Plan:
         "UZ_OP_BCAST_CHANNELS": (1,), "UZ_OP_BCAST_CHANNELS_BWD": (1,), "UZ_OP_EVENT_RECORD": (0,), "UZ_OP_ABSMAX": (1,),
         "UZ_OP_ADD_VIEWS": (2,), "UZ_OP_W3D_PERMUTE": (1,), "UZ_OP_AVGPOOL3D_FWD": (1,), "UZ_OP_AVGPOOL3D_BWD": (1,),
         "UZ_OP_DEPTH_LERP_FWD": (1,), "UZ_OP_DEPTH_LERP_BWD": (1,), "UZ_OP_NEAREST3D_FWD": (1,), "UZ_OP_NEAREST3D_BWD": (1,),
-        "UZ_OP_ABSMAX_COPY": (), "UZ_OP_PACK_WEIGHTS": (2,), "UZ_OP_CHAN_SUM_PARTIALS": (1,), "UZ_OP_CHAN_SUM_TABLE": (1,),
+        "UZ_OP_ABSMAX_COPY": (), "UZ_OP_PACK_WEIGHTS": (2,), "UZ_OP_CHAN_SUM_PARTIALS": (1,), "UZ_OP_CHAN_SUM_TABLE": (1,), "UZ_OP_WGRAD_REDUCE_TABLE": (1,),
     }
 
     def _resources(self, r):

@@ -10,6 +10,7 @@
 //    second read of the <= 32 KB channel comes from L1/L2).
 // Statistics are accumulated in fp64 so that E[y^2]-E[y]^2 carries no cancellation error into the
 // 30+ stacked normalisations of PHiSeg.
+#include <stdlib.h>
 #include <type_traits>
 #include "uz_common.h"
 #include "split_f16.h"
@@ -591,6 +592,92 @@ __global__ __launch_bounds__(256) void bn_fused_small_bwd(const BnP p) {
     }
 }
 
+// ------------------------------------------------------------------ backward, mid path (round 4)
+// 4096 < N*H*W <= MID_LIMIT (the 16 x 16 and 32 x 32 levels at batch 32: 40 of PHiSeg's 106 units): ONE 1024-thread workgroup per
+// channel keeps the channel's y and dA in registers (<= 32 + 32 values per thread) - both are read once, the sums, the gradient and
+// the conv-bias sum come from the registers.  One launch and three passes over memory instead of three launches and five passes
+// (reduce: dA, y; apply: dA, y, dy; bias-gradient summation): 192 ch @ 32 x 32: 32 -> 13 us.  The price: the tensor-wide bound of dy
+// is only known when every workgroup is done, so dy cannot be written as split storage here - its bound is atomic-max accumulated
+// like the small path's (the plans pack dy on the larger planes only).
+constexpr int MID_LIMIT = 32768, MID_NT = 1024, MID_EPT4 = MID_LIMIT / MID_NT / 4;      // float4 per thread: 8
+__global__ __launch_bounds__(MID_NT) void bn_fused_mid_bwd(const BnP p) {
+    __shared__ double smd[16 * 2];
+    __shared__ float bc[2];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hw4 = p.HW / 4, total4 = p.N * hw4;
+    float alpha, beta_, mean, rstd;
+    alpha_beta(p, c, alpha, beta_, mean, rstd);
+    float4 yv[MID_EPT4], dv[MID_EPT4];
+#pragma unroll
+    for (int j = 0; j < MID_EPT4; ++j) {
+        const int e = tid + j * MID_NT;
+        const int b = e / hw4, q = e - b * hw4;
+        const bool ok = e < total4;
+        yv[j] = ok ? *reinterpret_cast<const float4*>(p.y + ((size_t)b * p.CtotY + c) * p.HW + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dv[j] = ok ? *reinterpret_cast<const float4*>(p.da + ((size_t)b * p.CtotDa + c) * p.HW + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // dz (ReLU mask) in place of dA, x_hat in place of y
+    float s1 = 0.f, s2 = 0.f;
+    auto prep = [&](float& yy, float& dd) {
+        dd = (!p.relu || fmaf(yy, alpha, beta_) > 0.f) ? dd : 0.f;
+        yy = (yy - mean) * rstd;
+        s1 += dd; s2 += dd * yy;
+    };
+    double v2[2] = {0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < MID_EPT4; ++j) {
+        s1 = 0.f; s2 = 0.f;
+        prep(yv[j].x, dv[j].x); prep(yv[j].y, dv[j].y); prep(yv[j].z, dv[j].z); prep(yv[j].w, dv[j].w);
+        v2[0] += (double)s1; v2[1] += (double)s2;     // (padding elements are zeros: they add nothing)
+    }
+    v2[0] = uz::wave_sum_d(v2[0]); v2[1] = uz::wave_sum_d(v2[1]);
+    if (lane == 0) { smd[wave * 2] = v2[0]; smd[wave * 2 + 1] = v2[1]; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < MID_NT / 64; ++w) { a += smd[w * 2]; b += smd[w * 2 + 1]; }      // fixed order
+        if (p.dbeta) p.dbeta[c] = (float)a;
+        if (p.dgamma) p.dgamma[c] = (float)b;
+        const double n = (double)p.N * p.HW;
+        bc[0] = (float)(a / n); bc[1] = (float)(b / n);
+    }
+    __syncthreads();
+    const float m1 = bc[0], m2 = bc[1];
+    float sd = 0.f, vmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < MID_EPT4; ++j) {
+        const int e = tid + j * MID_NT;
+        if (e < total4) {
+            float4 r;
+            r.x = alpha * (dv[j].x - m1 - yv[j].x * m2); r.y = alpha * (dv[j].y - m1 - yv[j].y * m2);
+            r.z = alpha * (dv[j].z - m1 - yv[j].z * m2); r.w = alpha * (dv[j].w - m1 - yv[j].w * m2);
+            const int b = e / hw4, q = e - b * hw4;
+            *reinterpret_cast<float4*>(p.out + ((size_t)b * p.CtotOut + c) * p.HW + 4 * q) = r;
+            sd += (r.x + r.y) + (r.z + r.w);
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+        }
+    }
+    if (p.amax) uz::amax_publish(vmax, p.amax);
+    if (p.dbias) {
+        double t = uz::wave_sum_d((double)sd);
+        __syncthreads();
+        if (lane == 0) smd[wave] = t;
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0;
+            for (int w = 0; w < MID_NT / 64; ++w) a += smd[w];
+            p.dbias[c] = (float)a;
+        }
+    }
+}
+
+// (round 4, measured and dropped: a "cluster" variant for the 64 x 64 / 128 x 128 levels - G = N*H*W / 32768 workgroups per channel,
+//  each keeping its slice of y and dA in registers, meeting on a device-scope counter, adding the G partials in a fixed order - i.e.
+//  one launch and three passes instead of three launches and five.  128 ch @ 128 x 128 ran 697 us against 266 us: the agent-scope
+//  fences around the counter write back / invalidate the XCD's whole L2 while the other workgroups' dy stores are in flight; and
+//  two such launches on the two dependency lanes starve each other's workgroups until the queue scheduler time-slices them
+//  (3.7 images/s).  Cross-workgroup hand-offs inside a streaming kernel are not worth a kernel boundary on this chip.)
+
 // ------------------------------------------------------------------ ReLU-only backward (vanilla U-Net units)
 template <bool VEC>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ da, int CtotDa, const float* __restrict__ a, int CtotA,
@@ -758,18 +845,21 @@ extern "C" int uz_bn_relu_bwd(const float* da, int CtotDa, const float* y, int C
                               float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
                               int N, int H, int W, int relu, float* dy_amax, void* workspace, void* stream) {
     return uz_bn_relu_bwd_ex(da, CtotDa, y, C, CtotY, gamma, beta, save_mean_rstd, dy, CtotDy, dgamma, dbeta, dbias, N, H, W, relu, dy_amax, workspace,
-                             nullptr, 0, 0, stream);
+                             nullptr, 0, 0, nullptr, stream);
 }
 // uz_bn_relu_bwd with (a) conv_partials: n_partials rows [C][4] of {sum dz, sum dz x_hat, max |dz|, max |x_hat|} left by the data
 // gradient that wrote dA last (uz_conv_bwd_data_bn; dA then already carries the ReLU mask) - the reduction pass over dA and y is
 // replaced by a one-workgroup-per-channel finalise - and (b) out_packed: dy is written as split storage (needs dy_amax; the
-// finalise launch publishes the bound before the apply pass starts).  Large planes only (N*H*W > 4096).
+// finalise launch publishes the bound before the apply pass starts), (c) dbias_partials: uz_bn_bwd_dbias_rows() x C doubles that
+// receive the per-workgroup sums of dy instead of a summation launch per unit (uz_chan_sum_table adds all units' rows in ONE launch
+// at the end of a tape; dbias must then be NULL).  Large planes only (N*H*W > 4096).
 extern "C" int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, int C, int CtotY,
                                  const float* gamma, const float* beta, const float* save_mean_rstd,
                                  float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
                                  int N, int H, int W, int relu, float* dy_amax, void* workspace,
-                                 const float* conv_partials, int n_partials, int out_packed, void* stream) {
+                                 const float* conv_partials, int n_partials, int out_packed, double* dbias_partials, void* stream) {
     UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_bwd: empty tensor");
+    UZ_REQUIRE(!dbias_partials || (!dbias && (size_t)N * H * W > SMALL_LIMIT), "bn_relu_bwd_ex: dbias_partials replaces dbias on the large-plane path");
     UZ_REQUIRE(!(conv_partials || out_packed) || (size_t)N * H * W > SMALL_LIMIT, "bn_relu_bwd_ex: folded statistics / split storage only serve the large-plane path");
     UZ_REQUIRE(!conv_partials || n_partials > 0, "bn_relu_bwd_ex: conv_partials without rows");
     UZ_REQUIRE(!out_packed || dy_amax, "bn_relu_bwd_ex: split storage needs the bound slot");
@@ -786,8 +876,17 @@ extern "C" int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, in
         hipLaunchKernelGGL(bn_fused_small_bwd, dim3(C), dim3(256), 0, st, p);
         return uz::check_launch("bn_fused_small_bwd");
     }
+    static const bool mid_on = !(getenv("UZ_BN_MID") && atoi(getenv("UZ_BN_MID")) == 0);
+    if (mid_on && !conv_partials && !out_packed && !dbias_partials && (size_t)N * p.HW <= MID_LIMIT && vec_ok(p.HW, y, da, dy)) {
+        hipLaunchKernelGGL(bn_fused_mid_bwd, dim3(C), dim3(MID_NT), 0, st, p);
+        return uz::check_launch("bn_fused_mid_bwd");
+    }
     UZ_REQUIRE(workspace, "bn_relu_bwd: workspace required");
     carve(p, workspace);
+    if (dbias_partials) {      // the conv-bias gradient's per-workgroup sums go to the caller's rows; one table-driven launch adds them later (uz_chan_sum_table)
+        p.part2 = dbias_partials;
+        p.dbias = reinterpret_cast<float*>(dbias_partials);      // (non-null: "write the partials")
+    }
     const bool vec = vec_ok(p.HW, y, da, dy);
     const dim3 grid(p.parts, C, N);
     reduction_groups(p);
@@ -811,11 +910,19 @@ extern "C" int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, in
     } else if (vec) hipLaunchKernelGGL(bn_bwd_apply<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(bn_bwd_apply<false>, grid, dim3(256), 0, st, p);
     if (int rc = uz::check_launch("bn_bwd_apply")) return rc;
-    if (dbias) {
+    if (dbias && !dbias_partials) {
         hipLaunchKernelGGL(chan_partial_sum, dim3(uz::ceil_div(C, 4)), dim3(256), 0, st, p.part2, N * p.parts, C, dbias);
         if (int rc = uz::check_launch("chan_partial_sum")) return rc;
     }
     return 0;
+}
+// rows of dbias_partials a large-plane uz_bn_relu_bwd_ex call writes ([rows][C] doubles)
+extern "C" int uz_bn_bwd_dbias_rows(int N, int H, int W) { return (size_t)N * H * W > (size_t)uz_bn_bwd_fused_limit(H, W) ? N * uz::ceil_div(H * W, CHUNK) : 0; }
+// largest N*H*W whose backward runs as ONE launch with the channel's batch held on chip (no tensor-wide bound before the first
+// write: dy of such a unit is fp32, never split storage): the small path's limit, or the mid path's where H*W allows float4 rows
+extern "C" int uz_bn_bwd_fused_limit(int H, int W) {
+    static const bool mid_on = !(getenv("UZ_BN_MID") && atoi(getenv("UZ_BN_MID")) == 0);
+    return (mid_on && (H * W) % 4 == 0) ? MID_LIMIT : SMALL_LIMIT;
 }
 
 extern "C" int uz_relu_bwd(const float* da, int CtotDa, const float* a, int C, int CtotA,

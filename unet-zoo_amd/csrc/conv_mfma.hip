@@ -43,6 +43,9 @@ struct ConvP {
 template <int KS, int MSUB, int JMAX, bool DGRAD>
 __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const ConvP p) {
     constexpr int KK = KS * KS, HALO = KS / 2;
+    // (round 4, measured and dropped: LDS images as [k half][row][4 k] so that one ds_read_b128 per operand feeds four MFMA steps -
+    //  a quarter of the LDS instructions - ran 224 -> 128 @ 128 x 128 at 2.42 ms against 2.16 ms and the step at 879 against 893
+    //  images/s in fp32 mode: this kernel is not bound by its LDS reads)
     constexpr int COT = 32 * MSUB, COTP = COT + 1;
     constexpr int WSZ = KK * CK * COTP;
     constexpr int WELEMS = COT * CK * KK;

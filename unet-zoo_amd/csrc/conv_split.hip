@@ -558,13 +558,13 @@ UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_1_256_16, 1, 256, 16, 1, 1, false, 3)
 // round 4: input in split storage (conv_splitp_*), BatchNorm-backward reduction in the data gradient's epilogue (*_bn_*)
 UZ_SPLIT_KERNEL(conv_splitp_kernel_2_512_32, 2, 512, 32, 2, 0, true, 1)
 UZ_SPLIT_KERNEL(conv_splitp_kernel_1_512_32, 1, 512, 32, 2, 0, true, 4)
-UZ_SPLIT_KERNEL(conv_splitp_kernel_1_256_16, 1, 256, 16, 2, 0, true, 2)
+UZ_SPLIT_KERNEL(conv_splitp_kernel_1_256_16, 1, 256, 16, 2, 0, true, 3)
 UZ_SPLIT_KERNEL(conv_split_bn_kernel_2_512_32, 2, 512, 32, 2, 2, false, 1)
 UZ_SPLIT_KERNEL(conv_split_bn_kernel_1_512_32, 1, 512, 32, 2, 2, false, 4)
 UZ_SPLIT_KERNEL(conv_split_bn_kernel_1_256_16, 1, 256, 16, 2, 2, false, 2)
 UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_2_512_32, 2, 512, 32, 2, 2, true, 1)
 UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_512_32, 1, 512, 32, 2, 2, true, 4)
-UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_256_16, 1, 256, 16, 2, 2, true, 2)
+UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_256_16, 1, 256, 16, 2, 2, true, 3)
 #undef UZ_SPLIT_KERNEL
 
 template <int MSUB, int NTv, int TWv, int NP, int MK, bool XPK>

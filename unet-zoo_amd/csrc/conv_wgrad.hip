@@ -540,6 +540,8 @@ WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
     g.T = g.tilesX * g.tilesY * g.tilesB;
     g.WM = Cout > 32 ? 2 : 1;
     g.WN = Cin > 32 ? 2 : 1;
+    // (round 4, measured and dropped: 32 x 32 channel tiles on the 4 x 4 / 2 x 2 levels, where 64 x 64 tiles leave 18 ... 72 workgroups:
+    //  192 -> 192 @ 2 x 2 28 -> 26 us, @ 4 x 4 31 -> 37 us - these launches are bound by their fixed phases, not by workgroup count)
     g.WK = 8 / (g.WM * g.WN * (halo ? 2 : 1));
     g.nCoT = uz::ceil_div(Cout, 32 * g.WM);
     g.nCiT = uz::ceil_div(Cin, 32 * g.WN);
@@ -605,19 +607,92 @@ extern "C" int uz_conv_route(int kind, int Cin, int Cout, int N, int H, int W, i
     return uz::wgrad_split_ok(Cin, Cout, N, H, W, ks) ? 1 : 0;
 }
 
+// Number of partial-sum slabs [ks*ks][Cout][Cin] a weight-gradient call of this shape writes before its reduction (0: the call does
+// not go through slabs - the streaming 1x1 heads).  Mirrors the dispatch of uz_conv_bwd_weight_ex below.
+extern "C" int uz_conv_bwd_weight_slabs(int Cin, int Cout, int N, int H, int W, int ks) {
+    if ((ks != 1 && ks != 3) || Cin <= 0 || Cout <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
+    if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) return 0;
+    if (wgrad_thin_ok(Cin, Cout, N, H, W, ks)) {
+        const int total = N * (H / THIN_ROWS);
+        const int per_wg = uz::ceil_div(total, wgrad_thin_slabs(N, H));
+        return uz::ceil_div(total, per_wg);
+    }
+    const bool huge = (size_t)N * Cin * H * W >= (1ull << 30) || (size_t)N * Cout * H * W >= (1ull << 30);
+    if (!huge && uz::wgrad_split_ok(Cin, Cout, N, H, W, ks)) return uz::wgrad_split_splits(Cin, Cout, N, H, W);
+    const WGeom g = pick_wgeom(Cin, Cout, N, H, W, ks / 2);
+    return g.S * g.SW;
+}
+namespace {
+// All slab reductions of a tape in ONE launch.  table: n_layers rows of 8 int64 {slabs (address), dw (address), S, Cout, Cin, ks*ks,
+// first block, -}; a workgroup finds its layer by bisection over the first-block column; 256 (co, ci) pairs of one tap per
+// workgroup.  Same order of additions as the per-layer launches: groups of 32 slabs first when S > 64, then the group sums.
+__global__ __launch_bounds__(256) void wgrad_reduce_table_k(const long long* __restrict__ table, int n_layers) {
+    int lo = 0, hi = n_layers - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)table[8 * mid + 6] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const long long* t = table + 8 * lo;
+    const float* slab = reinterpret_cast<const float*>(t[0]);
+    float* dw = reinterpret_cast<float*>(t[1]);
+    const int S = (int)t[2], Cout = (int)t[3], Cin = (int)t[4], KK = (int)t[5], blk = (int)blockIdx.x - (int)t[6];
+    const int m = Cout * Cin, n = KK * m, per_tap = (m + 255) / 256;
+    const int tap = blk / per_tap, j = (blk - tap * per_tap) * 256 + threadIdx.x;
+    if (j >= m) return;
+    const float* src = slab + (size_t)tap * m + j;
+    const int RG = S > 64 ? 32 : 1;
+    float s = 0.f;
+    if (RG == 1) {
+        int k = 0;
+        for (; k + 8 <= S; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < S; ++k) s += src[(size_t)k * n];
+    } else {
+        for (int g0 = 0; g0 < S; g0 += RG) {
+            const int ge = min(S, g0 + RG);
+            float sg = 0.f;
+            int k = g0;
+            for (; k + 8 <= ge; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * n];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sg += v[u];
+            }
+            for (; k < ge; ++k) sg += src[(size_t)k * n];
+            s += sg;
+        }
+    }
+    dw[(size_t)j * KK + tap] = s;
+}
+}  // namespace
+extern "C" int uz_wgrad_reduce_blocks(int Cin, int Cout, int ks) { return ks * ks * uz::ceil_div(Cout * Cin, 256); }
+extern "C" int uz_wgrad_reduce_table(const int64_t* table, int n_layers, int total_blocks, void* stream) {
+    UZ_REQUIRE(table && n_layers > 0 && total_blocks > 0, "wgrad_reduce_table: bad arguments");
+    hipLaunchKernelGGL(wgrad_reduce_table_k, dim3(total_blocks), dim3(256), 0, uz::S(stream), reinterpret_cast<const long long*>(table), n_layers);
+    return uz::check_launch("wgrad_reduce_table_k");
+}
+
 extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
                                   float* dw, float* db, int N, int H, int W, int ks,
                                   const float* x_amax, const float* dy_amax,
                                   void* workspace, size_t workspace_bytes, void* stream) {
-    return uz_conv_bwd_weight_ex(x, Cin, CinTot, dy, Cout, CoutTot, dw, db, N, H, W, ks, x_amax, dy_amax, workspace, workspace_bytes, 0, nullptr, 0, 0, stream);
+    return uz_conv_bwd_weight_ex(x, Cin, CinTot, dy, Cout, CoutTot, dw, db, N, H, W, ks, x_amax, dy_amax, workspace, workspace_bytes, 0, nullptr, 0, 0, nullptr, stream);
 }
 // ... with either operand in split storage (include/uz_api.h, round 4): only on the split-fp16 path, bias gradient not available
 // (db reads dy as fp32).
 extern "C" int uz_conv_bwd_weight_ex(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
                                      float* dw, float* db, int N, int H, int W, int ks,
                                      const float* x_amax, const float* dy_amax, void* workspace, size_t workspace_bytes,
-                                     int x_packed, const float* x_amax2, int seg_channels, int dy_packed, void* stream) {
+                                     int x_packed, const float* x_amax2, int seg_channels, int dy_packed, float* slabs_out, void* stream) {
     UZ_REQUIRE(ks == 1 || ks == 3, "conv_bwd_weight: kernel size %d unsupported", ks);
+    // slabs_out: the call stops behind its main kernel and leaves its uz_conv_bwd_weight_slabs() partial-sum slabs [S][ks*ks][Cout][Cin]
+    // there; uz_wgrad_reduce_table adds the slabs of MANY layers in one launch (the plans: one at the end of the backward tape
+    // instead of one or two reduction launches behind every weight gradient).  dw is not written, db must be NULL.
+    UZ_REQUIRE(!slabs_out || (!db && uz_conv_bwd_weight_slabs(Cin, Cout, N, H, W, ks) > 0 && !(ks == 3 && Cin == 3 * CinTot)),
+               "conv_bwd_weight_ex: slabs_out on a call that writes no slabs (uz_conv_bwd_weight_slabs() == 0), asks for a bias gradient or is a depth window");
     const bool any_packed = x_packed || dy_packed;
     UZ_REQUIRE(!any_packed || (uz_conv_route(2, Cin, Cout, N, H, W, ks) == 1 && uz::conv_np() == 2 && !(dy_packed && db)),
                "conv_bwd_weight_ex: an operand in split storage, but this shape / math mode does not take the split-fp16 path (or a bias gradient was requested)");
@@ -634,7 +709,7 @@ extern "C" int uz_conv_bwd_weight_ex(const float* x, int Cin, int CinTot, const 
     UZ_REQUIRE(workspace && workspace_bytes >= need, "conv_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = uz::S(stream);
     WgP p;
-    p.x = x; p.dy = dy; p.slab = static_cast<float*>(workspace);
+    p.x = x; p.dy = dy; p.slab = slabs_out ? slabs_out : static_cast<float*>(workspace);
     p.N = N; p.H = H; p.W = W; p.HW = H * W;
     p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot;
     p.TW = g.TW; p.TH = g.TH; p.TB = g.TB; p.lgTW = uz::ilog2(g.TW); p.lgTH = uz::ilog2(g.TH);
@@ -727,6 +802,7 @@ extern "C" int uz_conv_bwd_weight_ex(const float* x, int Cin, int CinTot, const 
         else UZ_WG_FAST_T(8, 8);
     } else if (ks == 3) UZ_WG_TILE(3); else UZ_WG_TILE(1);
     if (int rc = uz::check_launch("wgrad_kernel")) return rc;
+    if (slabs_out) return 0;
     const int n = ks * ks * Cout * Cin;
     int rgrid = uz::ceil_div(n, 256);
     if (rgrid > 4096) rgrid = 4096;

@@ -351,6 +351,7 @@ bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks) {
     const int mode = conv_math_mode();
     if (!mode || ks != 3 || (W % 32 != 0 && W != 16)) return false;
     if (mode == 2) return true;
+    if (H < 16 || W < 16) return false;          // the default policy keeps planes below 16 x 16 on the fp32 MFMA (tensor-max-relative error, see tests/test_host_cpu.py)
     const long long px = (long long)N * H * W;
     const int lo = Cin < Cout ? Cin : Cout;
     // 64-channel tiles when both sides have them; 32-channel tiles when one side is narrow (32 -> 32, and the decoder's
@@ -372,7 +373,8 @@ int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
     const int nt = ceil_div(Cout, ct) * ceil_div(Cin, ct);
     const int tw = tile_w(W);
     const int T = N * ceil_div(H, PT / tw) * (W / tw);
-    int s = 256 / nt;                                  // one workgroup per CU either way (the 32-channel kernel's 166 VGPRs allow no second one: 512 splits measured 6 % slower)
+    static const int target = getenv("UZ_WGS_TARGET") ? atoi(getenv("UZ_WGS_TARGET")) : 256;
+    int s = target / nt;                               // one workgroup per CU either way (the 32-channel kernel's 166 VGPRs allow no second one: 512 splits measured 6 % slower)
     if (s < 1) s = 1;
     if (s > T) s = T;
     return s;

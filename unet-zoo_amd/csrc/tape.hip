@@ -63,7 +63,41 @@ extern "C" int uz_device_info(int* n_cu, char* name, int name_cap) {
     return 0;
 }
 
+// Diagnostics only (tools/what_if.sh): UZ_DIAG_SKIP="conv:8,bn:8,resample:4,convmin:64" drops every convolution / BatchNorm / resampling
+// op on planes up to (convmin: from) that height from a tape - the results are garbage, the step time shows what those ops cost
+// on the critical path (an upper bound for any optimisation of them).  Unset in every product run.
+static bool diag_skip(const uz_op& o) {
+    static const char* env = getenv("UZ_DIAG_SKIP");
+    if (!env) return false;
+    static int conv = -1, bn = -1, rs = -1, convmin = 1 << 30, init = 0, fwd = -1, dgrad = -1, wgrad = -1, bnf = -1, bnb = -1, only = 0;
+    if (!init) {
+        init = 1;
+        const char* q;
+        if ((q = strstr(env, "conv:"))) conv = atoi(q + 5);
+        if ((q = strstr(env, "bn:"))) bn = atoi(q + 3);
+        if ((q = strstr(env, "resample:"))) rs = atoi(q + 9);
+        if ((q = strstr(env, "convmin:"))) convmin = atoi(q + 8);
+        if ((q = strstr(env, "fwd:"))) fwd = atoi(q + 4);            // per direction: fwd:8 = forward convolutions on planes up to 8 rows
+        if ((q = strstr(env, "dgrad:"))) dgrad = atoi(q + 6);
+        if ((q = strstr(env, "wgrad:"))) wgrad = atoi(q + 6);
+        if ((q = strstr(env, "bnf:"))) bnf = atoi(q + 4);
+        if ((q = strstr(env, "bnb:"))) bnb = atoi(q + 4);
+        if ((q = strstr(env, "only:"))) only = atoi(q + 5);          // only:16 = the limits above select planes of EXACTLY that height
+    }
+    auto hit = [&](int h, int lim) { return only ? (h == only && lim >= only) : h <= lim; };
+    switch (o.code) {
+        case UZ_OP_CONV_FWD: return hit(o.i[5], conv) || hit(o.i[5], fwd) || o.i[5] >= convmin;
+        case UZ_OP_CONV_BWD_DATA: return hit(o.i[5], conv) || hit(o.i[5], dgrad) || o.i[5] >= convmin;
+        case UZ_OP_CONV_BWD_WEIGHT: return hit(o.i[5], conv) || hit(o.i[5], wgrad) || o.i[5] >= convmin;
+        case UZ_OP_BN_RELU_FWD: return hit(o.i[4], bn) || hit(o.i[4], bnf);
+        case UZ_OP_BN_RELU_BWD: return hit(o.i[5], bn) || hit(o.i[5], bnb);
+        case UZ_OP_AVGPOOL_FWD: case UZ_OP_AVGPOOL_BWD: case UZ_OP_BILINEAR_FWD: case UZ_OP_BILINEAR_BWD: return hit(o.i[4], rs);
+        default: return false;
+    }
+}
+
 static int run_one(const uz_op& o, void* st) {
+    if (diag_skip(o)) return 0;
     const int32_t* i = o.i;
     const float* f = o.f;
     void* const* p = o.p;
@@ -83,16 +117,18 @@ static int run_one(const uz_op& o, void* st) {
                                        i[10] == 2 ? CFP(7) : nullptr, i[9], CFP(10), i[12], FP(8), st);
         case UZ_OP_CONV_BWD_WEIGHT:
             // i[8] = x in split storage, p[7] / i[9] = second scale segment of x, i[10] = dy in split storage
+            // i[11]: slabs only, into p[8] (added by UZ_OP_WGRAD_REDUCE_TABLE at the end of the tape)
             return uz_conv_bwd_weight_ex(CFP(0), i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], i[7], CFP(5), CFP(6), p[4], (size_t)o.n,
-                                         i[8], CFP(7), i[9], i[10], st);
+                                         i[8], CFP(7), i[9], i[10], i[11] ? FP(8) : nullptr, st);
         case UZ_OP_BN_RELU_FWD:
             if (i[9] > 1) return uz_bn_relu_fwd_slabs(CFP(10), i[9], CFP(11), FP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], FP(8), st);
             // (save holds 4 C floats in plans; i[10] = write the activation as split storage)
             return uz_bn_relu_fwd_ex(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], FP(8), p[7], CFP(9), i[8], i[10], st);
         case UZ_OP_BN_RELU_BWD:
             // p[11] / i[8] = reduction partials left by the data gradient that wrote dA last, i[9] = write dy as split storage
-            return uz_bn_relu_bwd_ex(CFP(0), i[0], CFP(1), i[1], i[2], CFP(2), CFP(3), CFP(4), FP(5), i[3], FP(6), FP(7), FP(8), i[4], i[5], i[6], i[7], FP(10), p[9],
-                                     CFP(11), i[8], i[9], st);
+            // i[10]: p[8] holds the rows for the conv-bias gradient's partial sums instead of the gradient itself (added by UZ_OP_CHAN_SUM_TABLE)
+            return uz_bn_relu_bwd_ex(CFP(0), i[0], CFP(1), i[1], i[2], CFP(2), CFP(3), CFP(4), FP(5), i[3], FP(6), FP(7), i[10] ? nullptr : FP(8), i[4], i[5], i[6], i[7], FP(10), p[9],
+                                     CFP(11), i[8], i[9], i[10] ? static_cast<double*>(p[8]) : nullptr, st);
         case UZ_OP_RELU_BWD:
             return uz_relu_bwd(CFP(0), i[0], CFP(1), i[1], i[2], FP(2), i[3], FP(3), i[4], i[5], i[6], FP(5), p[4], st);
         case UZ_OP_AVGPOOL_FWD:
@@ -143,6 +179,8 @@ static int run_one(const uz_op& o, void* st) {
             return uz_l2_norms_bwd(CFP(0), static_cast<const int64_t*>(p[1]), i[0], CFP(2), CFP(3), FP(4), st);
         case UZ_OP_CHAN_SUM_TABLE:
             return uz_chan_sum_table(static_cast<const int64_t*>(p[0]), i[0], i[1], st);
+        case UZ_OP_WGRAD_REDUCE_TABLE:
+            return uz_wgrad_reduce_table(static_cast<const int64_t*>(p[0]), i[0], i[1], st);
         case UZ_OP_CHAN_SUM_PARTIALS:
             return i[2] ? uz_chan_sum_partials_d(static_cast<const double*>(p[0]), i[0], i[1], FP(1), st) : uz_chan_sum_partials(CFP(0), i[0], i[1], FP(1), st);
         case UZ_OP_PACK_WEIGHTS:

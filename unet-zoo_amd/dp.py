@@ -164,11 +164,13 @@ class GradSync:
         check(L.uz_stream_create(C.byref(s), int(os.environ.get("UZ_DP_STREAM_PRIORITY", "1"))), "stream_create")
         self.stream = s.value
         ev = []
-        for timing in (0, 1, 1):
+        for timing in (0, 1, 1) + (1,) * len(self.buckets):
             e = C.c_void_p()
             check(L.uz_event_create(C.byref(e), timing), "event_create")
             ev.append(e.value)
-        self.done, self.t0, self.t1 = ev
+        self.done, self.t0, self.t1 = ev[:3]
+        self.tb = ev[3:]                 # one timing event per bucket: recorded on the communication stream behind that bucket's all-reduce
+        self._tb_order = []
 
     def nranks(self):
         """Ranks of the data-parallel group as the communication library itself reports them (ncclCommCount behind
@@ -225,11 +227,14 @@ class GradSync:
                 self._warned_null = True
             serial = True
         check(L.uz_event_record(self.t0, cs), "event_record")              # compute stream: backward tape done
+        self._tb_order = []
         if self.overlap and plan.events and not serial:
             for b in self.order(plan):
                 lo, hi = self.buckets[b]
                 check(L.uz_stream_wait_event(self.stream, plan.events[b]), "stream_wait_event")
                 check(L.uz_allreduce_mean_f32(self.comm, base + 4 * lo, hi - lo, self.stream), "allreduce")
+                check(L.uz_event_record(self.tb[b], self.stream), "event_record")
+                self._tb_order.append(b)
         else:                                                                # one blocking-order all-reduce behind the whole tape
             check(L.uz_stream_wait_event(self.stream, self.t0), "stream_wait_event")
             check(L.uz_allreduce_mean_f32(self.comm, base, gflat.numel(), self.stream), "allreduce")
@@ -245,6 +250,22 @@ class GradSync:
         ms = self.C.c_float()
         self._ffi.check(self.L.uz_event_elapsed_ms(self.t0, self.t1, self.C.byref(ms)), "event_elapsed")
         return float(ms.value)
+
+    def exposed_ms_per_bucket(self):
+        """For every bucket of the most recent overlapped step, in exchange order: (first float, floats, milliseconds between the end
+        of the backward tape and the end of that bucket's all-reduce) - negative = the exchange finished that long BEFORE the tape
+        did (fully hidden); the last bucket's positive value is what the collective adds to the step.  Synchronises."""
+        if self.backend != "rccl" or not self._tb_order:
+            return None
+        torch.cuda.synchronize()
+        out = []
+        for b in self._tb_order:
+            ms = self.C.c_float()
+            # hipEventElapsedTime(t0, tb) is negative when tb was recorded first
+            self._ffi.check(self.L.uz_event_elapsed_ms(self.t0, self.tb[b], self.C.byref(ms)), "event_elapsed")
+            lo, hi = self.buckets[b]
+            out.append(dict(first_float=int(lo), floats=int(hi - lo), ms_after_backward=round(float(ms.value), 4)))
+        return out
 
     def close(self):
         if self.comm:
