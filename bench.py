@@ -110,17 +110,25 @@ def conv_roof(op, L):
     return {0: PEAK_F32_MFMA_TFLOPS, 1: split_roof, 2: None}[r]
 
 
+def _bn_limit(which, H, W):
+    from unet_zoo_amd import _ffi
+    L = _ffi.lib()
+    return (L.uz_bn_fwd_fused_limit if which == "fwd" else L.uz_bn_bwd_fused_limit)(H, W)
+
+
 def op_bytes(op):
     """Algorithmic HBM bytes of a streaming (non-conv) op: every tensor argument read or written once."""
     c, i = op["code"], op["i"]
     f4 = 4.0
     if c == "UZ_OP_BN_RELU_FWD":
         C, N, H, W, training = i[0], i[3], i[4], i[5], i[6]
-        big = N * H * W > 8192 and not (len(i) > 8 and i[8])        # i[8] > 0: statistics come from the convolution's epilogue partials
+        # three passes (statistics: y; apply: y, a) only on the streaming path without the convolution's partials (i[8] > 0); the
+        # one-launch paths (channel's batch in registers, up to uz_bn_fwd_fused_limit) read y once
+        big = N * H * W > _bn_limit("fwd", H, W) and not (len(i) > 8 and i[8])
         return f4 * C * N * H * W * ((3 if big else 2) if training else 2)
     if c in ("UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
         C, N, H, W = i[1], i[4], i[5], i[6]
-        big = N * H * W > 8192
+        big = N * H * W > _bn_limit("bwd", H, W)                    # reduce (dA, y) + apply (dA, y, dy); one-launch paths: dA, y, dy
         return f4 * C * N * H * W * ((5 if big else 3) if c == "UZ_OP_BN_RELU_BWD" else 3)
     if c in ("UZ_OP_AVGPOOL_FWD", "UZ_OP_AVGPOOL_BWD"):
         C, N, H, W = i[0], i[3], i[4], i[5]

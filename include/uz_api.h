@@ -229,6 +229,7 @@ int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, int C, int Ct
                       float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
                       int N, int H, int W, int relu, float* dy_amax, void* workspace,
                       const float* conv_partials, int n_partials, int out_packed, double* dbias_partials, void* stream);
+int uz_bn_fwd_fused_limit(int H, int W);         /* N*H*W up to which the training-mode uz_bn_relu_fwd(_ex) WITHOUT conv_partials is one launch (statistics + apply from registers) */
 int uz_bn_bwd_fused_limit(int H, int W);         /* N*H*W up to which uz_bn_relu_bwd(_ex) is one launch with the channel's batch on chip: no out_packed / dbias_partials there */
 int uz_bn_bwd_dbias_rows(int N, int H, int W);   /* rows of dbias_partials ([rows][C] doubles, summed by uz_chan_sum_table); 0: small-plane path */
 int uz_avgpool2_fwd_ex(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W,

@@ -1,6 +1,8 @@
 """End-to-end parity of the native PHISeg against (a) golden vectors generated from the real
 reference and (b) the CPU oracle run live on the same seeded inputs.  Gates follow BASELINE.json:
 segmentation logits within 1e-4 (fp32), bit-exact argmax label maps."""
+import os
+
 import numpy as np
 import pytest
 import torch

@@ -81,7 +81,10 @@ class NativeModel(nn.Module):
     def check_bounds(self, clear=True):
         """Device flag word of the split-fp16 convolution path (uz_device_flags): 0 when every tensor stayed within the
         magnitude bound its consumer was given; bit 1 / 2 / 4 = an activation / weight / gradient exceeded its bound by more
-        than 4x and was clamped (results wrong but finite).  Synchronises the stream - call it per epoch, not per step."""
+        than 4x and was clamped (results wrong but finite).  The check is SAMPLED - every workgroup of a split kernel tests the first
+        chunk / pixel tile it stages (a stale or wrong bound is a property of the whole tensor and shows there; the clamp itself
+        covers every element), operands that arrive as split storage are not checked at all (their producer derived the scale from
+        the bound it wrote them with).  Synchronises the stream - call it per epoch, not per step."""
         self._require_gpu()
         out = C.c_int(0)
         _ffi.check(_ffi.lib().uz_device_flags(C.byref(out), 1 if clear else 0, C.c_void_p(self._stream())), "device_flags")
@@ -302,12 +305,25 @@ class NativeModel(nn.Module):
 
     def _rng_state(self):
         """{seed, offset} of the device-side latent-noise stream (uz_randn_fill): seeded from torch's default generator when
-        first used, so torch.manual_seed(...) before the first draw makes runs repeatable."""
+        first used, so torch.manual_seed(...) before the first draw makes runs repeatable.  Under data parallelism the rank is
+        mixed into the Philox key: ranks that share a torch seed still draw different noise for their different shards."""
         st = self.__dict__.get("_rng_state_t")
         if st is None:
-            st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=self.device)
+            rank = int(os.environ.get("RANK", "0")) if getattr(self, "_dp", None) is not None or int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0
+            seed = (torch.initial_seed() ^ (rank << 32) ^ (rank * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF
+            st = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
             object.__setattr__(self, "_rng_state_t", st)
         return st
+
+    def rng_state(self):
+        """(seed, offset) of the latent-noise stream as host integers - what a resumed run hands to set_rng_state() to continue the
+        sequence instead of replaying it from offset 0 (the reference's checkpoints hold the state_dict only, train_model.py:558-564;
+        state_dict keys are part of the drop-in surface, so the stream is not stored there)."""
+        s = self._rng_state().cpu()
+        return int(s[0]), int(s[1])
+
+    def set_rng_state(self, seed, offset=0):
+        self._rng_state().copy_(torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, int(offset)], dtype=torch.int64))
 
     def _fill_normal(self, t):
         """t.normal_() without ATen: Philox / Box-Muller on the device, the stream offset advanced behind the fill."""

@@ -494,7 +494,9 @@ class Plan:
         # where the forward kernel supports it, it leaves per-tile {sum, sum of squares, max, max(-y)} partials and the
         # BatchNorm finalises them instead of streaming y a second time
         npart = 0
-        if self.bn_training and os.environ.get("UZ_BN_FUSE_STATS", "1") == "1" and x.N * x.H * x.W > 4096 and \
+        # (not where the BatchNorm forward is ONE launch that forms the statistics from the channel's batch in registers anyway:
+        #  the small path, and the mid path up to uz_bn_fwd_fused_limit)
+        if self.bn_training and os.environ.get("UZ_BN_FUSE_STATS", "1") == "1" and x.N * x.H * x.W > self.L.uz_bn_fwd_fused_limit(x.H, x.W) and \
                 (x.nb is None or (ks == 3 and os.environ.get("UZ_BN_FUSE_STATS_VOL", "1") == "1")):
             # (a volume's Conv3d is the 2-D kernel over its slices with the depth window as 3 Cin input channels: same epilogue)
             npart = self.L.uz_conv_bn_partials(x.C if x.nb is None else 3 * x.C, cout, x.N, x.H, x.W, ks)
@@ -1077,8 +1079,12 @@ class Plan:
                             if not isinstance(r, View) or r.nb is not None:
                                 ok = False
                             elif c in self._PACK_WRITERS and j == self._PACK_WRITERS[c][0]:
-                                if c == "UZ_OP_BN_RELU_FWD" and not (o["i"][6] and o["i"][8] > 0 and o["i"][9] == 0):
-                                    ok = False               # needs the bound before the apply pass: statistics from the convolution's partials
+                                if c == "UZ_OP_BN_RELU_FWD":
+                                    i = o["i"]
+                                    npx = i[3] * i[4] * i[5]
+                                    one_launch = 4096 < npx <= self.L.uz_bn_fwd_fused_limit(i[4], i[5])      # mid path: a-priori bound from the parameters
+                                    if not (i[6] and i[9] == 0 and (i[8] > 0 or one_launch)):
+                                        ok = False           # needs the bound before the first word is written
                                 if c != "UZ_OP_BN_RELU_FWD" and o["p"][2] is None:
                                     ok = False               # pooling / interpolation forward their INPUT's bound
                                 wr_list.append((o, r))

@@ -592,6 +592,94 @@ __global__ __launch_bounds__(256) void bn_fused_small_bwd(const BnP p) {
     }
 }
 
+// ------------------------------------------------------------------ forward, mid path (round 4)
+// 4096 < N*H*W <= MID_LIMIT, training mode: ONE 1024-thread workgroup per channel reads the channel's batch once into registers,
+// forms the statistics (fp64 block reduction, fixed order) and the normalised output from them - one launch instead of
+// [statistics | finalise] + apply, and no dependence on the convolution's partials.
+// PK (split storage): a workgroup only knows its own channel's range, and the tensor-wide bound is needed BEFORE the first word is
+// written - so the scale comes from an A-PRIORI bound every workgroup can form alone: |x_hat| <= sqrt(n - 1) for any n samples
+// (Samuelson), hence |a| <= max_c (|gamma_c| sqrt(n - 1) + |beta_c|).  That bound is loose by sqrt(n) / (actual max |x_hat|) ~ 2^5:
+// an element is then stored to max(2^-22 |a|, 2^-33 A) instead of max(2^-22 |a|, 2^-38 A) - still 2^9 below fp32's own rounding of
+// the tensor's large elements.
+template <bool PK>
+__global__ __launch_bounds__(1024) void bn_fused_mid_fwd(const BnP p) {
+    __shared__ double smd[16 * 2];
+    __shared__ float bc[3];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hw4 = p.HW / 4, total4 = p.N * hw4;
+    float4 yv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int e = tid + j * 1024;
+        const int b = e / hw4, q = e - b * hw4;
+        yv[j] = e < total4 ? *reinterpret_cast<const float4*>(p.y + ((size_t)b * p.CtotY + c) * p.HW + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    double v2[2] = {0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float s = (yv[j].x + yv[j].y) + (yv[j].z + yv[j].w);
+        const float ss = (yv[j].x * yv[j].x + yv[j].y * yv[j].y) + (yv[j].z * yv[j].z + yv[j].w * yv[j].w);
+        v2[0] += (double)s; v2[1] += (double)ss;                     // (padding elements are zeros)
+    }
+    v2[0] = uz::wave_sum_d(v2[0]); v2[1] = uz::wave_sum_d(v2[1]);
+    if (lane == 0) { smd[wave * 2] = v2[0]; smd[wave * 2 + 1] = v2[1]; }
+    float apriori = 0.f;
+    if (PK && wave == 1) {                                            // the a-priori bound of the whole tensor, from the parameters alone
+        const float root = sqrtf((float)(p.N * p.HW - 1));
+        for (int k = lane; k < p.C; k += 64) apriori = fmaxf(apriori, fabsf(p.gamma ? p.gamma[k] : 1.f) * root + fabsf(p.beta ? p.beta[k] : 0.f));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) apriori = fmaxf(apriori, __shfl_xor(apriori, o, 64));
+        if (lane == 0) bc[2] = apriori;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < 16; ++w) { a += smd[w * 2]; b += smd[w * 2 + 1]; }
+        const double n = (double)p.N * p.HW;
+        const double m = a / n;
+        double var = b / n - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        p.save[c] = mean; p.save[p.C + c] = rstd;
+        if (p.rmean) {
+            const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+            p.rmean[c] = (float)((1.0 - p.momentum) * p.rmean[c] + p.momentum * m);
+            p.rvar[c] = (float)((1.0 - p.momentum) * p.rvar[c] + p.momentum * unb);
+        }
+        const float g = p.gamma ? p.gamma[c] : 1.f, bb = p.beta ? p.beta[c] : 0.f;
+        const float alpha = g * rstd, beta_ = bb - mean * alpha;
+        if (p.save4) { p.save[2 * p.C + c] = alpha; p.save[3 * p.C + c] = beta_; }
+        bc[0] = alpha; bc[1] = beta_;
+    }
+    __syncthreads();
+    const float alpha = bc[0], beta_ = bc[1], floor_ = p.relu ? 0.f : -INFINITY;
+    const float s = PK ? uz::split_scale(bc[2]) : 1.f;
+    float vmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int e = tid + j * 1024;
+        if (e < total4) {
+            const int b = e / hw4, q = e - b * hw4;
+            float4 r;
+            r.x = fmaxf(fmaf(yv[j].x, alpha, beta_), floor_); r.y = fmaxf(fmaf(yv[j].y, alpha, beta_), floor_);
+            r.z = fmaxf(fmaf(yv[j].z, alpha, beta_), floor_); r.w = fmaxf(fmaf(yv[j].w, alpha, beta_), floor_);
+            float* dst = p.out + ((size_t)b * p.CtotOut + c) * p.HW + 4 * q;
+            if (PK) {
+                uint4 o;
+                o.x = uz::pack_split(r.x, s); o.y = uz::pack_split(r.y, s); o.z = uz::pack_split(r.z, s); o.w = uz::pack_split(r.w, s);
+                *reinterpret_cast<uint4*>(dst) = o;
+            } else {
+                *reinterpret_cast<float4*>(dst) = r;
+                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+            }
+        }
+    }
+    if (p.amax) {
+        if (PK) { if (c == 0 && tid == 0) uz::amax_publish_one(bc[2], p.amax, 0u); }
+        else uz::amax_publish(vmax, p.amax);
+    }
+}
+
 // ------------------------------------------------------------------ backward, mid path (round 4)
 // 4096 < N*H*W <= MID_LIMIT (the 16 x 16 and 32 x 32 levels at batch 32: 40 of PHiSeg's 106 units): ONE 1024-thread workgroup per
 // channel keeps the channel's y and dA in registers (<= 32 + 32 values per thread) - both are read once, the sums, the gradient and
@@ -761,8 +849,10 @@ static int bn_relu_fwd_impl(const float* y, int C, int CtotY, const float* gamma
                             const float* conv_partials, int n_partials, const float* slabs, int n_slabs, const float* conv_bias, void* stream,
                             int save4 = 0, int out_packed = 0) {
     UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_fwd: empty tensor");
-    UZ_REQUIRE(!out_packed || (training && conv_partials && a_amax && (size_t)N * H * W > SMALL_LIMIT),
-               "bn_relu_fwd_ex: split storage needs the output's bound before the apply pass - training mode, statistics from the convolution's partials, a bound slot");
+    const bool mid = training && !conv_partials && !slabs && (size_t)N * H * W > SMALL_LIMIT && (size_t)N * H * W <= (size_t)uz_bn_fwd_fused_limit(H, W) &&
+                     vec_ok(H * W, y, a, nullptr);
+    UZ_REQUIRE(!out_packed || (training && (conv_partials || mid) && a_amax && (size_t)N * H * W > SMALL_LIMIT),
+               "bn_relu_fwd_ex: split storage needs the output's bound before the apply pass - training mode, a bound slot, and statistics from the convolution's partials (or the one-launch mid path)");
     UZ_REQUIRE(!conv_partials || (training && n_partials > 0 && (size_t)N * H * W > SMALL_LIMIT), "bn_relu_fwd: convolution partials only serve the training-mode large-plane path");
     UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_fwd: N or C exceeds grid limits");
     UZ_REQUIRE(!training || save_mean_rstd, "bn_relu_fwd: training needs save_mean_rstd");
@@ -780,6 +870,11 @@ static int bn_relu_fwd_impl(const float* y, int C, int CtotY, const float* gamma
         p.slab = slabs; p.nslab = n_slabs; p.cbias = conv_bias; p.ywr = const_cast<float*>(y);
         hipLaunchKernelGGL(bn_fused_small_fwd, dim3(C), dim3(256), 0, st, p);
         return uz::check_launch("bn_fused_small_fwd");
+    }
+    if (mid) {
+        if (out_packed) hipLaunchKernelGGL(bn_fused_mid_fwd<true>, dim3(C), dim3(1024), 0, st, p);
+        else hipLaunchKernelGGL(bn_fused_mid_fwd<false>, dim3(C), dim3(1024), 0, st, p);
+        return uz::check_launch("bn_fused_mid_fwd");
     }
     const bool vec = vec_ok(p.HW, y, a, nullptr);
     const dim3 grid(p.parts, C, N);
@@ -918,6 +1013,12 @@ extern "C" int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, in
 }
 // rows of dbias_partials a large-plane uz_bn_relu_bwd_ex call writes ([rows][C] doubles)
 extern "C" int uz_bn_bwd_dbias_rows(int N, int H, int W) { return (size_t)N * H * W > (size_t)uz_bn_bwd_fused_limit(H, W) ? N * uz::ceil_div(H * W, CHUNK) : 0; }
+// largest N*H*W whose training-mode FORWARD runs as one launch (small or mid path; the plans ask the convolution for no statistics
+// partials there)
+extern "C" int uz_bn_fwd_fused_limit(int H, int W) {
+    static const bool mid_on = !(getenv("UZ_BN_MID_FWD") && atoi(getenv("UZ_BN_MID_FWD")) == 0);
+    return (mid_on && (H * W) % 4 == 0) ? MID_LIMIT : SMALL_LIMIT;
+}
 // largest N*H*W whose backward runs as ONE launch with the channel's batch held on chip (no tensor-wide bound before the first
 // write: dy of such a unit is fp32, never split storage): the small path's limit, or the mid path's where H*W allows float4 rows
 extern "C" int uz_bn_bwd_fused_limit(int H, int W) {

@@ -77,7 +77,7 @@ struct SP {
     const float* x_amax2; int segc;
     float* slab;                                  // [kSplit][N][Cout][HW] partial sums (kSplit > 1), summed in order by splitk_reduce
     long long* stamps;                            // diagnostics (uz_debug_stamps): 8 cycle stamps per workgroup, normally null
-    int* flags;                                   // device flag word (bound violations), nullable
+    int* flags; int flag_bit;                     // device flag word (bound violations), nullable; the bit this launch raises: activation (forward) or gradient (data gradient)
     float* bnpart;                                // nullable: per-(pixel tile, row half, channel) {sum, sum of squares, max, max of negated} of y
 };
 
@@ -317,7 +317,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < CK; k += 2) bad |= uz::bound_violated(pr[k] * xs, pr[k + 1] * xs);
-        if (bad) atomicOr(p.flags, uz::FLAG_X_BOUND);
+        if (bad) atomicOr(p.flags, p.flag_bit);
     }
     // A 64-channel tile whose upper 32 channels lie beyond Cout (Cout = 224 = 3 x 64 + 32: the data gradient of the heaviest
     // layer) skips that half's MFMAs, fragment reads and epilogue pass: 12.5 % of that launch's matrix work were zeros.
@@ -803,7 +803,7 @@ static int conv_split_impl(const float* x, int Kc, int KcTot, const float* w, in
     UZ_REQUIRE(!relu_mask || (p.kSplit == 1 && dgrad), "conv_split: the folded ReLU / BatchNorm backward needs an unsplit data gradient");
     p.slab = reinterpret_cast<float*>(image + image_bytes(Kc, Mc, W));
     p.stamps = uz::debug_stamps;
-    p.flags = dev_flags_ptr();
+    p.flags = dev_flags_ptr(); p.flag_bit = dgrad ? FLAG_DY_BOUND : FLAG_X_BOUND;
     p.bnpart = bn_partials;
     const long long grid = (long long)p.tilesX * p.tilesY * N * p.nCoTiles * p.kSplit;
     UZ_REQUIRE(grid < (1ll << 31), "conv_split: grid too large");
