@@ -271,16 +271,17 @@ def dominant_kernel_live(net, plan, L, heaviest, reps=20):
         # one product per MAC puts these layers on the memory side of the ridge for narrow channel counts: report the HBM view too
         out["hbm_view"] = dict(achieved_gbs=round(alg_bytes / ms / 1e6, 1), peak_gbs=HBM_PEAK_GBS, frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                                note="algorithmic bytes (fp32 storage: input + output tensor once) / launch duration against 8 TB/s")
-    try:                                                    # round 3: per-layer dispatch table (tools/prof_layers.sh), keyed on layer and direction
-        tab = json.load(open(os.path.join(ROOT, "profiles", "r3_layer_table.json")))
-        for row in tab["layers"]:
-            if (row["kind"], row["cin"], row["cout"], row["n"], row["h"], row["w"], row["ks"]) == (kind, cin, cout, n, h, w, ks):
-                out.update(traffic=row["hbm_bytes"], traffic_source="profiles/r3_layer_table.json", kernel=row["dominant_kernel"],
-                           profiled=dict(avg_launch_us=row["avg_launch_us"], mfma_busy_fraction=row["mfma_busy_fraction"],
-                                         traffic_over_algorithmic=row["traffic_over_algorithmic"]))
-                return out
-    except Exception:
-        pass
+    for tabname in ("r4_layer_table.json", "r3_layer_table.json"):      # per-layer dispatch table (tools/prof_layers.sh), keyed on layer and direction; newest first
+        try:
+            tab = json.load(open(os.path.join(ROOT, "profiles", tabname)))
+            for row in tab["layers"]:
+                if (row["kind"], row["cin"], row["cout"], row["n"], row["h"], row["w"], row["ks"]) == (kind, cin, cout, n, h, w, ks):
+                    out.update(traffic=row["hbm_bytes"], traffic_source="profiles/" + tabname, kernel=row["dominant_kernel"],
+                               profiled=dict(avg_launch_us=row["avg_launch_us"], mfma_busy_fraction=row["mfma_busy_fraction"],
+                                             traffic_over_algorithmic=row["traffic_over_algorithmic"]))
+                    return out
+        except Exception:
+            pass
     for prof in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))

@@ -35,6 +35,9 @@ for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
             best = min(best, e0.elapsed_time(e1))
         o = ops[k]
         rows.append((best, which, o["code"].replace("UZ_OP_", ""), o["i"][:9], conv_flops(o, None), op_bytes(o, plan)))
+if os.environ.get("UZ_OP_PROFILE_JSON"):      # every op in tape order with its isolated time: input of tools/critical_path.py
+    import json
+    json.dump([dict(ms=r[0], tape=r[1], code=r[2], i=list(r[3])) for r in rows], open(os.environ["UZ_OP_PROFILE_JSON"], "w"))
 tot = sum(r[0] for r in rows)
 print(f"total {tot:.2f} ms over {len(rows)} ops")
 agg = {}

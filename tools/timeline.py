@@ -16,9 +16,9 @@ def wgs(r):
 
 def klass(name, nwg, dur_us):
     n = name
-    if re.search(r"conv_split_kernel|wgrad_split_kernel|conv_mfma_kernel|wgrad_kernel|wgrad_fast_kernel", n):
+    if re.search(r"conv_splitp?(_bn|_relu)?_kernel|conv_bf16|wgrad_split_kernel|conv_mfma_kernel|wgrad_kernel|wgrad_fast_kernel", n):
         return "matrix_heavy" if (nwg >= 192 and dur_us >= 25) else "matrix_small"
-    if re.search(r"bn_|relu_bwd|bilinear|avgpool|nearest|c1_|adam|pack_all|absmax|zero_k|copy_k|ce_|kl_|latent|add_views|splitk_reduce|wgrad_reduce|chan_", n):
+    if re.search(r"bn_|relu_bwd|bilinear|avgpool|nearest|c1_|adam|pack_all|absmax|zero_k|copy_k|ce_|kl_|latent|add_views|splitk_reduce|wgrad_reduce|chan_|pack_split", n):
         return "streaming" if dur_us >= 12 else "small"
     return "small"
 

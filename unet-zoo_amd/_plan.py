@@ -1602,6 +1602,10 @@ class Plan:
             for k in range(first[gi], last[gi] + 1):
                 sched[k].lane = lane
                 ops[k]["lane"] = lane
+        # the scheduled DAG, for diagnostics (tools/critical_path.py): per group in schedule order its op range, lane and predecessors
+        pos = {gi: n_ for n_, gi in enumerate(order)}
+        self.__dict__.setdefault("dag", {})[id(ops)] = [dict(first=first[gi], last=last[gi], lane=lane_of[gi], deps=sorted(pos[d] for d in deps[gi]))
+                                                         for gi in order]
         return sched
 
     # ------------------------------------------------------------------ execution helpers

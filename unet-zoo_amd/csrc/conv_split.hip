@@ -543,6 +543,8 @@ template <int MSUB, int NTv, int TWv, int NP, int MK, bool XPK> struct SplitKern
 #define UZ_SPLIT_KERNEL(name, MSUB_, NT_, TW_, NP_, MK_, XPK_, OCC_)                                                     \
     __global__ __launch_bounds__(NT_, OCC_) void name(const SP p) { conv_split_body<MSUB_, NT_, TW_, NP_, MK_, XPK_>(p); } \
     template <> struct SplitKernel<MSUB_, NT_, TW_, NP_, MK_, XPK_> { static constexpr auto fn = name; };
+// (round 4: the 32-channel-tile kernels keep (512, 4) although that bound costs them ~30 spilled registers - with (512, 3), no spills
+//  but one workgroup per CU, 32 -> 32 @ 128 x 128 ran 55 -> 61 us forward and the PHiSeg step lost 0.8 %)
 UZ_SPLIT_KERNEL(conv_split_kernel_2_512_32, 2, 512, 32, 2, 0, false, 1)
 UZ_SPLIT_KERNEL(conv_split_kernel_1_512_32, 1, 512, 32, 2, 0, false, 4)
 UZ_SPLIT_KERNEL(conv_split_kernel_1_256_16, 1, 256, 16, 2, 0, false, 2)
