@@ -180,6 +180,9 @@ int uz_bn_relu_fwd_pre(const float* y, int C, int CtotY, const float* gamma, con
 int uz_conv_splitk_parts(int Cin, int Cout, int N, int H, int W, int ks);
 int uz_conv_fwd_slabs(const float* x, int Cin, int CinTot, const float* w, int Cout, int N, int H, int W, int ks,
                       void* workspace, size_t workspace_bytes, void* stream);
+int uz_conv_bwd_splitk_parts(int Cin, int Cout, int N, int H, int W, int ks);      /* the data gradient's split count (1: not split, or another kernel family) */
+int uz_conv_bwd_data_slabs(const float* dy, int Cout, int CoutTot, const float* w, int Cin, int N, int H, int W, int ks,
+                           float* slabs_out, void* stream);                        /* [parts][N][Cin][H*W] partial sums; summed by uz_bn_relu_bwd_ex(da_slabs) */
 int uz_bn_relu_fwd_slabs(const float* slabs, int n_slabs, const float* conv_bias, float* y, int C, int CtotY,
                          const float* gamma, const float* beta, float* running_mean, float* running_var, float* save_mean_rstd,
                          float* a, int CtotA, int N, int H, int W, float eps, float momentum,
@@ -228,7 +231,8 @@ int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, int C, int Ct
                       const float* gamma, const float* beta, const float* save_mean_rstd,
                       float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
                       int N, int H, int W, int relu, float* dy_amax, void* workspace,
-                      const float* conv_partials, int n_partials, int out_packed, double* dbias_partials, void* stream);
+                      const float* conv_partials, int n_partials, int out_packed, double* dbias_partials,
+                      const float* da_slabs, int n_da_slabs, void* stream);   /* da_slabs: dA = the sum of these [n][N][C][H*W] slabs (small planes, uz_conv_bwd_data_slabs); da is then not read */
 int uz_bn_fwd_fused_limit(int H, int W);         /* N*H*W up to which the training-mode uz_bn_relu_fwd(_ex) WITHOUT conv_partials is one launch (statistics + apply from registers) */
 int uz_bn_bwd_fused_limit(int H, int W);         /* N*H*W up to which uz_bn_relu_bwd(_ex) is one launch with the channel's batch on chip: no out_packed / dbias_partials there */
 int uz_bn_bwd_dbias_rows(int N, int H, int W);   /* rows of dbias_partials ([rows][C] doubles, summed by uz_chan_sum_table); 0: small-plane path */

@@ -64,13 +64,14 @@ def main():
         gr = {k: v.grad for k, v in lv.items() if v.requires_grad}
         ref = gr if ref is None else {k: (None if v is None else v + gr[k]) for k, v in ref.items()}
     noise = G.bn_shadowed_biases(ref.keys())
-    worst = 0.0
+    worst, devs = 0.0, []
     for k, v in ref.items():
         if v is None or k in noise:
             continue
         v = v / world
         mine = net._ptab.gview(k).cpu() if False else g_dp[net._ptab.poff[k]:net._ptab.poff[k] + v.numel()].view(v.shape).cpu()
-        worst = max(worst, float((mine - v).abs().max() / (1e-3 + v.abs().max())))
+        devs.append(float((mine - v).abs().max() / (1e-3 + v.abs().max())))
+        worst = max(worst, devs[-1])
     for _ in range(2):
         step()
     ref_g, ref_p = g_dp.clone(), net._ptab.pflat.clone()
@@ -80,7 +81,15 @@ def main():
     print(f"rank {rank}: identical_across_ranks={same} worst_rel_dev_from_mean_of_oracle_shard_grads={worst:.3e}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
-    sys.exit(0 if (same and worst < 2e-2) else 1)
+    # Gates.  What this test is about - the exchange - fails by O(1): a shard left out or a sum instead of the mean moves EVERY tensor by
+    # 50 - 100 %.  Rounding does not: the median tensor sits at 1e-4 of its largest entry (gate 1e-3).  The worst tensor is a different
+    # matter: one pixel of a 64 x 64 plane whose pre-activation is zero to an ulp can carry the largest upstream gradient of its
+    # tensor, and whether its ReLU mask is 0 or 1 moves a weight gradient by 3 % (measured on this seed, tools/diag_midfwd.py: ONE
+    # mask element differs between two forward kernels whose outputs agree to 1 ulp, the fp64 oracle sides with either) - so the
+    # worst-tensor gate is 1e-1, far below what a wrong exchange does and above what a knife-edge mask does.
+    med = sorted(devs)[len(devs) // 2]
+    print(f"rank {rank}: median_rel_dev={med:.3e}", flush=True)
+    sys.exit(0 if (same and worst < 1e-1 and med < 1e-3) else 1)
 
 
 if __name__ == "__main__":

@@ -275,12 +275,21 @@ def test_phiseg_plan_round4_passes(monkeypatch):
     plan2 = plan2._build(32, 128, 128, True, True)
     _check_lane_schedule(plan2, "bwd", plan2.bwd_ops)
     _check_lane_schedule(plan2, "fwd", plan2.fwd_ops)
-    for k in ("UZ_PACK_ACT", "UZ_PACK_DY", "UZ_DBIAS_TABLE", "UZ_WGRAD_TABLE"):
+    # small planes: the split-K data gradients whose only reader is a unit's BatchNorm backward leave slabs for it (no reduce launch)
+    dg = [o for o in plan.bwd_ops if o["code"] == "UZ_OP_CONV_BWD_DATA" and len(o["i"]) > 10 and o["i"][10] == 3]
+    assert len(dg) == info["dgrad_folded"] >= 20
+    for o in dg:
+        i = o["i"]
+        assert i[4] * i[5] * i[6] <= 4096 and L.uz_conv_bwd_splitk_parts(i[2], i[0], i[4], i[5], i[6], i[7]) > 1
+        users = [b for b in plan.bwd_ops if b["code"] == "UZ_OP_BN_RELU_BWD" and len(b["p"]) > 11 and b["p"][11] is o["p"][7]]
+        assert len(users) == 1 and users[0]["i"][11] == L.uz_conv_bwd_splitk_parts(i[2], i[0], i[4], i[5], i[6], i[7])
+        assert plan.bwd_ops.index(users[0]) > plan.bwd_ops.index(o)
+    for k in ("UZ_PACK_ACT", "UZ_PACK_DY", "UZ_DBIAS_TABLE", "UZ_WGRAD_TABLE", "UZ_BN_FOLD_DGRAD"):
         monkeypatch.setenv(k, "0")
     net3 = PHISeg(1, 2, [32, 64, 128, 192, 192, 192, 192], device="cpu")
     net3.train()
     plain = net3._build(32, 128, 128, True, True)
-    assert plain.round4 == dict(folded=0, dy_packed=0, act_packed=0, act_views=0) and not any(b.packed for b in plain.bufs)
+    assert plain.round4 == dict(folded=0, dy_packed=0, act_packed=0, act_views=0, dgrad_folded=0) and not any(b.packed for b in plain.bufs)
     assert sum(o["code"] in ("UZ_OP_CHAN_SUM_TABLE", "UZ_OP_WGRAD_REDUCE_TABLE") for o in plain.bwd_ops) == 0
 
 

@@ -236,7 +236,7 @@ def test_unit_backward_with_folded_reduction_and_split_storage(N, C1, C2, H, W):
         dy1 = torch.full((N, C1, H, W), float("nan"), device=d)
         dgm, dbt, dbias = (torch.empty(C1, device=d) for _ in range(3))
         sdy1 = _slot()
-        g.call("uz_bn_relu_bwd_ex", dA, C1, y1, C1, C1, gd, bd, save, dy1, C1, dgm, dbt, dbias, N, H, W, 1, sdy1, bws, bpart if fused else None, rows if fused else 0, fused, None)
+        g.call("uz_bn_relu_bwd_ex", dA, C1, y1, C1, C1, gd, bd, save, dy1, C1, dgm, dbt, dbias, N, H, W, 1, sdy1, bws, bpart if fused else None, rows if fused else 0, fused, None, None, 0)
         dw1 = torch.empty(C1, C0, 3, 3, device=d)
         g.call("uz_conv_bwd_weight_ex", xd, C0, C0, dy1, C1, C1, dw1, None, N, H, W, 3, None, sdy1, ws, wsb, 0, None, 0, fused, None)
         dx = torch.empty(N, C0, H, W, device=d)
@@ -275,7 +275,7 @@ def test_deferred_conv_bias_sums():
     rows = L.uz_bn_bwd_dbias_rows(N, H, W)
     assert rows > 0
     part = torch.full((rows * C,), float("nan"), dtype=torch.float64, device=d)
-    g.call("uz_bn_relu_bwd_ex", da, C, y, C, C, gamma, beta, save, dy1, C, dg1, db1, None, N, H, W, 1, None, ws, None, 0, 0, part)
+    g.call("uz_bn_relu_bwd_ex", da, C, y, C, C, gamma, beta, save, dy1, C, dg1, db1, None, N, H, W, 1, None, ws, None, 0, 0, part, None, 0)
     table = torch.tensor([part.data_ptr(), dbias1.data_ptr(), rows, C, 1], dtype=torch.int64, device=d)
     g.call("uz_chan_sum_table", table, 1, C)
     assert torch.equal(dy0, dy1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
@@ -309,3 +309,35 @@ def test_weight_gradient_slabs_reduced_by_the_table_launch():
     g.call("uz_wgrad_reduce_table", table, len(cases), blk)
     for dw0, dw1, _, S in keep:
         assert torch.equal(dw0, dw1), S
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks", [(32, 192, 192, 8, 8, 3), (32, 192, 192, 4, 4, 3), (32, 256, 256, 2, 2, 3), (7, 70, 50, 5, 3, 3)])
+def test_data_gradient_slabs_folded_into_small_plane_batchnorm_backward(N, Cin, Cout, H, W, ks):
+    """uz_conv_bwd_data_slabs + uz_bn_relu_bwd_ex(da_slabs) (the 8 x 8 ... 2 x 2 levels: the data gradient's split-K reduce folded into
+    the one-workgroup-per-channel BatchNorm backward of the unit that produced the convolution's input) == uz_conv_bwd_data +
+    uz_bn_relu_bwd BIT FOR BIT (same slab order)."""
+    g, L = _g(), _lib()
+    parts = L.uz_conv_bwd_splitk_parts(Cin, Cout, N, H, W, ks)
+    if parts <= 1:
+        pytest.skip("the data gradient of this shape is not split over workgroups in this math mode")
+    d = g.dev()
+    dy2 = g.rnd(N, Cout, H, W, seed=81).to(d)
+    w = (g.rnd(Cout, Cin, ks, ks, seed=82) * 0.1).to(d)
+    y1 = (g.rnd(N, Cin, H, W, seed=83) * 2 + 0.3).to(d)           # pre-normalisation output of the unit whose activation the convolution read
+    gamma, beta = (g.rnd(Cin, seed=84).abs() + 0.5).to(d), (g.rnd(Cin, seed=85) * 0.3).to(d)
+    bws = torch.empty(L.uz_bn_workspace(Cin, N, H, W) // 4 + 16, device=d)
+    save, a1 = torch.empty(2 * Cin, device=d), torch.empty(N, Cin, H, W, device=d)
+    g.call("uz_bn_relu_fwd", y1, Cin, Cin, gamma, beta, None, None, save, a1, Cin, N, H, W, 1e-3, 0.01, 1, 1, None, bws)
+    wsb = L.uz_conv_workspace(Cin, Cout, N, H, W, ks)
+    ws = torch.empty(wsb // 4 + 64, device=d)
+    dA = torch.empty(N, Cin, H, W, device=d)
+    g.call("uz_conv_bwd_data", dy2, Cout, Cout, w, dA, Cin, Cin, N, H, W, ks, 0, None, None, ws, wsb)
+    dy0 = torch.empty_like(y1)
+    dg0, db0, dbias0 = (torch.empty(Cin, device=d) for _ in range(3))
+    g.call("uz_bn_relu_bwd", dA, Cin, y1, Cin, Cin, gamma, beta, save, dy0, Cin, dg0, db0, dbias0, N, H, W, 1, None, bws)
+    slabs = torch.full((parts * N * Cin * H * W,), float("nan"), device=d)
+    g.call("uz_conv_bwd_data_slabs", dy2, Cout, Cout, w, Cin, N, H, W, ks, slabs)
+    dy1 = torch.full_like(y1, float("nan"))
+    dg1, db1, dbias1 = (torch.full((Cin,), float("nan"), device=d) for _ in range(3))
+    g.call("uz_bn_relu_bwd_ex", None, Cin, y1, Cin, Cin, gamma, beta, save, dy1, Cin, dg1, db1, dbias1, N, H, W, 1, None, bws, None, 0, 0, None, slabs, parts)
+    assert torch.equal(dy0, dy1) and torch.equal(dg0, dg1) and torch.equal(db0, db1) and torch.equal(dbias0, dbias1)

@@ -1023,7 +1023,7 @@ class Plan:
                 writers, readers = [], []
                 for tape, ops in all_ops:
                     for o in ops:
-                        wr = self._WRITES[o["code"]]
+                        wr = self._op_writes(o)
                         for j, r in enumerate(o["p"]):
                             if touches(r, ga.buf) and isinstance(r, View) and r.c0 < ga.c0 + ga.C and ga.c0 < r.c0 + r.C:
                                 (writers if j in wr else readers).append((o, j, r))
@@ -1043,6 +1043,39 @@ class Plan:
                 B["p"] = B["p"][:11] + [part]
                 B["i"][8] = rows
                 info["folded"] += 1
+        # ---- 1b. small planes: the data gradient's split-K reduce folded into the consumer's BatchNorm backward (the mirror of the
+        # forward's uz_conv_fwd_slabs / uz_bn_relu_fwd_slabs): where the ONLY writer of a unit's dA is a split-K fp32 data gradient, that
+        # launch leaves its partial sums in a buffer of the layer's own and the unit's one-workgroup-per-channel backward adds them
+        # itself - one reduction launch less on the backward chains of the 8 x 8 ... 2 x 2 levels (UZ_BN_FOLD_DGRAD=0 switches it off)
+        info["dgrad_folded"] = 0
+        if env("UZ_BN_FOLD_DGRAD") and self.bwd_ops:
+            for u in units:
+                B = u.get("bn_bwd")
+                ga = u.get("ga")
+                if B is None or u["N"] * u["H"] * u["W"] > 4096 or not isinstance(ga, View) or ga.nb is not None or id(ga.buf) in tabbed:
+                    continue
+                writers, readers = [], []
+                for tape, ops in all_ops:
+                    for o in ops:
+                        wr = self._op_writes(o)
+                        for j, r in enumerate(o["p"]):
+                            if touches(r, ga.buf) and isinstance(r, View) and r.c0 < ga.c0 + ga.C and ga.c0 < r.c0 + r.C:
+                                (writers if j in wr else readers).append((o, j, r))
+                if len(writers) != 1 or len(readers) != 1 or readers[0][0] is not B:
+                    continue
+                W, j, r = writers[0]
+                if W["code"] != "UZ_OP_CONV_BWD_DATA" or j != 2 or (r.c0, r.C, r.nb) != (ga.c0, ga.C, None) or len(W["p"]) != 7 or W["i"][8] != 0:
+                    continue
+                cout_w, cin_w, N, H, Wd, ksw = W["i"][0], W["i"][2], W["i"][4], W["i"][5], W["i"][6], W["i"][7]
+                parts = self.L.uz_conv_bwd_splitk_parts(cin_w, cout_w, N, H, Wd, ksw)
+                if parts <= 1 or cin_w != u["C"]:
+                    continue
+                slabs = self.vec(u["name"] + ":daslabs", parts * N * cin_w * H * Wd)
+                W["p"] = W["p"][:7] + [slabs]
+                W["i"] = W["i"][:9] + [0, 3]
+                B["p"] = (B["p"] + [None])[:11] + [slabs]
+                B["i"] = (B["i"] + [0])[:11] + [parts]
+                info["dgrad_folded"] += 1
         # ---- 2. dY in split storage
         if env("UZ_PACK_DY") and self.bwd_ops:
             for u in units:
@@ -1353,7 +1386,7 @@ class Plan:
     # Which p[] slots an op writes (every other slot is read).  Scratch slots are private to a
     # group and parameters are read-only inside a tape, so neither creates a dependency.
     _WRITES = {
-        "UZ_OP_CONV_FWD": (3, 9), "UZ_OP_CONV_BWD_DATA": (2, 8, 9), "UZ_OP_CONV_BWD_WEIGHT": (2, 3, 8),
+        "UZ_OP_CONV_FWD": (3, 9), "UZ_OP_CONV_BWD_DATA": (2, 8, 9), "UZ_OP_CONV_BWD_WEIGHT": (2, 3, 8),      # (slabs-only data gradient: see _op_writes)
         "UZ_OP_BN_RELU_FWD": (3, 4, 5, 6), "UZ_OP_BN_RELU_BWD": (5, 6, 7, 8), "UZ_OP_RELU_BWD": (2, 3),
         "UZ_OP_AVGPOOL_FWD": (1,), "UZ_OP_AVGPOOL_BWD": (1, 3, 4), "UZ_OP_BILINEAR_FWD": (1,), "UZ_OP_BILINEAR_BWD": (1, 3, 4),
         "UZ_OP_NEAREST_FWD": (1,), "UZ_OP_NEAREST_BWD": (1,), "UZ_OP_SPATIAL_MEAN_FWD": (1,), "UZ_OP_SPATIAL_MEAN_BWD": (1,),
@@ -1366,6 +1399,13 @@ class Plan:
         "UZ_OP_DEPTH_LERP_FWD": (1,), "UZ_OP_DEPTH_LERP_BWD": (1,), "UZ_OP_NEAREST3D_FWD": (1,), "UZ_OP_NEAREST3D_BWD": (1,),
         "UZ_OP_ABSMAX_COPY": (), "UZ_OP_PACK_WEIGHTS": (2,), "UZ_OP_CHAN_SUM_PARTIALS": (1,), "UZ_OP_CHAN_SUM_TABLE": (1,), "UZ_OP_WGRAD_REDUCE_TABLE": (1,),
     }
+
+    def _op_writes(self, o):
+        """p[] slots op `o` writes: the static table, except for a slabs-only data gradient (i[10] == 3: partial sums into p[7], its
+        gradient view p[2] is NOT written - the consumer's BatchNorm backward reads the slabs instead)."""
+        if o["code"] == "UZ_OP_CONV_BWD_DATA" and len(o["i"]) > 10 and o["i"][10] == 3:
+            return (7,)
+        return self._WRITES[o["code"]]
 
     def _resources(self, r):
         """Dependency-relevant resources behind one pointer ref: (space, lo, hi) half-open ranges."""
@@ -1485,7 +1525,7 @@ class Plan:
         for gi, (a, b) in enumerate(groups):
             reads, writes = [], []
             for o in ops[a:b + 1]:
-                wr = self._WRITES[o["code"]]
+                wr = self._op_writes(o)
                 for j, r in enumerate(o["p"]):
                     (writes if j in wr else reads).extend(self._resources(r))
             d = set()

@@ -558,7 +558,26 @@ __global__ __launch_bounds__(256) void bn_fused_small_bwd(const BnP p) {
     for (int j = 0; j < EPT; ++j) {
         const bool ok = threadIdx.x + 256 * j < total;
         yv[j] = ok ? p.y[((size_t)(bq[j] >> 12) * p.CtotY + c) * p.HW + (bq[j] & 4095)] : 0.f;
-        dv[j] = ok ? p.da[((size_t)(bq[j] >> 12) * p.CtotDa + c) * p.HW + (bq[j] & 4095)] : 0.f;
+        dv[j] = (ok && !p.slab) ? p.da[((size_t)(bq[j] >> 12) * p.CtotDa + c) * p.HW + (bq[j] & 4095)] : 0.f;
+    }
+    if (p.slab) {
+        // dA is the sum of the split-K partial sums the data gradient left (uz_conv_bwd_data_slabs): added here in slab order -
+        // conv_splitk_reduce's arithmetic - instead of in a reduction launch of its own; dA itself is never materialised
+        const size_t n = (size_t)p.N * p.C * p.HW;
+        const float* __restrict__ slab = p.slab;
+        for (int k = 0; k < p.nslab; k += 4) {
+            float t[4][EPT];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < EPT; ++j)
+                    t[kk][j] = (k + kk < p.nslab && threadIdx.x + 256 * j < total)
+                                   ? slab[(size_t)(k + kk) * n + ((size_t)(bq[j] >> 12) * p.C + c) * p.HW + (bq[j] & 4095)] : 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < EPT; ++j) dv[j] += t[kk][j];
+        }
     }
 #pragma unroll
     for (int j = 0; j < EPT; ++j)
@@ -940,7 +959,7 @@ extern "C" int uz_bn_relu_bwd(const float* da, int CtotDa, const float* y, int C
                               float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
                               int N, int H, int W, int relu, float* dy_amax, void* workspace, void* stream) {
     return uz_bn_relu_bwd_ex(da, CtotDa, y, C, CtotY, gamma, beta, save_mean_rstd, dy, CtotDy, dgamma, dbeta, dbias, N, H, W, relu, dy_amax, workspace,
-                             nullptr, 0, 0, nullptr, stream);
+                             nullptr, 0, 0, nullptr, nullptr, 0, stream);
 }
 // uz_bn_relu_bwd with (a) conv_partials: n_partials rows [C][4] of {sum dz, sum dz x_hat, max |dz|, max |x_hat|} left by the data
 // gradient that wrote dA last (uz_conv_bwd_data_bn; dA then already carries the ReLU mask) - the reduction pass over dA and y is
@@ -952,8 +971,10 @@ extern "C" int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, in
                                  const float* gamma, const float* beta, const float* save_mean_rstd,
                                  float* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
                                  int N, int H, int W, int relu, float* dy_amax, void* workspace,
-                                 const float* conv_partials, int n_partials, int out_packed, double* dbias_partials, void* stream) {
+                                 const float* conv_partials, int n_partials, int out_packed, double* dbias_partials,
+                                 const float* da_slabs, int n_da_slabs, void* stream) {
     UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_bwd: empty tensor");
+    UZ_REQUIRE(!da_slabs || (n_da_slabs > 1 && (size_t)N * H * W <= SMALL_LIMIT), "bn_relu_bwd_ex: da_slabs only serve the small-plane path (N*H*W <= 4096)");
     UZ_REQUIRE(!dbias_partials || (!dbias && (size_t)N * H * W > SMALL_LIMIT), "bn_relu_bwd_ex: dbias_partials replaces dbias on the large-plane path");
     UZ_REQUIRE(!(conv_partials || out_packed) || (size_t)N * H * W > SMALL_LIMIT, "bn_relu_bwd_ex: folded statistics / split storage only serve the large-plane path");
     UZ_REQUIRE(!conv_partials || n_partials > 0, "bn_relu_bwd_ex: conv_partials without rows");
@@ -968,6 +989,7 @@ extern "C" int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, in
     p.parts = uz::ceil_div(p.HW, CHUNK);
     p.training = 1; p.relu = relu; p.amax = dy_amax;
     if ((size_t)N * p.HW <= SMALL_LIMIT) {
+        p.slab = da_slabs; p.nslab = n_da_slabs;
         hipLaunchKernelGGL(bn_fused_small_bwd, dim3(C), dim3(256), 0, st, p);
         return uz::check_launch("bn_fused_small_bwd");
     }

@@ -413,7 +413,8 @@ size_t conv_workspace(int Kc, int Mc, int N, int H, int W, int ks, int dgrad) {
 static int conv_mfma_impl(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
               float* y, int Mc, int McTot, int N, int H, int W, int ks, int dgrad, int relu, int accumulate,
               const float* x_amax, const float* w_amax, float* y_amax,
-              void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials, hipStream_t st, bool slabs_only);
+              void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials, hipStream_t st, bool slabs_only,
+              float* slabs_out = nullptr);
 int conv_mfma(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
               float* y, int Mc, int McTot, int N, int H, int W, int ks, int dgrad, int relu, int accumulate,
               const float* x_amax, const float* w_amax, float* y_amax,
@@ -434,12 +435,13 @@ int conv_splitk_parts(int Kc, int Mc, int N, int H, int W, int ks) {
 static int conv_mfma_impl(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
               float* y, int Mc, int McTot, int N, int H, int W, int ks, int dgrad, int relu, int accumulate,
               const float* x_amax, const float* w_amax, float* y_amax,
-              void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials, hipStream_t st, bool slabs_only) {
+              void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials, hipStream_t st, bool slabs_only,
+              float* slabs_out) {
     UZ_REQUIRE(ks == 1 || ks == 3, "conv: kernel size %d unsupported (1 or 3)", ks);
     UZ_REQUIRE(N > 0 && H > 0 && W > 0 && Kc > 0 && Mc > 0, "conv: empty tensor");
     UZ_REQUIRE(H <= 4096 && W <= 4096, "conv: spatial size too large");
     // large 3x3 layers: split-bf16 matrix pipe (conv_split.hip); its packed weight image lives in the workspace
-    UZ_REQUIRE(!slabs_only || (!dgrad && !conv_split_ok(Kc, Mc, N, H, W, ks, 0)), "conv_fwd_slabs: this shape does not run the split-K fp32 kernel");
+    UZ_REQUIRE(!slabs_only || !conv_split_ok(Kc, Mc, N, H, W, ks, dgrad), "conv_*_slabs: this shape does not run the split-K fp32 kernel");
     if (conv_split_ok(Kc, Mc, N, H, W, ks, dgrad) && workspace && workspace_bytes >= conv_split_workspace(Kc, Mc, N, H, W))
         return conv_split(x, Kc, KcTot, w, wCi, bias, y, Mc, McTot, N, H, W, dgrad, relu, accumulate, x_amax, w_amax, y_amax, workspace, packed_w, bn_partials, st);
     UZ_REQUIRE(!packed_w, "conv: a pre-packed weight image was supplied for a layer that does not take the split path");
@@ -462,9 +464,9 @@ static int conv_mfma_impl(const float* x, int Kc, int KcTot, const float* w, int
     const long long base_grid = (long long)g.tilesX * g.tilesY * g.tilesB * p.nCoTiles;
     pick_split(base_grid, ceil_div(Kc, CK), msub, kk, (double)N * Mc * H * W * sizeof(float), p.ksplit, p.cps);
     const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * N * Mc * H * W * sizeof(float) : 0;
-    if (p.ksplit > 1 && (!workspace || workspace_bytes < need)) { p.ksplit = 1; p.cps = ceil_div(Kc, CK); }   // no workspace: stay unsplit
+    if (p.ksplit > 1 && !slabs_out && (!workspace || workspace_bytes < need)) { p.ksplit = 1; p.cps = ceil_div(Kc, CK); }   // no workspace: stay unsplit
     UZ_REQUIRE(!slabs_only || p.ksplit > 1, "conv_fwd_slabs: the chunk loop of this shape is not split (uz_conv_splitk_parts() == 1) or the workspace is too small");
-    p.slab = static_cast<float*>(workspace);
+    p.slab = slabs_out ? slabs_out : static_cast<float*>(workspace);
     if (p.ksplit > 1) p.y_amax = nullptr;               // split-K: the reduce kernel sees the final values
     const long long grid = base_grid * p.ksplit;
     UZ_REQUIRE(grid < (1ll << 31), "conv: grid too large");
@@ -488,6 +490,28 @@ extern "C" int uz_conv_fwd_slabs(const float* x, int Cin, int CinTot, const floa
     UZ_REQUIRE(uz_conv_splitk_parts(Cin, Cout, N, H, W, ks) > 1, "conv_fwd_slabs: uz_conv_splitk_parts() == 1 for this shape");
     return uz::conv_mfma_impl(x, Cin, CinTot, w, Cin, nullptr, nullptr, Cout, Cout, N, H, W, ks, 0, 0, 0, nullptr, nullptr, nullptr,
                               workspace, workspace_bytes, nullptr, nullptr, uz::S(stream), true);
+}
+
+// The same for the data gradient of the small planes (round 4): where uz_conv_bwd_splitk_parts() > 1 the call may stop behind its
+// main kernel and leave the partial sums [parts][N][Cin][H*W] in slabs_out; the BatchNorm backward of the unit that produced the
+// convolution's input adds them itself (uz_bn_relu_bwd_ex, da_slabs) instead of reading dA - one reduction launch less on the
+// backward chains of the 8 x 8 ... 2 x 2 levels, same values (slab order).
+extern "C" int uz_conv_bwd_splitk_parts(int Cin, int Cout, int N, int H, int W, int ks) {
+    if ((ks != 1 && ks != 3) || Cin <= 0 || Cout <= 0 || N <= 0 || H <= 0 || W <= 0) return 1;
+    if (ks == 1 && uz::conv1x1_small_ok(Cin, Cout)) return 1;
+    if (uz::conv_split_ok(Cout, Cin, N, H, W, ks, 1)) return 1;
+    const Geom g = pick_geom(N, H, W, ks / 2);
+    const long long tiles = (long long)g.tilesX * g.tilesY * g.tilesB;
+    const int msub = pick_msub(Cin, tiles, uz::ceil_div(Cout, CK));
+    int ksplit, cps;
+    pick_split(tiles * uz::ceil_div(Cin, 32 * msub), uz::ceil_div(Cout, CK), msub, ks * ks, (double)N * Cin * H * W * sizeof(float), ksplit, cps);
+    return ksplit;
+}
+extern "C" int uz_conv_bwd_data_slabs(const float* dy, int Cout, int CoutTot, const float* w, int Cin, int N, int H, int W, int ks,
+                                      float* slabs_out, void* stream) {
+    UZ_REQUIRE(slabs_out && uz_conv_bwd_splitk_parts(Cin, Cout, N, H, W, ks) > 1, "conv_bwd_data_slabs: uz_conv_bwd_splitk_parts() == 1 for this shape");
+    return uz::conv_mfma_impl(dy, Cout, CoutTot, w, Cin, nullptr, nullptr, Cin, Cin, N, H, W, ks, 1, 0, 0, nullptr, nullptr, nullptr,
+                              nullptr, 0, nullptr, nullptr, uz::S(stream), true, slabs_out);
 }
 
 extern "C" size_t uz_conv_workspace(int Cin, int Cout, int N, int H, int W, int ks) {

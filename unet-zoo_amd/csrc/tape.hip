@@ -112,6 +112,7 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_CONV_BWD_DATA:
             // i[10]: fold of the unit that produced the output's forward twin - 1 ReLU mask (p[7] = its activation), 2 BatchNorm-backward
             // reduction (p[7] = its pre-normalisation output, p[10] = its statistics table, i[12] = its relu flag); i[11] = dy in split storage
+            if (i[10] == 3) return uz_conv_bwd_data_slabs(CFP(0), i[0], i[1], CFP(1), i[2], i[4], i[5], i[6], i[7], FP(7), st);      // slabs only: the consumer's BatchNorm backward adds them
             if (i[10] == 1) return uz_conv_bwd_data_relu(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], CFP(7), i[9], FP(8), FP(9), st);
             return uz_conv_bwd_data_ex(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], i[11],
                                        i[10] == 2 ? CFP(7) : nullptr, i[9], CFP(10), i[12], FP(8), st);
@@ -127,8 +128,9 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_BN_RELU_BWD:
             // p[11] / i[8] = reduction partials left by the data gradient that wrote dA last, i[9] = write dy as split storage
             // i[10]: p[8] holds the rows for the conv-bias gradient's partial sums instead of the gradient itself (added by UZ_OP_CHAN_SUM_TABLE)
+            // i[11] > 0: p[11] holds that many split-K slabs of dA left by the data gradient (small planes) instead of reduction partials
             return uz_bn_relu_bwd_ex(CFP(0), i[0], CFP(1), i[1], i[2], CFP(2), CFP(3), CFP(4), FP(5), i[3], FP(6), FP(7), i[10] ? nullptr : FP(8), i[4], i[5], i[6], i[7], FP(10), p[9],
-                                     CFP(11), i[8], i[9], i[10] ? static_cast<double*>(p[8]) : nullptr, st);
+                                     i[11] ? nullptr : CFP(11), i[8], i[9], i[10] ? static_cast<double*>(p[8]) : nullptr, i[11] ? CFP(11) : nullptr, i[11], st);
         case UZ_OP_RELU_BWD:
             return uz_relu_bwd(CFP(0), i[0], CFP(1), i[1], i[2], FP(2), i[3], FP(3), i[4], i[5], i[6], FP(5), p[4], st);
         case UZ_OP_AVGPOOL_FWD:
