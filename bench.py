@@ -545,6 +545,9 @@ def main():
     ap.add_argument("--conv-math", choices=["default", "f32", "split", "bf16"], default=None,
                     help="arithmetic of the large 3x3 convolutions (= UZ_CONV_MATH): default = fp32-accurate fp16 split; bf16 = one bf16 piece per "
                          "operand, fp32 accumulation.  phiseg3d defaults to bf16 (BASELINE configs[4] is quoted in bf16), everything else to default")
+    ap.add_argument("--storage", choices=["f32", "bf16"], default=None,
+                    help="phiseg3d with --conv-math bf16: keep the large volume tensors (activations, their gradients, dy) in bf16 STORAGE "
+                         "(= UZ_STORE_B16=1; BASELINE configs[4] 'bf16': the default of --model phiseg3d), or everything in fp32")
     ap.add_argument("--strong", action="store_true", help="strong scaling (SURVEY 8d): the GLOBAL batch stays at --batch (default 32), "
                                                           "each of the N GPUs takes batch / N images")
     args = ap.parse_args()
@@ -553,6 +556,10 @@ def main():
         args.conv_math = "bf16"
     if args.conv_math and args.conv_math != "default":
         os.environ["UZ_CONV_MATH"] = args.conv_math          # read by the library when it first routes a convolution; inherited by the ranks
+    if args.storage is None and args.model == "phiseg3d" and os.environ.get("UZ_CONV_MATH") == "bf16" and "UZ_STORE_B16" not in os.environ:
+        args.storage = "bf16"
+    if args.storage:
+        os.environ["UZ_STORE_B16"] = "1" if args.storage == "bf16" else "0"          # read when a plan is built; inherited by the ranks
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
@@ -737,7 +744,15 @@ def main():
                 roof["dominant_family"] = dict(name=dom, **fams[dom])
             except Exception as e:                          # never lose the headline line to the per-family pass
                 roof["families_error"] = str(e)[:200]
+        b16 = getattr(getattr(net, "_cur", None), "b16_info", None) or {}
+        store_b16 = bool(b16.get("buffers"))
         math_note = ("fp32 MFMA only (UZ_CONV_MATH=f32)" if conv_math() == "f32" else
+                     "bf16 STORAGE + bf16 ARITHMETIC (UZ_CONV_MATH=bf16, UZ_STORE_B16=1): the volume's large tensors - %d activation buffers, %d gradient "
+                     "buffers, the dy of %d units (%.2f GB less than fp32) - hold 2-byte bf16 elements (round to nearest even when written); the 3x3x3 "
+                     "convolutions stage them as they are, one v_mfma_f32_32x32x16_bf16 product per MAC, fp32 accumulation; BatchNorm statistics fp32 / fp64 "
+                     "of the stored values, parameters / gradients / optimiser state fp32; planes of 32 x 32 and below, the 1x1x1 heads' operands, the "
+                     "in-plane interpolation stage, latent and loss tensors stay fp32" % (b16["buffers"], b16["grads"], b16["dy"], b16["bytes_saved"] / 1e9)
+                     if (conv_math() == "bf16" and store_b16) else
                      "bf16 ARITHMETIC in the large 3x3(x3) convolutions (UZ_CONV_MATH=bf16): operands rounded to bf16 (round to nearest even) while they "
                      "are staged, one v_mfma_f32_32x32x16_bf16 product per MAC, fp32 accumulation; activations, gradients and BatchNorm statistics are "
                      "STORED in fp32 (bf16 storage is not built); small planes and 1x1 heads stay on the fp32 kernels" if conv_math() == "bf16" else
@@ -746,7 +761,7 @@ def main():
                      "products on the fp16 matrix pipe (error vs fp64 no larger than the fp32-MFMA kernels', tests/test_full_configs_gpu.py); other layers: fp32 MFMA")
         line = dict(metric=M["metric"], value=round(ips, 3 if vol else 2), unit=M.get("unit", "images/s"), n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="strong" if args.strong else "weak",
-                    vs_baseline=None, dtype="bf16 arithmetic / f32 storage" if conv_math() == "bf16" else "f32", data="synthetic",
+                    vs_baseline=None, dtype=("bf16" if store_b16 else "bf16 arithmetic / f32 storage") if conv_math() == "bf16" else "f32", data="synthetic",
                     config=dict(workload=M["workload"], batch_per_gpu=args.batch, global_batch=global_batch, parallelism=f"dp{world}",
                                 graphs=not args.no_graphs, final_loss=final_loss, conv_math=math_note),
                     roofline=roof)

@@ -485,6 +485,50 @@ int uz_depth_lerp2x_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotD
 int uz_nearest3d_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int D, int H, int W, int f, int fz, void* stream);
 int uz_nearest3d_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int D, int H, int W, int f, int fz, int accumulate, void* stream);
 
+/* ---------------------------------------------------------------- bf16 storage (BASELINE config 5: PHiSeg3D "bf16"; phiseg3D.py:13-35)
+ * A tensor in bf16 storage has the same N x C x H x W shape with 2-byte elements (round to nearest even when written, widened exactly
+ * when read); every arithmetic stays what the fp32-storage entry points do in the single-piece bf16 mode (uz_set_conv_math(3)):
+ * bf16 operands, fp32 accumulation, fp32 / fp64 BatchNorm statistics (of the STORED values), fp32 parameters and gradients.  Each
+ * tensor operand of these entry points carries its own flag (0 = fp32, 1 = bf16), so a plan may keep any subset of its buffers in
+ * bf16.  Scope: the large planes of a volume - 3x3 convolutions on the matrix-pipe path with an unsplit chunk loop (weight
+ * gradient: rows a multiple of 32 wide), the large-plane BatchNorm path (N*H*W > 32 768, H*W % 4 == 0), AvgPool3d and the depth
+ * stage of the trilinear interpolation.  Replaces, for such tensors: uz_conv_fwd_packed / uz_conv_bwd_data_packed /
+ * uz_conv_bwd_weight_ex, uz_bn_relu_fwd_pre / uz_bn_relu_bwd, uz_avgpool3d_* / uz_depth_lerp2x_*.                               */
+int uz_conv_fwd_b16(const void* x, int Cin, int CinTot, const float* w, const float* bias,
+                    void* y, int Cout, int CoutTot, int N, int H, int W, int ks,
+                    void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials,
+                    int x_b16, int y_b16, void* stream);
+int uz_conv_bwd_data_b16(const void* dy, int Cout, int CoutTot, const float* w, void* dx, int Cin, int CinTot,
+                         int N, int H, int W, int ks, int accumulate,
+                         void* workspace, size_t workspace_bytes, const void* packed_w, int dy_b16, int dx_b16, void* stream);
+int uz_conv_split_parts(int kind, int Cin, int Cout, int N, int H, int W);   /* chunk-loop split of the matrix-pipe kernel (kind 0 forward, 1 data gradient); the *_b16 convolutions need 1 */
+int uz_conv_bwd_weight_b16(const void* x, int Cin, int CinTot, const void* dy, int Cout, int CoutTot,
+                           float* dw, int N, int H, int W, int ks, void* workspace, size_t workspace_bytes,
+                           int x_b16, int dy_b16, float* slabs_out, void* stream);
+int uz_bn_relu_fwd_b16(const void* y, int C, int CtotY, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float* save_mean_rstd,
+                       void* a, int CtotA, int N, int H, int W, float eps, float momentum, int training, int relu,
+                       void* workspace, const float* conv_partials, int n_partials, int y_b16, int a_b16, void* stream);
+int uz_bn_relu_bwd_b16(const void* da, int CtotDa, const void* y, int C, int CtotY,
+                       const float* gamma, const float* beta, const float* save_mean_rstd,
+                       void* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
+                       int N, int H, int W, int relu, void* workspace, int da_b16, int y_b16, int dy_b16, void* stream);
+int uz_avgpool3d_fwd_b16(const void* x, int C, int CtotX, void* y, int CtotY, int D, int H, int W, int x_b16, int y_b16, void* stream);
+int uz_avgpool3d_bwd_b16(const void* dy, int C, int CtotDy, void* dx, int CtotDx, int D, int H, int W, int accumulate, int dy_b16, int dx_b16, void* stream);
+int uz_depth_lerp2x_fwd_b16(const void* x, int C, int CtotX, void* y, int CtotY, int D, int H, int W, int x_b16, int y_b16, void* stream);
+int uz_depth_lerp2x_bwd_b16(const void* dy, int C, int CtotDy, void* dx, int CtotDx, int D, int H, int W, int accumulate, int dy_b16, int dx_b16, void* stream);
+/* 1x1(x1) heads with 1 .. 8 outputs (mu_conv / sigma_conv phiseg3D.py:83-84, s_layer): the many-channel operand (x; dx of the data
+ * gradient) in bf16 storage, the few-channel side (y, dy) fp32.  Replace uz_conv_fwd / uz_conv_bwd_data / uz_conv_bwd_weight (ks = 1). */
+int uz_conv1x1_fwd_b16(const void* x, int Cin, int CinTot, const float* w, const float* bias, float* y, int Cout, int CoutTot,
+                       int N, int H, int W, int x_b16, void* stream);
+int uz_conv1x1_bwd_data_b16(const float* dy, int Cout, int CoutTot, const float* w, void* dx, int Cin, int CinTot,
+                            int N, int H, int W, int accumulate, int dx_b16, void* stream);
+int uz_conv1x1_bwd_weight_b16(const void* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* dw, float* db,
+                              int N, int H, int W, void* workspace, size_t workspace_bytes, int x_b16, void* stream);
+/* element-wise conversions between the two storage formats (n elements, contiguous) */
+int uz_cvt_f32_to_b16(const float* src, void* dst, size_t n, void* stream);
+int uz_cvt_b16_to_f32(const void* src, float* dst, size_t n, void* stream);
+
 /* Fcomb input (probabilistic_unet.py:172-197) */
 /* z (N,L) tiled over HxW into channels of a (N,Ctot,H,W) buffer, and its backward (sum over pixels) */
 int uz_bcast_channels_fwd(const float* z, int L, float* y, int CtotY, int N, int H, int W, void* stream);

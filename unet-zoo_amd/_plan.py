@@ -83,7 +83,7 @@ class ParamTable:
 
 
 class Buf:
-    __slots__ = ("name", "N", "C", "H", "W", "off", "gbuf", "requires_grad", "amax", "amax_cov", "alias", "relu", "packed")
+    __slots__ = ("name", "N", "C", "H", "W", "off", "gbuf", "requires_grad", "amax", "amax_cov", "alias", "relu", "packed", "b16", "vol")
 
     def __init__(self, name, N, C, H, W, requires_grad=True):
         self.name, self.N, self.C, self.H, self.W = name, int(N), int(C), int(H), int(W)
@@ -92,10 +92,21 @@ class Buf:
         self.alias = None                        # pooled scratch: several differently shaped Bufs share one arena region
         self.relu = None                         # set by Plan.conv_relu: {(c0, C): state} of Conv -> ReLU units writing into this buffer
         self.packed = False                      # kept in split storage (Plan._round4_passes): Plan.tensor() of it is NOT fp32 values
+        self.b16 = False                         # kept in bf16 storage (Plan._b16_pass): 2-byte elements, Plan.tensor() of it is a bfloat16 tensor
+        self.vol = False                         # a volume (Plan.vol): [D + 2][C][H][W]
 
     @property
     def numel(self):
         return self.N * self.C * self.H * self.W
+
+    @property
+    def words(self):
+        """32-bit words of arena the buffer occupies."""
+        return (self.numel + 1) // 2 if self.b16 else self.numel
+
+    @property
+    def esz(self):
+        return 2 if self.b16 else 4
 
 
 class View:
@@ -187,6 +198,7 @@ class Plan:
     def gview(self, v):
         if v.buf.gbuf is None:
             g = Buf("grad:" + v.buf.name, v.buf.N, v.buf.C, v.buf.H, v.buf.W, False)
+            g.vol = v.buf.vol
             self.bufs.append(g)
             v.buf.gbuf = g
         return View(v.buf.gbuf, v.c0, v.C, v.b0, v.nb)
@@ -196,6 +208,7 @@ class Plan:
         the returned view addresses the real slices as a batch of D images.  The arena is zero-initialised and nothing ever
         writes the two border slices, so they ARE the depth padding of the 3x3x3 convolutions."""
         b = Buf(name, D + 2, C, H, W, requires_grad)
+        b.vol = True
         self.bufs.append(b)
         return View(b, 0, C, 1, D)
 
@@ -349,7 +362,7 @@ class Plan:
             self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
             # (a depth-window call - 3 C view channels over a C-channel buffer - writes the Conv3d gradient layout itself:
             # uz_conv_bwd_weight's slab reduction does the [co][kd][ci] -> [co][ci][kd] permutation on the way out)
-            self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
+            rec["wgrad"] = self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
                        p=[("win", x), gy, self.G(wkey), None, ("scratch", "wgrad"), self.amax_in(x), self.amax_in(gy)],
                        i=[3 * cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, 3], n=ws)
             x = x_orig
@@ -364,7 +377,7 @@ class Plan:
                     # the data gradient's weight layout is prepared in the FORWARD tape (same parameters: the optimiser only steps
                     # behind the backward tape), as a group of its own - not in the layer's backward chain
                     self._emit(self.fwd_ops, "UZ_OP_W3D_PERMUTE", p=[self.P(wkey), wp2], i=[cout, cin, 1], detached=True)
-                self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
+                rec["dgrad"] = self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_DATA",
                            p=[("gywin", gy.zkey), wp2, self.gview(x), ("scratch", "wgrad"), self.amax_in(gy), ("amax", 0), packed],
                            i=[3 * cout, gy.Ctot, cin, x.Ctot, x.N, x.H, x.W, 3, acc], n=ws2)
             return
@@ -559,6 +572,9 @@ class Plan:
                 self._dbias_jobs.append((dbpart, bkey, dbrows, cout, 1))
             rec = {}
             self._conv_bwd(x, wkey, gyv, ks, rec=rec)
+            if x.nb is not None and ks == 3 and ybuf is None and a_grad is None and self.__dict__.get("_rev_ctx") is None:
+                # volume unit: its three backward ops share the zero-bordered dy scratch (see _b16_pass)
+                self.__dict__.setdefault("_vol_units", []).append(dict(bn_bwd=op_bwd, gyv=gyv, wgrad=rec.get("wgrad"), dgrad=rec.get("dgrad")))
             if unit is not None:
                 unit.update(bn_bwd=op_bwd, ga=ga, ks=ks, cin=x.C, wgrad=rec.get("wgrad"), dgrad=rec.get("dgrad"))
         self._push_bwd(bwd)
@@ -1176,6 +1192,132 @@ class Plan:
                 info["act_views"] += len(wr_list)
         return info
 
+    # ------------------------------------------------------------------ bf16 storage (BASELINE config 5: PHiSeg3D "bf16")
+    # tensor operand slots of the ops that have a bf16-storage form (include/uz_api.h, "bf16 storage"), in the order of the bits of i[13]
+    _B16_SLOTS = {
+        "UZ_OP_CONV_FWD": (0, 3), "UZ_OP_CONV_BWD_DATA": (0, 2), "UZ_OP_CONV_BWD_WEIGHT": (0, 1),
+        "UZ_OP_BN_RELU_FWD": (0, 6), "UZ_OP_BN_RELU_BWD": (0, 1, 5),
+        "UZ_OP_AVGPOOL3D_FWD": (0, 1), "UZ_OP_AVGPOOL3D_BWD": (0, 1), "UZ_OP_DEPTH_LERP_FWD": (0, 1), "UZ_OP_DEPTH_LERP_BWD": (0, 1),
+    }
+
+    def _b16_ok(self, o):
+        """Can op `o` run through its bf16-storage entry point (whatever the formats of its operands turn out to be)?"""
+        c, i, p = o["code"], o["i"], o["p"]
+        if c in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA", "UZ_OP_CONV_BWD_WEIGHT"):
+            kind = {"UZ_OP_CONV_FWD": 0, "UZ_OP_CONV_BWD_DATA": 1, "UZ_OP_CONV_BWD_WEIGHT": 2}[c]
+            W = i[6]
+            if i[7] != 3 or W % 32 or any(i[8:]) and kind != 1:
+                return False
+            if kind == 1 and (any(i[9:]) or len(p) > 7):
+                return False
+            if kind == 2 and p[3] is not None:
+                return False
+            cin, cout = (i[2], i[0]) if kind == 1 else (i[0], i[2])
+            if kind != 2 and self.L.uz_conv_split_parts(kind, cin, cout, i[4], i[5], i[6]) != 1:
+                return False
+            return self.L.uz_conv_route(kind, cin, cout, i[4], i[5], i[6], 3) == 1
+        if c == "UZ_OP_BN_RELU_FWD":
+            return i[3] * i[4] * i[5] > 32768 and (i[4] * i[5]) % 4 == 0 and i[6] == 1 and not any(i[9:])
+        if c == "UZ_OP_BN_RELU_BWD":
+            return i[4] * i[5] * i[6] > 32768 and (i[5] * i[6]) % 4 == 0 and not any(i[8:]) and len(p) <= 11
+        if c in ("UZ_OP_AVGPOOL3D_FWD", "UZ_OP_AVGPOOL3D_BWD"):
+            return i[5] % 4 == 0 and i[4] % 2 == 0
+        if c in ("UZ_OP_DEPTH_LERP_FWD", "UZ_OP_DEPTH_LERP_BWD"):
+            return (i[4] * i[5]) % 4 == 0
+        return False
+
+    def _b16_pass(self):
+        """Which volume tensors are kept in bf16 (UZ_STORE_B16=1 / Plan.store_b16, single-piece bf16 arithmetic only): a buffer whose
+        EVERY reader and writer - in every tape - is an op with a bf16-storage form on a shape that form serves (the 3x3x3
+        convolutions on the matrix pipe with planes wider than 32, the large-plane BatchNorm path, AvgPool3d, the depth stage of the
+        trilinear interpolation).  The decision is per buffer, every op carries one format bit per tensor operand (i[13]), so the
+        two formats mix freely: what some other op touches (the 1x1x1 heads' inputs, the in-plane interpolation's operands, the
+        latent and loss tensors, the image) stays fp32.  A unit's dy moves to a bf16 twin of the zero-bordered scratch class when
+        its three backward ops all qualify.  Returns / keeps a summary in self.b16_info."""
+        info = self.b16_info = dict(buffers=0, grads=0, dy=0, bytes_saved=0, ops=0)
+        on = os.environ.get("UZ_STORE_B16", "1" if self.__dict__.get("store_b16") else "0") == "1"
+        if not on or self.L.uz_get_conv_math() != 3 or not self.bn_training or self.extra_ops:
+            return info
+        all_ops = [o for ops in (self.fwd_ops, self.loss_ops, self.bwd_ops) for o in ops]
+        tabbed = {id(q.buf) for t in self.ptr_tables for q in t if isinstance(q, View)}
+        named = {id(v.buf) for v in self.named.values() if isinstance(v, View)}
+
+        def buf_of(r):
+            if isinstance(r, View):
+                return r.buf
+            if isinstance(r, _ScratchView):
+                return r.view.buf if r.view is not None else None
+            if isinstance(r, tuple) and r and r[0] == "win":
+                return r[1].buf
+            return None
+        ok_cache = {}
+        bad, seen = set(), set()
+        for o in all_ops:
+            slots = self._B16_SLOTS.get(o["code"], ())
+            if id(o) not in ok_cache:
+                ok_cache[id(o)] = bool(slots) and self._b16_ok(o)
+            for j, r in enumerate(o["p"]):
+                b = buf_of(r)
+                if b is None:
+                    continue
+                seen.add(id(b))
+                if not (ok_cache[id(o)] and j in slots):
+                    bad.add(id(b))
+        for b in self.bufs:
+            if not b.vol or b.alias is not None or id(b) in tabbed or id(b) in named or id(b) in bad or id(b) not in seen:
+                continue
+            if b.W % 32 or (b.N - 2) * b.H * b.W <= 32768:
+                continue
+            b.b16 = True
+            info["grads" if b.name.startswith("grad:") else "buffers"] += 1
+            info["bytes_saved"] += 2 * b.numel
+        # dy of the units: the lane's zero-bordered scratch class (slices, elements per slice) -> its bf16 twin
+        for u in self.__dict__.get("_vol_units", []):
+            B, Wg, Dg, gyv = u["bn_bwd"], u["wgrad"], u["dgrad"], u["gyv"]
+            if Wg is None or gyv.zkey is None or gyv.view is not None:
+                continue
+            if not (self._b16_ok(B) and self._b16_ok(Wg) and (Dg is None or self._b16_ok(Dg))):
+                continue
+            old = gyv.zkey
+            new = (old[0], old[1], 16)
+            self._gyz[new] = max(self._gyz.get(new, 0), (self._gyz[old] + 1) // 2)
+            gyv.zkey = new
+            assert B["p"][5] == ("gyvol", old)
+            B["p"][5] = ("gyvol", new)
+            B["b16_dy"] = Wg["b16_dy"] = True
+            if Dg is not None:
+                assert Dg["p"][0] == ("gywin", old)
+                Dg["p"][0] = ("gywin", new)
+                Dg["b16_dy"] = True
+            info["dy"] += 1
+        used = set()
+        for o in all_ops:
+            for q in o["p"]:
+                if isinstance(q, _ScratchView) and q.zkey is not None:
+                    used.add(q.zkey)
+                elif isinstance(q, tuple) and q and q[0] in ("gyvol", "gywin"):
+                    used.add(q[1])
+        for k in [k for k in self._gyz if k not in used]:
+            del self._gyz[k]                                   # an fp32 class every unit has left
+        # format bits
+        for o in all_ops:
+            slots = self._B16_SLOTS.get(o["code"])
+            if not slots or not ok_cache.get(id(o)):
+                continue
+            bits = 0
+            for k, j in enumerate(slots):
+                r = o["p"][j]
+                b = buf_of(r)
+                is16 = b is not None and b.b16
+                if o.get("b16_dy") and ((o["code"] == "UZ_OP_BN_RELU_BWD" and j == 5) or (o["code"] == "UZ_OP_CONV_BWD_WEIGHT" and j == 1) or (o["code"] == "UZ_OP_CONV_BWD_DATA" and j == 0)):
+                    is16 = True
+                bits |= int(is16) << k
+            if bits:
+                o["i"] = (o["i"] + [0] * 14)[:14]
+                o["i"][13] = bits
+                info["ops"] += 1
+        return info
+
     # ------------------------------------------------------------------ finalisation
     def finalize(self, want_backward=True):
         assert not self.finalized
@@ -1216,6 +1358,7 @@ class Plan:
                 self._emit(self.bwd_ops, "UZ_OP_EVENT_RECORD", p=[("event", b), ("gflat_range", lo, hi)])
         self._bwd = []
         self._round4_passes()
+        self._b16_pass()
         # magnitude-bound slots: zero the forward-side slots and measure the parameter bound at the head of the forward tape,
         # zero the backward-side slots at the head of the backward tape (group 0 of each tape: everything else depends on it)
         self.n_amax_fwd = self.n_amax
@@ -1269,7 +1412,7 @@ class Plan:
                 b.off = b.alias["off"]
                 continue
             b.off = off
-            off += -(-b.numel // _ALIGN) * _ALIGN
+            off += -(-b.words // _ALIGN) * _ALIGN
         # scratch regions are private to a scheduling group, so every capture lane gets its own copy
         self.gy_off, self.scratch_off, self.gyz_off = [], [], []
         for _ in range(self.n_lanes):
@@ -1322,11 +1465,11 @@ class Plan:
             if r.view is not None:
                 return self._resolve(r.view, lane)
             if r.zkey is not None:
-                return self.base + 4 * (self.gyz_off[lane][r.zkey] + r.off)
+                return self.base + 4 * self.gyz_off[lane][r.zkey] + (2 if len(r.zkey) > 2 else 4) * r.off
             return self.base + 4 * (self.gy_off[lane] + r.off)
         if isinstance(r, View):
             assert r.buf.off is not None
-            return self.base + 4 * (r.buf.off + (r.b0 * r.buf.C + r.c0) * r.buf.H * r.buf.W)
+            return self.base + 4 * r.buf.off + r.buf.esz * ((r.b0 * r.buf.C + r.c0) * r.buf.H * r.buf.W)
         kind = r[0]
         if kind == "param":
             return self.ptab.pflat.data_ptr() + 4 * (self.ptab.poff[r[1]] + r[2])
@@ -1350,11 +1493,11 @@ class Plan:
             return int(r[1])
         if kind == "win":                                    # depth window of a volume: starts one slice before the view
             v = r[1]
-            return self.base + 4 * (v.buf.off + ((v.b0 - 1) * v.buf.C + v.c0) * v.buf.H * v.buf.W)
+            return self.base + 4 * v.buf.off + v.buf.esz * (((v.b0 - 1) * v.buf.C + v.c0) * v.buf.H * v.buf.W)
         if kind == "gywin":                                  # depth window of a volume unit's dy scratch (dy lives one slice into it)
             return self.base + 4 * self.gyz_off[lane][r[1]]
         if kind == "gyvol":                                  # dy of a volume unit: the real slices start one slice in
-            return self.base + 4 * (self.gyz_off[lane][r[1]] + r[1][1])
+            return self.base + 4 * self.gyz_off[lane][r[1]] + (2 if len(r[1]) > 2 else 4) * r[1][1]
         if kind == "amax":
             return self.base + 4 * (self.amax_off + _AMAX_FLOATS * self._amax_remap[r[1]])
         if kind == "amaxw":
@@ -1652,7 +1795,10 @@ class Plan:
     def tensor(self, v):
         """torch view (storage only) of a plan buffer slice, NCHW (volumes: the D real slices, i.e. DCHW)."""
         b = v.buf
-        full = self.arena[b.off:b.off + b.numel].view(b.N, b.C, b.H, b.W)
+        if b.b16:
+            full = self.arena[b.off:b.off + b.words].view(torch.bfloat16)[:b.numel].view(b.N, b.C, b.H, b.W)
+        else:
+            full = self.arena[b.off:b.off + b.numel].view(b.N, b.C, b.H, b.W)
         if v.nb is not None:
             full = full[v.b0:v.b0 + v.nb]
         return full[:, v.c0:v.c0 + v.C]

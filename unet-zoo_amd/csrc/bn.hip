@@ -38,6 +38,7 @@ struct BnP {
     int save4;                                         // save[] holds 4 C floats: mean, rstd and (written by the finalise kernel) alpha = gamma rstd, beta' = beta - mean alpha
     int out_packed;                                    // out is written as split storage (split_f16.h: two fp16 pieces of v * split_scale(*amax) per word)
     float* chanf;                                      // backward, finalised: [C] m1 = mean(dz), [C] m2 = mean(dz x_hat)
+    int yb, dab, outb;                                 // bf16 STORAGE of y / da / out (2-byte elements; the *_st kernels)
 };
 
 // block-wide maxima of two floats (blockDim.x == 256); result valid in thread 0
@@ -533,6 +534,147 @@ __global__ __launch_bounds__(256) void chan_partial_sum(const double* __restrict
     for (int i = lane; i < P; i += 64) s += part[(size_t)i * C + c];
     s = uz::wave_sum_d(s);
     if (lane == 0) out[c] = (float)s;
+}
+
+// ------------------------------------------------------------------ bf16 STORAGE (round 4, the volume path: BASELINE config 5)
+// The large-path kernels once more with every tensor operand either fp32 or bf16 (p.yb / p.dab / p.outb, workgroup-uniform branches
+// around the loads and stores): half the bytes where a tensor is bf16, arithmetic and statistics in fp32 / fp64 as before.  H*W % 4
+// == 0 (8-byte rows).  The statistics are those of the STORED (rounded) y, so forward and backward see the same numbers.
+__global__ __launch_bounds__(256) void bn_stats_partial_st(const BnP p) {
+    __shared__ double sm[8];
+    __shared__ float smf[8];
+    const int c = blockIdx.y, grp = blockIdx.z, part = blockIdx.x;
+    const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
+    double v2[2] = {0.0, 0.0};
+    float vmx = -INFINITY, vmn = -INFINITY;
+    for (int b = grp * p.nb; b < min(p.N, (grp + 1) * p.nb); ++b) {
+        const size_t row = ((size_t)b * p.CtotY + c) * p.HW;
+        float s = 0.f, ss = 0.f;
+#pragma unroll 4
+        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+            const uz::f32x4 v = uz::ld_elem4(p.y, row + 4 * (size_t)i, p.yb);
+            s += (v.x + v.y) + (v.z + v.w);
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            vmx = fmaxf(fmaxf(vmx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+            vmn = fmaxf(fmaxf(vmn, fmaxf(-v.x, -v.y)), fmaxf(-v.z, -v.w));
+        }
+        v2[0] += (double)s; v2[1] += (double)ss;
+    }
+    uz::block_sum_d<2>(v2, sm);
+    block_max2(vmx, vmn, smf);
+    if (threadIdx.x == 0) {
+        const size_t e = (size_t)(grp * p.parts + part) * p.C + c;
+        p.part[e * 2] = v2[0]; p.part[e * 2 + 1] = v2[1];
+        p.mm[e * 2] = vmx; p.mm[e * 2 + 1] = vmn;
+    }
+}
+// apply pass; the statistics are in save[] already (bn_finalize_conv_partials) or come from the partials of bn_stats_partial_st
+__global__ __launch_bounds__(256) void bn_apply_st(const BnP p) {
+    __shared__ double red[2];
+    const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
+    float alpha, beta_, mean, rstd;
+    if (p.training && !p.pre) {
+        double s, ss;
+        channel_totals(p, c, red, s, ss);
+        const double n = (double)p.N * p.HW;
+        const double m = s / n;
+        double var = ss / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        if (b == 0 && part == 0 && threadIdx.x == 0) {
+            p.save[c] = mean;
+            p.save[p.C + c] = rstd;
+            if (p.rmean) {
+                const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                p.rmean[c] = (float)((1.0 - p.momentum) * p.rmean[c] + p.momentum * m);
+                p.rvar[c] = (float)((1.0 - p.momentum) * p.rvar[c] + p.momentum * unb);
+            }
+        }
+        const float g = p.gamma ? p.gamma[c] : 1.f, bb = p.beta ? p.beta[c] : 0.f;
+        alpha = g * rstd;
+        beta_ = bb - mean * alpha;
+    } else {
+        alpha_beta(p, c, alpha, beta_, mean, rstd);
+    }
+    const size_t yrow = ((size_t)b * p.CtotY + c) * p.HW, orow = ((size_t)b * p.CtotOut + c) * p.HW;
+    const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
+    const float floor_ = p.relu ? 0.f : -INFINITY;
+    for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+        uz::f32x4 v = uz::ld_elem4(p.y, yrow + 4 * (size_t)i, p.yb);
+        v.x = fmaxf(fmaf(v.x, alpha, beta_), floor_); v.y = fmaxf(fmaf(v.y, alpha, beta_), floor_);
+        v.z = fmaxf(fmaf(v.z, alpha, beta_), floor_); v.w = fmaxf(fmaf(v.w, alpha, beta_), floor_);
+        uz::st_elem4(p.out, orow + 4 * (size_t)i, v, p.outb);
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_reduce_partial_st(const BnP p) {
+    __shared__ double sm[8];
+    __shared__ float smf[8];
+    const int c = blockIdx.y, grp = blockIdx.z, part = blockIdx.x;
+    float alpha, beta_, mean, rstd;
+    alpha_beta(p, c, alpha, beta_, mean, rstd);
+    const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
+    double v2[2] = {0.0, 0.0};
+    float mdz = 0.f, mxh = 0.f;
+    for (int b = grp * p.nb; b < min(p.N, (grp + 1) * p.nb); ++b) {
+        const size_t yrow = ((size_t)b * p.CtotY + c) * p.HW, drow = ((size_t)b * p.CtotDa + c) * p.HW;
+        float s1 = 0.f, s2 = 0.f;
+        auto one = [&](float yv, float dv) {
+            const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
+            const float xh = (yv - mean) * rstd;
+            s1 += dz; s2 += dz * xh;
+            mdz = fmaxf(mdz, fabsf(dz)); mxh = fmaxf(mxh, fabsf(xh));
+        };
+#pragma unroll 4
+        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+            const uz::f32x4 yv = uz::ld_elem4(p.y, yrow + 4 * (size_t)i, p.yb), dv = uz::ld_elem4(p.da, drow + 4 * (size_t)i, p.dab);
+            one(yv.x, dv.x); one(yv.y, dv.y); one(yv.z, dv.z); one(yv.w, dv.w);
+        }
+        v2[0] += (double)s1; v2[1] += (double)s2;
+    }
+    uz::block_sum_d<2>(v2, sm);
+    block_max2(mdz, mxh, smf);
+    if (threadIdx.x == 0) {
+        const size_t e = (size_t)(grp * p.parts + part) * p.C + c;
+        p.part[e * 2] = v2[0]; p.part[e * 2 + 1] = v2[1];
+        p.mm[e * 2] = mdz; p.mm[e * 2 + 1] = mxh;
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_st(const BnP p) {
+    __shared__ double sm[4];
+    __shared__ double red[2];
+    const int c = blockIdx.y, b = blockIdx.z, part = blockIdx.x;
+    float alpha, beta_, mean, rstd;
+    alpha_beta(p, c, alpha, beta_, mean, rstd);
+    double s1, s2;
+    channel_totals(p, c, red, s1, s2);
+    const double n = (double)p.N * p.HW;
+    const float m1 = (float)(s1 / n), m2 = (float)(s2 / n);
+    if (b == 0 && part == 0 && threadIdx.x == 0) {
+        if (p.dbeta) p.dbeta[c] = (float)s1;
+        if (p.dgamma) p.dgamma[c] = (float)s2;
+    }
+    const size_t yrow = ((size_t)b * p.CtotY + c) * p.HW, drow = ((size_t)b * p.CtotDa + c) * p.HW, orow = ((size_t)b * p.CtotOut + c) * p.HW;
+    const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
+    float sd = 0.f;
+    auto one = [&](float yv, float dv) -> float {
+        const float dz = (!p.relu || fmaf(yv, alpha, beta_) > 0.f) ? dv : 0.f;
+        float r = alpha * (dz - m1 - ((yv - mean) * rstd) * m2);
+        if (p.outb) r = uz::bf16_round(r);            // (the conv-bias sum below is that of the stored values)
+        sd += r;
+        return r;
+    };
+    for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+        const uz::f32x4 yv = uz::ld_elem4(p.y, yrow + 4 * (size_t)i, p.yb), dv = uz::ld_elem4(p.da, drow + 4 * (size_t)i, p.dab);
+        uz::f32x4 r;
+        r.x = one(yv.x, dv.x); r.y = one(yv.y, dv.y); r.z = one(yv.z, dv.z); r.w = one(yv.w, dv.w);
+        uz::st_elem4(p.out, orow + 4 * (size_t)i, r, p.outb);
+    }
+    if (p.dbias) {
+        double v1[1] = {(double)sd};
+        uz::block_sum_d<1>(v1, sm);
+        if (threadIdx.x == 0) p.part2[(size_t)(b * p.parts + part) * p.C + c] = v1[0];
+    }
 }
 
 // ------------------------------------------------------------------ backward, small path
@@ -1046,6 +1188,71 @@ extern "C" int uz_bn_fwd_fused_limit(int H, int W) {
 extern "C" int uz_bn_bwd_fused_limit(int H, int W) {
     static const bool mid_on = !(getenv("UZ_BN_MID") && atoi(getenv("UZ_BN_MID")) == 0);
     return (mid_on && (H * W) % 4 == 0) ? MID_LIMIT : SMALL_LIMIT;
+}
+
+// ---- bf16 STORAGE entry points (include/uz_api.h, "bf16 storage").  y / a / da / dy each either fp32 or bf16 (flags), large-plane
+// path only (N*H*W > 32 768, H*W % 4 == 0); statistics from the convolution's partials (conv_partials) or from a streaming pass.
+extern "C" int uz_bn_relu_fwd_b16(const void* y, int C, int CtotY, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float* save_mean_rstd,
+                                  void* a, int CtotA, int N, int H, int W, float eps, float momentum, int training, int relu,
+                                  void* workspace, const float* conv_partials, int n_partials, int y_b16, int a_b16, void* stream) {
+    UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_fwd_b16: empty tensor");
+    UZ_REQUIRE((size_t)N * H * W > MID_LIMIT && (H * W) % 4 == 0, "bn_relu_fwd_b16: the bf16-storage kernels serve the large-plane path (N*H*W > 32768, H*W %% 4 == 0)");
+    UZ_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0, "bn_relu_fwd_b16: views must be 16-byte aligned");
+    UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_fwd_b16: N or C exceeds grid limits");
+    UZ_REQUIRE(!training || save_mean_rstd, "bn_relu_fwd_b16: training needs save_mean_rstd");
+    UZ_REQUIRE(training || (running_mean && running_var), "bn_relu_fwd_b16: eval needs running statistics");
+    UZ_REQUIRE(!conv_partials || (training && n_partials > 0), "bn_relu_fwd_b16: convolution partials only serve training mode");
+    hipStream_t st = uz::S(stream);
+    BnP p = {};
+    p.y = static_cast<const float*>(y); p.gamma = gamma; p.beta = beta; p.rmean = running_mean; p.rvar = running_var; p.save = save_mean_rstd;
+    p.out = static_cast<float*>(a); p.C = C; p.CtotY = CtotY; p.CtotOut = CtotA; p.N = N; p.HW = H * W;
+    p.parts = uz::ceil_div(p.HW, CHUNK);
+    p.eps = eps; p.momentum = momentum; p.training = training; p.relu = relu;
+    p.yb = y_b16 != 0; p.outb = a_b16 != 0;
+    const dim3 grid(p.parts, C, N);
+    reduction_groups(p);
+    if (training && conv_partials) {
+        p.pre = 1; p.cpart = conv_partials; p.ncpart = n_partials;
+        hipLaunchKernelGGL(bn_finalize_conv_partials, dim3(C), dim3(256), 0, st, p);
+        if (int rc = uz::check_launch("bn_finalize_conv_partials")) return rc;
+    } else if (training) {
+        UZ_REQUIRE(workspace, "bn_relu_fwd_b16: workspace required");
+        carve(p, workspace);
+        hipLaunchKernelGGL(bn_stats_partial_st, dim3(p.parts, C, p.ngrp), dim3(256), 0, st, p);
+        if (int rc = uz::check_launch("bn_stats_partial_st")) return rc;
+    }
+    hipLaunchKernelGGL(bn_apply_st, grid, dim3(256), 0, st, p);
+    return uz::check_launch("bn_apply_st");
+}
+extern "C" int uz_bn_relu_bwd_b16(const void* da, int CtotDa, const void* y, int C, int CtotY,
+                                  const float* gamma, const float* beta, const float* save_mean_rstd,
+                                  void* dy, int CtotDy, float* dgamma, float* dbeta, float* dbias,
+                                  int N, int H, int W, int relu, void* workspace, int da_b16, int y_b16, int dy_b16, void* stream) {
+    UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_bwd_b16: empty tensor");
+    UZ_REQUIRE((size_t)N * H * W > MID_LIMIT && (H * W) % 4 == 0, "bn_relu_bwd_b16: the bf16-storage kernels serve the large-plane path (N*H*W > 32768, H*W %% 4 == 0)");
+    UZ_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(da) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0, "bn_relu_bwd_b16: views must be 16-byte aligned");
+    UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_bwd_b16: N or C exceeds grid limits");
+    UZ_REQUIRE(save_mean_rstd && workspace, "bn_relu_bwd_b16: needs the saved statistics and a workspace");
+    hipStream_t st = uz::S(stream);
+    BnP p = {};
+    p.y = static_cast<const float*>(y); p.da = static_cast<const float*>(da); p.gamma = gamma; p.beta = beta; p.save = const_cast<float*>(save_mean_rstd);
+    p.out = static_cast<float*>(dy); p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias;
+    p.C = C; p.CtotY = CtotY; p.CtotDa = CtotDa; p.CtotOut = CtotDy; p.N = N; p.HW = H * W;
+    p.parts = uz::ceil_div(p.HW, CHUNK);
+    p.training = 1; p.relu = relu;
+    p.yb = y_b16 != 0; p.dab = da_b16 != 0; p.outb = dy_b16 != 0;
+    carve(p, workspace);
+    reduction_groups(p);
+    hipLaunchKernelGGL(bn_bwd_reduce_partial_st, dim3(p.parts, C, p.ngrp), dim3(256), 0, st, p);
+    if (int rc = uz::check_launch("bn_bwd_reduce_partial_st")) return rc;
+    hipLaunchKernelGGL(bn_bwd_apply_st, dim3(p.parts, C, N), dim3(256), 0, st, p);
+    if (int rc = uz::check_launch("bn_bwd_apply_st")) return rc;
+    if (dbias) {
+        hipLaunchKernelGGL(chan_partial_sum, dim3(uz::ceil_div(C, 4)), dim3(256), 0, st, p.part2, N * p.parts, C, dbias);
+        if (int rc = uz::check_launch("chan_partial_sum")) return rc;
+    }
+    return 0;
 }
 
 extern "C" int uz_relu_bwd(const float* da, int CtotDa, const float* a, int C, int CtotA,

@@ -7,6 +7,7 @@
 //   bwd_data   dx[b,c,p] (+)= sum_n w[n][c] dy[b,n,p]                writes dx once
 //   bwd_weight dw[n][c] = sum_{b,p} dy[b,n,p] x[b,c,p], db[n] = sum dy   reads x once, fp64 ordered partials
 #include "uz_common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -16,6 +17,7 @@ constexpr int PIX = 1024;        // pixels per workgroup (256 threads x float4)
 struct C1P {
     const float* x; const float* w; const float* bias; const float* dy; float* y; float* dx; double* part;
     int Cin, CinTot, Cout, CoutTot, N, HW, nchunk, accumulate, cgroup;
+    int xb16;        // the many-channel tensor (x; dx in the data gradient) holds 2-byte bf16 elements (float4 paths only); y / dy stay fp32
 };
 
 template <int NO, bool VEC>
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(256) void c1_fwd(const C1P p) {
         for (int n = 0; n < NO; ++n) { const float bv = p.bias ? p.bias[n] : 0.f; acc[n] = make_float4(bv, bv, bv, bv); }
 #pragma unroll 8
         for (int c = 0; c < p.Cin; ++c) {
-            const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)c * p.HW + q);
+            const uz::f32x4 v = uz::ld_elem4(p.x, ((size_t)b * p.CinTot + c) * p.HW + q, p.xb16);
 #pragma unroll
             for (int n = 0; n < NO; ++n) {
                 const float wv = ws[n * p.Cin + c];
@@ -77,14 +79,14 @@ __global__ __launch_bounds__(256) void c1_bwd_data(const C1P p) {
         for (int n = 0; n < NO; ++n) g[n] = *reinterpret_cast<const float4*>(db + (size_t)n * p.HW + q);
 #pragma unroll 4
         for (int c = c_lo; c < c_hi; ++c) {
-            float4* dst = reinterpret_cast<float4*>(xb + (size_t)c * p.HW + q);
-            float4 r = p.accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
+            const size_t e = ((size_t)b * p.CinTot + c) * p.HW + q;
+            uz::f32x4 r = p.accumulate ? uz::ld_elem4(p.dx, e, p.xb16) : uz::f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int n = 0; n < NO; ++n) {
                 const float wv = ws[n * p.Cin + c];
                 r.x = fmaf(wv, g[n].x, r.x); r.y = fmaf(wv, g[n].y, r.y); r.z = fmaf(wv, g[n].z, r.z); r.w = fmaf(wv, g[n].w, r.w);
             }
-            *dst = r;
+            uz::st_elem4(p.dx, e, r, p.xb16);
         }
     } else {
         for (int q = blockIdx.x * PIX + threadIdx.x; q < min(p.HW, (int)(blockIdx.x + 1) * PIX); q += 256) {
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void c1_bwd_weight_partial(const C1P p) {
         long long i = lo + 4 * threadIdx.x;
         int b = (int)(i / p.HW), q = (int)(i - (long long)b * p.HW), cnt = 0;
         for (; i < hi; i += 1024) {
-            const float4 xv = *reinterpret_cast<const float4*>(p.x + ((size_t)b * p.CinTot + c) * p.HW + q);
+            const uz::f32x4 xv = uz::ld_elem4(p.x, ((size_t)b * p.CinTot + c) * p.HW + q, p.xb16);
 #pragma unroll
             for (int n = 0; n < NO; ++n) {
                 const float4 g = *reinterpret_cast<const float4*>(p.dy + ((size_t)b * p.CoutTot + n) * p.HW + q);
@@ -222,18 +224,20 @@ bool conv1x1_small_ok(int Cin, int Cout) { return Cout <= MAXN && Cin <= 512; }
 
 // returns -2 when this (Cout) is not covered (caller falls back to the MFMA kernel)
 int conv1x1_small_fwd(const float* x, int Cin, int CinTot, const float* w, const float* bias, float* y, int Cout, int CoutTot,
-                      int N, int H, int W, hipStream_t st) {
-    C1P p = {}; p.x = x; p.w = w; p.bias = bias; p.y = y; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot; p.N = N; p.HW = H * W;
+                      int N, int H, int W, hipStream_t st, int x_b16) {
+    C1P p = {}; p.xb16 = x_b16; p.x = x; p.w = w; p.bias = bias; p.y = y; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot; p.N = N; p.HW = H * W;
     const bool v = vec4(p.HW, x, y);
+    if (x_b16 && !v) return fail("conv1x1 forward: bf16 storage needs H*W %% 4 == 0 and 16-byte aligned views");
     const dim3 grid(ceil_div(p.HW, PIX), N);
     C1_DISPATCH(c1_fwd, v, grid)
     return check_launch("c1_fwd");
 }
 int conv1x1_small_bwd_data(const float* dy, int Cout, int CoutTot, const float* w, float* dx, int Cin, int CinTot,
-                           int N, int H, int W, int accumulate, hipStream_t st) {
-    C1P p = {}; p.dy = dy; p.w = w; p.dx = dx; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot; p.N = N; p.HW = H * W;
+                           int N, int H, int W, int accumulate, hipStream_t st, int dx_b16) {
+    C1P p = {}; p.xb16 = dx_b16; p.dy = dy; p.w = w; p.dx = dx; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot; p.N = N; p.HW = H * W;
     p.accumulate = accumulate;
     const bool v = vec4(p.HW, dy, dx);
+    if (dx_b16 && !v) return fail("conv1x1 data gradient: bf16 storage needs H*W %% 4 == 0 and 16-byte aligned views");
     // low-resolution planes have few pixel blocks: split the input channels over grid.z until ~1024 workgroups exist
     const int pixblk = ceil_div(p.HW, PIX) * N;
     int groups = ceil_div(1024, pixblk);
@@ -251,8 +255,9 @@ size_t conv1x1_small_bwd_weight_ws(int Cin, int Cout, int N, int H, int W) {
     return ((size_t)nchunk * Cout * Cin + (size_t)nchunk * Cout) * sizeof(double);
 }
 int conv1x1_small_bwd_weight(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* dw, float* db,
-                             int N, int H, int W, void* ws, hipStream_t st) {
-    C1P p = {}; p.x = x; p.dy = dy; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot; p.N = N; p.HW = H * W;
+                             int N, int H, int W, void* ws, hipStream_t st, int x_b16) {
+    if (x_b16 && ((H * W) % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0)) return fail("conv1x1 weight gradient: bf16 storage needs H*W %% 4 == 0 and a 16-byte aligned view");
+    C1P p = {}; p.xb16 = x_b16; p.x = x; p.dy = dy; p.Cin = Cin; p.CinTot = CinTot; p.Cout = Cout; p.CoutTot = CoutTot; p.N = N; p.HW = H * W;
     const long long total = (long long)N * H * W;
     p.nchunk = (int)((total + 16383) / 16384);
     if (p.nchunk > 64) p.nchunk = 64;
@@ -272,3 +277,25 @@ int conv1x1_small_bwd_weight(const float* x, int Cin, int CinTot, const float* d
 }
 
 }  // namespace uz
+
+// ---- bf16 STORAGE of the many-channel operand of a 1x1(x1) head (include/uz_api.h, "bf16 storage"): x (forward, weight gradient) / dx
+// (data gradient) hold 2-byte bf16 elements, the 1 .. 8-channel side (y, dy) stays fp32.  Cout in {1, 2, 3, 4, 6, 8}, Cin <= 512.
+extern "C" int uz_conv1x1_fwd_b16(const void* x, int Cin, int CinTot, const float* w, const float* bias, float* y, int Cout, int CoutTot,
+                                  int N, int H, int W, int x_b16, void* stream) {
+    UZ_REQUIRE(uz::conv1x1_small_ok(Cin, Cout) && N > 0 && H > 0 && W > 0, "conv1x1_fwd_b16: shape not covered by the streaming 1x1 kernels");
+    const int rc = uz::conv1x1_small_fwd(static_cast<const float*>(x), Cin, CinTot, w, bias, y, Cout, CoutTot, N, H, W, uz::S(stream), x_b16 != 0);
+    return rc == -2 ? uz::fail("conv1x1_fwd_b16: %d outputs not covered", Cout) : rc;
+}
+extern "C" int uz_conv1x1_bwd_data_b16(const float* dy, int Cout, int CoutTot, const float* w, void* dx, int Cin, int CinTot,
+                                       int N, int H, int W, int accumulate, int dx_b16, void* stream) {
+    UZ_REQUIRE(uz::conv1x1_small_ok(Cin, Cout) && N > 0 && H > 0 && W > 0, "conv1x1_bwd_data_b16: shape not covered by the streaming 1x1 kernels");
+    const int rc = uz::conv1x1_small_bwd_data(dy, Cout, CoutTot, w, static_cast<float*>(dx), Cin, CinTot, N, H, W, accumulate, uz::S(stream), dx_b16 != 0);
+    return rc == -2 ? uz::fail("conv1x1_bwd_data_b16: %d outputs not covered", Cout) : rc;
+}
+extern "C" int uz_conv1x1_bwd_weight_b16(const void* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* dw, float* db,
+                                         int N, int H, int W, void* workspace, size_t workspace_bytes, int x_b16, void* stream) {
+    UZ_REQUIRE(uz::conv1x1_small_ok(Cin, Cout) && N > 0 && H > 0 && W > 0, "conv1x1_bwd_weight_b16: shape not covered by the streaming 1x1 kernels");
+    UZ_REQUIRE(workspace && workspace_bytes >= uz::conv1x1_small_bwd_weight_ws(Cin, Cout, N, H, W), "conv1x1_bwd_weight_b16: workspace too small");
+    const int rc = uz::conv1x1_small_bwd_weight(static_cast<const float*>(x), Cin, CinTot, dy, Cout, CoutTot, dw, db, N, H, W, workspace, uz::S(stream), x_b16 != 0);
+    return rc == -2 ? uz::fail("conv1x1_bwd_weight_b16: %d outputs not covered", Cout) : rc;
+}

@@ -589,6 +589,33 @@ extern "C" int uz_conv_bwd_data_ex(const float* dy, int Cout, int CoutTot, const
     return uz::conv_split_ex(dy, Cout, CoutTot, w, Cin, nullptr, dx, Cin, CinTot, N, H, W, 1, 0, accumulate, dy_amax, w_amax, nullptr, workspace, packed_w,
                              bn_y ? bn_partials : nullptr, uz::S(stream), o);
 }
+// bf16 STORAGE (include/uz_api.h, "bf16 storage"; BASELINE config 5): the input and / or the output tensor hold 2-byte bf16 elements
+// (same NCHW shape).  Single-piece bf16 mode (uz_set_conv_math(3)), 3x3 shapes on the matrix-pipe path with planes wider than 32;
+// fp32 accumulation, values rounded to nearest even when written; the fused BatchNorm statistics are those of the STORED values.
+extern "C" int uz_conv_fwd_b16(const void* x, int Cin, int CinTot, const float* w, const float* bias,
+                               void* y, int Cout, int CoutTot, int N, int H, int W, int ks,
+                               void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials,
+                               int x_b16, int y_b16, void* stream) {
+    UZ_REQUIRE(ks == 3 && uz::conv_np() == 1 && uz_conv_route(0, Cin, Cout, N, H, W, ks) == 1,
+               "conv_fwd_b16: bf16 storage needs uz_set_conv_math(3) and a 3x3 shape on the matrix-pipe path (unsplit chunk loop)");
+    UZ_REQUIRE(workspace && workspace_bytes >= uz::conv_split_workspace(Cin, Cout, N, H, W), "conv_fwd_b16: workspace too small");
+    UZ_REQUIRE(!bn_partials || uz_conv_bn_partials(Cin, Cout, N, H, W, ks) > 0, "conv_fwd_b16: this shape writes no fused statistics (uz_conv_bn_partials() == 0)");
+    uz::SplitOpts o;
+    o.x_b16 = x_b16 != 0; o.y_b16 = y_b16 != 0;
+    return uz::conv_split_ex(static_cast<const float*>(x), Cin, CinTot, w, Cin, bias, static_cast<float*>(y), Cout, CoutTot, N, H, W, 0, 0, 0,
+                             nullptr, nullptr, nullptr, workspace, packed_w, bn_partials, uz::S(stream), o);
+}
+extern "C" int uz_conv_bwd_data_b16(const void* dy, int Cout, int CoutTot, const float* w, void* dx, int Cin, int CinTot,
+                                    int N, int H, int W, int ks, int accumulate,
+                                    void* workspace, size_t workspace_bytes, const void* packed_w, int dy_b16, int dx_b16, void* stream) {
+    UZ_REQUIRE(ks == 3 && uz::conv_np() == 1 && uz_conv_route(1, Cin, Cout, N, H, W, ks) == 1,
+               "conv_bwd_data_b16: bf16 storage needs uz_set_conv_math(3) and a 3x3 shape on the matrix-pipe path (unsplit chunk loop)");
+    UZ_REQUIRE(workspace && workspace_bytes >= uz::conv_split_workspace(Cout, Cin, N, H, W), "conv_bwd_data_b16: workspace too small");
+    uz::SplitOpts o;
+    o.x_b16 = dy_b16 != 0; o.y_b16 = dx_b16 != 0;
+    return uz::conv_split_ex(static_cast<const float*>(dy), Cout, CoutTot, w, Cin, nullptr, static_cast<float*>(dx), Cin, CinTot, N, H, W, 1, 0, accumulate,
+                             nullptr, nullptr, nullptr, workspace, packed_w, nullptr, uz::S(stream), o);
+}
 extern "C" int uz_conv_bwd_data_packed(const float* dy, int Cout, int CoutTot, const float* w,
                                        float* dx, int Cin, int CinTot, int N, int H, int W, int ks, int accumulate,
                                        const float* dy_amax, const float* w_amax,

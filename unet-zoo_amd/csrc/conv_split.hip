@@ -79,6 +79,7 @@ struct SP {
     long long* stamps;                            // diagnostics (uz_debug_stamps): 8 cycle stamps per workgroup, normally null
     int* flags; int flag_bit;                     // device flag word (bound violations), nullable; the bit this launch raises: activation (forward) or gradient (data gradient)
     float* bnpart;                                // nullable: per-(pixel tile, row half, channel) {sum, sum of squares, max, max of negated} of y
+    int yb16;                                     // y (and what it accumulates onto) is stored as bf16 (single-piece mode, kSplit == 1)
 };
 
 
@@ -135,10 +136,14 @@ constexpr int lds_bytes() {
     const int epilogue = 16 * (NTv + 4) * 4;
     return main_loop > epilogue ? main_loop : epilogue;
 }
-// MK: 1 = the folded ReLU-backward mask (kernels of their own: +12 VGPRs), 2 = the folded BatchNorm-backward reduction; XPK = input in split storage
-template <int MSUB, int NTv, int TWv, int NP, int MK = 0, bool XPK = false>
+// MK: 1 = the folded ReLU-backward mask (kernels of their own: +12 VGPRs), 2 = the folded BatchNorm-backward reduction;
+// XF = input format: 0 fp32 values, 1 split storage (two fp16 pieces per word), 2 bf16 storage (2-byte elements, single-piece mode)
+template <int MSUB, int NTv, int TWv, int NP, int MK = 0, int XF = 0>
 __device__ __forceinline__ void conv_split_body(const SP& p) {
+    constexpr bool XPK = XF == 1, XB = XF == 2;
+    constexpr unsigned ESZ = XB ? 2u : 4u;               // bytes per input element
     static_assert(!XPK || NP == 2, "split storage is the two-piece fp16 format");
+    static_assert(!XB || NP == 1, "bf16 storage feeds the single-piece bf16 mode");
     using uz::u32x4;
     using GEO = Geo<NTv, TWv>;
     constexpr int NT = GEO::NT, TW = GEO::TW, PW = GEO::PW, PSI = GEO::PSI, PSR = GEO::PSR, G = GEO::G, CE = GEO::CE;
@@ -170,7 +175,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 
     // ---- staging maps (chunk invariant).  An all-ones mask OR'd into an offset fails the buffer range check: the load returns 0.
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x + (size_t)b0 * p.CinTot * p.HW), 0, (unsigned)((size_t)p.Cin * p.HW * sizeof(float)), 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(p.x) + (size_t)b0 * p.CinTot * p.HW * ESZ), 0, (unsigned)((size_t)p.Cin * p.HW * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(p.wp), 0, (unsigned)((size_t)p.nChunks * p.nCoTiles * NP * WPLANE), 0x00020000);
     // patch rows: row tid (all 16 channels) for every thread; the rows beyond NT are shared out G threads per
@@ -183,12 +188,12 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
         if (r < PSI) {
             const int py = r / PW, px = r - py * PW;
             const int yy = y0 + py - 1, xx = x0 + px - 1;
-            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) { g = 4u * (unsigned)(yy * p.W + xx); gm = 0; }
+            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) { g = ESZ * (unsigned)(yy * p.W + xx); gm = 0; }
         }
         goff[j] = g; gmask[j] = gm;
     }
     const int prow1 = NT + tid / G, q4 = tid & (G - 1);
-    const unsigned xstep = 4u * (unsigned)p.HW;
+    const unsigned xstep = ESZ * (unsigned)p.HW;
     const unsigned wblock = (unsigned)NP * WPLANE;
     const float xs = (NP == 2 && !XPK) ? uz::split_scale(uz::amax_read(p.x_amax)) : 1.f;
 
@@ -218,13 +223,18 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     //   taps 4..8  issue the packed-weight loads,
     //   taps 4..7  split the patch values that arrived (two parts each) - pure register work.
     // After the barrier only LDS writes remain.
+    // one input element (XB: the 2-byte element sits zero-extended in the low half of the register)
+    auto xload = [&](unsigned off) -> float {
+        if constexpr (XB) return __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rx, off, 0, 0));
+        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+    };
     auto patch_loads = [&](int c, int part) {
         const int k0 = c * CK;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int k = 2 * part + kk;
             const unsigned kvm = (k0 + k) < p.Cin ? 0u : 0xFFFFFFFFu;       // K tail
-            pr[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (goff[0] + (unsigned)(k0 + k) * xstep) | gmask[0] | kvm, 0, 0));
+            pr[k] = xload((goff[0] + (unsigned)(k0 + k) * xstep) | gmask[0] | kvm);
         }
     };
     auto shared_row_loads = [&](int c) {
@@ -232,7 +242,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 #pragma unroll
         for (int kk = 0; kk < CE; ++kk) {
             const unsigned kvm = (k0 + kk) < p.Cin ? 0u : 0xFFFFFFFFu;
-            pr1[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (goff[1] + (unsigned)(k0 + kk) * xstep) | gmask[1] | kvm, 0, 0));
+            pr1[kk] = xload((goff[1] + (unsigned)(k0 + kk) * xstep) | gmask[1] | kvm);
         }
     };
     auto weight_load = [&](int c, int i) {
@@ -244,6 +254,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     // staging is two byte permutes per pair instead of scale / clamp / convert / subtract / convert
     auto pair_pieces = [&](float v0, float v1, unsigned (&out)[NP]) {
         if constexpr (XPK) uz::packed_pair(__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), out[0], out[1]);
+        else if constexpr (XB) out[0] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, v1), __builtin_bit_cast(unsigned, v0), 0x05040100u);   // the two stored bf16 values, as they are
         else pieces<NP>(v0 * xs, v1 * xs, out);
     };
     auto convert = [&](int j) {              // split / round the values of k 4j .. 4j + 3 (j = 0 also the shared-row share)
@@ -408,10 +419,12 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     constexpr int Q = NT / 4;                            // float4 per channel row
     float* El = reinterpret_cast<float*>(lds);
     const bool split = p.kSplit > 1;                     // partial sums only: bias / accumulate / ReLU / bound happen in the reduce
+    const int yb = (NP == 1 && !split) ? p.yb16 : 0;     // the output tensor holds bf16 elements (offsets below are in ELEMENTS either way)
     float* const obase = split ? p.slab + (size_t)part * p.N * p.Cout * p.HW + (size_t)b0 * p.Cout * p.HW
-                               : p.y + (size_t)b0 * p.CoutTot * p.HW;
+                       : yb ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(p.y) + (size_t)b0 * p.CoutTot * p.HW)
+                            : p.y + (size_t)b0 * p.CoutTot * p.HW;
     const float* const mbase = (MK != 0 && p.mask) ? p.mask + (size_t)b0 * p.maskCtot * p.HW : nullptr;
-    const bool vec = (p.W & 3) == 0 && (reinterpret_cast<uintptr_t>(obase) & 15) == 0 && (reinterpret_cast<uintptr_t>(mbase) & 15) == 0;
+    const bool vec = (p.W & 3) == 0 && (reinterpret_cast<uintptr_t>(obase) & (yb ? 7 : 15)) == 0 && (reinterpret_cast<uintptr_t>(mbase) & 15) == 0;
     const int c4 = tid % Q, rsub = tid / Q;              // this thread's float4 column and row phase (rows rsub, rsub + 4, ...)
     const int px = 4 * c4, ty = px / TW, tx = px % TW;
     const int oy = y0 + ty, ox = x0 + tx;
@@ -433,7 +446,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
                     const int co = co0 + m * 32 + g0 * 8 + 4 * j + rsub;
                     if (co < p.Cout && rowok) {
                         const size_t off = (size_t)co * p.HW + (size_t)oy * p.W + ox;
-                        if (pre_a) pre_acc[j] = *reinterpret_cast<const f32x4*>(obase + off);
+                        if (pre_a) pre_acc[j] = uz::ld_elem4(obase, off, yb);
                         if (pre_m) pre_mk[j] = *reinterpret_cast<const f32x4*>(mbase + off);
                     }
                 }
@@ -454,7 +467,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
                 f32x4 st4 = {0.f, 0.f, -INFINITY, -INFINITY};     // BatchNorm partials of this thread's four pixels: sum, sum of squares, max, max(-y)
                 if (co < p.Cout && rowok) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(El + row * ROWF + px);
-                    float* dst = obase + (size_t)co * p.HW + (size_t)oy * p.W + ox;
+                    const size_t doff = (size_t)co * p.HW + (size_t)oy * p.W + ox;
                     if (split) {
                         v *= inv;
                     } else {
@@ -481,7 +494,11 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
                             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                             vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                         }
-                        *reinterpret_cast<f32x4*>(dst) = v;
+                        if (yb) {                           // round once: the statistics below are those of the STORED values
+                            const uint2 w2 = uz::bf16x4_pack(v);
+                            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(obase) + doff) = w2;
+                            v = uz::bf16x4_widen(w2);
+                        } else *reinterpret_cast<f32x4*>(obase + doff) = v;
                         if (MK == 2) st4 = f32x4{(v.x + v.y) + (v.z + v.w), (v.x * xh.x + v.y * xh.y) + (v.z * xh.z + v.w * xh.w),
                                                  fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))),
                                                  fmaxf(fmaxf(fabsf(xh.x), fabsf(xh.y)), fmaxf(fabsf(xh.z), fabsf(xh.w)))};
@@ -493,20 +510,21 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
                             if (ox + e < p.W) {
                                 float t = v[e];
                                 if (!split) {
-                                    if (p.accumulate) t += dst[e];
-                                    if (MK == 1 && mbase) t = mbase[(dst - obase) + e] > 0.f ? t : 0.f;
+                                    if (p.accumulate) t += uz::ld_elem(obase, doff + e, yb);
+                                    if (MK == 1 && mbase) t = mbase[doff + e] > 0.f ? t : 0.f;
                                     if (p.relu) t = fmaxf(t, 0.f);
                                     vmax = fmaxf(vmax, fabsf(t));
                                 }
                                 if (MK == 2 && mbase) {
-                                    const float yy = mbase[(dst - obase) + e];
+                                    const float yy = mbase[doff + e];
                                     if (p.mk_relu) t = fmaf(yy, p.mk_save[2 * p.Cout + co], p.mk_save[3 * p.Cout + co]) > 0.f ? t : 0.f;
                                     const float xh1 = (yy - p.mk_save[co]) * p.mk_save[p.Cout + co];
-                                    dst[e] = t;
+                                    obase[doff + e] = t;
                                     st4 = f32x4{st4.x + t, st4.y + t * xh1, fmaxf(st4.z, fabsf(t)), fmaxf(st4.w, fabsf(xh1))};
                                     continue;
                                 }
-                                dst[e] = t;
+                                if (yb) t = uz::bf16_round(t);
+                                uz::st_elem(obase, doff + e, t, yb);
                                 st4 = f32x4{st4.x + t, st4.y + t * t, fmaxf(st4.z, t), fmaxf(st4.w, -t)};
                             }
                     }
@@ -539,41 +557,45 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 // The instances as kernels of their own (attributes take literal constants only; names show up in profiles): three tile
 // geometries x {split-fp16 (fp32-accurate), single-piece bf16} x epilogue {plain, folded ReLU backward, folded BatchNorm-backward
 // reduction} x input {fp32, split storage}.
-template <int MSUB, int NTv, int TWv, int NP, int MK, bool XPK> struct SplitKernel;
-#define UZ_SPLIT_KERNEL(name, MSUB_, NT_, TW_, NP_, MK_, XPK_, OCC_)                                                     \
-    __global__ __launch_bounds__(NT_, OCC_) void name(const SP p) { conv_split_body<MSUB_, NT_, TW_, NP_, MK_, XPK_>(p); } \
-    template <> struct SplitKernel<MSUB_, NT_, TW_, NP_, MK_, XPK_> { static constexpr auto fn = name; };
+template <int MSUB, int NTv, int TWv, int NP, int MK, int XF> struct SplitKernel;
+#define UZ_SPLIT_KERNEL(name, MSUB_, NT_, TW_, NP_, MK_, XF_, OCC_)                                                     \
+    __global__ __launch_bounds__(NT_, OCC_) void name(const SP p) { conv_split_body<MSUB_, NT_, TW_, NP_, MK_, XF_>(p); } \
+    template <> struct SplitKernel<MSUB_, NT_, TW_, NP_, MK_, XF_> { static constexpr auto fn = name; };
 // (round 4: the 32-channel-tile kernels keep (512, 4) although that bound costs them ~30 spilled registers - with (512, 3), no spills
 //  but one workgroup per CU, 32 -> 32 @ 128 x 128 ran 55 -> 61 us forward and the PHiSeg step lost 0.8 %)
-UZ_SPLIT_KERNEL(conv_split_kernel_2_512_32, 2, 512, 32, 2, 0, false, 1)
-UZ_SPLIT_KERNEL(conv_split_kernel_1_512_32, 1, 512, 32, 2, 0, false, 4)
-UZ_SPLIT_KERNEL(conv_split_kernel_1_256_16, 1, 256, 16, 2, 0, false, 2)
-UZ_SPLIT_KERNEL(conv_bf16_kernel_2_512_32, 2, 512, 32, 1, 0, false, 1)
-UZ_SPLIT_KERNEL(conv_bf16_kernel_1_512_32, 1, 512, 32, 1, 0, false, 4)
-UZ_SPLIT_KERNEL(conv_bf16_kernel_1_256_16, 1, 256, 16, 1, 0, false, 3)
-UZ_SPLIT_KERNEL(conv_split_relu_kernel_2_512_32, 2, 512, 32, 2, 1, false, 1)
-UZ_SPLIT_KERNEL(conv_split_relu_kernel_1_512_32, 1, 512, 32, 2, 1, false, 4)
-UZ_SPLIT_KERNEL(conv_split_relu_kernel_1_256_16, 1, 256, 16, 2, 1, false, 2)
-UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_2_512_32, 2, 512, 32, 1, 1, false, 1)
-UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_1_512_32, 1, 512, 32, 1, 1, false, 4)
-UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_1_256_16, 1, 256, 16, 1, 1, false, 3)
+UZ_SPLIT_KERNEL(conv_split_kernel_2_512_32, 2, 512, 32, 2, 0, 0, 1)
+UZ_SPLIT_KERNEL(conv_split_kernel_1_512_32, 1, 512, 32, 2, 0, 0, 4)
+UZ_SPLIT_KERNEL(conv_split_kernel_1_256_16, 1, 256, 16, 2, 0, 0, 2)
+UZ_SPLIT_KERNEL(conv_bf16_kernel_2_512_32, 2, 512, 32, 1, 0, 0, 1)
+UZ_SPLIT_KERNEL(conv_bf16_kernel_1_512_32, 1, 512, 32, 1, 0, 0, 4)
+UZ_SPLIT_KERNEL(conv_bf16_kernel_1_256_16, 1, 256, 16, 1, 0, 0, 3)
+UZ_SPLIT_KERNEL(conv_split_relu_kernel_2_512_32, 2, 512, 32, 2, 1, 0, 1)
+UZ_SPLIT_KERNEL(conv_split_relu_kernel_1_512_32, 1, 512, 32, 2, 1, 0, 4)
+UZ_SPLIT_KERNEL(conv_split_relu_kernel_1_256_16, 1, 256, 16, 2, 1, 0, 2)
+UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_2_512_32, 2, 512, 32, 1, 1, 0, 1)
+UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_1_512_32, 1, 512, 32, 1, 1, 0, 4)
+UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_1_256_16, 1, 256, 16, 1, 1, 0, 3)
 // round 4: input in split storage (conv_splitp_*), BatchNorm-backward reduction in the data gradient's epilogue (*_bn_*)
-UZ_SPLIT_KERNEL(conv_splitp_kernel_2_512_32, 2, 512, 32, 2, 0, true, 1)
-UZ_SPLIT_KERNEL(conv_splitp_kernel_1_512_32, 1, 512, 32, 2, 0, true, 4)
-UZ_SPLIT_KERNEL(conv_splitp_kernel_1_256_16, 1, 256, 16, 2, 0, true, 3)
-UZ_SPLIT_KERNEL(conv_split_bn_kernel_2_512_32, 2, 512, 32, 2, 2, false, 1)
-UZ_SPLIT_KERNEL(conv_split_bn_kernel_1_512_32, 1, 512, 32, 2, 2, false, 4)
-UZ_SPLIT_KERNEL(conv_split_bn_kernel_1_256_16, 1, 256, 16, 2, 2, false, 2)
-UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_2_512_32, 2, 512, 32, 2, 2, true, 1)
-UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_512_32, 1, 512, 32, 2, 2, true, 4)
-UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_256_16, 1, 256, 16, 2, 2, true, 3)
+UZ_SPLIT_KERNEL(conv_splitp_kernel_2_512_32, 2, 512, 32, 2, 0, 1, 1)
+UZ_SPLIT_KERNEL(conv_splitp_kernel_1_512_32, 1, 512, 32, 2, 0, 1, 4)
+UZ_SPLIT_KERNEL(conv_splitp_kernel_1_256_16, 1, 256, 16, 2, 0, 1, 3)
+UZ_SPLIT_KERNEL(conv_split_bn_kernel_2_512_32, 2, 512, 32, 2, 2, 0, 1)
+UZ_SPLIT_KERNEL(conv_split_bn_kernel_1_512_32, 1, 512, 32, 2, 2, 0, 4)
+UZ_SPLIT_KERNEL(conv_split_bn_kernel_1_256_16, 1, 256, 16, 2, 2, 0, 2)
+UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_2_512_32, 2, 512, 32, 2, 2, 1, 1)
+UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_512_32, 1, 512, 32, 2, 2, 1, 4)
+UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_256_16, 1, 256, 16, 2, 2, 1, 3)
+// bf16 STORAGE of the input (the volume path, planes wider than 32): 2-byte patch loads, no conversion while staging
+UZ_SPLIT_KERNEL(conv_b16_kernel_2_512_32, 2, 512, 32, 1, 0, 2, 1)
+UZ_SPLIT_KERNEL(conv_b16_kernel_1_512_32, 1, 512, 32, 1, 0, 2, 4)
+UZ_SPLIT_KERNEL(conv_b16_kernel_1_256_16, 1, 256, 16, 1, 0, 2, 3)
 #undef UZ_SPLIT_KERNEL
 
-template <int MSUB, int NTv, int TWv, int NP, int MK, bool XPK>
+template <int MSUB, int NTv, int TWv, int NP, int MK, int XF>
 int launch_one(const SP& p, int grid, hipStream_t st) {
     constexpr size_t smem = lds_bytes<MSUB, NTv, TWv, NP>();
     static bool attr_done = false;
-    auto kern = SplitKernel<MSUB, NTv, TWv, NP, MK, XPK>::fn;
+    auto kern = SplitKernel<MSUB, NTv, TWv, NP, MK, XF>::fn;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return uz::fail("conv_split: cannot raise dynamic LDS limit");
@@ -584,17 +606,22 @@ int launch_one(const SP& p, int grid, hipStream_t st) {
 }
 // mk: 0 plain, 1 folded ReLU backward, 2 folded BatchNorm-backward reduction; xpk: input in split storage (two-piece mode only)
 template <int MSUB, int NTv, int TWv, int NP>
-int launch(const SP& p, int grid, hipStream_t st, int mk, int xpk) {
+int launch(const SP& p, int grid, hipStream_t st, int mk, int xpk, int xb16) {
     if constexpr (NP == 2) {
+        if (xb16 || p.yb16) return uz::fail("conv_split: bf16 storage needs the single-piece bf16 mode (uz_set_conv_math(3))");
         if (xpk) {
             if (mk == 1) return uz::fail("conv_split: the folded ReLU backward takes an fp32 gradient");
-            return mk == 2 ? launch_one<MSUB, NTv, TWv, 2, 2, true>(p, grid, st) : launch_one<MSUB, NTv, TWv, 2, 0, true>(p, grid, st);
+            return mk == 2 ? launch_one<MSUB, NTv, TWv, 2, 2, 1>(p, grid, st) : launch_one<MSUB, NTv, TWv, 2, 0, 1>(p, grid, st);
         }
-        if (mk == 2) return launch_one<MSUB, NTv, TWv, 2, 2, false>(p, grid, st);
+        if (mk == 2) return launch_one<MSUB, NTv, TWv, 2, 2, 0>(p, grid, st);
     } else {
         if (xpk || mk == 2) return uz::fail("conv_split: split storage / the folded BatchNorm reduction need the two-piece fp16 mode");
+        if (xb16) {
+            if (mk != 0) return uz::fail("conv_split: bf16 storage of the input has no folded-ReLU instance");
+            return launch_one<MSUB, NTv, TWv, 1, 0, 2>(p, grid, st);
+        }
     }
-    return mk == 1 ? launch_one<MSUB, NTv, TWv, NP, 1, false>(p, grid, st) : launch_one<MSUB, NTv, TWv, NP, 0, false>(p, grid, st);
+    return mk == 1 ? launch_one<MSUB, NTv, TWv, NP, 1, 0>(p, grid, st) : launch_one<MSUB, NTv, TWv, NP, 0, 0>(p, grid, st);
 }
 
 // tile geometry of a layer: 16 x 32 tiles (512 threads, 64- or 32-channel tiles) when the plane is wider than 32,
@@ -807,6 +834,8 @@ static int conv_split_impl(const float* x, int Kc, int KcTot, const float* w, in
     p.stamps = uz::debug_stamps;
     p.flags = dev_flags_ptr(); p.flag_bit = dgrad ? FLAG_DY_BOUND : FLAG_X_BOUND;
     p.bnpart = bn_partials;
+    p.yb16 = o.y_b16;
+    UZ_REQUIRE(!(o.x_b16 || o.y_b16) || (np == 1 && p.kSplit == 1 && !relu_mask), "conv_split: bf16 storage needs the single-piece bf16 mode, an unsplit chunk loop and a plain epilogue");
     const long long grid = (long long)p.tilesX * p.tilesY * N * p.nCoTiles * p.kSplit;
     UZ_REQUIRE(grid < (1ll << 31), "conv_split: grid too large");
     // per-image buffer resources and 64-bit output addressing: only ONE image's input view has to fit 32-bit byte offsets
@@ -823,11 +852,11 @@ static int conv_split_impl(const float* x, int Kc, int KcTot, const float* w, in
     if (int rc = check_launch("pack_weights_kernel")) return rc;
     int rc;
     if (np == 2) {
-        if (tw == 16) rc = launch<1, 256, 16, 2>(p, (int)grid, st, o.mk, o.x_packed);
-        else rc = cot == 32 ? launch<1, 512, 32, 2>(p, (int)grid, st, o.mk, o.x_packed) : launch<2, 512, 32, 2>(p, (int)grid, st, o.mk, o.x_packed);
+        if (tw == 16) rc = launch<1, 256, 16, 2>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16);
+        else rc = cot == 32 ? launch<1, 512, 32, 2>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16) : launch<2, 512, 32, 2>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16);
     } else {
-        if (tw == 16) rc = launch<1, 256, 16, 1>(p, (int)grid, st, o.mk, o.x_packed);
-        else rc = cot == 32 ? launch<1, 512, 32, 1>(p, (int)grid, st, o.mk, o.x_packed) : launch<2, 512, 32, 1>(p, (int)grid, st, o.mk, o.x_packed);
+        if (tw == 16) rc = launch<1, 256, 16, 1>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16);
+        else rc = cot == 32 ? launch<1, 512, 32, 1>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16) : launch<2, 512, 32, 1>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16);
     }
     if (rc || p.kSplit == 1) return rc;
     return splitk_reduce(p.slab, p.kSplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax, st);
@@ -871,6 +900,14 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const long long* __restri
 }
 }  // namespace
 
+// Number of workgroups the matrix-pipe kernel shares one tile's chunk loop out over (kind 0 forward, 1 data gradient); > 1: partial
+// sums go through fp32 slabs and a reduce launch - such shapes have no bf16-storage form (uz_conv_fwd_b16 / uz_conv_bwd_data_b16)
+extern "C" int uz_conv_split_parts(int kind, int Cin, int Cout, int N, int H, int W) {
+    const int Kc = kind == 1 ? Cout : Cin, Mc = kind == 1 ? Cin : Cout;
+    const int nChunks = uz::ceil_div(Kc, CK);
+    const int S = uz::split_parts(Kc, Mc, N, H, W);
+    return uz::ceil_div(nChunks, uz::ceil_div(nChunks, S));
+}
 extern "C" size_t uz_conv_packed_bytes(int Cin, int Cout, int W, int dgrad) {
     return dgrad ? uz::image_bytes(Cout, Cin, W) : uz::image_bytes(Cin, Cout, W);
 }

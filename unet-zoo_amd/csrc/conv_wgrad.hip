@@ -683,10 +683,33 @@ extern "C" int uz_conv_bwd_weight(const float* x, int Cin, int CinTot, const flo
 }
 // ... with either operand in split storage (include/uz_api.h, round 4): only on the split-fp16 path, bias gradient not available
 // (db reads dy as fp32).
+static int conv_bwd_weight_impl(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
+                                float* dw, float* db, int N, int H, int W, int ks,
+                                const float* x_amax, const float* dy_amax, void* workspace, size_t workspace_bytes,
+                                int x_packed, const float* x_amax2, int seg_channels, int dy_packed, float* slabs_out, void* stream,
+                                int x_b16, int dy_b16);
 extern "C" int uz_conv_bwd_weight_ex(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
                                      float* dw, float* db, int N, int H, int W, int ks,
                                      const float* x_amax, const float* dy_amax, void* workspace, size_t workspace_bytes,
                                      int x_packed, const float* x_amax2, int seg_channels, int dy_packed, float* slabs_out, void* stream) {
+    return conv_bwd_weight_impl(x, Cin, CinTot, dy, Cout, CoutTot, dw, db, N, H, W, ks, x_amax, dy_amax, workspace, workspace_bytes,
+                                x_packed, x_amax2, seg_channels, dy_packed, slabs_out, stream, 0, 0);
+}
+// bf16 STORAGE (include/uz_api.h, "bf16 storage"): x and / or dy hold 2-byte bf16 elements; single-piece bf16 mode, 3x3 shapes on the
+// matrix-pipe path with rows a multiple of 32 wide; the gradient itself stays fp32 (fp32 accumulation, fp32 slabs, ordered reduce).
+extern "C" int uz_conv_bwd_weight_b16(const void* x, int Cin, int CinTot, const void* dy, int Cout, int CoutTot,
+                                      float* dw, int N, int H, int W, int ks, void* workspace, size_t workspace_bytes,
+                                      int x_b16, int dy_b16, float* slabs_out, void* stream) {
+    UZ_REQUIRE(uz::conv_np() == 1 && ks == 3 && W % 32 == 0 && uz_conv_route(2, Cin, Cout, N, H, W, ks) == 1,
+               "conv_bwd_weight_b16: bf16 storage needs uz_set_conv_math(3), a 3x3 shape on the matrix-pipe path and rows a multiple of 32 wide");
+    return conv_bwd_weight_impl(static_cast<const float*>(x), Cin, CinTot, static_cast<const float*>(dy), Cout, CoutTot, dw, nullptr, N, H, W, ks,
+                                nullptr, nullptr, workspace, workspace_bytes, 0, nullptr, 0, 0, slabs_out, stream, x_b16 != 0, dy_b16 != 0);
+}
+static int conv_bwd_weight_impl(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot,
+                                float* dw, float* db, int N, int H, int W, int ks,
+                                const float* x_amax, const float* dy_amax, void* workspace, size_t workspace_bytes,
+                                int x_packed, const float* x_amax2, int seg_channels, int dy_packed, float* slabs_out, void* stream,
+                                int x_b16, int dy_b16) {
     UZ_REQUIRE(ks == 1 || ks == 3, "conv_bwd_weight: kernel size %d unsupported", ks);
     // slabs_out: the call stops behind its main kernel and leaves its uz_conv_bwd_weight_slabs() partial-sum slabs [S][ks*ks][Cout][Cin]
     // there; uz_wgrad_reduce_table adds the slabs of MANY layers in one launch (the plans: one at the end of the backward tape
@@ -743,18 +766,19 @@ extern "C" int uz_conv_bwd_weight_ex(const float* x, int Cin, int CinTot, const 
     UZ_REQUIRE(!(huge && g.fast), "conv_bwd_weight: a channel-slice view of a buffer of 2^30 elements or more is not supported by the tiled kernels");
     const bool split_math = !thin && !huge && uz::wgrad_split_ok(Cin, Cout, N, H, W, ks);
     UZ_REQUIRE(!any_packed || split_math, "conv_bwd_weight_ex: split storage on a call that left the split-fp16 path");
+    UZ_REQUIRE(!(x_b16 || dy_b16) || (split_math && !db), "conv_bwd_weight_b16: bf16 storage on a call that left the matrix-pipe path");
     if (split_math) {                              // large layers: split-fp16 matrix pipe (conv_wgrad_split.hip), same slab layout
         Stot = uz::wgrad_split_splits(Cin, Cout, N, H, W);
         const size_t slab_bytes = (size_t)Stot * 9 * Cout * Cin * sizeof(float);
         constexpr size_t slot_bytes = uz::AMAX_FLOATS * sizeof(float);
         UZ_REQUIRE(workspace_bytes >= slab_bytes + 2 * slot_bytes, "conv_bwd_weight: workspace too small for the split path");
-        if (!x_amax || !dy_amax) {             // no bounds from the caller: measure them (stand-alone C-ABI path)
+        if (uz::conv_np() == 2 && (!x_amax || !dy_amax)) {             // no bounds from the caller: measure them (stand-alone C-ABI path; the bf16 mode has no scales)
             float* slots = reinterpret_cast<float*>(static_cast<char*>(workspace) + slab_bytes);
             if (hipMemsetAsync(slots, 0, 2 * slot_bytes, st) != hipSuccess) return uz::fail("conv_bwd_weight: memset failed");
             if (!x_amax) { if (int rc = uz::absmax_view(x, Cin, CinTot, N, H * W, slots, st)) return rc; x_amax = slots; }
             if (!dy_amax) { if (int rc = uz::absmax_view(dy, Cout, CoutTot, N, H * W, slots + uz::AMAX_FLOATS, st)) return rc; dy_amax = slots + uz::AMAX_FLOATS; }
         }
-        if (int rc = uz::wgrad_split(x, Cin, CinTot, dy, Cout, CoutTot, p.slab, N, H, W, Stot, x_amax, dy_amax, st, x_packed, x_amax2, seg_channels, dy_packed)) return rc;
+        if (int rc = uz::wgrad_split(x, Cin, CinTot, dy, Cout, CoutTot, p.slab, N, H, W, Stot, x_amax, dy_amax, st, x_packed, x_amax2, seg_channels, dy_packed, x_b16, dy_b16)) return rc;
     }
 #define UZ_WG_LAUNCH(KS_, WM_, WN_, PF_)                                                                         \
     do {                                                                                                         \

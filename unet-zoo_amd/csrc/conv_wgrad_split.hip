@@ -65,9 +65,14 @@ struct WS {
 
 // CT = channel tile on both sides: 64 (waves = co half x ci half x tap group) or 32 (waves = pixel quarter x tap
 // group; the four pixel quarters are folded through LDS at the end; 74 KB of LDS -> two workgroups per CU)
-template <int TWv, int CT, int NP, bool XPK = false, bool DPK = false>
+// XF / DF = storage format of X / dY: 0 fp32 values, 1 split storage (two fp16 pieces per word, NP == 2), 2 bf16 storage (2-byte
+// elements, NP == 1: staged as they are - no conversion, half the bytes)
+template <int TWv, int CT, int NP, int XF = 0, int DF = 0>
 __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
+    constexpr bool XPK = XF == 1, DPK = DF == 1, XB = XF == 2, DB = DF == 2;
+    constexpr unsigned XE = XB ? 2u : 4u, DE = DB ? 2u : 4u;      // bytes per element
     static_assert(NP == 2 || (!XPK && !DPK), "split storage is the two-piece fp16 format");
+    static_assert(NP == 1 || (!XB && !DB), "bf16 storage feeds the single-piece bf16 mode");
     using GEO = WGeo<TWv>;
     constexpr int TW = GEO::TW, TH = GEO::TH, XROW = GEO::XROW, QROWX = GEO::QROWX, PROWS = GEO::PROWS;
     constexpr int QROW = TW / 4, SROW = TW / 16;          // float4 quads / 16-pixel k-steps per tile row
@@ -96,9 +101,9 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
     for (int i = tid * 16; i < NP * DYPLANE + NP * XPLANE; i += NT * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0u, 0u, 0u, 0u};
 
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.dy), 0, (unsigned)(((size_t)(p.N - 1) * p.CoutTot + p.Cout) * p.HW * sizeof(float)), 0x00020000);
+        const_cast<float*>(p.dy), 0, (unsigned)(((size_t)(p.N - 1) * p.CoutTot + p.Cout) * p.HW * DE), 0x00020000);
     const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x), 0, (unsigned)(((size_t)(p.N - 1) * p.CinTot + p.Cin) * p.HW * sizeof(float)), 0x00020000);
+        const_cast<float*>(p.x), 0, (unsigned)(((size_t)(p.N - 1) * p.CinTot + p.Cin) * p.HW * XE), 0x00020000);
 
     // ---- staging maps
     // dY: float4 e = tid + i * 512 -> co = e / 32, quad q = e % 32 (row q / QROW, columns 4 (q % QROW) ..); the
@@ -113,13 +118,16 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
     auto gload = [&](int t, int part) __attribute__((always_inline)) {
         const int txi = t % p.tilesX, t2 = t / p.tilesX;
         const int x0 = txi * TW, y0 = (t2 % p.tilesY) * TH, b0 = t2 / p.tilesY;
-        const unsigned dbase = 4u * (unsigned)((b0 * p.CoutTot + co0) * p.HW + y0 * p.W + x0);
+        const unsigned dbase = DE * (unsigned)((b0 * p.CoutTot + co0) * p.HW + y0 * p.W + x0);
 #pragma unroll
         for (int i = 0; i < DYSLOTS; ++i) {
             if (part >= 0 && i % NPARTS != part % NPARTS) continue;
             const int e = tid + i * NT, co = e >> 5, q = e & 31, row = q / QROW, c4 = (q % QROW) * 4;
             const unsigned m = ((y0 + row) < p.H && (co0 + co) < p.Cout) ? 0u : 0xFFFFFFFFu;      // all-ones: the range check returns 0
-            dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (dbase + 4u * (unsigned)(co * p.HW + row * p.W + c4)) | m, 0, 0));
+            if constexpr (DB) {                         // four bf16 pixels: 8 bytes, staged as they are
+                const uz::f32x2 t = __builtin_bit_cast(uz::f32x2, __builtin_amdgcn_raw_buffer_load_b64(rdy, (dbase + DE * (unsigned)(co * p.HW + row * p.W + c4)) | m, 0, 0));
+                dreg[i][0] = t.x; dreg[i][1] = t.y;
+            } else dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (dbase + DE * (unsigned)(co * p.HW + row * p.W + c4)) | m, 0, 0));
         }
         // X patch: a quad slot is 4 consecutive patch pixels of one row (patch pixels 4 q .. 4 q + 3 = image columns x0 - 1 + 4 q ..):
         // one 16-byte load (dword aligned; a wave's lanes read one contiguous run) whose LDS image is one aligned 8-byte store per
@@ -136,7 +144,10 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             const int sh = (q == 0 && x0 == 0) ? 1 : 0;           // image column -1: load columns 0..3 and shift (never reads before the row)
             const int off = xbase + ci * p.HW + (prow - 1) * p.W + 4 * q - 1 + sh;
             // (the shift itself happens in lstore: a use of the loaded value here would wait for the load inside the MFMA loop)
-            xq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxx, rowok ? 4u * (unsigned)off : 0xFFFFFFFFu, 0, 0));
+            if constexpr (XB) {                         // (a 2-byte aligned 8-byte load: the quad starts at an odd column)
+                const uz::f32x2 t = __builtin_bit_cast(uz::f32x2, __builtin_amdgcn_raw_buffer_load_b64(rxx, rowok ? XE * (unsigned)off : 0xFFFFFFFFu, 0, 0));
+                xq[i][0] = t.x; xq[i][1] = t.y;
+            } else xq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxx, rowok ? XE * (unsigned)off : 0xFFFFFFFFu, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < XPSLOTS; ++i) {
@@ -146,8 +157,13 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             const int yy = y0 + prow - 1;
             const bool rowok = e < CIT * PROWS && (ci0 + ci) < p.Cin && yy >= 0 && yy < p.H;
             const int off = xbase + ci * p.HW + (prow - 1) * p.W + TW - 1;        // image columns x0 + TW - 1 (inside the image) and x0 + TW
-            xp[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, rowok ? 4u * (unsigned)off : 0xFFFFFFFFu, 0, 0));
-            xp[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (rowok && x0 + TW < p.W) ? 4u * (unsigned)(off + 1) : 0xFFFFFFFFu, 0, 0));
+            if constexpr (XB) {
+                xp[i][0] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rxx, rowok ? XE * (unsigned)off : 0xFFFFFFFFu, 0, 0));
+                xp[i][1] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rxx, (rowok && x0 + TW < p.W) ? XE * (unsigned)(off + 1) : 0xFFFFFFFFu, 0, 0));
+            } else {
+                xp[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, rowok ? 4u * (unsigned)off : 0xFFFFFFFFu, 0, 0));
+                xp[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (rowok && x0 + TW < p.W) ? 4u * (unsigned)(off + 1) : 0xFFFFFFFFu, 0, 0));
+            }
         }
     };
     const float sdy = NP == 2 ? uz::split_scale(uz::amax_read(p.dy_amax)) : 1.f, sx = NP == 2 ? uz::split_scale(uz::amax_read(p.x_amax)) : 1.f;
@@ -165,8 +181,11 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
 #pragma unroll
         for (int i = 0; i < DYSLOTS; ++i) {
             unsigned pa[NP], pb[NP];
-            dpieces(dreg[i][0], dreg[i][1], pa);
-            dpieces(dreg[i][2], dreg[i][3], pb);
+            if constexpr (DB) { pa[0] = uz::fbits(dreg[i][0]); pb[0] = uz::fbits(dreg[i][1]); }
+            else {
+                dpieces(dreg[i][0], dreg[i][1], pa);
+                dpieces(dreg[i][2], dreg[i][3], pb);
+            }
             const int e = tid + i * NT, co = e >> 5, q = e & 31;
             char* d = dYl + co * DYROW + ((q / QROW) * TW + (q % QROW) * 4) * 2;
 #pragma unroll
@@ -178,9 +197,16 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             if (e < CIT * PROWS * QROWX) {
                 const int q = e % QROWX, r = e / QROWX, ci = r / PROWS, prow = r - ci * PROWS;
                 unsigned pa[NP], pb[NP];
-                const f32x4 v = (left_edge && q == 0) ? f32x4{0.f, xq[i][0], xq[i][1], xq[i][2]} : xq[i];
-                xpieces(v[0], v[1], pa);
-                xpieces(v[2], v[3], pb);
+                if constexpr (XB) {
+                    const unsigned w0 = uz::fbits(xq[i][0]), w1 = uz::fbits(xq[i][1]);
+                    const bool sh = left_edge && q == 0;          // columns 0..2 were loaded into pixels 0..2: move them to pixels 1..3, pixel 0 = padding
+                    pa[0] = sh ? w0 << 16 : w0;
+                    pb[0] = sh ? __builtin_amdgcn_alignbit(w1, w0, 16) : w1;
+                } else {
+                    const f32x4 v = (left_edge && q == 0) ? f32x4{0.f, xq[i][0], xq[i][1], xq[i][2]} : xq[i];
+                    xpieces(v[0], v[1], pa);
+                    xpieces(v[2], v[3], pb);
+                }
                 char* d = Xl + ci * XCH + prow * XROW + q * 8;
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * XPLANE) = make_uint2(pa[pl], pb[pl]);
@@ -192,7 +218,8 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
             if (e < CIT * PROWS) {
                 const int ci = e / PROWS, prow = e - ci * PROWS;
                 unsigned pa[NP];
-                xpieces(xp[i][0], xp[i][1], pa);
+                if constexpr (XB) pa[0] = __builtin_bit_cast(unsigned, xp[i][0]) | (__builtin_bit_cast(unsigned, xp[i][1]) << 16);
+                else xpieces(xp[i][0], xp[i][1], pa);
                 char* d = Xl + ci * XCH + prow * XROW + QROWX * 8;
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<unsigned*>(d + pl * XPLANE) = pa[pl];
@@ -380,7 +407,7 @@ int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
     return s;
 }
 
-template <int TWv, int CT, int NP, bool XPK = false, bool DPK = false>
+template <int TWv, int CT, int NP, int XPK = 0, int DPK = 0>
 static int launch_wgrad_np(const WS& p, int grid, hipStream_t st) {
     // (the 32-channel kernel folds its pixel quarters through this LDS at the end: three taps x 16 x 64 floats per wave pair)
     constexpr size_t stage = NP * (size_t)(CT * DYROW) + NP * (size_t)(CT * XCH), fold = CT == 32 ? (size_t)4 * 3 * 16 * 64 * 4 : 0;
@@ -395,18 +422,23 @@ static int launch_wgrad_np(const WS& p, int grid, hipStream_t st) {
     return check_launch("wgrad_split_kernel");
 }
 template <int TWv, int CT>
-static int launch_wgrad(const WS& p, int grid, hipStream_t st, int xpk, int dpk) {
+static int launch_wgrad(const WS& p, int grid, hipStream_t st, int xpk, int dpk, int xb16, int db16) {
     if (conv_np() != 2) {
         if (xpk || dpk) return fail("wgrad_split: split storage needs the two-piece fp16 mode");
+        if constexpr (TWv == 32) {
+            if (xb16) return db16 ? launch_wgrad_np<TWv, CT, 1, 2, 2>(p, grid, st) : launch_wgrad_np<TWv, CT, 1, 2, 0>(p, grid, st);
+            if (db16) return launch_wgrad_np<TWv, CT, 1, 0, 2>(p, grid, st);
+        } else if (xb16 || db16) return fail("wgrad_split: bf16 storage serves planes whose width is a multiple of 32");
         return launch_wgrad_np<TWv, CT, 1>(p, grid, st);
     }
-    if (xpk) return dpk ? launch_wgrad_np<TWv, CT, 2, true, true>(p, grid, st) : launch_wgrad_np<TWv, CT, 2, true, false>(p, grid, st);
-    return dpk ? launch_wgrad_np<TWv, CT, 2, false, true>(p, grid, st) : launch_wgrad_np<TWv, CT, 2, false, false>(p, grid, st);
+    if (xb16 || db16) return fail("wgrad_split: bf16 storage needs the single-piece bf16 mode");
+    if (xpk) return dpk ? launch_wgrad_np<TWv, CT, 2, 1, 1>(p, grid, st) : launch_wgrad_np<TWv, CT, 2, 1, 0>(p, grid, st);
+    return dpk ? launch_wgrad_np<TWv, CT, 2, 0, 1>(p, grid, st) : launch_wgrad_np<TWv, CT, 2, 0, 0>(p, grid, st);
 }
 
 int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* slab,
                 int N, int H, int W, int S, const float* x_amax, const float* dy_amax, hipStream_t st,
-                int x_packed, const float* x_amax2, int seg_channels, int dy_packed) {
+                int x_packed, const float* x_amax2, int seg_channels, int dy_packed, int x_b16, int dy_b16) {
     WS p;
     p.x_amax2 = (x_packed && seg_channels > 0) ? x_amax2 : nullptr; p.seg_channels = seg_channels;
     UZ_REQUIRE(!x_packed || seg_channels == 0 || (x_amax2 && seg_channels < Cin), "wgrad_split: the second scale segment needs its bound");
@@ -417,8 +449,8 @@ int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, 
     p.nCoT = ceil_div(Cout, ct); p.nCiT = ceil_div(Cin, ct);
     UZ_REQUIRE((size_t)N * CinTot * p.HW < (1ull << 30) && (size_t)N * CoutTot * p.HW < (1ull << 30), "wgrad_split: tensor too large for 32-bit offsets (the dispatcher routes such tensors to the fp32 kernel)");
     const int grid = p.nCoT * p.nCiT * S;
-    if (ct == 32) return tw == 16 ? launch_wgrad<16, 32>(p, grid, st, x_packed, dy_packed) : launch_wgrad<32, 32>(p, grid, st, x_packed, dy_packed);
-    return tw == 16 ? launch_wgrad<16, 64>(p, grid, st, x_packed, dy_packed) : launch_wgrad<32, 64>(p, grid, st, x_packed, dy_packed);
+    if (ct == 32) return tw == 16 ? launch_wgrad<16, 32>(p, grid, st, x_packed, dy_packed, x_b16, dy_b16) : launch_wgrad<32, 32>(p, grid, st, x_packed, dy_packed, x_b16, dy_b16);
+    return tw == 16 ? launch_wgrad<16, 64>(p, grid, st, x_packed, dy_packed, x_b16, dy_b16) : launch_wgrad<32, 64>(p, grid, st, x_packed, dy_packed, x_b16, dy_b16);
 }
 
 }  // namespace uz

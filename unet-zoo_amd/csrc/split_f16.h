@@ -78,6 +78,36 @@ __device__ __forceinline__ void packed_pair(unsigned w0, unsigned w1, unsigned& 
     p2 = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
 }
 
+// ---- bf16 storage (round 4, the volume path: BASELINE config 5).  A tensor kept as bf16 has the same NCHW shape with 2-byte
+// elements; values are rounded to nearest even when they are written (v_cvt_pk_bf16_f32) and widened exactly when they are read.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// bits of a float passed BY VALUE.  (__builtin_bit_cast applied directly to an element of an ext_vector - v[1], v.y - reads element 0
+// with this compiler: it copies from the vector's base address.  Going through a by-value parameter reads the right element.)
+__device__ __forceinline__ unsigned fbits(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2_t)); }
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
+__device__ __forceinline__ float bf16_round(float v) { return bf16_lo(pack_bf16x2(v, 0.f) & 0xFFFFu); }
+__device__ __forceinline__ f32x4 bf16x4_widen(uint2 w) { return f32x4{bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y)}; }
+__device__ __forceinline__ uint2 bf16x4_pack(f32x4 v) { return make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+// element e of a tensor stored as fp32 (b16 == 0) or bf16 (b16 != 0) behind the same pointer type
+__device__ __forceinline__ float ld_elem(const float* base, size_t e, int b16) {
+    return b16 ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(base)[e] << 16) : base[e];
+}
+__device__ __forceinline__ void st_elem(float* base, size_t e, float v, int b16) {
+    if (b16) reinterpret_cast<unsigned short*>(base)[e] = (unsigned short)(pack_bf16x2(v, 0.f) & 0xFFFFu);
+    else base[e] = v;
+}
+// four consecutive elements starting at element e (e % 4 == 0, row 16-byte / 8-byte aligned)
+__device__ __forceinline__ f32x4 ld_elem4(const float* base, size_t e, int b16) {
+    if (b16) return bf16x4_widen(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + e));
+    return *reinterpret_cast<const f32x4*>(base + e);
+}
+__device__ __forceinline__ void st_elem4(float* base, size_t e, f32x4 v, int b16) {
+    if (b16) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + e) = bf16x4_pack(v);
+    else *reinterpret_cast<f32x4*>(base + e) = v;
+}
+
 // ---- magnitude-bound slots.  A slot is AMAX_SUB sub-slots AMAX_STRIDE floats (64 bytes) apart; its value is the maximum
 // over the sub-slots.  Same-address float atomics serialise at the memory side (MI355X_MICROARCH.md, Global float atomics:
 // every workgroup into one row is 14x slower), so producers (a) spread their updates over the sub-slots and (b) read the

@@ -105,6 +105,8 @@ static int run_one(const uz_op& o, void* st) {
 #define CFP(k) static_cast<const float*>(p[k])
     switch (o.code) {
         case UZ_OP_CONV_FWD:
+            // i[13]: bf16 STORAGE bits (Plan._b16_pass) - bit 0 = x, bit 1 = y hold 2-byte bf16 elements
+            if (i[13]) return uz_conv_fwd_b16(p[0], i[0], i[1], CFP(1), CFP(2), p[3], i[2], i[3], i[4], i[5], i[6], i[7], p[4], (size_t)o.n, p[8], FP(9), i[13] & 1, (i[13] >> 1) & 1, st);
             if (i[9]) return uz_conv_fwd_slabs(CFP(0), i[0], i[1], CFP(1), i[2], i[4], i[5], i[6], i[7], p[4], (size_t)o.n, st);      // the unit's BatchNorm adds the slabs
             // i[10] = input in split storage, p[10] / i[11] = bound and first channel of its second scale segment
             return uz_conv_fwd_ex(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(5), CFP(6), FP(7), p[4], (size_t)o.n, p[8], FP(9),
@@ -112,6 +114,7 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_CONV_BWD_DATA:
             // i[10]: fold of the unit that produced the output's forward twin - 1 ReLU mask (p[7] = its activation), 2 BatchNorm-backward
             // reduction (p[7] = its pre-normalisation output, p[10] = its statistics table, i[12] = its relu flag); i[11] = dy in split storage
+            if (i[13]) return uz_conv_bwd_data_b16(p[0], i[0], i[1], CFP(1), p[2], i[2], i[3], i[4], i[5], i[6], i[7], i[8], p[3], (size_t)o.n, p[6], i[13] & 1, (i[13] >> 1) & 1, st);      // bit 0 = dy, bit 1 = dx in bf16 storage
             if (i[10] == 3) return uz_conv_bwd_data_slabs(CFP(0), i[0], i[1], CFP(1), i[2], i[4], i[5], i[6], i[7], FP(7), st);      // slabs only: the consumer's BatchNorm backward adds them
             if (i[10] == 1) return uz_conv_bwd_data_relu(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], CFP(7), i[9], FP(8), FP(9), st);
             return uz_conv_bwd_data_ex(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], i[11],
@@ -119,9 +122,11 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_CONV_BWD_WEIGHT:
             // i[8] = x in split storage, p[7] / i[9] = second scale segment of x, i[10] = dy in split storage
             // i[11]: slabs only, into p[8] (added by UZ_OP_WGRAD_REDUCE_TABLE at the end of the tape)
+            if (i[13]) return uz_conv_bwd_weight_b16(p[0], i[0], i[1], p[1], i[2], i[3], FP(2), i[4], i[5], i[6], i[7], p[4], (size_t)o.n, i[13] & 1, (i[13] >> 1) & 1, i[11] ? FP(8) : nullptr, st);      // bit 0 = x, bit 1 = dy in bf16 storage
             return uz_conv_bwd_weight_ex(CFP(0), i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], i[7], CFP(5), CFP(6), p[4], (size_t)o.n,
                                          i[8], CFP(7), i[9], i[10], i[11] ? FP(8) : nullptr, st);
         case UZ_OP_BN_RELU_FWD:
+            if (i[13]) return uz_bn_relu_fwd_b16(p[0], i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), p[6], i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], p[7], CFP(9), i[8], i[13] & 1, (i[13] >> 1) & 1, st);      // bit 0 = y, bit 1 = a in bf16 storage
             if (i[9] > 1) return uz_bn_relu_fwd_slabs(CFP(10), i[9], CFP(11), FP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], FP(8), st);
             // (save holds 4 C floats in plans; i[10] = write the activation as split storage)
             return uz_bn_relu_fwd_ex(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], FP(8), p[7], CFP(9), i[8], i[10], st);
@@ -129,6 +134,7 @@ static int run_one(const uz_op& o, void* st) {
             // p[11] / i[8] = reduction partials left by the data gradient that wrote dA last, i[9] = write dy as split storage
             // i[10]: p[8] holds the rows for the conv-bias gradient's partial sums instead of the gradient itself (added by UZ_OP_CHAN_SUM_TABLE)
             // i[11] > 0: p[11] holds that many split-K slabs of dA left by the data gradient (small planes) instead of reduction partials
+            if (i[13]) return uz_bn_relu_bwd_b16(p[0], i[0], p[1], i[1], i[2], CFP(2), CFP(3), CFP(4), p[5], i[3], FP(6), FP(7), FP(8), i[4], i[5], i[6], i[7], p[9], i[13] & 1, (i[13] >> 1) & 1, (i[13] >> 2) & 1, st);      // bits: dA, y, dy
             return uz_bn_relu_bwd_ex(CFP(0), i[0], CFP(1), i[1], i[2], CFP(2), CFP(3), CFP(4), FP(5), i[3], FP(6), FP(7), i[10] ? nullptr : FP(8), i[4], i[5], i[6], i[7], FP(10), p[9],
                                      i[11] ? nullptr : CFP(11), i[8], i[9], i[10] ? static_cast<double*>(p[8]) : nullptr, i[11] ? CFP(11) : nullptr, i[11], st);
         case UZ_OP_RELU_BWD:
@@ -200,12 +206,16 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_W3D_PERMUTE:
             return uz_w3d_permute(CFP(0), FP(1), i[0], i[1], i[2], st);
         case UZ_OP_AVGPOOL3D_FWD:
+            if (i[13]) return uz_avgpool3d_fwd_b16(p[0], i[0], i[1], p[1], i[2], i[3], i[4], i[5], i[13] & 1, (i[13] >> 1) & 1, st);
             return uz_avgpool3d_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], st);
         case UZ_OP_AVGPOOL3D_BWD:
+            if (i[13]) return uz_avgpool3d_bwd_b16(p[0], i[0], i[1], p[1], i[2], i[3], i[4], i[5], i[6], i[13] & 1, (i[13] >> 1) & 1, st);
             return uz_avgpool3d_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], st);
         case UZ_OP_DEPTH_LERP_FWD:
+            if (i[13]) return uz_depth_lerp2x_fwd_b16(p[0], i[0], i[1], p[1], i[2], i[3], i[4], i[5], i[13] & 1, (i[13] >> 1) & 1, st);
             return uz_depth_lerp2x_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], st);
         case UZ_OP_DEPTH_LERP_BWD:
+            if (i[13]) return uz_depth_lerp2x_bwd_b16(p[0], i[0], i[1], p[1], i[2], i[3], i[4], i[5], i[6], i[13] & 1, (i[13] >> 1) & 1, st);
             return uz_depth_lerp2x_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], st);
         case UZ_OP_NEAREST3D_FWD:
             return uz_nearest3d_fwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], i[7], st);

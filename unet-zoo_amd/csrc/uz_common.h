@@ -73,6 +73,8 @@ struct SplitOpts {
     const float* mask = nullptr; int maskCtot = 0;
     const float* mk_save = nullptr;         // mk == 2: [4][C] {mean, rstd, alpha, beta'} of the producing unit (uz_bn_relu_fwd_ex)
     int mk_relu = 1;
+    // bf16 STORAGE (single-piece bf16 mode only, unsplit chunk loops): the input operand / the output tensor hold 2-byte bf16 elements
+    int x_b16 = 0, y_b16 = 0;
 };
 int conv_split_ex(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                   float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
@@ -88,17 +90,18 @@ bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks);
 int wgrad_split_splits(int Cin, int Cout, int N, int H, int W);
 int wgrad_split(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* slab,
                 int N, int H, int W, int S, const float* x_amax, const float* dy_amax, hipStream_t st,
-                int x_packed = 0, const float* x_amax2 = nullptr, int seg_channels = 0, int dy_packed = 0);      // *_packed: operand in split storage
+                int x_packed = 0, const float* x_amax2 = nullptr, int seg_channels = 0, int dy_packed = 0,       // *_packed: operand in split storage
+                int x_b16 = 0, int dy_b16 = 0);                                                                    // *_b16: operand stored as bf16 (single-piece mode)
 
 // conv1x1_small.hip: streaming VALU kernels for 1x1 convolutions with <= 8 outputs (-2 = shape not covered)
 bool conv1x1_small_ok(int Cin, int Cout);
 int conv1x1_small_fwd(const float* x, int Cin, int CinTot, const float* w, const float* bias, float* y, int Cout, int CoutTot,
-                      int N, int H, int W, hipStream_t st);
+                      int N, int H, int W, hipStream_t st, int x_b16 = 0);
 int conv1x1_small_bwd_data(const float* dy, int Cout, int CoutTot, const float* w, float* dx, int Cin, int CinTot,
-                           int N, int H, int W, int accumulate, hipStream_t st);
+                           int N, int H, int W, int accumulate, hipStream_t st, int dx_b16 = 0);
 size_t conv1x1_small_bwd_weight_ws(int Cin, int Cout, int N, int H, int W);
 int conv1x1_small_bwd_weight(const float* x, int Cin, int CinTot, const float* dy, int Cout, int CoutTot, float* dw, float* db,
-                             int N, int H, int W, void* ws, hipStream_t st);
+                             int N, int H, int W, void* ws, hipStream_t st, int x_b16 = 0);
 
 }  // namespace uz
 

@@ -205,6 +205,74 @@ __global__ __launch_bounds__(256) void nearest3d_bwd_wave_k(const float* __restr
     }
 }
 
+// ---- bf16 STORAGE variants (include/uz_api.h, "bf16 storage"): the float4 kernels above with each tensor either fp32 or bf16
+// (xb / yb: workgroup-uniform flags), arithmetic in fp32, values rounded to nearest even where the output is bf16
+__global__ __launch_bounds__(256) void avgpool3d_fwd_st(const float* __restrict__ x, int CtotX, float* __restrict__ y, int CtotY,
+                                                         int C, int D, int H, int W, int Do, int Ho, int Wo, int xb, int yb) {
+    const int od = blockIdx.z, c = blockIdx.y, W4 = W / 4, n2 = Ho * W4;
+    const int d0 = 2 * od, d1 = min(d0 + 2, D);
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < n2; q += gridDim.x * 256) {
+        const int oy = q / W4, j = q - oy * W4, y0 = 2 * oy, y1 = min(y0 + 2, H);
+        float a0 = 0.f, a1 = 0.f;
+        for (int d = d0; d < d1; ++d)
+            for (int yy = y0; yy < y1; ++yy) {
+                const uz::f32x4 v = uz::ld_elem4(x, ((size_t)d * CtotX + c) * H * W + (size_t)yy * W + 4 * j, xb);
+                a0 += v.x + v.y; a1 += v.z + v.w;
+            }
+        const float inv = 1.f / (float)((d1 - d0) * (y1 - y0) * 2);
+        const size_t o = ((size_t)od * CtotY + c) * Ho * Wo + (size_t)oy * Wo + 2 * j;
+        if (yb) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(y) + o) = uz::pack_bf16x2(a0 * inv, a1 * inv);
+        else *reinterpret_cast<float2*>(y + o) = make_float2(a0 * inv, a1 * inv);
+    }
+}
+__global__ __launch_bounds__(256) void avgpool3d_bwd_st(const float* __restrict__ dy, int CtotDy, float* __restrict__ dx, int CtotDx,
+                                                         int C, int D, int H, int W, int Do, int Ho, int Wo, int accumulate, int dyb, int dxb) {
+    const int d = blockIdx.z, c = blockIdx.y, W4 = W / 4, n4 = H * W4, od = d >> 1;
+    const int cd = min(2 * od + 2, D) - 2 * od;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < n4; q += gridDim.x * 256) {
+        const int yy = q / W4, j = q - yy * W4, oy = yy >> 1;
+        const float inv = 1.f / (float)(cd * (min(2 * oy + 2, H) - 2 * oy) * 2);
+        const size_t go = ((size_t)od * CtotDy + c) * Ho * Wo + (size_t)oy * Wo + 2 * j;
+        float g0, g1;
+        if (dyb) { const unsigned w = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(dy) + go); g0 = uz::bf16_lo(w); g1 = uz::bf16_hi(w); }
+        else { const float2 g = *reinterpret_cast<const float2*>(dy + go); g0 = g.x; g1 = g.y; }
+        const size_t o = ((size_t)d * CtotDx + c) * H * W + (size_t)yy * W + 4 * j;
+        uz::f32x4 v = {g0 * inv, g0 * inv, g1 * inv, g1 * inv};
+        if (accumulate) v += uz::ld_elem4(dx, o, dxb);
+        uz::st_elem4(dx, o, v, dxb);
+    }
+}
+__global__ __launch_bounds__(256) void depth_lerp_fwd_st(const float* __restrict__ x, int CtotX, float* __restrict__ y, int CtotY,
+                                                          int C, int D, int HW, int xb, int yb) {
+    const int od = blockIdx.z, c = blockIdx.y;
+    int d0, dp; float t;
+    depth_src(od, D, d0, dp, t);
+    const size_t ra = ((size_t)d0 * CtotX + c) * HW, rb = ((size_t)(d0 + dp) * CtotX + c) * HW, ro = ((size_t)od * CtotY + c) * HW;
+    const float s = 1.f - t;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < HW / 4; q += gridDim.x * 256) {
+        const uz::f32x4 u = uz::ld_elem4(x, ra + 4 * (size_t)q, xb), v = uz::ld_elem4(x, rb + 4 * (size_t)q, xb);
+        uz::st_elem4(y, ro + 4 * (size_t)q, uz::f32x4{s * u.x + t * v.x, s * u.y + t * v.y, s * u.z + t * v.z, s * u.w + t * v.w}, yb);
+    }
+}
+__global__ __launch_bounds__(256) void depth_lerp_bwd_st(const float* __restrict__ dy, int CtotDy, float* __restrict__ dx, int CtotDx,
+                                                          int C, int D, int HW, int accumulate, int dyb, int dxb) {
+    const int d = blockIdx.z, c = blockIdx.y;
+    float w[6]; int ods[6], nw = 0;
+    for (int od = max(0, 2 * d - 2); od <= min(2 * D - 1, 2 * d + 3); ++od) {
+        int d0, dp; float t;
+        depth_src(od, D, d0, dp, t);
+        const float ww = (d0 == d ? 1.f - t : 0.f) + (d0 + dp == d ? t : 0.f);
+        if (ww != 0.f) { w[nw] = ww; ods[nw] = od; ++nw; }
+    }
+    const size_t ro = ((size_t)d * CtotDx + c) * HW;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < HW / 4; q += gridDim.x * 256) {
+        uz::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nw; ++k) acc += w[k] * uz::ld_elem4(dy, ((size_t)ods[k] * CtotDy + c) * HW + 4 * (size_t)q, dyb);
+        if (accumulate) acc += uz::ld_elem4(dx, ro + 4 * (size_t)q, dxb);
+        uz::st_elem4(dx, ro + 4 * (size_t)q, acc, dxb);
+    }
+}
+
 inline int gx(int n) { int g = (n + 255) / 256; return g < 1 ? 1 : (g > 64 ? 64 : g); }
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -238,6 +306,35 @@ extern "C" int uz_avgpool3d_bwd(const float* dy, int C, int CtotDy, float* dx, i
         hipLaunchKernelGGL(avgpool3d_bwd_k, dim3(gx(H * W), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, C, D, H, W, Do, Ho, Wo, accumulate);
     return uz::check_launch("avgpool3d_bwd_k");
 }
+// bf16 STORAGE variants: x / y (dy / dx) each fp32 or bf16; W % 4 == 0 (pooling) or H*W % 4 == 0 (depth stage), 16-byte aligned views
+extern "C" int uz_avgpool3d_fwd_b16(const void* x, int C, int CtotX, void* y, int CtotY, int D, int H, int W, int x_b16, int y_b16, void* stream) {
+    UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && D <= 65535, "avgpool3d_fwd_b16: bad sizes");
+    UZ_REQUIRE(W % 4 == 0 && H % 2 == 0 && a16(x) && a16(y), "avgpool3d_fwd_b16: needs W %% 4 == 0, even H and 16-byte aligned views");
+    const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    hipLaunchKernelGGL(avgpool3d_fwd_st, dim3(gx(Ho * W / 4), C, Do), dim3(256), 0, uz::S(stream), static_cast<const float*>(x), CtotX, static_cast<float*>(y), CtotY,
+                       C, D, H, W, Do, Ho, Wo, x_b16, y_b16);
+    return uz::check_launch("avgpool3d_fwd_st");
+}
+extern "C" int uz_avgpool3d_bwd_b16(const void* dy, int C, int CtotDy, void* dx, int CtotDx, int D, int H, int W, int accumulate, int dy_b16, int dx_b16, void* stream) {
+    UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && D <= 65535, "avgpool3d_bwd_b16: bad sizes");
+    UZ_REQUIRE(W % 4 == 0 && H % 2 == 0 && a16(dx) && a16(dy), "avgpool3d_bwd_b16: needs W %% 4 == 0, even H and 16-byte aligned views");
+    const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    hipLaunchKernelGGL(avgpool3d_bwd_st, dim3(gx(H * W / 4), C, D), dim3(256), 0, uz::S(stream), static_cast<const float*>(dy), CtotDy, static_cast<float*>(dx), CtotDx,
+                       C, D, H, W, Do, Ho, Wo, accumulate, dy_b16, dx_b16);
+    return uz::check_launch("avgpool3d_bwd_st");
+}
+extern "C" int uz_depth_lerp2x_fwd_b16(const void* x, int C, int CtotX, void* y, int CtotY, int D, int H, int W, int x_b16, int y_b16, void* stream) {
+    UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && 2 * D <= 65535, "depth_lerp2x_fwd_b16: bad sizes");
+    UZ_REQUIRE((H * W) % 4 == 0 && a16(x) && a16(y), "depth_lerp2x_fwd_b16: needs H*W %% 4 == 0 and 16-byte aligned views");
+    hipLaunchKernelGGL(depth_lerp_fwd_st, dim3(gx(H * W / 4), C, 2 * D), dim3(256), 0, uz::S(stream), static_cast<const float*>(x), CtotX, static_cast<float*>(y), CtotY, C, D, H * W, x_b16, y_b16);
+    return uz::check_launch("depth_lerp_fwd_st");
+}
+extern "C" int uz_depth_lerp2x_bwd_b16(const void* dy, int C, int CtotDy, void* dx, int CtotDx, int D, int H, int W, int accumulate, int dy_b16, int dx_b16, void* stream) {
+    UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && D <= 65535, "depth_lerp2x_bwd_b16: bad sizes");
+    UZ_REQUIRE((H * W) % 4 == 0 && a16(dx) && a16(dy), "depth_lerp2x_bwd_b16: needs H*W %% 4 == 0 and 16-byte aligned views");
+    hipLaunchKernelGGL(depth_lerp_bwd_st, dim3(gx(H * W / 4), C, D), dim3(256), 0, uz::S(stream), static_cast<const float*>(dy), CtotDy, static_cast<float*>(dx), CtotDx, C, D, H * W, accumulate, dy_b16, dx_b16);
+    return uz::check_launch("depth_lerp_bwd_st");
+}
 extern "C" int uz_depth_lerp2x_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int D, int H, int W, void* stream) {
     UZ_REQUIRE(C > 0 && D > 0 && H > 0 && W > 0 && C <= 65535 && 2 * D <= 65535, "depth_lerp2x_fwd: bad sizes");
     if ((H * W) % 4 == 0 && a16(x) && a16(y))
@@ -266,4 +363,28 @@ extern "C" int uz_nearest3d_bwd(const float* dy, int C, int CtotDy, float* dx, i
     else
         hipLaunchKernelGGL(nearest3d_bwd_k, dim3(gx(H * W), C, D), dim3(256), 0, uz::S(stream), dy, CtotDy, dx, CtotDx, H, W, f, fz, accumulate);
     return uz::check_launch("nearest3d_bwd_k");
+}
+
+// ---- storage-format conversions (bf16 <-> fp32), contiguous
+namespace {
+__global__ __launch_bounds__(256) void cvt_f32_b16_k(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (unsigned short)(uz::pack_bf16x2(src[i], 0.f) & 0xFFFFu);
+}
+__global__ __launch_bounds__(256) void cvt_b16_f32_k(const unsigned short* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = __builtin_bit_cast(float, (unsigned)src[i] << 16);
+}
+}  // namespace
+extern "C" int uz_cvt_f32_to_b16(const float* src, void* dst, size_t n, void* stream) {
+    UZ_REQUIRE(src && dst, "cvt_f32_to_b16: null argument");
+    if (n == 0) return 0;
+    size_t g = (n + 255) / 256; if (g > 65535) g = 65535;
+    hipLaunchKernelGGL(cvt_f32_b16_k, dim3((unsigned)g), dim3(256), 0, uz::S(stream), src, static_cast<unsigned short*>(dst), n);
+    return uz::check_launch("cvt_f32_b16_k");
+}
+extern "C" int uz_cvt_b16_to_f32(const void* src, float* dst, size_t n, void* stream) {
+    UZ_REQUIRE(src && dst, "cvt_b16_to_f32: null argument");
+    if (n == 0) return 0;
+    size_t g = (n + 255) / 256; if (g > 65535) g = 65535;
+    hipLaunchKernelGGL(cvt_b16_f32_k, dim3((unsigned)g), dim3(256), 0, uz::S(stream), static_cast<const unsigned short*>(src), dst, n);
+    return uz::check_launch("cvt_b16_f32_k");
 }
