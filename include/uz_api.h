@@ -517,6 +517,9 @@ int uz_avgpool3d_fwd_b16(const void* x, int C, int CtotX, void* y, int CtotY, in
 int uz_avgpool3d_bwd_b16(const void* dy, int C, int CtotDy, void* dx, int CtotDx, int D, int H, int W, int accumulate, int dy_b16, int dx_b16, void* stream);
 int uz_depth_lerp2x_fwd_b16(const void* x, int C, int CtotX, void* y, int CtotY, int D, int H, int W, int x_b16, int y_b16, void* stream);
 int uz_depth_lerp2x_bwd_b16(const void* dy, int C, int CtotDy, void* dx, int CtotDx, int D, int H, int W, int accumulate, int dy_b16, int dx_b16, void* stream);
+/* in-plane stage of the trilinear interpolation: the HIGH-resolution side (y; dy) in bf16 storage, the low-resolution side fp32 */
+int uz_bilinear2x_fwd_b16(const float* x, int C, int CtotX, void* y, int CtotY, int N, int H, int W, int align_corners, int y_b16, void* stream);
+int uz_bilinear2x_bwd_b16(const void* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int align_corners, int accumulate, int dy_b16, void* stream);
 /* 1x1(x1) heads with 1 .. 8 outputs (mu_conv / sigma_conv phiseg3D.py:83-84, s_layer): the many-channel operand (x; dx of the data
  * gradient) in bf16 storage, the few-channel side (y, dy) fp32.  Replace uz_conv_fwd / uz_conv_bwd_data / uz_conv_bwd_weight (ks = 1). */
 int uz_conv1x1_fwd_b16(const void* x, int Cin, int CinTot, const float* w, const float* bias, float* y, int Cout, int CoutTot,

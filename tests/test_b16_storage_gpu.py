@@ -226,3 +226,55 @@ def test_pooling_and_depth_interpolation_in_bf16_storage(C, D, H, W):
     back = torch.empty(1000, device=d)
     g.call("uz_cvt_b16_to_f32", h16, back, 1000)
     assert torch.equal(back, h16.float())
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(6, 96, 2, 64, 32), (3, 40, 3, 32, 48)])
+def test_one_by_one_heads_with_the_wide_operand_in_bf16_storage(N, Cin, Cout, H, W):
+    """mu_conv / sigma_conv / s_layer (phiseg3D.py:83-84): x (forward, weight gradient) / dx (data gradient) in bf16 storage, the
+    2 - 3-channel side fp32.  Arithmetic is fp32 VALU on widened values: a bf16 INPUT gives bit-identical results, a bf16 OUTPUT the
+    rounding of the fp32 one."""
+    g, L = _g(), _lib()
+    d = g.dev()
+    x = _rb(g.rnd(N, Cin, H, W, seed=41))
+    w = g.rnd(Cout, Cin, 1, 1, seed=42, scale=0.2).to(d)
+    b = g.rnd(Cout, seed=43).to(d)
+    dy = g.rnd(N, Cout, H, W, seed=44).to(d)
+    x32b, x32 = _embed(x, Cin + 3, 3, torch.float32)
+    x16b, x16 = _embed(x, Cin + 3, 3, torch.bfloat16)
+    y0, y1 = torch.empty(N, Cout, H, W, device=d), torch.empty(N, Cout, H, W, device=d)
+    g.call("uz_conv_fwd", x32, Cin, Cin + 3, w, b, y0, Cout, Cout, N, H, W, 1, 0, None, None, None, None, 0)
+    g.call("uz_conv1x1_fwd_b16", x16, Cin, Cin + 3, w, b, y1, Cout, Cout, N, H, W, 1)
+    assert torch.equal(y0, y1)
+    assert g.relerr(y0, F.conv2d(x, w.cpu(), b.cpu())) <= 2e-6
+    wsb = L.uz_conv_bwd_weight_workspace(Cin, Cout, N, H, W, 1)
+    ws = torch.empty(wsb // 4 + 64, device=d)
+    dw0, db0, dw1, db1 = torch.empty_like(w), torch.empty_like(b), torch.full_like(w, float("nan")), torch.full_like(b, float("nan"))
+    g.call("uz_conv_bwd_weight", x32, Cin, Cin + 3, dy, Cout, Cout, dw0, db0, N, H, W, 1, None, None, ws, wsb)
+    g.call("uz_conv1x1_bwd_weight_b16", x16, Cin, Cin + 3, dy, Cout, Cout, dw1, db1, N, H, W, ws, wsb, 1)
+    assert torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    base = _rb(g.rnd(N, Cin, H, W, seed=45)).to(d)
+    dx0 = torch.full((N, Cin + 3, H, W), float("nan"), device=d)
+    dx0[:, 3:] = base
+    g.call("uz_conv_bwd_data", dy, Cout, Cout, w, dx0[:, 3:], Cin, Cin + 3, N, H, W, 1, 1, None, None, None, 0)
+    dx1 = torch.full((N, Cin + 3, H, W), float("nan"), device=d, dtype=torch.bfloat16)
+    dx1[:, 3:] = base.to(torch.bfloat16)
+    g.call("uz_conv1x1_bwd_data_b16", dy, Cout, Cout, w, dx1[:, 3:], Cin, Cin + 3, N, H, W, 1, 1)
+    assert torch.equal(dx1[:, 3:], dx0[:, 3:].to(torch.bfloat16)) and torch.isnan(dx1[:, :3]).all()
+
+
+@pytest.mark.parametrize("N,C,H,W,ac", [(5, 6, 32, 16, 1), (3, 4, 64, 32, 1), (2, 3, 16, 64, 0)])
+def test_in_plane_interpolation_with_the_high_resolution_side_in_bf16_storage(N, C, H, W, ac):
+    g, L = _g(), _lib()
+    d = g.dev()
+    x = g.rnd(N, C, H, W, seed=51).to(d)
+    y0 = torch.empty(N, C, 2 * H, 2 * W, device=d)
+    g.call("uz_bilinear2x_fwd", x, C, C, y0, C, N, H, W, ac, None, None)
+    y1 = torch.full((N, C + 2, 2 * H, 2 * W), float("nan"), device=d, dtype=torch.bfloat16)
+    g.call("uz_bilinear2x_fwd_b16", x, C, C, y1[:, 2:], C + 2, N, H, W, ac, 1)
+    assert torch.equal(y1[:, 2:], y0.to(torch.bfloat16)) and torch.isnan(y1[:, :2]).all()
+    gy = _rb(g.rnd(N, C, 2 * H, 2 * W, seed=52)).to(d)
+    base = g.rnd(N, C, H, W, seed=53).to(d)
+    dx0, dx1 = base.clone(), base.clone()
+    g.call("uz_bilinear2x_bwd", gy, C, C, dx0, C, N, H, W, ac, 1)
+    g.call("uz_bilinear2x_bwd_b16", gy.to(torch.bfloat16), C, C, dx1, C, N, H, W, ac, 1, 1)
+    assert torch.equal(dx0, dx1)

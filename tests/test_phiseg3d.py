@@ -47,6 +47,70 @@ def test_plan_builds_schedules_and_rejects_what_the_reference_rejects():
         net.forward(torch.zeros(1, 4, 16, 32, 32), torch.zeros(1, 3, 16, 32, 32))
 
 
+def test_bf16_storage_pass_marks_buffers_and_operands_consistently(monkeypatch):
+    """Plan._b16_pass (BASELINE config 5, bf16 STORAGE): which volume tensors become 2-byte buffers is decided per buffer from its
+    readers and writers; every op then carries one format bit per tensor operand (i[13]).  Checked here on the CPU: the bits of every
+    op agree with the buffers behind its operands (a bf16 buffer read as fp32, or the reverse, would be silent garbage on the device),
+    only ops with a bf16-storage form touch a bf16 buffer, a unit's three backward ops agree on their dy scratch class, the arena
+    shrinks, the lane schedule still orders every hazard, and nothing changes outside the bf16 arithmetic mode."""
+    from tests.test_host_cpu import _check_lane_schedule
+    from unet_zoo_amd import _ffi
+    from unet_zoo_amd._plan import View, _ScratchView
+    from unet_zoo_amd.models.phiseg3D import PHISeg3D
+    L = _ffi.lib()
+
+    def build(b16, mode):
+        monkeypatch.setenv("UZ_STORE_B16", b16)
+        L.uz_set_conv_math(mode)
+        try:
+            net = PHISeg3D(4, 3, [32, 64, 64], latent_levels=2, device="cpu")
+            return net._build(32, 64, 64, True, True)
+        finally:
+            L.uz_set_conv_math(-1)
+    off = build("0", 3)
+    on = build("1", 3)
+    assert off.b16_info["buffers"] == 0 and not any(b.b16 for b in off.bufs) and not any(len(o["i"]) > 13 and o["i"][13] for o in off.fwd_ops + off.bwd_ops)
+    assert build("1", 1).b16_info["buffers"] == 0                   # the fp32-accurate split mode never stores bf16
+    info = on.b16_info
+    assert info["buffers"] >= 10 and info["grads"] >= 5 and info["dy"] >= 5 and info["ops"] >= 40, info
+    assert on.arena_floats < 0.8 * off.arena_floats
+    assert all(b.vol and b.W % 32 == 0 and (b.N - 2) * b.H * b.W > 32768 for b in on.bufs if b.b16)
+
+    def fmt(r):
+        if isinstance(r, View):
+            return r.buf.b16
+        if isinstance(r, tuple) and r and r[0] == "win":
+            return r[1].buf.b16
+        if isinstance(r, _ScratchView) and r.zkey is not None:
+            return len(r.zkey) > 2
+        if isinstance(r, tuple) and r and r[0] in ("gyvol", "gywin"):
+            return len(r[1]) > 2
+        return None
+    flagged = 0
+    for ops in (on.fwd_ops, on.loss_ops, on.bwd_ops):
+        for o in ops:
+            slots = dict(on._b16_slots(o))
+            bits = o["i"][13] if len(o["i"]) > 13 else 0
+            for j, r in enumerate(o["p"]):
+                f = fmt(r)
+                if f is None:
+                    continue
+                if j in slots:
+                    assert bool((bits >> slots[j]) & 1) == bool(f), (o["code"], j, bits)
+                    flagged += bool(f)
+                else:
+                    assert not f, (o["code"], j)                     # an operand slot without a bf16 form only ever sees fp32 buffers
+            assert not bits or on._b16_ok(o)
+    assert flagged >= 100
+    for which, ops in (("fwd", on.fwd_ops), ("bwd", on.bwd_ops)):
+        _check_lane_schedule(on, which, ops)
+    # byte-typed pointers: consecutive bf16 buffers are packed at 2 bytes per element
+    b = next(b for b in on.bufs if b.b16)
+    assert b.words == (b.numel + 1) // 2 and on.tensor(View(b)).dtype == torch.bfloat16 and on.tensor(View(b)).shape == (b.N, b.C, b.H, b.W)
+    v = View(b, 1, b.C - 1, 1, b.N - 2)
+    assert on._resolve(v) - on._resolve(View(b)) == 2 * (b.C + 1) * b.H * b.W
+
+
 def test_brats_experiment_file_resolves_to_the_native_model():
     import os
     from unet_zoo_amd import train_model as TM
@@ -527,7 +591,74 @@ def test_baseline_config5_full_volume_in_bf16_mode():
 
 
 @pytest.mark.gpu
-def test_bf16_mode_against_the_reference_modules_run_in_bf16():
+def test_baseline_config5_full_volume_in_bf16_storage(monkeypatch):
+    """BASELINE.json configs[4] LITERALLY - bf16 arithmetic AND bf16 storage, 4 x 128 x 128 x 64: with UZ_STORE_B16=1
+    the plan keeps the volume's large tensors (activations, their gradients, every unit's dy on the 128 x 64 and 64 x 32 planes) as
+    2-byte bf16 elements (Plan._b16_pass; the kernels are pinned per op, by equalities, in tests/test_b16_storage_gpu.py).
+    Reference points on the device: the same network with fp32 storage in the same arithmetic, and in the fp32-accurate split mode
+    (pinned against the CPU oracle on the 64 x 64 x 32 sub-volume above).  Gates: first-step loss within 1e-3 of both (measured 1e-5 /
+    4e-5), level logits within 5 % of their range of the split mode's (measured 2.4 %; fp32 storage: 2.0 %), > 7 GB of tensors in bf16
+    and a third less arena, three replayed training steps finite and decreasing."""
+    from unet_zoo_amd import _ffi
+    from unet_zoo_amd.models.phiseg3D import PHISeg3D, phiseg3d_spec
+    from unet_zoo_amd.optim import FusedAdam
+    L = _ffi.lib()
+    if L.uz_get_conv_math() == 0:
+        pytest.skip("fp32-only run")
+    dev = torch.device("cuda", 0)
+    filters, K, Cin, dhw = [32, 64, 128, 192, 192], 3, 4, (128, 128, 64)
+    sd0 = oracle.deterministic_state_dict(phiseg3d_spec(Cin, K, filters, 5), seed=11)
+    shapes = R3.phiseg3d_eps_shapes(*dhw, 5, 5)
+    x, onehot, lab, eps = R3.synthetic_volume(Cin, K, dhw, 9, shapes + shapes)
+    xd, od, ld = (torch.from_numpy(a).to(dev) for a in (x, onehot, lab))
+    epsd = [torch.from_numpy(e).to(dev) for e in eps]
+    res = {}
+    try:
+        for tag, mode, b16 in (("split", 1, "0"), ("f32 storage", 3, "0"), ("bf16 storage", 3, "1")):
+            L.uz_set_conv_math(mode)
+            monkeypatch.setenv("UZ_STORE_B16", b16)
+            net = PHISeg3D(Cin, K, filters, latent_levels=5, image_size=(Cin, *dhw))
+            net.load_state_dict(sd0)
+            net.train()
+            s = net.forward(xd, od, training=True, eps=epsd)
+            res[tag] = (float(net.loss(ld)), [t.float().clone() for t in s], net._cur.arena_floats)
+            info = net._cur.b16_info
+            if tag == "bf16 storage":
+                assert info["buffers"] >= 60 and info["grads"] >= 30 and info["dy"] >= 30 and info["bytes_saved"] >= 7e9, info
+                from unet_zoo_amd._plan import View
+                stored = [b for b in net._cur.bufs if b.b16]
+                t16 = net._cur.tensor(View(stored[0]))
+                assert t16.dtype == torch.bfloat16 and bool(torch.isfinite(t16.float()).all())
+                net.enable_graphs(True)
+                opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
+                losses = []
+                for _ in range(4):
+                    net.forward(xd, od, training=True, eps=epsd)
+                    l = net.loss(ld)
+                    opt.zero_grad(); l.backward(); opt.step()
+                    losses.append(float(l))
+                assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+                assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+            else:
+                assert info["buffers"] == 0 and info["ops"] == 0
+            del net
+            torch.cuda.empty_cache()
+    finally:
+        L.uz_set_conv_math(-1)
+    l_split, s_split, _ = res["split"]
+    l_f32, s_f32, a_f32 = res["f32 storage"]
+    l_b16, s_b16, a_b16 = res["bf16 storage"]
+    print(f"config 5, bf16 storage: loss {l_b16:.7g} (fp32 storage {l_f32:.7g}, split {l_split:.7g}); arena {4 * a_b16 / 1e9:.2f} GB vs {4 * a_f32 / 1e9:.2f} GB")
+    assert abs(l_b16 - l_f32) <= 1e-3 * abs(l_f32) and abs(l_b16 - l_split) <= 1e-3 * abs(l_split)
+    assert a_b16 <= 0.67 * a_f32
+    for a, b in zip(s_split, s_b16):
+        rng = float(a.max() - a.min())
+        assert float((a - b).abs().max()) <= 5e-2 * max(rng, 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_bf16_mode_against_the_reference_modules_run_in_bf16(storage, monkeypatch):
     """tests/golden/phiseg3d_bf16.*: the reference's Posterior / prior / Likelihood modules run under
     torch.autocast('cpu', torch.bfloat16) (and in fp32) on a 32 x 64 x 64 volume, filters 32-32-64 - large enough that the
     library routes the 3x3x3 layers to the matrix-pipe kernels (tools/gen_golden.py 3d_bf16; every 7th element stored).
@@ -543,9 +674,13 @@ def test_bf16_mode_against_the_reference_modules_run_in_bf16():
     shapes = phiseg3d_eps_shapes(D, H, W, len(meta["filters"]), Lv)
     x, onehot, lab, eps = synthetic_volume(meta["input_channels"], meta["num_classes"], (D, H, W), meta["input_seed"], shapes + shapes)
     inputs = dict(patch=x, mask_onehot=onehot, labels=lab, **{f"eps{k}": e for k, e in enumerate(eps)})
+    # storage == "bf16": the full-resolution tensors of this volume are also STORED in bf16 (UZ_STORE_B16=1, Plan._b16_pass) - what the
+    # reference's autocast run does with every convolution output; the gates below are the same for both storages
+    monkeypatch.setenv("UZ_STORE_B16", "1" if storage == "bf16" else "0")
     try:
         L.uz_set_conv_math(3)
         net, s, loss = _run_native(meta, inputs)
+        assert (net._cur.b16_info["buffers"] >= 10) == (storage == "bf16"), net._cur.b16_info
         n_bf16 = sum(1 for o in net._cur.fwd_ops if o["code"] == "UZ_OP_CONV_FWD" and o["i"][7] == 3 and
                      L.uz_conv_route(0, o["i"][0], o["i"][2], o["i"][4], o["i"][5], o["i"][6], 3) == 1)
         assert n_bf16 >= 10, n_bf16                                   # the mode is really exercised
@@ -562,7 +697,7 @@ def test_bf16_mode_against_the_reference_modules_run_in_bf16():
             worst_vs_bf16 = max(worst_vs_bf16, G.maxabs(got, rb) / rng)
             worst_vs_f32 = max(worst_vs_f32, G.maxabs(got, rf) / rng)
             ref_gap = max(ref_gap, G.maxabs(rb, rf) / rng)
-    print(f"native bf16 mode vs reference-bf16 {worst_vs_bf16:.3e}, vs reference-fp32 {worst_vs_f32:.3e}; reference bf16 vs its fp32 {ref_gap:.3e}")
+    print(f"native bf16 mode ({storage} storage) vs reference-bf16 {worst_vs_bf16:.3e}, vs reference-fp32 {worst_vs_f32:.3e}; reference bf16 vs its fp32 {ref_gap:.3e}")
     assert worst_vs_bf16 <= 6e-2 and worst_vs_f32 <= ref_gap
     lf, lb = float(arrays["fp32:loss"]), float(arrays["bf16:loss"])
     assert abs(float(loss) - lf) <= 1e-3 * abs(lf) and abs(float(loss) - lb) <= 1e-3 * abs(lb), (float(loss), lf, lb)

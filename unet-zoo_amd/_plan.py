@@ -1198,11 +1198,36 @@ class Plan:
         "UZ_OP_CONV_FWD": (0, 3), "UZ_OP_CONV_BWD_DATA": (0, 2), "UZ_OP_CONV_BWD_WEIGHT": (0, 1),
         "UZ_OP_BN_RELU_FWD": (0, 6), "UZ_OP_BN_RELU_BWD": (0, 1, 5),
         "UZ_OP_AVGPOOL3D_FWD": (0, 1), "UZ_OP_AVGPOOL3D_BWD": (0, 1), "UZ_OP_DEPTH_LERP_FWD": (0, 1), "UZ_OP_DEPTH_LERP_BWD": (0, 1),
+        "UZ_OP_BILINEAR_FWD": (0, 1), "UZ_OP_BILINEAR_BWD": (0, 1),          # (only the high-resolution side: see _b16_slots)
     }
+
+    def _b16_slots(self, o):
+        """(p[] slot, bit of i[13]) of the tensor operands of op `o` that may be bf16; () = no bf16-storage form."""
+        c = o["code"]
+        slots = self._B16_SLOTS.get(c)
+        if not slots:
+            return ()
+        if c.startswith("UZ_OP_CONV_") and o["i"][7] == 1:       # 1x1 head: only the many-channel side (x / dx), the 1 .. 8-channel side stays fp32
+            return {"UZ_OP_CONV_FWD": ((0, 0),), "UZ_OP_CONV_BWD_DATA": ((2, 1),), "UZ_OP_CONV_BWD_WEIGHT": ((0, 0),)}[c]
+        if c == "UZ_OP_BILINEAR_FWD":
+            return ((1, 1),)
+        if c == "UZ_OP_BILINEAR_BWD":
+            return ((0, 0),)
+        return tuple((j, k) for k, j in enumerate(slots))
 
     def _b16_ok(self, o):
         """Can op `o` run through its bf16-storage entry point (whatever the formats of its operands turn out to be)?"""
-        c, i, p = o["code"], o["i"], o["p"]
+        c, i, p = o["code"], o["i"][:13], o["p"]                # (i[13] = the format bits this pass sets)
+        if c in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA", "UZ_OP_CONV_BWD_WEIGHT") and i[7] == 1:
+            kind = {"UZ_OP_CONV_FWD": 0, "UZ_OP_CONV_BWD_DATA": 1, "UZ_OP_CONV_BWD_WEIGHT": 2}[c]
+            cin, cout = (i[2], i[0]) if kind == 1 else (i[0], i[2])
+            if cout not in (1, 2, 3, 4, 6, 8) or cin > 512 or (i[5] * i[6]) % 4:
+                return False
+            if kind == 0:
+                return not any(i[8:])                          # (no ReLU, no slabs)
+            if kind == 1:
+                return not any(i[9:]) and len(p) <= 7
+            return not any(i[8:])
         if c in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA", "UZ_OP_CONV_BWD_WEIGHT"):
             kind = {"UZ_OP_CONV_FWD": 0, "UZ_OP_CONV_BWD_DATA": 1, "UZ_OP_CONV_BWD_WEIGHT": 2}[c]
             W = i[6]
@@ -1224,6 +1249,10 @@ class Plan:
             return i[5] % 4 == 0 and i[4] % 2 == 0
         if c in ("UZ_OP_DEPTH_LERP_FWD", "UZ_OP_DEPTH_LERP_BWD"):
             return (i[4] * i[5]) % 4 == 0
+        if c == "UZ_OP_BILINEAR_FWD":                          # i = [C, CtotX, CtotY, N, H, W, align_corners, (packed)]: the band kernel's shapes
+            return i[5] % 4 == 0 and i[5] <= 128 and i[4] >= 4 and not any(i[7:]) and (len(p) < 3 or True)
+        if c == "UZ_OP_BILINEAR_BWD":                          # i = [C, CtotDy, CtotDx, N, H, W, align_corners, acc]
+            return 2 * i[5] <= 128 and i[4] >= 4 and 256 % i[5] == 0 and len(p) <= 2 and not any(i[8:])
         return False
 
     def _b16_pass(self):
@@ -1253,7 +1282,7 @@ class Plan:
         ok_cache = {}
         bad, seen = set(), set()
         for o in all_ops:
-            slots = self._B16_SLOTS.get(o["code"], ())
+            slots = [j for j, _ in self._b16_slots(o)]
             if id(o) not in ok_cache:
                 ok_cache[id(o)] = bool(slots) and self._b16_ok(o)
             for j, r in enumerate(o["p"]):
@@ -1301,11 +1330,11 @@ class Plan:
             del self._gyz[k]                                   # an fp32 class every unit has left
         # format bits
         for o in all_ops:
-            slots = self._B16_SLOTS.get(o["code"])
+            slots = self._b16_slots(o)
             if not slots or not ok_cache.get(id(o)):
                 continue
             bits = 0
-            for k, j in enumerate(slots):
+            for j, k in slots:
                 r = o["p"][j]
                 b = buf_of(r)
                 is16 = b is not None and b.b16

@@ -22,6 +22,7 @@ struct RsP {
     // backward kernels, optional: dst is the gradient w.r.t. the OUTPUT A of a Conv -> ReLU unit (vanilla U-Net blocks) and this launch
     // is its last writer - apply the unit's ReLU mask (a > 0), leave per-workgroup sums for its bias gradient, publish max |dst|
     const float* mask; int CtotM; double* part; float* m_amax;
+    int hb16;                             // bilinear band kernels: the HIGH-resolution tensor (forward: dst, backward: src) holds 2-byte bf16 elements
 };
 struct ReluFold { float sd = 0.f, vmax = 0.f; };
 __device__ __forceinline__ float fold_value(const RsP& p, const float* mplane, int q, float v, ReluFold& f) {
@@ -205,8 +206,15 @@ __global__ __launch_bounds__(256) void bilinear_bwd_sep_k(const RsP p) {   // sr
             const int oy = ob + r;
             float acc = 0.f;
             if (oy >= 0 && oy < p.Ho) {
-                const float2* row = reinterpret_cast<const float2*>(s + (size_t)oy * p.Wo + 2 * ix - 2);
-                const float2 a = v0 ? row[0] : make_float2(0.f, 0.f), m = row[1], z = v2 ? row[2] : make_float2(0.f, 0.f);
+                float2 a, m, z;
+                if (p.hb16) {                                 // bf16 storage: a pair is one aligned dword
+                    const unsigned* row = reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(p.src) + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo + (size_t)oy * p.Wo + 2 * ix - 2);
+                    const unsigned wa = v0 ? row[0] : 0u, wm = row[1], wz = v2 ? row[2] : 0u;
+                    a = make_float2(uz::bf16_lo(wa), uz::bf16_hi(wa)); m = make_float2(uz::bf16_lo(wm), uz::bf16_hi(wm)); z = make_float2(uz::bf16_lo(wz), uz::bf16_hi(wz));
+                } else {
+                    const float2* row = reinterpret_cast<const float2*>(s + (size_t)oy * p.Wo + 2 * ix - 2);
+                    a = v0 ? row[0] : make_float2(0.f, 0.f); m = row[1]; z = v2 ? row[2] : make_float2(0.f, 0.f);
+                }
                 acc = wx[0] * a.x + wx[1] * a.y + wx[2] * m.x + wx[3] * m.y + wx[4] * z.x + wx[5] * z.y;
             }
             tx[r * p.W + ix] = acc;
@@ -269,7 +277,11 @@ __global__ __launch_bounds__(256) void bilinear_fwd_band_k(const RsP p) {
             const float w1l = xl[ox], w0l = 1.f - w1l;
             v[j] = h0l * (w0l * r0[w1] + w1l * r0[w1 + wp]) + h1l * (w0l * r1[w1] + w1l * r1[w1 + wp]);
         }
-        *reinterpret_cast<float4*>(d + (size_t)oy * p.Wo + 4 * q) = make_float4(out_word(p, v[0], ps), out_word(p, v[1], ps), out_word(p, v[2], ps), out_word(p, v[3], ps));
+        if (p.hb16)
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.dst) + ((size_t)b * p.CtotD + c) * p.Ho * p.Wo + (size_t)oy * p.Wo + 4 * q) =
+                make_uint2(uz::pack_bf16x2(v[0], v[1]), uz::pack_bf16x2(v[2], v[3]));
+        else
+            *reinterpret_cast<float4*>(d + (size_t)oy * p.Wo + 4 * q) = make_float4(out_word(p, v[0], ps), out_word(p, v[1], ps), out_word(p, v[2], ps), out_word(p, v[3], ps));
     }
 }
 
@@ -426,6 +438,26 @@ static int bilinear2x_bwd_impl(const float* dy, int C, int CtotDy, float* dx, in
         return uz::check_launch("bilinear_bwd_sep_k");
     }
     RS_LAUNCH(bilinear_bwd_k, H * W);
+}
+// bf16 STORAGE of the HIGH-resolution side (include/uz_api.h, "bf16 storage"): the in-plane stage of a volume's trilinear
+// interpolation writes its output (forward) / reads the incoming gradient (backward) as 2-byte bf16 elements; the low-resolution
+// side stays fp32.  Band kernels only: W % 4 == 0, W <= 128 / 2 W <= 128, H >= 4, 256 % W == 0 (backward), 16-byte aligned views.
+extern "C" int uz_bilinear2x_fwd_b16(const float* x, int C, int CtotX, void* y, int CtotY, int N, int H, int W, int align_corners, int y_b16, void* stream) {
+    if (int rc = check_dims("bilinear2x_fwd_b16", C, N, H, W)) return rc;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    UZ_REQUIRE(W % 4 == 0 && W <= FWMAX && H >= 4 && al16(x) && al16(y), "bilinear2x_fwd_b16: shape not served by the band kernel (W %% 4 == 0, W <= 128, H >= 4, 16-byte aligned views)");
+    RsP p = {}; p.src = x; p.dst = static_cast<float*>(y); p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N; p.hb16 = y_b16 != 0;
+    p.H = H; p.W = W; p.Ho = 2 * H; p.Wo = 2 * W; p.ac = align_corners; bil_scales(p);
+    hipLaunchKernelGGL(bilinear_fwd_band_k, dim3(uz::ceil_div(p.Ho, OB), C, N), dim3(256), 0, uz::S(stream), p);
+    return uz::check_launch("bilinear_fwd_band_k");
+}
+extern "C" int uz_bilinear2x_bwd_b16(const void* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int align_corners, int accumulate, int dy_b16, void* stream) {
+    if (int rc = check_dims("bilinear2x_bwd_b16", C, N, H, W)) return rc;
+    UZ_REQUIRE(2 * W <= BWMAX && H >= 4 && 256 % W == 0 && (reinterpret_cast<uintptr_t>(dy) & 7) == 0, "bilinear2x_bwd_b16: shape not served by the band kernel (2 W <= 128, H >= 4, 256 %% W == 0, 8-byte aligned dy)");
+    RsP p = {}; p.src = static_cast<const float*>(dy); p.dst = dx; p.C = C; p.CtotS = CtotDy; p.CtotD = CtotDx; p.N = N; p.hb16 = dy_b16 != 0;
+    p.H = H; p.W = W; p.Ho = 2 * H; p.Wo = 2 * W; p.ac = align_corners; p.accumulate = accumulate; bil_scales(p);
+    hipLaunchKernelGGL(bilinear_bwd_sep_k, dim3((long long)C * N >= 2048 ? 1 : uz::ceil_div(H, LB), C, N), dim3(256), 0, uz::S(stream), p);
+    return uz::check_launch("bilinear_bwd_sep_k");
 }
 extern "C" int uz_nearest_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W, int factor, void* stream) {
     if (int rc = check_dims("nearest_fwd", C, N, H, W)) return rc;

@@ -106,6 +106,7 @@ static int run_one(const uz_op& o, void* st) {
     switch (o.code) {
         case UZ_OP_CONV_FWD:
             // i[13]: bf16 STORAGE bits (Plan._b16_pass) - bit 0 = x, bit 1 = y hold 2-byte bf16 elements
+            if (i[13] && i[7] == 1) return uz_conv1x1_fwd_b16(p[0], i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[13] & 1, st);      // a 1x1 head: only x may be bf16
             if (i[13]) return uz_conv_fwd_b16(p[0], i[0], i[1], CFP(1), CFP(2), p[3], i[2], i[3], i[4], i[5], i[6], i[7], p[4], (size_t)o.n, p[8], FP(9), i[13] & 1, (i[13] >> 1) & 1, st);
             if (i[9]) return uz_conv_fwd_slabs(CFP(0), i[0], i[1], CFP(1), i[2], i[4], i[5], i[6], i[7], p[4], (size_t)o.n, st);      // the unit's BatchNorm adds the slabs
             // i[10] = input in split storage, p[10] / i[11] = bound and first channel of its second scale segment
@@ -114,6 +115,7 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_CONV_BWD_DATA:
             // i[10]: fold of the unit that produced the output's forward twin - 1 ReLU mask (p[7] = its activation), 2 BatchNorm-backward
             // reduction (p[7] = its pre-normalisation output, p[10] = its statistics table, i[12] = its relu flag); i[11] = dy in split storage
+            if (i[13] && i[7] == 1) return uz_conv1x1_bwd_data_b16(CFP(0), i[0], i[1], CFP(1), p[2], i[2], i[3], i[4], i[5], i[6], i[8], (i[13] >> 1) & 1, st);
             if (i[13]) return uz_conv_bwd_data_b16(p[0], i[0], i[1], CFP(1), p[2], i[2], i[3], i[4], i[5], i[6], i[7], i[8], p[3], (size_t)o.n, p[6], i[13] & 1, (i[13] >> 1) & 1, st);      // bit 0 = dy, bit 1 = dx in bf16 storage
             if (i[10] == 3) return uz_conv_bwd_data_slabs(CFP(0), i[0], i[1], CFP(1), i[2], i[4], i[5], i[6], i[7], FP(7), st);      // slabs only: the consumer's BatchNorm backward adds them
             if (i[10] == 1) return uz_conv_bwd_data_relu(CFP(0), i[0], i[1], CFP(1), FP(2), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(4), CFP(5), p[3], (size_t)o.n, p[6], CFP(7), i[9], FP(8), FP(9), st);
@@ -122,6 +124,7 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_CONV_BWD_WEIGHT:
             // i[8] = x in split storage, p[7] / i[9] = second scale segment of x, i[10] = dy in split storage
             // i[11]: slabs only, into p[8] (added by UZ_OP_WGRAD_REDUCE_TABLE at the end of the tape)
+            if (i[13] && i[7] == 1) return uz_conv1x1_bwd_weight_b16(p[0], i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], p[4], (size_t)o.n, i[13] & 1, st);
             if (i[13]) return uz_conv_bwd_weight_b16(p[0], i[0], i[1], p[1], i[2], i[3], FP(2), i[4], i[5], i[6], i[7], p[4], (size_t)o.n, i[13] & 1, (i[13] >> 1) & 1, i[11] ? FP(8) : nullptr, st);      // bit 0 = x, bit 1 = dy in bf16 storage
             return uz_conv_bwd_weight_ex(CFP(0), i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], i[7], CFP(5), CFP(6), p[4], (size_t)o.n,
                                          i[8], CFP(7), i[9], i[10], i[11] ? FP(8) : nullptr, st);
@@ -145,8 +148,10 @@ static int run_one(const uz_op& o, void* st) {
             if (p[2]) return uz_avgpool2_bwd_relu(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], CFP(2), i[7], static_cast<double*>(p[3]), FP(4), st);
             return uz_avgpool2_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], st);
         case UZ_OP_BILINEAR_FWD:
+            if (i[13]) return uz_bilinear2x_fwd_b16(CFP(0), i[0], i[1], p[1], i[2], i[3], i[4], i[5], i[6], (i[13] >> 1) & 1, st);      // bf16 storage of the high-resolution output
             return uz_bilinear2x_fwd_ex(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], CFP(2), FP(3), i[7], st);
         case UZ_OP_BILINEAR_BWD:
+            if (i[13]) return uz_bilinear2x_bwd_b16(p[0], i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], i[7], i[13] & 1, st);      // bf16 storage of the incoming (high-resolution) gradient
             if (p[2]) return uz_bilinear2x_bwd_relu(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], i[7], CFP(2), i[8], static_cast<double*>(p[3]), FP(4), st);
             return uz_bilinear2x_bwd(CFP(0), i[0], i[1], FP(1), i[2], i[3], i[4], i[5], i[6], i[7], st);
         case UZ_OP_NEAREST_FWD:
