@@ -86,12 +86,20 @@ def conv_flops(op):
     return 2.0 * n * h * w * cin * cout * ks * ks
 
 
+def _esz(op, bit):
+    """Bytes per element of the tensor operand behind format bit `bit` of a plan op (i[13], Plan._b16_pass): 2 in bf16 storage, else 4."""
+    i = op["i"]
+    return 2.0 if (len(i) > 13 and (i[13] >> bit) & 1) else 4.0
+
+
 def conv_bytes(op):
-    """Algorithmic HBM bytes of a convolution op: input + output tensor once, weights once."""
+    """Algorithmic HBM bytes of a convolution op: input + output tensor once (at their storage width), weights once."""
     d = conv_dims(op)
     if d is None:
         return 0.0
     kind, cin, cout, n, h, w, ks = d
+    # format bits: forward (x, y), data gradient (dy, dx), weight gradient (x, dy)
+    e_cin, e_cout = {0: (_esz(op, 0), _esz(op, 1)), 1: (_esz(op, 1), _esz(op, 0)), 2: (_esz(op, 0), _esz(op, 1))}[kind]
     win = op["i"][0] == 3 * op["i"][1]                       # depth window of a volume (3 C channels over a C-channel buffer): read once
     if win and kind in (0, 2):
         cin_t, cout_t = cin // 3, cout
@@ -99,7 +107,7 @@ def conv_bytes(op):
         cin_t, cout_t = cin, cout // 3
     else:
         cin_t, cout_t = cin, cout
-    return 4.0 * (n * h * w * (cin_t + cout_t) + cin * cout * ks * ks)
+    return n * h * w * (cin_t * e_cin + cout_t * e_cout) + 4.0 * cin * cout * ks * ks
 
 
 def conv_roof(op, L):
@@ -125,26 +133,30 @@ def op_bytes(op):
         # three passes (statistics: y; apply: y, a) only on the streaming path without the convolution's partials (i[8] > 0); the
         # one-launch paths (channel's batch in registers, up to uz_bn_fwd_fused_limit) read y once
         big = N * H * W > _bn_limit("fwd", H, W) and not (len(i) > 8 and i[8])
-        return f4 * C * N * H * W * ((3 if big else 2) if training else 2)
+        return C * N * H * W * ((2 if (big and training) else 1) * _esz(op, 0) + _esz(op, 1))          # (format bits: y, a)
     if c in ("UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
         C, N, H, W = i[1], i[4], i[5], i[6]
         big = N * H * W > _bn_limit("bwd", H, W)                    # reduce (dA, y) + apply (dA, y, dy); one-launch paths: dA, y, dy
-        return f4 * C * N * H * W * ((5 if big else 3) if c == "UZ_OP_BN_RELU_BWD" else 3)
+        if c == "UZ_OP_RELU_BWD":
+            return f4 * C * N * H * W * 3
+        return C * N * H * W * ((2 if big else 1) * (_esz(op, 0) + _esz(op, 1)) + _esz(op, 2))        # (format bits: dA, y, dy)
     if c in ("UZ_OP_AVGPOOL_FWD", "UZ_OP_AVGPOOL_BWD"):
         C, N, H, W = i[0], i[3], i[4], i[5]
         return f4 * C * N * H * W * 1.25
     if c in ("UZ_OP_BILINEAR_FWD", "UZ_OP_BILINEAR_BWD"):
         C, N, H, W = i[0], i[3], i[4], i[5]
-        return f4 * C * N * H * W * 5
+        return C * N * H * W * (f4 + 4 * _esz(op, 1 if c == "UZ_OP_BILINEAR_FWD" else 0))               # (only the high-resolution side may be bf16)
     if c in ("UZ_OP_NEAREST_FWD", "UZ_OP_NEAREST_BWD"):
         C, N, H, W, f = i[0], i[3], i[4], i[5], i[6]
         return f4 * C * N * H * W * (1 + f * f)
     if c in ("UZ_OP_AVGPOOL3D_FWD", "UZ_OP_AVGPOOL3D_BWD"):
         C, D, H, W = i[0], i[3], i[4], i[5]
-        return f4 * C * D * H * W * 1.125
+        hi, lo = (0, 1) if c == "UZ_OP_AVGPOOL3D_FWD" else (1, 0)      # format bits: (x, y) / (dy, dx)
+        return C * D * H * W * (_esz(op, hi) + 0.125 * _esz(op, lo))
     if c in ("UZ_OP_DEPTH_LERP_FWD", "UZ_OP_DEPTH_LERP_BWD"):
         C, D, H, W = i[0], i[3], i[4], i[5]
-        return f4 * C * D * H * W * 3
+        lo, hi = (0, 1) if c == "UZ_OP_DEPTH_LERP_FWD" else (1, 0)     # D slices on the low side, 2 D on the high side
+        return C * D * H * W * (_esz(op, lo) + 2 * _esz(op, hi))
     if c in ("UZ_OP_NEAREST3D_FWD", "UZ_OP_NEAREST3D_BWD"):
         C, D, H, W, f, fz = i[0], i[3], i[4], i[5], i[6], i[7]
         return f4 * C * D * H * W * (1 + f * f * fz)
@@ -258,7 +270,7 @@ def dominant_kernel_live(net, plan, L, heaviest, reps=20):
     kname = {0: "conv_split_kernel (+ pack_weights_kernel)" if split else "conv_mfma_kernel",
              1: "conv_split_kernel, data gradient (+ pack_weights_kernel)" if split else "conv_mfma_kernel, data gradient",
              2: "wgrad_split_kernel (+ wgrad_reduce)" if split else "wgrad_fast_kernel (+ wgrad_reduce)"}[kind]
-    alg_bytes = 4.0 * (n * h * w * (cin + cout) + cin * cout * ks * ks)
+    alg_bytes = conv_bytes(ops[k])
     out = dict(kernel=kname, op={0: "forward", 1: "data gradient", 2: "weight gradient"}[kind],
                layer=f"{ks}x{ks} {cin}->{cout} @ {n}x{h}x{w}", flops_per_launch=flops, avg_launch_ms=round(ms, 4),
                achieved=round(flops / ms / 1e9, 2), peak=round(roof, 1), unit="TFLOP/s", frac=round(flops / ms / 1e9 / roof, 4),
@@ -270,7 +282,7 @@ def dominant_kernel_live(net, plan, L, heaviest, reps=20):
     if roof == PEAK_F16_MFMA_TFLOPS:
         # one product per MAC puts these layers on the memory side of the ridge for narrow channel counts: report the HBM view too
         out["hbm_view"] = dict(achieved_gbs=round(alg_bytes / ms / 1e6, 1), peak_gbs=HBM_PEAK_GBS, frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                               note="algorithmic bytes (fp32 storage: input + output tensor once) / launch duration against 8 TB/s")
+                               note="algorithmic bytes (input + output tensor once, at their storage width) / launch duration against 8 TB/s")
     for tabname in ("r4_layer_table.json", "r3_layer_table.json"):      # per-layer dispatch table (tools/prof_layers.sh), keyed on layer and direction; newest first
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", tabname)))

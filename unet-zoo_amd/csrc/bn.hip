@@ -39,6 +39,7 @@ struct BnP {
     int out_packed;                                    // out is written as split storage (split_f16.h: two fp16 pieces of v * split_scale(*amax) per word)
     float* chanf;                                      // backward, finalised: [C] m1 = mean(dz), [C] m2 = mean(dz x_hat)
     int yb, dab, outb;                                 // bf16 STORAGE of y / da / out (2-byte elements; the *_st kernels)
+    int nba;                                           // *_st apply kernels: images per workgroup
 };
 
 // block-wide maxima of two floats (blockDim.x == 256); result valid in thread 0
@@ -550,13 +551,22 @@ __global__ __launch_bounds__(256) void bn_stats_partial_st(const BnP p) {
     for (int b = grp * p.nb; b < min(p.N, (grp + 1) * p.nb); ++b) {
         const size_t row = ((size_t)b * p.CtotY + c) * p.HW;
         float s = 0.f, ss = 0.f;
-#pragma unroll 4
-        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
-            const uz::f32x4 v = uz::ld_elem4(p.y, row + 4 * (size_t)i, p.yb);
+        auto one4 = [&](const uz::f32x4 v) {
             s += (v.x + v.y) + (v.z + v.w);
             ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             vmx = fmaxf(fmaxf(vmx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
             vmn = fmaxf(fmaxf(vmn, fmaxf(-v.x, -v.y)), fmaxf(-v.z, -v.w));
+        };
+        if (p.HW % 8 == 0) {
+#pragma unroll 2
+            for (int i = lo / 8 + threadIdx.x; i < hi / 8; i += 256) {
+                uz::f32x4 a, b2;
+                uz::ld_elem8(p.y, row + 8 * (size_t)i, p.yb, a, b2);
+                one4(a); one4(b2);
+            }
+        } else {
+#pragma unroll 4
+            for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) one4(uz::ld_elem4(p.y, row + 4 * (size_t)i, p.yb));
         }
         v2[0] += (double)s; v2[1] += (double)ss;
     }
@@ -597,14 +607,28 @@ __global__ __launch_bounds__(256) void bn_apply_st(const BnP p) {
     } else {
         alpha_beta(p, c, alpha, beta_, mean, rstd);
     }
-    const size_t yrow = ((size_t)b * p.CtotY + c) * p.HW, orow = ((size_t)b * p.CtotOut + c) * p.HW;
     const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
     const float floor_ = p.relu ? 0.f : -INFINITY;
-    for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
-        uz::f32x4 v = uz::ld_elem4(p.y, yrow + 4 * (size_t)i, p.yb);
+    auto map4 = [&](uz::f32x4 v) -> uz::f32x4 {
         v.x = fmaxf(fmaf(v.x, alpha, beta_), floor_); v.y = fmaxf(fmaf(v.y, alpha, beta_), floor_);
         v.z = fmaxf(fmaf(v.z, alpha, beta_), floor_); v.w = fmaxf(fmaf(v.w, alpha, beta_), floor_);
-        uz::st_elem4(p.out, orow + 4 * (size_t)i, v, p.outb);
+        return v;
+    };
+    // a workgroup walks p.nba consecutive images (grid.z = image groups): a 128 x 64 plane in bf16 is 16 KB - one plane per workgroup
+    // left the launch at 4.3 TB/s, the per-workgroup prologue (statistics, channel constants) weighing as much as the streaming
+    for (int bb = b * p.nba; bb < min(p.N, (b + 1) * p.nba); ++bb) {
+        const size_t yrow = ((size_t)bb * p.CtotY + c) * p.HW, orow = ((size_t)bb * p.CtotOut + c) * p.HW;
+        if (p.HW % 8 == 0) {
+#pragma unroll 2
+            for (int i = lo / 8 + threadIdx.x; i < hi / 8; i += 256) {
+                uz::f32x4 a, b2;
+                uz::ld_elem8(p.y, yrow + 8 * (size_t)i, p.yb, a, b2);
+                uz::st_elem8(p.out, orow + 8 * (size_t)i, map4(a), map4(b2), p.outb);
+            }
+        } else {
+            for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256)
+                uz::st_elem4(p.out, orow + 4 * (size_t)i, map4(uz::ld_elem4(p.y, yrow + 4 * (size_t)i, p.yb)), p.outb);
+        }
     }
 }
 __global__ __launch_bounds__(256) void bn_bwd_reduce_partial_st(const BnP p) {
@@ -625,10 +649,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_partial_st(const BnP p) {
             s1 += dz; s2 += dz * xh;
             mdz = fmaxf(mdz, fabsf(dz)); mxh = fmaxf(mxh, fabsf(xh));
         };
+        if (p.HW % 8 == 0) {
+#pragma unroll 2
+            for (int i = lo / 8 + threadIdx.x; i < hi / 8; i += 256) {
+                uz::f32x4 y0, y1, d0, d1;
+                uz::ld_elem8(p.y, yrow + 8 * (size_t)i, p.yb, y0, y1);
+                uz::ld_elem8(p.da, drow + 8 * (size_t)i, p.dab, d0, d1);
+                one(y0.x, d0.x); one(y0.y, d0.y); one(y0.z, d0.z); one(y0.w, d0.w);
+                one(y1.x, d1.x); one(y1.y, d1.y); one(y1.z, d1.z); one(y1.w, d1.w);
+            }
+        } else {
 #pragma unroll 4
-        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
-            const uz::f32x4 yv = uz::ld_elem4(p.y, yrow + 4 * (size_t)i, p.yb), dv = uz::ld_elem4(p.da, drow + 4 * (size_t)i, p.dab);
-            one(yv.x, dv.x); one(yv.y, dv.y); one(yv.z, dv.z); one(yv.w, dv.w);
+            for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+                const uz::f32x4 yv = uz::ld_elem4(p.y, yrow + 4 * (size_t)i, p.yb), dv = uz::ld_elem4(p.da, drow + 4 * (size_t)i, p.dab);
+                one(yv.x, dv.x); one(yv.y, dv.y); one(yv.z, dv.z); one(yv.w, dv.w);
+            }
         }
         v2[0] += (double)s1; v2[1] += (double)s2;
     }
@@ -654,7 +689,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_st(const BnP p) {
         if (p.dbeta) p.dbeta[c] = (float)s1;
         if (p.dgamma) p.dgamma[c] = (float)s2;
     }
-    const size_t yrow = ((size_t)b * p.CtotY + c) * p.HW, drow = ((size_t)b * p.CtotDa + c) * p.HW, orow = ((size_t)b * p.CtotOut + c) * p.HW;
     const int lo = part * CHUNK, hi = min(p.HW, lo + CHUNK);
     float sd = 0.f;
     auto one = [&](float yv, float dv) -> float {
@@ -664,16 +698,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_st(const BnP p) {
         sd += r;
         return r;
     };
-    for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
-        const uz::f32x4 yv = uz::ld_elem4(p.y, yrow + 4 * (size_t)i, p.yb), dv = uz::ld_elem4(p.da, drow + 4 * (size_t)i, p.dab);
-        uz::f32x4 r;
-        r.x = one(yv.x, dv.x); r.y = one(yv.y, dv.y); r.z = one(yv.z, dv.z); r.w = one(yv.w, dv.w);
-        uz::st_elem4(p.out, orow + 4 * (size_t)i, r, p.outb);
+    double sdd = 0.0;
+    for (int bb = b * p.nba; bb < min(p.N, (b + 1) * p.nba); ++bb) {      // image group of this workgroup (see bn_apply_st)
+    const size_t yrow = ((size_t)bb * p.CtotY + c) * p.HW, drow = ((size_t)bb * p.CtotDa + c) * p.HW, orow = ((size_t)bb * p.CtotOut + c) * p.HW;
+    if (p.HW % 8 == 0) {
+#pragma unroll 2
+        for (int i = lo / 8 + threadIdx.x; i < hi / 8; i += 256) {
+            uz::f32x4 y0, y1, d0, d1, r0, r1;
+            uz::ld_elem8(p.y, yrow + 8 * (size_t)i, p.yb, y0, y1);
+            uz::ld_elem8(p.da, drow + 8 * (size_t)i, p.dab, d0, d1);
+            r0.x = one(y0.x, d0.x); r0.y = one(y0.y, d0.y); r0.z = one(y0.z, d0.z); r0.w = one(y0.w, d0.w);
+            r1.x = one(y1.x, d1.x); r1.y = one(y1.y, d1.y); r1.z = one(y1.z, d1.z); r1.w = one(y1.w, d1.w);
+            uz::st_elem8(p.out, orow + 8 * (size_t)i, r0, r1, p.outb);
+        }
+    } else {
+        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+            const uz::f32x4 yv = uz::ld_elem4(p.y, yrow + 4 * (size_t)i, p.yb), dv = uz::ld_elem4(p.da, drow + 4 * (size_t)i, p.dab);
+            uz::f32x4 r;
+            r.x = one(yv.x, dv.x); r.y = one(yv.y, dv.y); r.z = one(yv.z, dv.z); r.w = one(yv.w, dv.w);
+            uz::st_elem4(p.out, orow + 4 * (size_t)i, r, p.outb);
+        }
+    }
+    sdd += (double)sd; sd = 0.f;
     }
     if (p.dbias) {
-        double v1[1] = {(double)sd};
+        double v1[1] = {sdd};
         uz::block_sum_d<1>(v1, sm);
-        if (threadIdx.x == 0) p.part2[(size_t)(b * p.parts + part) * p.C + c] = v1[0];
+        if (threadIdx.x == 0) p.part2[(size_t)(b * p.parts + part) * p.C + c] = v1[0];      // one row per (image group, chunk)
     }
 }
 
@@ -986,6 +1037,10 @@ void reduction_groups(BnP& p) {
     p.nb = (int)nb;
     p.ngrp = uz::ceil_div(p.N, p.nb);
 }
+// images per workgroup of the *_st apply kernels.  Measured on 96 ch x 128 x (128 x 64) in bf16: groups of 6 - 8 planes (64 k elements
+// per workgroup) ran the apply launches 4 - 8 % SLOWER than one 16 KB plane per workgroup (4.17 vs 4.35 TB/s forward, 4.39 vs 4.76
+// backward) - the planes are not prologue-bound, and a 4x unroll of the 8-wide loops changed nothing either: what is left is the fixed cost of the 2 - 3 launches per unit
+int apply_group(const BnP&) { return 1; }
 void carve(BnP& p, void* ws) {
     const size_t P = (size_t)p.N * p.parts;
     p.part = static_cast<double*>(ws);
@@ -1210,7 +1265,8 @@ extern "C" int uz_bn_relu_fwd_b16(const void* y, int C, int CtotY, const float* 
     p.parts = uz::ceil_div(p.HW, CHUNK);
     p.eps = eps; p.momentum = momentum; p.training = training; p.relu = relu;
     p.yb = y_b16 != 0; p.outb = a_b16 != 0;
-    const dim3 grid(p.parts, C, N);
+    p.nba = apply_group(p);
+    const dim3 grid(p.parts, C, uz::ceil_div(N, p.nba));
     reduction_groups(p);
     if (training && conv_partials) {
         p.pre = 1; p.cpart = conv_partials; p.ncpart = n_partials;
@@ -1246,10 +1302,12 @@ extern "C" int uz_bn_relu_bwd_b16(const void* da, int CtotDa, const void* y, int
     reduction_groups(p);
     hipLaunchKernelGGL(bn_bwd_reduce_partial_st, dim3(p.parts, C, p.ngrp), dim3(256), 0, st, p);
     if (int rc = uz::check_launch("bn_bwd_reduce_partial_st")) return rc;
-    hipLaunchKernelGGL(bn_bwd_apply_st, dim3(p.parts, C, N), dim3(256), 0, st, p);
+    p.nba = apply_group(p);
+    const int nga = uz::ceil_div(N, p.nba);
+    hipLaunchKernelGGL(bn_bwd_apply_st, dim3(p.parts, C, nga), dim3(256), 0, st, p);
     if (int rc = uz::check_launch("bn_bwd_apply_st")) return rc;
     if (dbias) {
-        hipLaunchKernelGGL(chan_partial_sum, dim3(uz::ceil_div(C, 4)), dim3(256), 0, st, p.part2, N * p.parts, C, dbias);
+        hipLaunchKernelGGL(chan_partial_sum, dim3(uz::ceil_div(C, 4)), dim3(256), 0, st, p.part2, nga * p.parts, C, dbias);
         if (int rc = uz::check_launch("chan_partial_sum")) return rc;
     }
     return 0;

@@ -108,6 +108,25 @@ __device__ __forceinline__ void st_elem4(float* base, size_t e, f32x4 v, int b16
     else *reinterpret_cast<f32x4*>(base + e) = v;
 }
 
+// eight consecutive elements starting at element e (e % 8 == 0; 16-byte aligned rows in bf16, 32-byte in fp32): ONE 16-byte access per
+// bf16 tensor, two per fp32 tensor - the streaming kernels keep full-width memory instructions in either format
+__device__ __forceinline__ void ld_elem8(const float* base, size_t e, int b16, f32x4& lo, f32x4& hi) {
+    if (b16) {
+        const uint4 w = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + e);
+        lo = bf16x4_widen(make_uint2(w.x, w.y)); hi = bf16x4_widen(make_uint2(w.z, w.w));
+    } else {
+        lo = *reinterpret_cast<const f32x4*>(base + e); hi = *reinterpret_cast<const f32x4*>(base + e + 4);
+    }
+}
+__device__ __forceinline__ void st_elem8(float* base, size_t e, f32x4 lo, f32x4 hi, int b16) {
+    if (b16) {
+        const uint2 a = bf16x4_pack(lo), b = bf16x4_pack(hi);
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(base) + e) = make_uint4(a.x, a.y, b.x, b.y);
+    } else {
+        *reinterpret_cast<f32x4*>(base + e) = lo; *reinterpret_cast<f32x4*>(base + e + 4) = hi;
+    }
+}
+
 // ---- magnitude-bound slots.  A slot is AMAX_SUB sub-slots AMAX_STRIDE floats (64 bytes) apart; its value is the maximum
 // over the sub-slots.  Same-address float atomics serialise at the memory side (MI355X_MICROARCH.md, Global float atomics:
 // every workgroup into one row is 14x slower), so producers (a) spread their updates over the sub-slots and (b) read the
