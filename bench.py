@@ -283,6 +283,20 @@ def dominant_kernel_live(net, plan, L, heaviest, reps=20):
         # one product per MAC puts these layers on the memory side of the ridge for narrow channel counts: report the HBM view too
         out["hbm_view"] = dict(achieved_gbs=round(alg_bytes / ms / 1e6, 1), peak_gbs=HBM_PEAK_GBS, frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                                note="algorithmic bytes (input + output tensor once, at their storage width) / launch duration against 8 TB/s")
+    # bf16-STORAGE volume path: the PMC passes of tools/prof_b16.sh on the heaviest PHiSeg3D layer (profiles/r4_pmc_traffic_b16.json)
+    op_i = ops[k]["i"]
+    if len(op_i) > 13 and op_i[13]:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_traffic_b16.json")))
+            if f"{cin} -> {cout}" in pmc.get("layer", "") and kind in (0, 1, 2):
+                key = "wgrad_split_kernel<32, 64, 1, 2, 2>" if kind == 2 else "conv_b16_kernel_2_512_32"
+                e = pmc["kernels"][key]
+                out.update(traffic=e["hbm_bytes"], traffic_source="profiles/r4_pmc_traffic_b16.json", kernel=key,
+                           traffic_note="FETCH_SIZE + WRITE_SIZE per launch (L2 fills: Infinity-Cache hits included), calibrated; x %.2f of the algorithmic bytes - "
+                                        "the depth window reads every input slice for three output slices" % e["ratio"])
+                return out
+        except Exception:
+            pass
     for tabname in ("r4_layer_table.json", "r3_layer_table.json"):      # per-layer dispatch table (tools/prof_layers.sh), keyed on layer and direction; newest first
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", tabname)))
