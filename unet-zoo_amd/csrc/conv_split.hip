@@ -152,6 +152,9 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     constexpr int PPLANE = PSR * CK * 2;                 // bytes per patch plane
     constexpr int WVEC = NP * WPLANE / 16;               // 16-byte vectors of one packed weight block (2304 / 1152)
     constexpr int WREGS = (WVEC + NT - 1) / NT;          // per thread
+    // (bf16 single-product mode on the 32-wide geometry, round 4: DEEP 1 030 -> 1 208 us and DEEP + PREF 1 085 us on 288 -> 96 @ 128 x
+    //  (128 x 64) - that kernel is not waiting for its loads; timing-only builds with half the patch load instructions -13 %, with a
+    //  third of the B-fragment reads -2 %: neither the LDS reads nor the vector-memory issue rate alone is the bound)
     constexpr bool DEEP = TWv == 16;                     // patch loads two chunks ahead (see stage_deep)
     constexpr bool PREF = TWv == 16;                     // fragment reads one tap ahead of the MFMAs
 #ifndef UZ_UNCOND_TW
