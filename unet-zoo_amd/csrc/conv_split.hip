@@ -566,6 +566,8 @@ template <int MSUB, int NTv, int TWv, int NP, int MK, int XF> struct SplitKernel
     template <> struct SplitKernel<MSUB_, NT_, TW_, NP_, MK_, XF_> { static constexpr auto fn = name; };
 // (round 4: the 32-channel-tile kernels keep (512, 4) although that bound costs them ~30 spilled registers - with (512, 3), no spills
 //  but one workgroup per CU, 32 -> 32 @ 128 x 128 ran 55 -> 61 us forward and the PHiSeg step lost 0.8 %)
+// (round 4, single-product mode: (512, 4) = two workgroups per CU on the 64-channel-tile bf16 kernels needs 128 VGPRs - 168 in use, 76 - 80
+//  spilled into the chunk loop: 288 -> 96 @ 128 x (128 x 64) 1 030 -> 2 253 us, PHiSeg3D 34.9 -> 43.6 ms.  One workgroup per CU it stays.)
 UZ_SPLIT_KERNEL(conv_split_kernel_2_512_32, 2, 512, 32, 2, 0, 0, 1)
 UZ_SPLIT_KERNEL(conv_split_kernel_1_512_32, 1, 512, 32, 2, 0, 0, 4)
 UZ_SPLIT_KERNEL(conv_split_kernel_1_256_16, 1, 256, 16, 2, 0, 0, 2)
