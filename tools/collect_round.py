@@ -27,7 +27,7 @@ def last_json_line(path):
 
 
 names = {"phiseg": "bench_phiseg.json", "unet": "bench_unet.json", "probunet": "bench_probunet.json", "phiseg3d": "bench_phiseg3d.json",
-         "phiseg3d_f32split": "bench_phiseg3d_f32split.json", "phiseg3d_rev": "bench_phiseg3d_rev.json",
+         "phiseg3d_f32split": "bench_phiseg3d_f32split.json", "phiseg3d_f32storage": "bench_phiseg3d_f32storage.json", "phiseg3d_rev": "bench_phiseg3d_rev.json",
          "phiseg_bf16math": "bench_phiseg_bf16math.json", "2ranks_one_device": "bench_2ranks_one_device.json",
          "unet_cpu_b4": "bench_unet_cpu_b4.json"}
 lines = {k: last_json_line(os.path.join(src, v)) for k, v in names.items()}
@@ -42,5 +42,7 @@ lines["gpu_test_tier"] = tests
 json.dump(lines, open(os.path.join(dst, f"r{R}_bench_lines.json"), "w"), indent=1)
 # the PMC passes of prof_round.sh as one json (tools/pmc_to_json.py reads the three summaries)
 os.system(f"cd {root} && python tools/pmc_to_json.py {R} profiles/r{R}_pmc_fetch_size_summary.txt profiles/r{R}_pmc_write_size_summary.txt profiles/r{R}_pmc_mfma_busy_summary.txt > /dev/null")
+if os.path.exists(os.path.join(dst, f"r{R}_pmc_b16_fetch_size_summary.txt")):
+    os.system(f"cd {root} && python tools/pmc_b16_to_json.py {R} profiles/r{R}_pmc_b16_fetch_size_summary.txt profiles/r{R}_pmc_b16_write_size_summary.txt > /dev/null")
 print("copied", len(copied), "files;", "bench lines:", ", ".join(f"{k}={v.get('value')}" for k, v in lines.items() if isinstance(v, dict) and "value" in v))
 print("gpu tests:", tests)

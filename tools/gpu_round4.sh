@@ -10,6 +10,7 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/bench_phiseg.json 2> gpurun_o
 for m in unet probunet phiseg3d; do
   python bench.py --model $m --steps 20 --warmup 5 > gpurun_out/bench_$m.json 2> gpurun_out/bench_$m.err; echo "bench $m rc=$?"; cut -c1-200 gpurun_out/bench_$m.json
 done
+python bench.py --model phiseg3d --storage f32 --steps 20 --warmup 5 --skip-cpu > gpurun_out/bench_phiseg3d_f32storage.json 2>/dev/null; cut -c1-200 gpurun_out/bench_phiseg3d_f32storage.json
 python bench.py --model phiseg3d --conv-math default --steps 10 --warmup 3 --skip-cpu --no-profile > gpurun_out/bench_phiseg3d_f32split.json 2>/dev/null; cut -c1-200 gpurun_out/bench_phiseg3d_f32split.json
 python bench.py --conv-math bf16 --steps 20 --warmup 5 --skip-cpu --no-profile --no-f32-leg > gpurun_out/bench_phiseg_bf16math.json 2>/dev/null; cut -c1-200 gpurun_out/bench_phiseg_bf16math.json
 python bench.py --model phiseg3d --reversible --steps 10 --warmup 3 --skip-cpu --no-profile > gpurun_out/bench_phiseg3d_rev.json 2> gpurun_out/bench_phiseg3d_rev.err; cut -c1-200 gpurun_out/bench_phiseg3d_rev.json
@@ -30,3 +31,5 @@ for m in unet probunet phiseg3d; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$m -- python bench.py --model $m --steps 10 --warmup 5 --skip-cpu --no-profile --no-f32-leg > gpurun_out/prof_${m}_line.json 2>/dev/null
   cp $(ls gpurun_out/prof_$m/*/*kernel_stats.csv | head -1) gpurun_out/r4_bench_kernel_stats_graph_$m.csv; rm -rf gpurun_out/prof_$m
 done
+# bf16-storage volume path: kernel statistics of its bench run and the PMC passes on its heaviest layer
+bash tools/prof_b16.sh 4 > gpurun_out/prof_b16.log 2>&1; tail -4 gpurun_out/prof_b16.log | cut -c1-200
