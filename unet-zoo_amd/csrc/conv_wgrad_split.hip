@@ -402,6 +402,21 @@ int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
     const int T = N * ceil_div(H, PT / tw) * (W / tw);
     static const int target = getenv("UZ_WGS_TARGET") ? atoi(getenv("UZ_WGS_TARGET")) : 256;
     int s = target / nt;                               // one workgroup per CU either way (the 32-channel kernel's 166 VGPRs allow no second one: 512 splits measured 6 % slower)
+    // ... but every split writes (and the reduction reads back) a full 9 x Cout x Cin slab: on the 32 x 32 and 16 x 16 planes that
+    // traffic exceeds the operands' own (192 -> 192 @ 32 x 16 x 16: 12.6 MB of x and dy against 74 MB of slabs at 28 splits).  Cap the
+    // splits where the slabs would outweigh the operands by more than 1 / UZ_WGS_K, never below UZ_WGS_MINWG workgroups (round 4: measured
+    // on the STEP, not per layer - in isolation more workgroups always win, in the step the other lane fills the CUs a shorter grid leaves
+    // free: PHiSeg 1 749 -> 1 775 - 1 780 images/s at K = 1, MINWG = 128; K = 0.5 the same, K = 2 / 4 +0.8 / +0.6 %, MINWG = 32 -0.3 %;
+    // a uniform target of 128 instead of 256 workgroups +1.3 %, of 64 -9.6 %)
+    static const double kslab = getenv("UZ_WGS_K") ? atof(getenv("UZ_WGS_K")) : 1.0;
+    static const int smin_wg = getenv("UZ_WGS_MINWG") ? atoi(getenv("UZ_WGS_MINWG")) : 128;
+    if (kslab > 0.0) {
+        const double operands = 4.0 * (double)N * H * W * ((double)Cin + Cout), slab = 2.0 * 4.0 * 9.0 * (double)Cin * Cout;
+        int cap = (int)(operands / (kslab * slab));
+        const int floor_s = ceil_div(smin_wg, nt);
+        if (cap < floor_s) cap = floor_s;
+        if (s > cap) s = cap;
+    }
     if (s < 1) s = 1;
     if (s > T) s = T;
     return s;
