@@ -195,6 +195,28 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
         }
         goff[j] = g; gmask[j] = gm;
     }
+    // XB (bf16 storage): the own rows are staged in PAIRS - threads 2 j and 2 j + 1 hold the patch pixels 2 j and 2 j + 1 (same patch row:
+    // PW is even); each loads ONE dword = both pixels of a channel, thread 2 j for channels 0 - 7, thread 2 j + 1 for channels 8 - 15, and
+    // the two exchange the halves that belong to the other's pixel through a DPP move.  8 load instructions per thread and chunk instead of
+    // 16 (a timing-only build with half the patch load instructions ran the single-product kernels 10 - 13 % faster: with one MFMA per
+    // operand pair the vector-memory ISSUE rate counts, not the bytes).  The pair's dword starts at an odd column (2-byte aligned: fine
+    // for buffer loads on gfx950, tools/micro/unaligned_buf.hip); at the image borders it is fetched one column further in and the
+    // field extraction below picks / zeroes the right half: my* / ot* = (bit offset, width) of this thread's own pixel and of its
+    // partner's pixel inside the loaded dword (width 0 = padding).
+    const int h2 = tid & 1;
+    unsigned gpair = 0, gpmask = 0xFFFFFFFFu, my_off = 0, my_w = 0, ot_off = 0, ot_w = 0;
+    if constexpr (XB) {
+        const int rp = tid & ~1, py = rp / PW, px = rp - py * PW;
+        const int yy = y0 + py - 1, c0 = x0 + px - 1;            // image columns c0 (even pixel of the pair), c0 + 1 (odd pixel)
+        if (yy >= 0 && yy < p.H && c0 < p.W && p.W >= 2) {
+            int col = c0, e_off = 0, e_w = 16, o_off = 16, o_w = 16;        // fields of the even / odd pixel in the dword loaded at `col`
+            if (c0 < 0) { col = 0; e_w = 0; o_off = 0; }                    // left image border: load (0, 1), the odd pixel is its low half
+            else if (c0 + 1 >= p.W) { col = p.W - 2; e_off = 16; o_w = 0; } // right border: load (W - 2, W - 1), the even pixel is its high half
+            gpair = ESZ * (unsigned)(yy * p.W + col); gpmask = 0;
+            my_off = h2 ? o_off : e_off; my_w = h2 ? o_w : e_w;
+            ot_off = h2 ? e_off : o_off; ot_w = h2 ? e_w : o_w;
+        }
+    }
     const int prow1 = NT + tid / G, q4 = tid & (G - 1);
     const unsigned xstep = ESZ * (unsigned)p.HW;
     const unsigned wblock = (unsigned)NP * WPLANE;
@@ -217,6 +239,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+    unsigned pw[XB ? 8 : 1], mypk[XB ? 4 : 1], rcpk[XB ? 4 : 1];      // XB: the pair dwords of this thread's 8 channels; packed channel pairs of its own pixel (own / received)
     float pr[CK], pr1[CE];            // raw patch values of the next chunk: own row, share of an extra row
     unsigned pk[NP][CK / 2], pk1[NP][CE / 2]; // ... and their two fp16 planes, packed pairwise as they get split
     u32x4 wq[WREGS];
@@ -233,6 +256,12 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     };
     auto patch_loads = [&](int c, int part) {
         const int k0 = c * CK;
+        if constexpr (XB) {           // one dword (both pixels of the pair) of channel 8 h2 + part
+            const int k = 8 * h2 + part;
+            const unsigned kvm = (k0 + k) < p.Cin ? 0u : 0xFFFFFFFFu;
+            pw[part] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rx, (gpair + (unsigned)(k0 + k) * xstep) | gpmask | kvm, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int k = 2 * part + kk;
@@ -262,11 +291,19 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     };
     auto convert = [&](int j) {              // split / round the values of k 4j .. 4j + 3 (j = 0 also the shared-row share)
         const int i0 = 2 * j;
+        if constexpr (XB) {
+            // pair dwords 2 j, 2 j + 1 (channels 8 h2 + 2 j, + 1): own pixel's halves stay, the partner pixel's halves go to the partner
+            const unsigned m0 = __builtin_amdgcn_ubfe(pw[2 * j], my_off, my_w), m1 = __builtin_amdgcn_ubfe(pw[2 * j + 1], my_off, my_w);
+            const unsigned o0 = __builtin_amdgcn_ubfe(pw[2 * j], ot_off, ot_w), o1 = __builtin_amdgcn_ubfe(pw[2 * j + 1], ot_off, ot_w);
+            mypk[j] = m0 | (m1 << 16);
+            rcpk[j] = (unsigned)__builtin_amdgcn_mov_dpp((int)(o0 | (o1 << 16)), 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]: lane ^ 1
+        } else {
         unsigned t0[NP], t1[NP];
         pair_pieces(pr[2 * i0], pr[2 * i0 + 1], t0);
         pair_pieces(pr[2 * i0 + 2], pr[2 * i0 + 3], t1);
 #pragma unroll
         for (int q = 0; q < NP; ++q) { pk[q][i0] = t0[q]; pk[q][i0 + 1] = t1[q]; }
+        }
         if (j == 0) {
 #pragma unroll
             for (int i = 0; i < CE / 2; ++i) {
@@ -305,10 +342,15 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     };
     auto lstore = [&]() {
         char* dst = Pl + tid * 16;
+        if constexpr (XB) {           // this thread loaded channels 8 h2 .. 8 h2 + 7 itself and received the other eight
+            *reinterpret_cast<u32x4*>(dst + (h2 ? PPLANE / 2 : 0)) = u32x4{mypk[0], mypk[1], mypk[2], mypk[3]};
+            *reinterpret_cast<u32x4*>(dst + (h2 ? 0 : PPLANE / 2)) = u32x4{rcpk[0], rcpk[1], rcpk[2], rcpk[3]};
+        } else {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             *reinterpret_cast<u32x4*>(dst + q * PPLANE) = u32x4{pk[q][0], pk[q][1], pk[q][2], pk[q][3]};                     // k 0..7
             *reinterpret_cast<u32x4*>(dst + q * PPLANE + PPLANE / 2) = u32x4{pk[q][4], pk[q][5], pk[q][6], pk[q][7]};       // k 8..15
+        }
         }
         // shared rows: this thread holds channels [CE * q4, CE * q4 + CE) of row prow1 (CE = 4: 8 bytes, CE = 8: one 16-byte piece)
         char* dst1 = Pl + prow1 * 16 + ((CE * q4) >> 3) * (PPLANE / 2) + ((CE * q4) & 7) * 2;
