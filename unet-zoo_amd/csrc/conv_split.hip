@@ -203,6 +203,9 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     // for buffer loads on gfx950, tools/micro/unaligned_buf.hip); at the image borders it is fetched one column further in and the
     // field extraction below picks / zeroes the right half: my* / ot* = (bit offset, width) of this thread's own pixel and of its
     // partner's pixel inside the loaded dword (width 0 = padding).
+    // (The same scheme for 4-byte elements - 8-byte pair loads of fp32 values / split-storage words - was built and measured: isolated
+    //  kernels +-1 % (768 -> 778 us on 224 -> 128 @ 128 x 128), PHiSeg step +0.5 % inside the noise: with three MFMAs per operand pair the
+    //  load issue rate is not what limits the two-piece kernels.  Not kept.)
     const int h2 = tid & 1;
     unsigned gpair = 0, gpmask = 0xFFFFFFFFu, my_off = 0, my_w = 0, ot_off = 0, ot_w = 0;
     if constexpr (XB) {
