@@ -561,11 +561,12 @@ WGeom pick_wgeom(int Cin, int Cout, int N, int H, int W, int halo) {
         const double px = (double)g.TW * g.TH * g.TB;
         const double t_tile = (32.0 * g.WM) * (32.0 * g.WN) * kk * px * 2.0 / (613e9 * 0.6) + 1.0e-6;   // s per tile per workgroup
         const int slots = 256 * ((g.WM * g.WN == 4 && halo) ? 1 : 2);
+        static const double slabcost = getenv("UZ_WG_SLABCOST") ? atof(getenv("UZ_WG_SLABCOST")) : 1.0;      // weight of the slab traffic in the model (step-level tuning knob)
         double best = 1e30;
         int s = 1;
         for (int c = 1; c <= g.T && c <= 4096; ++c) {       // any split count: nt * c should land just under a whole number of rounds
             const double rounds = ceil((double)nt * c / slots);
-            const double t = rounds * ceil((double)g.T / c) * t_tile + (double)c * g.SW * n_out * 4.0 * 2.0 / 2.5e12 + 4e-6 * (c * g.SW > 64 ? 2 : 1);
+            const double t = rounds * ceil((double)g.T / c) * t_tile + slabcost * (double)c * g.SW * n_out * 4.0 * 2.0 / 2.5e12 + 4e-6 * (c * g.SW > 64 ? 2 : 1);
             if (t < best) { best = t; s = c; }
         }
         g.S = s;

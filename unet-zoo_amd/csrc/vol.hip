@@ -285,7 +285,10 @@ extern "C" int uz_absmax_copy(const float* src_slot, float* dst_slot, void* stre
 }
 extern "C" int uz_w3d_permute(const float* src, float* dst, int Cout, int Cin, int mode, void* stream) {
     UZ_REQUIRE(src && dst && Cout > 0 && Cin > 0 && mode >= 0 && mode <= 2, "w3d_permute: bad arguments");
-    hipLaunchKernelGGL(w3d_permute_k, dim3(gx(Cout * Cin * 27)), dim3(256), 0, uz::S(stream), src, dst, Cout, Cin, mode);
+    // (up to 27 x 256 x 256 elements: a grid capped at 64 workgroups walked 64 elements per thread and took 26 us a launch, 72 launches a step)
+    int g = (Cout * Cin * 27 + 255) / 256;
+    g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    hipLaunchKernelGGL(w3d_permute_k, dim3(g), dim3(256), 0, uz::S(stream), src, dst, Cout, Cin, mode);
     return uz::check_launch("w3d_permute_k");
 }
 extern "C" int uz_avgpool3d_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int D, int H, int W, void* stream) {
