@@ -78,8 +78,13 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
     constexpr int QROW = TW / 4, SROW = TW / 16;          // float4 quads / 16-pixel k-steps per tile row
     constexpr int COT = CT, CIT = CT, WK = CT == 64 ? 1 : 4;
     constexpr int DYPLANE = COT * DYROW, XPLANE = CIT * XCH;
-    constexpr int DYSLOTS = COT * PT / 4 / NT;            // float4 per thread: 4 / 2
-    constexpr int XQSLOTS = (CIT * PROWS * QROWX + NT - 1) / NT;     // quads per thread: 6 / 5 (64 channels), 3 (32 channels)
+    // pixels per staging slot = one 16-byte load: 4 (fp32 values / split-storage words) or 8 (bf16 storage - half as many load
+    // instructions per tile, which is what the single-product kernels are short of: a timing-only build with half the loads ran 5 - 12 % faster)
+    constexpr int XPIX = XB ? 8 : 4, DPIX = DB ? 8 : 4;
+    constexpr int DQ = PT / DPIX, DQROW = TW / DPIX;      // dY slots per co row of the tile, per tile row
+    constexpr int XQ = TW / XPIX;                         // X slots per patch row (+ the pair slot of its last two pixels)
+    constexpr int DYSLOTS = COT * DQ / NT;                // per thread: 4 / 2 (2 / 1 in bf16 storage)
+    constexpr int XQSLOTS = (CIT * PROWS * XQ + NT - 1) / NT;        // per thread: 6 / 5 (64 channels), 3 (32 channels); half of that in bf16 storage
     constexpr int XPSLOTS = (CIT * PROWS + NT - 1) / NT;             // pairs per thread: 1 / 2
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dYl = lds;
@@ -122,12 +127,10 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
 #pragma unroll
         for (int i = 0; i < DYSLOTS; ++i) {
             if (part >= 0 && i % NPARTS != part % NPARTS) continue;
-            const int e = tid + i * NT, co = e >> 5, q = e & 31, row = q / QROW, c4 = (q % QROW) * 4;
+            const int e = tid + i * NT, co = e / DQ, q = e % DQ, row = q / DQROW, c4 = (q % DQROW) * DPIX;
             const unsigned m = ((y0 + row) < p.H && (co0 + co) < p.Cout) ? 0u : 0xFFFFFFFFu;      // all-ones: the range check returns 0
-            if constexpr (DB) {                         // four bf16 pixels: 8 bytes, staged as they are
-                const uz::f32x2 t = __builtin_bit_cast(uz::f32x2, __builtin_amdgcn_raw_buffer_load_b64(rdy, (dbase + DE * (unsigned)(co * p.HW + row * p.W + c4)) | m, 0, 0));
-                dreg[i][0] = t.x; dreg[i][1] = t.y;
-            } else dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (dbase + DE * (unsigned)(co * p.HW + row * p.W + c4)) | m, 0, 0));
+            // (DB: eight bf16 pixels in the same 16 bytes, staged as they are)
+            dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (dbase + DE * (unsigned)(co * p.HW + row * p.W + c4)) | m, 0, 0));
         }
         // X patch: a quad slot is 4 consecutive patch pixels of one row (patch pixels 4 q .. 4 q + 3 = image columns x0 - 1 + 4 q ..):
         // one 16-byte load (dword aligned; a wave's lanes read one contiguous run) whose LDS image is one aligned 8-byte store per
@@ -138,16 +141,14 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         for (int i = 0; i < XQSLOTS; ++i) {
             if (part >= 0 && (i + DYSLOTS) % NPARTS != part % NPARTS) continue;
             const int e = tid + i * NT;
-            const int q = e % QROWX, r = e / QROWX, ci = r / PROWS, prow = r - ci * PROWS;
+            const int q = e % XQ, r = e / XQ, ci = r / PROWS, prow = r - ci * PROWS;
             const int yy = y0 + prow - 1;
-            const bool rowok = e < CIT * PROWS * QROWX && (ci0 + ci) < p.Cin && yy >= 0 && yy < p.H;
-            const int sh = (q == 0 && x0 == 0) ? 1 : 0;           // image column -1: load columns 0..3 and shift (never reads before the row)
-            const int off = xbase + ci * p.HW + (prow - 1) * p.W + 4 * q - 1 + sh;
+            const bool rowok = e < CIT * PROWS * XQ && (ci0 + ci) < p.Cin && yy >= 0 && yy < p.H;
+            const int sh = (q == 0 && x0 == 0) ? 1 : 0;           // image column -1: load columns 0.. and shift (never reads before the row)
+            const int off = xbase + ci * p.HW + (prow - 1) * p.W + XPIX * q - 1 + sh;
             // (the shift itself happens in lstore: a use of the loaded value here would wait for the load inside the MFMA loop)
-            if constexpr (XB) {                         // (a 2-byte aligned 8-byte load: the quad starts at an odd column)
-                const uz::f32x2 t = __builtin_bit_cast(uz::f32x2, __builtin_amdgcn_raw_buffer_load_b64(rxx, rowok ? XE * (unsigned)off : 0xFFFFFFFFu, 0, 0));
-                xq[i][0] = t.x; xq[i][1] = t.y;
-            } else xq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxx, rowok ? XE * (unsigned)off : 0xFFFFFFFFu, 0, 0));
+            // (XB: eight bf16 pixels, a 2-byte aligned 16-byte load - the slot starts at an odd column)
+            xq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxx, rowok ? XE * (unsigned)off : 0xFFFFFFFFu, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < XPSLOTS; ++i) {
@@ -180,36 +181,36 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         const bool left_edge = t % p.tilesX == 0;               // tile column 0: the quads with q == 0 were loaded one column to the right
 #pragma unroll
         for (int i = 0; i < DYSLOTS; ++i) {
-            unsigned pa[NP], pb[NP];
-            if constexpr (DB) { pa[0] = uz::fbits(dreg[i][0]); pb[0] = uz::fbits(dreg[i][1]); }
+            const int e = tid + i * NT, co = e / DQ, q = e % DQ;
+            char* d = dYl + co * DYROW + ((q / DQROW) * TW + (q % DQROW) * DPIX) * 2;
+            if constexpr (DB) *reinterpret_cast<u32x4*>(d) = __builtin_bit_cast(u32x4, dreg[i]);
             else {
+                unsigned pa[NP], pb[NP];
                 dpieces(dreg[i][0], dreg[i][1], pa);
                 dpieces(dreg[i][2], dreg[i][3], pb);
-            }
-            const int e = tid + i * NT, co = e >> 5, q = e & 31;
-            char* d = dYl + co * DYROW + ((q / QROW) * TW + (q % QROW) * 4) * 2;
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * DYPLANE) = make_uint2(pa[pl], pb[pl]);
+                for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * DYPLANE) = make_uint2(pa[pl], pb[pl]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < XQSLOTS; ++i) {
             const int e = tid + i * NT;
-            if (e < CIT * PROWS * QROWX) {
-                const int q = e % QROWX, r = e / QROWX, ci = r / PROWS, prow = r - ci * PROWS;
-                unsigned pa[NP], pb[NP];
+            if (e < CIT * PROWS * XQ) {
+                const int q = e % XQ, r = e / XQ, ci = r / PROWS, prow = r - ci * PROWS;
+                char* d = Xl + ci * XCH + prow * XROW + q * (2 * XPIX);
                 if constexpr (XB) {
-                    const unsigned w0 = uz::fbits(xq[i][0]), w1 = uz::fbits(xq[i][1]);
-                    const bool sh = left_edge && q == 0;          // columns 0..2 were loaded into pixels 0..2: move them to pixels 1..3, pixel 0 = padding
-                    pa[0] = sh ? w0 << 16 : w0;
-                    pb[0] = sh ? __builtin_amdgcn_alignbit(w1, w0, 16) : w1;
+                    const u32x4 w = __builtin_bit_cast(u32x4, xq[i]);
+                    // left image edge: columns 0..6 were loaded into pixels 0..6 - move them one pixel up, pixel 0 = padding
+                    const u32x4 ws = u32x4{w.x << 16, __builtin_amdgcn_alignbit(w.y, w.x, 16), __builtin_amdgcn_alignbit(w.z, w.y, 16), __builtin_amdgcn_alignbit(w.w, w.z, 16)};
+                    *reinterpret_cast<u32x4*>(d) = (left_edge && q == 0) ? ws : w;
                 } else {
+                    unsigned pa[NP], pb[NP];
                     const f32x4 v = (left_edge && q == 0) ? f32x4{0.f, xq[i][0], xq[i][1], xq[i][2]} : xq[i];
                     xpieces(v[0], v[1], pa);
                     xpieces(v[2], v[3], pb);
-                }
-                char* d = Xl + ci * XCH + prow * XROW + q * 8;
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * XPLANE) = make_uint2(pa[pl], pb[pl]);
+                    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * XPLANE) = make_uint2(pa[pl], pb[pl]);
+                }
             }
         }
 #pragma unroll
