@@ -265,10 +265,18 @@ def test_phiseg_plan_round4_passes(monkeypatch):
     n3 = sum(o["code"] == "UZ_OP_BN_RELU_BWD" and o["i"][10] == 1 for o in plan.bwd_ops)
     assert 10 <= info["dy_packed"] <= n3
     assert sum(o["code"] == "UZ_OP_CHAN_SUM_TABLE" for o in plan.bwd_ops) == (1 if n3 else 0)
-    # weight-gradient slab reductions: one table-driven launch for all 3 x 3 layers, none inside the layers' own ops
+    # weight-gradient slab reductions: table-driven launches over chunks of 16 layers in backward order (each chunk is ready as soon as ITS
+    # layers' slabs are written and runs beside the rest of the backward pass), none inside the layers' own ops; every layer in exactly one
     tab = [o for o in plan.bwd_ops if o["code"] == "UZ_OP_WGRAD_REDUCE_TABLE"]
     wg = [o for o in plan.bwd_ops if o["code"] == "UZ_OP_CONV_BWD_WEIGHT" and o["i"][7] == 3]
-    assert len(tab) == 1 and tab[0]["i"][0] == len(wg) == 106 and all(o["i"][11] == 1 and o["p"][8] is not None for o in wg)
+    assert len(tab) == 7 and sum(t["i"][0] for t in tab) == len(wg) == 106 and all(o["i"][11] == 1 and o["p"][8] is not None for o in wg)
+    assert max(t["i"][0] for t in tab) == 16
+    reduced = [k for t in tab for k in t["p"][1][1]]
+    assert len(reduced) == len(set(reduced)) == 106
+    for t in tab:                                                     # a chunk's table sits behind every weight gradient it reduces
+        pos = plan.bwd_ops.index(t)
+        slabs = {id(q.buf) for q in plan.ptr_tables[t["p"][0][1]] if hasattr(q, "buf")}
+        assert all(plan.bwd_ops.index(o) < pos for o in wg if id(o["p"][8].buf) in slabs)
     monkeypatch.setenv("UZ_LANES", "2")
     plan2 = PHISeg(1, 2, [32, 64, 128, 192, 192, 192, 192], device="cpu")
     plan2.train()

@@ -1371,13 +1371,20 @@ class Plan:
                 self._dbias_jobs = []
             jobs = self.__dict__.get("_wgrad_jobs", [])
             if jobs:
-                refs, blk = [], 0
-                for slabbuf, wkey, nslab, co, ci, kk in jobs:
-                    refs += [slabbuf, self.G(wkey), ("raw", nslab), ("raw", co), ("raw", ci), ("raw", kk), ("raw", blk), ("raw", 0)]
-                    blk += self.L.uz_wgrad_reduce_blocks(ci, co, 3 if kk == 9 else 1)
-                self._newgroup()
-                self._emit(self.bwd_ops, "UZ_OP_WGRAD_REDUCE_TABLE",
-                           p=[self.ptr_table(refs), ("gflat_keys", tuple(j[1] for j in jobs))], i=[len(jobs), blk])
+                # One launch for ALL layers sits behind the last weight gradient of the tape - 0.3 - 0.4 ms of streaming with nothing else left
+                # to run beside it.  In chunks of UZ_WGRAD_TABLE_CHUNK layers (emission = backward order) every chunk is a scheduling group
+                # that becomes ready when ITS layers' slabs are written, and the lane scheduler runs it beside the rest of the backward pass.
+                chunk = int(os.environ.get("UZ_WGRAD_TABLE_CHUNK", "16"))
+                chunk = len(jobs) if chunk <= 0 else chunk
+                for j0 in range(0, len(jobs), chunk):
+                    part = jobs[j0:j0 + chunk]
+                    refs, blk = [], 0
+                    for slabbuf, wkey, nslab, co, ci, kk in part:
+                        refs += [slabbuf, self.G(wkey), ("raw", nslab), ("raw", co), ("raw", ci), ("raw", kk), ("raw", blk), ("raw", 0)]
+                        blk += self.L.uz_wgrad_reduce_blocks(ci, co, 3 if kk == 9 else 1)
+                    self._newgroup()
+                    self._emit(self.bwd_ops, "UZ_OP_WGRAD_REDUCE_TABLE",
+                               p=[self.ptr_table(refs), ("gflat_keys", tuple(j[1] for j in part))], i=[len(part), blk])
                 self._wgrad_jobs = []
             # data parallel: one event per gradient bucket, recorded as soon as every writer of that slice of the flat
             # gradient buffer is done (the scheduler hoists the marker to that point of the DAG); the communication
