@@ -401,10 +401,10 @@ int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
     const int nt = ceil_div(Cout, ct) * ceil_div(Cin, ct);
     const int tw = tile_w(W);
     const int T = N * ceil_div(H, PT / tw) * (W / tw);
-    static const int target = getenv("UZ_WGS_TARGET") ? atoi(getenv("UZ_WGS_TARGET")) : 192;
-    // one workgroup per CU either way (the 32-channel kernel's 166 VGPRs allow no second one: 512 splits measured 6 % slower); 192 rather
-    // than 256 workgroups: per layer 256 is fastest, in the STEP 192 is (+0.5 %, three alternations: 1 767 / 1 771 / 1 776 / 1 769 images/s at
-    // 256 / 224 / 192 / 160) - a quarter of the CUs stays with the other lane's launches
+    static const int target = getenv("UZ_WGS_TARGET") ? atoi(getenv("UZ_WGS_TARGET")) : 256;
+    // one workgroup per CU either way (the 32-channel kernel's 166 VGPRs allow no second one: 512 splits measured 6 % slower).  (192
+    // workgroups measured +0.5 % on the STEP - a quarter of the CUs stays with the other lane - but the heaviest launch itself 767 -> 909 us
+    // with 1.35x -> 1.77x its algorithmic HBM traffic: not kept.)
     int s = target / nt;
     // ... but every split writes (and the reduction reads back) a full 9 x Cout x Cin slab: on the 32 x 32 and 16 x 16 planes that
     // traffic exceeds the operands' own (192 -> 192 @ 32 x 16 x 16: 12.6 MB of x and dy against 74 MB of slabs at 28 splits).  Cap the
