@@ -212,8 +212,14 @@ __global__ __launch_bounds__(256) void bilinear_bwd_sep_k(const RsP p) {   // sr
                     const unsigned wa = v0 ? row[0] : 0u, wm = row[1], wz = v2 ? row[2] : 0u;
                     a = make_float2(uz::bf16_lo(wa), uz::bf16_hi(wa)); m = make_float2(uz::bf16_lo(wm), uz::bf16_hi(wm)); z = make_float2(uz::bf16_lo(wz), uz::bf16_hi(wz));
                 } else {
-                    const float2* row = reinterpret_cast<const float2*>(s + (size_t)oy * p.Wo + 2 * ix - 2);
-                    a = v0 ? row[0] : make_float2(0.f, 0.f); m = row[1]; z = v2 ? row[2] : make_float2(0.f, 0.f);
+                    // ONE aligned float2 per lane (high-res columns 2 ix, 2 ix + 1); the pairs to its left and right are the neighbouring
+                    // lanes' loads (a wave holds whole rows: 256 % W == 0 and W <= 64) - a third of the load instructions, no re-reads
+                    // through the vector L1 (three overlapping float2 per lane: 150 - 160 us on 192 ch 64 x 64 -> 128 x 128, this way 140 - 147 us = 3.4 - 3.6 TB/s;
+                    // 128 ch: 98 -> 87 us)
+                    m = *reinterpret_cast<const float2*>(s + (size_t)oy * p.Wo + 2 * ix);
+                    const float ax = __shfl_up(m.x, 1), ay = __shfl_up(m.y, 1), zx = __shfl_down(m.x, 1), zy = __shfl_down(m.y, 1);
+                    a = v0 ? make_float2(ax, ay) : make_float2(0.f, 0.f);
+                    z = v2 ? make_float2(zx, zy) : make_float2(0.f, 0.f);
                 }
                 acc = wx[0] * a.x + wx[1] * a.y + wx[2] * m.x + wx[3] * m.y + wx[4] * z.x + wx[5] * z.y;
             }
