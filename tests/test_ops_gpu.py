@@ -422,7 +422,7 @@ def test_bilinear(ac, H, W):
     assert g.maxabs(dx, 2 * x.grad) <= 2e-5
 
 
-@pytest.mark.parametrize("f", [1, 2, 16])
+@pytest.mark.parametrize("f", [1, 2, 8, 16])
 def test_nearest(f):
     g = _g()
     N, C, H, W = 2, 2, 8, 8
@@ -436,6 +436,8 @@ def test_nearest(f):
     dx = torch.empty(N, C, H, W, device=g.dev())
     g.call("uz_nearest_bwd", dy.to(g.dev()), C, C, dx, C, N, H, W, f, 0)
     assert g.maxabs(dx, x.grad) <= 1e-4
+    g.call("uz_nearest_bwd", dy.to(g.dev()), C, C, dx, C, N, H, W, f, 1)               # accumulate (f >= 8: one wave per element)
+    assert g.maxabs(dx, 2 * x.grad) <= 2e-4
 
 
 def test_spatial_mean_and_bcast():

@@ -520,11 +520,39 @@ extern "C" int uz_nearest_fwd(const float* x, int C, int CtotX, float* y, int Ct
     p.H = H; p.W = W; p.Ho = H * factor; p.Wo = W * factor; p.factor = factor;
     RS_LAUNCH(nearest_fwd_k, p.Ho * p.Wo);
 }
+namespace {
+// Large factors (the deep levels' logits resized to full resolution, phiseg.py:321: 8 x 8 and 16 x 16 children per element): one WAVE per
+// low-resolution element - its lanes stride over the children (x fastest: coalesced runs of `factor` floats), butterfly sum, lane 0
+// writes - instead of one thread walking 64 - 256 strided values (25 us a launch at the head of the backward tape).  The children are
+// added in a different order than nearest_bwd_k adds them: rounding-level difference (sum of f^2 fp32 values).
+__global__ __launch_bounds__(256) void nearest_bwd_wave_k(const RsP p) {
+    const int c = blockIdx.y, b = blockIdx.z, n = p.H * p.W;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= n) return;
+    const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
+    const int iy = q / p.W, ix = q - iy * p.W, f = p.factor, m = f * f;
+    float acc = 0.f;
+    for (int e = lane; e < m; e += 64) {
+        const int yy = e / f, xx = e - yy * f;
+        acc += s[(size_t)(iy * f + yy) * p.Wo + ix * f + xx];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+        float* d = p.dst + ((size_t)b * p.CtotD + c) * n + q;
+        *d = p.accumulate ? *d + acc : acc;
+    }
+}
+}  // namespace
 extern "C" int uz_nearest_bwd(const float* dy, int C, int CtotDy, float* dx, int CtotDx, int N, int H, int W, int factor, int accumulate, void* stream) {
     if (int rc = check_dims("nearest_bwd", C, N, H, W)) return rc;
     UZ_REQUIRE(factor >= 1, "nearest_bwd: factor must be >= 1");
     RsP p = {}; p.src = dy; p.dst = dx; p.C = C; p.CtotS = CtotDy; p.CtotD = CtotDx; p.N = N;
     p.H = H; p.W = W; p.Ho = H * factor; p.Wo = W * factor; p.factor = factor; p.accumulate = accumulate;
+    if (factor * factor >= 64 && (H * W + 3) / 4 <= 65535) {
+        hipLaunchKernelGGL(nearest_bwd_wave_k, dim3((H * W + 3) / 4, C, N), dim3(256), 0, uz::S(stream), p);
+        return uz::check_launch("nearest_bwd_wave_k");
+    }
     RS_LAUNCH(nearest_bwd_k, H * W);
 }
 extern "C" int uz_spatial_mean_fwd(const float* x, int C, int CtotX, float* y, int N, int H, int W, void* stream) {
