@@ -104,6 +104,15 @@ def test_bf16_storage_pass_marks_buffers_and_operands_consistently(monkeypatch):
     assert flagged >= 100
     for which, ops in (("fwd", on.fwd_ops), ("bwd", on.bwd_ops)):
         _check_lane_schedule(on, which, ops)
+    # bench.py prices every operand at its storage width (the HBM fractions of the bf16 line would otherwise be 2x too high)
+    import bench
+    for o in on.fwd_ops + on.bwd_ops:
+        bits = o["i"][13] if len(o["i"]) > 13 else 0
+        if o["code"] == "UZ_OP_BN_RELU_BWD" and bits == 7:
+            i = o["i"]
+            assert bench.op_bytes(o) == i[1] * i[4] * i[5] * i[6] * (2 * (2 + 2) + 2) == bench.op_bytes(dict(o, i=i[:13])) / 2
+        if o["code"] == "UZ_OP_CONV_FWD" and bits == 3 and o["i"][7] == 3:
+            assert bench.conv_bytes(o) < 0.55 * bench.conv_bytes(dict(o, i=o["i"][:13])) + 4.0 * o["i"][0] * o["i"][2] * 9
     # byte-typed pointers: consecutive bf16 buffers are packed at 2 bytes per element
     b = next(b for b in on.bufs if b.b16)
     assert b.words == (b.numel + 1) // 2 and on.tensor(View(b)).dtype == torch.bfloat16 and on.tensor(View(b)).shape == (b.N, b.C, b.H, b.W)
