@@ -161,6 +161,9 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
         for (int i = 0; i < WREGS; ++i) Wl[wlds[i]] = wr[i];
     };
 
+    // a 64-channel tile whose upper half lies beyond Cout (224 = 3 x 64 + 32: the data gradient of PHiSeg's heaviest layer) skips that
+    // half's MFMAs - an eighth of that launch's matrix work was zeros (the split-fp16 kernel has done this since round 3)
+    const bool half_tile = MSUB == 2 && p.Cout - co0 <= 32;
     const int nChunksAll = (p.Cin + CK - 1) / CK;
     const int cBeg = ksp * p.cps;
     const int nChunks = min(nChunksAll, cBeg + p.cps);
@@ -184,10 +187,12 @@ __global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const
 #pragma unroll
                 for (int n = 0; n < NSUB; ++n) b[n] = Pl[poff[n] + 2 * kk * PSR + tapoff];
 #pragma unroll
-                for (int m = 0; m < MSUB; ++m)
+                for (int m = 0; m < MSUB; ++m) {
+                    if (MSUB == 2 && m == 1 && half_tile) continue;      // workgroup-uniform: the upper 32 channels of this tile lie beyond Cout
 #pragma unroll
                     for (int n = 0; n < NSUB; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+                }
             }
         }
         if (more) lstore((c + 1) & 1);
