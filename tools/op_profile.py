@@ -12,6 +12,7 @@ from unet_zoo_amd.synthetic import synthetic_batch
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 MODEL = sys.argv[2] if len(sys.argv) > 2 else "phiseg"
+BURST = int(os.environ.get("UZ_OP_PROFILE_BURST", "1"))       # launches per timed bracket (bench.py's family timing uses 4)
 import bench
 net = bench.build(MODEL); net.train()
 x, m, _ = synthetic_batch(B)
@@ -28,11 +29,11 @@ rows = []
 for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
     arr, n = plan.tapes[which]
     for k in range(n):
-        one = (type(arr[0]) * 1)(arr[k]); best = 1e9
+        one = (type(arr[0]) * BURST)(*([arr[k]] * BURST)); best = 1e9
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); _ffi.check(L.uz_run_tape(one, 1, st), "op"); e1.record(); e1.synchronize()
-            best = min(best, e0.elapsed_time(e1))
+            e0.record(); _ffi.check(L.uz_run_tape(one, BURST, st), "op"); e1.record(); e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) / BURST)
         o = ops[k]
         rows.append((best, which, o["code"].replace("UZ_OP_", ""), o["i"][:9], conv_flops(o, None), op_bytes(o, plan)))
 if os.environ.get("UZ_OP_PROFILE_JSON"):      # every op in tape order with its isolated time: input of tools/critical_path.py
@@ -40,6 +41,10 @@ if os.environ.get("UZ_OP_PROFILE_JSON"):      # every op in tape order with its 
     json.dump([dict(ms=r[0], tape=r[1], code=r[2], i=list(r[3])) for r in rows], open(os.environ["UZ_OP_PROFILE_JSON"], "w"))
 tot = sum(r[0] for r in rows)
 print(f"total {tot:.2f} ms over {len(rows)} ops")
+if os.environ.get("UZ_OP_PROFILE_STREAMING"):                 # the bandwidth-bound launches (>= 32 MB), slowest rate first
+    big = [r for r in rows if not r[4] and r[5] >= bench.LARGE_OP_BYTES]
+    for r in sorted(big, key=lambda r: r[5] / r[0]):
+        print(f"   {r[2]:14s} {str(list(r[3])):52s} {r[0] * 1e3:7.1f} us {r[5] / 1e6:7.1f} MB {r[5] / r[0] / 1e6:6.0f} GB/s")
 agg = {}
 for r in rows:
     key = (r[2], tuple(r[3]))

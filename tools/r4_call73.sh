@@ -1,10 +1,9 @@
-cd $GRAFT_REPO_ROOT
-export UZ_CONV_MATH=f32
-B="python bench.py --steps 15 --warmup 3 --skip-cpu --no-profile --no-f32-leg"
-for r in 1 2; do
-  echo -n "base: "; $B 2>/dev/null | tail -1 | cut -c60-100
-  echo -n "slabcost 3: "; UZ_WG_SLABCOST=3 $B 2>/dev/null | tail -1 | cut -c60-100
-  echo -n "slabcost 0.3: "; UZ_WG_SLABCOST=0.3 $B 2>/dev/null | tail -1 | cut -c60-100
-  echo -n "lanes 3: "; UZ_LANES=3 $B 2>/dev/null | tail -1 | cut -c60-100
-  echo -n "lanes 1: "; UZ_LANES=1 $B 2>/dev/null | tail -1 | cut -c60-100
-done
+#!/bin/bash
+# bilinear backward: float4-per-lane kernel vs the pair kernel; ops tests; bench line with burst family timing
+cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+{
+echo "== quad"; python tools/bench_resample.py 2>&1 | grep bilinear
+echo "== pair"; UZ_BILINEAR_BWD_PAIR=1 python tools/bench_resample.py 2>&1 | grep bilinear
+echo "== tests"; python -m pytest tests/test_ops_gpu.py tests/test_split_storage_gpu.py -q -p no:cacheprovider -x 2>&1 | tail -3
+echo "== bench"; python bench.py 2>/dev/null | tail -1
+} > gpurun_out/r4_call73.txt 2>&1

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
         const float s = uz::split_scale(uz::amax_read(p.amax));
         const float4* s4 = reinterpret_cast<const float4*>(src);
         uint4* d4 = reinterpret_cast<uint4*>(dst);
+#pragma unroll 4
         for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
             const float4 v = s4[i];
             uint4 o;
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
     if (VEC) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
         float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll 4
         for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
             float4 v = s4[i];
             v.x = fmaxf(fmaf(v.x, alpha, beta_), floor_); v.y = fmaxf(fmaf(v.y, alpha, beta_), floor_);

@@ -278,6 +278,75 @@ __global__ __launch_bounds__(256) void bilinear_bwd_sep_k(const RsP p) {   // sr
     fold_finish(p, c, b, fo);
 }
 
+// Two low-resolution columns per lane: ONE aligned float4 of a high-res row per lane (columns 4 j .. 4 j + 3), so a wave's load is a
+// contiguous 1 KB run and there are half as many load instructions per byte; the pair to the left of low-res column 2 j and the pair to
+// the right of column 2 j + 1 are the neighbouring lanes' halves (a wave holds whole rows: 64 % (W / 2) == 0).  Same expressions, in
+// the same order, as bilinear_bwd_sep_k: identical bits.
+__global__ __launch_bounds__(256) void bilinear_bwd_sep4_k(const RsP p) {
+    __shared__ float wyT[LB * KT];
+    __shared__ __attribute__((aligned(8))) float tx[BROWS * (BWMAX / 2)];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float* s = p.src + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo;
+    float* d = p.dst + ((size_t)b * p.CtotD + c) * p.H * p.W;
+    const float* mpl = p.mask ? p.mask + ((size_t)b * p.CtotM + c) * p.H * p.W : nullptr;
+    ReluFold fo;
+    constexpr int MAXR = (BROWS + 7) / 8;           // band rows per thread: rstep = 256 / (W / 2) >= 8
+    const int W2 = p.W >> 1, j = threadIdx.x % W2, rstep = 256 / W2, r0 = threadIdx.x / W2, ix = 2 * j;
+    float wa[KT], wb[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        wa[k] = tap_weight(2 * ix - 2 + k, p.Wo, p.sw, p.ac, p.W, ix);
+        wb[k] = tap_weight(2 * ix + k, p.Wo, p.sw, p.ac, p.W, ix + 1);
+    }
+    const bool v0 = j > 0, v2 = j + 1 < W2;
+    for (int iy0 = blockIdx.x * LB; iy0 < p.H; iy0 += gridDim.x * LB) {
+        const int nrow = min(LB, p.H - iy0);
+        const int ob = 2 * iy0 - 2, nb = 2 * nrow + KT - 2;
+        for (int e = threadIdx.x; e < nrow * KT; e += 256) {
+            const int i = e / KT, k = e - i * KT;
+            wyT[e] = tap_weight(2 * (iy0 + i) - 2 + k, p.Ho, p.sh, p.ac, p.H, iy0 + i);
+        }
+        // all of a thread's band rows (<= 5: 36 rows over >= 8 row groups) are loaded before the first is used - the shuffles keep
+        // the compiler from unrolling a loop around them, and one load in flight per thread was what held the pair kernel at 3 TB/s
+        float4 m[MAXR];
+#pragma unroll
+        for (int u = 0; u < MAXR; ++u) {
+            const int r = r0 + u * rstep, oy = ob + r;
+            m[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nb && oy >= 0 && oy < p.Ho) m[u] = *reinterpret_cast<const float4*>(s + (size_t)oy * p.Wo + 4 * j);
+        }
+#pragma unroll
+        for (int u = 0; u < MAXR; ++u) {
+            const int r = r0 + u * rstep;
+            const float pz = __shfl_up(m[u].z, 1), pw = __shfl_up(m[u].w, 1), nx = __shfl_down(m[u].x, 1), ny = __shfl_down(m[u].y, 1);
+            const float ax = v0 ? pz : 0.f, ay = v0 ? pw : 0.f, zx = v2 ? nx : 0.f, zy = v2 ? ny : 0.f;
+            float2 acc;
+            acc.x = wa[0] * ax + wa[1] * ay + wa[2] * m[u].x + wa[3] * m[u].y + wa[4] * m[u].z + wa[5] * m[u].w;
+            acc.y = wb[0] * m[u].x + wb[1] * m[u].y + wb[2] * m[u].z + wb[3] * m[u].w + wb[4] * zx + wb[5] * zy;
+            if (r < nb) *reinterpret_cast<float2*>(tx + r * p.W + ix) = acc;
+        }
+        __syncthreads();
+        for (int il = r0; il < nrow; il += rstep) {
+            const float* col = tx + (2 * il) * p.W + ix;
+            const float* wy = wyT + il * KT;
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const float2 t = *reinterpret_cast<const float2*>(col + k * p.W);
+                acc.x += wy[k] * t.x; acc.y += wy[k] * t.y;
+            }
+            const int q = (iy0 + il) * p.W + ix;
+            float2* dst = reinterpret_cast<float2*>(d + q);
+            if (p.accumulate) { const float2 o = *dst; acc.x = o.x + acc.x; acc.y = o.y + acc.y; }
+            acc.x = fold_value(p, mpl, q, acc.x, fo);
+            acc.y = fold_value(p, mpl, q + 1, acc.y, fo);
+            *dst = acc;
+        }
+        __syncthreads();
+    }
+    fold_finish(p, c, b, fo);
+}
+
 // Forward: a workgroup produces OB output rows of one plane from the <= OB / 2 + 2 source rows they touch (staged in LDS by
 // float4), four consecutive outputs per thread and one float4 store each; same expression as bilinear_fwd_k.
 constexpr int OB = 32, FWMAX = 128, FROWS = OB / 2 + 3;
@@ -488,7 +557,14 @@ static int bilinear2x_bwd_impl(const float* dy, int C, int CtotDy, float* dx, in
     if (p.Wo <= BWMAX && p.H >= 4 && 256 % p.W == 0 && (reinterpret_cast<uintptr_t>(dy) & 7) == 0) {
         // Wo is even: an 8-byte aligned view keeps every float2 of every row aligned
         // enough planes to fill the chip: one workgroup per plane walks its bands (2.8 -> 3.3 TB/s on 192 ch 64^2 -> 128^2, 3.1 -> 3.75 on 32^2)
-        hipLaunchKernelGGL(bilinear_bwd_sep_k, dim3((long long)C * N >= 2048 ? 1 : uz::ceil_div(H, LB), C, N), dim3(256), 0, uz::S(stream), p);
+        const dim3 grid((long long)C * N >= 2048 ? 1 : uz::ceil_div(H, LB), C, N);
+        static const bool quad = !getenv("UZ_BILINEAR_BWD_PAIR");
+        if (quad && W >= 32 && 64 % (W / 2) == 0 &&       // 16 x 16 planes: one or two band rows per thread, the pair kernel is 3 us quicker
+            (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(dx) & 7) == 0) {
+            hipLaunchKernelGGL(bilinear_bwd_sep4_k, grid, dim3(256), 0, uz::S(stream), p);
+            return uz::check_launch("bilinear_bwd_sep4_k");
+        }
+        hipLaunchKernelGGL(bilinear_bwd_sep_k, grid, dim3(256), 0, uz::S(stream), p);
         return uz::check_launch("bilinear_bwd_sep_k");
     }
     RS_LAUNCH(bilinear_bwd_k, H * W);
