@@ -145,7 +145,8 @@ def op_bytes(op):
         return f4 * C * N * H * W * 1.25
     if c in ("UZ_OP_BILINEAR_FWD", "UZ_OP_BILINEAR_BWD"):
         C, N, H, W = i[0], i[3], i[4], i[5]
-        return C * N * H * W * (f4 + 4 * _esz(op, 1 if c == "UZ_OP_BILINEAR_FWD" else 0))               # (only the high-resolution side may be bf16)
+        acc = f4 if (c == "UZ_OP_BILINEAR_BWD" and len(i) > 7 and i[7]) else 0                            # dx += ...: the low-resolution gradient is read as well
+        return C * N * H * W * (f4 + acc + 4 * _esz(op, 1 if c == "UZ_OP_BILINEAR_FWD" else 0))         # (only the high-resolution side may be bf16)
     if c in ("UZ_OP_NEAREST_FWD", "UZ_OP_NEAREST_BWD"):
         C, N, H, W, f = i[0], i[3], i[4], i[5], i[6]
         return f4 * C * N * H * W * (1 + f * f)

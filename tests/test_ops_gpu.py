@@ -404,7 +404,7 @@ def test_avgpool(H, W):
 
 
 @pytest.mark.parametrize("ac", [1, 0])
-@pytest.mark.parametrize("H,W", [(4, 4), (1, 1), (2, 2), (5, 3), (32, 32), (64, 64), (20, 12), (9, 64), (128, 64), (40, 128), (6, 8)])
+@pytest.mark.parametrize("H,W", [(4, 4), (1, 1), (2, 2), (5, 3), (32, 32), (64, 64), (20, 12), (9, 64), (128, 64), (40, 128), (6, 8), (40, 32), (19, 64)])
 def test_bilinear(ac, H, W):
     g = _g()
     N, C = 2, 3

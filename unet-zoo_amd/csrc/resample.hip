@@ -313,7 +313,14 @@ __global__ __launch_bounds__(256) void bilinear_bwd_sep4_k(const RsP p) {
         for (int u = 0; u < MAXR; ++u) {
             const int r = r0 + u * rstep, oy = ob + r;
             m[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < nb && oy >= 0 && oy < p.Ho) m[u] = *reinterpret_cast<const float4*>(s + (size_t)oy * p.Wo + 4 * j);
+            if (r < nb && oy >= 0 && oy < p.Ho) {
+                if (p.hb16) {                              // bf16 storage: the lane's four columns are one aligned 8-byte load
+                    const uint2 w2 = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.src) + ((size_t)b * p.CtotS + c) * p.Ho * p.Wo + (size_t)oy * p.Wo + 4 * j);
+                    m[u] = make_float4(uz::bf16_lo(w2.x), uz::bf16_hi(w2.x), uz::bf16_lo(w2.y), uz::bf16_hi(w2.y));
+                } else {
+                    m[u] = *reinterpret_cast<const float4*>(s + (size_t)oy * p.Wo + 4 * j);
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < MAXR; ++u) {
@@ -586,7 +593,14 @@ extern "C" int uz_bilinear2x_bwd_b16(const void* dy, int C, int CtotDy, float* d
     UZ_REQUIRE(2 * W <= BWMAX && H >= 4 && 256 % W == 0 && (reinterpret_cast<uintptr_t>(dy) & 7) == 0, "bilinear2x_bwd_b16: shape not served by the band kernel (2 W <= 128, H >= 4, 256 %% W == 0, 8-byte aligned dy)");
     RsP p = {}; p.src = static_cast<const float*>(dy); p.dst = dx; p.C = C; p.CtotS = CtotDy; p.CtotD = CtotDx; p.N = N; p.hb16 = dy_b16 != 0;
     p.H = H; p.W = W; p.Ho = 2 * H; p.Wo = 2 * W; p.ac = align_corners; p.accumulate = accumulate; bil_scales(p);
-    hipLaunchKernelGGL(bilinear_bwd_sep_k, dim3((long long)C * N >= 2048 ? 1 : uz::ceil_div(H, LB), C, N), dim3(256), 0, uz::S(stream), p);
+    const dim3 grid((long long)C * N >= 2048 ? 1 : uz::ceil_div(H, LB), C, N);
+    if (W >= 32 && 64 % (W / 2) == 0 && (reinterpret_cast<uintptr_t>(dx) & 7) == 0) {        // (8-byte aligned dy: four bf16 columns or, in fp32, checked below)
+        if (dy_b16 || (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
+            hipLaunchKernelGGL(bilinear_bwd_sep4_k, grid, dim3(256), 0, uz::S(stream), p);
+            return uz::check_launch("bilinear_bwd_sep4_k");
+        }
+    }
+    hipLaunchKernelGGL(bilinear_bwd_sep_k, grid, dim3(256), 0, uz::S(stream), p);
     return uz::check_launch("bilinear_bwd_sep_k");
 }
 extern "C" int uz_nearest_fwd(const float* x, int C, int CtotX, float* y, int CtotY, int N, int H, int W, int factor, void* stream) {

@@ -9,6 +9,7 @@
 //   * BatchNorm3d / ReLU / 1x1x1 heads / latent ops are their 2-D kernels over the batch of D slices;
 //   * AvgPool3d(2, ceil_mode) (phiseg3D.py:101) and trilinear x2 (align_corners=True: phiseg3D.py:146,306,376) are the kernels
 //     below (trilinear = the 2-D bilinear kernel per slice, then linear interpolation along the depth).
+#include <type_traits>
 #include "uz_common.h"
 #include "split_f16.h"
 
@@ -265,11 +266,30 @@ __global__ __launch_bounds__(256) void depth_lerp_bwd_st(const float* __restrict
         if (ww != 0.f) { w[nw] = ww; ods[nw] = od; ++nw; }
     }
     const size_t ro = ((size_t)d * CtotDx + c) * HW;
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < HW / 4; q += gridDim.x * 256) {
-        uz::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < nw; ++k) acc += w[k] * uz::ld_elem4(dy, ((size_t)ods[k] * CtotDy + c) * HW + 4 * (size_t)q, dyb);
-        if (accumulate) acc += uz::ld_elem4(dx, ro + 4 * (size_t)q, dxb);
-        uz::st_elem4(dx, ro + 4 * (size_t)q, acc, dxb);
+    // the number of contributing slices (3 ... 5, block-uniform) becomes a compile-time count: all of a thread's loads are issued before
+    // the first is used (with a run-time count the weights and slice numbers were indexed dynamically and each load waited for
+    // the one before it: 173 us on 192 ch 32 -> 64 slices of 128 x 128)
+    auto sweep = [&](auto nwc) {
+        constexpr int NW = decltype(nwc)::value;
+        for (int q = blockIdx.x * 256 + threadIdx.x; q < HW / 4; q += gridDim.x * 256) {
+            uz::f32x4 v[NW];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) v[k] = uz::ld_elem4(dy, ((size_t)ods[k] * CtotDy + c) * HW + 4 * (size_t)q, dyb);
+            uz::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < NW; ++k) acc += w[k] * v[k];
+            if (accumulate) acc += uz::ld_elem4(dx, ro + 4 * (size_t)q, dxb);
+            uz::st_elem4(dx, ro + 4 * (size_t)q, acc, dxb);
+        }
+    };
+    if (nw == 0) { w[0] = 0.f; ods[0] = 0; nw = 1; }
+    switch (nw) {
+        case 1: sweep(std::integral_constant<int, 1>{}); break;
+        case 2: sweep(std::integral_constant<int, 2>{}); break;
+        case 3: sweep(std::integral_constant<int, 3>{}); break;
+        case 4: sweep(std::integral_constant<int, 4>{}); break;
+        case 5: sweep(std::integral_constant<int, 5>{}); break;
+        default: sweep(std::integral_constant<int, 6>{}); break;
     }
 }
 
