@@ -227,6 +227,8 @@ __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
         }
         return;
     }
+    // (round 4, measured and dropped: non-temporal loads of y here - the step gained 0.5 %, inside the noise between boxes, and the
+    //  launch itself lost 8 % when its input was still in the memory-side cache)
     if (VEC) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
         float4* d4 = reinterpret_cast<float4*>(dst);
