@@ -3,6 +3,7 @@ op (and against the reference-generated golden vectors for the reference-authore
 All calls go through the C ABI of libuz_hip.so.  Tolerances: fp32 MFMA == k-ordered fmaf chain, the
 CPU reference sums in a different order, so convolutions agree to ~1e-6 relative; gates below are
 2e-5 relative to the largest reference magnitude unless stated."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -420,6 +421,25 @@ def test_bilinear(ac, H, W):
     assert g.maxabs(dx, x.grad) <= 1e-5
     g.call("uz_bilinear2x_bwd", dy.to(g.dev()), C, C, dx, C, N, H, W, ac, 1)         # accumulate
     assert g.maxabs(dx, 2 * x.grad) <= 2e-5
+
+
+def test_the_two_bilinear_backward_band_kernels_give_the_same_bits():
+    """uz_bilinear2x_bwd takes the float4-per-lane kernel or the pair kernel by the ALIGNMENT of its views (a lane's scratch moves between
+    eager execution and graph replay, and between the plans of a data-parallel and a single-process run): the two must be
+    interchangeable bit for bit, or "graph replay == eager" and "DP at world size 1 == no DP" break (round 4: they did, with
+    compiler-contracted sums).  Two fresh processes (the choice is read once per process), checksums of the same calls."""
+    import subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "diag_bilinear_bits.py")
+    outs = []
+    for pair in ("", "1"):
+        env = dict(os.environ)
+        env.pop("UZ_BILINEAR_BWD_PAIR", None)
+        if pair:
+            env["UZ_BILINEAR_BWD_PAIR"] = pair
+        r = subprocess.run([sys.executable, tool], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("(")])
+    assert len(outs[0]) >= 4 and outs[0] == outs[1], (outs[0], outs[1])
 
 
 @pytest.mark.parametrize("f", [1, 2, 8, 16])

@@ -211,6 +211,14 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const RsP p) {   // src = 
 // multiply-adds per output instead of a KT x KT gather.  Low-res index i only receives from high-res 2i-1 .. 2i+2 (both
 // align_corners modes, any size - enumerated); the tap tables cover 2i-2 .. 2i+3 and hold exactly the forward's weights.
 constexpr int LB = 16, BWMAX = 128, KT = 6, BROWS = 2 * LB + KT - 2;
+// The six-tap sums of the two band kernels as explicit fused multiply-add chains: the pair and the float4 kernel are chosen by the
+// ALIGNMENT of the views they get (lane scratch moves between eager and graph replay, between plans), so they must produce the same
+// bits - left to the compiler, the same source expression was contracted differently in the two kernels.
+__device__ __forceinline__ float dot6(const float* w, float a0, float a1, float a2, float a3, float a4, float a5) {
+    float t = w[0] * a0;
+    t = fmaf(w[1], a1, t); t = fmaf(w[2], a2, t); t = fmaf(w[3], a3, t); t = fmaf(w[4], a4, t); t = fmaf(w[5], a5, t);
+    return t;
+}
 __global__ __launch_bounds__(256) void bilinear_bwd_sep_k(const RsP p) {   // src = dy (high res), dst = dx (low res)
     __shared__ float wyT[LB * KT];
     __shared__ float tx[BROWS * (BWMAX / 2)];                               // dY reduced along x
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_sep_k(const RsP p) {   // sr
                     a = v0 ? make_float2(ax, ay) : make_float2(0.f, 0.f);
                     z = v2 ? make_float2(zx, zy) : make_float2(0.f, 0.f);
                 }
-                acc = wx[0] * a.x + wx[1] * a.y + wx[2] * m.x + wx[3] * m.y + wx[4] * z.x + wx[5] * z.y;
+                acc = dot6(wx, a.x, a.y, m.x, m.y, z.x, z.y);
             }
             tx[r * p.W + ix] = acc;
         }
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_sep_k(const RsP p) {   // sr
             const float* wy = wyT + il * KT;
             float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < KT; ++k) acc += wy[k] * col[k * p.W];
+            for (int k = 0; k < KT; ++k) acc = fmaf(wy[k], col[k * p.W], acc);
             float* dst = d + (size_t)(iy0 + il) * p.W + ix;
             *dst = fold_value(p, mpl, (iy0 + il) * p.W + ix, p.accumulate ? *dst + acc : acc, fo);
         }
@@ -280,8 +288,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_sep_k(const RsP p) {   // sr
 
 // Two low-resolution columns per lane: ONE aligned float4 of a high-res row per lane (columns 4 j .. 4 j + 3), so a wave's load is a
 // contiguous 1 KB run and there are half as many load instructions per byte; the pair to the left of low-res column 2 j and the pair to
-// the right of column 2 j + 1 are the neighbouring lanes' halves (a wave holds whole rows: 64 % (W / 2) == 0).  Same expressions, in
-// the same order, as bilinear_bwd_sep_k: identical bits.
+// the right of column 2 j + 1 are the neighbouring lanes' halves (a wave holds whole rows: 64 % (W / 2) == 0).  Same fused
+// multiply-add chains (dot6, fmaf) as bilinear_bwd_sep_k: identical bits (tests/test_ops_gpu.py compares the two kernels' outputs).
 __global__ __launch_bounds__(256) void bilinear_bwd_sep4_k(const RsP p) {
     __shared__ float wyT[LB * KT];
     __shared__ __attribute__((aligned(8))) float tx[BROWS * (BWMAX / 2)];
@@ -328,8 +336,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_sep4_k(const RsP p) {
             const float pz = __shfl_up(m[u].z, 1), pw = __shfl_up(m[u].w, 1), nx = __shfl_down(m[u].x, 1), ny = __shfl_down(m[u].y, 1);
             const float ax = v0 ? pz : 0.f, ay = v0 ? pw : 0.f, zx = v2 ? nx : 0.f, zy = v2 ? ny : 0.f;
             float2 acc;
-            acc.x = wa[0] * ax + wa[1] * ay + wa[2] * m[u].x + wa[3] * m[u].y + wa[4] * m[u].z + wa[5] * m[u].w;
-            acc.y = wb[0] * m[u].x + wb[1] * m[u].y + wb[2] * m[u].z + wb[3] * m[u].w + wb[4] * zx + wb[5] * zy;
+            acc.x = dot6(wa, ax, ay, m[u].x, m[u].y, m[u].z, m[u].w);
+            acc.y = dot6(wb, m[u].x, m[u].y, m[u].z, m[u].w, zx, zy);
             if (r < nb) *reinterpret_cast<float2*>(tx + r * p.W + ix) = acc;
         }
         __syncthreads();
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_sep4_k(const RsP p) {
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const float2 t = *reinterpret_cast<const float2*>(col + k * p.W);
-                acc.x += wy[k] * t.x; acc.y += wy[k] * t.y;
+                acc.x = fmaf(wy[k], t.x, acc.x); acc.y = fmaf(wy[k], t.y, acc.y);
             }
             const int q = (iy0 + il) * p.W + ix;
             float2* dst = reinterpret_cast<float2*>(d + q);
