@@ -296,6 +296,20 @@ class Plan:
     def in_loss_phase(self):
         return self.target is self.loss_ops
 
+    def _tables_ok(self):
+        """Deferred table-driven reductions (weight-gradient slabs, bias-gradient rows).  Data parallel: a bucket's gradients must be
+        final when its all-reduce starts, so there the tables are cut per BUCKET (finalize(): one launch per bucket, and the bucket's
+        "final" marker depends on it through the gradient ranges it writes); UZ_DP_TABLES=0 restores one reduction launch per layer."""
+        return not self.grad_buckets or os.environ.get("UZ_DP_TABLES", "1") == "1"
+
+    def _by_bucket(self, jobs, key_of):
+        """jobs split by the gradient bucket their parameter lies in (one group when there are no buckets), emission order kept."""
+        if not self.grad_buckets:
+            return [jobs]
+        groups = [[j for j in jobs if lo <= self.ptab.poff[key_of(j)] < hi] for lo, hi in self.grad_buckets]
+        assert sum(len(g) for g in groups) == len(jobs), "a deferred reduction's parameter lies outside every gradient bucket"
+        return [g for g in groups if g]
+
     def l2_reg(self, keys, term, coeff):
         """coeff * sum_k ||p_k||_2 over the listed parameter tensors (utils.l2_regularisation, utils.py:93-101)."""
         n = len(keys)
@@ -390,7 +404,7 @@ class Plan:
             # 3 x 3 layer leaves its partial-sum slabs in a buffer of its own and ONE table-driven launch at the end of the tape adds
             # the slabs of every layer (UZ_OP_WGRAD_REDUCE_TABLE) - PHiSeg: 106 + 27 small reduction launches less per step
             nslab = 0
-            if ks == 3 and db_key is None and wrow0 == 0 and not self.grad_buckets and os.environ.get("UZ_WGRAD_TABLE", "1") == "1" \
+            if ks == 3 and db_key is None and wrow0 == 0 and self._tables_ok() and os.environ.get("UZ_WGRAD_TABLE", "1") == "1" \
                     and not self.__dict__.get("_in_rev", False) and self.__dict__.get("_rev_ctx") is None:
                 nslab = self.L.uz_conv_bwd_weight_slabs(cin, cout, x.N, x.H, x.W, ks)
             slabbuf = self.vec(wkey + ":wslabs", nslab * ks * ks * cout * cin) if nslab else None
@@ -562,7 +576,7 @@ class Plan:
             # conv-bias gradient (the sum of dy: analytically zero behind a training-mode BatchNorm, the reference returns its
             # rounding noise and so do we): outside data-parallel runs the large-plane units leave their per-workgroup sums in rows of
             # their own and ONE table-driven launch at the end of the tape adds them - a summation launch less in every unit's chain
-            dbrows = self.L.uz_bn_bwd_dbias_rows(x.N, x.H, x.W) if (plain and not self.grad_buckets and os.environ.get("UZ_DBIAS_TABLE", "1") == "1") else 0
+            dbrows = self.L.uz_bn_bwd_dbias_rows(x.N, x.H, x.W) if (plain and self._tables_ok() and os.environ.get("UZ_DBIAS_TABLE", "1") == "1") else 0
             dbpart = self.vec(name + ":dbrows", 2 * dbrows * cout) if dbrows else None
             op_bwd = self._emit(self.bwd_ops, "UZ_OP_BN_RELU_BWD",
                                 p=[ga, y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), dbpart if dbrows else self.G(bkey), ("scratch", "bn"),
@@ -742,8 +756,7 @@ class Plan:
                 if self._nclaims.get(a.buf, 0) != fold["claims"]:
                     raise RuntimeError(f"{prefix}: a later writer of grad({a.buf.name}) follows the data gradient that folded the ReLU "
                                        "backward - set UZ_FOLD_RELU_BWD=0 for this model")
-                if self.grad_buckets or os.environ.get("UZ_DBIAS_TABLE", "1") != "1":
-                    # (data parallel: a bias gradient has to be final when its bucket's all-reduce starts)
+                if not self._tables_ok() or os.environ.get("UZ_DBIAS_TABLE", "1") != "1":
                     self._emit(self.bwd_ops, "UZ_OP_CHAN_SUM_PARTIALS", p=[fold["part"], self.G(bkey)], i=[fold["npart"], cout, fold.get("dbl", 0)])
                 else:
                     self._dbias_jobs.append((fold["part"], bkey, fold["npart"], cout, fold.get("dbl", 0)))
@@ -1363,11 +1376,12 @@ class Plan:
                 fn()
             if self._dbias_jobs:
                 # all bias gradients of the folded ReLU backward in one launch (21 launches of ~7 us in U-Net's single chain)
-                refs = [q for part, bkey, rows, c, dbl in self._dbias_jobs for q in (part, self.G(bkey), ("raw", rows), ("raw", c), ("raw", dbl))]
-                self._newgroup()
-                self._emit(self.bwd_ops, "UZ_OP_CHAN_SUM_TABLE",
-                           p=[self.ptr_table(refs), ("gflat_keys", tuple(j[1] for j in self._dbias_jobs))],
-                           i=[len(self._dbias_jobs), max(j[3] for j in self._dbias_jobs)])
+                for part_jobs in self._by_bucket(self._dbias_jobs, lambda j: j[1]):
+                    refs = [q for part, bkey, rows, c, dbl in part_jobs for q in (part, self.G(bkey), ("raw", rows), ("raw", c), ("raw", dbl))]
+                    self._newgroup()
+                    self._emit(self.bwd_ops, "UZ_OP_CHAN_SUM_TABLE",
+                               p=[self.ptr_table(refs), ("gflat_keys", tuple(j[1] for j in part_jobs))],
+                               i=[len(part_jobs), max(j[3] for j in part_jobs)])
                 self._dbias_jobs = []
             jobs = self.__dict__.get("_wgrad_jobs", [])
             if jobs:
@@ -1377,8 +1391,8 @@ class Plan:
                 # of 16 / 8: they delay the critical chains.  The single launch behind the tape stays.)
                 chunk = int(os.environ.get("UZ_WGRAD_TABLE_CHUNK", "0"))
                 chunk = len(jobs) if chunk <= 0 else chunk
-                for j0 in range(0, len(jobs), chunk):
-                    part = jobs[j0:j0 + chunk]
+                parts = self._by_bucket(jobs, lambda j: j[1]) if self.grad_buckets else [jobs[j0:j0 + chunk] for j0 in range(0, len(jobs), chunk)]
+                for part in parts:
                     refs, blk = [], 0
                     for slabbuf, wkey, nslab, co, ci, kk in part:
                         refs += [slabbuf, self.G(wkey), ("raw", nslab), ("raw", co), ("raw", ci), ("raw", kk), ("raw", blk), ("raw", 0)]
