@@ -96,6 +96,28 @@ def test_bucket_events_are_scheduled_behind_every_writer_of_their_bucket():
                    for (space, a, c) in plan._resources(o["p"][idx]) if space == ("gflat",) and a < hi and lo < c]
         assert writers and max(writers) < k
     assert min(marks) < len(ops) - 3          # at least one bucket is final well before the tape ends
+    # deferred reductions are cut per bucket: every table writes gradients of ONE bucket only (so that bucket's marker, and nobody
+    # else's, waits for it), at most one table of a kind per bucket
+    for code in ("UZ_OP_WGRAD_REDUCE_TABLE", "UZ_OP_CHAN_SUM_TABLE"):
+        tabs = [o for o in ops if o["code"] == code]
+        assert len(tabs) <= len(plan.grad_buckets)
+        owners = []
+        for o in tabs:
+            offs = {plan.ptab.poff[k] for k in o["p"][1][1]}
+            own = {b for b, (lo, hi) in enumerate(plan.grad_buckets) if any(lo <= x < hi for x in offs)}
+            assert len(own) == 1, (code, own)
+            owners.append(own.pop())
+        assert len(set(owners)) == len(owners)
+    assert any(o["code"] == "UZ_OP_WGRAD_REDUCE_TABLE" for o in ops)
+
+
+def test_data_parallel_plan_without_tables_reduces_behind_every_layer(monkeypatch):
+    from unet_zoo_amd.models.phiseg import PHISeg
+    monkeypatch.setenv("UZ_DP_TABLES", "0")
+    net = PHISeg(1, 2, [4, 8, 8, 8, 8, 8, 8], image_size=(1, 64, 64), device="cpu")
+    net._dp = type("S", (), dict(overlap=True, buckets=dp.param_buckets(net._ptab, min_floats=1)))()
+    plan = net._build(2, 64, 64, True, True)
+    assert not [o for o in plan.bwd_ops if o["code"] in ("UZ_OP_WGRAD_REDUCE_TABLE", "UZ_OP_CHAN_SUM_TABLE")]
 
 
 def _sync_worker(rank, world, port, out_dir):
