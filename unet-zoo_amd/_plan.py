@@ -376,9 +376,17 @@ class Plan:
             self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
             # (a depth-window call - 3 C view channels over a C-channel buffer - writes the Conv3d gradient layout itself:
             # uz_conv_bwd_weight's slab reduction does the [co][kd][ci] -> [co][ci][kd] permutation on the way out)
+            # (slab reductions deferred to the table launch like the 2-D layers': the table row carries the window's C)
+            nslab = 0
+            if self._tables_ok() and os.environ.get("UZ_WGRAD_TABLE", "1") == "1" and os.environ.get("UZ_WGRAD_TABLE_VOL", "1") == "1" \
+                    and not self.__dict__.get("_in_rev", False) and self.__dict__.get("_rev_ctx") is None:
+                nslab = self.L.uz_conv_bwd_weight_slabs(3 * cin, cout, x.N, x.H, x.W, 3)
+            slabbuf = self.vec(wkey + ":wslabs", nslab * 9 * cout * 3 * cin) if nslab else None
             rec["wgrad"] = self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
-                       p=[("win", x), gy, self.G(wkey), None, ("scratch", "wgrad"), self.amax_in(x), self.amax_in(gy)],
-                       i=[3 * cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, 3], n=ws)
+                       p=[("win", x), gy, self.G(wkey), None, ("scratch", "wgrad"), self.amax_in(x), self.amax_in(gy), None, slabbuf],
+                       i=[3 * cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, 3, 0, 0, 0, 1 if nslab else 0], n=ws)
+            if nslab:
+                self.__dict__.setdefault("_wgrad_jobs", []).append((slabbuf, wkey, nslab, cout, 3 * cin, 9, cin))
             x = x_orig
             if x.buf.requires_grad:
                 acc = self._claim(x)
@@ -1244,7 +1252,8 @@ class Plan:
         if c in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA", "UZ_OP_CONV_BWD_WEIGHT"):
             kind = {"UZ_OP_CONV_FWD": 0, "UZ_OP_CONV_BWD_DATA": 1, "UZ_OP_CONV_BWD_WEIGHT": 2}[c]
             W = i[6]
-            if i[7] != 3 or W % 32 or any(i[8:]) and kind != 1:
+            # (a weight gradient may leave its slabs to the table launch - i[11] - in either storage: uz_conv_bwd_weight_b16 takes slabs_out)
+            if i[7] != 3 or W % 32 or (any(i[8:11]) or any(i[12:]) if kind == 2 else any(i[8:]) and kind != 1):
                 return False
             if kind == 1 and (any(i[9:]) or len(p) > 7):
                 return False
@@ -1394,8 +1403,8 @@ class Plan:
                 parts = self._by_bucket(jobs, lambda j: j[1]) if self.grad_buckets else [jobs[j0:j0 + chunk] for j0 in range(0, len(jobs), chunk)]
                 for part in parts:
                     refs, blk = [], 0
-                    for slabbuf, wkey, nslab, co, ci, kk in part:
-                        refs += [slabbuf, self.G(wkey), ("raw", nslab), ("raw", co), ("raw", ci), ("raw", kk), ("raw", blk), ("raw", 0)]
+                    for slabbuf, wkey, nslab, co, ci, kk, *vol in part:          # (vol: the C of a depth window's row, else absent)
+                        refs += [slabbuf, self.G(wkey), ("raw", nslab), ("raw", co), ("raw", ci), ("raw", kk), ("raw", blk), ("raw", vol[0] if vol else 0)]
                         blk += self.L.uz_wgrad_reduce_blocks(ci, co, 3 if kk == 9 else 1)
                     self._newgroup()
                     self._emit(self.bwd_ops, "UZ_OP_WGRAD_REDUCE_TABLE",

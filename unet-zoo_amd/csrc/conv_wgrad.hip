@@ -625,8 +625,9 @@ extern "C" int uz_conv_bwd_weight_slabs(int Cin, int Cout, int N, int H, int W, 
 }
 namespace {
 // All slab reductions of a tape in ONE launch.  table: n_layers rows of 8 int64 {slabs (address), dw (address), S, Cout, Cin, ks*ks,
-// first block, -}; a workgroup finds its layer by bisection over the first-block column; 256 (co, ci) pairs of one tap per
+// first block, volC}; a workgroup finds its layer by bisection over the first-block column; 256 (co, ci) pairs of one tap per
 // workgroup.  Same order of additions as the per-layer launches: groups of 32 slabs first when S > 64, then the group sums.
+// volC > 0: the row is a depth window (Cin = 3 volC, k = kd volC + ci) and the sum leaves in the Conv3d layout [Cout][volC][3][3][3].
 __global__ __launch_bounds__(256) void wgrad_reduce_table_k(const long long* __restrict__ table, int n_layers) {
     int lo = 0, hi = n_layers - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)table[8 * mid + 6] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
@@ -666,7 +667,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_table_k(const long long* __r
             s += sg;
         }
     }
-    dw[(size_t)j * KK + tap] = s;
+    const int volC = (int)t[7];
+    if (volC > 0) {
+        const int co = j / Cin, kc = j - co * Cin, kd = kc / volC, ci = kc - kd * volC;
+        dw[(((size_t)co * volC + ci) * 3 + kd) * KK + tap] = s;
+    } else {
+        dw[(size_t)j * KK + tap] = s;
+    }
 }
 }  // namespace
 extern "C" int uz_wgrad_reduce_blocks(int Cin, int Cout, int ks) { return ks * ks * uz::ceil_div(Cout * Cin, 256); }
@@ -715,8 +722,10 @@ static int conv_bwd_weight_impl(const float* x, int Cin, int CinTot, const float
     // slabs_out: the call stops behind its main kernel and leaves its uz_conv_bwd_weight_slabs() partial-sum slabs [S][ks*ks][Cout][Cin]
     // there; uz_wgrad_reduce_table adds the slabs of MANY layers in one launch (the plans: one at the end of the backward tape
     // instead of one or two reduction launches behind every weight gradient).  dw is not written, db must be NULL.
-    UZ_REQUIRE(!slabs_out || (!db && uz_conv_bwd_weight_slabs(Cin, Cout, N, H, W, ks) > 0 && !(ks == 3 && Cin == 3 * CinTot)),
-               "conv_bwd_weight_ex: slabs_out on a call that writes no slabs (uz_conv_bwd_weight_slabs() == 0), asks for a bias gradient or is a depth window");
+    // (a depth window - 3 C view channels over a C-channel buffer - may leave slabs too: its table row carries C, and the table kernel
+    //  writes the Conv3d parameter layout exactly as this call's own reduction does)
+    UZ_REQUIRE(!slabs_out || (!db && uz_conv_bwd_weight_slabs(Cin, Cout, N, H, W, ks) > 0),
+               "conv_bwd_weight_ex: slabs_out on a call that writes no slabs (uz_conv_bwd_weight_slabs() == 0) or asks for a bias gradient");
     const bool any_packed = x_packed || dy_packed;
     UZ_REQUIRE(!any_packed || (uz_conv_route(2, Cin, Cout, N, H, W, ks) == 1 && uz::conv_np() == 2 && !(dy_packed && db)),
                "conv_bwd_weight_ex: an operand in split storage, but this shape / math mode does not take the split-fp16 path (or a bias gradient was requested)");
