@@ -255,7 +255,9 @@ int uz_conv_bwd_weight_ex(const float* x, int Cin, int CinTot, const float* dy, 
                           int x_packed, const float* x_amax2, int seg_channels, int dy_packed, float* slabs_out, void* stream);
 /* Weight-gradient slab reductions of many layers in ONE launch.  slabs_out (above, nullable): the call leaves its
  * uz_conv_bwd_weight_slabs() x ks*ks x Cout x Cin partial sums there instead of reducing them into dw; uz_wgrad_reduce_table adds
- * them later - table rows of 8 int64 {slabs, dw, S, Cout, Cin, ks*ks, first block, 0}, blocks counted by uz_wgrad_reduce_blocks().
+ * them later - table rows of 8 int64 {slabs, dw, S, Cout, Cin, ks*ks, first block, volC}, blocks counted by uz_wgrad_reduce_blocks();
+ * volC = 0, or - the call was a depth window (Cin = 3 volC view channels over a volC-channel buffer) - the window's C: the sum
+ * then leaves in the Conv3d parameter layout [Cout][volC][3][3][3] exactly as the call's own reduction writes it.
  * Same order of additions as the in-call reduction (bitwise the same dw).                                                        */
 int uz_conv_bwd_weight_slabs(int Cin, int Cout, int N, int H, int W, int ks);
 int uz_wgrad_reduce_blocks(int Cin, int Cout, int ks);

@@ -305,8 +305,27 @@ def test_weight_gradient_slabs_reduced_by_the_table_launch():
         rows += [slabs.data_ptr(), dw1.data_ptr(), S, Cout, Cin, 9, blk, 0]
         blk += L.uz_wgrad_reduce_blocks(Cin, Cout, 3)
         keep.append((dw0, dw1, slabs, S))
+    # a depth window (Conv3d as the 2-D kernel over slices: 3 C view channels on a C-channel buffer, Cin = 3 C): the table row carries
+    # C and the sum leaves in the Conv3d layout [Cout][C][3][3][3] like the call's own reduction
+    for k, (D, C, Cout, H, W) in enumerate([(10, 32, 32, 64, 64), (6, 16, 24, 16, 16)]):
+        vol = torch.zeros(D + 2, C, H, W, device=d)
+        vol[1:-1] = g.rnd(D, C, H, W, seed=80 + k).to(d)
+        dy = g.rnd(D, Cout, H, W, seed=90 + k).to(d)
+        wsb = L.uz_conv_bwd_weight_workspace(3 * C, Cout, D, H, W, 3)
+        ws = torch.empty(wsb // 4 + 64, device=d)
+        dw0 = torch.empty(Cout, C, 3, 3, 3, device=d)
+        g.call("uz_conv_bwd_weight", vol, 3 * C, C, dy, Cout, Cout, dw0, None, D, H, W, 3, None, None, ws, wsb)
+        S = L.uz_conv_bwd_weight_slabs(3 * C, Cout, D, H, W, 3)
+        assert S > 0
+        slabs = torch.full((S * 9 * Cout * 3 * C,), float("nan"), device=d)
+        dw1 = torch.full_like(dw0, float("nan"))
+        g.call("uz_conv_bwd_weight_ex", vol, 3 * C, C, dy, Cout, Cout, dw1, None, D, H, W, 3, None, None, ws, wsb, 0, None, 0, 0, slabs)
+        assert torch.isnan(dw1).all()
+        rows += [slabs.data_ptr(), dw1.data_ptr(), S, Cout, 3 * C, 9, blk, C]
+        blk += L.uz_wgrad_reduce_blocks(3 * C, Cout, 3)
+        keep.append((dw0, dw1, slabs, S))
     table = torch.tensor(rows, dtype=torch.int64, device=d)
-    g.call("uz_wgrad_reduce_table", table, len(cases), blk)
+    g.call("uz_wgrad_reduce_table", table, len(keep), blk)
     for dw0, dw1, _, S in keep:
         assert torch.equal(dw0, dw1), S
 
