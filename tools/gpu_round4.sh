@@ -3,6 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 free -g | head -2 > gpurun_out/host.txt; nproc >> gpurun_out/host.txt
+python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -1
 python -m pytest tests -m gpu -q --timeout=1800 -p no:cacheprovider > gpurun_out/pytest_gpu_default.log 2>&1; echo "pytest default rc=$?"; tail -3 gpurun_out/pytest_gpu_default.log
 UZ_CONV_MATH=f32 python -m pytest tests -m gpu -q --timeout=1800 -p no:cacheprovider > gpurun_out/pytest_gpu_f32.log 2>&1; echo "pytest f32 rc=$?"; tail -3 gpurun_out/pytest_gpu_f32.log
 UZ_CONV_MATH=split python -m pytest tests -m gpu -q --timeout=1800 -p no:cacheprovider > gpurun_out/pytest_gpu_split.log 2>&1; echo "pytest split rc=$?"; tail -4 gpurun_out/pytest_gpu_split.log
