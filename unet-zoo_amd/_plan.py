@@ -1380,9 +1380,6 @@ class Plan:
             for fn in reversed(self._bwd):
                 self._newgroup()
                 fn()
-            for fn in self._bwd_tail:
-                self._newgroup()
-                fn()
             if self._dbias_jobs:
                 # all bias gradients of the folded ReLU backward in one launch (21 launches of ~7 us in U-Net's single chain)
                 for part_jobs in self._by_bucket(self._dbias_jobs, lambda j: j[1]):
@@ -1410,6 +1407,13 @@ class Plan:
                     self._emit(self.bwd_ops, "UZ_OP_WGRAD_REDUCE_TABLE",
                                p=[self.ptr_table(refs), ("gflat_keys", tuple(j[1] for j in part))], i=[len(part), blk])
                 self._wgrad_jobs = []
+            # the regulariser's gradients ADD to what the layers wrote (g += coeff w / |w|): behind the deferred table reductions, which
+            # ASSIGN the bias / weight gradients they sum (round 4 until its last hours ran them in front - the table overwrote the
+            # regulariser's share of every 3 x 3 weight gradient; tests/test_unet_probunet_gpu.py now compares the plans with and
+            # without tables bit for bit)
+            for fn in self._bwd_tail:
+                self._newgroup()
+                fn()
             # data parallel: one event per gradient bucket, recorded as soon as every writer of that slice of the flat
             # gradient buffer is done (the scheduler hoists the marker to that point of the DAG); the communication
             # stream waits for it and all-reduces the bucket beside the rest of the backward tape
