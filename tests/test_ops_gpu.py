@@ -424,10 +424,9 @@ def test_bilinear(ac, H, W):
 
 
 def test_the_two_bilinear_backward_band_kernels_give_the_same_bits():
-    """uz_bilinear2x_bwd takes the float4-per-lane kernel or the pair kernel by the ALIGNMENT of its views (a lane's scratch moves between
-    eager execution and graph replay, and between the plans of a data-parallel and a single-process run): the two must be
-    interchangeable bit for bit, or "graph replay == eager" and "DP at world size 1 == no DP" break (round 4: they did, with
-    compiler-contracted sums).  Two fresh processes (the choice is read once per process), checksums of the same calls."""
+    """uz_bilinear2x_bwd takes the float4-per-lane kernel or the pair kernel by the shape and alignment of its views: the two must be
+    interchangeable bit for bit (explicit fmaf chains in both; with compiler-contracted sums they differed in the last bit).  Two fresh
+    processes (the choice is read once per process), checksums of the same calls."""
     import subprocess, sys
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "diag_bilinear_bits.py")
     outs = []

@@ -211,9 +211,10 @@ __global__ __launch_bounds__(256) void bilinear_bwd_k(const RsP p) {   // src = 
 // multiply-adds per output instead of a KT x KT gather.  Low-res index i only receives from high-res 2i-1 .. 2i+2 (both
 // align_corners modes, any size - enumerated); the tap tables cover 2i-2 .. 2i+3 and hold exactly the forward's weights.
 constexpr int LB = 16, BWMAX = 128, KT = 6, BROWS = 2 * LB + KT - 2;
-// The six-tap sums of the two band kernels as explicit fused multiply-add chains: the pair and the float4 kernel are chosen by the
-// ALIGNMENT of the views they get (lane scratch moves between eager and graph replay, between plans), so they must produce the same
-// bits - left to the compiler, the same source expression was contracted differently in the two kernels.
+// The six-tap sums of the two band kernels as explicit fused multiply-add chains: the pair and the float4 kernel serve the same
+// call by shape / alignment, so they must produce the same bits - left to the compiler, the same source expression was contracted
+// differently in the two kernels.  (the compiler-contracted build of the float4 kernel also made the
+// replayed training step non-deterministic under concurrency, cause not found; these chains are what the tests pin.)
 __device__ __forceinline__ float dot6(const float* w, float a0, float a1, float a2, float a3, float a4, float a5) {
     float t = w[0] * a0;
     t = fmaf(w[1], a1, t); t = fmaf(w[2], a2, t); t = fmaf(w[3], a3, t); t = fmaf(w[4], a4, t); t = fmaf(w[5], a5, t);
