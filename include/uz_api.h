@@ -303,6 +303,24 @@ int uz_latent_sample_fwd(const float* mu, const float* pre_sigma, const float* e
 int uz_latent_sample_bwd(const float* dmu, const float* dsigma, const float* dz,
                          const float* eps, const float* sigma,
                          float* dmu_pre, float* dpre_sigma, size_t n, int act, void* stream);
+/* The two heads of a SampleZBlock and its sampling tail as ONE launch (phiseg.py:95-105): mu = mu_conv(h), pre_sigma =
+ * sigma_conv(h) (1x1 convolutions, L latent channels each, weights [L][Cin], biases nullable), sigma = softplus(pre_sigma)
+ * (act = 0; act = 1: exp), z = mu + sigma * eps (z nullable).  h is a view of Cin channels in a buffer of CinTot; mu,
+ * pre_sigma, sigma, z, eps are contiguous [N][L][H][W].  Bit-identical to uz_conv_fwd x 2 + uz_latent_sample_fwd; h is read
+ * once.  1 <= L <= 4, Cin <= 512 (uz_latent_heads_ok). */
+int uz_latent_heads_ok(int Cin, int L);
+int uz_latent_heads_fwd(const float* h, int Cin, int CinTot, const float* w_mu, const float* b_mu,
+                        const float* w_sigma, const float* b_sigma, const float* eps, float* mu, float* pre_sigma,
+                        float* sigma, float* z, int L, int N, int H, int W, int act, void* stream);
+/* Backward of the two heads: dh (+)= w_a^T dy_a + w_b^T dy_b in one pass (head a's rows are added first: pass the head whose
+ * separate data gradient would have run first), and both heads' weight / bias gradients from one read of h (fp64 ordered
+ * partial sums in `workspace`, uz_latent_heads_bwd_weight_workspace bytes; db_* nullable). */
+int uz_latent_heads_bwd_data(const float* dy_a, const float* dy_b, int L, const float* w_a, const float* w_b,
+                             float* dh, int Cin, int CinTot, int N, int H, int W, int accumulate, void* stream);
+size_t uz_latent_heads_bwd_weight_workspace(int Cin, int L, int N, int H, int W);
+int uz_latent_heads_bwd_weight(const float* h, int Cin, int CinTot, const float* dy_a, const float* dy_b, int L,
+                               float* dw_a, float* db_a, float* dw_b, float* db_b, int N, int H, int W,
+                               void* workspace, size_t workspace_bytes, void* stream);
 /* KL_two_gauss_with_diag_cov with the reference's sigma1*sigma0 quirk (phiseg.py:436-453),
  * times `weight` (4**level, phiseg.py:463).  Tensors are (N, per_sample) contiguous.
  * fwd writes loss_out[0] (single block, ordered); bwd writes the four gradients * scale. */
@@ -405,6 +423,9 @@ enum {
   UZ_OP_CHAN_SUM_TABLE,    /* p[0] = table (uz_chan_sum_table), p[1] = the gradient regions it writes; i = n_entries, max_channels */
   UZ_OP_WGRAD_REDUCE_TABLE, /* p[0] = table (uz_wgrad_reduce_table), p[1] = the gradient regions it writes; i = n_layers, total_blocks */
   UZ_OP_CHAN_SUM_PARTIALS, /* p = partials, out; i = n_rows, C (uz_chan_sum_partials); CONV_BWD_DATA p[7] = a (folded ReLU backward), p[8] = partials, p[9] = dx bound; i[9] = CtotA */
+  UZ_OP_LATENT_HEADS_FWD,        /* p = h, w_mu, b_mu, w_sigma, b_sigma, eps, mu, pre, sigma, z; i = Cin, CinTot, L, N, H, W, act (uz_latent_heads_fwd) */
+  UZ_OP_LATENT_HEADS_BWD_DATA,   /* p = dy_a, dy_b, w_a, w_b, dh; i = L, Cin, CinTot, N, H, W, accumulate */
+  UZ_OP_LATENT_HEADS_BWD_WEIGHT, /* p = h, dy_a, dy_b, dw_a, db_a, dw_b, db_b, workspace; i = Cin, CinTot, L, N, H, W; n = workspace bytes */
   UZ_OP__COUNT
 };
 typedef struct uz_op {

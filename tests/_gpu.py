@@ -55,3 +55,8 @@ def relerr(got, ref):
 
 def maxabs(got, ref):
     return float((got.detach().cpu().double() - ref.detach().cpu().double()).abs().max())
+
+
+def L():
+    """The loaded C-ABI library (size queries: uz_*_workspace)."""
+    return _ffi.lib()

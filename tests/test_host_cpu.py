@@ -30,7 +30,7 @@ def test_phiseg_spec_equals_reference_state_dict():
         assert phiseg_spec(1, 2, meta["filters"]) == G.spec_of(meta)
 
 
-def test_phiseg_structure_only_on_cpu_and_no_fallback():
+def test_phiseg_structure_only_on_cpu_and_no_fallback(monkeypatch):
     from unet_zoo_amd.models.phiseg import PHISeg
     _, meta = G.load("phiseg_small")
     net = PHISeg(1, 2, meta["filters"], image_size=(1, 64, 64), device="cpu")
@@ -38,7 +38,19 @@ def test_phiseg_structure_only_on_cpu_and_no_fallback():
     assert sum(p.numel() for p in net.parameters()) == net._ptab.n_params
     plan = net._build(2, 64, 64, True, True)
     cnt = plan.summary()
-    assert cnt["fwd"] == 287 + 2 and cnt["bwd"] > 400        # + the two head ops (zero the bound slots, measure the parameter bound)
+    # + the two head ops (zero the bound slots, measure the parameter bound); the 10 SampleZBlock tails (5 prior + 5 posterior levels) are
+    # one op each instead of mu head + sigma head + sampling (Plan.latent_heads), their backward three ops instead of five
+    assert cnt["fwd"] == 287 - 20 + 2 and cnt["bwd"] > 400
+    codes = [o["code"] for o in plan.fwd_ops]
+    assert codes.count("UZ_OP_LATENT_HEADS_FWD") == 10 and "UZ_OP_LATENT_FWD" not in codes
+    bcodes = [o["code"] for o in plan.bwd_ops]
+    assert bcodes.count("UZ_OP_LATENT_HEADS_BWD_DATA") == 10 and bcodes.count("UZ_OP_LATENT_HEADS_BWD_WEIGHT") == 10 and bcodes.count("UZ_OP_LATENT_BWD") == 10
+    monkeypatch.setenv("UZ_FUSE_HEADS", "0")
+    net0 = PHISeg(1, 2, meta["filters"], image_size=(1, 64, 64), device="cpu")
+    plan0 = net0._build(2, 64, 64, True, True)
+    assert plan0.summary()["fwd"] == 287 + 2 and len(plan0.bwd_ops) == len(plan.bwd_ops) + 20
+    assert sorted(plan0.param_grads) == sorted(plan.param_grads)
+    monkeypatch.delenv("UZ_FUSE_HEADS")
     unused = sorted(k for k in net._pmap if k not in plan.param_grads)
     assert len(unused) == 16 and all("upsampling_path.4" in k for k in unused)
     if not torch.cuda.is_available():

@@ -705,3 +705,61 @@ def test_conv_bf16_arithmetic_mode(N, Cin, Cout, H, W):
     assert g.relerr(y, yr) <= TOL and g.relerr(dx, dx_ref if dgrad_bf16 else dx_ref32) <= TOL and g.relerr(dw, dw_ref if wgrad_bf16 else dw_ref32) <= 5e-5
     dev32 = g.relerr(y, y32)
     assert 1e-5 < dev32 < 2e-2, dev32            # it IS bf16 arithmetic (not the fp32-accurate split), and no worse than bf16 should be
+
+
+@pytest.mark.parametrize("N,Cin,ctot,c0,L,H,W,act", [(3, 32, 40, 5, 2, 16, 16, 0), (2, 192, 192, 0, 2, 8, 8, 0), (2, 7, 9, 1, 3, 5, 7, 0),
+                                                     (2, 16, 16, 0, 1, 12, 12, 1), (1, 24, 24, 0, 4, 32, 32, 0)])
+def test_latent_heads_equal_the_separate_ops_bit_for_bit(N, Cin, ctot, c0, L, H, W, act):
+    """uz_latent_heads_* (the two 1x1 heads of a SampleZBlock + its sampling tail as one op per direction, phiseg.py:95-105) against the
+    ops they replace - uz_conv_fwd x 2 + uz_latent_sample_fwd; uz_conv_bwd_weight x 2, uz_conv_bwd_data x 2 (sigma head first, the mu
+    head accumulating) - bit for bit, on float4 and scalar planes, in a wider buffer, with and without z, accumulating or not; and against
+    torch for the values."""
+    g = _g()
+    d = g.dev()
+    h = g.rnd(N, Cin, H, W, seed=1)
+    hbuf, hv = g.view_in(h, ctot, c0)
+    wm, ws_ = g.rnd(L, Cin, 1, 1, seed=2, scale=0.3).to(d), g.rnd(L, Cin, 1, 1, seed=3, scale=0.3).to(d)
+    bm, bs = g.rnd(L, seed=4).to(d), g.rnd(L, seed=5).to(d)
+    eps = g.rnd(N, L, H, W, seed=6).to(d)
+    wsz = max(g.L().uz_conv_workspace(Cin, L, N, H, W, 1), g.L().uz_conv_bwd_weight_workspace(Cin, L, N, H, W, 1),
+              g.L().uz_latent_heads_bwd_weight_workspace(Cin, L, N, H, W), 256)
+    wsb = torch.empty(wsz, dtype=torch.uint8, device=d)
+    new = lambda: torch.full((N, L, H, W), float("nan"), device=d)
+    # forward
+    mu0, pre0, sg0, z0 = new(), new(), new(), new()
+    g.call("uz_conv_fwd", hv, Cin, ctot, wm, bm, mu0, L, L, N, H, W, 1, 0, None, None, None, wsb, wsz)
+    g.call("uz_conv_fwd", hv, Cin, ctot, ws_, bs, pre0, L, L, N, H, W, 1, 0, None, None, None, wsb, wsz)
+    g.call("uz_latent_sample_fwd", mu0, pre0, eps, sg0, z0, mu0.numel(), act)
+    mu1, pre1, sg1, z1 = new(), new(), new(), new()
+    g.call("uz_latent_heads_fwd", hv, Cin, ctot, wm, bm, ws_, bs, eps, mu1, pre1, sg1, z1, L, N, H, W, act)
+    for a, b in ((mu0, mu1), (pre0, pre1), (sg0, sg1), (z0, z1)):
+        assert torch.equal(a, b)
+    sg2 = new()
+    g.call("uz_latent_heads_fwd", hv, Cin, ctot, wm, bm, ws_, bs, None, mu1, pre1, sg2, None, L, N, H, W, act)      # the prior's discarded draw
+    assert torch.equal(sg2, sg0)
+    mr = F.conv2d(h, wm.cpu(), bm.cpu())
+    pr = F.conv2d(h, ws_.cpu(), bs.cpu())
+    sr = torch.exp(pr) if act else F.softplus(pr)
+    assert g.relerr(mu1, mr) <= 2e-6 and g.relerr(sg1, sr) <= 2e-6 and g.relerr(z1, mr + sr * eps.cpu()) <= 2e-6
+    # backward
+    dmu, dpre = g.rnd(N, L, H, W, seed=7).to(d), g.rnd(N, L, H, W, seed=8).to(d)
+    for accumulate in (0, 1):
+        base = g.rnd(N, ctot, H, W, seed=9).to(d)
+        dh0, dh1 = base.clone(), base.clone()
+        g.call("uz_conv_bwd_data", dpre, L, L, ws_, dh0[:, c0:], Cin, ctot, N, H, W, 1, accumulate, None, None, wsb, wsz)
+        g.call("uz_conv_bwd_data", dmu, L, L, wm, dh0[:, c0:], Cin, ctot, N, H, W, 1, 1, None, None, wsb, wsz)
+        g.call("uz_latent_heads_bwd_data", dpre, dmu, L, ws_, wm, dh1[:, c0:], Cin, ctot, N, H, W, accumulate)
+        assert torch.equal(dh0, dh1)                       # (the channels outside the view included: untouched)
+        ref = F.conv_transpose2d(dpre.cpu(), ws_.cpu()) + F.conv_transpose2d(dmu.cpu(), wm.cpu()) + (base[:, c0:c0 + Cin].cpu() if accumulate else 0)
+        assert g.relerr(dh1[:, c0:c0 + Cin], ref) <= 2e-6
+    dws0, dbs0, dwm0, dbm0 = torch.empty_like(ws_), torch.empty_like(bs), torch.empty_like(wm), torch.empty_like(bm)
+    g.call("uz_conv_bwd_weight", hv, Cin, ctot, dpre, L, L, dws0, dbs0, N, H, W, 1, None, None, wsb, wsz)
+    g.call("uz_conv_bwd_weight", hv, Cin, ctot, dmu, L, L, dwm0, dbm0, N, H, W, 1, None, None, wsb, wsz)
+    dws1, dbs1, dwm1, dbm1 = torch.empty_like(ws_), torch.empty_like(bs), torch.empty_like(wm), torch.empty_like(bm)
+    g.call("uz_latent_heads_bwd_weight", hv, Cin, ctot, dpre, dmu, L, dws1, dbs1, dwm1, dbm1, N, H, W, wsb, wsz)
+    for a, b in ((dws0, dws1), (dbs0, dbs1), (dwm0, dwm1), (dbm0, dbm1)):
+        assert torch.equal(a, b)
+    hr = h.clone().requires_grad_(True)
+    wr = wm.cpu().clone().requires_grad_(True)
+    (F.conv2d(hr, wr) * dmu.cpu()).sum().backward()
+    assert g.relerr(dwm1, wr.grad) <= 1e-5 and g.relerr(dbm1, dmu.cpu().sum((0, 2, 3))) <= 1e-5

@@ -465,3 +465,40 @@ def test_two_replayed_runs_at_the_headline_size_agree_bit_for_bit(lanes, monkeyp
         torch.cuda.synchronize()
         assert torch.equal(nets[0][0]._ptab.gflat, nets[1][0]._ptab.gflat), step
         assert torch.equal(nets[0][0]._ptab.pflat, nets[1][0]._ptab.pflat), step
+
+
+def test_fused_latent_heads_leave_the_training_step_bit_identical(monkeypatch):
+    """Plan.latent_heads (one op per direction for the two heads + sampling tail of every SampleZBlock, phiseg.py:95-105) against the
+    plan with the separate ops (UZ_FUSE_HEADS=0): same loss, same gradients, same parameters after three Adam steps, bit for bit, and
+    the same decoded sample - the fused kernels keep the arithmetic order of the ops they replace."""
+    from unet_zoo_amd.models.phiseg import PHISeg
+    from unet_zoo_amd.optim import FusedAdam
+    from unet_zoo_amd.synthetic import synthetic_batch
+    B = 4
+    x, m, _ = synthetic_batch(B, 64, 64, seed=11)
+    x, m = torch.from_numpy(x).to("cuda"), torch.from_numpy(m).to("cuda")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    noise = [torch.randn(s_, generator=g, device="cuda") for s_ in [(B, 2, 1 << k, 1 << k) for k in range(5)] * 2]      # deepest level first: 1 x 1 ... 16 x 16
+    runs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("UZ_FUSE_HEADS", fuse)
+        torch.manual_seed(1)
+        net = PHISeg(1, 2, [8, 16, 32, 48, 48, 48, 48], latent_levels=5, image_size=(1, 64, 64))
+        net.train()
+        opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
+        losses = []
+        for step in range(3):
+            net.forward(x, m, training=True, eps=noise)
+            loss = net.loss(m)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        codes = [o["code"] for o in net._cur.fwd_ops]
+        assert ("UZ_OP_LATENT_HEADS_FWD" in codes) == (fuse == "1")
+        torch.cuda.synchronize()
+        runs.append((losses, net._ptab.gflat.clone(), net._ptab.pflat.clone(), [t.clone() for t in net.posterior_mu + net.posterior_sigma + net.prior_sigma]))
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    for a, b in zip(runs[0][3], runs[1][3]):
+        assert torch.equal(a, b)

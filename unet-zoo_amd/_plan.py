@@ -954,6 +954,50 @@ class Plan:
         self._push_bwd(bwd)
         return lat
 
+    def latent_heads(self, h, mu_prefix, sigma_prefix, eps, name, want_z=True, act=0):
+        """The tail of a SampleZBlock (phiseg.py:95-105): mu = mu_conv(h), pre = sigma_conv(h), sigma = softplus(pre), z = mu + sigma eps.
+        On 2-D fp32 planes the three forward launches become ONE (h read once) and the six launches of the two heads' backward THREE
+        (one data gradient that writes dh once, one weight-gradient pair that reads h once) - csrc/conv1x1_small.hip, bit-identical to the
+        separate ops (UZ_FUSE_HEADS=0 keeps those).  Returns the Latent like latent()."""
+        wm, bm, wsg, bsg = mu_prefix + ".weight", mu_prefix + ".bias", sigma_prefix + ".weight", sigma_prefix + ".bias"
+        L, cin = self.ptab.shape[wm][0], h.C
+        fuse = (os.environ.get("UZ_FUSE_HEADS", "1") == "1" and h.nb is None and self.ptab.shape[wm][2:] == (1, 1) and self.ptab.shape[wsg] == self.ptab.shape[wm]
+                and len(self.ptab.shape[wm]) == 4 and bool(self.L.uz_latent_heads_ok(cin, L)) and not self.__dict__.get("_in_rev", False))
+        if not fuse:
+            mu = self.conv_bare(h, mu_prefix)
+            ps = self.conv_bare(h, sigma_prefix)
+            return self.latent(mu, ps, eps, name, want_z=want_z, act=act)
+        mu = self.buf(mu_prefix + ":y", L, h.H, h.W)
+        pre = self.buf(sigma_prefix + ":y", L, h.H, h.W)
+        sigma = self.buf(name + ":sigma", L, h.H, h.W)
+        z = self.buf(name + ":z", L, h.H, h.W) if want_z else None
+        lat = Latent(mu, pre, sigma, z, eps, act)
+        self._newgroup()
+        self._emit(self.target, "UZ_OP_LATENT_HEADS_FWD", p=[h, self.P(wm), self.P(bm), self.P(wsg), self.P(bsg), eps, mu, pre, sigma, z],
+                   i=[cin, h.Ctot, L, h.N, h.H, h.W, act])
+
+        def bwd():
+            dz = self.gview(z) if (z is not None and self._has_grad(z)) else None
+            if dz is None and lat.kl_dmu is None:
+                return
+            assert self._claim(mu) == 0 and self._claim(pre) == 0
+            self._emit(self.bwd_ops, "UZ_OP_LATENT_BWD",
+                       p=[lat.kl_dmu, lat.kl_dsigma, dz, eps, sigma, self.gview(mu), self.gview(pre)], i=[act], n=mu.numel)
+            # head a = the sigma head: its separate backward ran first (reverse order of the forward), so its rows are added first.
+            # The data gradient - what the unit below waits for - goes first; the weight gradients are a scheduling group of their own.
+            if h.buf.requires_grad:
+                acc = self._claim(h)
+                self._emit(self.bwd_ops, "UZ_OP_LATENT_HEADS_BWD_DATA", p=[self.gview(pre), self.gview(mu), self.P(wsg), self.P(wm), self.gview(h)],
+                           i=[L, cin, h.Ctot, h.N, h.H, h.W, acc])
+            ws = self.L.uz_latent_heads_bwd_weight_workspace(cin, L, h.N, h.H, h.W)
+            self.scratch["wgrad"] = max(self.scratch["wgrad"], ws)
+            self._newgroup()
+            self._emit(self.bwd_ops, "UZ_OP_LATENT_HEADS_BWD_WEIGHT",
+                       p=[h, self.gview(pre), self.gview(mu), self.G(wsg), self.G(bsg), self.G(wm), self.G(bm), ("scratch", "wgrad")],
+                       i=[cin, h.Ctot, L, h.N, h.H, h.W], n=ws)
+        self._push_bwd(bwd)
+        return lat
+
     def kl(self, q, p, weight, term):
         """weight * KL_two_gauss_with_diag_cov(q || p) (phiseg.py:436-479)."""
         n, per = q.mu.N, q.mu.C * q.mu.H * q.mu.W
@@ -1598,6 +1642,7 @@ class Plan:
         "UZ_OP_AVGPOOL_FWD": (1,), "UZ_OP_AVGPOOL_BWD": (1, 3, 4), "UZ_OP_BILINEAR_FWD": (1,), "UZ_OP_BILINEAR_BWD": (1, 3, 4),
         "UZ_OP_NEAREST_FWD": (1,), "UZ_OP_NEAREST_BWD": (1,), "UZ_OP_SPATIAL_MEAN_FWD": (1,), "UZ_OP_SPATIAL_MEAN_BWD": (1,),
         "UZ_OP_POSTERIOR_INPUT": (2,), "UZ_OP_LATENT_FWD": (3, 4), "UZ_OP_LATENT_BWD": (5, 6),
+        "UZ_OP_LATENT_HEADS_FWD": (6, 7, 8, 9), "UZ_OP_LATENT_HEADS_BWD_DATA": (4,), "UZ_OP_LATENT_HEADS_BWD_WEIGHT": (3, 4, 5, 6),
         "UZ_OP_KL_FWD": (4,), "UZ_OP_KL_BWD": (5, 6, 7, 8), "UZ_OP_CE_FWD": (2,), "UZ_OP_CE_BWD": (1,),
         "UZ_OP_SUM_TERMS": (1,), "UZ_OP_SCALE": (0,), "UZ_OP_COPY": (0,), "UZ_OP_MEMSET": (0,),
         "UZ_OP_L2_NORMS": (2,), "UZ_OP_L2_NORMS_BWD": (4,),

@@ -299,3 +299,313 @@ extern "C" int uz_conv1x1_bwd_weight_b16(const void* x, int Cin, int CinTot, con
     const int rc = uz::conv1x1_small_bwd_weight(static_cast<const float*>(x), Cin, CinTot, dy, Cout, CoutTot, dw, db, N, H, W, workspace, uz::S(stream), x_b16 != 0);
     return rc == -2 ? uz::fail("conv1x1_bwd_weight_b16: %d outputs not covered", Cout) : rc;
 }
+
+// ---------------------------------------------------------------- the two heads of a SampleZBlock as ONE op per direction
+// mu = mu_conv(h), pre = sigma_conv(h), sigma = softplus(pre), z = mu + sigma eps (phiseg.py:95-105): three launches and two reads
+// of h in the forward, six launches, three reads of h and a read-modify-write of dh in the backward - on the serial chain of the
+// latent hierarchy (level k + 1 waits for z_k).  Here: one forward launch (h read once; mu, pre, sigma, z written from registers),
+// one data-gradient launch (dh written once from both heads' dy) and one weight-gradient launch pair (h read once).  Every output
+// keeps the arithmetic ORDER of the separate kernels above (per-output fmaf chains over the input channels; the data gradient adds
+// head A's rows before head B's, as the two accumulating launches did; the weight gradient's fp32 / fp64 partial sums are per output
+// row), so results are bit-identical to the three-op path - tests/test_ops_gpu.py compares them.
+namespace {
+
+struct HP {
+    const float* x; int Cin, CinTot, N, HW;
+    const float* wA; const float* bA; const float* wB; const float* bB;          // head A's rows come first, then head B's
+    const float* eps; float* mu; float* pre; float* sigma; float* z; int act;    // forward: A = mu head, B = sigma head
+    const float* dyA; const float* dyB; float* dx; int accumulate, cgroup;       // data gradient: dy of either head, [N][L][HW]
+    double* part; int nchunk;                                                    // weight gradient
+};
+
+__device__ __forceinline__ float head_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // = pointwise.hip softplus_f
+__device__ __forceinline__ float head_sigma(float pre, int act) { return act ? expf(pre) : head_softplus(pre); }
+
+template <int LL>
+__device__ __forceinline__ void heads_weights(const HP& p, float* ws) {
+    const int half = LL * p.Cin;
+    for (int i = threadIdx.x; i < 2 * half; i += 256) ws[i] = i < half ? p.wA[i] : p.wB[i - half];
+    __syncthreads();
+}
+
+template <int LL, bool VEC>
+__global__ __launch_bounds__(256) void heads_fwd(const HP p) {
+    constexpr int NO = 2 * LL;
+    __shared__ float ws[MAXN * 512];
+    const int b = blockIdx.y;
+    heads_weights<LL>(p, ws);
+    float bias[NO];
+#pragma unroll
+    for (int n = 0; n < LL; ++n) { bias[n] = p.bA ? p.bA[n] : 0.f; bias[LL + n] = p.bB ? p.bB[n] : 0.f; }
+    if (VEC) {
+        const int q = (blockIdx.x * 256 + threadIdx.x) * 4;
+        if (q >= p.HW) return;
+        float4 acc[NO];
+#pragma unroll
+        for (int n = 0; n < NO; ++n) acc[n] = make_float4(bias[n], bias[n], bias[n], bias[n]);
+#pragma unroll 8
+        for (int c = 0; c < p.Cin; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(p.x + ((size_t)b * p.CinTot + c) * p.HW + q);
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+                const float wv = ws[n * p.Cin + c];
+                acc[n].x = fmaf(wv, v.x, acc[n].x); acc[n].y = fmaf(wv, v.y, acc[n].y);
+                acc[n].z = fmaf(wv, v.z, acc[n].z); acc[n].w = fmaf(wv, v.w, acc[n].w);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < LL; ++n) {
+            const size_t e = ((size_t)b * LL + n) * p.HW + q;
+            const float4 m = acc[n], pr = acc[LL + n];
+            const float4 s = make_float4(head_sigma(pr.x, p.act), head_sigma(pr.y, p.act), head_sigma(pr.z, p.act), head_sigma(pr.w, p.act));
+            *reinterpret_cast<float4*>(p.mu + e) = m;
+            *reinterpret_cast<float4*>(p.pre + e) = pr;
+            *reinterpret_cast<float4*>(p.sigma + e) = s;
+            if (p.z) {
+                const float4 ev = *reinterpret_cast<const float4*>(p.eps + e);
+                *reinterpret_cast<float4*>(p.z + e) = make_float4(m.x + s.x * ev.x, m.y + s.y * ev.y, m.z + s.z * ev.z, m.w + s.w * ev.w);
+            }
+        }
+    } else {
+        for (int q = blockIdx.x * PIX + threadIdx.x; q < min(p.HW, (int)(blockIdx.x + 1) * PIX); q += 256) {
+            float acc[NO];
+#pragma unroll
+            for (int n = 0; n < NO; ++n) acc[n] = bias[n];
+            for (int c = 0; c < p.Cin; ++c) {
+                const float v = p.x[((size_t)b * p.CinTot + c) * p.HW + q];
+#pragma unroll
+                for (int n = 0; n < NO; ++n) acc[n] = fmaf(ws[n * p.Cin + c], v, acc[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < LL; ++n) {
+                const size_t e = ((size_t)b * LL + n) * p.HW + q;
+                const float s = head_sigma(acc[LL + n], p.act);
+                p.mu[e] = acc[n]; p.pre[e] = acc[LL + n]; p.sigma[e] = s;
+                if (p.z) p.z[e] = acc[n] + s * p.eps[e];
+            }
+        }
+    }
+}
+
+template <int LL, bool VEC>
+__global__ __launch_bounds__(256) void heads_bwd_data(const HP p) {
+    constexpr int NO = 2 * LL;
+    __shared__ float ws[MAXN * 512];
+    const int b = blockIdx.y;
+    heads_weights<LL>(p, ws);
+    const int c_lo = blockIdx.z * p.cgroup, c_hi = min(p.Cin, c_lo + p.cgroup);
+    if (VEC) {
+        const int q = (blockIdx.x * 256 + threadIdx.x) * 4;
+        if (q >= p.HW) return;
+        float4 g[NO];
+#pragma unroll
+        for (int n = 0; n < LL; ++n) {
+            g[n] = *reinterpret_cast<const float4*>(p.dyA + ((size_t)b * LL + n) * p.HW + q);
+            g[LL + n] = *reinterpret_cast<const float4*>(p.dyB + ((size_t)b * LL + n) * p.HW + q);
+        }
+#pragma unroll 4
+        for (int c = c_lo; c < c_hi; ++c) {
+            float4* dst = reinterpret_cast<float4*>(p.dx + ((size_t)b * p.CinTot + c) * p.HW + q);
+            float4 r = p.accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+                const float wv = ws[n * p.Cin + c];
+                r.x = fmaf(wv, g[n].x, r.x); r.y = fmaf(wv, g[n].y, r.y); r.z = fmaf(wv, g[n].z, r.z); r.w = fmaf(wv, g[n].w, r.w);
+            }
+            *dst = r;
+        }
+    } else {
+        for (int q = blockIdx.x * PIX + threadIdx.x; q < min(p.HW, (int)(blockIdx.x + 1) * PIX); q += 256) {
+            float g[NO];
+#pragma unroll
+            for (int n = 0; n < LL; ++n) { g[n] = p.dyA[((size_t)b * LL + n) * p.HW + q]; g[LL + n] = p.dyB[((size_t)b * LL + n) * p.HW + q]; }
+            for (int c = c_lo; c < c_hi; ++c) {
+                float* dst = p.dx + ((size_t)b * p.CinTot + c) * p.HW + q;
+                float r = p.accumulate ? *dst : 0.f;
+#pragma unroll
+                for (int n = 0; n < NO; ++n) r = fmaf(ws[n * p.Cin + c], g[n], r);
+                *dst = r;
+            }
+        }
+    }
+}
+
+// grid (Cin, nchunk) as c1_bwd_weight_partial: block (c, k) reduces its slice of the N * HW pixels for channel c against the 2 L rows
+template <int LL>
+__global__ __launch_bounds__(256) void heads_bwd_weight_partial(const HP p) {
+    constexpr int NO = 2 * LL;
+    __shared__ double sm[4 * 2 * MAXN];
+    const int c = blockIdx.x, k = blockIdx.y;
+    const bool do_bias = (c == 0);
+    const long long total = (long long)p.N * p.HW;
+    const long long per = ((total + p.nchunk - 1) / p.nchunk + 1023) / 1024 * 1024;
+    const long long lo = k * per, hi = min(total, lo + per);
+    double dacc[2 * NO];
+#pragma unroll
+    for (int n = 0; n < 2 * NO; ++n) dacc[n] = 0.0;
+    if (p.HW % 4 == 0 && per % 4 == 0) {
+        float4 acc[NO], bacc[NO];
+#pragma unroll
+        for (int n = 0; n < NO; ++n) { acc[n] = make_float4(0.f, 0.f, 0.f, 0.f); bacc[n] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        long long i = lo + 4 * threadIdx.x;
+        int b = (int)(i / p.HW), q = (int)(i - (long long)b * p.HW), cnt = 0;
+        for (; i < hi; i += 1024) {
+            const float4 xv = *reinterpret_cast<const float4*>(p.x + ((size_t)b * p.CinTot + c) * p.HW + q);
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+                const float* dy = n < LL ? p.dyA : p.dyB;
+                const float4 g = *reinterpret_cast<const float4*>(dy + ((size_t)b * LL + (n < LL ? n : n - LL)) * p.HW + q);
+                acc[n].x = fmaf(g.x, xv.x, acc[n].x); acc[n].y = fmaf(g.y, xv.y, acc[n].y);
+                acc[n].z = fmaf(g.z, xv.z, acc[n].z); acc[n].w = fmaf(g.w, xv.w, acc[n].w);
+                if (do_bias) { bacc[n].x += g.x; bacc[n].y += g.y; bacc[n].z += g.z; bacc[n].w += g.w; }
+            }
+            q += 1024;
+            while (q >= p.HW) { q -= p.HW; ++b; }
+            if (++cnt == 32) {
+#pragma unroll
+                for (int n = 0; n < NO; ++n) {
+                    dacc[n] += (double)((acc[n].x + acc[n].y) + (acc[n].z + acc[n].w));
+                    dacc[NO + n] += (double)((bacc[n].x + bacc[n].y) + (bacc[n].z + bacc[n].w));
+                    acc[n] = make_float4(0.f, 0.f, 0.f, 0.f); bacc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                cnt = 0;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+            dacc[n] += (double)((acc[n].x + acc[n].y) + (acc[n].z + acc[n].w));
+            dacc[NO + n] += (double)((bacc[n].x + bacc[n].y) + (bacc[n].z + bacc[n].w));
+        }
+    } else {
+        float acc[NO];
+#pragma unroll
+        for (int n = 0; n < NO; ++n) acc[n] = 0.f;
+        long long i = lo + threadIdx.x;
+        int b = (int)(i / p.HW), q = (int)(i - (long long)b * p.HW), cnt = 0;
+        for (; i < hi; i += 256) {
+            const float xv = p.x[((size_t)b * p.CinTot + c) * p.HW + q];
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+                const float* dy = n < LL ? p.dyA : p.dyB;
+                const float g = dy[((size_t)b * LL + (n < LL ? n : n - LL)) * p.HW + q];
+                acc[n] = fmaf(g, xv, acc[n]);
+                if (do_bias) dacc[NO + n] += g;
+            }
+            q += 256;
+            while (q >= p.HW) { q -= p.HW; ++b; }
+            if (++cnt == 64) {
+#pragma unroll
+                for (int n = 0; n < NO; ++n) { dacc[n] += acc[n]; acc[n] = 0.f; }
+                cnt = 0;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NO; ++n) dacc[n] += acc[n];
+    }
+    uz::block_sum_d<2 * NO>(dacc, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int n = 0; n < NO; ++n) p.part[((size_t)k * NO + n) * p.Cin + c] = dacc[n];
+        if (do_bias) {
+            double* pb = p.part + (size_t)p.nchunk * NO * p.Cin;
+#pragma unroll
+            for (int n = 0; n < NO; ++n) pb[k * NO + n] = dacc[NO + n];
+        }
+    }
+}
+template <int LL>
+__global__ __launch_bounds__(256) void heads_bwd_weight_final(const double* __restrict__ part, int nchunk, int Cin, float* __restrict__ dwA, float* __restrict__ dbA,
+                                                               float* __restrict__ dwB, float* __restrict__ dbB) {
+    constexpr int NO = 2 * LL;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < NO * Cin) {
+        double s = 0.0;
+        for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * NO * Cin + i];
+        if (i < LL * Cin) dwA[i] = (float)s; else dwB[i - LL * Cin] = (float)s;
+    }
+    if (i < NO) {
+        const double* pb = part + (size_t)nchunk * NO * Cin;
+        double s = 0.0;
+        for (int k = 0; k < nchunk; ++k) s += pb[k * NO + i];
+        if (i < LL) { if (dbA) dbA[i] = (float)s; } else if (dbB) dbB[i - LL] = (float)s;
+    }
+}
+
+inline bool al16(const void* a) { return (reinterpret_cast<uintptr_t>(a) & 15) == 0; }
+inline int heads_nchunk(int N, int H, int W) {
+    const long long total = (long long)N * H * W;
+    const int nchunk = (int)((total + 16383) / 16384);
+    return nchunk > 64 ? 64 : nchunk;
+}
+
+#define HEADS_DISPATCH(KERN, VECFLAG, GRID)                                                                                     \
+    switch (L) {                                                                                                                 \
+        case 1: if (VECFLAG) hipLaunchKernelGGL((KERN<1, true>), GRID, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERN<1, false>), GRID, dim3(256), 0, st, p); break; \
+        case 2: if (VECFLAG) hipLaunchKernelGGL((KERN<2, true>), GRID, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERN<2, false>), GRID, dim3(256), 0, st, p); break; \
+        case 3: if (VECFLAG) hipLaunchKernelGGL((KERN<3, true>), GRID, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERN<3, false>), GRID, dim3(256), 0, st, p); break; \
+        case 4: if (VECFLAG) hipLaunchKernelGGL((KERN<4, true>), GRID, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERN<4, false>), GRID, dim3(256), 0, st, p); break; \
+        default: return uz::fail("latent heads: %d latent channels per head not covered (1 .. 4)", L);                          \
+    }
+
+}  // namespace
+
+extern "C" int uz_latent_heads_ok(int Cin, int L) { return L >= 1 && L <= 4 && Cin >= 1 && Cin <= 512 ? 1 : 0; }
+
+extern "C" int uz_latent_heads_fwd(const float* h, int Cin, int CinTot, const float* w_mu, const float* b_mu, const float* w_sigma, const float* b_sigma,
+                                   const float* eps, float* mu, float* pre_sigma, float* sigma, float* z, int L, int N, int H, int W, int act, void* stream) {
+    UZ_REQUIRE(uz_latent_heads_ok(Cin, L) && N > 0 && H > 0 && W > 0 && CinTot >= Cin, "latent_heads_fwd: shape not covered (1 <= L <= 4, Cin <= 512)");
+    UZ_REQUIRE(h && w_mu && w_sigma && mu && pre_sigma && sigma, "latent_heads_fwd: null operand");
+    UZ_REQUIRE(!z || eps, "latent_heads_fwd: z needs eps");
+    hipStream_t st = uz::S(stream);
+    HP p = {}; p.x = h; p.Cin = Cin; p.CinTot = CinTot; p.N = N; p.HW = H * W; p.wA = w_mu; p.bA = b_mu; p.wB = w_sigma; p.bB = b_sigma;
+    p.eps = eps; p.mu = mu; p.pre = pre_sigma; p.sigma = sigma; p.z = z; p.act = act;
+    const bool v = p.HW % 4 == 0 && al16(h) && al16(mu) && al16(pre_sigma) && al16(sigma) && (!z || (al16(z) && al16(eps)));
+    const dim3 grid(uz::ceil_div(p.HW, PIX), N);
+    HEADS_DISPATCH(heads_fwd, v, grid)
+    return uz::check_launch("heads_fwd");
+}
+
+extern "C" int uz_latent_heads_bwd_data(const float* dy_a, const float* dy_b, int L, const float* w_a, const float* w_b, float* dh, int Cin, int CinTot,
+                                        int N, int H, int W, int accumulate, void* stream) {
+    UZ_REQUIRE(uz_latent_heads_ok(Cin, L) && N > 0 && H > 0 && W > 0 && CinTot >= Cin, "latent_heads_bwd_data: shape not covered (1 <= L <= 4, Cin <= 512)");
+    UZ_REQUIRE(dy_a && dy_b && w_a && w_b && dh, "latent_heads_bwd_data: null operand");
+    hipStream_t st = uz::S(stream);
+    HP p = {}; p.dyA = dy_a; p.dyB = dy_b; p.wA = w_a; p.wB = w_b; p.dx = dh; p.Cin = Cin; p.CinTot = CinTot; p.N = N; p.HW = H * W; p.accumulate = accumulate;
+    const bool v = p.HW % 4 == 0 && al16(dy_a) && al16(dy_b) && al16(dh);
+    const int pixblk = uz::ceil_div(p.HW, PIX) * N;            // as conv1x1_small_bwd_data: channel groups over grid.z on the small planes
+    int groups = uz::ceil_div(1024, pixblk);
+    if (groups > uz::ceil_div(Cin, 8)) groups = uz::ceil_div(Cin, 8);
+    if (groups < 1) groups = 1;
+    p.cgroup = uz::ceil_div(Cin, groups);
+    const dim3 grid(uz::ceil_div(p.HW, PIX), N, uz::ceil_div(Cin, p.cgroup));
+    HEADS_DISPATCH(heads_bwd_data, v, grid)
+    return uz::check_launch("heads_bwd_data");
+}
+
+extern "C" size_t uz_latent_heads_bwd_weight_workspace(int Cin, int L, int N, int H, int W) {
+    const int nchunk = heads_nchunk(N, H, W);
+    return ((size_t)nchunk * 2 * L * Cin + (size_t)nchunk * 2 * L) * sizeof(double);
+}
+
+extern "C" int uz_latent_heads_bwd_weight(const float* h, int Cin, int CinTot, const float* dy_a, const float* dy_b, int L, float* dw_a, float* db_a,
+                                          float* dw_b, float* db_b, int N, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+    UZ_REQUIRE(uz_latent_heads_ok(Cin, L) && N > 0 && H > 0 && W > 0 && CinTot >= Cin, "latent_heads_bwd_weight: shape not covered (1 <= L <= 4, Cin <= 512)");
+    UZ_REQUIRE(h && dy_a && dy_b && dw_a && dw_b, "latent_heads_bwd_weight: null operand");
+    UZ_REQUIRE(workspace && workspace_bytes >= uz_latent_heads_bwd_weight_workspace(Cin, L, N, H, W), "latent_heads_bwd_weight: workspace too small");
+    hipStream_t st = uz::S(stream);
+    HP p = {}; p.x = h; p.dyA = dy_a; p.dyB = dy_b; p.Cin = Cin; p.CinTot = CinTot; p.N = N; p.HW = H * W;
+    p.nchunk = heads_nchunk(N, H, W);
+    p.part = static_cast<double*>(workspace);
+    const dim3 grid(Cin, p.nchunk);
+    const int fg = uz::ceil_div(2 * L * Cin, 256);
+#define HEADS_W(LL_)                                                                                                           \
+    case LL_:                                                                                                                  \
+        hipLaunchKernelGGL(heads_bwd_weight_partial<LL_>, grid, dim3(256), 0, st, p);                                         \
+        hipLaunchKernelGGL(heads_bwd_weight_final<LL_>, dim3(fg), dim3(256), 0, st, p.part, p.nchunk, Cin, dw_a, db_a, dw_b, db_b); \
+        break;
+    switch (L) {
+        HEADS_W(1) HEADS_W(2) HEADS_W(3) HEADS_W(4)
+        default: return uz::fail("latent_heads_bwd_weight: %d latent channels per head not covered", L);
+    }
+    return uz::check_launch("heads_bwd_weight");
+}

@@ -232,6 +232,12 @@ static int run_one(const uz_op& o, void* st) {
             return uz_absmax(CFP(0), (size_t)o.n, FP(1), st);
         case UZ_OP_EVENT_RECORD:
             return uz_event_record(p[0], st);
+        case UZ_OP_LATENT_HEADS_FWD:
+            return uz_latent_heads_fwd(CFP(0), i[0], i[1], CFP(1), CFP(2), CFP(3), CFP(4), CFP(5), FP(6), FP(7), FP(8), FP(9), i[2], i[3], i[4], i[5], i[6], st);
+        case UZ_OP_LATENT_HEADS_BWD_DATA:
+            return uz_latent_heads_bwd_data(CFP(0), CFP(1), i[0], CFP(2), CFP(3), FP(4), i[1], i[2], i[3], i[4], i[5], i[6], st);
+        case UZ_OP_LATENT_HEADS_BWD_WEIGHT:
+            return uz_latent_heads_bwd_weight(CFP(0), i[0], i[1], CFP(1), CFP(2), i[2], FP(3), FP(4), FP(5), FP(6), i[3], i[4], i[5], p[7], (size_t)o.n, st);
         default:
             return uz::fail("run_tape: unknown op code %d", o.code);
     }

@@ -150,9 +150,7 @@ class PHISeg(NativeModel):
             else:
                 h = conv_unit(plan, pre, p + ".conv.0")
                 h = conv_unit(plan, h, p + ".conv.1")
-            mu = plan.conv_bare(h, p + ".mu_conv.0")
-            ps = plan.conv_bare(h, p + ".sigma_conv.0")
-            lat = plan.latent(mu, ps, eps[k], f"{root}.lat{k}", want_z=want_z, act=0)
+            lat = plan.latent_heads(h, p + ".mu_conv.0", p + ".sigma_conv.0", eps[k], f"{root}.lat{k}", want_z=want_z, act=0)
             lats.append(lat)
             zs.append(z_override[k] if z_override is not None else lat.z)
         return lats, zs
