@@ -275,7 +275,8 @@ class NativeModel(nn.Module):
         for key in plan.param_grads:
             p = self._pmap[key]
             g = self._ptab.gview(key)
-            if p.grad is None or p.grad.data_ptr() == g.data_ptr():
+            pg = p.grad
+            if pg is None or pg is g or pg.data_ptr() == g.data_ptr():
                 p.grad = g
             else:
                 p.grad.add_(g)

@@ -71,8 +71,14 @@ class ParamTable:
         return self.pflat[o:o + _numel(self.shape[k])].view(self.shape[k])
 
     def gview(self, k):
-        o = self.poff[k]
-        return self.gflat[o:o + _numel(self.shape[k])].view(self.shape[k])
+        """View of parameter k's gradient in the flat buffer.  The view OBJECTS are cached (the buffer never moves): a backward pass
+        re-attaches ~400 of them and the optimiser compares them by identity - slicing them anew cost 2 ms of host time per step."""
+        cache = self.__dict__.setdefault("_gviews", {})
+        v = cache.get(k)
+        if v is None:
+            o = self.poff[k]
+            v = cache[k] = self.gflat[o:o + _numel(self.shape[k])].view(self.shape[k])
+        return v
 
     def bview(self, k):
         o = self.boff[k]
