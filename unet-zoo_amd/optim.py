@@ -45,11 +45,11 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         # gradients normally ARE views of the flat gradient buffer; copy in foreign ones
         for key, p in self.model._pmap.items():
-            g = p.grad
-            if g is not None:
+            pg = p.grad
+            if pg is not None:
                 gv = pt.gview(key)
-                if g is not gv and g.data_ptr() != gv.data_ptr():
-                    gv.copy_(g)
+                if pg is not gv and pg.data_ptr() != gv.data_ptr():
+                    gv.copy_(pg)
         self.step_count += 1
         L = _ffi.lib()
         st = C.c_void_p(self.model._stream())
