@@ -325,6 +325,25 @@ int uz_cpu_latent_sample_bwd(const float* dmu, const float* dsigma, const float*
     }
     return 0;
 }
+/* The tail of a SampleZBlock as one call (phiseg.py:95-105: mu = mu_conv(h); sigma = softplus(sigma_conv(h)); z = mu + sigma * eps) and its
+ * backward: twins of uz_latent_heads_* - by definition the composition of the 1x1 convolution twins and the sampling twins above. */
+int uz_cpu_latent_heads_fwd(const float* h, int Cin, int CinTot, const float* w_mu, const float* b_mu, const float* w_sigma, const float* b_sigma,
+                            const float* eps, float* mu, float* pre_sigma, float* sigma, float* z, int L, int N, int H, int W, int act) {
+    uz_cpu_conv_fwd(h, Cin, CinTot, w_mu, b_mu, mu, L, L, N, H, W, 1, 0, NULL, NULL, NULL, NULL, 0);
+    uz_cpu_conv_fwd(h, Cin, CinTot, w_sigma, b_sigma, pre_sigma, L, L, N, H, W, 1, 0, NULL, NULL, NULL, NULL, 0);
+    return uz_cpu_latent_sample_fwd(mu, pre_sigma, eps, sigma, z, (size_t)N * L * H * W, act);
+}
+int uz_cpu_latent_heads_bwd_data(const float* dy_a, const float* dy_b, int L, const float* w_a, const float* w_b, float* dh, int Cin, int CinTot,
+                                 int N, int H, int W, int accumulate) {
+    uz_cpu_conv_bwd_data(dy_a, L, L, w_a, dh, Cin, CinTot, N, H, W, 1, accumulate, NULL, NULL, NULL, 0);
+    return uz_cpu_conv_bwd_data(dy_b, L, L, w_b, dh, Cin, CinTot, N, H, W, 1, 1, NULL, NULL, NULL, 0);
+}
+int uz_cpu_latent_heads_bwd_weight(const float* h, int Cin, int CinTot, const float* dy_a, const float* dy_b, int L, float* dw_a, float* db_a,
+                                   float* dw_b, float* db_b, int N, int H, int W, void* workspace, size_t workspace_bytes) {
+    (void)workspace; (void)workspace_bytes;
+    uz_cpu_conv_bwd_weight(h, Cin, CinTot, dy_a, L, L, dw_a, db_a, N, H, W, 1, NULL, NULL, NULL, 0);
+    return uz_cpu_conv_bwd_weight(h, Cin, CinTot, dy_b, L, L, dw_b, db_b, N, H, W, 1, NULL, NULL, NULL, 0);
+}
 /* KL_two_gauss_with_diag_cov with sigma1_fs = sigma1 * sigma0 (phiseg.py:438-439) */
 int uz_cpu_kl_fwd(const float* mu0, const float* s0, const float* mu1, const float* s1, int N, int per_sample, float weight, float* loss_out) {
     double tot = 0.0;

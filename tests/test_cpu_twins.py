@@ -236,3 +236,60 @@ def test_hip_resampling_and_losses_vs_cpu_twins():
     res = _both("kl_bwd", [mu0, s0, mu1, s1, N, per, C.c_float(16.0), np.array([0.25], np.float32)] + [np.zeros_like(mu0) for _ in range(4)], [8, 9, 10, 11])
     for h, c_ in res:
         assert close(h, c_, 1e-4)
+
+
+def _heads_case(N=2, Cin=12, ctot=15, L=2, H=6, W=8):
+    h = rnd(N, ctot, H, W, seed=11)
+    wm, ws_ = rnd(L, Cin, 1, 1, seed=12, scale=0.3), rnd(L, Cin, 1, 1, seed=13, scale=0.3)
+    bm, bs = rnd(L, seed=14), rnd(L, seed=15)
+    eps = rnd(N, L, H, W, seed=16)
+    dmu, dpre = rnd(N, L, H, W, seed=17), rnd(N, L, H, W, seed=18)
+    return h, wm, bm, ws_, bs, eps, dmu, dpre
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_latent_heads_twins_vs_torch(act):
+    """uz_cpu_latent_heads_* (oracle of uz_latent_heads_*: the tail of SampleZBlock.forward, phiseg.py:95-105, and its backward) against
+    torch autograd on the reference's own expressions."""
+    N, Cin, ctot, L, H, W = 2, 12, 15, 2, 6, 8
+    h, wm, bm, ws_, bs, eps, dmu, dpre = _heads_case(N, Cin, ctot, L, H, W)
+    hv = np.ascontiguousarray(h.reshape(-1)[1 * H * W:])                      # the heads read channels [1, 1 + Cin) of a wider buffer
+    mu, pre, sg, z = (np.zeros((N, L, H, W), np.float32) for _ in range(4))
+    T.call("uz_cpu_latent_heads_fwd", hv, Cin, ctot, wm, bm, ws_, bs, eps, mu, pre, sg, z, L, N, H, W, act)
+    ht = torch.from_numpy(h[:, 1:1 + Cin].copy()).requires_grad_(True)
+    tw = [torch.from_numpy(a.copy()).requires_grad_(True) for a in (wm, bm, ws_, bs)]
+    mr = F.conv2d(ht, tw[0], tw[1])
+    pr = F.conv2d(ht, tw[2], tw[3])
+    sr = torch.exp(pr) if act else F.softplus(pr)
+    zr = mr + sr * torch.from_numpy(eps)
+    assert close(mu, mr.detach()) and close(sg, sr.detach()) and close(z, zr.detach()) and close(pre, pr.detach())
+    (mr * torch.from_numpy(dmu) + pr * torch.from_numpy(dpre)).sum().backward()
+    dh = np.full((N, ctot, H, W), 7.0, np.float32)
+    dhv = dh.reshape(-1)[1 * H * W:]
+    T.call("uz_cpu_latent_heads_bwd_data", dpre, dmu, L, ws_, wm, dhv, Cin, ctot, N, H, W, 0)
+    assert close(dh[:, 1:1 + Cin], ht.grad) and np.all(dh[:, 0] == 7.0) and np.all(dh[:, 1 + Cin:] == 7.0)
+    dws, dbs, dwm, dbm = np.zeros_like(ws_), np.zeros_like(bs), np.zeros_like(wm), np.zeros_like(bm)
+    T.call("uz_cpu_latent_heads_bwd_weight", hv, Cin, ctot, dpre, dmu, L, dws, dbs, dwm, dbm, N, H, W, None, 0)
+    for got, ref in ((dwm, tw[0].grad), (dbm, tw[1].grad), (dws, tw[2].grad), (dbs, tw[3].grad)):
+        assert close(got, ref, 1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_latent_heads_vs_cpu_twins():
+    from unet_zoo_amd import _ffi
+    N, Cin, ctot, L, H, W = 2, 12, 15, 2, 6, 8
+    h, wm, bm, ws_, bs, eps, dmu, dpre = _heads_case(N, Cin, ctot, L, H, W)
+    hv = np.ascontiguousarray(h.reshape(-1)[1 * H * W:])
+    new = lambda: np.zeros((N, L, H, W), np.float32)
+    for act in (0, 1):
+        res = _both("latent_heads_fwd", [hv, Cin, ctot, wm, bm, ws_, bs, eps, new(), new(), new(), new(), L, N, H, W, act], [8, 9, 10, 11])
+        for hh, cc in res:
+            assert close(hh, cc)
+    dh = np.full((N * ctot * H * W - H * W,), 3.0, np.float32)
+    (hh, cc), = _both("latent_heads_bwd_data", [dpre, dmu, L, ws_, wm, dh, Cin, ctot, N, H, W, 1], [5])
+    assert close(hh, cc)
+    wsb = _ffi.lib().uz_latent_heads_bwd_weight_workspace(Cin, L, N, H, W)
+    res = _both("latent_heads_bwd_weight", [hv, Cin, ctot, dpre, dmu, L, np.zeros_like(ws_), np.zeros_like(bs), np.zeros_like(wm), np.zeros_like(bm), N, H, W,
+                                            np.zeros(wsb // 4 + 16, np.float32), wsb], [6, 7, 8, 9])
+    for hh, cc in res:
+        assert close(hh, cc, 1e-4)

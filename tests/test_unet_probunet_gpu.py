@@ -181,3 +181,49 @@ def test_probunet_gradients_with_and_without_deferred_tables_agree_bit_for_bit(m
     assert torch.equal(grads[0], grads[1])
     # and the regulariser's share is really in there: without it the gradient differs
     assert float(grads[0].abs().sum()) > 0
+
+
+def test_gradient_views_second_backward_and_foreign_gradients_like_torch():
+    """Host semantics around the flat gradient buffer (train_model.py:160-179 relies on them like on any torch module): parameters'
+    .grad are cached VIEWS of the buffer (same objects after every backward); a second backward() without zero_grad() accumulates;
+    a gradient the user replaced by a tensor of their own is copied in by FusedAdam.step(), whose update then equals
+    torch.optim.Adam's on the same numbers; zero_grad() detaches them again."""
+    from unet_zoo_amd.models.unet import Unet
+    from unet_zoo_amd.optim import FusedAdam
+    torch.manual_seed(5)
+    net = Unet(1, 2, [8, 16, 16, 16])
+    net.train()
+    x, mask, _ = oracle.synthetic_batch(2, 32, 32, seed=3)
+    xd, md = torch.from_numpy(x).to(DEV()), torch.from_numpy(mask).to(DEV())
+    opt = FusedAdam(net, lr=1e-3, weight_decay=1e-5)
+
+    def backward():
+        net.forward(xd)
+        loss = net.loss(md)
+        loss.backward()
+    opt.zero_grad()
+    backward()
+    params = dict(net.named_parameters())
+    views = {k: p.grad for k, p in params.items()}
+    g1 = {k: v.clone() for k, v in views.items()}
+    assert all(v.data_ptr() == net._ptab.gview(k).data_ptr() for k, v in views.items())
+    backward()                                                  # no zero_grad: accumulates, like autograd
+    for k, p in params.items():
+        assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-5, atol=1e-7), k
+    opt.zero_grad()
+    assert all(p.grad is None for p in params.values())
+    backward()
+    assert all(params[k].grad is views[k] for k in params)      # the cached view objects again
+    for k in params:
+        assert torch.equal(params[k].grad, g1[k]), k            # and the same numbers as the first pass (the tape overwrites)
+    # a foreign gradient on one parameter; torch.optim.Adam on clones as the reference
+    ref = {k: torch.nn.Parameter(p.detach().clone()) for k, p in params.items()}
+    ropt = torch.optim.Adam(list(ref.values()), lr=1e-3, weight_decay=1e-5)
+    key = next(k for k in params if k.endswith("weight") and params[k].dim() == 4)
+    params[key].grad = g1[key] * 3.0                            # new storage, not a view of the flat buffer
+    for k, p in ref.items():
+        p.grad = (g1[k] * 3.0 if k == key else g1[k]).clone()
+    opt.step()
+    ropt.step()
+    for k in params:
+        assert torch.allclose(params[k].detach(), ref[k].detach(), rtol=1e-6, atol=1e-7), k
