@@ -294,6 +294,47 @@ def test_conv_with_fused_bn_statistics(N, Cin, Cout, H, W):
     assert g.relerr(save, save2) <= 2e-6
 
 
+@pytest.mark.parametrize("offset,tol_var", [(0.0, 2e-6), (30.0, 2e-5), (1000.0, 2e-2)])
+def test_fused_bn_statistics_of_a_channel_with_a_large_offset(offset, tol_var):
+    """The convolution epilogue's BatchNorm partials are fp32 sums over 256 pixels (their accumulation across partials is fp64): how far
+    E[y^2] - E[y]^2 drifts when a channel's |mean| / std is large (bn.hip header).  Mean and variance from the fused path
+    (uz_conv_fwd_bnstats + uz_bn_relu_fwd_pre) against an fp64 evaluation of the y the kernel stored: exact to rounding without an
+    offset, 2e-5 of the variance at |mean| / std = 30, within 2 % at 1000 (measured 2e-3; the stand-alone statistics pass has the same
+    per-thread fp32 stage and the same figures - it is the second leg of the loop below)."""
+    g = _g()
+    from unet_zoo_amd import _ffi
+    L = _ffi.lib()
+    N, Cin, Cout, H, W = 8, 32, 64, 64, 64
+    npart = L.uz_conv_bn_partials(Cin, Cout, N, H, W, 3)
+    if L.uz_get_conv_math() == 0 or npart <= 0:
+        pytest.skip("no fused statistics in this math mode")
+    x = g.rnd(N, Cin, H, W, seed=1)
+    w = g.rnd(Cout, Cin, 3, 3, seed=2, scale=0.1)
+    std = float(F.conv2d(x, w, None, padding=1).std())
+    b = torch.full((Cout,), offset * std)
+    d = g.dev()
+    wsb = L.uz_conv_workspace(Cin, Cout, N, H, W, 3)
+    ws = torch.empty(wsb // 4 + 16, device=d)
+    y = torch.empty(N, Cout, H, W, device=d)
+    part = torch.zeros(npart * Cout * 4, device=d)
+    g.call("uz_conv_fwd_bnstats", x.to(d), Cin, Cin, w.to(d), b.to(d), y, Cout, Cout, N, H, W, 3, 0, None, None, None, ws, wsb, None, part)
+    y64 = y.double()
+    mean64, var64 = y64.mean((0, 2, 3)), y64.var((0, 2, 3), unbiased=False)
+    bws = torch.empty(L.uz_bn_workspace(Cout, N, H, W) // 4 + 16, device=d)
+    a = torch.empty_like(y)
+    ones, zeros = torch.ones(Cout, device=d), torch.zeros(Cout, device=d)
+    for fused in (True, False):
+        save, rm, rv = torch.empty(2 * Cout, device=d), zeros.clone(), ones.clone()
+        if fused:
+            g.call("uz_bn_relu_fwd_pre", y, Cout, Cout, ones, zeros, rm, rv, save, a, Cout, N, H, W, 0.0, 0.01, 1, 0, None, bws, part, npart)
+        else:
+            g.call("uz_bn_relu_fwd", y, Cout, Cout, ones, zeros, rm, rv, save, a, Cout, N, H, W, 0.0, 0.01, 1, 0, None, bws)
+        mean, var = save[:Cout].double(), 1.0 / save[Cout:].double() ** 2
+        assert float(((mean - mean64).abs() / (mean64.abs() + std)).max()) <= 2e-7
+        err = float(((var - var64).abs() / var64).max())
+        assert err <= tol_var, (fused, offset, err)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W,ks,training", [(32, 192, 192, 8, 8, 3, 1), (32, 192, 192, 4, 4, 3, 1), (32, 256, 256, 2, 2, 3, 1),
                                                        (32, 2, 64, 4, 4, 3, 1), (32, 192, 192, 8, 8, 3, 0), (7, 70, 50, 5, 3, 3, 1)])
 def test_conv_reduce_folded_into_small_plane_batchnorm(N, Cin, Cout, H, W, ks, training):
