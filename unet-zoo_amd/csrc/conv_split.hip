@@ -27,6 +27,9 @@ using uz::f32x16; using uz::f32x4; using uz::f16x8; using uz::u32x4; using uz::s
 
 
 constexpr int CK = 16, NSUB = 2, KK = 9, TH = 16;
+#ifndef UZ_EXP_PRODUCTS
+#define UZ_EXP_PRODUCTS 3
+#endif
 // NP = planes per operand: 2 = fp32-accurate split (two fp16 pieces, three products), 1 = ONE bf16 piece and one product per
 // (a, b) pair - bf16 arithmetic with fp32 accumulation (UZ_CONV_MATH=bf16: BASELINE config 5, PHiSeg3D "bf16"); bf16 keeps fp32's
 // exponent range, so that mode needs neither operand scales nor magnitude bounds.
@@ -38,8 +41,10 @@ template <int NP> __device__ __forceinline__ void pieces(float v0, float v1, uns
 }
 template <int NP> __device__ __forceinline__ f32x16 mma(f32x16 t, const u32x4 (&a)[NP], const u32x4 (&b)[NP]) {
     if constexpr (NP == 2) {                       // smallest products first
-        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), t, 0, 0, 0);
+        // (UZ_EXP_PRODUCTS = 2 / 1: timing-only experiment builds that drop one / two of the three piece products - what the step would
+        //  cost with fewer matrix products per output, everything else unchanged; results lose accuracy, never used in a product build)
+        if constexpr (UZ_EXP_PRODUCTS >= 3) t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), t, 0, 0, 0);
+        if constexpr (UZ_EXP_PRODUCTS >= 2) t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), t, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), t, 0, 0, 0);
     } else {
         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), t, 0, 0, 0);
