@@ -1,5 +1,7 @@
 # What would fewer matrix products per output buy?  Timing-only experiment builds of the split kernels with 2 / 1 of the 3 piece products
 # (csrc: UZ_EXP_PRODUCTS; staging, LDS images and epilogues unchanged; results lose accuracy but stay finite - real data, real clocks).
+# Build the two experiment libraries first (they are not part of the product build and are not committed):
+#   make -C unet-zoo_amd/csrc VARIANT=p2 XFLAGS=-DUZ_EXP_PRODUCTS=2 && make -C unet-zoo_amd/csrc VARIANT=p1 XFLAGS=-DUZ_EXP_PRODUCTS=1
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT/unet-zoo_amd
