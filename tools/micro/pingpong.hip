@@ -1,0 +1,154 @@
+// Micro-benchmark for DESIGN.md section 9 item 0: does overlapping a staging phase with a matrix phase pay on MI355X, or does the clock
+// give it back?  One 512-thread workgroup per CU (8 waves, 2 per SIMD), per iteration and wave:
+//   M = 108 x v_mfma_f32_32x32x16_f16 on four accumulator tiles, fragments re-read from LDS (4 ds_read_b128 per 3 MFMAs), like one
+//       16-channel chunk of conv_split's 64-channel tile;
+//   S = 6 x 16-byte global loads (a 64 MB buffer, different lines every iteration), wait, 12 byte permutes, 6 x ds_write_b128.
+// Kernels: M only, S only, "serial" (all waves S, barrier, all waves M, barrier - the structure of the product kernels) and "ping-pong"
+// (the two waves of a SIMD in opposite phases, a barrier at every hand-over).  Prints the time per iteration and the shader clock
+// (s_memtime cycles per s_memrealtime tick at 100 MHz).  Build + run: hipcc --offload-arch=gfx950 -O3 pingpong.hip -o /tmp/pingpong && /tmp/pingpong
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NT = 512, LDSB = 96 * 1024;      // 96 KB of LDS per workgroup: one workgroup per CU
+
+struct St { f32x16 acc[4]; u32x4 hold[6]; unsigned mix; };
+
+__device__ __forceinline__ void phase_m(St& s, const char* lds, int lane) {
+    asm volatile("" ::: "memory");                                // the fragments are re-read every iteration (no hoisting in the M-only kernel)
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {                                  // 9 taps x 4 tiles x 3 products = 108 MFMAs
+        u32x4 a[2][2], b[2][2];                                    // [tile half][piece]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                a[i][q] = *reinterpret_cast<const u32x4*>(lds + ((r * 4 + i * 2 + q) * 64 + lane) * 16);
+                b[i][q] = *reinterpret_cast<const u32x4*>(lds + 36864 + ((r * 4 + i * 2 + q) * 64 + lane) * 16);
+            }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                f32x16 t = s.acc[m * 2 + n];
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[m][1]), __builtin_bit_cast(f16x8, b[n][0]), t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[m][0]), __builtin_bit_cast(f16x8, b[n][1]), t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[m][0]), __builtin_bit_cast(f16x8, b[n][0]), t, 0, 0, 0);
+                s.acc[m * 2 + n] = t;
+            }
+    }
+}
+
+__device__ __forceinline__ void phase_s(St& s, const u32x4* g, size_t nvec, int it, char* lds, int tid, int slot) {
+    const size_t base = ((size_t)blockIdx.x * 9973 + (size_t)it * 1237) * NT * 6;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s.hold[j] = g[(base + (size_t)j * NT + tid) % nvec];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        u32x4 v = s.hold[j];
+        v.x = __builtin_amdgcn_perm(v.x, v.y, 0x05040100u); v.z = __builtin_amdgcn_perm(v.z, v.w, 0x07060302u);
+        s.mix ^= v.x + v.z;
+        v.x = (v.x & 0x03ff03ffu) | 0x3c003c00u; v.y = (v.y & 0x03ff03ffu) | 0x3c003c00u;       // keep the fp16 pieces finite (1.0 .. 2.0)
+        v.z = (v.z & 0x03ff03ffu) | 0x3c003c00u; v.w = (v.w & 0x03ff03ffu) | 0x3c003c00u;
+        *reinterpret_cast<u32x4*>(lds + ((size_t)j * NT + slot) * 16) = v;
+    }
+}
+
+template <int MODE>      // 0 = M only (constant fragments), 1 = S only, 2 = serial, 3 = ping-pong, 4 = M only on random fragments, 5 = serial with the loads issued one iteration ahead
+__global__ __launch_bounds__(NT, 1) void kern(const u32x4* g, size_t nvec, float* out, long long* clk, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, group = wave >> 2;      // waves 0-3 / 4-7: one of each per SIMD
+    St s;
+    for (int i = 0; i < 4; ++i) s.acc[i] = f32x16{};
+    s.mix = 0;
+    for (int i = tid; i < LDSB / 16; i += NT) *reinterpret_cast<u32x4*>(lds + (size_t)i * 16) = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    __syncthreads();
+    if (MODE == 4 || MODE == 5) {                       // random mantissas in every fragment the matrix phase reads
+        for (int k = 0; k < 2; ++k) { phase_s(s, g, nvec, 7 + k, lds + k * 49152 * 0 + k * 24576, tid, tid); }
+        __syncthreads();
+    }
+    long long t0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0 || MODE == 4) { phase_m(s, lds, lane); }
+        else if (MODE == 5) {
+            // loads of iteration it + 1 in flight during the matrix phase of iteration it; only the permutes and LDS writes stay exposed
+            u32x4 nxt[6];
+            const size_t base = ((size_t)blockIdx.x * 9973 + (size_t)(it + 1) * 1237) * NT * 6;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) nxt[j] = g[(base + (size_t)j * NT + tid) % nvec];
+            phase_m(s, lds, lane);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                u32x4 v = nxt[j];
+                v.x = __builtin_amdgcn_perm(v.x, v.y, 0x05040100u); v.z = __builtin_amdgcn_perm(v.z, v.w, 0x07060302u);
+                s.mix ^= v.x + v.z;
+                v.x = (v.x & 0x03ff03ffu) | 0x3c003c00u; v.y = (v.y & 0x03ff03ffu) | 0x3c003c00u;
+                v.z = (v.z & 0x03ff03ffu) | 0x3c003c00u; v.w = (v.w & 0x03ff03ffu) | 0x3c003c00u;
+                *reinterpret_cast<u32x4*>(lds + ((size_t)j * NT + tid) * 16) = v;
+            }
+            __syncthreads();
+        }
+        else if (MODE == 1) { phase_s(s, g, nvec, it, lds, tid, tid); __syncthreads(); }
+        else if (MODE == 2) { phase_s(s, g, nvec, it, lds, tid, tid); __syncthreads(); phase_m(s, lds, lane); __syncthreads(); }
+        else {
+            if (group == 0) phase_m(s, lds, lane); else phase_s(s, g, nvec, it, lds + 49152, tid, tid & 255);
+            __syncthreads();
+            if (group == 0) phase_s(s, g, nvec, it, lds + 49152, tid, tid & 255); else phase_m(s, lds, lane);
+            __syncthreads();
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) { clk[0] = __builtin_amdgcn_s_memtime() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    float v = (float)s.mix;
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) v += s.acc[i][r];
+    out[(size_t)blockIdx.x * NT + tid] = v;
+}
+
+template <int MODE>
+void run(const char* name, const u32x4* g, size_t nvec, float* out, long long* clk, int iters, int grid) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    long long h[2] = {0, 0};
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(kern<MODE>, dim3(grid), dim3(NT), LDSB, 0, g, nvec, out, clk, iters);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) { best = ms; hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost); }
+    }
+    const double rounds = (double)grid / 256.0;
+    const double us_it = best * 1e3 / iters / rounds;
+    const double mfma = MODE == 1 ? 0.0 : 108.0 * 8 * 256 * 32768.0 / (us_it * 1e-6) / 1e15;        // PFLOP/s of fp16 MFMAs over the chip
+    printf("%-10s %8.3f ms  %7.3f us per iteration and workgroup  clock %.2f GHz  fp16 MFMA %.2f PF/s\n", name, best, us_it,
+           h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0, mfma);
+}
+
+int main() {
+    const size_t bytes = 64ull << 20, nvec = bytes / 16;
+    u32x4* g; float* out; long long* clk;
+    hipMalloc(&g, bytes); hipMalloc(&out, 4096 * NT * sizeof(float)); hipMalloc(&clk, 16);
+    unsigned* hbuf = (unsigned*)malloc(bytes);
+    srand(1);
+    for (size_t i = 0; i < bytes / 4; ++i) hbuf[i] = (unsigned)rand() * 2654435761u;
+    hipMemcpy(g, hbuf, bytes, hipMemcpyHostToDevice);
+    const int iters = 400, grid = 1024;            // 4 rounds of 256 workgroups
+    run<0>("M only", g, nvec, out, clk, iters, grid);
+    run<1>("S only", g, nvec, out, clk, iters, grid);
+    run<2>("serial", g, nvec, out, clk, iters, grid);
+    run<3>("ping-pong", g, nvec, out, clk, iters, grid);
+    run<0>("M only", g, nvec, out, clk, iters, grid);
+    run<2>("serial", g, nvec, out, clk, iters, grid);
+    run<3>("ping-pong", g, nvec, out, clk, iters, grid);
+    run<4>("M random", g, nvec, out, clk, iters, grid);
+    run<5>("serial+pf", g, nvec, out, clk, iters, grid);
+    run<4>("M random", g, nvec, out, clk, iters, grid);
+    run<5>("serial+pf", g, nvec, out, clk, iters, grid);
+    return 0;
+}

@@ -1,0 +1,5 @@
+# tools/micro/pingpong.hip: serial staging / matrix phases against ping-pong wave groups
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/pingpong.hip -o /tmp/pingpong 2>&1 | grep -i error
+timeout 120 /tmp/pingpong
