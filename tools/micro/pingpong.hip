@@ -9,11 +9,13 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NT = 512, LDSB = 96 * 1024;      // 96 KB of LDS per workgroup: one workgroup per CU
+constexpr int NT = 512, LDSB = 128 * 1024;     // 128 KB of LDS per workgroup: one workgroup per CU
+constexpr int IMG = 73728;                     // bytes of fragments the matrix phase reads (a: 36 x 1 KB, b: 36 x 1 KB)
 
 struct St { f32x16 acc[4]; u32x4 hold[6]; unsigned mix; };
 
@@ -57,8 +59,9 @@ __device__ __forceinline__ void phase_s(St& s, const u32x4* g, size_t nvec, int 
     }
 }
 
-template <int MODE>      // 0 = M only (constant fragments), 1 = S only, 2 = serial, 3 = ping-pong, 4 = M only on random fragments, 5 = serial with the loads issued one iteration ahead
-__global__ __launch_bounds__(NT, 1) void kern(const u32x4* g, size_t nvec, float* out, long long* clk, int iters) {
+template <int MODE>      // 0 = M only (constant fragments), 1 = S only, 2 = serial, 3 = ping-pong, 4 = M only on random fragments, 5 = serial with the loads issued one iteration ahead,
+                         // 6 = M only on REALISTIC fragments (split pieces of post-ReLU activations x small weights), 7 = serial on them (S writes elsewhere)
+__global__ __launch_bounds__(NT, 1) void kern(const u32x4* g, size_t nvec, float* out, long long* clk, int iters, const u32x4* img) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, group = wave >> 2;      // waves 0-3 / 4-7: one of each per SIMD
     St s;
@@ -70,10 +73,15 @@ __global__ __launch_bounds__(NT, 1) void kern(const u32x4* g, size_t nvec, float
         for (int k = 0; k < 2; ++k) { phase_s(s, g, nvec, 7 + k, lds + k * 49152 * 0 + k * 24576, tid, tid); }
         __syncthreads();
     }
+    if (MODE == 6 || MODE == 7) {
+        for (int i = tid; i < IMG / 16; i += NT) *reinterpret_cast<u32x4*>(lds + (size_t)i * 16) = img[i];
+        __syncthreads();
+    }
     long long t0 = 0, r0 = 0;
     if (blockIdx.x == 0 && tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     for (int it = 0; it < iters; ++it) {
-        if (MODE == 0 || MODE == 4) { phase_m(s, lds, lane); }
+        if (MODE == 0 || MODE == 4 || MODE == 6) { phase_m(s, lds, lane); }
+        else if (MODE == 7) { phase_s(s, g, nvec, it, lds + IMG, tid, tid); __syncthreads(); phase_m(s, lds, lane); __syncthreads(); }
         else if (MODE == 5) {
             // loads of iteration it + 1 in flight during the matrix phase of iteration it; only the permutes and LDS writes stay exposed
             u32x4 nxt[6];
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(NT, 1) void kern(const u32x4* g, size_t nvec, float
 }
 
 template <int MODE>
-void run(const char* name, const u32x4* g, size_t nvec, float* out, long long* clk, int iters, int grid) {
+void run(const char* name, const u32x4* g, size_t nvec, float* out, long long* clk, int iters, int grid, const u32x4* img = nullptr) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -117,7 +125,7 @@ void run(const char* name, const u32x4* g, size_t nvec, float* out, long long* c
     long long h[2] = {0, 0};
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(kern<MODE>, dim3(grid), dim3(NT), LDSB, 0, g, nvec, out, clk, iters);
+        hipLaunchKernelGGL(kern<MODE>, dim3(grid), dim3(NT), LDSB, 0, g, nvec, out, clk, iters, img);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -138,6 +146,19 @@ int main() {
     srand(1);
     for (size_t i = 0; i < bytes / 4; ++i) hbuf[i] = (unsigned)rand() * 2654435761u;
     hipMemcpy(g, hbuf, bytes, hipMemcpyHostToDevice);
+    // realistic fragments: a = the two fp16 pieces (hi | lo, scaled by 2^11) of post-ReLU activations (|N(0,1)|, half of them zero),
+    // b = the pieces of weights ~ N(0, 0.05) scaled by 2^14; fragment f = tap * 4 + half * 2 + piece
+    _Float16* himg = (_Float16*)malloc(IMG);
+    for (int side = 0; side < 2; ++side)
+        for (int f = 0; f < 36; ++f)
+            for (int e = 0; e < 512; ++e) {
+                float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = (rand() + 1.0f) / (RAND_MAX + 2.0f);
+                float n = sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
+                float v = side == 0 ? ((rand() & 1) ? fabsf(n) : 0.f) * 2048.f : n * 0.05f * 16384.f;
+                _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                himg[(side * 36 + f) * 512 + e] = (f & 1) ? lo : hi;
+            }
+    u32x4* img; hipMalloc(&img, IMG); hipMemcpy(img, himg, IMG, hipMemcpyHostToDevice);
     const int iters = 400, grid = 1024;            // 4 rounds of 256 workgroups
     run<0>("M only", g, nvec, out, clk, iters, grid);
     run<1>("S only", g, nvec, out, clk, iters, grid);
@@ -150,5 +171,9 @@ int main() {
     run<5>("serial+pf", g, nvec, out, clk, iters, grid);
     run<4>("M random", g, nvec, out, clk, iters, grid);
     run<5>("serial+pf", g, nvec, out, clk, iters, grid);
+    for (int k = 0; k < 2; ++k) {
+        run<6>("M real", g, nvec, out, clk, iters, grid, img);
+        run<7>("serial real", g, nvec, out, clk, iters, grid, img);
+    }
     return 0;
 }
