@@ -19,6 +19,9 @@ constexpr int IMG = 73728;                     // bytes of fragments the matrix 
 
 struct St { f32x16 acc[4]; u32x4 hold[6]; unsigned mix; };
 
+#ifndef INTERLEAVE
+#define INTERLEAVE 0
+#endif
 __device__ __forceinline__ void phase_m(St& s, const char* lds, int lane) {
     asm volatile("" ::: "memory");                                // the fragments are re-read every iteration (no hoisting in the M-only kernel)
 #pragma unroll
@@ -31,16 +34,27 @@ __device__ __forceinline__ void phase_m(St& s, const char* lds, int lane) {
                 a[i][q] = *reinterpret_cast<const u32x4*>(lds + ((r * 4 + i * 2 + q) * 64 + lane) * 16);
                 b[i][q] = *reinterpret_cast<const u32x4*>(lds + 36864 + ((r * 4 + i * 2 + q) * 64 + lane) * 16);
             }
+        if (INTERLEAVE) {                                          // consecutive MFMAs on DIFFERENT accumulator tiles (a single wave keeps the pipe full)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+            for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                f32x16 t = s.acc[m * 2 + n];
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[m][1]), __builtin_bit_cast(f16x8, b[n][0]), t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[m][0]), __builtin_bit_cast(f16x8, b[n][1]), t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[m][0]), __builtin_bit_cast(f16x8, b[n][0]), t, 0, 0, 0);
-                s.acc[m * 2 + n] = t;
-            }
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        s.acc[m * 2 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[m][pr == 0]), __builtin_bit_cast(f16x8, b[n][pr == 1]),
+                                                                                  s.acc[m * 2 + n], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    f32x16 t = s.acc[m * 2 + n];
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[m][1]), __builtin_bit_cast(f16x8, b[n][0]), t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[m][0]), __builtin_bit_cast(f16x8, b[n][1]), t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[m][0]), __builtin_bit_cast(f16x8, b[n][0]), t, 0, 0, 0);
+                    s.acc[m * 2 + n] = t;
+                }
+        }
     }
 }
 
@@ -59,8 +73,23 @@ __device__ __forceinline__ void phase_s(St& s, const u32x4* g, size_t nvec, int 
     }
 }
 
+// consume the loads issued half a period ago (permutes + LDS writes), then issue the next ones: their latency hides behind this group's own matrix phase
+__device__ __forceinline__ void stage_prefetched(St& s, const u32x4* g, size_t nvec, int it, char* lds, int tid, int slot) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        u32x4 v = s.hold[j];
+        v.x = __builtin_amdgcn_perm(v.x, v.y, 0x05040100u); v.z = __builtin_amdgcn_perm(v.z, v.w, 0x07060302u);
+        s.mix ^= v.x + v.z;
+        *reinterpret_cast<u32x4*>(lds + ((size_t)j * NT + slot) * 16) = v;
+    }
+    const size_t base = ((size_t)blockIdx.x * 9973 + (size_t)(it + 1) * 1237) * NT * 6;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s.hold[j] = g[(base + (size_t)j * NT + tid) % nvec];
+}
+
 template <int MODE>      // 0 = M only (constant fragments), 1 = S only, 2 = serial, 3 = ping-pong, 4 = M only on random fragments, 5 = serial with the loads issued one iteration ahead,
-                         // 6 = M only on REALISTIC fragments (split pieces of post-ReLU activations x small weights), 7 = serial on them (S writes elsewhere)
+                         // 6 = M only on REALISTIC fragments (split pieces of post-ReLU activations x small weights), 7 = serial on them (S writes elsewhere),
+                         // 8 = ping-pong on them with the loads issued half a period ahead (the proposal of DESIGN section 9 item 0)
 __global__ __launch_bounds__(NT, 1) void kern(const u32x4* g, size_t nvec, float* out, long long* clk, int iters, const u32x4* img) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, group = wave >> 2;      // waves 0-3 / 4-7: one of each per SIMD
@@ -73,7 +102,7 @@ __global__ __launch_bounds__(NT, 1) void kern(const u32x4* g, size_t nvec, float
         for (int k = 0; k < 2; ++k) { phase_s(s, g, nvec, 7 + k, lds + k * 49152 * 0 + k * 24576, tid, tid); }
         __syncthreads();
     }
-    if (MODE == 6 || MODE == 7) {
+    if (MODE == 6 || MODE == 7 || MODE == 8) {
         for (int i = tid; i < IMG / 16; i += NT) *reinterpret_cast<u32x4*>(lds + (size_t)i * 16) = img[i];
         __syncthreads();
     }
@@ -81,6 +110,13 @@ __global__ __launch_bounds__(NT, 1) void kern(const u32x4* g, size_t nvec, float
     if (blockIdx.x == 0 && tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0 || MODE == 4 || MODE == 6) { phase_m(s, lds, lane); }
+        else if (MODE == 8) {
+            if (it == 0) for (int j = 0; j < 6; ++j) s.hold[j] = g[((size_t)blockIdx.x * 6 * NT + (size_t)j * NT + tid) % nvec];
+            if (group == 0) phase_m(s, lds, lane); else stage_prefetched(s, g, nvec, it, lds + IMG, tid, tid & 255);
+            __syncthreads();
+            if (group == 0) stage_prefetched(s, g, nvec, it, lds + IMG, tid, tid & 255); else phase_m(s, lds, lane);
+            __syncthreads();
+        }
         else if (MODE == 7) { phase_s(s, g, nvec, it, lds + IMG, tid, tid); __syncthreads(); phase_m(s, lds, lane); __syncthreads(); }
         else if (MODE == 5) {
             // loads of iteration it + 1 in flight during the matrix phase of iteration it; only the permutes and LDS writes stay exposed
@@ -134,7 +170,7 @@ void run(const char* name, const u32x4* g, size_t nvec, float* out, long long* c
     const double rounds = (double)grid / 256.0;
     const double us_it = best * 1e3 / iters / rounds;
     const double mfma = MODE == 1 ? 0.0 : 108.0 * 8 * 256 * 32768.0 / (us_it * 1e-6) / 1e15;        // PFLOP/s of fp16 MFMAs over the chip
-    printf("%-10s %8.3f ms  %7.3f us per iteration and workgroup  clock %.2f GHz  fp16 MFMA %.2f PF/s\n", name, best, us_it,
+    printf("%-14s %8.3f ms  %7.3f us per iteration and workgroup  clock %.2f GHz  fp16 MFMA %.2f PF/s\n", name, best, us_it,
            h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0, mfma);
 }
 
@@ -174,6 +210,7 @@ int main() {
     for (int k = 0; k < 2; ++k) {
         run<6>("M real", g, nvec, out, clk, iters, grid, img);
         run<7>("serial real", g, nvec, out, clk, iters, grid, img);
+        run<8>("pingpong real", g, nvec, out, clk, iters, grid, img);
     }
     return 0;
 }

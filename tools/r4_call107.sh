@@ -3,3 +3,6 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/pingpong.hip -o /tmp/pingpong 2>&1 | grep -i error
 timeout 120 /tmp/pingpong
+echo "== consecutive MFMAs on different accumulator tiles (-DINTERLEAVE=1)"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -DINTERLEAVE=1 tools/micro/pingpong.hip -o /tmp/pingpong_i 2>&1 | grep -i error
+timeout 120 /tmp/pingpong_i | grep real
