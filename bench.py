@@ -284,6 +284,11 @@ def dominant_kernel_live(net, plan, L, heaviest, reps=20):
                           "dense fp16 MFMA peak 2500 TFLOP/s / 3 piece products per fp32 product" if split else "fp32 MFMA peak"))
     if split:
         out["fp16_mfma_tflops"] = round((1 if roof == PEAK_F16_MFMA_TFLOPS else SPLIT_PRODUCTS) * flops / ms / 1e9, 1)
+        if roof != PEAK_F16_MFMA_TFLOPS:
+            # informational, not the contract's peak: what the chip sustains with its matrix pipe saturated on operand pieces like these
+            # (tools/micro/pingpong.hip on one MI355X: 1.51 - 1.60 PF/s of fp16 MFMAs at 1.5 - 1.7 GHz, profiles/r4_call107_pingpong.txt)
+            out["sustained_ceiling_note"] = ("measured power-limited ceiling of the fp16 matrix pipe on realistic split pieces: 1510 - 1600 TFLOP/s = "
+                                             "503 - 533 TFLOP/s fp32-equivalent = 0.60 - 0.64 of `peak` (tools/micro/pingpong.hip)")
     if roof == PEAK_F16_MFMA_TFLOPS:
         # one product per MAC puts these layers on the memory side of the ridge for narrow channel counts: report the HBM view too
         out["hbm_view"] = dict(achieved_gbs=round(alg_bytes / ms / 1e6, 1), peak_gbs=HBM_PEAK_GBS, frac=round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
@@ -767,7 +772,7 @@ def main():
                             note="dominant kernel = the longest convolution launch of the step, re-timed live (20 launches between two HIP events "
                                  "on its launch stream); achieved = algorithmic fp32-equivalent FLOPs per launch / average launch duration; traffic = "
                                  "PMC-measured HBM bytes per launch of this kernel on this layer (profiles/), null when no committed PMC pass covers it")
-                for k in ("fp16_mfma_tflops", "traffic_source"):
+                for k in ("fp16_mfma_tflops", "traffic_source", "sustained_ceiling_note"):
                     if k in dk:
                         roof[k] = dk[k]
                 step_view.pop("traffic", None)
