@@ -161,7 +161,10 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     //  (128 x 64) - that kernel is not waiting for its loads; timing-only builds with half the patch load instructions -13 %, with a
     //  third of the B-fragment reads -2 %: neither the LDS reads nor the vector-memory issue rate alone is the bound)
     constexpr bool DEEP = TWv == 16;                     // patch loads two chunks ahead (see stage_deep)
-    constexpr bool PREF = TWv == 16;                     // fragment reads one tap ahead of the MFMAs
+#ifndef UZ_EXP_PREF_ALL
+#define UZ_EXP_PREF_ALL 0
+#endif
+    constexpr bool PREF = TWv == 16 || (UZ_EXP_PREF_ALL && MSUB == 2);  // fragment reads one tap ahead of the MFMAs (UZ_EXP_PREF_ALL: experiment builds, every geometry)
 #ifndef UZ_UNCOND_TW
 #define UZ_UNCOND_TW 16
 #endif
