@@ -22,7 +22,42 @@ struct St { f32x16 acc[4]; u32x4 hold[6]; unsigned mix; };
 #ifndef INTERLEAVE
 #define INTERLEAVE 0
 #endif
+#ifndef PREFM
+#define PREFM 0            // 1: the matrix phase reads the fragments of tap r + 1 before it issues the MFMAs of tap r (software pipelined)
+#endif
+struct Frag { u32x4 a[2][2], b[2][2]; };
+__device__ __forceinline__ void frag_load(Frag& f, const char* lds, int lane, int r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f.a[i][q] = *reinterpret_cast<const u32x4*>(lds + ((r * 4 + i * 2 + q) * 64 + lane) * 16);
+            f.b[i][q] = *reinterpret_cast<const u32x4*>(lds + 36864 + ((r * 4 + i * 2 + q) * 64 + lane) * 16);
+        }
+}
+__device__ __forceinline__ void frag_mma(St& s, const Frag& f) {
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                s.acc[m * 2 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[m][pr == 0]), __builtin_bit_cast(f16x8, f.b[n][pr == 1]),
+                                                                          s.acc[m * 2 + n], 0, 0, 0);
+}
+__device__ __forceinline__ void phase_m_pref(St& s, const char* lds, int lane) {
+    asm volatile("" ::: "memory");
+    Frag f[2];
+    frag_load(f[0], lds, lane, 0);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        if (r + 1 < 9) frag_load(f[(r + 1) & 1], lds, lane, r + 1);
+        __builtin_amdgcn_sched_barrier(0);                          // keep the next tap's reads ahead of this tap's MFMAs
+        frag_mma(s, f[r & 1]);
+    }
+}
 __device__ __forceinline__ void phase_m(St& s, const char* lds, int lane) {
+    if (PREFM) { phase_m_pref(s, lds, lane); return; }
     asm volatile("" ::: "memory");                                // the fragments are re-read every iteration (no hoisting in the M-only kernel)
 #pragma unroll
     for (int r = 0; r < 9; ++r) {                                  // 9 taps x 4 tiles x 3 products = 108 MFMAs
