@@ -22,6 +22,9 @@ struct St { f32x16 acc[4]; u32x4 hold[6]; unsigned mix; };
 #ifndef INTERLEAVE
 #define INTERLEAVE 0
 #endif
+#ifndef LDSBAR
+#define LDSBAR 1           // 1: the ping-pong hand-over waits for LDS traffic only (0: __syncthreads(), which drains the global loads too)
+#endif
 #ifndef PREFM
 #define PREFM 0            // 1: the matrix phase reads the fragments of tap r + 1 before it issues the MFMAs of tap r (software pipelined)
 #endif
@@ -147,10 +150,12 @@ __global__ __launch_bounds__(NT, 1) void kern(const u32x4* g, size_t nvec, float
         if (MODE == 0 || MODE == 4 || MODE == 6) { phase_m(s, lds, lane); }
         else if (MODE == 8) {
             if (it == 0) for (int j = 0; j < 6; ++j) s.hold[j] = g[((size_t)blockIdx.x * 6 * NT + (size_t)j * NT + tid) % nvec];
+            // LDS-only barrier (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() also waits for vmcnt(0), i.e. for the loads that were
+            // issued to stay in flight across the hand-over - with it the half period equals the load round trip (LDSBAR=0 shows that)
             if (group == 0) phase_m(s, lds, lane); else stage_prefetched(s, g, nvec, it, lds + IMG, tid, tid & 255);
-            __syncthreads();
+            if (LDSBAR) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); } else __syncthreads();
             if (group == 0) stage_prefetched(s, g, nvec, it, lds + IMG, tid, tid & 255); else phase_m(s, lds, lane);
-            __syncthreads();
+            if (LDSBAR) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); } else __syncthreads();
         }
         else if (MODE == 7) { phase_s(s, g, nvec, it, lds + IMG, tid, tid); __syncthreads(); phase_m(s, lds, lane); __syncthreads(); }
         else if (MODE == 5) {
