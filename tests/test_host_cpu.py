@@ -107,25 +107,21 @@ def _check_lane_schedule(plan, which, ops):
         last[o["lane"]] = k
         if k and ops[k - 1]["gid"] == o["gid"]:
             assert ops[k - 1]["lane"] == o["lane"]
-    acc = []
-    for o in ops:
-        wr = plan._WRITES[o["code"]]
-        r, w = [], []
-        for j, ref in enumerate(o["p"]):
-            (w if j in wr else r).extend(plan._resources(ref))
-        acc.append((r, w))
+    acc = [plan._access(o) for o in ops]            # (reads, writes, accumulates): accumulates (bound slots) commute with each other only
 
     def overlap(xs, ys):
         return any(a[0] == b[0] and a[1] < b[2] and b[1] < a[2] for a in xs for b in ys)
-    pairs = 0
+    pairs = amax_pairs = 0
     for j in range(n):
-        rj, wj = acc[j]
+        rj, wj, aj = acc[j]
         for k in range(j + 1, n):
-            rk, wk = acc[k]
-            if overlap(wj, rk) or overlap(wj, wk) or overlap(rj, wk):
+            rk, wk, ak = acc[k]
+            slot = overlap(aj, rk) or overlap(rj, ak)           # a bound slot's accumulator against one of its readers
+            if overlap(wj, rk) or overlap(wj, wk) or overlap(rj, wk) or overlap(wj, ak) or overlap(aj, wk) or slot:
                 pairs += 1
+                amax_pairs += bool(slot)
                 assert (hb[k] >> j) & 1, (which, j, ops[j]["code"], k, ops[k]["code"])
-    return pairs, len({o["lane"] for o in ops})
+    return pairs, len({o["lane"] for o in ops}), amax_pairs
 
 
 @pytest.mark.parametrize("lanes", ["1", "3", "4"])
@@ -137,13 +133,54 @@ def test_lane_schedule_preserves_every_dependency(lanes, monkeypatch):
     net = PHISeg(1, 2, meta["filters"], image_size=(1, 64, 64), device="cpu")
     plan = net._build(2, 64, 64, True, True)
     for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
-        pairs, used = _check_lane_schedule(plan, which, ops)
-        assert pairs > 100 and used == min(int(lanes), 4)
+        pairs, used, amax_pairs = _check_lane_schedule(plan, which, ops)
+        assert pairs > 100 and used == min(int(lanes), 4) and amax_pairs > 20
     _, meta = G.load("probunet_small")
     pu = ProbabilisticUnet(1, 2, meta["filters"], latent_dim=meta["latent_dim"], no_convs_fcomb=3, device="cpu")
     for plan in (pu._build(2, 64, 64, True, True), pu._build(2, 64, 64, False, False)):
         for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops), *plan.extra_ops.items()):
             _check_lane_schedule(plan, which, ops)
+
+
+@pytest.mark.parametrize("lanes", ["2", "3"])
+def test_bound_slot_readers_are_ordered_against_every_accumulator_at_the_headline_size(lanes, monkeypatch):
+    """a magnitude-bound slot is shared by all producers of a concat buffer; a consumer of a channel sub-range
+    derives its operand scale from the slot several times while it runs, so NO producer of the slot may run beside it - also one
+    that writes channels the consumer never reads.  Walks every (accumulator, reader) pair of every slot of the headline plan
+    (PHiSeg 7 / 5, batch 32, 128 x 128) and asserts that the schedule orders it, in either direction."""
+    from unet_zoo_amd.models.phiseg import PHISeg
+    monkeypatch.setenv("UZ_LANES", lanes)
+    net = PHISeg(1, 2, [32, 64, 128, 192, 192, 192, 192], latent_levels=5, image_size=(1, 128, 128), device="cpu")
+    plan = net._build(32, 128, 128, True, True)
+    total = 0
+    for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
+        sc, n = plan.scheds[which], len(ops)
+        hb, last = [0] * n, {}
+        for k, o in enumerate(ops):
+            m = 0
+            if o["lane"] in last:
+                m |= hb[last[o["lane"]]] | (1 << last[o["lane"]])
+            for w in range(sc[k].n_wait):
+                m |= hb[sc[k].wait[w]] | (1 << sc[k].wait[w])
+            hb[k] = m
+            last[o["lane"]] = k
+        accs, reads = {}, {}
+        for k, o in enumerate(ops):
+            r_, w_, a_ = plan._access(o)
+            for sp, lo, hi in a_:
+                accs.setdefault(lo, []).append(k)
+            for sp, lo, hi in r_:
+                if sp == ("amax",):
+                    reads.setdefault(lo, []).append(k)
+        for slot, ks in accs.items():
+            for a in ks:
+                for r in reads.get(slot, ()):
+                    if a == r:
+                        continue
+                    lo_, hi_ = min(a, r), max(a, r)
+                    total += 1
+                    assert (hb[hi_] >> lo_) & 1, (which, slot, a, ops[a]["code"], r, ops[r]["code"])
+    assert total > 300
 
 
 # ----------------------------------------------------------------------------- U2: the three initialisers
@@ -252,10 +289,10 @@ def test_phiseg_plan_round4_passes(monkeypatch):
                 if c == "UZ_OP_BN_RELU_FWD":
                     assert j == 6 and i[10] == 1 and o["p"][8] is not None
                     assert i[8] > 0 or 4096 < i[3] * i[4] * i[5] <= L.uz_bn_fwd_fused_limit(i[4], i[5])      # statistics from the convolution's partials, or the one-launch mid path
-                    slots.add(o["p"][8])
+                    slots.add(o["p"][8][:2])       # (producers tag the ref "acc": compare slot numbers)
                 elif c in ("UZ_OP_BILINEAR_FWD", "UZ_OP_AVGPOOL_FWD"):
                     assert j == 1 and i[7 if c == "UZ_OP_BILINEAR_FWD" else 6] == 1 and o["p"][2] is not None
-                    slots.add(o["p"][3])
+                    slots.add(o["p"][3][:2])
                 elif c == "UZ_OP_CONV_FWD":
                     assert j == 0 and i[10] == 1 and L.uz_conv_route(0, i[0], i[2], i[4], i[5], i[6], 3) == 1
                     assert i[11] % 16 == 0 and (i[11] == 0) == (o["p"][10] is None)

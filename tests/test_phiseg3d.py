@@ -32,7 +32,7 @@ def test_plan_builds_schedules_and_rejects_what_the_reference_rejects():
         net = PHISeg3D(4, 3, [8, 16, 16], latent_levels=2, reversible=rev, device="cpu")
         plan = net._build(16, 32, 32, True, True)
         for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
-            pairs, _ = _check_lane_schedule(plan, which, ops)
+            pairs, _, _ = _check_lane_schedule(plan, which, ops)
             assert pairs > 100
         codes = [o["code"] for o in plan.fwd_ops]
         assert "UZ_OP_W3D_PERMUTE" in codes and "UZ_OP_AVGPOOL3D_FWD" in codes and "UZ_OP_DEPTH_LERP_FWD" in codes

@@ -70,7 +70,7 @@ def test_reversible_plan_saves_memory_and_keeps_every_dependency():
     small = PHISeg(1, 2, [4, 8, 8, 8, 8, 8, 8], image_size=(1, 64, 64), reversible=True, device="cpu")
     plan = small._build(2, 64, 64, True, True)
     for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
-        pairs, _ = _check_lane_schedule(plan, which, ops)
+        pairs, _, _ = _check_lane_schedule(plan, which, ops)
         assert pairs > 100
     assert sum(o["code"] == "UZ_OP_ADD_VIEWS" for o in plan.bwd_ops) > 50        # x2 = y2 - G(y1), x1 = y1 - F(x2) per block
 

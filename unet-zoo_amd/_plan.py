@@ -229,12 +229,12 @@ class Plan:
     def amax_out(self, v):
         """Slot reference a producer of view `v` accumulates max|v| into (creates the buffer's slot on first use)."""
         if isinstance(v, _ScratchView):
-            return ("amax", v.amax) if v.amax is not None else None
+            return ("amax", v.amax, "acc") if v.amax is not None else None
         b = v.buf
         if b.amax is None:
             b.amax = self._new_amax()
         b.amax_cov.append((v.c0, v.c0 + v.C))
-        return ("amax", b.amax)
+        return ("amax", b.amax, "acc")       # third element: this op ACCUMULATES into the slot (see _access)
 
     def amax_in(self, v):
         """Slot reference bounding |v| for a consumer, or None when some producer of its channels keeps no bound
@@ -594,7 +594,7 @@ class Plan:
             dbpart = self.vec(name + ":dbrows", 2 * dbrows * cout) if dbrows else None
             op_bwd = self._emit(self.bwd_ops, "UZ_OP_BN_RELU_BWD",
                                 p=[ga, y, self.P(gam), self.P(bet), save, gy, self.G(gam), self.G(bet), dbpart if dbrows else self.G(bkey), ("scratch", "bn"),
-                                   ("amax", gyv.amax)],
+                                   ("amax", gyv.amax, "acc")],
                                 i=[ga.Ctot, cout, y.Ctot, cout, x.N, x.H, x.W, int(relu), 0, 0, 1 if dbrows else 0])
             if dbrows:
                 self._dbias_jobs.append((dbpart, bkey, dbrows, cout, 1))
@@ -779,7 +779,7 @@ class Plan:
             gy = self._gy_scratch(a)
             gyv = _ScratchView(a.N, cout, a.H, a.W, amax=self._new_amax(bwd=True))
             self._emit(self.bwd_ops, "UZ_OP_RELU_BWD",
-                       p=[self.gview(a), a, gy, self.G(bkey), ("scratch", "bn"), ("amax", gyv.amax)],
+                       p=[self.gview(a), a, gy, self.G(bkey), ("scratch", "bn"), ("amax", gyv.amax, "acc")],
                        i=[a.Ctot, cout, a.Ctot, cout, x.N, x.H, x.W])
             self._conv_bwd(x, wkey, gyv, ks)
         self._push_bwd(bwd)
@@ -1236,7 +1236,7 @@ class Plan:
                 for o, r in wr_list:
                     vi, bi = self._PACK_WRITERS[o["code"]]
                     slot = slot_of[(r.c0, r.c0 + r.C)] = ("amax", self._new_amax())
-                    o["p"][bi] = slot
+                    o["p"][bi] = slot + ("acc",)
                     if o["code"] == "UZ_OP_BN_RELU_FWD":
                         o["i"] = (o["i"] + [0])[:11]
                         o["i"][10] = 1
@@ -1665,6 +1665,20 @@ class Plan:
             return (7,)
         return self._WRITES[o["code"]]
 
+    def _access(self, o):
+        """(reads, writes, accumulates) of op `o` as resource ranges.  Accumulates (bound slots only) commute with each other
+        and conflict with reads and writes."""
+        wr = self._op_writes(o)
+        reads, writes, accs = [], [], []
+        for j, r in enumerate(o["p"]):
+            if j in wr:
+                writes.extend(self._resources(r))
+            elif isinstance(r, tuple) and len(r) == 3 and r[0] == "amax" and r[2] == "acc":
+                accs.extend(self._resources(r))
+            else:
+                reads.extend(self._resources(r))
+        return reads, writes, accs
+
     def _resources(self, r):
         """Dependency-relevant resources behind one pointer ref: (space, lo, hi) half-open ranges."""
         if isinstance(r, _ScratchView) and r.view is not None:
@@ -1694,10 +1708,12 @@ class Plan:
         if kind in ("gywin", "gyvol"):
             return []
         if kind == "amax":
-            # Bound slots are atomic-max accumulated by the same kernels that write the data they bound, so every
-            # producer -> consumer order is already implied by the data buffers; only the zeroing (and the parameter-bound
-            # measurement) at the head of the tape must come first.  Producers and consumers therefore both count as READERS
-            # of the slot (no false write-write serialisation between the producers of one concat buffer).
+            # Bound slots are atomic-max accumulated by the kernels that write the data they bound.  A slot has three access
+            # classes (_access): the zeroing / parameter-bound measurement at the head of a tape WRITES it; producers ACCUMULATE
+            # (refs tagged "acc": unordered among themselves - no false serialisation between the producers of one concat buffer);
+            # consumers READ it - and a reader is ordered against EVERY accumulator of its slot, also one that writes channels the
+            # reader never touches: a kernel derives its operand scale from the slot more than once (workgroup by workgroup, main
+            # loop and epilogue), so the value must not move while it runs.
             return [(("amax",), r[1], r[1] + 1)]
         if kind == "amaxw":
             return [(("amax",), 0, 1)]
@@ -1778,36 +1794,49 @@ class Plan:
                 groups.append([k, k])
         G = len(groups)
         # ---- 1. hazards
-        hist = {}                                           # space -> list of [lo, hi, last_writer_gi, readers{gi}]
+        hist = {}                                           # space -> list of [lo, hi, last_writer_gi, readers{gi}, accumulators{gi}]
         deps = []
         for gi, (a, b) in enumerate(groups):
-            reads, writes = [], []
+            reads, writes, accs = [], [], []
             for o in ops[a:b + 1]:
-                wr = self._op_writes(o)
-                for j, r in enumerate(o["p"]):
-                    (writes if j in wr else reads).extend(self._resources(r))
+                r_, w_, a_ = self._access(o)
+                reads.extend(r_); writes.extend(w_); accs.extend(a_)
             d = set()
-            for space, lo, hi in reads:
+            for space, lo, hi in reads:                     # after the last writer and every accumulator since
                 for e in hist.get(space, ()):
-                    if e[0] < hi and lo < e[1] and e[2] is not None:
-                        d.add(e[2])
+                    if e[0] < hi and lo < e[1]:
+                        if e[2] is not None:
+                            d.add(e[2])
+                        d.update(e[4])
+            for space, lo, hi in accs:                      # after the last writer and every reader since (not after other accumulators)
+                for e in hist.get(space, ()):
+                    if e[0] < hi and lo < e[1]:
+                        if e[2] is not None:
+                            d.add(e[2])
+                        d.update(e[3])
             for space, lo, hi in writes:
                 for e in hist.get(space, ()):
                     if e[0] < hi and lo < e[1]:
                         if e[2] is not None:
                             d.add(e[2])
                         d.update(e[3])
+                        d.update(e[4])
             d.discard(gi)
             deps.append(d)
             for space, lo, hi in reads:
                 for e in hist.setdefault(space, []):
                     if e[0] < hi and lo < e[1]:
                         e[3].add(gi)
-                hist[space].append([lo, hi, None, {gi}])
+                hist[space].append([lo, hi, None, {gi}, set()])
+            for space, lo, hi in accs:
+                for e in hist.setdefault(space, []):
+                    if e[0] < hi and lo < e[1]:
+                        e[4].add(gi)
+                hist[space].append([lo, hi, None, set(), {gi}])
             for space, lo, hi in writes:
                 lst = hist.setdefault(space, [])
                 keep = [e for e in lst if not (lo <= e[0] and e[1] <= hi)]     # fully covered entries are superseded
-                keep.append([lo, hi, gi, set()])
+                keep.append([lo, hi, gi, set(), set()])
                 hist[space] = keep
         # ---- 2. list scheduling in simulated time
         cost = [sum(self._op_cost(o) for o in ops[a:b + 1]) for a, b in groups]

@@ -135,15 +135,19 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 
 // dynamic LDS of an instance: the staging images of the main loop, or (single-plane mode) the 16 channel rows x all pixels the
 // epilogue passes through it, whichever is larger
-template <int MSUB, int NTv, int TWv, int NP>
+template <int MSUB, int NTv, int TWv, int NP, int DB = 0>
 constexpr int lds_bytes() {
-    const int main_loop = NP * (KK * 32 * MSUB * CK * 2) + NP * (Geo<NTv, TWv>::PSR * CK * 2);
+    const int main_loop = (DB ? 2 : 1) * (NP * (KK * 32 * MSUB * CK * 2) + NP * (Geo<NTv, TWv>::PSR * CK * 2));
     const int epilogue = 16 * (NTv + 4) * 4;
     return main_loop > epilogue ? main_loop : epilogue;
 }
 // MK: 1 = the folded ReLU-backward mask (kernels of their own: +12 VGPRs), 2 = the folded BatchNorm-backward reduction;
 // XF = input format: 0 fp32 values, 1 split storage (two fp16 pieces per word), 2 bf16 storage (2-byte elements, single-piece mode)
-template <int MSUB, int NTv, int TWv, int NP, int MK = 0, int XF = 0>
+// DB (round 5): TWO staging images.  The chunk loop runs the MFMAs of chunk c on one image while chunk c + 1 is staged into the other:
+// the packed weight block goes global -> LDS by LDS-DMA (buffer_load ... lds: it is stored in the LDS image's order, so no register,
+// no VALU and no ds_write touches it), the patch values are loaded early in the chunk and written to the other image behind its last
+// tap.  One barrier per chunk instead of two, and no phase in which every wave stages while the matrix pipe idles.
+template <int MSUB, int NTv, int TWv, int NP, int MK = 0, int XF = 0, int DB = 0>
 __device__ __forceinline__ void conv_split_body(const SP& p) {
     constexpr bool XPK = XF == 1, XB = XF == 2;
     constexpr unsigned ESZ = XB ? 2u : 4u;               // bytes per input element
@@ -156,11 +160,14 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     constexpr int WPLANE = KK * COT * CK * 2;            // bytes per weight plane
     constexpr int PPLANE = PSR * CK * 2;                 // bytes per patch plane
     constexpr int WVEC = NP * WPLANE / 16;               // 16-byte vectors of one packed weight block (2304 / 1152)
-    constexpr int WREGS = (WVEC + NT - 1) / NT;          // per thread
+    constexpr int WREGS = DB ? 1 : (WVEC + NT - 1) / NT; // per thread (DB: the weights never pass through registers)
+    constexpr int IMG = NP * WPLANE + NP * PPLANE;       // bytes of one staging image (weights + patch)
+    constexpr int WDMA = WVEC / 64;                      // DB: 1 KiB LDS-DMA pieces of one weight block (36 / 18 / 9)
+    static_assert(!DB || (WVEC % 64 == 0 && TWv == 32), "LDS-DMA staging: whole 1 KiB pieces, the 32-pixel-wide geometry");
     // (bf16 single-product mode on the 32-wide geometry, round 4: DEEP 1 030 -> 1 208 us and DEEP + PREF 1 085 us on 288 -> 96 @ 128 x
     //  (128 x 64) - that kernel is not waiting for its loads; timing-only builds with half the patch load instructions -13 %, with a
     //  third of the B-fragment reads -2 %: neither the LDS reads nor the vector-memory issue rate alone is the bound)
-    constexpr bool DEEP = TWv == 16;                     // patch loads two chunks ahead (see stage_deep)
+    constexpr bool DEEP = TWv == 16 && !DB;              // patch loads two chunks ahead (see stage_deep)
 #ifndef UZ_EXP_PREF_ALL
 #define UZ_EXP_PREF_ALL 0
 #endif
@@ -170,8 +177,9 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 #endif
     constexpr bool UNCOND = TWv <= UZ_UNCOND_TW;         // stage the (non-existent) chunk after the last one too
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* Wl = lds;
+    char* Wl = lds;                                      // DB: the image being READ; the staging lambdas write to Wl / Pl + sto
     char* Pl = lds + NP * WPLANE;
+    int sto = 0;                                         // DB: byte offset of the image being WRITTEN relative to the one being read (+-IMG)
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -288,6 +296,16 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
             pr1[kk] = xload((goff[1] + (unsigned)(k0 + kk) * xstep) | gmask[1] | kvm);
         }
     };
+    // DB: this wave's share of the weight block of chunk c, 1 KiB per instruction straight into the image being written
+    auto weight_dma = [&](int c) {
+        const unsigned blk = (unsigned)(c * p.nCoTiles + coT) * wblock + 16u * (unsigned)lane;
+#pragma unroll
+        for (int i = 0; i < (WDMA + NT / 64 - 1) / (NT / 64); ++i) {
+            const int j = i * (NT / 64) + wave;
+            if (j < WDMA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(Wl + sto + j * 1024), 16, blk + 1024u * (unsigned)j, 0, 0, 0);
+        }
+    };
     auto weight_load = [&](int c, int i) {
         const int v = tid + i * NT;
         const unsigned off = v < WVEC ? (unsigned)(c * p.nCoTiles + coT) * wblock + 16u * (unsigned)v : 0xFFFFFFFFu;
@@ -326,6 +344,14 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
         }
     };
     auto stage = [&](int c, int tap) {
+        if constexpr (DB) {             // weights first (DMA), patch loads over taps 1..4, conversions over taps 5..8
+            if (tap == 0) weight_dma(c);
+            else if (tap < 5) {
+                patch_loads(c, 2 * (tap - 1)); patch_loads(c, 2 * (tap - 1) + 1);
+                if (tap == 1) shared_row_loads(c);
+            } else convert(tap - 5);
+            return;
+        }
         if (tap < 4) {
             patch_loads(c, 2 * tap); patch_loads(c, 2 * tap + 1);
             if (tap == 0) shared_row_loads(c);
@@ -352,7 +378,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
         }
     };
     auto lstore = [&]() {
-        char* dst = Pl + tid * 16;
+        char* dst = Pl + sto + tid * 16;
         if constexpr (XB) {           // this thread loaded channels 8 h2 .. 8 h2 + 7 itself and received the other eight
             *reinterpret_cast<u32x4*>(dst + (h2 ? PPLANE / 2 : 0)) = u32x4{mypk[0], mypk[1], mypk[2], mypk[3]};
             *reinterpret_cast<u32x4*>(dst + (h2 ? 0 : PPLANE / 2)) = u32x4{rcpk[0], rcpk[1], rcpk[2], rcpk[3]};
@@ -364,15 +390,17 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
         }
         }
         // shared rows: this thread holds channels [CE * q4, CE * q4 + CE) of row prow1 (CE = 4: 8 bytes, CE = 8: one 16-byte piece)
-        char* dst1 = Pl + prow1 * 16 + ((CE * q4) >> 3) * (PPLANE / 2) + ((CE * q4) & 7) * 2;
+        char* dst1 = Pl + sto + prow1 * 16 + ((CE * q4) >> 3) * (PPLANE / 2) + ((CE * q4) & 7) * 2;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             if (CE == 4) *reinterpret_cast<uint2*>(dst1 + q * PPLANE) = make_uint2(pk1[q][0], pk1[q][1]);
             else *reinterpret_cast<u32x4*>(dst1 + q * PPLANE) = u32x4{pk1[q][0], pk1[q][1], pk1[q][CE / 2 - 2], pk1[q][CE / 2 - 1]};
         }
+        if constexpr (!DB) {
 #pragma unroll
         for (int i = 0; i < WREGS; ++i)
             if (tid + i * NT < WVEC) *reinterpret_cast<u32x4*>(Wl + 16 * (tid + i * NT)) = wq[i];
+        }
     };
 
     const int nChunks = cend;
@@ -394,6 +422,12 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 #pragma unroll
         for (int tap = 0; tap < 4; ++tap) stage(cbeg + 1, tap);       // the raw registers are free again: chunk cbeg is converted
     }
+    if constexpr (DB) {                        // the first chunk goes into the image the loop reads first
+        lstore();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces have landed ...
+        __syncthreads();                                      // ... and so have everybody else's
+        sto = IMG;
+    }
     for (int c = cbeg; c < nChunks; ++c) {
         long long ta = 0;
         if (p.stamps) ta = __builtin_amdgcn_s_memtime();
@@ -405,9 +439,11 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 #pragma unroll
                 for (int n = 0; n < NSUB; ++n) acc[m][n] *= ratio;
         }
+        if constexpr (!DB) {
         __syncthreads();                       // every wave has finished the MFMAs of the previous chunk
         lstore();
         __syncthreads();
+        }
         if (p.stamps) { const long long tb = __builtin_amdgcn_s_memtime(); if (c == cbeg) st1 = tb; else stl += tb - ta; }
         const bool more = c + 1 < nChunks;
         const char* Al = Wl + l31 * 16 + h * (WPLANE / 2);
@@ -457,6 +493,14 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
                 __builtin_amdgcn_sched_barrier(0);           // ... and the next tap's work stays behind this tap's MFMAs
             }
         }
+        if constexpr (DB) {
+            // hand-over: the patch of chunk c + 1 goes into the other image (nobody reads it: every wave passed the previous
+            // hand-over), this wave's DMA pieces are waited for, and ONE barrier closes the chunk; then the images swap roles
+            if (more) lstore();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            Wl += sto; Pl += sto; sto = -sto;
+        }
     }
 
     long long st2 = 0;
@@ -468,7 +512,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
     // comes back as float4 rows: a quarter of the store instructions, each wave writing whole 128-byte lines.
     const float* const xa_last = (XPK && p.segc > 0 && nChunks > p.segc) ? p.x_amax2 : p.x_amax;      // the bound the LAST chunk of this part was scaled from
     const float inv = NP == 2 ? uz::split_inv_scale(uz::amax_read(xa_last)) * uz::split_inv_scale(uz::amax_read(p.w_amax)) : 1.f;
-    constexpr int LDS_BYTES = lds_bytes<MSUB, NTv, TWv, NP>();
+    constexpr int LDS_BYTES = DB ? IMG : lds_bytes<MSUB, NTv, TWv, NP>();      // DB: the epilogue passes fit one image
     constexpr int GP = (32 * NT * 4 <= LDS_BYTES) ? 4 : ((16 * NT * 4 <= LDS_BYTES) ? 2 : 1);    // channel groups of 8 per pass
     constexpr int ROWF = NT + 4;                         // floats per channel row (one pixel per thread, + 16 B: rows start on different banks)
     static_assert(8 * GP * ROWF * 4 <= LDS_BYTES, "epilogue staging must fit the main loop's LDS");
@@ -613,10 +657,11 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 // The instances as kernels of their own (attributes take literal constants only; names show up in profiles): three tile
 // geometries x {split-fp16 (fp32-accurate), single-piece bf16} x epilogue {plain, folded ReLU backward, folded BatchNorm-backward
 // reduction} x input {fp32, split storage}.
-template <int MSUB, int NTv, int TWv, int NP, int MK, int XF> struct SplitKernel;
-#define UZ_SPLIT_KERNEL(name, MSUB_, NT_, TW_, NP_, MK_, XF_, OCC_)                                                     \
-    __global__ __launch_bounds__(NT_, OCC_) void name(const SP p) { conv_split_body<MSUB_, NT_, TW_, NP_, MK_, XF_>(p); } \
-    template <> struct SplitKernel<MSUB_, NT_, TW_, NP_, MK_, XF_> { static constexpr auto fn = name; };
+template <int MSUB, int NTv, int TWv, int NP, int MK, int XF, int DB = 0> struct SplitKernel;
+#define UZ_SPLIT_KERNEL_(name, MSUB_, NT_, TW_, NP_, MK_, XF_, OCC_, DB_)                                                     \
+    __global__ __launch_bounds__(NT_, OCC_) void name(const SP p) { conv_split_body<MSUB_, NT_, TW_, NP_, MK_, XF_, DB_>(p); } \
+    template <> struct SplitKernel<MSUB_, NT_, TW_, NP_, MK_, XF_, DB_> { static constexpr auto fn = name; };
+#define UZ_SPLIT_KERNEL(name, MSUB_, NT_, TW_, NP_, MK_, XF_, OCC_) UZ_SPLIT_KERNEL_(name, MSUB_, NT_, TW_, NP_, MK_, XF_, OCC_, 0)
 // (round 4: the 32-channel-tile kernels keep (512, 4) although that bound costs them ~30 spilled registers - with (512, 3), no spills
 //  but one workgroup per CU, 32 -> 32 @ 128 x 128 ran 55 -> 61 us forward and the PHiSeg step lost 0.8 %)
 // (round 4, single-product mode: (512, 4) = two workgroups per CU on the 64-channel-tile bf16 kernels needs 128 VGPRs - 168 in use, 76 - 80
@@ -647,13 +692,25 @@ UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_256_16, 1, 256, 16, 2, 2, 1, 3)
 UZ_SPLIT_KERNEL(conv_b16_kernel_2_512_32, 2, 512, 32, 1, 0, 2, 1)
 UZ_SPLIT_KERNEL(conv_b16_kernel_1_512_32, 1, 512, 32, 1, 0, 2, 4)
 UZ_SPLIT_KERNEL(conv_b16_kernel_1_256_16, 1, 256, 16, 1, 0, 2, 3)
+// round 5: the 64-channel tile with two staging images and LDS-DMA weight staging (conv_*db_*), one workgroup per CU (152 KB of LDS)
+UZ_SPLIT_KERNEL_(conv_split_db_kernel_2_512_32, 2, 512, 32, 2, 0, 0, 1, 1)
+UZ_SPLIT_KERNEL_(conv_split_relu_db_kernel_2_512_32, 2, 512, 32, 2, 1, 0, 1, 1)
+UZ_SPLIT_KERNEL_(conv_splitp_db_kernel_2_512_32, 2, 512, 32, 2, 0, 1, 1, 1)
+UZ_SPLIT_KERNEL_(conv_split_bn_db_kernel_2_512_32, 2, 512, 32, 2, 2, 0, 1, 1)
+UZ_SPLIT_KERNEL_(conv_splitp_bn_db_kernel_2_512_32, 2, 512, 32, 2, 2, 1, 1, 1)
+UZ_SPLIT_KERNEL_(conv_bf16_db_kernel_2_512_32, 2, 512, 32, 1, 0, 0, 1, 1)
+UZ_SPLIT_KERNEL_(conv_bf16_relu_db_kernel_2_512_32, 2, 512, 32, 1, 1, 0, 1, 1)
+UZ_SPLIT_KERNEL_(conv_b16_db_kernel_2_512_32, 2, 512, 32, 1, 0, 2, 1, 1)
 #undef UZ_SPLIT_KERNEL
+#undef UZ_SPLIT_KERNEL_
+// UZ_CONV_DB=0: the single-image kernels everywhere (A/B runs)
+inline bool db_enabled() { static const bool on = !(getenv("UZ_CONV_DB") && atoi(getenv("UZ_CONV_DB")) == 0); return on; }
 
-template <int MSUB, int NTv, int TWv, int NP, int MK, int XF>
-int launch_one(const SP& p, int grid, hipStream_t st) {
-    constexpr size_t smem = lds_bytes<MSUB, NTv, TWv, NP>();
+template <int MSUB, int NTv, int TWv, int NP, int MK, int XF, int DB>
+int launch_db(const SP& p, int grid, hipStream_t st) {
+    constexpr size_t smem = lds_bytes<MSUB, NTv, TWv, NP, DB>();
     static bool attr_done = false;
-    auto kern = SplitKernel<MSUB, NTv, TWv, NP, MK, XF>::fn;
+    auto kern = SplitKernel<MSUB, NTv, TWv, NP, MK, XF, DB>::fn;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return uz::fail("conv_split: cannot raise dynamic LDS limit");
@@ -661,6 +718,13 @@ int launch_one(const SP& p, int grid, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTv), smem, st, p);
     return uz::check_launch("conv_split_kernel");
+}
+template <int MSUB, int NTv, int TWv, int NP, int MK, int XF>
+int launch_one(const SP& p, int grid, hipStream_t st) {
+    if constexpr (MSUB == 2 && NTv == 512 && TWv == 32) {
+        if (db_enabled()) return launch_db<MSUB, NTv, TWv, NP, MK, XF, 1>(p, grid, st);
+    }
+    return launch_db<MSUB, NTv, TWv, NP, MK, XF, 0>(p, grid, st);
 }
 // mk: 0 plain, 1 folded ReLU backward, 2 folded BatchNorm-backward reduction; xpk: input in split storage (two-piece mode only)
 template <int MSUB, int NTv, int TWv, int NP>
