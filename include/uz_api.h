@@ -452,6 +452,14 @@ typedef struct uz_sched {
 } uz_sched;
 int  uz_graph_create_lanes(const uz_op* ops, const uz_sched* sched, int n_ops, int n_lanes,
                            void* stream, void** graph_exec_out);
+/* The same DAG replayed WITHOUT a hipGraph: lane 0 runs on `stream`, every other lane on a library-owned stream that forks from
+ * and joins `stream`; every cross-lane edge is one event that names exactly the op it waits for.  Replaces the reference's
+ * implicit stream order (it has none: PyTorch issues phiseg.py:326-537 op by op on one stream). */
+int  uz_run_tape_lanes(const uz_op* ops, const uz_sched* sched, int n_ops, int n_lanes, void* stream);
+/* diagnostics (tools/lane_trace.py): enable != 0 arms one timing event behind each of the first `capacity` ops of every following
+ * uz_run_tape_lanes call; enable == 0 disarms and, with out != NULL, writes the end time (ms since the call began) of every op of the
+ * last call and returns their count */
+int  uz_lane_trace(int enable, int capacity, float* out, int n_out);
 int  uz_graph_launch(void* graph_exec, void* stream);
 void uz_graph_destroy(void* graph_exec);
 

@@ -149,6 +149,15 @@ class NativeModel(nn.Module):
         return p
 
     default_lanes = 2          # dependency lanes of the captured graphs (UZ_LANES overrides); see ProbabilisticUnet
+    # How enable_graphs() replays a tape: "lanes" (default since round 5) = the tape's DAG issued by the host on one HIP stream per
+    # lane with one event per cross-lane edge (uz_run_tape_lanes); "graph" = one hipGraph per tape (the DAG captured by
+    # uz_graph_create_lanes).  UZ_REPLAY overrides.  Measured on MI355X, same box: the ROCm 7.2 graph executor enqueues a captured DAG in
+    # an order of its own and ready nodes wait behind unrelated ones in the in-order hardware queues (the prior's encoder of a PHiSeg
+    # step started 1.3 ms late); host-issued lanes start every op when ITS predecessors are done: PHiSeg 17.2 -> 16.3 ms with three
+    # lanes, Probabilistic U-Net 3 107 -> 3 240 images/s, U-Net / PHiSeg3D unchanged.  (More than four concurrently active hardware
+    # queues collapse the step to 27 ms: lanes <= 4, GPU_MAX_HW_QUEUES >= lanes.)
+    replay_mode = os.environ.get("UZ_REPLAY", "lanes")
+    default_lanes_by_mode = {}  # per-model override of default_lanes for a replay mode, e.g. {"lanes": 3}
     # Planes (N*H*W pixels) up to which a layer's weight gradient becomes a scheduling group of its own (Plan._decouple_wgrad;
     # UZ_DECOUPLE_WGRAD overrides).  Measured A/B on one MI355X: PHiSeg 19.49 -> 19.26 ms with 8192 (the deep levels' backward
     # chains no longer carry the weight gradients), Probabilistic U-Net 11.33 -> 11.66 ms (three lanes already interleave its
@@ -159,7 +168,9 @@ class NativeModel(nn.Module):
     def _new_plan(self, N, bn_training):
         plan = Plan(N, self._ptab, bn_training, self.device)
         if "UZ_LANES" not in os.environ:
-            plan.n_lanes = self.default_lanes
+            plan.n_lanes = self.default_lanes_by_mode.get(self.replay_mode, self.default_lanes)
+        # the scheduler's "one device-filling group at a time" rule pays in the graph replay only
+        plan.sched_heavy = os.environ.get("UZ_SCHED_HEAVY", "off" if self.replay_mode == "lanes" else "r4")
         plan.decouple_wgrad_px = self.decouple_wgrad_px
         plan.decouple_wgrad_prefixes = tuple(self.decouple_wgrad_prefixes)
         dp = getattr(self, "_dp", None)
@@ -216,6 +227,12 @@ class NativeModel(nn.Module):
     def _run(self, plan, which):
         if not self._use_graphs or which == "loss":
             plan.run(which, self._stream())
+            return
+        if self.replay_mode == "lanes" and plan.n_lanes > 1 and which in plan.scheds:
+            # the tape's DAG issued by the host on one stream per lane, one event per cross-lane edge (uz_run_tape_lanes)
+            arr, n = plan.tapes[which]
+            if n:
+                _ffi.check(plan.L.uz_run_tape_lanes(arr, plan.scheds[which], n, plan.n_lanes, C.c_void_p(self._stream())), f"lane replay '{which}'")
             return
         key = (id(plan), which)
         g = self._graphs.get(key)

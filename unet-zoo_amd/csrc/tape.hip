@@ -357,6 +357,128 @@ extern "C" int uz_graph_create_lanes(const uz_op* ops, const uz_sched* sched, in
     *graph_exec_out = exec;
     return 0;
 }
+// Lane replay WITHOUT a hipGraph (round 5): the same DAG, issued by the host on one HIP stream per lane with one event per
+// cross-lane edge - lane 0 is `stream` itself, the other lanes are library-owned non-blocking streams that fork from and join
+// `stream`.  Every wait names exactly the op it waits for, so an op starts as soon as ITS predecessors are done (the ROCm 7.2
+// graph executor enqueues a captured DAG in an order of its own and an in-order hardware queue then holds ready nodes behind
+// unrelated waits: the prior's encoder started 1.3 ms late in a replayed PHiSeg step).
+namespace {
+struct LanePool {
+    hipStream_t lanes[UZ_MAX_LANES] = {};
+    hipEvent_t* ev = nullptr; int n_ev = 0;
+    hipEvent_t fork = nullptr, join[UZ_MAX_LANES] = {};
+};
+LanePool g_lp;
+// diagnostics (uz_lane_trace): a timing event behind every op of the last uz_run_tape_lanes call
+struct LaneTrace { bool on = false; hipEvent_t base = nullptr; hipEvent_t* ev = nullptr; int cap = 0, n = 0; };
+LaneTrace g_lt;
+int lane_pool_reserve(int n_lanes, int n_events) {
+    for (int l = 1; l < n_lanes; ++l) {
+        if (!g_lp.lanes[l]) {
+            // UZ_LANE_PRIO: one letter per lane from lane 1 on - h(igh), n(ormal), l(ow) stream priority (default: all normal).  A low-priority
+            // lane's workgroups are dispatched when the other lanes leave room: deferred device-filling work (weight gradients) then fills
+            // the gaps of the critical chain instead of sharing the chip with it
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            const char* pr = getenv("UZ_LANE_PRIO");
+            const char c = (pr && (int)strlen(pr) >= l) ? pr[l - 1] : 'n';
+            const int prio = c == 'h' ? greatest : c == 'l' ? least : (least + greatest) / 2;
+            // UZ_HEAVY_CUS=<n>: the LAST lane (the device-filling lane of UZ_SCHED_POLICY=typed) may only use n of the 256 CUs - the
+            // latency-bound chains of the other lanes then always find free CUs instead of queueing behind device-filling workgroups
+            const char* hc = getenv("UZ_HEAVY_CUS");
+            const int ncu = hc ? atoi(hc) : 0;
+            if (l == n_lanes - 1 && ncu > 0 && ncu < 256) {
+                uint32_t mask[8];
+                const char* lay = getenv("UZ_HEAVY_CUS_LAYOUT");      // "lo" (default): the first 256 - n mask bits are cleared; "hi": the last ones
+                for (int b = 0; b < 256; ++b) {
+                    const bool on = (lay && lay[0] == 'h') ? b < ncu : b >= 256 - ncu;
+                    if (b % 32 == 0) mask[b / 32] = 0;
+                    if (on) mask[b / 32] |= 1u << (b % 32);
+                }
+                if (hipExtStreamCreateWithCUMask(&g_lp.lanes[l], 8, mask) != hipSuccess) return uz::fail("run_tape_lanes: cannot create the CU-masked lane stream");
+            } else if (hipStreamCreateWithPriority(&g_lp.lanes[l], hipStreamNonBlocking, prio) != hipSuccess) return uz::fail("run_tape_lanes: cannot create lane stream");
+        }
+        if (!g_lp.join[l] && hipEventCreateWithFlags(&g_lp.join[l], hipEventDisableTiming) != hipSuccess) return uz::fail("run_tape_lanes: cannot create event");
+    }
+    if (!g_lp.fork && hipEventCreateWithFlags(&g_lp.fork, hipEventDisableTiming) != hipSuccess) return uz::fail("run_tape_lanes: cannot create event");
+    if (n_events > g_lp.n_ev) {
+        hipEvent_t* ne = static_cast<hipEvent_t*>(realloc(g_lp.ev, sizeof(hipEvent_t) * static_cast<size_t>(n_events)));
+        if (!ne) return uz::fail("run_tape_lanes: out of host memory");
+        g_lp.ev = ne;
+        for (int k = g_lp.n_ev; k < n_events; ++k)
+            if (hipEventCreateWithFlags(&g_lp.ev[k], hipEventDisableTiming) != hipSuccess) { g_lp.n_ev = k; return uz::fail("run_tape_lanes: cannot create event"); }
+        g_lp.n_ev = n_events;
+    }
+    return 0;
+}
+}  // namespace
+extern "C" int uz_run_tape_lanes(const uz_op* ops, const uz_sched* sched, int n_ops, int n_lanes, void* stream) {
+    UZ_REQUIRE(n_lanes >= 1 && n_lanes <= UZ_MAX_LANES, "run_tape_lanes: n_lanes %d outside [1,%d]", n_lanes, UZ_MAX_LANES);
+    int n_sig = 0;
+    for (int k = 0; k < n_ops; ++k) {
+        UZ_REQUIRE(sched[k].lane >= 0 && sched[k].lane < n_lanes, "run_tape_lanes: op %d lane %d", k, sched[k].lane);
+        UZ_REQUIRE(sched[k].n_wait >= 0 && sched[k].n_wait <= UZ_MAX_LANES, "run_tape_lanes: op %d n_wait %d", k, sched[k].n_wait);
+        for (int w = 0; w < sched[k].n_wait; ++w)
+            UZ_REQUIRE(sched[k].wait[w] >= 0 && sched[k].wait[w] < k && sched[sched[k].wait[w]].signal,
+                       "run_tape_lanes: op %d waits on op %d which is not an earlier signalling op", k, sched[k].wait[w]);
+        n_sig += sched[k].signal != 0;
+    }
+    if (int rc = lane_pool_reserve(n_lanes, n_sig)) return rc;
+    hipStream_t main = uz::S(stream);
+    int* ev_of = static_cast<int*>(malloc(sizeof(int) * static_cast<size_t>(n_ops > 0 ? n_ops : 1)));
+    if (!ev_of) return uz::fail("run_tape_lanes: out of host memory");
+    bool forked[UZ_MAX_LANES] = {};
+    int rc = 0, next_ev = 0;
+    auto ok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == 0) rc = uz::fail("run_tape_lanes: %s: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    if (n_lanes > 1) ok(hipEventRecord(g_lp.fork, main), "fork record");
+    if (g_lt.on) { (void)hipEventRecord(g_lt.base, main); g_lt.n = 0; }
+    for (int k = 0; k < n_ops && rc == 0; ++k) {
+        const int lane = sched[k].lane;
+        hipStream_t s = lane == 0 ? main : g_lp.lanes[lane];
+        if (lane != 0 && !forked[lane]) { forked[lane] = true; if (!ok(hipStreamWaitEvent(s, g_lp.fork, 0), "fork wait")) break; }
+        for (int w = 0; w < sched[k].n_wait; ++w)
+            if (!ok(hipStreamWaitEvent(s, g_lp.ev[ev_of[sched[k].wait[w]]], 0), "wait")) break;
+        if (rc) break;
+        if (run_one(ops[k], s) != 0) {
+            char prev[600];
+            strncpy(prev, uz::g_err, sizeof(prev) - 1);
+            prev[sizeof(prev) - 1] = 0;
+            rc = uz::fail("tape op %d (code %d): %s", k, ops[k].code, prev);
+            break;
+        }
+        if (sched[k].signal) { ev_of[k] = next_ev; ok(hipEventRecord(g_lp.ev[next_ev++], s), "signal record"); }
+        if (g_lt.on && k < g_lt.cap) { (void)hipEventRecord(g_lt.ev[k], s); g_lt.n = k + 1; }
+    }
+    for (int l = 1; l < n_lanes; ++l)               // join, also on errors: the lanes' work must not outlive the call's stream order
+        if (forked[l] && hipEventRecord(g_lp.join[l], g_lp.lanes[l]) == hipSuccess) (void)hipStreamWaitEvent(main, g_lp.join[l], 0);
+    free(ev_of);
+    return rc;
+}
+// diagnostics: enable = 1 arms a timing event behind each of the first `capacity` ops of every following uz_run_tape_lanes call;
+// enable = 0 with out != NULL synchronises and writes the end time (ms since the call's fork) of every op of the LAST call, returns their count
+extern "C" int uz_lane_trace(int enable, int capacity, float* out, int n_out) {
+    if (enable) {
+        if (!g_lt.base && hipEventCreate(&g_lt.base) != hipSuccess) return uz::fail("lane_trace: cannot create event");
+        if (capacity > g_lt.cap) {
+            hipEvent_t* ne = static_cast<hipEvent_t*>(realloc(g_lt.ev, sizeof(hipEvent_t) * static_cast<size_t>(capacity)));
+            if (!ne) return uz::fail("lane_trace: out of host memory");
+            g_lt.ev = ne;
+            for (int k = g_lt.cap; k < capacity; ++k) if (hipEventCreate(&g_lt.ev[k]) != hipSuccess) { g_lt.cap = k; return uz::fail("lane_trace: cannot create event"); }
+            g_lt.cap = capacity;
+        }
+        g_lt.on = true;
+        return 0;
+    }
+    g_lt.on = false;
+    if (!out) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return uz::fail("lane_trace: synchronize failed");
+    const int n = g_lt.n < n_out ? g_lt.n : n_out;
+    for (int k = 0; k < n; ++k) if (hipEventElapsedTime(&out[k], g_lt.base, g_lt.ev[k]) != hipSuccess) out[k] = -1.f;
+    return n;
+}
 extern "C" int uz_graph_launch(void* graph_exec, void* stream) {
     if (hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), uz::S(stream)) != hipSuccess) return uz::fail("graph_launch failed");
     return 0;
