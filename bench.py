@@ -198,32 +198,36 @@ def binding_roof(plan, L):
 
 
 def profile_families(net, plan, L, reps=3, burst=4):
-    """Live per-family timing: replay the fwd / bwd tapes one op at a time, each op as `burst` back-to-back launches bracketed
-    by HIP events on the launch stream (torch.cuda.Event records on torch's current stream, which IS the stream the tape is
-    launched on); time per launch = best burst / burst, so the ~5 us an event pair and an idle-queue launch cost is spread over
-    the burst instead of being charged to every 10 - 30 us kernel (inside the captured step the kernels follow each other the
-    same way).  The burst re-reads tensors the previous launch of the same op left in the 256 MB memory-side cache exactly as
-    the step's consumer finds them after its producer."""
+    """Live per-family timing: replay the fwd / bwd tapes one op at a time between two HIP events on the launch stream
+    (torch.cuda.Event records on torch's current stream, which IS the stream the tape is launched on).
+    Two figures per op: `ms` = best of `reps` SINGLE launches - what the HBM fractions are computed from; it carries the
+    ~5 us an event pair and a launch onto an idle queue cost, so it under-states short kernels - and `ms_burst` = best burst of
+    `burst` identical back-to-back launches / burst: launch overhead amortised, but launches 2..burst re-read what the first left in
+    the 256 MB memory-side cache, so it is CACHE-WARM and over-states bandwidth; reported beside the first, labelled, never as the
+    HBM fraction."""
     import ctypes as C
     import torch
     from unet_zoo_amd import _ffi
     stream = C.c_void_p(net._stream())
     fam, heaviest = {}, None
+
+    def timed(tape, n_launch):
+        best = None
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _ffi.check(L.uz_run_tape(tape, n_launch, stream), "profile op")
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / n_launch
+            best = ms if best is None else min(best, ms)
+        return best
     for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
         arr, n = plan.tapes[which]
         for k in range(n):
             name = FAMILY.get(ops[k]["code"], "other")
-            one = (type(arr[0]) * burst)(*([arr[k]] * burst))
-            best = None
-            for _ in range(reps):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                _ffi.check(L.uz_run_tape(one, burst, stream), "profile op")
-                e1.record()
-                e1.synchronize()
-                ms = e0.elapsed_time(e1) / burst
-                best = ms if best is None else min(best, ms)
-            d = fam.setdefault(name, dict(ms=0.0, flops=0.0, t_roof=0.0, bytes=0.0, launches=0, ms_large=0.0, bytes_large=0.0, n_large=0))
+            best = timed((type(arr[0]) * 1)(arr[k]), 1)
+            d = fam.setdefault(name, dict(ms=0.0, flops=0.0, t_roof=0.0, bytes=0.0, launches=0, ms_large=0.0, bytes_large=0.0, n_large=0, ms_large_burst=0.0))
             fl = conv_flops(ops[k])
             d["ms"] += best
             d["bytes"] += op_bytes(ops[k])
@@ -232,6 +236,8 @@ def profile_families(net, plan, L, reps=3, burst=4):
                 d["ms_large"] += best
                 d["bytes_large"] += op_bytes(ops[k])
                 d["n_large"] += 1
+                if not fl and ops[k]["code"] != "UZ_OP_EVENT_RECORD":
+                    d["ms_large_burst"] += timed((type(arr[0]) * burst)(*([arr[k]] * burst)), burst)
             if fl:
                 roof = conv_roof(ops[k], L)
                 if roof is not None:
@@ -758,8 +764,11 @@ def main():
                         if d["n_large"]:
                             e["large_ops"] = dict(launches=d["n_large"], ms_per_step=round(d["ms_large"], 3), gbs=round(d["bytes_large"] / d["ms_large"] / 1e6, 1),
                                                   frac_of_hbm_peak=round(d["bytes_large"] / d["ms_large"] / 1e6 / HBM_PEAK_GBS, 4),
-                                                  note=">= 32 MB of algorithmic traffic per launch (timed as bursts of 4 launches between two HIP events, per-launch = burst / 4); "
-                                                       "the rest of the family are latency-bound launches on the 16x16 ... 2x2 levels")
+                                                  cache_warm_burst4=dict(ms_per_step=round(d["ms_large_burst"], 3), gbs=round(d["bytes_large"] / d["ms_large_burst"] / 1e6, 1),
+                                                                         note="bursts of 4 identical launches / 4: launch overhead amortised, launches 2 - 4 re-read the "
+                                                                              "memory-side cache - NOT an HBM fraction") if d["ms_large_burst"] else None,
+                                                  note=">= 32 MB of algorithmic traffic per launch, each timed as ONE launch between two HIP events (includes ~5 us of event / "
+                                                       "launch overhead); the rest of the family are latency-bound launches on the 16x16 ... 2x2 levels")
                     fams[k] = e
                 dom = max((k for k in fam if fam[k]["flops"]), key=lambda k: fam[k]["ms"])
                 dk = dominant_kernel_live(net, plan, L, heaviest)
@@ -795,7 +804,7 @@ def main():
                      "STORED in fp32 (bf16 storage is not built); small planes and 1x1 heads stay on the fp32 kernels" if conv_math() == "bf16" else
                      "fp32 in / fp32 out, fp32 accumulate everywhere; 3x3 layers the library routes to the split path (forward, data gradient AND "
                      "weight gradient; share in roofline.flop_share_by_pipe): operands scaled by a power of two and split into 2 fp16 pieces, 3 piece "
-                     "products on the fp16 matrix pipe (error vs fp64 no larger than the fp32-MFMA kernels', tests/test_full_configs_gpu.py); other layers: fp32 MFMA")
+                     "products on the fp16 matrix pipe (22-bit operands: per layer within 2x the error of the fp32-MFMA kernels against fp64 (measured 0.5 - 0.8x on the heaviest layer); end to end at batch 32 the gradients' median error against fp64 is 1.6x the fp32 reference's own, logits within 1e-4, argmax bit-equal; tests/test_full_configs_gpu.py, tests/test_phiseg_gpu.py); other layers: fp32 MFMA")
         line = dict(metric=M["metric"], value=round(ips, 3 if vol else 2), unit=M.get("unit", "images/s"), n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="strong" if args.strong else "weak",
                     vs_baseline=None, dtype=("bf16" if store_b16 else "bf16 arithmetic / f32 storage") if conv_math() == "bf16" else "f32", data="synthetic",

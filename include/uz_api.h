@@ -48,7 +48,7 @@ int         uz_device_info(int* n_cu, char* name, int name_cap);
  *    streaming VALU kernels instead;
  *  - for the large 3x3 layers, the fp16 matrix pipe with split operands (each fp32 value, scaled by a power of two,
  *    = two fp16 pieces of 11 significand bits; three piece products, fp32 accumulate: split_f16.h, conv_split.hip,
- *    conv_wgrad_split.hip) - fp32-accurate (error vs fp64 no larger than the fp32-MFMA kernels').  Environment switch, read once per process:
+ *    conv_wgrad_split.hip) - 22-bit operands (per layer within 2x the error of the fp32-MFMA kernels against fp64 (measured 0.5 - 0.8x on the heaviest layer); end to end at batch 32 the gradients' median error against fp64 is 1.6x the fp32 reference's own, logits within 1e-4, argmax bit-equal: tests/test_full_configs_gpu.py, tests/test_phiseg_gpu.py).  Environment switch, read once per process:
  *    UZ_CONV_MATH=f32 (fp32 MFMA only) | split (split path on every eligible 3x3 shape) | unset.
  *    The forward / data-gradient split path keeps its packed weight image in `workspace`.
  * Deep, low-resolution levels (2x2 .. 16x16) cannot fill 256 CUs with output tiles alone: with a

@@ -28,8 +28,10 @@ def main():
     sd0 = oracle.deterministic_state_dict(phiseg_spec(1, 2, filters), seed=21)
     shapes = oracle.phiseg_eps_shapes(B, HW, HW)
 
+    seed0 = int(os.environ.get("UZ_DP_TEST_SEED", "900"))
+
     def shard(r):
-        return oracle.synthetic_batch(B, HW, HW, seed=100 + r, eps_shapes=shapes + shapes)
+        return oracle.synthetic_batch(B, HW, HW, seed=seed0 + r, eps_shapes=shapes + shapes)
 
     x, mask, eps = shard(rank)
     xd, md = torch.from_numpy(x).to(dev), torch.from_numpy(mask).to(dev)
@@ -82,14 +84,15 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     # Gates.  What this test is about - the exchange - fails by O(1): a shard left out or a sum instead of the mean moves EVERY tensor by
-    # 50 - 100 %.  Rounding does not: the median tensor sits at 1e-4 of its largest entry (gate 1e-3).  The worst tensor is a different
-    # matter: one pixel of a 64 x 64 plane whose pre-activation is zero to an ulp can carry the largest upstream gradient of its
-    # tensor, and whether its ReLU mask is 0 or 1 moves a weight gradient by 3 % (measured on this seed, tools/diag_midfwd.py: ONE
-    # mask element differs between two forward kernels whose outputs agree to 1 ulp, the fp64 oracle sides with either) - so the
-    # worst-tensor gate is 1e-1, far below what a wrong exchange does and above what a knife-edge mask does.
+    # 50 - 100 %, a single mis-bucketed layer or an overwritten regulariser share moves ITS tensors by 3 - 10 %.  Rounding does not: the
+    # median tensor sits at 1e-4 of its largest entry (gate 1e-3) and the worst at 4e-3 - 6e-3 (gate 2e-2) - on THIS
+    # data seed.  The seed matters: a pixel whose pre-activation is zero to an ulp can carry the largest upstream gradient of its
+    # tensor, and whether its ReLU mask is 0 or 1 then moves a weight gradient by 3 % (seeds 100 and 500 have such a pixel: worst
+    # 2.7e-2 with 1 - 2 tensors beyond 2e-2, tools/dp_seed_scan.sh; seeds 300 / 700 / 900: 1.6e-2 / 4.4e-3 / 5.6e-3, none) - so the
+    # test uses a seed without one instead of a gate wide enough to hide a real fault.
     med = sorted(devs)[len(devs) // 2]
-    print(f"rank {rank}: median_rel_dev={med:.3e}", flush=True)
-    sys.exit(0 if (same and worst < 1e-1 and med < 1e-3) else 1)
+    print(f"rank {rank}: median_rel_dev={med:.3e} tensors_above_2e-2={sum(d >= 2e-2 for d in devs)} seed={seed0}", flush=True)
+    sys.exit(0 if (same and worst < 2e-2 and med < 1e-3) else 1)
 
 
 if __name__ == "__main__":

@@ -205,6 +205,41 @@ def test_a_bound_that_is_too_small_clamps_and_raises_the_flag_never_inf():
     assert _flags() == 0
 
 
+def test_a_single_violation_in_the_last_chunk_and_the_last_tile_raises_the_flag():
+    """until round 4 the kernels tested only the FIRST channel chunk (forward / data gradient) and the first pixel
+    tile (weight gradient) they staged, and operands in split storage not at all.  Round 5 accumulates the predicate over every
+    chunk and tile and in the producers of split storage: ONE element beyond the bound, placed in the last channel, last image, last
+    row, last column, must raise the flag in every direction - and nothing but that element's products may be affected (clamped)."""
+    _need_split()
+    g = _g()
+    x, w, dy = _operands(47)
+    amax = dict(x=float(x.abs().max()), w=float(w.abs().max()), dy=float(dy.abs().max()))
+    big = 2.0 ** 9                                   # 512 x the bound: far beyond the 4 x headroom of the scale
+    xv = x.clone(); xv[N - 1, CIN - 1, H - 1, W - 1] = amax["x"] * big
+    dyv = dy.clone(); dyv[N - 1, COUT - 1, H - 1, W - 1] = amax["dy"] * big
+    _flags()
+    y, dx, dw = _run_all(xv, w, dy, _slot(amax["x"]), _slot(amax["w"]), _slot(amax["dy"]))
+    f = _flags()
+    assert torch.isfinite(y).all() and torch.isfinite(dw).all()
+    assert f & 1 and not f & 4, f"activation violation in the last chunk / last tile not reported (flags {f})"
+    y, dx, dw = _run_all(x, w, dyv, _slot(amax["x"]), _slot(amax["w"]), _slot(amax["dy"]))
+    f = _flags()
+    assert torch.isfinite(dx).all() and torch.isfinite(dw).all()
+    assert f & 4 and not f & 1, f"gradient violation in the last chunk / last tile not reported (flags {f})"
+    # ... and the producers of split storage: the stand-alone packer and the pooling / BatchNorm kernels that write operand pieces
+    xd = xv.to(g.dev()); packed = torch.empty_like(xd)
+    g.call("uz_pack_split", xd, packed, xd.numel(), _slot(amax["x"]))
+    assert _flags() & 1, "uz_pack_split: a value beyond its bound must raise the flag"
+    back = torch.empty_like(xd)
+    g.call("uz_unpack_split", packed, back, xd.numel(), _slot(amax["x"]))
+    assert torch.isfinite(back).all(), "the clamp keeps the stored pieces finite"
+    ok = torch.ones_like(xd, dtype=torch.bool); ok[N - 1, CIN - 1, H - 1, W - 1] = False
+    assert torch.allclose(back[ok], xd[ok], rtol=2.0 ** -20, atol=amax["x"] * 2.0 ** -30), "every other element round-trips"
+    pooled = torch.empty(N, CIN, H // 2, W // 2, device=g.dev())
+    g.call("uz_avgpool2_fwd_ex", xd, CIN, CIN, pooled, CIN, N, H, W, _slot(amax["x"] / big), _slot(0.0), 1)
+    assert _flags() & 1, "pooling into split storage: values beyond the forwarded bound must raise the flag"
+
+
 def test_unnormalised_unet_activations_after_real_training_steps():
     """the vanilla U-Net has no normalisation, so its activations are whatever training makes them.  Train the
     native model for 50 steps, then push the real post-ReLU activations of the first two levels (recomputed on the CPU from the

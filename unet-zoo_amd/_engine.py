@@ -101,10 +101,7 @@ class NativeModel(nn.Module):
         flags = self.check_bounds()
         if getattr(self, "_dp", None) is not None:
             from . import dp
-            agree = 0
-            for bit in (1, 2, 4):
-                agree |= bit if dp.max_int(1 if flags & bit else 0, self._dp.group) else 0
-            flags = agree
+            flags = dp.or_flags(flags, self._dp.group)          # ONE collective for the three bits
         if flags:
             import warnings
             warnings.warn(f"split-fp16 convolution path: magnitude bound exceeded (flags {flags:#x}: 1 activation, 2 weight, 4 gradient) - "

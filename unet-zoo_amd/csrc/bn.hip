@@ -46,6 +46,7 @@ struct BnP {
     float* chanf;                                      // backward, finalised: [C] m1 = mean(dz), [C] m2 = mean(dz x_hat)
     int yb, dab, outb;                                 // bf16 STORAGE of y / da / out (2-byte elements; the *_st kernels)
     int nba;                                           // *_st apply kernels: images per workgroup
+    int* flags;                                        // device flag word (uz_device_flags): raised when a value written as split storage exceeds its bound
 };
 
 // block-wide maxima of two floats (blockDim.x == 256); result valid in thread 0
@@ -223,14 +224,16 @@ __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
         const float s = uz::split_scale(uz::amax_read(p.amax));
         const float4* s4 = reinterpret_cast<const float4*>(src);
         uint4* d4 = reinterpret_cast<uint4*>(dst);
+        bool bad = false;
 #pragma unroll 4
         for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
             const float4 v = s4[i];
             uint4 o;
-            o.x = uz::pack_split(fmaxf(fmaf(v.x, alpha, beta_), floor_), s); o.y = uz::pack_split(fmaxf(fmaf(v.y, alpha, beta_), floor_), s);
-            o.z = uz::pack_split(fmaxf(fmaf(v.z, alpha, beta_), floor_), s); o.w = uz::pack_split(fmaxf(fmaf(v.w, alpha, beta_), floor_), s);
+            o.x = uz::pack_split(fmaxf(fmaf(v.x, alpha, beta_), floor_), s, bad); o.y = uz::pack_split(fmaxf(fmaf(v.y, alpha, beta_), floor_), s, bad);
+            o.z = uz::pack_split(fmaxf(fmaf(v.z, alpha, beta_), floor_), s, bad); o.w = uz::pack_split(fmaxf(fmaf(v.w, alpha, beta_), floor_), s, bad);
             d4[i] = o;
         }
+        uz::raise_flag(p.flags, bad, uz::FLAG_X_BOUND);
         return;
     }
     // (round 4, measured and dropped: non-temporal loads of y here - the step gained 0.5 %, inside the noise between boxes, and the
@@ -469,13 +472,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnP p) {
         if (PK) {
             const float s = uz::split_scale(uz::amax_read(p.amax));
             uint4* o4 = reinterpret_cast<uint4*>(p.out + ((size_t)b * p.CtotOut + c) * p.HW);
+            bool bad = false;
             for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
                 const float4 yv = y4[i], dv = d4[i];
                 uint4 o;
-                o.x = uz::pack_split(one(yv.x, dv.x), s); o.y = uz::pack_split(one(yv.y, dv.y), s);
-                o.z = uz::pack_split(one(yv.z, dv.z), s); o.w = uz::pack_split(one(yv.w, dv.w), s);
+                o.x = uz::pack_split(one(yv.x, dv.x), s, bad); o.y = uz::pack_split(one(yv.y, dv.y), s, bad);
+                o.z = uz::pack_split(one(yv.z, dv.z), s, bad); o.w = uz::pack_split(one(yv.w, dv.w), s, bad);
                 o4[i] = o;
             }
+            uz::raise_flag(p.flags, bad, uz::FLAG_DY_BOUND);
         } else if (VEC) {
             float4* o4 = reinterpret_cast<float4*>(p.out + ((size_t)b * p.CtotOut + c) * p.HW);
             for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
@@ -888,7 +893,9 @@ __global__ __launch_bounds__(1024) void bn_fused_mid_fwd(const BnP p) {
             float* dst = p.out + ((size_t)b * p.CtotOut + c) * p.HW + 4 * q;
             if (PK) {
                 uint4 o;
-                o.x = uz::pack_split(r.x, s); o.y = uz::pack_split(r.y, s); o.z = uz::pack_split(r.z, s); o.w = uz::pack_split(r.w, s);
+                bool bad = false;
+                o.x = uz::pack_split(r.x, s, bad); o.y = uz::pack_split(r.y, s, bad); o.z = uz::pack_split(r.z, s, bad); o.w = uz::pack_split(r.w, s, bad);
+                uz::raise_flag(p.flags, bad, uz::FLAG_X_BOUND);
                 *reinterpret_cast<uint4*>(dst) = o;
             } else {
                 *reinterpret_cast<float4*>(dst) = r;
@@ -1085,7 +1092,7 @@ static int bn_relu_fwd_impl(const float* y, int C, int CtotY, const float* gamma
     UZ_REQUIRE(training || (running_mean && running_var), "bn_relu_fwd: eval needs running statistics");
     UZ_REQUIRE(!training || (size_t)N * H * W > 1, "bn_relu_fwd: Expected more than 1 value per channel when training");
     hipStream_t st = uz::S(stream);
-    BnP p = {};
+    BnP p = {}; p.flags = uz::dev_flags_ptr();
     p.y = y; p.gamma = gamma; p.beta = beta; p.rmean = running_mean; p.rvar = running_var; p.save = save_mean_rstd;
     p.out = a; p.C = C; p.CtotY = CtotY; p.CtotOut = CtotA; p.N = N; p.HW = H * W;
     p.parts = uz::ceil_div(p.HW, CHUNK);
@@ -1189,7 +1196,7 @@ extern "C" int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, in
     UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_bwd: N or C exceeds grid limits");
     UZ_REQUIRE(save_mean_rstd, "bn_relu_bwd: needs the saved batch statistics");
     hipStream_t st = uz::S(stream);
-    BnP p = {};
+    BnP p = {}; p.flags = uz::dev_flags_ptr();
     p.y = y; p.da = da; p.gamma = gamma; p.beta = beta; p.save = const_cast<float*>(save_mean_rstd);
     p.out = dy; p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias;
     p.C = C; p.CtotY = CtotY; p.CtotDa = CtotDa; p.CtotOut = CtotDy; p.N = N; p.HW = H * W;
@@ -1269,7 +1276,7 @@ extern "C" int uz_bn_relu_fwd_b16(const void* y, int C, int CtotY, const float* 
     UZ_REQUIRE(training || (running_mean && running_var), "bn_relu_fwd_b16: eval needs running statistics");
     UZ_REQUIRE(!conv_partials || (training && n_partials > 0), "bn_relu_fwd_b16: convolution partials only serve training mode");
     hipStream_t st = uz::S(stream);
-    BnP p = {};
+    BnP p = {}; p.flags = uz::dev_flags_ptr();
     p.y = static_cast<const float*>(y); p.gamma = gamma; p.beta = beta; p.rmean = running_mean; p.rvar = running_var; p.save = save_mean_rstd;
     p.out = static_cast<float*>(a); p.C = C; p.CtotY = CtotY; p.CtotOut = CtotA; p.N = N; p.HW = H * W;
     p.parts = uz::ceil_div(p.HW, CHUNK);
@@ -1301,7 +1308,7 @@ extern "C" int uz_bn_relu_bwd_b16(const void* da, int CtotDa, const void* y, int
     UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_bwd_b16: N or C exceeds grid limits");
     UZ_REQUIRE(save_mean_rstd && workspace, "bn_relu_bwd_b16: needs the saved statistics and a workspace");
     hipStream_t st = uz::S(stream);
-    BnP p = {};
+    BnP p = {}; p.flags = uz::dev_flags_ptr();
     p.y = static_cast<const float*>(y); p.da = static_cast<const float*>(da); p.gamma = gamma; p.beta = beta; p.save = const_cast<float*>(save_mean_rstd);
     p.out = static_cast<float*>(dy); p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias;
     p.C = C; p.CtotY = CtotY; p.CtotDa = CtotDa; p.CtotOut = CtotDy; p.N = N; p.HW = H * W;

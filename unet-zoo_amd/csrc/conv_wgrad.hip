@@ -775,6 +775,11 @@ static int conv_bwd_weight_impl(const float* x, int Cin, int CinTot, const float
     const bool huge = (size_t)N * CinTot * H * W >= (1ull << 30) || (size_t)N * CoutTot * H * W >= (1ull << 30);
     UZ_REQUIRE(!(huge && g.fast), "conv_bwd_weight: a channel-slice view of a buffer of 2^30 elements or more is not supported by the tiled kernels");
     const bool split_math = !thin && !huge && uz::wgrad_split_ok(Cin, Cout, N, H, W, ks);
+    //  the slab-count query sees the VIEW's channels, this dispatch the buffer's: a channel slice of a >= 2^30-element
+    // buffer leaves the split path here but not there - a caller that sized slabs_out from the query must not be handed more slabs
+    UZ_REQUIRE(!slabs_out || (split_math ? uz::wgrad_split_splits(Cin, Cout, N, H, W) : Stot) == uz_conv_bwd_weight_slabs(Cin, Cout, N, H, W, ks),
+               "conv_bwd_weight_ex: slabs_out was sized for %d slabs (uz_conv_bwd_weight_slabs), this call writes another number (a channel-slice view of a huge buffer?)",
+               uz_conv_bwd_weight_slabs(Cin, Cout, N, H, W, ks));
     UZ_REQUIRE(!any_packed || split_math, "conv_bwd_weight_ex: split storage on a call that left the split-fp16 path");
     UZ_REQUIRE(!(x_b16 || dy_b16) || (split_math && !db), "conv_bwd_weight_b16: bf16 storage on a call that left the matrix-pipe path");
     if (split_math) {                              // large layers: split-fp16 matrix pipe (conv_wgrad_split.hip), same slab layout

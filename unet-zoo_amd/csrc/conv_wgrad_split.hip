@@ -172,13 +172,22 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
     };
     const float sdy = NP == 2 ? uz::split_scale(uz::amax_read(p.dy_amax)) : 1.f, sx = NP == 2 ? uz::split_scale(uz::amax_read(p.x_amax)) : 1.f;
     // XPK / DPK: X / dY arrive as split storage (split_f16.h): every word already holds the two fp16 pieces of its scaled value
+    // fp32 operands of the two-piece mode: every staged value is tested against the fp16 range, the predicates are accumulated over
+    // ALL tiles and raise the device flag word once behind the tile loop (round 5; until round 4 only the first tile was tested)
+    bool xbad = false, dbad = false;
     auto xpieces = [&](float v0, float v1, unsigned (&out)[NP]) __attribute__((always_inline)) {
         if constexpr (XPK) uz::packed_pair(__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), out[0], out[1]);
-        else pieces<NP>(v0 * sx, v1 * sx, out);
+        else {
+            if constexpr (NP == 2) xbad |= uz::bound_violated(v0 * sx, v1 * sx);
+            pieces<NP>(v0 * sx, v1 * sx, out);
+        }
     };
     auto dpieces = [&](float v0, float v1, unsigned (&out)[NP]) __attribute__((always_inline)) {
         if constexpr (DPK) uz::packed_pair(__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), out[0], out[1]);
-        else pieces<NP>(v0 * sdy, v1 * sdy, out);
+        else {
+            if constexpr (NP == 2) dbad |= uz::bound_violated(v0 * sdy, v1 * sdy);
+            pieces<NP>(v0 * sdy, v1 * sdy, out);
+        }
     };
     auto lstore = [&](int t) __attribute__((always_inline)) {
         const bool left_edge = t % p.tilesX == 0;               // tile column 0: the quads with q == 0 were loaded one column to the right
@@ -246,19 +255,6 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
         long long st0 = 0, st1 = 0, stl = 0, rt0 = 0;
         if (p.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
         if (t < p.T) gload(t, -1);
-        if (NP == 2 && p.flags && t < p.T) {            // bound check on the first tile (the clamp in split2 covers every tile)
-            bool bx = false, bd = false;
-            if (!DPK) {
-#pragma unroll
-                for (int i = 0; i < DYSLOTS; ++i) { bd |= uz::bound_violated(dreg[i][0] * sdy, dreg[i][1] * sdy); bd |= uz::bound_violated(dreg[i][2] * sdy, dreg[i][3] * sdy); }
-            }
-            if (!XPK) {
-#pragma unroll
-                for (int i = 0; i < XQSLOTS; ++i) { bx |= uz::bound_violated(xq[i][0] * sx, xq[i][1] * sx); bx |= uz::bound_violated(xq[i][2] * sx, xq[i][3] * sx); }
-            }
-            if (bd) atomicOr(p.flags, uz::FLAG_DY_BOUND);
-            if (bx) atomicOr(p.flags, uz::FLAG_X_BOUND);
-        }
         for (; t < p.T; t += p.S) {
             long long ta = 0;
             if (p.stamps) ta = __builtin_amdgcn_s_memtime();
@@ -310,6 +306,7 @@ __global__ __launch_bounds__(NT) void wgrad_split_kernel(const WS p) {
                 }
             }
         }
+        if (NP == 2) { uz::raise_flag(p.flags, xbad, uz::FLAG_X_BOUND); uz::raise_flag(p.flags, dbad, uz::FLAG_DY_BOUND); }
         long long st2 = 0;
         if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
         if constexpr (WK > 1) {

@@ -489,9 +489,11 @@ __global__ __launch_bounds__(256) void copy_k(float* __restrict__ d, const float
 }
 // ---- split storage <-> fp32 (include/uz_api.h, round 4; tests and tools - the model plans never convert whole tensors)
 namespace {
-__global__ __launch_bounds__(256) void pack_split_k(const float* __restrict__ x, unsigned* __restrict__ out, size_t n, const float* __restrict__ amax) {
+__global__ __launch_bounds__(256) void pack_split_k(const float* __restrict__ x, unsigned* __restrict__ out, size_t n, const float* __restrict__ amax, int* flags) {
     const float s = uz::split_scale(uz::amax_read(amax));
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = uz::pack_split(x[i], s);
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = uz::pack_split(x[i], s, bad);
+    uz::raise_flag(flags, bad, uz::FLAG_X_BOUND);
 }
 __global__ __launch_bounds__(256) void unpack_split_k(const unsigned* __restrict__ in, float* __restrict__ x, size_t n, const float* __restrict__ amax) {
     const float inv = uz::split_inv_scale(uz::amax_read(amax));
@@ -502,7 +504,7 @@ inline int stream_grid(size_t n) { size_t g = (n + 256 * 8 - 1) / (256 * 8); ret
 extern "C" int uz_pack_split(const float* x, float* packed, size_t n, const float* amax, void* stream) {
     UZ_REQUIRE(x && packed && amax, "pack_split: null argument");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(pack_split_k, dim3(stream_grid(n)), dim3(256), 0, uz::S(stream), x, reinterpret_cast<unsigned*>(packed), n, amax);
+    hipLaunchKernelGGL(pack_split_k, dim3(stream_grid(n)), dim3(256), 0, uz::S(stream), x, reinterpret_cast<unsigned*>(packed), n, amax, uz::dev_flags_ptr());
     return uz::check_launch("pack_split_k");
 }
 extern "C" int uz_unpack_split(const float* packed, float* x, size_t n, const float* amax, void* stream) {

@@ -22,6 +22,7 @@ struct RsP {
     // backward kernels, optional: dst is the gradient w.r.t. the OUTPUT A of a Conv -> ReLU unit (vanilla U-Net blocks) and this launch
     // is its last writer - apply the unit's ReLU mask (a > 0), leave per-workgroup sums for its bias gradient, publish max |dst|
     const float* mask; int CtotM; double* part; float* m_amax;
+    int* flags;                           // device flag word (uz_device_flags), raised by out_word
     int hb16;                             // bilinear band kernels: the HIGH-resolution tensor (forward: dst, backward: src) holds 2-byte bf16 elements
 };
 struct ReluFold { float sd = 0.f, vmax = 0.f; };
@@ -40,8 +41,14 @@ __device__ __forceinline__ void fold_finish(const RsP& p, int c, int b, const Re
 }
 
 // output value as stored: the fp32 value, or (split storage) the word holding its two fp16 pieces
+// (a value beyond the bound the scale was derived from - pooling and interpolation forward their INPUT's bound, so only a wrong
+//  bound handed in through the C ABI can do that - is clamped and raises the device flag word)
 __device__ __forceinline__ float out_word(const RsP& p, float v, float s) {
-    return p.pack ? __builtin_bit_cast(float, uz::pack_split(v, s)) : v;
+    if (!p.pack) return v;
+    bool bad = false;
+    const unsigned w = uz::pack_split(v, s, bad);
+    uz::raise_flag(p.flags, bad, uz::FLAG_X_BOUND);
+    return __builtin_bit_cast(float, w);
 }
 __device__ __forceinline__ float pack_scale(const RsP& p) { return p.pack ? uz::split_scale(uz::amax_read(p.x_amax)) : 1.f; }
 // the output bound of a pooling / interpolation pass is its input's bound (one lane of the grid forwards it)
@@ -494,7 +501,7 @@ extern "C" int uz_avgpool2_fwd_ex(const float* x, int C, int CtotX, float* y, in
                                   const float* x_amax, float* y_amax, int out_packed, void* stream) {
     if (int rc = check_dims("avgpool2_fwd", C, N, H, W)) return rc;
     UZ_REQUIRE(!out_packed || (x_amax && y_amax), "avgpool2_fwd_ex: split storage needs the input's bound and the output's slot");
-    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N; p.x_amax = x_amax; p.y_amax = y_amax; p.pack = out_packed;
+    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N; p.x_amax = x_amax; p.y_amax = y_amax; p.pack = out_packed; p.flags = uz::dev_flags_ptr();
     p.Ho = H; p.Wo = W; p.H = (H + 1) / 2; p.W = (W + 1) / 2;
     if (H % 2 == 0 && W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0) {
         // (the grid's x extent stays ceil(H W / 4 / PCH) workgroups per plane: PCH / 2 float2 outputs each)
@@ -544,7 +551,7 @@ extern "C" int uz_bilinear2x_fwd_ex(const float* x, int C, int CtotX, float* y, 
                                     const float* x_amax, float* y_amax, int out_packed, void* stream) {
     if (int rc = check_dims("bilinear2x_fwd", C, N, H, W)) return rc;
     UZ_REQUIRE(!out_packed || (x_amax && y_amax), "bilinear2x_fwd_ex: split storage needs the input's bound and the output's slot");
-    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N; p.x_amax = x_amax; p.y_amax = y_amax; p.pack = out_packed;
+    RsP p = {}; p.src = x; p.dst = y; p.C = C; p.CtotS = CtotX; p.CtotD = CtotY; p.N = N; p.x_amax = x_amax; p.y_amax = y_amax; p.pack = out_packed; p.flags = uz::dev_flags_ptr();
     p.H = H; p.W = W; p.Ho = 2 * H; p.Wo = 2 * W; p.ac = align_corners; bil_scales(p);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (W % 4 == 0 && W <= FWMAX && H >= 4 && al16(x) && al16(y)) {     // W % 4 == 0 keeps every (image, channel) plane of both sides float4-aligned

@@ -5,8 +5,9 @@
 // overflow; every element above 2^-17 * amax keeps both pieces in the normal fp16 range, smaller ones are off by at
 // most 2^-39 * amax in absolute terms).  A product a*b is accumulated in fp32 from THREE piece products
 //   a2*b1, a1*b2, a1*b1          (11-bit x 11-bit significands: exact in fp32)
-// the dropped a2*b2 is <= 2^-22 |ab|.  Fewer, larger partial sums than a k-ordered fp32 fmaf chain: measured against fp64
-// the result is as accurate as the fp32-MFMA kernels (tests/test_full_configs_gpu.py, tools/sim_split_accuracy.py).
+// the dropped a2*b2 is <= 2^-22 |ab|.  A 22-bit emulation with fewer, larger partial sums than a k-ordered fp32 fmaf chain:
+// measured against fp64, per layer 0.5 - 0.8x the error of the fp32-MFMA kernels (gate <= 2x: tests/test_full_configs_gpu.py,
+// tools/sim_split_accuracy.py); end to end the gradients' median error is 1.6x the fp32 reference's own (tests/test_phiseg_gpu.py).
 // Three fp16 MFMAs per 16-deep k-step cost 96 cycles against 512 for the eight fp32 MFMAs they replace.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -62,12 +63,19 @@ __device__ __forceinline__ void split2(float v0, float v1, unsigned& p1, unsigne
 // (low half = h1, high half = h2, s = split_scale(bound)) instead of the fp32 value.  Same bytes; the consuming matrix kernels
 // stage the word as it is (two byte permutes per pair of elements instead of scale / clamp / convert / subtract / convert), and
 // h1 + h2 reproduces v * s to 2^-22 - exactly the operand the consumer would have formed from the fp32 value itself.
+// (round 5: the scaled value is clamped to the finite fp16 range like split2's - a bound more than 4x too small must not put an
+//  infinity into a stored operand - and the three-argument form tells the caller, who raises the device flag word once per thread)
 __device__ __forceinline__ unsigned pack_split(float v, float s) {
-    const float t = v * s;
+    const float t = __builtin_amdgcn_fmed3f(v * s, -F16_MAX, F16_MAX);
     const _Float16 h1 = (_Float16)t;                                        // round to nearest even
     const _Float16 h2 = (_Float16)(t - (float)h1);                          // the subtraction is exact
     return (unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
 }
+__device__ __forceinline__ unsigned pack_split(float v, float s, bool& bad) {
+    bad |= fabsf(v * s) > F16_MAX;
+    return pack_split(v, s);
+}
+__device__ __forceinline__ void raise_flag(int* flags, bool bad, int bit) { if (bad && flags) atomicOr(flags, bit); }
 __device__ __forceinline__ float unpack_split(unsigned w, float inv_s) {
     const _Float16 h1 = __builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)), h2 = __builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
     return ((float)h1 + (float)h2) * inv_s;

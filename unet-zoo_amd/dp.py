@@ -61,6 +61,18 @@ def max_int(v, group=None):
     return int(t.item())
 
 
+def or_flags(word, group=None, bits=3):
+    """Bitwise OR of a small host flag word over the ranks in ONE collective (identity for a single process): the bits travel as a
+    vector of 0 / 1 and are combined with MAX (every backend has it; BOR is not available on all of them)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return int(word)
+    t = torch.tensor([(int(word) >> b) & 1 for b in range(bits)], dtype=torch.int64)
+    if dist.get_backend(group) != "gloo":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return sum(int(v) << b for b, v in enumerate(t.tolist()))
+
+
 def shard_bounds(n, rank, world):
     """Contiguous [lo, hi) slice of n samples owned by `rank` (sizes differ by at most one)."""
     base, rem = divmod(n, world)
