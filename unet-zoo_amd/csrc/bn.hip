@@ -261,7 +261,10 @@ __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
 
 // ------------------------------------------------------------------ forward, small path (one WG / channel)
 constexpr int EPT = SMALL_LIMIT / 256;      // elements per thread on the small path: a channel's whole batch lives in registers
-__global__ __launch_bounds__(256) void bn_fused_small_fwd(const BnP p) {
+#ifndef UZ_BN_SMALL_OCC
+#define UZ_BN_SMALL_OCC 0       // experiment builds: minimum waves per SIMD of the one-workgroup-per-channel kernels (4 -> at most 128 VGPRs)
+#endif
+__global__ __launch_bounds__(256, UZ_BN_SMALL_OCC ? UZ_BN_SMALL_OCC : 1) void bn_fused_small_fwd(const BnP p) {
     __shared__ double sm[8];
     __shared__ float bc[2];
     const int c = blockIdx.x;
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_st(const BnP p) {
 }
 
 // ------------------------------------------------------------------ backward, small path
-__global__ __launch_bounds__(256) void bn_fused_small_bwd(const BnP p) {
+__global__ __launch_bounds__(256, UZ_BN_SMALL_OCC ? UZ_BN_SMALL_OCC : 1) void bn_fused_small_bwd(const BnP p) {
     __shared__ double sm[8];
     __shared__ float bc[2];
     const int c = blockIdx.x;

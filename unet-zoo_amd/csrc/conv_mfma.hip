@@ -41,7 +41,10 @@ struct ConvP {
 };
 
 template <int KS, int MSUB, int JMAX, bool DGRAD>
-__global__ __launch_bounds__(256, JMAX == 2 ? 2 : 1) void conv_mfma_kernel(const ConvP p) {
+#ifndef UZ_SMALL_OCC
+#define UZ_SMALL_OCC 0          // experiment builds: minimum waves per SIMD of the small-plane kernels (caps their VGPRs: 4 -> 128, 5 -> 96)
+#endif
+__global__ __launch_bounds__(256, UZ_SMALL_OCC ? UZ_SMALL_OCC : (JMAX == 2 ? 2 : 1)) void conv_mfma_kernel(const ConvP p) {
     constexpr int KK = KS * KS, HALO = KS / 2;
     // (round 4, measured and dropped: LDS images as [k half][row][4 k] so that one ds_read_b128 per operand feeds four MFMA steps -
     //  a quarter of the LDS instructions - ran 224 -> 128 @ 128 x 128 at 2.42 ms against 2.16 ms and the step at 879 against 893

@@ -86,6 +86,7 @@ struct SP {
     int* flags; int flag_bit;                     // device flag word (bound violations), nullable; the bit this launch raises: activation (forward) or gradient (data gradient)
     float* bnpart;                                // nullable: per-(pixel tile, row half, channel) {sum, sum of squares, max, max of negated} of y
     int yb16;                                     // y (and what it accumulates onto) is stored as bf16 (single-piece mode, kSplit == 1)
+    int n_tiles;                                  // workgroup-sized tiles of the launch (== gridDim.x unless the launch is persistent)
 };
 
 
@@ -149,7 +150,7 @@ constexpr int lds_bytes() {
 // no VALU and no ds_write touches it), the patch values are loaded early in the chunk and written to the other image behind its last
 // tap.  One barrier per chunk instead of two, and no phase in which every wave stages while the matrix pipe idles.
 template <int MSUB, int NTv, int TWv, int NP, int MK = 0, int XF = 0, int DB = 0>
-__device__ __forceinline__ void conv_split_body(const SP& p) {
+__device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, const int n_tiles) {
     constexpr bool XPK = XF == 1, XB = XF == 2;
     constexpr unsigned ESZ = XB ? 2u : 4u;               // bytes per input element
     static_assert(!XPK || NP == 2, "split storage is the two-piece fp16 format");
@@ -184,7 +185,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wid0 = uz::xcd_remap(blockIdx.x, gridDim.x);
+    const int wid0 = uz::xcd_remap(tile_id, n_tiles);
     const int part = wid0 % p.kSplit, wid = wid0 / p.kSplit;     // the parts of one tile are neighbours: they share the patch in L2
     const int cbeg = part * p.cps, cend = min(p.nChunks, cbeg + p.cps);
     const int coT = wid % p.nCoTiles, pixT = wid / p.nCoTiles;
@@ -662,7 +663,14 @@ __device__ __forceinline__ void conv_split_body(const SP& p) {
 // reduction} x input {fp32, split storage}.
 template <int MSUB, int NTv, int TWv, int NP, int MK, int XF, int DB = 0> struct SplitKernel;
 #define UZ_SPLIT_KERNEL_(name, MSUB_, NT_, TW_, NP_, MK_, XF_, OCC_, DB_)                                                     \
-    __global__ __launch_bounds__(NT_, OCC_) void name(const SP p) { conv_split_body<MSUB_, NT_, TW_, NP_, MK_, XF_, DB_>(p); } \
+    __global__ __launch_bounds__(NT_, OCC_) void name(const SP p) {                                                           \
+        /* persistent form (UZ_CONV_PERSIST): fewer workgroups than tiles, each walks its tiles - the CUs the grid does not    */ \
+        /* reach stay free for the latency-bound launches of the other lanes ("co-residency")             */ \
+        for (int t = blockIdx.x; t < p.n_tiles; t += gridDim.x) {                                                             \
+            conv_split_body<MSUB_, NT_, TW_, NP_, MK_, XF_, DB_>(p, t, p.n_tiles);                                            \
+            if (t + (int)gridDim.x < p.n_tiles) __syncthreads();      /* the next tile's staging overwrites the epilogue's LDS */ \
+        }                                                                                                                     \
+    }                                                                                                                         \
     template <> struct SplitKernel<MSUB_, NT_, TW_, NP_, MK_, XF_, DB_> { static constexpr auto fn = name; };
 #define UZ_SPLIT_KERNEL(name, MSUB_, NT_, TW_, NP_, MK_, XF_, OCC_) UZ_SPLIT_KERNEL_(name, MSUB_, NT_, TW_, NP_, MK_, XF_, OCC_, 0)
 // (round 4: the 32-channel-tile kernels keep (512, 4) although that bound costs them ~30 spilled registers - with (512, 3), no spills
@@ -719,7 +727,14 @@ int launch_db(const SP& p, int grid, hipStream_t st) {
             return uz::fail("conv_split: cannot raise dynamic LDS limit");
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTv), smem, st, p);
+    SP q = p;
+    q.n_tiles = grid;
+    int g = grid;
+    if constexpr (MSUB == 2 && NTv == 512) {       // one workgroup per CU: UZ_CONV_PERSIST = number of workgroups (a multiple of 8, < 256) that walk the tiles
+        static const int persist = getenv("UZ_CONV_PERSIST") ? atoi(getenv("UZ_CONV_PERSIST")) : 0;
+        if (persist > 0 && grid > persist && !p.stamps) g = persist;
+    }
+    hipLaunchKernelGGL(kern, dim3(g), dim3(NTv), smem, st, q);
     return uz::check_launch("conv_split_kernel");
 }
 template <int MSUB, int NTv, int TWv, int NP, int MK, int XF>
