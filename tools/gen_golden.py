@@ -562,6 +562,77 @@ def phiseg3d_case(name, in_ch, num_classes, filters, latent_levels, dhw, seed):
                             no_grad=[n_ for n_, g in grads_of(net).items() if g is None]))
 
 
+def phiseg3d_digest_case(name, in_ch, num_classes, filters, latent_levels, dhw, seed, vol_seed, n_samp=2048, backward=True):
+    """BASELINE config 5 at its LITERAL size (4 x 128 x 128 x 64, filters 32 / 64 / 128 / 192 / 192) through the reference's own
+    modules in fp32 on the CPU: digests only - losses, sampled level logits / s_in / posterior and prior moments,
+    gradient norms and sampled gradient entries.  Inputs and weights are regenerated by the test from the same seeds
+    (oracle.deterministic_state_dict(seed), oracle.refgraph3d.synthetic_volume(vol_seed)).  Same call protocol as phiseg3d_case."""
+    from models.phiseg3D import PHISeg3D as Ref3D
+    import torch.nn.functional as TF
+    from oracle.refgraph3d import phiseg3d_eps_shapes, synthetic_volume
+    D, H, W = dhw
+    net = Ref3D(input_channels=in_ch, num_classes=num_classes, num_filters=filters, latent_levels=latent_levels,
+                image_size=(in_ch, D, H, W))
+    spec = kinds_for(net.state_dict())
+    net.load_state_dict(deterministic_state_dict(spec, seed=seed))
+    net.train()
+    R, L = len(filters), latent_levels
+    shapes = phiseg3d_eps_shapes(D, H, W, R, L)
+    x, onehot, lab, eps = synthetic_volume(in_ch, num_classes, dhw, vol_seed, shapes + shapes)
+    xt, ot, lt = torch.from_numpy(x), torch.from_numpy(onehot), torch.from_numpy(lab)
+    s_in = {}
+    hooks = [blk.register_forward_hook(lambda m, i, o, k=k: s_in.__setitem__(k, o)) for k, blk in enumerate(net.likelihood.s_layer)]
+    orig = TF.interpolate
+
+    def resize(inp, size=None, *a, **kw):
+        if size is not None and inp.dim() == 5 and len(size) == 2:
+            return orig(inp, size=[D, H, W], mode="nearest")
+        return orig(inp, size, *a, **kw)
+    ctx = torch.enable_grad() if backward else torch.no_grad()
+    with ctx:
+        with NoiseFeeder([torch.from_numpy(e) for e in eps]):
+            pz, pmu, psig = net.posterior(xt, ot)
+            qz, qmu, qsig = net.prior(xt, training_prior=True, z_list=pz)
+        TF.interpolate = resize
+        try:
+            s = net.likelihood(pz)
+        finally:
+            TF.interpolate = orig
+        for h in hooks:
+            h.remove()
+        net.posterior_latent_space, net.posterior_mu, net.posterior_sigma = pz, pmu, psig
+        net.prior_latent_space, net.prior_mu, net.prior_sigma = qz, qmu, qsig
+        net.s_out_list = s
+        loss = net.loss(lt)
+        if backward:
+            loss.backward()
+    rs = np.random.default_rng(seed + 7)
+    arrays = {}
+
+    def sample(key, t):
+        flat = t.detach().reshape(-1)
+        pick = np.arange(flat.numel()) if flat.numel() <= n_samp else np.sort(rs.choice(flat.numel(), size=n_samp, replace=False))
+        arrays["i:" + key] = pick.astype(np.int64)
+        arrays["v:" + key] = flat.numpy()[pick].astype(np.float32)
+        arrays["m:" + key] = np.array([float(flat.abs().max()), float(flat.double().norm()), float(flat.double().mean())])
+    for l in range(L):
+        sample(f"s{l}", s[l]); sample(f"s_in{l}", s_in[L - 1 - l])
+        sample(f"post_mu{l}", pmu[l]); sample(f"post_sigma{l}", psig[l]); sample(f"prior_mu{l}", qmu[l]); sample(f"prior_sigma{l}", qsig[l])
+    for k, v in net.loss_dict.items():
+        arrays["loss:" + k] = np.float32(float(v))
+    arrays["loss"] = np.float32(float(loss))
+    no_grad = []
+    if backward:
+        for n_, p_ in net.named_parameters():
+            if p_.grad is None:
+                no_grad.append(n_)
+            else:
+                sample("g:" + n_, p_.grad)
+    save(name, arrays, dict(model="PHISeg3D", input_channels=in_ch, num_classes=num_classes, filters=filters, latent_levels=L,
+                            dhw=list(dhw), weight_seed=seed, volume_seed=vol_seed, backward=bool(backward), no_grad=no_grad,
+                            spec=[[k, list(s_), kd] for k, s_, kd in spec]))
+
+
 def phiseg3d_bf16_case(name, in_ch, num_classes, filters, latent_levels, dhw, seed):
     """The reference's 3-D modules run IN BF16 the way PyTorch runs a model in bf16 with fp32 master weights:
     torch.autocast('cpu', dtype=torch.bfloat16) around Posterior / prior / Likelihood of a real PHISeg3D instance (Conv3d in bf16
@@ -726,6 +797,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "3d":
         phiseg3d_case("phiseg3d_small", 2, 3, [4, 8, 8], 2, (16, 16, 8), 1242)       # lvl_diff 1
         phiseg3d_case("phiseg3d_l3", 4, 3, [8, 8, 16], 3, (8, 16, 16), 1243)         # one latent level per resolution level
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "3d_full":
+        # BASELINE config 5 at its literal size: digests of the reference's fp32 CPU run (minutes, ~40 GB of host memory with the backward)
+        phiseg3d_digest_case("phiseg3d_full_digest", 4, 3, [32, 64, 128, 192, 192], 5, (128, 128, 64), 11, 9, backward=(len(sys.argv) < 3 or sys.argv[2] != "fwd"))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "3d_bf16":
         # large enough for the library to route its convolutions to the matrix-pipe kernels (32+ channels on 64-wide planes)
