@@ -600,6 +600,80 @@ def test_baseline_config5_full_volume_in_bf16_mode():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["split", "bf16_storage"])
+def test_baseline_config5_full_volume_vs_the_reference_digest(mode, monkeypatch):
+    """BASELINE.json configs[4] at its LITERAL size (4 x 128 x 128 x 64, filters 32 / 64 / 128 / 192 / 192) against the REAL reference
+    (VERDICT r4 P4): tests/golden/phiseg3d_full_digest holds what the reference's own Posterior / prior / Likelihood modules and loss
+    compute in fp32 on the CPU for the weights and the volume this test regenerates from the same seeds (tools/gen_golden.py 3d_full:
+    losses, 2 048 sampled entries + max / norm / mean of every level's logits, s_in, mu, sigma, and of every parameter gradient).
+    `split` = the fp32-accurate arithmetic: the north-star gate (1e-4 of the tensor's magnitude on every sampled activation, loss to
+    5e-5, gradients to 1e-2 of their largest entry like the 2-D headline test).  `bf16_storage` = the configuration as BASELINE words
+    it (bf16 arithmetic AND storage): what bf16 can hold - sampled activations within 8 % of the tensor's magnitude (measured 5 %), loss within
+    2e-3, gradient norms within 25 % (measured 13 %: a BatchNorm scale of the first block), their median within 3 %."""
+    from unet_zoo_amd import _ffi
+    from unet_zoo_amd.models.phiseg3D import PHISeg3D
+    L_ = _ffi.lib()
+    if L_.uz_get_conv_math() == 0 and mode != "split":
+        pytest.skip("fp32-only run")
+    arrays, meta = G.load("phiseg3d_full_digest")
+    dev = torch.device("cuda", 0)
+    filters, K, Cin, dhw, L = meta["filters"], meta["num_classes"], meta["input_channels"], tuple(meta["dhw"]), meta["latent_levels"]
+    sd0 = oracle.deterministic_state_dict(G.spec_of(meta), seed=meta["weight_seed"])
+    shapes = R3.phiseg3d_eps_shapes(*dhw, len(filters), L)
+    x, onehot, lab, eps = R3.synthetic_volume(Cin, K, dhw, meta["volume_seed"], shapes + shapes)
+    try:
+        if mode == "bf16_storage":
+            L_.uz_set_conv_math(3)
+            monkeypatch.setenv("UZ_STORE_B16", "1")
+        net = PHISeg3D(Cin, K, filters, latent_levels=L, image_size=(Cin, *dhw))
+        net.load_state_dict(sd0)
+        net.train()
+        s = net.forward(torch.from_numpy(x).to(dev), torch.from_numpy(onehot).to(dev), training=True, eps=[torch.from_numpy(e).to(dev) for e in eps])
+        loss = net.loss(torch.from_numpy(lab).to(dev))
+        ref_loss = float(arrays["loss"])
+        exact = mode == "split"
+        assert abs(float(loss) - ref_loss) <= (5e-5 if exact else 2e-3) * abs(ref_loss), (float(loss), ref_loss)
+        worst = 0.0
+        for l in range(L):
+            for got_t, key in ((s[l], f"s{l}"), (net.s_in_list[l], f"s_in{l}"), (net.posterior_mu[l], f"post_mu{l}"), (net.posterior_sigma[l], f"post_sigma{l}"),
+                               (net.prior_mu[l], f"prior_mu{l}"), (net.prior_sigma[l], f"prior_sigma{l}")):
+                idx, ref, mom = arrays["i:" + key], arrays["v:" + key], arrays["m:" + key]
+                got = got_t.float().reshape(-1)[torch.from_numpy(idx).to(dev)].cpu().numpy()
+                scale = max(1.0, float(mom[0]))                 # the tensor's largest magnitude in the reference run
+                err = float(np.abs(got - ref).max()) / scale
+                worst = max(worst, err)
+                assert err <= (1e-4 if exact else 8e-2), (key, err)        # (bf16: measured worst 5.0e-2 - the deepest level's prior mean)
+        loss.backward()
+        noise = G.bn_shadowed_biases([k for k, _, _ in meta["spec"]])
+        n, worst_g, wk, devs = 0, 0.0, None, []
+        for k, p_ in net.named_parameters():
+            if ("v:g:" + k) not in arrays:
+                assert p_.grad is None or k in meta["no_grad"] or float(p_.grad.abs().max()) == 0.0, k
+                continue
+            if k in noise:
+                continue
+            idx, ref, mom = arrays["i:g:" + k], arrays["v:g:" + k], arrays["m:g:" + k]
+            g_ = p_.grad.float()
+            got = g_.reshape(-1)[torch.from_numpy(idx).to(dev)].cpu().numpy()
+            if exact:
+                err = float(np.abs(got - ref).max()) / (float(mom[0]) + 1e-30)
+            else:
+                err = abs(float(g_.double().norm()) - float(mom[1])) / (float(mom[1]) + 1e-30)
+            n += 1
+            devs.append(err)
+            if err > worst_g:
+                worst_g, wk = err, k
+        med = sorted(devs)[len(devs) // 2]
+        print(f"config 5 at full size, {mode}: loss rel {abs(float(loss) - ref_loss) / abs(ref_loss):.1e}, worst activation sample {worst:.1e}, "
+              f"worst gradient {'sample' if exact else 'norm'} deviation {worst_g:.1e} at {wk} (median {med:.1e}) over {n} tensors")
+        # (bf16: per-tensor gradient NORMS against the fp32 reference - BatchNorm scale gradients are sums with heavy cancellation and
+        #  move by up to 13 % in bf16 arithmetic, the median tensor by under 1 %)
+        assert n > 100 and worst_g <= (1e-2 if exact else 2.5e-1) and med <= (2e-3 if exact else 3e-2), (worst_g, wk, med)
+    finally:
+        L_.uz_set_conv_math(-1)
+
+
+@pytest.mark.gpu
 def test_baseline_config5_full_volume_in_bf16_storage(monkeypatch):
     """BASELINE.json configs[4] LITERALLY - bf16 arithmetic AND bf16 storage, 4 x 128 x 128 x 64: with UZ_STORE_B16=1
     the plan keeps the volume's large tensors (activations, their gradients, every unit's dy on the 128 x 64 and 64 x 32 planes) as
