@@ -419,7 +419,8 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
     for (int tap = 0; tap < KK; ++tap) stage(cbeg, tap);
     // A 64-channel tile whose upper 32 channels lie beyond Cout (Cout = 224 = 3 x 64 + 32: the data gradient of the heaviest
     // layer) skips that half's MFMAs, fragment reads and epilogue pass: 12.5 % of that launch's matrix work were zeros.
-    const bool half_tile = MSUB == 2 && p.Cout - co0 <= 32;
+    const int mact = min(MSUB, (p.Cout - co0 + 31) / 32);           // 32-channel sub-tiles of this tile that hold real output channels
+    const bool half_tile = mact < MSUB;
     constexpr int MS = MSUB;
     if (DEEP && cbeg + 1 < cend) {
 #pragma unroll
@@ -479,7 +480,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
             // smallest products first
 #pragma unroll
             for (int m = 0; m < MS; ++m) {
-                if (m == 1 && half_tile) continue;           // workgroup-uniform: a scalar branch around six MFMAs
+                if (half_tile && m >= mact) continue;        // workgroup-uniform: a scalar branch around six MFMAs
 #pragma unroll
                 for (int n = 0; n < NSUB; ++n) acc[m][n] = mma<NP>(acc[m][n], a[cur][m], b[cur][n]);
             }
@@ -495,6 +496,9 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
                 }
                 __builtin_amdgcn_sched_barrier(0);           // ... and the next tap's work stays behind this tap's MFMAs
             }
+            // (128-channel tile: 128 accumulator registers - keep the scheduler from hoisting the next tap's six fragment reads above
+            //  this tap's eight MFMAs, which cost 15 spilled registers inside the loop)
+            if constexpr (MSUB == 4) __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (DB) {
             // hand-over: the patch of chunk c + 1 goes into the other image (nobody reads it: every wave passed the previous
@@ -536,7 +540,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
     float vmax = 0.f;
 #pragma unroll
     for (int m = 0; m < MSUB; ++m) {
-        if (m == 1 && half_tile) break;                  // workgroup-uniform
+        if (half_tile && m >= mact) break;               // workgroup-uniform
 #pragma unroll
         for (int g0 = 0; g0 < 4; g0 += GP) {
             // What the rows of this pass read from memory - the tensor they accumulate onto, the producing unit's activation (MK) -
@@ -677,28 +681,36 @@ template <int MSUB, int NTv, int TWv, int NP, int MK, int XF, int DB = 0> struct
 //  but one workgroup per CU, 32 -> 32 @ 128 x 128 ran 55 -> 61 us forward and the PHiSeg step lost 0.8 %)
 // (round 4, single-product mode: (512, 4) = two workgroups per CU on the 64-channel-tile bf16 kernels needs 128 VGPRs - 168 in use, 76 - 80
 //  spilled into the chunk loop: 288 -> 96 @ 128 x (128 x 64) 1 030 -> 2 253 us, PHiSeg3D 34.9 -> 43.6 ms.  One workgroup per CU it stays.)
+// UZ_OCC16 / UZ_OCC16P: minimum workgroups per SIMD of the 16 x 16-pixel instances (fp32 / split-storage input); experiment builds raise
+// them to 4 (at most 128 VGPRs: such a workgroup fits beside a 64-channel-tile convolution's two waves per SIMD, profiles/NOTES_r5.md section 4)
+#ifndef UZ_OCC16
+#define UZ_OCC16 2
+#endif
+#ifndef UZ_OCC16P
+#define UZ_OCC16P 3
+#endif
 UZ_SPLIT_KERNEL(conv_split_kernel_2_512_32, 2, 512, 32, 2, 0, 0, 1)
 UZ_SPLIT_KERNEL(conv_split_kernel_1_512_32, 1, 512, 32, 2, 0, 0, 4)
-UZ_SPLIT_KERNEL(conv_split_kernel_1_256_16, 1, 256, 16, 2, 0, 0, 2)
+UZ_SPLIT_KERNEL(conv_split_kernel_1_256_16, 1, 256, 16, 2, 0, 0, UZ_OCC16)
 UZ_SPLIT_KERNEL(conv_bf16_kernel_2_512_32, 2, 512, 32, 1, 0, 0, 1)
 UZ_SPLIT_KERNEL(conv_bf16_kernel_1_512_32, 1, 512, 32, 1, 0, 0, 4)
 UZ_SPLIT_KERNEL(conv_bf16_kernel_1_256_16, 1, 256, 16, 1, 0, 0, 3)
 UZ_SPLIT_KERNEL(conv_split_relu_kernel_2_512_32, 2, 512, 32, 2, 1, 0, 1)
 UZ_SPLIT_KERNEL(conv_split_relu_kernel_1_512_32, 1, 512, 32, 2, 1, 0, 4)
-UZ_SPLIT_KERNEL(conv_split_relu_kernel_1_256_16, 1, 256, 16, 2, 1, 0, 2)
+UZ_SPLIT_KERNEL(conv_split_relu_kernel_1_256_16, 1, 256, 16, 2, 1, 0, UZ_OCC16)
 UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_2_512_32, 2, 512, 32, 1, 1, 0, 1)
 UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_1_512_32, 1, 512, 32, 1, 1, 0, 4)
 UZ_SPLIT_KERNEL(conv_bf16_relu_kernel_1_256_16, 1, 256, 16, 1, 1, 0, 3)
 // round 4: input in split storage (conv_splitp_*), BatchNorm-backward reduction in the data gradient's epilogue (*_bn_*)
 UZ_SPLIT_KERNEL(conv_splitp_kernel_2_512_32, 2, 512, 32, 2, 0, 1, 1)
 UZ_SPLIT_KERNEL(conv_splitp_kernel_1_512_32, 1, 512, 32, 2, 0, 1, 4)
-UZ_SPLIT_KERNEL(conv_splitp_kernel_1_256_16, 1, 256, 16, 2, 0, 1, 3)
+UZ_SPLIT_KERNEL(conv_splitp_kernel_1_256_16, 1, 256, 16, 2, 0, 1, UZ_OCC16P)
 UZ_SPLIT_KERNEL(conv_split_bn_kernel_2_512_32, 2, 512, 32, 2, 2, 0, 1)
 UZ_SPLIT_KERNEL(conv_split_bn_kernel_1_512_32, 1, 512, 32, 2, 2, 0, 4)
-UZ_SPLIT_KERNEL(conv_split_bn_kernel_1_256_16, 1, 256, 16, 2, 2, 0, 2)
+UZ_SPLIT_KERNEL(conv_split_bn_kernel_1_256_16, 1, 256, 16, 2, 2, 0, UZ_OCC16)
 UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_2_512_32, 2, 512, 32, 2, 2, 1, 1)
 UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_512_32, 1, 512, 32, 2, 2, 1, 4)
-UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_256_16, 1, 256, 16, 2, 2, 1, 3)
+UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_256_16, 1, 256, 16, 2, 2, 1, UZ_OCC16P)
 // bf16 STORAGE of the input (the volume path, planes wider than 32): 2-byte patch loads, no conversion while staging
 UZ_SPLIT_KERNEL(conv_b16_kernel_2_512_32, 2, 512, 32, 1, 0, 2, 1)
 UZ_SPLIT_KERNEL(conv_b16_kernel_1_512_32, 1, 512, 32, 1, 0, 2, 4)
@@ -712,6 +724,10 @@ UZ_SPLIT_KERNEL_(conv_splitp_bn_db_kernel_2_512_32, 2, 512, 32, 2, 2, 1, 1, 1)
 UZ_SPLIT_KERNEL_(conv_bf16_db_kernel_2_512_32, 2, 512, 32, 1, 0, 0, 1, 1)
 UZ_SPLIT_KERNEL_(conv_bf16_relu_db_kernel_2_512_32, 2, 512, 32, 1, 1, 0, 1, 1)
 UZ_SPLIT_KERNEL_(conv_b16_db_kernel_2_512_32, 2, 512, 32, 1, 0, 2, 1, 1)
+// single-piece bf16 mode, 128-channel tile (always the two-image form: 115 KB of LDS)
+UZ_SPLIT_KERNEL_(conv_bf16_db_kernel_4_512_32, 4, 512, 32, 1, 0, 0, 1, 1)
+UZ_SPLIT_KERNEL_(conv_bf16_relu_db_kernel_4_512_32, 4, 512, 32, 1, 1, 0, 1, 1)
+UZ_SPLIT_KERNEL_(conv_b16_db_kernel_4_512_32, 4, 512, 32, 1, 0, 2, 1, 1)
 #undef UZ_SPLIT_KERNEL
 #undef UZ_SPLIT_KERNEL_
 // UZ_CONV_DB=0: the single-image kernels everywhere (A/B runs)
@@ -730,7 +746,7 @@ int launch_db(const SP& p, int grid, hipStream_t st) {
     SP q = p;
     q.n_tiles = grid;
     int g = grid;
-    if constexpr (MSUB == 2 && NTv == 512) {       // one workgroup per CU: UZ_CONV_PERSIST = number of workgroups (a multiple of 8, < 256) that walk the tiles
+    if constexpr (MSUB >= 2 && NTv == 512) {       // one workgroup per CU: UZ_CONV_PERSIST = number of workgroups (a multiple of 8, < 256) that walk the tiles
         static const int persist = getenv("UZ_CONV_PERSIST") ? atoi(getenv("UZ_CONV_PERSIST")) : 0;
         if (persist > 0 && grid > persist && !p.stamps) g = persist;
     }
@@ -739,10 +755,13 @@ int launch_db(const SP& p, int grid, hipStream_t st) {
 }
 template <int MSUB, int NTv, int TWv, int NP, int MK, int XF>
 int launch_one(const SP& p, int grid, hipStream_t st) {
-    if constexpr (MSUB == 2 && NTv == 512 && TWv == 32) {
-        if (db_enabled()) return launch_db<MSUB, NTv, TWv, NP, MK, XF, 1>(p, grid, st);
+    if constexpr (MSUB == 4) return launch_db<MSUB, NTv, TWv, NP, MK, XF, 1>(p, grid, st);
+    else {
+        if constexpr (MSUB == 2 && NTv == 512 && TWv == 32) {
+            if (db_enabled()) return launch_db<MSUB, NTv, TWv, NP, MK, XF, 1>(p, grid, st);
+        }
+        return launch_db<MSUB, NTv, TWv, NP, MK, XF, 0>(p, grid, st);
     }
-    return launch_db<MSUB, NTv, TWv, NP, MK, XF, 0>(p, grid, st);
 }
 // mk: 0 plain, 1 folded ReLU backward, 2 folded BatchNorm-backward reduction; xpk: input in split storage (two-piece mode only)
 template <int MSUB, int NTv, int TWv, int NP>
@@ -771,10 +790,19 @@ inline int tile_w(int W) { return small_geo(W) ? 16 : 32; }
 // 16 x 16 tiles carry 32 output channels (64 was measured 8 - 30 % slower: the layers that use this geometry want workgroups)
 // ... and on the large planes when the contraction is short (Kc <= 32: two chunks, the workgroup is mostly prologue and
 // epilogue): the 32-channel kernel keeps two workgroups per CU, the 64-channel one a single one (32 -> 96 @ 128 x 128: 202 -> 185 us).
-inline int tile_cot(int Kc, int Mc, int W) { return (small_geo(W) || Mc <= 32 || Kc <= 32) ? 32 : 64; }
+// ... and in the single-piece bf16 mode 128 where more than 64 output channels exist (round 5, conv_*_db_kernel_4_512_32): one product per
+// operand pair makes that mode LDS- and load-issue-bound in the 64-channel tile (one fragment read per MFMA); a wave tile of 128 channels x
+// 64 pixels reads 6 fragments per 8 MFMAs and stages the patch once per 128 output channels.  UZ_COT128=0 switches it off.
+int np_mode();
+inline bool cot128_enabled() { static const bool on = !(getenv("UZ_COT128") && atoi(getenv("UZ_COT128")) == 0); return on; }
+inline int tile_cot(int Kc, int Mc, int W) {
+    if (small_geo(W) || Mc <= 32 || Kc <= 32) return 32;
+    return (np_mode() == 1 && Mc > 64 && cot128_enabled()) ? 128 : 64;
+}
 
 }  // namespace
 
+namespace { int np_mode() { return uz::conv_math_mode() == 3 ? 1 : 2; } }
 namespace uz {
 
 // planes per operand under the current math mode: 1 = bf16 (UZ_CONV_MATH=bf16), 2 = fp32-accurate fp16 split
@@ -996,7 +1024,8 @@ static int conv_split_impl(const float* x, int Kc, int KcTot, const float* w, in
         else rc = cot == 32 ? launch<1, 512, 32, 2>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16) : launch<2, 512, 32, 2>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16);
     } else {
         if (tw == 16) rc = launch<1, 256, 16, 1>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16);
-        else rc = cot == 32 ? launch<1, 512, 32, 1>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16) : launch<2, 512, 32, 1>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16);
+        else rc = cot == 32 ? launch<1, 512, 32, 1>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16)
+                : cot == 128 ? launch<4, 512, 32, 1>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16) : launch<2, 512, 32, 1>(p, (int)grid, st, o.mk, o.x_packed, o.x_b16);
     }
     if (rc || p.kSplit == 1) return rc;
     return splitk_reduce(p.slab, p.kSplit, bias, y, Mc, McTot, N, H * W, relu, accumulate, y_amax, st);
