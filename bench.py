@@ -303,22 +303,28 @@ def dominant_kernel_live(net, plan, L, heaviest, reps=20):
     op_i = ops[k]["i"]
     if len(op_i) > 13 and op_i[13]:
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_traffic_b16.json")))
+            pname = next(n for n in ("r5_pmc_traffic_b16.json", "r4_pmc_traffic_b16.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pname)))
             if f"{cin} -> {cout}" in pmc.get("layer", "") and kind in (0, 1, 2):
-                key = "wgrad_split_kernel<32, 64, 1, 2, 2>" if kind == 2 else "conv_b16_kernel_2_512_32"
+                key = "wgrad_split_kernel<32, 64, 1, 2, 2>" if kind == 2 else next(k_ for k_ in ("conv_b16_db_kernel_4_512_32", "conv_b16_db_kernel_2_512_32", "conv_b16_kernel_2_512_32") if k_ in pmc["kernels"])
                 e = pmc["kernels"][key]
-                out.update(traffic=e["hbm_bytes"], traffic_source="profiles/r4_pmc_traffic_b16.json", kernel=key,
+                out.update(traffic=e["hbm_bytes"], traffic_source="profiles/" + pname, kernel=key,
                            traffic_note="FETCH_SIZE + WRITE_SIZE per launch (L2 fills: Infinity-Cache hits included), calibrated; x %.2f of the algorithmic bytes - "
                                         "the depth window reads every input slice for three output slices" % e["ratio"])
                 return out
         except Exception:
             pass
-    for tabname in ("r4_layer_table.json", "r3_layer_table.json"):      # per-layer dispatch table (tools/prof_layers.sh), keyed on layer and direction; newest first
+    for tabname in ("r5_layer_table.json", "r4_layer_table.json", "r3_layer_table.json"):      # per-layer dispatch table (tools/prof_layers.sh), keyed on layer and direction; newest first
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", tabname)))
             for row in tab["layers"]:
                 if (row["kind"], row["cin"], row["cout"], row["n"], row["h"], row["w"], row["ks"]) == (kind, cin, cout, n, h, w, ks):
-                    out.update(traffic=row["hbm_bytes"], traffic_source="profiles/" + tabname, kernel=row["dominant_kernel"],
+                    # (a COMMITTED table, not a measurement of this run: its git blob hash says which one, `profiled.kernel` which kernel it
+                    #  timed - regenerate it in the evidence call behind the last kernel commit)
+                    raw = open(os.path.join(ROOT, "profiles", tabname), "rb").read()
+                    import hashlib
+                    blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()
+                    out.update(traffic=row["hbm_bytes"], traffic_source="profiles/" + tabname, traffic_table_git_blob=blob, kernel=row["dominant_kernel"],
                                profiled=dict(avg_launch_us=row["avg_launch_us"], mfma_busy_fraction=row["mfma_busy_fraction"],
                                              traffic_over_algorithmic=row["traffic_over_algorithmic"]))
                     return out
@@ -781,7 +787,7 @@ def main():
                             note="dominant kernel = the longest convolution launch of the step, re-timed live (20 launches between two HIP events "
                                  "on its launch stream); achieved = algorithmic fp32-equivalent FLOPs per launch / average launch duration; traffic = "
                                  "PMC-measured HBM bytes per launch of this kernel on this layer (profiles/), null when no committed PMC pass covers it")
-                for k in ("fp16_mfma_tflops", "traffic_source", "sustained_ceiling_note"):
+                for k in ("fp16_mfma_tflops", "traffic_source", "traffic_table_git_blob", "sustained_ceiling_note"):
                     if k in dk:
                         roof[k] = dk[k]
                 step_view.pop("traffic", None)
@@ -809,7 +815,8 @@ def main():
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="strong" if args.strong else "weak",
                     vs_baseline=None, dtype=("bf16" if store_b16 else "bf16 arithmetic / f32 storage") if conv_math() == "bf16" else "f32", data="synthetic",
                     config=dict(workload=(M["workload"] % ("bf16" if store_b16 else "fp32")) if vol else M["workload"], batch_per_gpu=args.batch, global_batch=global_batch, parallelism=f"dp{world}",
-                                graphs=not args.no_graphs, final_loss=final_loss, conv_math=math_note),
+                                graphs=not args.no_graphs, replay=(getattr(net, "replay_mode", "graph") if not args.no_graphs else "eager, one stream"),
+                                lanes=getattr(plan, "n_lanes", None), final_loss=final_loss, conv_math=math_note),
                     roofline=roof)
         if world > 1:
             line["config"]["allreduce"] = "bucketed, overlapped with backward" if not args.no_overlap else "one blocking all-reduce after backward"

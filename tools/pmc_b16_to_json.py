@@ -27,6 +27,8 @@ cal = [v["FETCH_SIZE"] for k, v in fetch.items() if k.startswith("channel_sum_pa
 f = cal_expected / cal
 t = D * C * H * W * 2
 alg = {"conv_b16_kernel_2_512_32": ("3x3x3 forward / data gradient (mean of the two launches)", 2 * t + Cout * C * 27 * 4),
+       "conv_b16_db_kernel_2_512_32": ("3x3x3 forward / data gradient, 64-channel tile, two LDS images (mean of the two launches)", 2 * t + Cout * C * 27 * 4),
+       "conv_b16_db_kernel_4_512_32": ("3x3x3 forward / data gradient, 128-channel tile (round 5; mean of the two launches)", 2 * t + Cout * C * 27 * 4),
        "wgrad_split_kernel<32, 64, 1, 2, 2>": ("weight gradient (slabs)", 2 * t),
        "bn_apply_st": ("BatchNorm apply (y -> a)", 2 * t), "bn_bwd_reduce_partial_st": ("BatchNorm backward sums (dA, y)", 2 * t),
        "bn_bwd_apply_st": ("BatchNorm backward apply (dA, y -> dy)", 3 * t)}
