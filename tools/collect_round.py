@@ -29,7 +29,7 @@ def last_json_line(path):
 names = {"phiseg": "bench_phiseg.json", "unet": "bench_unet.json", "probunet": "bench_probunet.json", "phiseg3d": "bench_phiseg3d.json",
          "phiseg3d_f32split": "bench_phiseg3d_f32split.json", "phiseg3d_f32storage": "bench_phiseg3d_f32storage.json", "phiseg3d_rev": "bench_phiseg3d_rev.json",
          "phiseg_bf16math": "bench_phiseg_bf16math.json", "2ranks_one_device": "bench_2ranks_one_device.json",
-         "unet_cpu_b4": "bench_unet_cpu_b4.json"}
+         "unet_cpu_b4": "bench_unet_cpu_b4.json", "phiseg_graph_replay": "bench_phiseg_graph_replay.json"}
 lines = {k: last_json_line(os.path.join(src, v)) for k, v in names.items()}
 lines = {k: v for k, v in lines.items() if v is not None}
 tests = {}

@@ -86,7 +86,6 @@ struct SP {
     int* flags; int flag_bit;                     // device flag word (bound violations), nullable; the bit this launch raises: activation (forward) or gradient (data gradient)
     float* bnpart;                                // nullable: per-(pixel tile, row half, channel) {sum, sum of squares, max, max of negated} of y
     int yb16;                                     // y (and what it accumulates onto) is stored as bf16 (single-piece mode, kSplit == 1)
-    int n_tiles;                                  // workgroup-sized tiles of the launch (== gridDim.x unless the launch is persistent)
 };
 
 
@@ -419,7 +418,8 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
     for (int tap = 0; tap < KK; ++tap) stage(cbeg, tap);
     // A 64-channel tile whose upper 32 channels lie beyond Cout (Cout = 224 = 3 x 64 + 32: the data gradient of the heaviest
     // layer) skips that half's MFMAs, fragment reads and epilogue pass: 12.5 % of that launch's matrix work were zeros.
-    const int mact = min(MSUB, (p.Cout - co0 + 31) / 32);           // 32-channel sub-tiles of this tile that hold real output channels
+    // 32-channel sub-tiles of this tile that hold real output channels (MSUB == 2: the upper half is empty or not)
+    const int mact = MSUB == 4 ? min(MSUB, (p.Cout - co0 + 31) / 32) : ((MSUB == 2 && p.Cout - co0 <= 32) ? 1 : MSUB);
     const bool half_tile = mact < MSUB;
     constexpr int MS = MSUB;
     if (DEEP && cbeg + 1 < cend) {
@@ -667,14 +667,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
 // reduction} x input {fp32, split storage}.
 template <int MSUB, int NTv, int TWv, int NP, int MK, int XF, int DB = 0> struct SplitKernel;
 #define UZ_SPLIT_KERNEL_(name, MSUB_, NT_, TW_, NP_, MK_, XF_, OCC_, DB_)                                                     \
-    __global__ __launch_bounds__(NT_, OCC_) void name(const SP p) {                                                           \
-        /* persistent form (UZ_CONV_PERSIST): fewer workgroups than tiles, each walks its tiles - the CUs the grid does not    */ \
-        /* reach stay free for the latency-bound launches of the other lanes ("co-residency")             */ \
-        for (int t = blockIdx.x; t < p.n_tiles; t += gridDim.x) {                                                             \
-            conv_split_body<MSUB_, NT_, TW_, NP_, MK_, XF_, DB_>(p, t, p.n_tiles);                                            \
-            if (t + (int)gridDim.x < p.n_tiles) __syncthreads();      /* the next tile's staging overwrites the epilogue's LDS */ \
-        }                                                                                                                     \
-    }                                                                                                                         \
+    __global__ __launch_bounds__(NT_, OCC_) void name(const SP p) { conv_split_body<MSUB_, NT_, TW_, NP_, MK_, XF_, DB_>(p, blockIdx.x, gridDim.x); } \
     template <> struct SplitKernel<MSUB_, NT_, TW_, NP_, MK_, XF_, DB_> { static constexpr auto fn = name; };
 #define UZ_SPLIT_KERNEL(name, MSUB_, NT_, TW_, NP_, MK_, XF_, OCC_) UZ_SPLIT_KERNEL_(name, MSUB_, NT_, TW_, NP_, MK_, XF_, OCC_, 0)
 // (round 4: the 32-channel-tile kernels keep (512, 4) although that bound costs them ~30 spilled registers - with (512, 3), no spills
@@ -743,14 +736,11 @@ int launch_db(const SP& p, int grid, hipStream_t st) {
             return uz::fail("conv_split: cannot raise dynamic LDS limit");
         attr_done = true;
     }
-    SP q = p;
-    q.n_tiles = grid;
-    int g = grid;
-    if constexpr (MSUB >= 2 && NTv == 512) {       // one workgroup per CU: UZ_CONV_PERSIST = number of workgroups (a multiple of 8, < 256) that walk the tiles
-        static const int persist = getenv("UZ_CONV_PERSIST") ? atoi(getenv("UZ_CONV_PERSIST")) : 0;
-        if (persist > 0 && grid > persist && !p.stamps) g = persist;
-    }
-    hipLaunchKernelGGL(kern, dim3(g), dim3(NTv), smem, st, q);
+    // (round 5: a persistent form - fewer workgroups than tiles, each walking its tiles, so that the grid leaves CUs free for the other
+    //  lanes' small launches - was built and measured at commit d333d48: 224 workgroups unblock a chain of small launches in the
+    //  micro-benchmark, the step lost 2.5 %, and the tile loop around the body cost every instance registers: 72 -> 184 bytes of
+    //  scratch in the 32-channel-tile kernel, 144 -> 177 VGPRs in the 16 x 16-pixel one, SGPRs at their cap.  Removed.)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTv), smem, st, p);
     return uz::check_launch("conv_split_kernel");
 }
 template <int MSUB, int NTv, int TWv, int NP, int MK, int XF>
