@@ -88,6 +88,36 @@ def test_unet_and_probunet_specs_equal_reference_state_dict():
     assert n == 17956988
 
 
+def test_kernel_resource_table_matches_the_sources_and_the_budgets():
+    """profiles/kernel_resources.json (tools/kernel_resources.py: hipcc's own register / scratch / LDS report per kernel instance) must
+    have been generated from the committed kernel sources, and the instances the training step lives on must stay inside their
+    budgets.  Round 5 shipped, for a few hours, a wrapper loop that took the 32-channel-tile convolution from 72 to 340 bytes of scratch
+    and the 16 x 16-pixel one from three to two workgroups per CU (32->32 @ 128 x 128: 60 -> 117 us) - invisible in every
+    same-library A/B of the step."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "unet-zoo_amd", "csrc")
+    tab = json.load(open(os.path.join(root, "profiles", "kernel_resources.json")))
+    headers = [os.path.join(csrc, "uz_common.h"), os.path.join(csrc, "split_f16.h"), os.path.join(root, "include", "uz_api.h")]
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(".hip"):
+            continue
+        h = hashlib.sha1()
+        for p_ in [os.path.join(csrc, f)] + headers:
+            h.update(open(p_, "rb").read())
+        assert f in tab and tab[f]["sha1"] == h.hexdigest(), f"{f} changed since profiles/kernel_resources.json was generated: run tools/kernel_resources.py and LOOK at the diff"
+    k = tab["conv_split.hip"]["kernels"]
+    budgets = {  # instance: (max VGPRs, max scratch bytes per lane)
+        "conv_splitp_kernel_1_512_32": (128, 80), "conv_split_kernel_1_512_32": (128, 140), "conv_splitp_kernel_1_256_16": (168, 16),
+        "conv_split_kernel_1_256_16": (168, 0), "conv_splitp_db_kernel_2_512_32": (192, 0), "conv_split_db_kernel_2_512_32": (200, 0),
+        "conv_splitp_bn_db_kernel_2_512_32": (200, 0), "conv_b16_db_kernel_4_512_32": (248, 0), "conv_b16_db_kernel_2_512_32": (168, 0)}
+    for name, (vmax, smax) in budgets.items():
+        assert k[name]["vgpr"] <= vmax and k[name]["scratch"] <= smax, (name, k[name])
+    w = tab["conv_wgrad_split.hip"]["kernels"]
+    heavy = [v for n, v in w.items() if n.startswith("wgrad_split_kernel<32, 64, 2")]
+    assert heavy and all(v["vgpr"] <= 256 and v["scratch"] == 0 for v in heavy), heavy      # (236 - 254 since the bound predicate is accumulated over every tile)
+
+
 def _check_lane_schedule(plan, which, ops):
     """Brute force: every pair of ops touching overlapping memory with at least one write must be
     ordered by lane order + event waits; groups stay contiguous on one lane (private scratch)."""
