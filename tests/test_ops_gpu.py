@@ -750,13 +750,14 @@ def test_conv_bf16_arithmetic_mode(N, Cin, Cout, H, W):
 
 @pytest.mark.parametrize("N,Cin,ctot,c0,L,H,W,act", [(3, 32, 40, 5, 2, 16, 16, 0), (2, 192, 192, 0, 2, 8, 8, 0), (2, 7, 9, 1, 3, 5, 7, 0),
                                                      (2, 16, 16, 0, 1, 12, 12, 1), (1, 24, 24, 0, 4, 32, 32, 0)])
-def test_latent_heads_equal_the_separate_ops_bit_for_bit(N, Cin, ctot, c0, L, H, W, act):
+def test_latent_heads_equal_the_separate_ops_bit_for_bit(N, Cin, ctot, c0, L, H, W, act, monkeypatch):
     """uz_latent_heads_* (the two 1x1 heads of a SampleZBlock + its sampling tail as one op per direction, phiseg.py:95-105) against the
     ops they replace - uz_conv_fwd x 2 + uz_latent_sample_fwd; uz_conv_bwd_weight x 2, uz_conv_bwd_data x 2 (sigma head first, the mu
     head accumulating) - bit for bit, on float4 and scalar planes, in a wider buffer, with and without z, accumulating or not; and against
     torch for the values."""
     g = _g()
     d = g.dev()
+    monkeypatch.setenv("UZ_HEADS_PAR", "0")           # the sequential forward (the channel-parallel form of round 5: end of this test)
     h = g.rnd(N, Cin, H, W, seed=1)
     hbuf, hv = g.view_in(h, ctot, c0)
     wm, ws_ = g.rnd(L, Cin, 1, 1, seed=2, scale=0.3).to(d), g.rnd(L, Cin, 1, 1, seed=3, scale=0.3).to(d)
@@ -782,6 +783,17 @@ def test_latent_heads_equal_the_separate_ops_bit_for_bit(N, Cin, ctot, c0, L, H,
     pr = F.conv2d(h, ws_.cpu(), bs.cpu())
     sr = torch.exp(pr) if act else F.softplus(pr)
     assert g.relerr(mu1, mr) <= 2e-6 and g.relerr(sg1, sr) <= 2e-6 and g.relerr(z1, mr + sr * eps.cpu()) <= 2e-6
+    # the channel-parallel forward (power-of-two planes of the latent hierarchy): a fixed binary tree over channel groups instead of one
+    # fmaf chain - equal to rounding, deterministic from launch to launch
+    monkeypatch.setenv("UZ_HEADS_PAR", "1")
+    mu3, pre3, sg3, z3 = new(), new(), new(), new()
+    g.call("uz_latent_heads_fwd", hv, Cin, ctot, wm, bm, ws_, bs, eps, mu3, pre3, sg3, z3, L, N, H, W, act)
+    for a, b in ((mu1, mu3), (pre1, pre3), (sg1, sg3), (z1, z3)):
+        assert g.relerr(b, a.cpu()) <= 1e-6
+    mu4, pre4, sg4, z4 = new(), new(), new(), new()
+    g.call("uz_latent_heads_fwd", hv, Cin, ctot, wm, bm, ws_, bs, eps, mu4, pre4, sg4, z4, L, N, H, W, act)
+    assert torch.equal(mu3, mu4) and torch.equal(z3, z4)
+    monkeypatch.setenv("UZ_HEADS_PAR", "0")
     # backward
     dmu, dpre = g.rnd(N, L, H, W, seed=7).to(d), g.rnd(N, L, H, W, seed=8).to(d)
     for accumulate in (0, 1):

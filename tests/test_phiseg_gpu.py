@@ -480,6 +480,7 @@ def test_fused_latent_heads_leave_the_training_step_bit_identical(monkeypatch):
     g = torch.Generator(device="cuda").manual_seed(3)
     noise = [torch.randn(s_, generator=g, device="cuda") for s_ in [(B, 2, 1 << k, 1 << k) for k in range(5)] * 2]      # deepest level first: 1 x 1 ... 16 x 16
     runs = []
+    monkeypatch.setenv("UZ_HEADS_PAR", "0")          # the sequential forward keeps the separate ops' arithmetic order (the channel-parallel form: test_ops_gpu.py)
     for fuse in ("1", "0"):
         monkeypatch.setenv("UZ_FUSE_HEADS", fuse)
         torch.manual_seed(1)

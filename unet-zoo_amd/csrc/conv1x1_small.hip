@@ -387,6 +387,70 @@ __global__ __launch_bounds__(256) void heads_fwd(const HP p) {
     }
 }
 
+// Channel-parallel form of the forward for the latent hierarchy's own planes (round 5).  heads_fwd above gives every thread four pixels
+// and walks the input channels one after the other: on a 2 x 2 ... 32 x 32 plane that is ONE workgroup per image whose threads wait for
+// 192 dependent-by-queue loads (28 - 60 us per launch, ten launches on the forward's critical chain - level k + 1 waits for z_k).  Here a
+// workgroup owns QPB (<= 64) pixel quads of one image and CG = 256 / QPB channel groups: thread (g, q) accumulates channels g, g + CG, ...
+// for quad q, the CG partial sums are added in a fixed binary tree through LDS (deterministic; NOT the sequential order of heads_fwd:
+// results agree to rounding, tests/test_ops_gpu.py), and the threads of group 0 finish bias, softplus and sampling.  UZ_HEADS_PAR=0
+// keeps heads_fwd everywhere.
+template <int LL>
+__global__ __launch_bounds__(256) void heads_fwd_par(const HP p, const int qpb_log2) {
+    constexpr int NO = 2 * LL;
+    __shared__ float ws[MAXN * 512];
+    __shared__ float4 red[256 * NO];
+    const int b = blockIdx.y;
+    heads_weights<LL>(p, ws);
+    const int QPB = 1 << qpb_log2, CG = 256 >> qpb_log2;
+    const int g = threadIdx.x >> qpb_log2, q = (blockIdx.x << qpb_log2) + (threadIdx.x & (QPB - 1));       // channel group, pixel quad of the image
+    float4 acc[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = p.x + (size_t)b * p.CinTot * p.HW + 4 * q;
+#pragma unroll 4
+    for (int c = g; c < p.Cin; c += CG) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * p.HW);
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+            const float wv = ws[n * p.Cin + c];
+            acc[n].x = fmaf(wv, v.x, acc[n].x); acc[n].y = fmaf(wv, v.y, acc[n].y);
+            acc[n].z = fmaf(wv, v.z, acc[n].z); acc[n].w = fmaf(wv, v.w, acc[n].w);
+        }
+    }
+    for (int stride = CG >> 1; stride >= 1; stride >>= 1) {
+        if (g >= stride && g < 2 * stride) {
+#pragma unroll
+            for (int n = 0; n < NO; ++n) red[threadIdx.x * NO + n] = acc[n];
+        }
+        __syncthreads();
+        if (g < stride) {
+            const int o = threadIdx.x + (stride << qpb_log2);
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+                const float4 r = red[o * NO + n];
+                acc[n].x += r.x; acc[n].y += r.y; acc[n].z += r.z; acc[n].w += r.w;
+            }
+        }
+        __syncthreads();
+    }
+    if (g != 0) return;
+#pragma unroll
+    for (int n = 0; n < LL; ++n) {
+        const float bm = p.bA ? p.bA[n] : 0.f, bs = p.bB ? p.bB[n] : 0.f;
+        const size_t e = ((size_t)b * LL + n) * p.HW + 4 * q;
+        const float4 m = make_float4(acc[n].x + bm, acc[n].y + bm, acc[n].z + bm, acc[n].w + bm);
+        const float4 pr = make_float4(acc[LL + n].x + bs, acc[LL + n].y + bs, acc[LL + n].z + bs, acc[LL + n].w + bs);
+        const float4 sg = make_float4(head_sigma(pr.x, p.act), head_sigma(pr.y, p.act), head_sigma(pr.z, p.act), head_sigma(pr.w, p.act));
+        *reinterpret_cast<float4*>(p.mu + e) = m;
+        *reinterpret_cast<float4*>(p.pre + e) = pr;
+        *reinterpret_cast<float4*>(p.sigma + e) = sg;
+        if (p.z) {
+            const float4 ev = *reinterpret_cast<const float4*>(p.eps + e);
+            *reinterpret_cast<float4*>(p.z + e) = make_float4(m.x + sg.x * ev.x, m.y + sg.y * ev.y, m.z + sg.z * ev.z, m.w + sg.w * ev.w);
+        }
+    }
+}
+
 template <int LL, bool VEC>
 __global__ __launch_bounds__(256) void heads_bwd_data(const HP p) {
     constexpr int NO = 2 * LL;
@@ -560,6 +624,22 @@ extern "C" int uz_latent_heads_fwd(const float* h, int Cin, int CinTot, const fl
     HP p = {}; p.x = h; p.Cin = Cin; p.CinTot = CinTot; p.N = N; p.HW = H * W; p.wA = w_mu; p.bA = b_mu; p.wB = w_sigma; p.bB = b_sigma;
     p.eps = eps; p.mu = mu; p.pre = pre_sigma; p.sigma = sigma; p.z = z; p.act = act;
     const bool v = p.HW % 4 == 0 && al16(h) && al16(mu) && al16(pre_sigma) && al16(sigma) && (!z || (al16(z) && al16(eps)));
+    // the latent hierarchy's own planes (a power-of-two number of pixel quads, at most 1024 pixels per image at moderate batch): channel-parallel form
+    const int quads = p.HW / 4;
+    const char* par_env = getenv("UZ_HEADS_PAR");
+    if (v && quads >= 1 && (quads & (quads - 1)) == 0 && (long long)N * quads <= 16384 && !(par_env && atoi(par_env) == 0)) {
+        int lg = 0;
+        while ((1 << lg) < quads && lg < 6) ++lg;               // QPB = min(quads, 64)
+        const dim3 gp(quads >> lg, N);
+        switch (L) {
+            case 1: hipLaunchKernelGGL(heads_fwd_par<1>, gp, dim3(256), 0, st, p, lg); break;
+            case 2: hipLaunchKernelGGL(heads_fwd_par<2>, gp, dim3(256), 0, st, p, lg); break;
+            case 3: hipLaunchKernelGGL(heads_fwd_par<3>, gp, dim3(256), 0, st, p, lg); break;
+            case 4: hipLaunchKernelGGL(heads_fwd_par<4>, gp, dim3(256), 0, st, p, lg); break;
+            default: return uz::fail("latent heads: %d latent channels per head not covered (1 .. 4)", L);
+        }
+        return uz::check_launch("heads_fwd_par");
+    }
     const dim3 grid(uz::ceil_div(p.HW, PIX), N);
     HEADS_DISPATCH(heads_fwd, v, grid)
     return uz::check_launch("heads_fwd");
