@@ -43,11 +43,21 @@ def table(src):
 
 def main():
     out = {}
+    path = os.path.join(ROOT, "profiles", "kernel_resources.json")
+    old = json.load(open(path)) if os.path.exists(path) else {}
     for f in sorted(os.listdir(CSRC)):
         if f.endswith(".hip"):
             src = os.path.join(CSRC, f)
-            out[f] = dict(sha1=sha([src] + HEADERS), kernels=table(src))
+            h = sha([src] + HEADERS)
+            if f in old and old[f]["sha1"] == h:             # unchanged sources: keep the entry
+                out[f] = old[f]
+                continue
+            out[f] = dict(sha1=h, kernels=table(src))
             print(f, len(out[f]["kernels"]), "kernels", file=sys.stderr)
+            for k, v in sorted(out[f]["kernels"].items()):    # what changed against the committed table
+                o = old.get(f, {}).get("kernels", {}).get(k)
+                if o != v:
+                    print("   ", k, o and {q: o[q] for q in ("vgpr", "sgpr", "scratch")}, "->", {q: v[q] for q in ("vgpr", "sgpr", "scratch")}, file=sys.stderr)
     json.dump(out, open(os.path.join(ROOT, "profiles", "kernel_resources.json"), "w"), indent=1, sort_keys=True)
 
 
