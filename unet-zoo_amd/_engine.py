@@ -162,7 +162,16 @@ class NativeModel(nn.Module):
     decouple_wgrad_px = 0
     decouple_wgrad_prefixes = ()      # sub-networks (parameter-name prefixes) whose weight gradients are decoupled at every size
 
+    # Workgroups of the split-path weight gradients (uz_set_wgrad_target): a process setting of the library that sizes slab buffers at plan
+    # time and grids at launch time - set in front of every plan build and every tape of THIS model, so models with different values can
+    # alternate in one process.  256 = one workgroup per CU; PHISeg 128, ProbabilisticUnet 192 (measured under the lane replay).
+    wgrad_workgroups = 256
+
+    def _set_library_mode(self):
+        _ffi.lib().uz_set_wgrad_target(int(self.wgrad_workgroups))
+
     def _new_plan(self, N, bn_training):
+        self._set_library_mode()
         plan = Plan(N, self._ptab, bn_training, self.device)
         if "UZ_LANES" not in os.environ:
             plan.n_lanes = self.default_lanes_by_mode.get(self.replay_mode, self.default_lanes)
@@ -222,6 +231,7 @@ class NativeModel(nn.Module):
         return handle
 
     def _run(self, plan, which):
+        self._set_library_mode()
         if not self._use_graphs or which == "loss":
             plan.run(which, self._stream())
             return

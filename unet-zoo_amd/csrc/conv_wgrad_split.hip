@@ -395,13 +395,23 @@ bool wgrad_split_ok(int Cin, int Cout, int N, int H, int W, int ks) {
 static inline int tile_w(int W) { return W == 16 ? 16 : 32; }
 static inline int chan_tile(int Cin, int Cout) { return (Cin <= 32 || Cout <= 32) ? 32 : 64; }
 
-// number of pixel splits: one workgroup per CU, at most one split per pixel tile
+// Workgroups a split-path weight gradient is cut into (uz_set_wgrad_target; UZ_WGS_TARGET overrides; default 256 = one per CU).  Its
+// workgroups hold 472 - 508 of a SIMD's 512 registers for as long as the kernel runs, so on the CUs it occupies NOTHING else starts; a grid
+// of 128 leaves half the chip to the other lanes' launches - PHiSeg under the lane replay +3.3 % (1 907 -> 1 970 images/s, three
+// alternations; 192: +1.8 %, 96: +-0, 64: -7 %), Probabilistic U-Net best at 192 (+0.6 %), the single-lane U-Net at 256 (128: -8 %).
+static int g_wgs_target = 0;
+extern "C" void uz_set_wgrad_target(int workgroups) { g_wgs_target = workgroups; }
+extern "C" int uz_get_wgrad_target(void) {
+    static const int env = getenv("UZ_WGS_TARGET") ? atoi(getenv("UZ_WGS_TARGET")) : 0;
+    return env > 0 ? env : (g_wgs_target > 0 ? g_wgs_target : 256);
+}
+// number of pixel splits: at most one split per pixel tile
 int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
     const int ct = chan_tile(Cin, Cout);
     const int nt = ceil_div(Cout, ct) * ceil_div(Cin, ct);
     const int tw = tile_w(W);
     const int T = N * ceil_div(H, PT / tw) * (W / tw);
-    static const int target = getenv("UZ_WGS_TARGET") ? atoi(getenv("UZ_WGS_TARGET")) : 256;
+    const int target = uz_get_wgrad_target();
     // one workgroup per CU either way (the 32-channel kernel's 166 VGPRs allow no second one: 512 splits measured 6 % slower).  (192
     // workgroups measured +0.5 % on the STEP - a quarter of the CUs stays with the other lane - but the heaviest launch itself 767 -> 909 us
     // with 1.35x -> 1.77x its algorithmic HBM traffic: not kept.)

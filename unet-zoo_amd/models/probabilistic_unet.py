@@ -56,6 +56,7 @@ class ProbabilisticUnet(NativeModel):
     # measure 12.0 ms per step against 12.4 with two (PHiSeg, whose chains are dominated by device-filling kernels, loses 8 %
     # with three)
     default_lanes = 3
+    wgrad_workgroups = 192                     # NativeModel.wgrad_workgroups: 256 -> 3 230, 192 -> 3 255, 128 -> 3 208 images/s (one box)
 
     def __init__(self, input_channels=1, num_classes=1, num_filters=None, latent_levels=1, latent_dim=2, initializers=None,
                  no_convs_fcomb=4, image_size=(1, 128, 128), beta=10.0, reversible=False, device=None):
