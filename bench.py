@@ -209,7 +209,7 @@ def profile_families(net, plan, L, reps=3, burst=4):
     import torch
     from unet_zoo_amd import _ffi
     stream = C.c_void_p(net._stream())
-    fam, heaviest = {}, None
+    fam, heaviest, heaviest_full = {}, None, None
 
     def timed(tape, n_launch):
         best = None
@@ -245,7 +245,12 @@ def profile_families(net, plan, L, reps=3, burst=4):
                     d["t_roof"] += fl / (roof * 1e12)                 # seconds at the roof
                     if heaviest is None or best > heaviest[0]:
                         heaviest = (best, which, k, fl, roof)
-    return fam, heaviest
+                    # the longest launch among those whose grid covers the whole chip: a split-path weight gradient is cut into
+                    # uz_get_wgrad_target() workgroups (PHiSeg: 128 of 256 CUs, on purpose - the rest of the chip stays with the other lanes)
+                    reduced = ops[k]["code"] == "UZ_OP_CONV_BWD_WEIGHT" and roof != PEAK_F32_MFMA_TFLOPS and L.uz_get_wgrad_target() < 256
+                    if not reduced and (heaviest_full is None or best > heaviest_full[0]):
+                        heaviest_full = (best, which, k, fl, roof)
+    return fam, heaviest, heaviest_full
 
 
 def dominant_kernel_live(net, plan, L, heaviest, reps=20):
@@ -756,7 +761,7 @@ def main():
                          "hbm_fraction uses the unfused-graph bytes and cannot exceed ~0.21 in fp32")
         if not args.no_profile and world == 1:
             try:
-                fam, heaviest = profile_families(net, plan, L)
+                fam, heaviest, heaviest_full = profile_families(net, plan, L)
                 fams = {}
                 for k, d in fam.items():
                     e = dict(ms_per_step=round(d["ms"], 3), launches=d["launches"])
@@ -790,6 +795,14 @@ def main():
                 for k in ("fp16_mfma_tflops", "traffic_source", "traffic_table_git_blob", "sustained_ceiling_note"):
                     if k in dk:
                         roof[k] = dk[k]
+                if dk["op"] == "weight gradient" and dk["peak"] != PEAK_F32_MFMA_TFLOPS and L.uz_get_wgrad_target() < 256:
+                    wg = int(L.uz_get_wgrad_target())
+                    roof["grid_note"] = ("this launch is cut into %d workgroups ON PURPOSE (uz_set_wgrad_target: its workgroups hold 472 - 508 of a SIMD's 512 registers "
+                                         "for the whole kernel, so nothing else starts on the CUs it occupies; with %d of 256 CUs the step is 3 %% faster, profiles/NOTES_r5.md) - "
+                                         "`frac` is against the WHOLE chip's peak; against the peak of the CUs it occupies: %.4f" % (wg, wg, dk["frac"] * 256.0 / wg))
+                    if heaviest_full is not None and heaviest_full[2:3] != heaviest[2:3]:
+                        d2 = dominant_kernel_live(net, plan, L, heaviest_full)
+                        roof["longest_full_grid_launch"] = {k: d2[k] for k in ("kernel", "op", "layer", "avg_launch_ms", "achieved", "peak", "frac", "traffic", "algorithmic_bytes") if k in d2}
                 step_view.pop("traffic", None)
                 roof["step"] = step_view
                 roof["families"] = fams
