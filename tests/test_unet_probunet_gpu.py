@@ -1,6 +1,8 @@
 """End-to-end parity of the native vanilla U-Net and Probabilistic U-Net against golden vectors generated
 from the real reference (tools/gen_golden.py): predictions / features, loss, every parameter gradient,
 which parameters keep grad None, and the parameters after three Adam steps."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -152,6 +154,54 @@ def test_graph_replay_is_bit_identical_to_eager(model):
     assert l0 == l1
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+
+
+def test_models_with_different_weight_gradient_grids_alternate_in_one_process():
+    """uz_set_wgrad_target is a PROCESS setting of the library that sizes slab buffers at plan time and grids at launch time; the Python
+    face sets it per model (PHISeg 128, ProbabilisticUnet 192, Unet 256) in front of every plan build and every tape.  Two models with
+    different values stepping in turn must each reproduce, bit for bit, what they compute alone (a stale setting would either trip the
+    slab-count assertion of uz_conv_bwd_weight_ex or change the order of the slab sums)."""
+    from unet_zoo_amd import _ffi
+    from unet_zoo_amd.models.phiseg import PHISeg
+    from unet_zoo_amd.models.unet import Unet
+    from unet_zoo_amd.optim import FusedAdam
+    assert PHISeg.wgrad_workgroups != Unet.wgrad_workgroups
+    B = 8
+    x, mask, _ = oracle.synthetic_batch(B, 128, 128, seed=77)
+    xd, md = torch.from_numpy(x).to(DEV()), torch.from_numpy(mask).to(DEV())
+    g = torch.Generator(device="cuda").manual_seed(5)
+    noise = [torch.randn(B, 2, 2 << k, 2 << k, generator=g, device="cuda") for k in range(5)] * 2        # deepest level first: 2 x 2 ... 32 x 32
+
+    def make(kind):
+        torch.manual_seed(3)
+        net = PHISeg(1, 2, [32, 64, 64, 64, 64, 64, 64], latent_levels=5, image_size=(1, 128, 128)) if kind == "phiseg" else Unet(1, 2, [32, 64, 64, 64])
+        net.train(); net.enable_graphs(True)
+        return net, FusedAdam(net, lr=1e-3, weight_decay=1e-5)
+
+    def step(kind, net, opt):
+        if kind == "phiseg":
+            net.forward(xd, md, training=True, eps=noise)
+        else:
+            net.forward(xd)
+        loss = net.loss(md)
+        opt.zero_grad(); loss.backward(); opt.step()
+        return float(loss.detach())
+    alone = {}
+    for kind in ("phiseg", "unet"):
+        net, opt = make(kind)
+        losses = [step(kind, net, opt) for _ in range(3)]
+        torch.cuda.synchronize()
+        alone[kind] = (losses, net._ptab.pflat.clone())
+        assert _ffi.lib().uz_get_wgrad_target() == type(net).wgrad_workgroups or os.environ.get("UZ_WGS_TARGET")
+    nets = {kind: make(kind) for kind in ("phiseg", "unet")}
+    losses = {"phiseg": [], "unet": []}
+    for _ in range(3):
+        for kind in ("phiseg", "unet"):
+            losses[kind].append(step(kind, *nets[kind]))
+    torch.cuda.synchronize()
+    for kind in ("phiseg", "unet"):
+        assert losses[kind] == alone[kind][0], kind
+        assert torch.equal(nets[kind][0]._ptab.pflat, alone[kind][1]), kind
 
 
 def test_probunet_gradients_with_and_without_deferred_tables_agree_bit_for_bit(monkeypatch):
