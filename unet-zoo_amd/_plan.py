@@ -1840,18 +1840,6 @@ class Plan:
                 hist[space] = keep
         # ---- 2. list scheduling in simulated time
         cost = [sum(self._op_cost(o) for o in ops[a:b + 1]) for a, b in groups]
-        # UZ_SCHED_DEFER_W=<us>: device-filling weight-gradient groups (nothing on the backward chain waits for them) start only behind
-        # the LAST device-filling group of the backward chain itself - they then run beside the latency-bound tail of the tape (the
-        # posterior's deep levels and encoder) instead of sharing the chip with the data-gradient chain that tail is waiting for
-        dthr = float(os.environ.get("UZ_SCHED_DEFER_W", "0")) * 1e-6
-        if dthr > 0:
-            wonly = [all(o["code"] == "UZ_OP_CONV_BWD_WEIGHT" for o in ops[a:b + 1]) for a, b in groups]
-            chain = [gi for gi in range(G) if cost[gi] >= dthr and not wonly[gi] and any(o["code"] == "UZ_OP_CONV_BWD_DATA" for o in ops[groups[gi][0]:groups[gi][1] + 1])]
-            if chain:
-                anchor = chain[-1]
-                for gi in range(G):
-                    if wonly[gi] and cost[gi] >= dthr and gi != anchor:
-                        deps[gi].add(anchor)
         succ = [[] for _ in range(G)]
         indeg = [len(d) for d in deps]
         for gi, d in enumerate(deps):
@@ -1873,19 +1861,9 @@ class Plan:
             heavy = [False] * G
         else:
             heavy = [c >= float(hmode) * 1e-6 for c in cost]
-        # UZ_SCHED_POLICY=typed:<us>: groups whose modelled duration reaches <us> microseconds ("device-filling") all go to the last lane, in
-        # critical-path order, everything else to the other lanes: in the REPLAY two device-filling launches then never share the chip
-        # (no gain in that), and whatever lane 0 runs has the latency- and bandwidth-bound chains of the other lanes beside it
-        pol = os.environ.get("UZ_SCHED_POLICY", "list")
-        typed = None
-        if pol.startswith("typed") and K > 1:
-            thr = float(pol.split(":")[1]) * 1e-6 if ":" in pol else 100e-6
-            typed = [c >= thr for c in cost]
-            heavy = [False] * G
-        elif pol == "wlane" and K > 2:
-            # weight-gradient-only groups (decoupled: nothing on the backward chain waits for them) all go to the LAST lane, which the
-            # replay runs at low stream priority (UZ_LANE_PRIO): they fill what the chains of the other lanes leave idle
-            typed = [not all(o["code"] in ("UZ_OP_CONV_BWD_WEIGHT", "UZ_OP_LATENT_HEADS_BWD_WEIGHT") for o in ops[a:b + 1]) for a, b in groups]
+        # (round 5, measured under the lane replay and removed - commit 0cbd7b7 has the code: device-filling groups on a lane of their own
+        #  -7 %, weight-gradient-only groups on a low-priority lane -11 %, heavy weight gradients deferred behind the data-gradient chain -2 %;
+        #  profiles/NOTES_r5.md section 3)
         blevel = [0.0] * G
         for gi in reversed(range(G)):
             blevel[gi] = cost[gi] + max((blevel[sg] for sg in succ[gi]), default=0.0)
@@ -1900,10 +1878,6 @@ class Plan:
             started = False
             for gi in sorted((g for g in ready if ready_at[g] <= t + 1e-12), key=lambda g: (-blevel[g], g)):
                 lanes_free = [l for l in range(K) if l not in busy_lanes]
-                if typed is not None and pol == "wlane":
-                    lanes_free = [l for l in lanes_free if (l != K - 1) == typed[gi]]
-                elif typed is not None:
-                    lanes_free = [l for l in lanes_free if (l == K - 1) == typed[gi]]      # device-filling groups: the LAST lane (a library-owned stream: UZ_HEAVY_CUS)
                 if not lanes_free or (heavy[gi] and heavy_busy):
                     continue
                 pref = [l for l in lanes_free if tail[l] is not None and tail[l] in deps[gi]]

@@ -496,9 +496,6 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
                 }
                 __builtin_amdgcn_sched_barrier(0);           // ... and the next tap's work stays behind this tap's MFMAs
             }
-            // (128-channel tile: 128 accumulator registers - keep the scheduler from hoisting the next tap's six fragment reads above
-            //  this tap's eight MFMAs, which cost 15 spilled registers inside the loop)
-            if constexpr (MSUB == 4) __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (DB) {
             // hand-over: the patch of chunk c + 1 goes into the other image (nobody reads it: every wave passed the previous

@@ -375,28 +375,9 @@ LaneTrace g_lt;
 int lane_pool_reserve(int n_lanes, int n_events) {
     for (int l = 1; l < n_lanes; ++l) {
         if (!g_lp.lanes[l]) {
-            // UZ_LANE_PRIO: one letter per lane from lane 1 on - h(igh), n(ormal), l(ow) stream priority (default: all normal).  A low-priority
-            // lane's workgroups are dispatched when the other lanes leave room: deferred device-filling work (weight gradients) then fills
-            // the gaps of the critical chain instead of sharing the chip with it
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            const char* pr = getenv("UZ_LANE_PRIO");
-            const char c = (pr && (int)strlen(pr) >= l) ? pr[l - 1] : 'n';
-            const int prio = c == 'h' ? greatest : c == 'l' ? least : (least + greatest) / 2;
-            // UZ_HEAVY_CUS=<n>: the LAST lane (the device-filling lane of UZ_SCHED_POLICY=typed) may only use n of the 256 CUs - the
-            // latency-bound chains of the other lanes then always find free CUs instead of queueing behind device-filling workgroups
-            const char* hc = getenv("UZ_HEAVY_CUS");
-            const int ncu = hc ? atoi(hc) : 0;
-            if (l == n_lanes - 1 && ncu > 0 && ncu < 256) {
-                uint32_t mask[8];
-                const char* lay = getenv("UZ_HEAVY_CUS_LAYOUT");      // "lo" (default): the first 256 - n mask bits are cleared; "hi": the last ones
-                for (int b = 0; b < 256; ++b) {
-                    const bool on = (lay && lay[0] == 'h') ? b < ncu : b >= 256 - ncu;
-                    if (b % 32 == 0) mask[b / 32] = 0;
-                    if (on) mask[b / 32] |= 1u << (b % 32);
-                }
-                if (hipExtStreamCreateWithCUMask(&g_lp.lanes[l], 8, mask) != hipSuccess) return uz::fail("run_tape_lanes: cannot create the CU-masked lane stream");
-            } else if (hipStreamCreateWithPriority(&g_lp.lanes[l], hipStreamNonBlocking, prio) != hipSuccess) return uz::fail("run_tape_lanes: cannot create lane stream");
+            // (stream priorities and a CU-masked stream for one lane were measured in round 5 and removed: priorities change nothing, a masked
+            //  stream runs the heaviest convolution 27 % slower even with an all-ones mask - profiles/NOTES_r5.md section 3, commit 0cbd7b7)
+            if (hipStreamCreateWithFlags(&g_lp.lanes[l], hipStreamNonBlocking) != hipSuccess) return uz::fail("run_tape_lanes: cannot create lane stream");
         }
         if (!g_lp.join[l] && hipEventCreateWithFlags(&g_lp.join[l], hipEventDisableTiming) != hipSuccess) return uz::fail("run_tape_lanes: cannot create event");
     }
