@@ -589,6 +589,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling); default 32 (phiseg3d: 1 volume)")
     ap.add_argument("--reversible", action="store_true", help="phiseg3d: reversible blocks (the reference's BraTS experiment sets use_reversible)")
     ap.add_argument("--model", choices=sorted(MODELS), default="phiseg")
+    ap.add_argument("--tune-schedule", type=int, default=int(os.environ.get("UZ_TUNE_SCHEDULE", "3")),
+                    help="rounds of profile-guided lane scheduling before the timed region (Engine.tune_schedule; 0 = the static cost model)")
     ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-family HIP-event pass")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
@@ -700,6 +702,12 @@ def main():
 
     for _ in range(max(args.warmup, 3 if not args.no_graphs else 1)):
         loss = step()
+    tuned = None
+    if args.tune_schedule > 0 and not args.no_graphs and net.replay_mode == "lanes":
+        # profile-guided lane schedule (Engine.tune_schedule): set-up work like the graph capture, untimed, and every rank tunes its own
+        tuned = net.tune_schedule(step, rounds=args.tune_schedule)
+        for _ in range(2):
+            loss = step()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -829,7 +837,10 @@ def main():
                     vs_baseline=None, dtype=("bf16" if store_b16 else "bf16 arithmetic / f32 storage") if conv_math() == "bf16" else "f32", data="synthetic",
                     config=dict(workload=(M["workload"] % ("bf16" if store_b16 else "fp32")) if vol else M["workload"], batch_per_gpu=args.batch, global_batch=global_batch, parallelism=f"dp{world}",
                                 graphs=not args.no_graphs, replay=(getattr(net, "replay_mode", "graph") if not args.no_graphs else "eager, one stream"),
-                                lanes=getattr(plan, "n_lanes", None), final_loss=final_loss, conv_math=math_note),
+                                lanes=getattr(plan, "n_lanes", None),
+                                schedule=(dict(tuned_rounds=args.tune_schedule, **tuned, note="profile-guided lane schedule (Engine.tune_schedule) before the timed region")
+                                          if tuned else dict(cost_model=os.environ.get("UZ_SCHED_COST", getattr(plan, "sched_cost", "alone")))),
+                                final_loss=final_loss, conv_math=math_note),
                     roofline=roof)
         if world > 1:
             line["config"]["allreduce"] = "bucketed, overlapped with backward" if not args.no_overlap else "one blocking all-reduce after backward"

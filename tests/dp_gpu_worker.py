@@ -2,8 +2,9 @@
 two ranks on one device), checks the data-parallel gradient path of the native PHISeg on the device against the ORACLE:
   1. after the first loss.backward() every rank holds the SAME flat gradient buffer, and it equals
      mean_r(oracle_gradients(shard_r)) computed by the CPU oracle per shard (SURVEY.md 8e parity gate);
-  2. after two more steps (hipGraph capture + replay, bucketed exchange between backward and Adam) the parameters are still
-     bit-identical on every rank."""
+  2. after two more steps (hipGraph capture + replay, bucketed exchange between backward and Adam), a profile-guided re-scheduling of
+     the tapes (Engine.tune_schedule: one schedule and one bucket order on all ranks) and two steps under it, the gradients and
+     parameters are still bit-identical on every rank."""
 import os
 import sys
 
@@ -75,6 +76,18 @@ def main():
         devs.append(float((mine - v).abs().max() / (1e-3 + v.abs().max())))
         worst = max(worst, devs[-1])
     for _ in range(2):
+        step()
+    if net.replay_mode == "lanes":
+        # profile-guided schedule under data parallelism: the ranks agree on every measured number (dp.max_over_ranks), so they end with
+        # ONE schedule and one bucket exchange order - ranks that tuned on their own would exchange different buckets with each other
+        res = net.tune_schedule(step, rounds=2, samples=2, validate=2)
+        plan = net._cur
+        mine = [net._dp.order(plan), [o["lane"] for o in plan.bwd_ops]]
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        assert all(e == every[0] for e in every), "ranks hold different schedules after tune_schedule()"
+        print(f"rank {rank}: tuned {res['kept']} {res['step_ms']} bucket order {mine[0]}", flush=True)
+        g_dp = step()
         step()
     ref_g, ref_p = g_dp.clone(), net._ptab.pflat.clone()
     dist.broadcast(ref_g, src=0)

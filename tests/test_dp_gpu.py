@@ -16,6 +16,8 @@ def test_two_rank_gradient_allreduce_and_graph_replay_on_device():
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("identical_across_ranks=True") == 2, r.stdout[-2000:]
+    if os.environ.get("UZ_REPLAY", "lanes") == "lanes":
+        assert r.stdout.count(": tuned ") == 2, r.stdout[-2000:]
 
 
 def test_rccl_backend_world_size_one_step():

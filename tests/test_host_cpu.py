@@ -213,6 +213,37 @@ def test_bound_slot_readers_are_ordered_against_every_accumulator_at_the_headlin
     assert total > 300
 
 
+@pytest.mark.parametrize("cost_model", ["alone", "beside"])
+def test_rescheduling_with_measured_costs_keeps_every_dependency_and_restores_the_first_schedule(cost_model, monkeypatch):
+    """Engine.tune_schedule's CPU half: per-op measured durations (`cost_us`) replace the cost model, Plan.reschedule starts again from
+    the PROGRAM order (not from the previous schedule's order), the result is a different but equally valid schedule, and taking the
+    measured costs away again reproduces the first schedule op for op."""
+    import random
+    from unet_zoo_amd.models.phiseg import PHISeg
+    monkeypatch.setenv("UZ_LANES", "3")
+    monkeypatch.setenv("UZ_SCHED_HEAVY", "off")
+    monkeypatch.setenv("UZ_SCHED_COST", cost_model)
+    _, meta = G.load("phiseg_small")
+    net = PHISeg(1, 2, meta["filters"], image_size=(1, 64, 64), device="cpu")
+    plan = net._build(2, 64, 64, True, True)
+    rng = random.Random(7)
+    for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
+        first = [(id(o), o["lane"]) for o in ops]
+        members = {id(o) for o in ops}
+        for o in ops:
+            o["cost_us"] = rng.choice([3.0, 30.0, 300.0])
+        plan.reschedule(which)
+        assert {id(o) for o in ops} == members and len(ops) == len(first) == plan.tapes[which][1]
+        assert [(id(o), o["lane"]) for o in ops] != first
+        pairs, used, _ = _check_lane_schedule(plan, which, ops)
+        assert pairs > 100 and used == 3
+        for o in ops:
+            del o["cost_us"]
+        plan.reschedule(which)
+        assert [(id(o), o["lane"]) for o in ops] == first
+        _check_lane_schedule(plan, which, ops)
+
+
 # ----------------------------------------------------------------------------- U2: the three initialisers
 def _moments(t):
     a = t.detach().double()

@@ -467,6 +467,62 @@ def test_two_replayed_runs_at_the_headline_size_agree_bit_for_bit(lanes, monkeyp
         assert torch.equal(nets[0][0]._ptab.pflat, nets[1][0]._ptab.pflat), step
 
 
+def test_a_tuned_schedule_leaves_the_training_trajectory_bit_identical(monkeypatch):
+    """Engine.tune_schedule at the headline size: the profile-guided rounds really produce other schedules (measured per-op costs on the
+    plan's ops, a tape time per round), and a net stepped under the tuned schedule holds exactly the parameters and gradients of an
+    untuned twin stepped in lockstep - a schedule only chooses among orders the DAG allows."""
+    from unet_zoo_amd.models.phiseg import PHISeg
+    from unet_zoo_amd.optim import FusedAdam
+    from unet_zoo_amd.synthetic import synthetic_batch
+    monkeypatch.setenv("UZ_LANES", "3")
+    B = 32
+    x, m, _ = synthetic_batch(B, 128, 128, seed=5)
+    x, m = torch.from_numpy(x).to("cuda"), torch.from_numpy(m).to("cuda")
+    g = torch.Generator(device="cuda").manual_seed(7)
+    noise = [torch.randn(s_, generator=g, device="cuda") for s_ in [(B, 2, 2 << k, 2 << k) for k in range(5)] * 2]
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(1)
+        net = PHISeg(1, 2, [32, 64, 128, 192, 192, 192, 192], latent_levels=5, image_size=(1, 128, 128))
+        net.train()
+        net.enable_graphs(True)
+        nets.append((net, FusedAdam(net, lr=1e-3, weight_decay=1e-5)))
+    if nets[0][0].replay_mode != "lanes":
+        pytest.skip("tune_schedule() belongs to the lane replay")
+
+    def one(net, opt, update=True):
+        net.forward(x, m, training=True, eps=noise)
+        loss = net.loss(m)
+        opt.zero_grad()
+        loss.backward()
+        if update:
+            opt.step()
+    for net, opt in nets:
+        one(net, opt)
+    tuned, topt = nets[1]
+    plan = tuned._cur
+    before = {w: [(id(o), o["lane"]) for o in ops] for w, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops))}
+    calls = [0]
+
+    def tuned_step():                                 # no optimizer step: the twins stay in lockstep
+        calls[0] += 1
+        one(tuned, topt, update=False)
+    res = tuned.tune_schedule(tuned_step, rounds=2, samples=2, validate=2)
+    hist = res["tape_us"]
+    assert set(hist) == {"fwd", "bwd"} and all(len(v) == 3 and min(v) > 100.0 for v in hist.values()), res
+    assert res["kept"] in ("initial", "tuned") and set(res["step_ms"]) == {"initial", "tuned"}, res
+    after = {w: [(id(o), o["lane"]) for o in ops] for w, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops))}
+    print("tuning:", res, "schedule changed:", {w: before[w] != after[w] for w in before})
+    for _ in range(calls[0]):                        # the twin sees the same batches (BatchNorm running statistics)
+        one(nets[0][0], nets[0][1], update=False)
+    for step in range(3):
+        for net, opt in nets:
+            one(net, opt)
+        torch.cuda.synchronize()
+        assert torch.equal(nets[0][0]._ptab.gflat, nets[1][0]._ptab.gflat), step
+        assert torch.equal(nets[0][0]._ptab.pflat, nets[1][0]._ptab.pflat), step
+
+
 def test_fused_latent_heads_leave_the_training_step_bit_identical(monkeypatch):
     """Plan.latent_heads (one op per direction for the two heads + sampling tail of every SampleZBlock, phiseg.py:95-105) against the
     plan with the separate ops (UZ_FUSE_HEADS=0): same loss, same gradients, same parameters after three Adam steps, bit for bit, and

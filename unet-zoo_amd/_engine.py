@@ -177,6 +177,9 @@ class NativeModel(nn.Module):
             plan.n_lanes = self.default_lanes_by_mode.get(self.replay_mode, self.default_lanes)
         # the scheduler's "one device-filling group at a time" rule pays in the graph replay only
         plan.sched_heavy = os.environ.get("UZ_SCHED_HEAVY", "off" if self.replay_mode == "lanes" else "r4")
+        # the lane replay is scheduled with durations as it realises them beside other lanes' kernels (Plan._op_cost_beside), and
+        # tune_schedule() refines them by measurement; the graph replay keeps the isolated-launch model its rule was measured with
+        plan.sched_cost = os.environ.get("UZ_SCHED_COST", "beside" if self.replay_mode == "lanes" else "alone")
         plan.decouple_wgrad_px = self.decouple_wgrad_px
         plan.decouple_wgrad_prefixes = tuple(self.decouple_wgrad_prefixes)
         dp = getattr(self, "_dp", None)
@@ -238,8 +241,16 @@ class NativeModel(nn.Module):
         if self.replay_mode == "lanes" and plan.n_lanes > 1 and which in plan.scheds:
             # the tape's DAG issued by the host on one stream per lane, one event per cross-lane edge (uz_run_tape_lanes)
             arr, n = plan.tapes[which]
+            rec = self.__dict__.get("_tune_rec")
+            if n and rec is not None:                      # tune_schedule(): one timing event behind every op of this call
+                plan.L.uz_lane_trace(1, n, None, 0)
             if n:
                 _ffi.check(plan.L.uz_run_tape_lanes(arr, plan.scheds[which], n, plan.n_lanes, C.c_void_p(self._stream())), f"lane replay '{which}'")
+            if n and rec is not None:
+                buf = (C.c_float * n)()
+                got = plan.L.uz_lane_trace(0, 0, buf, n)
+                assert got == n, (got, n)
+                rec.setdefault((id(plan), which), (plan, []))[1].append([buf[k] * 1e3 for k in range(n)])
             return
         key = (id(plan), which)
         g = self._graphs.get(key)
@@ -257,6 +268,91 @@ class NativeModel(nn.Module):
                 _ffi.check(plan.L.uz_graph_launch(handle, st), f"graph launch '{which}'")
             if ev is not None:
                 _ffi.check(plan.L.uz_event_record(plan.events[ev], st), "event_record")
+
+    def tune_schedule(self, step, rounds=3, samples=5, damping=0.5, validate=8):
+        """Profile-guided lane schedule (lane replay only; the counterpart of cudnn.benchmark for the tape scheduler).  `step` is the
+        caller's closure that runs one forward / loss / backward on this model.  Each round replays it `samples` times with a timing event
+        behind every op, sets every op's cost to the duration the replay REALISED for it beside the other lanes' kernels (start = the later
+        of its lane predecessor and the ops it waits for; damped against the cost the current schedule was built from) and schedules the
+        tapes again.  Per tape the fastest schedule seen (median tape time of its samples) is the candidate; the candidates are then timed
+        against the schedules the call started with over `validate` un-instrumented steps each (twice, alternating) and the faster set
+        stays - so the call never leaves a slower schedule behind than it found.  Any schedule of the DAG gives the same bits
+        (Plan.reschedule).  Returns {"tape_us": {tape: [median microseconds per round]}, "step_ms": {"initial": a, "tuned": b}, "kept": which}."""
+        assert self._use_graphs and self.replay_mode == "lanes", "tune_schedule() needs enable_graphs() with the lane replay"
+        import statistics, time
+        from ._plan import Plan
+        from . import dp as _dp_mod
+        grp = getattr(self, "_dp_group", None)
+        if getattr(self, "_dp", None) is None:
+            def allmax(v):
+                return [float(x) for x in v]
+        else:                                             # data parallel: one schedule for all ranks (the bucket exchange order follows it)
+            def allmax(v):
+                return _dp_mod.max_over_ranks(v, None if grp is True else grp)
+
+        def tape_ops(plan, which):
+            return {"fwd": plan.fwd_ops, "bwd": plan.bwd_ops}.get(which) or plan.extra_ops.get(which)
+
+        def apply(costs):
+            for (pid, which), (used, plan) in costs.items():
+                for o in tape_ops(plan, which):
+                    c = used[id(o)]
+                    if c is None:
+                        o.pop("cost_us", None)
+                    else:
+                        o["cost_us"] = c
+                plan.reschedule(which)
+        hist, best, first = {}, {}, {}
+        for r in range(rounds + 1):
+            self.__dict__["_tune_rec"] = rec = {}
+            try:
+                for _ in range(samples):
+                    step()
+            finally:
+                self.__dict__["_tune_rec"] = None
+            for (pid, which), (plan, runs) in rec.items():          # (same plans, same order on every rank: the closure ran the same calls)
+                if plan.n_lanes <= 1:
+                    continue
+                ops, sc = tape_ops(plan, which), plan.scheds[which]
+                wall = allmax([statistics.median(max(e) for e in runs)])[0]
+                hist.setdefault(which, []).append(round(wall, 1))
+                used = {id(o): o.get("cost_us") for o in ops}
+                first.setdefault((pid, which), (used, plan))
+                if (pid, which) not in best or wall < best[(pid, which)][0]:
+                    best[(pid, which)] = (wall, used, plan)
+                if r == rounds:
+                    continue
+                cmodel = Plan._op_cost_beside if os.environ.get("UZ_SCHED_COST", plan.__dict__.get("sched_cost", "alone")) == "beside" else Plan._op_cost
+                last, dur = {}, [0.0] * len(ops)
+                for e in runs:
+                    last.clear()
+                    for k, o in enumerate(ops):
+                        pred = ([last[o["lane"]]] if o["lane"] in last else []) + [sc[k].wait[w] for w in range(sc[k].n_wait)]
+                        dur[k] += (e[k] - max((e[j] for j in pred), default=0.0)) / len(runs)
+                        last[o["lane"]] = k
+                dur = allmax(dur)
+                for k, o in enumerate(ops):
+                    old = o["cost_us"] if "cost_us" in o else cmodel(o) * 1e6
+                    o["cost_us"] = max(1.0, damping * old + (1.0 - damping) * dur[k])
+                plan.reschedule(which)
+        if not best:
+            return dict(tape_us=hist, step_ms={}, kept="initial")
+        sets = {"initial": first, "tuned": {k: (used, plan) for k, (_w, used, plan) in best.items()}}
+        ms = {"initial": [], "tuned": []}
+        for _ in range(2):
+            for name in ("initial", "tuned"):
+                apply(sets[name])
+                step()
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                for _ in range(validate):
+                    step()
+                torch.cuda.synchronize(self.device)
+                ms[name].append(1e3 * (time.perf_counter() - t0) / validate)
+        ms = {name: allmax(v) for name, v in ms.items()}
+        kept = "tuned" if min(ms["tuned"]) < min(ms["initial"]) else "initial"
+        apply(sets[kept])
+        return dict(tape_us=hist, step_ms={k: round(min(v), 3) for k, v in ms.items()}, kept=kept)
 
     # ------------------------------------------------------------------ backward
     def set_data_parallel(self, group=True, overlap=True, backend=None):

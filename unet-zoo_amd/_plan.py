@@ -1563,14 +1563,26 @@ class Plan:
                 k += 1
         if vals:
             self.ptrtab.copy_(torch.tensor(vals, dtype=torch.int64))
-        self.tapes, self.scheds = {}, {}
+        self.tapes, self.scheds, self._program_order = {}, {}, {}
         for nm, ops in (("fwd", self.fwd_ops), ("loss", self.loss_ops), ("bwd", self.bwd_ops), *self.extra_ops.items()):
+            self._program_order[nm] = list(ops)              # the scheduler reorders `ops` in place; reschedule() starts from this order again
             self.scheds[nm] = self._schedule(ops)
             self.tapes[nm] = self._materialize(ops)
         self.loss_scale_t = self.tensor(self.loss_scale).view(1)
         self.loss_scale_t.fill_(1.0)
         self.finalized = True
         return self
+
+    def reschedule(self, which):
+        """Schedules tape `which` again from its program order - after the per-op durations (`o["cost_us"]`, Engine.tune_schedule)
+        or the scheduler's settings changed - and rebuilds its op array.  Any schedule of the same DAG gives the same bits: ordered
+        pairs stay ordered, and the only unordered writers of one location are the commuting magnitude-bound maxima."""
+        ops = {"fwd": self.fwd_ops, "bwd": self.bwd_ops, "loss": self.loss_ops}.get(which)
+        if ops is None:
+            ops = self.extra_ops[which]
+        ops[:] = self._program_order[which]
+        self.scheds[which] = self._schedule(ops)
+        self.tapes[which] = self._materialize(ops)
 
     def _resolve(self, r, lane=0):
         if r is None:
@@ -1753,6 +1765,35 @@ class Plan:
         return 6e-6
 
     @staticmethod
+    def _op_cost_beside(o):
+        """Duration (s) of one op as the lane replay REALISES it beside the other lanes' kernels (round 5: fitted per op class to the
+        per-op lane traces profiles/r5_lane_trace_{fwd,bwd}.json of the headline configuration, tools/sched_calibrate.py prints the fit).
+        The isolated model above is 2 - 6x short for the small launches (a 7-us convolution takes 33 - 45 us beside a device-filling
+        kernel) and 1.4 - 10x long for the large ones: the list scheduler then queued off-critical weight gradients in front of a
+        critical chain on the same lane and the chain started 2 ms late."""
+        c = o["code"]
+        m = Plan._op_cost(o) * 1e6
+        if c in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA"):
+            us = 28.0 + 0.62 * m
+        elif c == "UZ_OP_CONV_BWD_WEIGHT":
+            us = 25.0 + 0.70 * m
+        elif c == "UZ_OP_BN_RELU_FWD":
+            us = 20.0 + 0.50 * m
+        elif c in ("UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
+            us = 25.0 + 0.80 * m
+        elif c in ("UZ_OP_AVGPOOL_FWD", "UZ_OP_AVGPOOL_BWD"):
+            us = 12.0 + 0.06 * m
+        elif c in ("UZ_OP_BILINEAR_FWD", "UZ_OP_BILINEAR_BWD", "UZ_OP_NEAREST_FWD", "UZ_OP_NEAREST_BWD"):
+            us = 18.0 + 0.42 * m
+        elif c == "UZ_OP_WGRAD_REDUCE_TABLE":
+            us = 300.0
+        elif c in ("UZ_OP_MEMSET",):
+            us = 8.0
+        else:
+            us = 25.0
+        return us * 1e-6
+
+    @staticmethod
     def _op_heavy(o):
         """True for ops that fill the chip on their own (only one of those is simulated in flight at a time)."""
         c, i = o["code"], o["i"]
@@ -1839,7 +1880,11 @@ class Plan:
                 keep.append([lo, hi, gi, set(), set()])
                 hist[space] = keep
         # ---- 2. list scheduling in simulated time
-        cost = [sum(self._op_cost(o) for o in ops[a:b + 1]) for a, b in groups]
+        # UZ_SCHED_COST: "alone" = the isolated-launch model, "beside" = the model fitted to the lane replay's realised durations
+        cmodel = os.environ.get("UZ_SCHED_COST", self.__dict__.get("sched_cost", "alone"))
+        assert cmodel in ("alone", "beside"), cmodel
+        op_cost = self._op_cost_beside if cmodel == "beside" else self._op_cost
+        cost = [sum((o["cost_us"] * 1e-6 if "cost_us" in o else op_cost(o)) for o in ops[a:b + 1]) for a, b in groups]    # cost_us: measured (tune_schedule)
         succ = [[] for _ in range(G)]
         indeg = [len(d) for d in deps]
         for gi, d in enumerate(deps):
@@ -1942,7 +1987,8 @@ class Plan:
                 ops[k]["lane"] = lane
         # the scheduled DAG, for diagnostics (tools/critical_path.py): per group in schedule order its op range, lane and predecessors
         pos = {gi: n_ for n_, gi in enumerate(order)}
-        self.__dict__.setdefault("dag", {})[id(ops)] = [dict(first=first[gi], last=last[gi], lane=lane_of[gi], deps=sorted(pos[d] for d in deps[gi]))
+        self.__dict__.setdefault("dag", {})[id(ops)] = [dict(first=first[gi], last=last[gi], lane=lane_of[gi], deps=sorted(pos[d] for d in deps[gi]),
+                                                              sim_start=finish[gi] - cost[gi], sim_cost=cost[gi], blevel=blevel[gi])
                                                          for gi in order]
         return sched
 

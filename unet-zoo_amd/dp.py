@@ -73,6 +73,20 @@ def or_flags(word, group=None, bits=3):
     return sum(int(v) << b for b, v in enumerate(t.tolist()))
 
 
+def max_over_ranks(values, group=None):
+    """Element-wise MAX of a list of host floats over the ranks in one collective (identity for a single process): every rank gets the
+    same list back, so decisions taken from it (Engine.tune_schedule: per-op durations, tape times, which schedule stays) are the same
+    on every rank - the bucket exchange order follows the scheduled tape and must not differ between ranks."""
+    vals = [float(v) for v in values]
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or not vals:
+        return vals
+    t = torch.tensor(vals, dtype=torch.float64)
+    if dist.get_backend(group) != "gloo":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t.tolist()
+
+
 def shard_bounds(n, rank, world):
     """Contiguous [lo, hi) slice of n samples owned by `rank` (sizes differ by at most one)."""
     base, rem = divmod(n, world)
