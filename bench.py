@@ -589,7 +589,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling); default 32 (phiseg3d: 1 volume)")
     ap.add_argument("--reversible", action="store_true", help="phiseg3d: reversible blocks (the reference's BraTS experiment sets use_reversible)")
     ap.add_argument("--model", choices=sorted(MODELS), default="phiseg")
-    ap.add_argument("--tune-schedule", type=int, default=int(os.environ.get("UZ_TUNE_SCHEDULE", "3")),
+    ap.add_argument("--tune-schedule", type=int, default=int(os.environ.get("UZ_TUNE_SCHEDULE", "8")),
                     help="rounds of profile-guided lane scheduling before the timed region (Engine.tune_schedule; 0 = the static cost model)")
     ap.add_argument("--no-graphs", action="store_true", help="launch kernels eagerly instead of hipGraph replay")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-family HIP-event pass")

@@ -29,10 +29,14 @@ def dump():
     n = L.uz_lane_trace(0, 0, buf, 1024)
     return [buf[k] for k in range(n)]
 for _ in range(6): step()
+if int(os.environ.get("UZ_TUNE_SCHEDULE", "0")) > 0:        # trace the profile-guided schedule instead of the static one
+    print("tuned:", net.tune_schedule(step, rounds=int(os.environ["UZ_TUNE_SCHEDULE"])))
+    step()
 torch.cuda.synchronize()
 ends = step(which)
 plan = next(iter(net._plans.values()))
 ops = plan.fwd_ops if which == "fwd" else plan.bwd_ops
+sc = plan.scheds[which]
 rows = []
 last = {}
 for k, (o, e) in enumerate(zip(ops, ends)):
@@ -41,7 +45,8 @@ for k, (o, e) in enumerate(zip(ops, ends)):
     if c.startswith("CONV"): shape = f"{i[0]}->{i[2]}@{i[5]}x{i[6]}k{i[7]}"
     elif c == "BN_RELU_FWD": shape = f"C{i[0]}@{i[4]}x{i[5]}"
     elif c == "BN_RELU_BWD": shape = f"C{i[1]}@{i[5]}x{i[6]}"
-    rows.append(dict(k=k, lane=o["lane"], gid=o["gid"], code=c, shape=shape, end_us=round(e * 1e3, 1), since_lane_prev_us=round((e - last.get(o["lane"], 0.0)) * 1e3, 1)))
+    rows.append(dict(k=k, lane=o["lane"], gid=o["gid"], code=c, shape=shape, end_us=round(e * 1e3, 1), since_lane_prev_us=round((e - last.get(o["lane"], 0.0)) * 1e3, 1),
+                     wait=[sc[k].wait[w] for w in range(sc[k].n_wait)]))
     last[o["lane"]] = e
 print(f"{which}: {len(rows)} ops, last end {max(r['end_us'] for r in rows):.0f} us")
 for r in rows: print(f"{r['k']:4d} lane{r['lane']} {r['end_us']:9.1f} (+{r['since_lane_prev_us']:7.1f}) {r['code']:22s} {r['shape']}")

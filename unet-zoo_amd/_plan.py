@@ -1786,7 +1786,7 @@ class Plan:
         elif c in ("UZ_OP_BILINEAR_FWD", "UZ_OP_BILINEAR_BWD", "UZ_OP_NEAREST_FWD", "UZ_OP_NEAREST_BWD"):
             us = 18.0 + 0.42 * m
         elif c == "UZ_OP_WGRAD_REDUCE_TABLE":
-            us = 300.0
+            us = 8.0 + 0.0031 * o["i"][1]                 # HBM-bound: PHiSeg's 106 layers = 95 301 blocks take 300 us
         elif c in ("UZ_OP_MEMSET",):
             us = 8.0
         else:
