@@ -116,6 +116,14 @@ def test_kernel_resource_table_matches_the_sources_and_the_budgets():
     w = tab["conv_wgrad_split.hip"]["kernels"]
     heavy = [v for n, v in w.items() if n.startswith("wgrad_split_kernel<32, 64, 2")]
     assert heavy and all(v["vgpr"] <= 256 and v["scratch"] == 0 for v in heavy), heavy      # (236 - 254 since the bound predicate is accumulated over every tile)
+    # Footprint discipline of the deep levels' BatchNorm launches: the headline convolution holds two waves x 184 VGPRs per SIMD, so a
+    # workgroup with W waves per SIMD starts beside it only under (512 - 2 * 184) / W registers (tools/bench_coresidency.py: 5 us alone,
+    # 9 us beside the convolution under the budget, 65 - 77 us above it)
+    free = 512 - 2 * k["conv_splitp_db_kernel_2_512_32"]["vgpr"]
+    b = tab["bn.hip"]["kernels"]
+    for name, waves in (("bn_fused_small_fwd<2>", 1), ("bn_fused_small_bwd<2>", 1), ("bn_fused_small_fwd<8>", 1), ("bn_fused_small_bwd<8>", 1),
+                        ("bn_fused_mid_fwd<false, 512, 4>", 2), ("bn_fused_mid_fwd<true, 512, 4>", 2), ("bn_fused_mid_bwd<512, 4>", 2)):
+        assert -(-b[name]["vgpr"] // 8) * 8 * waves <= free, (name, b[name], free)
 
 
 def _check_lane_schedule(plan, which, ops):

@@ -260,11 +260,14 @@ __global__ __launch_bounds__(256) void bn_apply(const BnP p) {
 }
 
 // ------------------------------------------------------------------ forward, small path (one WG / channel)
-constexpr int EPT = SMALL_LIMIT / 256;      // elements per thread on the small path: a channel's whole batch lives in registers
-#ifndef UZ_BN_SMALL_OCC
-#define UZ_BN_SMALL_OCC 0       // experiment builds: minimum waves per SIMD of the one-workgroup-per-channel kernels (4 -> at most 128 VGPRs)
-#endif
-__global__ __launch_bounds__(256, UZ_BN_SMALL_OCC ? UZ_BN_SMALL_OCC : 1) void bn_fused_small_fwd(const BnP p) {
+// EPT elements per thread: a channel's whole batch lives in registers.  Three instances (2 / 8 / 16 elements: N*H*W <= 512 / 2048 / 4096,
+// i.e. the 2x2 + 4x4 / 8x8 / larger planes at batch 32) instead of one sized for the largest: the deep levels' instances stay under
+// the registers a device-filling convolution leaves free on a SIMD (2 waves x 184 of 512), so their workgroups start beside it instead
+// of waiting for one of its workgroups to retire (tools/bench_coresidency.py: 5 us alone, 65 us beside the convolution at 156 VGPRs).
+// Same element-to-thread mapping and the same order of every sum in all three: bit-identical results.
+constexpr int small_ept(int total) { return total <= 2 * 256 ? 2 : total <= 8 * 256 ? 8 : SMALL_LIMIT / 256; }
+template <int EPT>
+__global__ __launch_bounds__(256) void bn_fused_small_fwd(const BnP p) {
     __shared__ double sm[8];
     __shared__ float bc[2];
     const int c = blockIdx.x;
@@ -291,8 +294,8 @@ __global__ __launch_bounds__(256, UZ_BN_SMALL_OCC ? UZ_BN_SMALL_OCC : 1) void bn
         for (int j = 0; j < EPT; ++j) v[j] = bv;
         // four slabs' loads in flight per round (the rounds are dependent trips to L2 / HBM: 12 slabs one at a time made this launch
         // 20 us); added in slab order.  E = elements per thread in use, as a compile-time bound (8 / 2 / 1 on 8x8 / 4x4 / 2x2 at batch 32)
-        auto add_slabs = [&](auto Ec) {
-            constexpr int E = decltype(Ec)::value, U = E <= 8 ? 4 : 1;
+        {
+            constexpr int E = EPT, U = E <= 8 ? 4 : 1;
             int k = 0;
             for (; k + U <= p.nslab; k += U) {
                 float t[U][E];
@@ -314,10 +317,7 @@ __global__ __launch_bounds__(256, UZ_BN_SMALL_OCC ? UZ_BN_SMALL_OCC : 1) void bn
 #pragma unroll
                 for (int j = 0; j < E; ++j) v[j] += t[j];
             }
-        };
-        if (total <= 2 * 256) add_slabs(std::integral_constant<int, 2>{});
-        else if (total <= 8 * 256) add_slabs(std::integral_constant<int, 8>{});
-        else add_slabs(std::integral_constant<int, EPT>{});
+        }
 #pragma unroll
         for (int j = 0; j < EPT; ++j)
             if (threadIdx.x + 256 * j < total) ywr[((size_t)(bq[j] >> 12) * p.CtotY + c) * p.HW + (bq[j] & 4095)] = v[j];
@@ -747,7 +747,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_st(const BnP p) {
 }
 
 // ------------------------------------------------------------------ backward, small path
-__global__ __launch_bounds__(256, UZ_BN_SMALL_OCC ? UZ_BN_SMALL_OCC : 1) void bn_fused_small_bwd(const BnP p) {
+template <int EPT>
+__global__ __launch_bounds__(256) void bn_fused_small_bwd(const BnP p) {
     __shared__ double sm[8];
     __shared__ float bc[2];
     const int c = blockIdx.x;
@@ -831,22 +832,25 @@ __global__ __launch_bounds__(256, UZ_BN_SMALL_OCC ? UZ_BN_SMALL_OCC : 1) void bn
 // (Samuelson), hence |a| <= max_c (|gamma_c| sqrt(n - 1) + |beta_c|).  That bound is loose by sqrt(n) / (actual max |x_hat|) ~ 2^5:
 // an element is then stored to max(2^-22 |a|, 2^-33 A) instead of max(2^-22 |a|, 2^-38 A) - still 2^9 below fp32's own rounding of
 // the tensor's large elements.
-template <bool PK>
-__global__ __launch_bounds__(1024) void bn_fused_mid_fwd(const BnP p) {
-    __shared__ double smd[16 * 2];
+// NT threads x E4 float4 per thread (round 5): <1024, 8> up to 32 768 values per channel; <512, 4> up to 8 192 (the 16 x 16 level at
+// batch 32) - two waves per SIMD under 72 VGPRs, which start beside a device-filling convolution's two waves instead of waiting for
+// a whole CU's registers (see bn_fused_small_fwd).
+template <bool PK, int NT, int E4>
+__global__ __launch_bounds__(NT) void bn_fused_mid_fwd(const BnP p) {
+    __shared__ double smd[(NT / 64) * 2];
     __shared__ float bc[3];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hw4 = p.HW / 4, total4 = p.N * hw4;
-    float4 yv[8];
+    float4 yv[E4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int e = tid + j * 1024;
+    for (int j = 0; j < E4; ++j) {
+        const int e = tid + j * NT;
         const int b = e / hw4, q = e - b * hw4;
         yv[j] = e < total4 ? *reinterpret_cast<const float4*>(p.y + ((size_t)b * p.CtotY + c) * p.HW + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     double v2[2] = {0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < E4; ++j) {
         const float s = (yv[j].x + yv[j].y) + (yv[j].z + yv[j].w);
         const float ss = (yv[j].x * yv[j].x + yv[j].y * yv[j].y) + (yv[j].z * yv[j].z + yv[j].w * yv[j].w);
         v2[0] += (double)s; v2[1] += (double)ss;                     // (padding elements are zeros)
@@ -864,7 +868,7 @@ __global__ __launch_bounds__(1024) void bn_fused_mid_fwd(const BnP p) {
     __syncthreads();
     if (tid == 0) {
         double a = 0.0, b = 0.0;
-        for (int w = 0; w < 16; ++w) { a += smd[w * 2]; b += smd[w * 2 + 1]; }
+        for (int w = 0; w < NT / 64; ++w) { a += smd[w * 2]; b += smd[w * 2 + 1]; }
         const double n = (double)p.N * p.HW;
         const double m = a / n;
         double var = b / n - m * m;
@@ -886,8 +890,8 @@ __global__ __launch_bounds__(1024) void bn_fused_mid_fwd(const BnP p) {
     const float s = PK ? uz::split_scale(bc[2]) : 1.f;
     float vmax = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int e = tid + j * 1024;
+    for (int j = 0; j < E4; ++j) {
+        const int e = tid + j * NT;
         if (e < total4) {
             const int b = e / hw4, q = e - b * hw4;
             float4 r;
@@ -919,9 +923,10 @@ __global__ __launch_bounds__(1024) void bn_fused_mid_fwd(const BnP p) {
 // (reduce: dA, y; apply: dA, y, dy; bias-gradient summation): 192 ch @ 32 x 32: 32 -> 13 us.  The price: the tensor-wide bound of dy
 // is only known when every workgroup is done, so dy cannot be written as split storage here - its bound is atomic-max accumulated
 // like the small path's (the plans pack dy on the larger planes only).
-constexpr int MID_LIMIT = 32768, MID_NT = 1024, MID_EPT4 = MID_LIMIT / MID_NT / 4;      // float4 per thread: 8
-__global__ __launch_bounds__(MID_NT) void bn_fused_mid_bwd(const BnP p) {
-    __shared__ double smd[16 * 2];
+constexpr int MID_LIMIT = 32768, MID_HALF_LIMIT = 8192;      // <1024 threads, 8 float4 each> | <512, 4> (see bn_fused_mid_fwd)
+template <int MID_NT, int MID_EPT4>
+__global__ __launch_bounds__(MID_NT) __attribute__((amdgpu_waves_per_eu(MID_NT == 512 ? 7 : 4, 8))) void bn_fused_mid_bwd(const BnP p) {
+    __shared__ double smd[(MID_NT / 64) * 2];
     __shared__ float bc[2];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hw4 = p.HW / 4, total4 = p.N * hw4;
@@ -1104,12 +1109,22 @@ static int bn_relu_fwd_impl(const float* y, int C, int CtotY, const float* gamma
     UZ_REQUIRE(!slabs || (n_slabs > 1 && (size_t)N * p.HW <= SMALL_LIMIT), "bn_relu_fwd_slabs: split-K slabs only serve the small-plane path (N*H*W <= 4096)");
     if ((size_t)N * p.HW <= SMALL_LIMIT) {
         p.slab = slabs; p.nslab = n_slabs; p.cbias = conv_bias; p.ywr = const_cast<float*>(y);
-        hipLaunchKernelGGL(bn_fused_small_fwd, dim3(C), dim3(256), 0, st, p);
+        switch (small_ept(N * H * W)) {
+            case 2: hipLaunchKernelGGL(bn_fused_small_fwd<2>, dim3(C), dim3(256), 0, st, p); break;
+            case 8: hipLaunchKernelGGL(bn_fused_small_fwd<8>, dim3(C), dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL(bn_fused_small_fwd<SMALL_LIMIT / 256>, dim3(C), dim3(256), 0, st, p);
+        }
         return uz::check_launch("bn_fused_small_fwd");
     }
     if (mid) {
-        if (out_packed) hipLaunchKernelGGL(bn_fused_mid_fwd<true>, dim3(C), dim3(1024), 0, st, p);
-        else hipLaunchKernelGGL(bn_fused_mid_fwd<false>, dim3(C), dim3(1024), 0, st, p);
+        const bool half = (size_t)N * p.HW <= MID_HALF_LIMIT;
+        if (half) {
+            if (out_packed) hipLaunchKernelGGL((bn_fused_mid_fwd<true, 512, 4>), dim3(C), dim3(512), 0, st, p);
+            else hipLaunchKernelGGL((bn_fused_mid_fwd<false, 512, 4>), dim3(C), dim3(512), 0, st, p);
+        } else {
+            if (out_packed) hipLaunchKernelGGL((bn_fused_mid_fwd<true, 1024, 8>), dim3(C), dim3(1024), 0, st, p);
+            else hipLaunchKernelGGL((bn_fused_mid_fwd<false, 1024, 8>), dim3(C), dim3(1024), 0, st, p);
+        }
         return uz::check_launch("bn_fused_mid_fwd");
     }
     const bool vec = vec_ok(p.HW, y, a, nullptr);
@@ -1207,12 +1222,17 @@ extern "C" int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, in
     p.training = 1; p.relu = relu; p.amax = dy_amax;
     if ((size_t)N * p.HW <= SMALL_LIMIT) {
         p.slab = da_slabs; p.nslab = n_da_slabs;
-        hipLaunchKernelGGL(bn_fused_small_bwd, dim3(C), dim3(256), 0, st, p);
+        switch (small_ept(N * H * W)) {
+            case 2: hipLaunchKernelGGL(bn_fused_small_bwd<2>, dim3(C), dim3(256), 0, st, p); break;
+            case 8: hipLaunchKernelGGL(bn_fused_small_bwd<8>, dim3(C), dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL(bn_fused_small_bwd<SMALL_LIMIT / 256>, dim3(C), dim3(256), 0, st, p);
+        }
         return uz::check_launch("bn_fused_small_bwd");
     }
     static const bool mid_on = !(getenv("UZ_BN_MID") && atoi(getenv("UZ_BN_MID")) == 0);
     if (mid_on && !conv_partials && !out_packed && !dbias_partials && (size_t)N * p.HW <= MID_LIMIT && vec_ok(p.HW, y, da, dy)) {
-        hipLaunchKernelGGL(bn_fused_mid_bwd, dim3(C), dim3(MID_NT), 0, st, p);
+        if ((size_t)N * p.HW <= MID_HALF_LIMIT) hipLaunchKernelGGL((bn_fused_mid_bwd<512, 4>), dim3(C), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((bn_fused_mid_bwd<1024, 8>), dim3(C), dim3(1024), 0, st, p);
         return uz::check_launch("bn_fused_mid_bwd");
     }
     UZ_REQUIRE(workspace, "bn_relu_bwd: workspace required");
