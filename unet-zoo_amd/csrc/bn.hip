@@ -996,6 +996,12 @@ __global__ __launch_bounds__(MID_NT) __attribute__((amdgpu_waves_per_eu(MID_NT =
     }
 }
 
+// UZ_BN_MID_HALF=0: the 1 024-thread instances also for <= 8 192 values per channel (A/B only)
+static bool mid_half_on() {
+    static const bool on = !(getenv("UZ_BN_MID_HALF") && atoi(getenv("UZ_BN_MID_HALF")) == 0);
+    return on;
+}
+
 // (round 4, measured and dropped: a "cluster" variant for the 64 x 64 / 128 x 128 levels - G = N*H*W / 32768 workgroups per channel,
 //  each keeping its slice of y and dA in registers, meeting on a device-scope counter, adding the G partials in a fixed order - i.e.
 //  one launch and three passes instead of three launches and five.  128 ch @ 128 x 128 ran 697 us against 266 us: the agent-scope
@@ -1117,7 +1123,7 @@ static int bn_relu_fwd_impl(const float* y, int C, int CtotY, const float* gamma
         return uz::check_launch("bn_fused_small_fwd");
     }
     if (mid) {
-        const bool half = (size_t)N * p.HW <= MID_HALF_LIMIT;
+        const bool half = (size_t)N * p.HW <= MID_HALF_LIMIT && mid_half_on();
         if (half) {
             if (out_packed) hipLaunchKernelGGL((bn_fused_mid_fwd<true, 512, 4>), dim3(C), dim3(512), 0, st, p);
             else hipLaunchKernelGGL((bn_fused_mid_fwd<false, 512, 4>), dim3(C), dim3(512), 0, st, p);
@@ -1231,7 +1237,7 @@ extern "C" int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, in
     }
     static const bool mid_on = !(getenv("UZ_BN_MID") && atoi(getenv("UZ_BN_MID")) == 0);
     if (mid_on && !conv_partials && !out_packed && !dbias_partials && (size_t)N * p.HW <= MID_LIMIT && vec_ok(p.HW, y, da, dy)) {
-        if ((size_t)N * p.HW <= MID_HALF_LIMIT) hipLaunchKernelGGL((bn_fused_mid_bwd<512, 4>), dim3(C), dim3(512), 0, st, p);
+        if ((size_t)N * p.HW <= MID_HALF_LIMIT && mid_half_on()) hipLaunchKernelGGL((bn_fused_mid_bwd<512, 4>), dim3(C), dim3(512), 0, st, p);
         else hipLaunchKernelGGL((bn_fused_mid_bwd<1024, 8>), dim3(C), dim3(1024), 0, st, p);
         return uz::check_launch("bn_fused_mid_bwd");
     }

@@ -153,6 +153,11 @@ class UNetModel:
         if self.world > 1:
             self.net.set_data_parallel(True, backend="rccl" if torch.cuda.is_available() and os.environ.get("UZ_DP_BACKEND", "rccl") == "rccl" else "torch")
             self.net._dp.broadcast_params()
+        # static shapes: replay the tapes' dependency DAGs on the engine's lanes (NativeModel.enable_graphs; bit-identical to the
+        # one-stream tape) and, once the plan exists, let the engine measure its own schedule (tune_schedule; UZ_TUNE_SCHEDULE rounds, 0 = off)
+        if torch.cuda.is_available() and hasattr(self.net, "enable_graphs") and os.environ.get("UZ_TRAIN_REPLAY", "1") != "0":
+            self.net.enable_graphs(True)
+        self._tune_rounds = int(os.environ.get("UZ_TUNE_SCHEDULE", "8"))
         self.log_root = log_root
         self.tot_loss = self.kl_loss = self.reconstruction_loss = 0
         self.iteration = 0
@@ -183,6 +188,27 @@ class UNetModel:
         self.optimizer.step()
         return self.loss
 
+    def tune_schedule(self):
+        """Profile-guided lane schedule on the batch of the last train_step (NativeModel.tune_schedule): every tuning pass starts from
+        the same BatchNorm buffers, counters and noise-stream position (snapshot_step / restore_step) and leaves them as it found
+        them; no optimiser step runs; gradients are overwritten by the next step anyway.  Collective under data parallelism."""
+        net = self.net
+        if self._tune_rounds <= 0 or not getattr(net, "_use_graphs", False) or getattr(net, "replay_mode", "") != "lanes" or not hasattr(net, "snapshot_step"):
+            return None
+        net.snapshot_step()
+
+        def step():
+            net.restore_step()
+            net.forward(self.patch, self.mask, training=True)
+            loss = net.loss(self.mask)
+            self.optimizer.zero_grad()
+            loss.backward()
+        res = net.tune_schedule(step, rounds=self._tune_rounds)
+        net.restore_step()
+        if self.rank == 0:
+            self.logger.info("lane schedule tuned: %s", res)
+        return res
+
     def train(self, data, iterations=None):
         self.net.train()
         n_it = iterations if iterations is not None else self.exp_config.iterations
@@ -194,6 +220,8 @@ class UNetModel:
         for self.iteration in range(1, n_it):
             x_b, s_b = data.train.next_batch(self.batch_size)
             loss = self.train_step(x_b, s_b)
+            if self.iteration == 3:                              # the plan exists and is warm: measure its schedule once
+                self.tune_schedule()
             val_every = getattr(self.exp_config, "validation_frequency", 0)
             if val_every and self.iteration % val_every == 0:
                 self.validate(data)
