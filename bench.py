@@ -250,6 +250,13 @@ def profile_families(net, plan, L, reps=3, burst=4):
                     reduced = ops[k]["code"] == "UZ_OP_CONV_BWD_WEIGHT" and roof != PEAK_F32_MFMA_TFLOPS and L.uz_get_wgrad_target() < 256
                     if not reduced and (heaviest_full is None or best > heaviest_full[0]):
                         heaviest_full = (best, which, k, fl, roof)
+    # The DOMINANT launch is the one that takes the most of the CHIP's time: duration x the share of the CUs its grid occupies.  A weight
+    # gradient cut into 128 workgroups runs 1.25 ms on HALF the CUs (0.63 chip-ms) while other lanes use the rest; the data gradient of the
+    # same layer holds all 256 CUs for 0.81 ms.  The longest launch is reported beside it (roofline.longest_launch_reduced_grid).
+    if heaviest is not None and heaviest_full is not None and heaviest[1:3] != heaviest_full[1:3]:
+        share = min(1.0, L.uz_get_wgrad_target() / 256.0)
+        if heaviest_full[0] >= heaviest[0] * share:
+            heaviest, heaviest_full = heaviest_full, heaviest
     return fam, heaviest, heaviest_full
 
 
@@ -797,20 +804,30 @@ def main():
                 roof = dict(bound="mfma", achieved=dk["achieved"], peak=dk["peak"], unit="TFLOP/s", frac=dk["frac"], traffic=dk["traffic"],
                             kernel=dk["kernel"], op=dk["op"], layer=dk["layer"], flops_per_launch=dk["flops_per_launch"],
                             avg_launch_ms=dk["avg_launch_ms"], algorithmic_bytes=dk["algorithmic_bytes"], peak_note=dk["peak_note"],
-                            note="dominant kernel = the longest convolution launch of the step, re-timed live (20 launches between two HIP events "
-                                 "on its launch stream); achieved = algorithmic fp32-equivalent FLOPs per launch / average launch duration; traffic = "
+                            note="dominant kernel = the convolution launch that takes the most chip time of the step (duration x share of the CUs its grid "
+                                 "occupies), re-timed live (20 launches between two HIP events on its launch stream); achieved = algorithmic fp32-equivalent FLOPs per launch / average launch duration; traffic = "
                                  "PMC-measured HBM bytes per launch of this kernel on this layer (profiles/), null when no committed PMC pass covers it")
                 for k in ("fp16_mfma_tflops", "traffic_source", "traffic_table_git_blob", "sustained_ceiling_note"):
                     if k in dk:
                         roof[k] = dk[k]
-                if dk["op"] == "weight gradient" and dk["peak"] != PEAK_F32_MFMA_TFLOPS and L.uz_get_wgrad_target() < 256:
+                def grid_note(d_):
                     wg = int(L.uz_get_wgrad_target())
-                    roof["grid_note"] = ("this launch is cut into %d workgroups ON PURPOSE (uz_set_wgrad_target: its workgroups hold 472 - 508 of a SIMD's 512 registers "
-                                         "for the whole kernel, so nothing else starts on the CUs it occupies; with %d of 256 CUs the step is 3 %% faster, profiles/NOTES_r5.md) - "
-                                         "`frac` is against the WHOLE chip's peak; against the peak of the CUs it occupies: %.4f" % (wg, wg, dk["frac"] * 256.0 / wg))
-                    if heaviest_full is not None and heaviest_full[2:3] != heaviest[2:3]:
-                        d2 = dominant_kernel_live(net, plan, L, heaviest_full)
-                        roof["longest_full_grid_launch"] = {k: d2[k] for k in ("kernel", "op", "layer", "avg_launch_ms", "achieved", "peak", "frac", "traffic", "algorithmic_bytes") if k in d2}
+                    return ("this launch is cut into %d workgroups ON PURPOSE (uz_set_wgrad_target: its workgroups hold 472 - 508 of a SIMD's 512 registers "
+                            "for the whole kernel, so nothing else starts on the CUs it occupies; with %d of 256 CUs the step is 3 %% faster, profiles/NOTES_r5.md) - "
+                            "`frac` is against the WHOLE chip's peak; against the peak of the CUs it occupies: %.4f" % (wg, wg, d_["frac"] * 256.0 / wg))
+
+                def is_reduced(d_):
+                    return d_["op"] == "weight gradient" and d_["peak"] != PEAK_F32_MFMA_TFLOPS and L.uz_get_wgrad_target() < 256
+                if is_reduced(dk):
+                    roof["grid_note"] = grid_note(dk)
+                if heaviest_full is not None and heaviest_full[1:3] != heaviest[1:3]:
+                    d2 = dominant_kernel_live(net, plan, L, heaviest_full)
+                    other = {k: d2[k] for k in ("kernel", "op", "layer", "avg_launch_ms", "achieved", "peak", "frac", "traffic", "algorithmic_bytes") if k in d2}
+                    if is_reduced(d2):                  # the longest launch of the step, on a reduced grid: less chip time than the dominant one
+                        other["grid_note"] = grid_note(d2)
+                        roof["longest_launch_reduced_grid"] = other
+                    elif is_reduced(dk):
+                        roof["longest_full_grid_launch"] = other
                 step_view.pop("traffic", None)
                 roof["step"] = step_view
                 roof["families"] = fams

@@ -1495,7 +1495,11 @@ class Plan:
                 refs += [self.P(wkey), ("packw", which, wkey), ("raw", e["mc"]), ("raw", e["kc"]), ("raw", e["cin"]), ("raw", e["cot"]),
                          ("raw", e["dgrad"] | (e["vol"] << 1)), ("raw", e["row0"])]
             self._packbuf[which] = self.vec("packed_weights:" + which, off // 4)
-            pack_ops[which] = dict(code="UZ_OP_PACK_WEIGHTS", p=[self.ptr_table(refs), ("amaxw", 0), self._packbuf[which]], i=[len(lst), rows], f=[], n=0, gid=head)
+            # a scheduling group of its own (gid head - 1) behind the bound measurement: only the layers that READ the packed images wait for
+            # it - the first layers of both encoders (1 / 3 input channels: fp32 matrix path) start beside it (40 us off the forward's chain)
+            own = os.environ.get("UZ_PACK_OWN_GROUP", "1") == "1"
+            pack_ops[which] = dict(code="UZ_OP_PACK_WEIGHTS", p=[self.ptr_table(refs), ("amaxw", 0), self._packbuf[which]], i=[len(lst), rows], f=[], n=0,
+                                   gid=head - 1 if own else head)
         if "bwd" in pack_ops and self.bwd_ops:
             self.bwd_ops[:0] = [pack_ops["bwd"]]
         if self.fwd_ops:
