@@ -1916,12 +1916,9 @@ class Plan:
         blevel = [0.0] * G
         for gi in reversed(range(G)):
             blevel[gi] = cost[gi] + max((blevel[sg] for sg in succ[gi]), default=0.0)
-        boost = float(os.environ.get("UZ_WGRAD_TABLE_BOOST", "0")) * 1e-6       # experiment: priority of the chunked slab-reduction tables
         for gi, (a, b) in enumerate(groups):
             if any(o["code"] == "UZ_OP_EVENT_RECORD" for o in ops[a:b + 1]):
                 blevel[gi], cost[gi] = 1e9, 1e-7      # bucket-final markers cost nothing and must fire the moment their bucket is done
-            elif boost and any(o["code"] == "UZ_OP_WGRAD_REDUCE_TABLE" for o in ops[a:b + 1]):
-                blevel[gi] += boost
         t, running = 0.0, []
         while len(order) < G:
             running = [(f, g) for f, g in running if f > t + 1e-12]
