@@ -47,6 +47,47 @@ def test_allreduce_mean_world2_gloo(tmp_path):
     assert np.array_equal(got[0], got[1])           # replicas stay bitwise identical
 
 
+def _resched_worker(rank, world, port, out_dir):
+    """Engine.tune_schedule's rank-consistency step without a GPU: every rank 'measures' different per-op durations, the ranks agree on
+    the element-wise maximum (dp.max_over_ranks), reschedule from it - and must end with the same tape order and lanes."""
+    import json
+    import random
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      UZ_LANES="3", UZ_SCHED_HEAVY="off", UZ_SCHED_COST="beside")
+    dp.init_from_env(backend="gloo")
+    from tests import _golden as G
+    from unet_zoo_amd.models.phiseg import PHISeg
+    _, meta = G.load("phiseg_small")
+    net = PHISeg(1, 2, meta["filters"], image_size=(1, 64, 64), device="cpu")
+    plan = net._build(2, 64, 64, True, True)
+    rng = random.Random(1000 + rank)
+    out = {"flags": dp.or_flags(1 << rank), "max": dp.max_over_ranks([float(rank), 10.0 - rank, 3.5])}
+    for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
+        prog = plan._program_order[which]
+        mine = [rng.choice([3.0, 30.0, 300.0]) for _ in prog]
+        agreed = dp.max_over_ranks(mine)
+        for o, c in zip(prog, agreed):
+            o["cost_us"] = c
+        plan.reschedule(which)
+        index = {id(o): k for k, o in enumerate(prog)}
+        out[which] = [(index[id(o)], o["lane"]) for o in ops]
+        out[which + "_mine"] = mine[:8]
+    json.dump(out, open(os.path.join(out_dir, f"s{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_that_agree_on_the_measured_costs_end_with_one_schedule_world2_gloo(tmp_path):
+    import json
+    world = 2
+    mp.spawn(_resched_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = (json.load(open(tmp_path / f"s{r}.json")) for r in range(world))
+    assert a["flags"] == b["flags"] == 3 and a["max"] == b["max"] == [1.0, 10.0, 3.5]
+    assert a["fwd_mine"] != b["fwd_mine"]                    # the ranks did measure different things
+    for which in ("fwd", "bwd"):
+        assert a[which] == b[which] and len(a[which]) > 50, which
+
+
 def test_shard_bounds_cover_batch():
     for n, world in [(32, 8), (32, 3), (5, 8), (1, 2)]:
         spans = [dp.shard_bounds(n, r, world) for r in range(world)]
