@@ -307,6 +307,25 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(Wl + sto + j * 1024), 16, blk + 1024u * (unsigned)j, 0, 0, 0);
         }
     };
+#ifdef UZ_EXP_PATCH_DMA
+    // TIMING-ONLY experiment build (tools/exp_variants.sh): the patch image of the DB kernels fetched by LDS-DMA too, as if the storage
+    // were plane-separated 16-byte pieces (4 pixels of one channel row per lane) - no registers, no permutes, no ds_write.  The values
+    // land in the wrong layout: the build prices the staging, it does not compute.
+    auto patch_dma = [&](int c) {
+        constexpr int PD = (NP * PPLANE + 1023) / 1024;
+#pragma unroll
+        for (int i = 0; i < (PD + NT / 64 - 1) / (NT / 64); ++i) {
+            const int j = i * (NT / 64) + wave;
+            if (j < PD) {
+                const int e = j * 64 + lane, k = e & 15, q = e >> 4, row = q / 9, g = q - row * 9;
+                const int yy = y0 + row - 1, xx = x0 + 4 * g - 1;
+                const unsigned off = (yy >= 0 && yy < p.H && xx >= 0 && xx + 3 < p.W && c * CK + k < p.Cin)
+                                         ? ESZ * (unsigned)(yy * p.W + xx) + (unsigned)(c * CK + k) * xstep : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(Pl + sto + j * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+#endif
     auto weight_load = [&](int c, int i) {
         const int v = tid + i * NT;
         const unsigned off = v < WVEC ? (unsigned)(c * p.nCoTiles + coT) * wblock + 16u * (unsigned)v : 0xFFFFFFFFu;
@@ -353,6 +372,10 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
     };
     auto stage = [&](int c, int tap) {
         if constexpr (DB) {             // weights first (DMA), patch loads over taps 1..4, conversions over taps 5..8
+#ifdef UZ_EXP_PATCH_DMA
+            if (tap == 0) { weight_dma(c); patch_dma(c); }
+            return;
+#endif
             if (tap == 0) weight_dma(c);
             else if (tap < 5) {
                 patch_loads(c, 2 * (tap - 1)); patch_loads(c, 2 * (tap - 1) + 1);
@@ -386,6 +409,9 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
         }
     };
     auto lstore = [&]() {
+#ifdef UZ_EXP_PATCH_DMA
+        if constexpr (DB) return;
+#endif
         char* dst = Pl + sto + tid * 16;
         if constexpr (XB) {           // this thread loaded channels 8 h2 .. 8 h2 + 7 itself and received the other eight
             *reinterpret_cast<u32x4*>(dst + (h2 ? PPLANE / 2 : 0)) = u32x4{mypk[0], mypk[1], mypk[2], mypk[3]};
