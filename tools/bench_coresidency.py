@@ -31,8 +31,8 @@ ws2b = max(L.uz_conv_workspace(c, c, N, h, h, 3), 1 << 16); ws2 = torch.empty(ws
 pooled = torch.empty(N, c, h // 2, h // 2, device=dev)
 big = torch.randn(N, 32, 32, 32, device=dev); bigp = torch.empty(N, 32, 16, 16, device=dev)
 kinds = {
-    "bn_fused_small_fwd (156 VGPRs)": lambda st: L.uz_bn_relu_fwd(P(ys), c, c, P(gam), P(bet), P(rm), P(rv), P(save), P(a), c, N, h, h, 1e-3, 0.01, 1, 1, None, P(wsm), st),
-    "bn_fused_small_bwd (260 VGPRs)": lambda st: L.uz_bn_relu_bwd(P(da), c, P(ys), c, c, P(gam), P(bet), P(save), P(dy), c, P(dg), P(db), P(dbias), N, h, h, 1, None, P(wsm), st),
+    "bn_fused_small_fwd<2> (34 VGPRs; 156 until round 5)": lambda st: L.uz_bn_relu_fwd(P(ys), c, c, P(gam), P(bet), P(rm), P(rv), P(save), P(a), c, N, h, h, 1e-3, 0.01, 1, 1, None, P(wsm), st),
+    "bn_fused_small_bwd<2> (36 VGPRs; 260 until round 5)": lambda st: L.uz_bn_relu_bwd(P(da), c, P(ys), c, c, P(gam), P(bet), P(save), P(dy), c, P(dg), P(db), P(dbias), N, h, h, 1, None, P(wsm), st),
     "conv_mfma 192->192@4x4 (122-156 VGPRs)": lambda st: L.uz_conv_fwd(P(ys), c, c, P(w2), None, P(a), c, c, N, h, h, 3, 0, None, None, None, P(ws2), ws2b, st),
     "avgpool 32ch@32x32 (low VGPRs)": lambda st: L.uz_avgpool2_fwd_ex(P(big), 32, 32, P(bigp), 32, N, 32, 32, None, None, 0, st),
 }
@@ -52,4 +52,4 @@ heavy(sA, 2); torch.cuda.synchronize()
 for name, fn in kinds.items():
     chain(fn, sB, 3); torch.cuda.synchronize()
     alone = min(timed(fn, False) for _ in range(3)); beside = min(timed(fn, True) for _ in range(3))
-    print(f"{name:42s} alone {alone:7.1f} us/launch   beside the convolution {beside:7.1f} us/launch   x{beside / alone:.2f}")
+    print(f"{name:54s} alone {alone:7.1f} us/launch   beside the convolution {beside:7.1f} us/launch   x{beside / alone:.2f}")
