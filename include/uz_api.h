@@ -426,6 +426,8 @@ enum {
   UZ_OP_LATENT_HEADS_FWD,        /* p = h, w_mu, b_mu, w_sigma, b_sigma, eps, mu, pre, sigma, z; i = Cin, CinTot, L, N, H, W, act (uz_latent_heads_fwd) */
   UZ_OP_LATENT_HEADS_BWD_DATA,   /* p = dy_a, dy_b, w_a, w_b, dh; i = L, Cin, CinTot, N, H, W, accumulate */
   UZ_OP_LATENT_HEADS_BWD_WEIGHT, /* p = h, dy_a, dy_b, dw_a, db_a, dw_b, db_b, workspace; i = Cin, CinTot, L, N, H, W; n = workspace bytes */
+  UZ_OP_CHAIN,           /* p = sub-op table, phase table, state; i = n_phases, n_workgroups, n_sub_ops (uz_chain_run); p[3..] = the buffers it touches (scheduling only) */
+  UZ_OP_CHAIN_PACK,      /* p = table, w_amax, images; i = n_layers, total_blocks (uz_chain_pack_weights) */
   UZ_OP__COUNT
 };
 typedef struct uz_op {
@@ -467,6 +469,56 @@ int  uz_run_tape_lanes(const uz_op* ops, const uz_sched* sched, int n_ops, int n
 int  uz_lane_trace(int enable, int capacity, float* out, int n_out);
 int  uz_graph_launch(void* graph_exec, void* stream);
 void uz_graph_destroy(void* graph_exec);
+
+/* ---------------------------------------------------------------- deep-level chain (round 6)
+ * The 16 x 16 ... 2 x 2 levels of PHiSeg (phiseg.py:14-39 encoder levels 3 - 6, :42-73 UpConvolutionalBlock, :76-106 SampleZBlock,
+ * :209-221 / :269-277 the likelihood's small planes) are ~340 launches of 5 - 40 us per step on the step's critical chains; beside the
+ * device-filling convolutions of the other lanes each of them waits 80 - 180 us for a register slot.  uz_chain_run executes a whole
+ * sub-DAG of such ops as PHASES of ONE persistent launch: n_workgroups slim workgroups (256 threads, <= 128 VGPRs, < 8 KB LDS - they
+ * start beside any other kernel and then keep their slot) walk the phase table; the sub-ops of one phase are independent and are cut
+ * into workgroup tiles (tile0 / ntiles, counted by uz_chain_op_tiles) dealt round-robin; phases are separated by a grid barrier among
+ * the launch's own workgroups (bounded spin: a barrier that does not complete within ~2 s raises the status word and every
+ * workgroup leaves - uz_chain_status).  Sub-ops mirror the per-op entry points above (same operands, same results to fp32 rounding;
+ * the 3 x 3 convolutions run on the fp16 matrix pipe with two-piece split operands like uz_conv_fwd_ex's split path, staged straight
+ * from global memory: no LDS).  Device tables: `ops` = n_ops uz_chain_op in phase order, `phases` = n_phases pairs {first op, op
+ * count}; `state` = uz_chain_state_bytes() bytes (zeroed by the call).                                                              */
+enum {
+  UZ_CH_CONV3 = 1,      /* 3x3 pad 1, contraction channels % 16 == 0, output channels % 32 == 0 (forward and data gradient differ only in the packed image).
+                           p = x, image (uz_chain_pack_weights), bias|NULL, y, slabs|NULL, x_amax, w_amax; i = Kc, KcTot, Mc, McTot, N, H, W, S, accumulate.
+                           S == 1: y (+)= conv + bias; S > 1: slabs[S][N][Mc][HW] = partial sums (the consumer adds bias + slabs in order) */
+  UZ_CH_CONV3_SMALL,    /* 3x3 pad 1 on the vector pipe, contraction channels <= 4 (the 2-channel latents), forward only.
+                           p = x, w [Mc][Kc][3][3], bias|NULL, y; i = Kc, KcTot, Mc, McTot, N, H, W */
+  UZ_CH_BN_FWD,         /* training-mode BatchNorm + ReLU of one Conv2D unit (torchlayers.py:18-21), N*H*W <= 8192.
+                           p = y, gamma, beta, running_mean, running_var, save, a, slabs|NULL, a_amax|NULL, conv bias|NULL; i = C, CtotY, CtotA, N, HW, relu, S; f = eps, momentum */
+  UZ_CH_AVGPOOL_FWD,    /* p = x, y, x_amax|NULL, y_amax|NULL; i = C, CtotX, CtotY, N, H, W (input plane) */
+  UZ_CH_BILINEAR_FWD,   /* p = x, y, x_amax|NULL, y_amax|NULL; i = C, CtotX, CtotY, N, H, W (input plane), align_corners */
+  UZ_CH_HEADS_FWD,      /* uz_latent_heads_fwd with L == 2: p = h, w_mu, b_mu, w_sigma, b_sigma, eps, mu, pre, sigma, z|NULL; i = Cin, CinTot, N, HW, act */
+  UZ_CH_BN_BWD,         /* backward of UZ_CH_BN_FWD. p = dA, y, gamma, save, dy [N][C][HW], dgamma, dbeta, dbias|NULL, dy_amax|NULL, slabs|NULL (of dA), beta; i = C, CtotDa, CtotY, N, HW, relu, S */
+  UZ_CH_AVGPOOL_BWD,    /* p = dy, dx; i = C, CtotDy, CtotDx, N, H, W (high-resolution plane), accumulate */
+  UZ_CH_BILINEAR_BWD,   /* p = dy, dx; i = C, CtotDy, CtotDx, N, H, W (low-resolution plane), align_corners, accumulate */
+  UZ_CH_HEADS_BWD_DATA, /* uz_latent_heads_bwd_data with L == 2: p = dy_a, dy_b, w_a, w_b, dh; i = Cin, CinTot, N, HW, accumulate */
+  UZ_CH_CONV3_SMALL_BWD_DATA, /* data gradient of UZ_CH_CONV3_SMALL: p = dy, w [Mc][Kc][3][3], dx; i = Kc (<= 4, channels of dx), KcTot, Mc, McTot, N, H, W, accumulate */
+  UZ_CH__COUNT
+};
+typedef struct uz_chain_op {
+  int32_t code;        /* UZ_CH_* */
+  int32_t tile0;       /* first workgroup tile of this sub-op inside its phase */
+  int32_t ntiles;      /* uz_chain_op_tiles */
+  int32_t rsv;
+  int32_t i[16];
+  float   f[4];
+  void*   p[12];
+} uz_chain_op;
+int    uz_chain_op_tiles(const uz_chain_op* op);                 /* host: workgroup tiles of one sub-op, < 0 on a shape it does not cover */
+int    uz_chain_conv_ksplit(int Kc, int Mc, int N, int H, int W, int n_workgroups);   /* S a UZ_CH_CONV3 of this shape should run with */
+size_t uz_chain_packed_bytes(int Kc, int Mc);                     /* bytes of one packed image */
+int    uz_chain_pack_blocks(int Kc, int Mc);                      /* 256-thread blocks uz_chain_pack_weights spends on one image */
+/* table (device, int64): per layer {w, image, Mc, Kc, Cin of the parameter tensor, dgrad, first block}: image = the two fp16 pieces of
+ * w * split_scale(*w_amax) in MFMA fragment order [tap][Kc / 16][Mc / 32][piece][lane][8]; dgrad: rows = input channels, taps flipped */
+int    uz_chain_pack_weights(const int64_t* table, int n_layers, int total_blocks, const float* w_amax, void* stream);
+size_t uz_chain_state_bytes(void);
+int    uz_chain_run(const uz_chain_op* ops, const int32_t* phases, int n_phases, int n_workgroups, void* state, void* stream);
+int    uz_chain_status(const void* state, int* out, void* stream);   /* synchronises; out = 0 ok, else 1 + the phase whose barrier timed out */
 
 /* ---------------------------------------------------------------- data-parallel gradient exchange (RCCL over xGMI)
  * New component (the reference has no communication layer): one process per GPU, full replica, and

@@ -160,6 +160,9 @@ class NativeModel(nn.Module):
     # chains no longer carry the weight gradients), Probabilistic U-Net 11.33 -> 11.66 ms (three lanes already interleave its
     # chains) - so it is a per-model default.
     decouple_wgrad_px = 0
+    # Planes (N*H*W pixels) up to which a tape's small-plane ops run as phases of ONE persistent launch (Plan._chain_pass, csrc/chain.hip;
+    # UZ_CHAIN overrides, 0 = off).  PHISeg: 8192 = its 16 x 16 ... 2 x 2 levels at batch 32.
+    chain_px = 0
     decouple_wgrad_prefixes = ()      # sub-networks (parameter-name prefixes) whose weight gradients are decoupled at every size
 
     # Workgroups of the split-path weight gradients (uz_set_wgrad_target): a process setting of the library that sizes slab buffers at plan
@@ -181,6 +184,7 @@ class NativeModel(nn.Module):
         # tune_schedule() refines them by measurement; the graph replay keeps the isolated-launch model its rule was measured with
         plan.sched_cost = os.environ.get("UZ_SCHED_COST", "beside" if self.replay_mode == "lanes" else "alone")
         plan.decouple_wgrad_px = self.decouple_wgrad_px
+        plan.chain_px = self.chain_px
         plan.decouple_wgrad_prefixes = tuple(self.decouple_wgrad_prefixes)
         dp = getattr(self, "_dp", None)
         if dp is not None and dp.overlap:

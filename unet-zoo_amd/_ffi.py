@@ -31,6 +31,31 @@ class uz_op(C.Structure):
     _fields_ = [("code", C.c_int32), ("i", C.c_int32 * 15), ("f", C.c_float * 4), ("n", C.c_int64), ("p", C.c_void_p * 12)]
 
 
+class uz_chain_op(C.Structure):
+    _fields_ = [("code", C.c_int32), ("tile0", C.c_int32), ("ntiles", C.c_int32), ("rsv", C.c_int32),
+                ("i", C.c_int32 * 16), ("f", C.c_float * 4), ("p", C.c_void_p * 12)]
+
+
+def chain_codes():
+    """The UZ_CH_* enum of the header (sub-ops of uz_chain_run)."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    body = next(b for b in re.findall(r"enum\s*\{(.*?)\};", text, flags=re.S) if "UZ_CH_" in b)
+    codes, nxt = {}, 0
+    for tok in body.split(","):
+        tok = tok.strip()
+        if not tok:
+            continue
+        if "=" in tok:
+            name, val = [t.strip() for t in tok.split("=")]
+            nxt = int(val)
+        else:
+            name = tok
+        codes[name] = nxt
+        nxt += 1
+    return codes
+
+
 def header_symbols():
     """Every function name declared in include/uz_api.h."""
     with open(HEADER_PATH) as f:

@@ -187,6 +187,11 @@ class Plan:
         self.decouple_wgrad_prefixes = ()    # NativeModel.decouple_wgrad_prefixes
         self._nclaims = {}                   # backward writers seen per buffer (conv_relu's folded ReLU backward checks it was the last one)
         self._dbias_jobs = []                # folded ReLU backward: bias gradients still to be summed from their partials (one launch at the tape's end)
+        self.chain_px = 0                    # NativeModel.chain_px: planes (N*H*W) up to which a tape's ops run as phases of ONE persistent launch (_chain_pass)
+        self.chain_wgs = 256                 # workgroups of that launch
+        self._chains = []                    # per chain op: dict(sub=[...], phases=[...]) -> device tables built on first resolve
+        self._chain_imgs = {}                # tape -> {wkey: dict(off, bytes, mc, kc, cin, dgrad)} packed weight images of the chain convolutions
+        self._chain_imgbuf = {}
 
     def _newgroup(self):
         self._gid += 1
@@ -1187,8 +1192,8 @@ class Plan:
         if env("UZ_PACK_ACT") and not self.extra_ops:
             named = {id(v.buf) for v in self.named.values() if isinstance(v, View)}
             for b in self.bufs:
-                if b.alias is not None or id(b) in tabbed or id(b) in named or (b.H * b.W) % 4 or b.N * b.H * b.W <= 4096:
-                    continue
+                if b.alias is not None or id(b) in tabbed or id(b) in named or (b.H * b.W) % 4 or b.N * b.H * b.W <= max(4096, self._chain_limit()):
+                    continue                                 # (planes of the deep-level chain stay fp32: its convolutions split on the fly)
                 wr_list, rd_list, ok = [], [], True
                 for tape, ops in all_ops:
                     for o in ops:
@@ -1420,6 +1425,270 @@ class Plan:
         return info
 
     # ------------------------------------------------------------------ finalisation
+
+    # ------------------------------------------------------------------ deep-level chain (round 6; csrc/chain.hip)
+    def _chain_limit(self):
+        """Largest N*H*W whose ops run inside the persistent chain launch (0: off).  Only with two-piece operands (the chain's
+        convolutions are split-fp16: UZ_CONV_MATH=f32 keeps every convolution on the fp32 matrix pipe, bf16 is the volume path) and
+        training-mode BatchNorm."""
+        px = int(os.environ.get("UZ_CHAIN", str(self.chain_px)))
+        if px <= 0 or not self.bn_training or self.L.uz_get_conv_math() in (0, 3) or self.extra_ops:
+            return 0
+        return px
+
+    def _hazard_deps(self, ops):
+        """Per op of `ops` (program order) the set of earlier ops it must follow (RAW, WAR, WAW over the same resources the lane
+        scheduler uses; bound-slot accumulators commute with each other)."""
+        hist, deps = {}, []
+        for k, o in enumerate(ops):
+            reads, writes, accs = self._access(o)
+            d = set()
+            for space, lo, hi in reads:
+                for e in hist.get(space, ()):
+                    if e[0] < hi and lo < e[1]:
+                        if e[2] is not None:
+                            d.add(e[2])
+                        d.update(e[4])
+            for space, lo, hi in accs:
+                for e in hist.get(space, ()):
+                    if e[0] < hi and lo < e[1]:
+                        if e[2] is not None:
+                            d.add(e[2])
+                        d.update(e[3])
+            for space, lo, hi in writes:
+                for e in hist.get(space, ()):
+                    if e[0] < hi and lo < e[1]:
+                        if e[2] is not None:
+                            d.add(e[2])
+                        d.update(e[3])
+                        d.update(e[4])
+            d.discard(k)
+            deps.append(d)
+            for space, lo, hi in reads:
+                for e in hist.setdefault(space, []):
+                    if e[0] < hi and lo < e[1]:
+                        e[3].add(k)
+                hist[space].append([lo, hi, None, {k}, set()])
+            for space, lo, hi in accs:
+                for e in hist.setdefault(space, []):
+                    if e[0] < hi and lo < e[1]:
+                        e[4].add(k)
+                hist[space].append([lo, hi, None, set(), {k}])
+            for space, lo, hi in writes:
+                lst = hist.setdefault(space, [])
+                keep = [e for e in lst if not (lo <= e[0] and e[1] <= hi)]
+                keep.append([lo, hi, k, set(), set()])
+                hist[space] = keep
+        return deps
+
+    def _chain_eligible_fwd(self, o, px):
+        c, i, p = o["code"], o["i"], o["p"]
+        b16 = len(i) > 13 and i[13]
+        if b16:
+            return False
+        if c == "UZ_OP_CONV_FWD":
+            cin, cout, N, H, W, ks = i[0], i[2], i[4], i[5], i[6], i[7]
+            if ks != 3 or N * H * W > px or i[8] or (len(i) > 10 and i[10]) or (len(p) > 9 and p[9] is not None) or not isinstance(p[0], View) or p[0].nb is not None:
+                return False
+            if cin <= 4:
+                return True
+            return cin % 16 == 0 and cout % 32 == 0 and p[5] is not None
+        if c == "UZ_OP_BN_RELU_FWD":
+            return i[6] == 1 and i[8] == 0 and not (len(i) > 10 and i[10]) and i[3] * i[4] * i[5] <= px and isinstance(p[0], View) and p[0].nb is None
+        if c == "UZ_OP_AVGPOOL_FWD":
+            return i[3] * ((i[4] + 1) // 2) * ((i[5] + 1) // 2) <= px and not (len(i) > 6 and i[6]) and p[0].nb is None
+        if c == "UZ_OP_BILINEAR_FWD":
+            return i[3] * 4 * i[4] * i[5] <= px and not (len(i) > 7 and i[7]) and p[0].nb is None
+        if c == "UZ_OP_LATENT_HEADS_FWD":
+            return i[2] == 2 and i[3] * i[4] * i[5] <= px
+        return False
+
+    def _chain_pass(self):
+        """Collects the small-plane ops of the forward tape into ONE UZ_OP_CHAIN op (uz_chain_run): the sub-DAG is levelled into
+        phases of independent sub-ops, every 3 x 3 convolution gets a split-K factor and a slab buffer of its own, its weights a
+        fragment-ordered image packed once per tape (UZ_OP_CHAIN_PACK).  The tape keeps a valid program order: [every op the chain
+        depends on] [chain] [the rest]; the set must be convex in the dependency DAG (an op outside may not sit between two inside)."""
+        self.chain_info = {}
+        px = self._chain_limit()
+        if px <= 0:
+            return
+        for which, ops, elig in (("fwd", self.fwd_ops, self._chain_eligible_fwd),):
+            if not ops:
+                continue
+            E = [k for k, o in enumerate(ops) if elig(o, px)]
+            if len(E) < 8:
+                continue
+            deps = self._hazard_deps(ops)
+            # a unit's convolution and BatchNorm go together: a BatchNorm whose convolution leaves slabs for it must run where that
+            # convolution runs
+            ywriter = {}
+            for k, o in enumerate(ops):
+                if o["code"] == "UZ_OP_CONV_FWD" and isinstance(o["p"][3], View):
+                    ywriter[(id(o["p"][3].buf), o["p"][3].c0)] = k
+            Es = set(E)
+            changed = True
+            while changed:
+                changed = False
+                for k in sorted(Es):
+                    o = ops[k]
+                    if o["code"] == "UZ_OP_BN_RELU_FWD" and o["i"][9] > 0:
+                        ck = ywriter.get((id(o["p"][0].buf), o["p"][0].c0))
+                        if ck is None or ck not in Es:
+                            Es.discard(k); changed = True
+                    if o["code"] == "UZ_OP_CONV_FWD" and o["i"][9]:
+                        bk = next((j for j in range(k + 1, len(ops)) if ops[j]["code"] == "UZ_OP_BN_RELU_FWD" and ops[j]["p"][0].buf is o["p"][3].buf
+                                   and ops[j]["p"][0].c0 == o["p"][3].c0), None)
+                        if bk is None or bk not in Es:
+                            Es.discard(k); changed = True
+                # convexity: no op outside may both depend on the set and be depended on by it
+                desc = set()                       # ops (in or out) that depend on the set
+                for k in range(len(ops)):
+                    if any(d in Es or d in desc for d in deps[k]):
+                        desc.add(k)
+                bad = {k for k in Es if any((d not in Es) and (d in desc) for d in deps[k])}
+                if bad:
+                    # drop the offenders and everything of the set behind them
+                    drop = set(bad)
+                    for k in sorted(Es):
+                        if any(d in drop for d in deps[k]):
+                            drop.add(k)
+                    Es -= drop
+                    changed = True
+            if len(Es) < 8:
+                continue
+            # ancestors of the set (outside it) go first
+            anc = set()
+            for k in reversed(range(len(ops))):
+                if k in Es or k in anc:
+                    anc.update(d for d in deps[k] if d not in Es)
+            # levels inside the set
+            level = {}
+            for k in sorted(Es):
+                level[k] = 1 + max((level[d] for d in deps[k] if d in Es), default=-1)
+            order = sorted(Es, key=lambda k: (level[k], k))
+            sub, slab_of = [], {}
+            imgs = self._chain_imgs.setdefault(which, {})
+            G = int(os.environ.get("UZ_CHAIN_WGS", str(self.chain_wgs)))
+            for k in order:
+                o = ops[k]
+                c, i, p = o["code"], o["i"], o["p"]
+                if c == "UZ_OP_CONV_FWD":
+                    cin, cout, N, H, W = i[0], i[2], i[4], i[5], i[6]
+                    if cin <= 4:
+                        e = dict(code="UZ_CH_CONV3_SMALL", p=[p[0], p[1], p[2], p[3]], i=[cin, i[1], cout, i[3], N, H, W], f=[])
+                    else:
+                        has_bn = any(ops[j]["code"] == "UZ_OP_BN_RELU_FWD" and j in Es and ops[j]["p"][0].buf is p[3].buf and ops[j]["p"][0].c0 == p[3].c0 for j in range(k + 1, len(ops)))
+                        S = self.L.uz_chain_conv_ksplit(cin, cout, N, H, W, G) if has_bn else 1
+                        wkey = p[1][1]
+                        assert p[1][0] == "param" and p[1][2] == 0, p[1]
+                        if wkey not in imgs:
+                            imgs[wkey] = dict(mc=cout, kc=cin, cin=cin, dgrad=0, bytes=self.L.uz_chain_packed_bytes(cin, cout), blocks=self.L.uz_chain_pack_blocks(cin, cout))
+                        slab = self.vec(wkey + ":chslab", S * N * cout * H * W) if S > 1 else None
+                        if slab is not None:
+                            slab_of[(id(p[3].buf), p[3].c0)] = (slab, S)
+                        e = dict(code="UZ_CH_CONV3", p=[p[0], ("chainimg", which, wkey), p[2] if S == 1 else None, p[3] if S == 1 else None, slab, p[5], p[6]],
+                                 i=[cin, i[1], cout, i[3], N, H, W, S, 0], f=[])
+                        # the image replaces the per-tape LDS image of the split kernels
+                        self._packs["fwd"].pop(wkey, None)
+                elif c == "UZ_OP_BN_RELU_FWD":
+                    slab, S = slab_of.get((id(p[0].buf), p[0].c0), (None, 1))
+                    cbias = None
+                    if S > 1:
+                        ck = ywriter[(id(p[0].buf), p[0].c0)]
+                        cbias = ops[ck]["p"][2]
+                    e = dict(code="UZ_CH_BN_FWD", p=[p[0], p[1], p[2], p[3], p[4], p[5], p[6], slab, p[8], cbias],
+                             i=[i[0], i[1], i[2], i[3], i[4] * i[5], i[7], S], f=[o["f"][0], o["f"][1]])
+                elif c == "UZ_OP_AVGPOOL_FWD":
+                    e = dict(code="UZ_CH_AVGPOOL_FWD", p=[p[0], p[1], p[2], p[3]], i=i[:6], f=[])
+                elif c == "UZ_OP_BILINEAR_FWD":
+                    e = dict(code="UZ_CH_BILINEAR_FWD", p=[p[0], p[1], p[2], p[3]], i=i[:7], f=[])
+                elif c == "UZ_OP_LATENT_HEADS_FWD":
+                    e = dict(code="UZ_CH_HEADS_FWD", p=list(p[:10]), i=[i[0], i[1], i[3], i[4] * i[5], i[6]], f=[])
+                else:
+                    raise AssertionError(c)
+                e["level"], e["orig"] = level[k], o
+                sub.append(e)
+            idx = len(self._chains)
+            self._chains.append(dict(sub=sub, which=which, n_wgs=G))
+            # access of the whole launch = the union of what its sub-ops touch (the packed images instead of the split kernels' ones)
+            acc_ops = []
+            for e in sub:
+                q = dict(e["orig"])
+                q["p"] = list(q["p"])
+                if q["code"] == "UZ_OP_CONV_FWD" and len(q["p"]) > 8:
+                    q["p"][8] = None
+                acc_ops.append(q)
+            n_ph = 1 + max(e["level"] for e in sub)
+            flops = sum(2.0 * e["i"][4] * e["i"][5] * e["i"][6] * e["i"][0] * e["i"][2] * 9 for e in sub if e["code"] == "UZ_CH_CONV3")
+            chain_op = dict(code="UZ_OP_CHAIN", p=[("chaintab", idx, "ops"), ("chaintab", idx, "phases"), ("chaintab", idx, "state")],
+                            i=[n_ph, G, len(sub)], f=[], n=0, gid=("chain", idx), _acc_ops=acc_ops, _which=which,
+                            _cost_s=n_ph * 8e-6 + flops / 150e12)        # (first guess for the lane scheduler; tune_schedule measures it)
+            new_ops = [ops[k] for k in range(len(ops)) if k in anc] + [chain_op] + [ops[k] for k in range(len(ops)) if k not in anc and k not in Es]
+            ops[:] = new_ops
+            self.chain_info[which] = dict(ops=len(sub), phases=n_ph, convs=sum(e["code"] == "UZ_CH_CONV3" for e in sub), workgroups=G)
+        # the chain's weight images: one buffer and one packing launch per tape, a scheduling group of its own behind the parameter bound
+        for which, imgs in self._chain_imgs.items():
+            if not imgs:
+                continue
+            off = blk = 0
+            refs = []
+            for wkey, e in imgs.items():
+                e["off"], e["blk0"] = off, blk
+                refs += [self.P(wkey), ("chainimg", which, wkey), ("raw", e["mc"]), ("raw", e["kc"]), ("raw", e["cin"]), ("raw", e["dgrad"]), ("raw", blk)]
+                off += e["bytes"]
+                blk += e["blocks"]
+            self._chain_imgbuf[which] = self.vec("chain_weights:" + which, off // 4)
+            tape = self.fwd_ops if which == "fwd" else self.bwd_ops
+            pos = next(k for k, o in enumerate(tape) if o["code"] == "UZ_OP_CHAIN")
+            tape.insert(pos, dict(code="UZ_OP_CHAIN_PACK", p=[self.ptr_table(refs), ("amaxw", 0), self._chain_imgbuf[which]], i=[len(imgs), blk], f=[], n=0,
+                                  gid=("chainpack", which)))
+
+    def _chain_tables(self, idx):
+        """Device tables of chain `idx` (built once, when the arena exists): the sub-ops in phase order with their tile ranges, the
+        phase table, the barrier state."""
+        ch = self._chains[idx]
+        if "dev" in ch:
+            return ch["dev"]
+        codes = _ffi.chain_codes()
+        sub = ch["sub"]
+        arr = (_ffi.uz_chain_op * len(sub))()
+        phases, tile0, cur = [], 0, None
+        for k, e in enumerate(sub):
+            a = arr[k]
+            a.code = codes[e["code"]]
+            assert len(e["i"]) <= 16 and len(e["p"]) <= 12
+            for j, v in enumerate(e["i"]):
+                a.i[j] = int(v)
+            for j, v in enumerate(e["f"]):
+                a.f[j] = float(v)
+            for j, r in enumerate(e["p"]):
+                a.p[j] = self._resolve(r, 0)
+            nt = self.L.uz_chain_op_tiles(C.byref(a))
+            if nt <= 0:
+                raise RuntimeError(f"chain sub-op {e['code']} {e['i']} is not covered by uz_chain_run")
+            if e["level"] != cur:
+                cur, tile0 = e["level"], 0
+                phases.append([k, 0])
+            a.tile0, a.ntiles = tile0, nt
+            tile0 += nt
+            phases[-1][1] += 1
+            e["tile0"], e["ntiles"] = a.tile0, nt
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+        dev = dict(ops=raw.to(self.device), phases=torch.tensor(phases, dtype=torch.int32).reshape(-1).to(self.device),
+                   state=torch.zeros(self.L.uz_chain_state_bytes() // 4, dtype=torch.int32, device=self.device), n_phases=len(phases))
+        ch["dev"] = dev
+        return dev
+
+    def chain_status(self, stream_ptr):
+        """0 when every chain launch of the last replay completed, else 1 + the phase whose grid barrier timed out (synchronises)."""
+        worst = 0
+        for idx, ch in enumerate(self._chains):
+            if "dev" in ch:
+                out = C.c_int(0)
+                _ffi.check(self.L.uz_chain_status(C.c_void_p(ch["dev"]["state"].data_ptr()), C.byref(out), C.c_void_p(stream_ptr)), "chain_status")
+                worst = max(worst, out.value)
+        return worst
+
     def finalize(self, want_backward=True):
         assert not self.finalized
         self.loss_scale = self.vec("loss_scale", 1)
@@ -1473,6 +1742,7 @@ class Plan:
         self._bwd = []
         self._round4_passes()
         self._b16_pass()
+        self._chain_pass()
         # magnitude-bound slots: zero the forward-side slots and measure the parameter bound at the head of the forward tape,
         # zero the backward-side slots at the head of the backward tape (group 0 of each tape: everything else depends on it)
         self.n_amax_fwd = self.n_amax
@@ -1621,6 +1891,10 @@ class Plan:
             return self.base + 4 * self._packbuf[r[1]].buf.off + self._packs[r[1]][r[2]]["off"]
         if kind == "raw":
             return int(r[1])
+        if kind == "chaintab":
+            return self._chain_tables(r[1])[r[2]].data_ptr()
+        if kind == "chainimg":
+            return self.base + 4 * self._chain_imgbuf[r[1]].buf.off + self._chain_imgs[r[1]][r[2]]["off"]
         if kind == "win":                                    # depth window of a volume: starts one slice before the view
             v = r[1]
             return self.base + 4 * v.buf.off + v.buf.esz * (((v.b0 - 1) * v.buf.C + v.c0) * v.buf.H * v.buf.W)
@@ -1671,7 +1945,7 @@ class Plan:
         "UZ_OP_BCAST_CHANNELS": (1,), "UZ_OP_BCAST_CHANNELS_BWD": (1,), "UZ_OP_EVENT_RECORD": (0,), "UZ_OP_ABSMAX": (1,),
         "UZ_OP_ADD_VIEWS": (2,), "UZ_OP_W3D_PERMUTE": (1,), "UZ_OP_AVGPOOL3D_FWD": (1,), "UZ_OP_AVGPOOL3D_BWD": (1,),
         "UZ_OP_DEPTH_LERP_FWD": (1,), "UZ_OP_DEPTH_LERP_BWD": (1,), "UZ_OP_NEAREST3D_FWD": (1,), "UZ_OP_NEAREST3D_BWD": (1,),
-        "UZ_OP_ABSMAX_COPY": (), "UZ_OP_PACK_WEIGHTS": (2,), "UZ_OP_CHAN_SUM_PARTIALS": (1,), "UZ_OP_CHAN_SUM_TABLE": (1,), "UZ_OP_WGRAD_REDUCE_TABLE": (1,),
+        "UZ_OP_ABSMAX_COPY": (), "UZ_OP_PACK_WEIGHTS": (2,), "UZ_OP_CHAIN_PACK": (2,), "UZ_OP_CHAN_SUM_PARTIALS": (1,), "UZ_OP_CHAN_SUM_TABLE": (1,), "UZ_OP_WGRAD_REDUCE_TABLE": (1,),
     }
 
     def _op_writes(self, o):
@@ -1684,6 +1958,16 @@ class Plan:
     def _access(self, o):
         """(reads, writes, accumulates) of op `o` as resource ranges.  Accumulates (bound slots only) commute with each other
         and conflict with reads and writes."""
+        if o["code"] == "UZ_OP_CHAIN":
+            reads, writes, accs = [], [], []
+            for q in o["_acc_ops"]:
+                r_, w_, a_ = self._access(q)
+                reads.extend(r_); writes.extend(w_); accs.extend(a_)
+            reads.extend(self._resources(self._chain_imgbuf[o["_which"]]))
+            # (inside the launch the accumulators of a bound slot are ordered against its readers by the phases; towards the rest of the
+            #  tape the launch both accumulates into and reads those slots: declare them written)
+            writes.extend(accs)
+            return reads, writes, []
         wr = self._op_writes(o)
         reads, writes, accs = [], [], []
         for j, r in enumerate(o["p"]):
@@ -1718,7 +2002,11 @@ class Plan:
         if kind == "ptrtab":
             return [x for q in self.ptr_tables[r[1]] for x in self._resources(q)]
         if kind == "packw":
-            return self._resources(self._packbuf[r[1]])
+            return self._resources(self._packbuf[r[1]]) if r[1] in self._packbuf else [(("packw", r[1]), 0, 1)]      # (before finalize() lays the images out: _chain_pass)
+        if kind == "chainimg":
+            return self._resources(self._chain_imgbuf[r[1]])
+        if kind == "chaintab":
+            return []
         if kind == "win":
             return self._resources(r[1])
         if kind in ("gywin", "gyvol"):
@@ -1749,6 +2037,8 @@ class Plan:
         """Rough duration (s) of one op on MI355X - only the RELATIVE sizes matter: the list scheduler
         below uses them to decide which chains can share a lane."""
         c, i = o["code"], o["i"]
+        if "_cost_s" in o:
+            return o["_cost_s"]
         if c in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA", "UZ_OP_CONV_BWD_WEIGHT"):
             cin, cout, N, H, W, ks = i[0], i[2], i[4], i[5], i[6], i[7]
             flop = 2.0 * N * H * W * cin * cout * ks * ks
@@ -1776,6 +2066,8 @@ class Plan:
         kernel) and 1.4 - 10x long for the large ones: the list scheduler then queued off-critical weight gradients in front of a
         critical chain on the same lane and the chain started 2 ms late."""
         c = o["code"]
+        if "_cost_s" in o:
+            return o["_cost_s"]
         m = Plan._op_cost(o) * 1e6
         if c in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA"):
             us = 28.0 + 0.62 * m

@@ -1,0 +1,792 @@
+// Deep-level chain (round 6): the 16 x 16 ... 2 x 2 levels of PHiSeg as PHASES of one persistent launch.
+//
+// Reference: phiseg.py:14-39 (DownConvolutionalBlock, levels 3 - 6), :42-73 (UpConvolutionalBlock), :76-106 (SampleZBlock),
+// :209-221 / :269-277 (the likelihood's small planes), each Conv2D unit = torchlayers.py:18-21.  Per training step these levels
+// are ~340 launches of 5 - 40 us on the step's critical chains, and beside the device-filling convolutions of the other lanes
+// every one of them waits 80 - 180 us for a register slot (profiles/NOTES_r5.md section 4).  Here a sub-DAG of such ops is
+// ONE launch of slim workgroups (256 threads, one wave per SIMD, <= 128 VGPRs, < 8 KB of LDS: a workgroup starts beside any other
+// kernel's waves and then KEEPS its slot) that walk a phase table built by the host (unet-zoo_amd/_plan.py, Plan._chain_pass):
+//
+//   for phase:  for tile = workgroup; tile < tiles of the phase; tile += workgroups:  run the tile of the sub-op it falls into
+//               grid barrier among the launch's own workgroups
+//
+// Sub-ops of one phase are independent (the host levels the sub-DAG), so the tiny planes of the posterior, the prior and the
+// likelihood fill a phase together.  Design points:
+//   * 3 x 3 convolutions: fp16 matrix pipe with two-piece split operands (split_f16.h: a 22-bit emulation, three products per
+//     operand pair, fp32 accumulation - the arithmetic of conv_split.hip).  A WAVE owns a 64-channel x 32-pixel output tile over a
+//     slice of the contraction; operands go global memory -> registers -> MFMA, no LDS and no workgroup barrier inside a tile:
+//     the weights come from an image packed once per tape in fragment order (one 16-byte load per lane and fragment), the
+//     activations as eight channel-strided dwords per lane (coalesced over the 32 pixels of a fragment column), split on the way.
+//     Planes this small live in L2; what the launch is sized by is latency, not bytes.
+//   * split-K: the host cuts a convolution's contraction into S slices so that a phase has enough tiles; slices leave partial
+//     sums (slabs) that the unit's BatchNorm adds in slab order (bias first) - deterministic, no atomics on data.
+//   * BatchNorm: one workgroup per channel, the channel's batch (<= 8192 values) in registers, fp64 statistics in a fixed order.
+//   * cross-workgroup visibility: every workgroup ends a phase with s_waitcnt vmcnt(0) + an agent-scope release fence before it
+//     arrives on the barrier counter and starts the next with an agent-scope acquire fence (MI355X_MICROARCH.md, barrier-counter).
+//     Bound slots and the barrier words are only touched with agent-scope atomics.  Every spin is bounded: a barrier that does not
+//     complete raises the status word, every workgroup leaves, uz_chain_status reports the phase.
+#include <stdlib.h>
+#include "uz_common.h"
+#include "split_f16.h"
+
+namespace {
+
+using uz::f32x16; using uz::f16x8; using uz::u32x4;
+
+constexpr int NTHREADS = 256;
+constexpr int PXB = 32;            // pixels per wave tile (one MFMA column block)
+constexpr int COB = 64;            // output channels per wave tile (two MFMA row blocks)
+constexpr int BN_MAX_EPT = 32;     // values per thread of a BatchNorm tile: N*H*W <= 8192
+constexpr int MIN_KSTEPS = 6;      // 16-deep k-steps a split-K slice keeps at least
+
+// state words (unsigned), each on a 64-byte line of its own
+constexpr int ST_ARRIVE = 0, ST_STATUS = 16, ST_STAMPS = 32, MAX_STAMPS = 512, ST_WORDS = ST_STAMPS + 2 * MAX_STAMPS;      // stamps: 100 MHz clock of workgroup 0 at launch and behind every phase (diagnostics)
+constexpr unsigned SPIN_LIMIT = 4u << 20;     // polls of ~0.5 us: ~2 s
+
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float amax_read_agent(const float* slot) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < uz::AMAX_SUB; ++i)
+        m = fmaxf(m, __builtin_bit_cast(float, ld_agent(reinterpret_cast<const unsigned*>(slot) + i * uz::AMAX_STRIDE)));
+    return m;
+}
+__device__ __forceinline__ void amax_publish_key(float m, float* slot, unsigned key) {
+    if (m > 0.f) uz::amax_publish_one(m, slot, key);
+}
+
+// Grid barrier among the launch's workgroups.  Returns false when the launch is to be abandoned (status word raised).
+__device__ __forceinline__ bool grid_barrier(unsigned* st, unsigned n_wg, unsigned epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every wave: its stores have left
+    __syncthreads();
+    __shared__ unsigned verdict;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler may drop the wait behind the write-back: cdna guide, compiler hazard)
+        __hip_atomic_fetch_add(st + ST_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = n_wg * epoch;
+        unsigned ok = 1, spins = 0;
+        while (ld_agent(st + ST_ARRIVE) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > SPIN_LIMIT || ld_agent(st + ST_STATUS) != 0u) {
+                __hip_atomic_fetch_max(st + ST_STATUS, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        verdict = ok;
+    }
+    __syncthreads();
+    return verdict != 0u;
+}
+
+// ---------------------------------------------------------------------------------------------- 3 x 3 convolution, matrix pipe
+// wave tile wt -> (slice s, channel block cb, pixel block pb), pixel block fastest: the four waves of a workgroup tile share the
+// weight fragments of one (s, cb) through L1.
+__device__ __forceinline__ void conv3_wave_tile(const uz_chain_op& o, int wt, int lane) {
+    const int Kc = o.i[0], KcTot = o.i[1], Mc = o.i[2], McTot = o.i[3], N = o.i[4], H = o.i[5], W = o.i[6], S = o.i[7], accumulate = o.i[8];
+    const int HW = H * W, P = N * HW, PB = (P + PXB - 1) / PXB, CB = (Mc + COB - 1) / COB;
+    const int pb = wt % PB, r = wt / PB, cb = r % CB, s = r / CB;
+    if (s >= S) return;
+    const float* __restrict__ x = static_cast<const float*>(o.p[0]);
+    const char* __restrict__ img = static_cast<const char*>(o.p[1]);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int p = pb * PXB + l31;
+    const bool pvalid = p < P;
+    const int pc = pvalid ? p : P - 1;
+    const int n = pc / HW, hw = pc - n * HW, h = hw / W, w = hw - h * W;
+    const float ax = amax_read_agent(static_cast<const float*>(o.p[5])), aw = amax_read_agent(static_cast<const float*>(o.p[6]));
+    const float sx = uz::split_scale(ax);
+    const int KB = Kc / 16, M32 = Mc / 32, T = 9 * KB;
+    const int q0 = (int)((long long)s * T / S), q1 = (int)((long long)(s + 1) * T / S);
+    const float* xb = x + ((size_t)n * KcTot + 8 * half) * HW;
+    const bool second = cb * 2 + 1 < M32;                       // the tile's upper 32 channels exist (Mc % 64 == 32: last block is half)
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    int tap = q0 / KB, kb = q0 - tap * KB;
+    for (int q = q0; q < q1; ++q) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int hh = h + dy, ww = w + dx;
+        const bool inb = pvalid && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        const float* src = xb + (size_t)(kb * 16) * HW + (inb ? hh * W + ww : hw);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * HW];
+        // weight fragments: [(tap * KB + kb)][m32][piece][lane][8 halfs]
+        const char* wsrc = img + ((size_t)(tap * KB + kb) * M32 + cb * 2) * 2048 + lane * 16;
+        u32x4 a0[2], a1[2];
+        a0[0] = *reinterpret_cast<const u32x4*>(wsrc);
+        a0[1] = *reinterpret_cast<const u32x4*>(wsrc + 1024);
+        if (second) {
+            a1[0] = *reinterpret_cast<const u32x4*>(wsrc + 2048);
+            a1[1] = *reinterpret_cast<const u32x4*>(wsrc + 3072);
+        }
+        u32x4 b[2];
+        {
+            unsigned p1[4], p2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v0 = inb ? v[2 * j] * sx : 0.f, v1 = inb ? v[2 * j + 1] * sx : 0.f;
+                uz::split2(v0, v1, p1[j], p2[j]);
+            }
+            b[0] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+            b[1] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+        }
+        // smallest products first (conv_split.hip: a2 b1, a1 b2, a1 b1)
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[1]), __builtin_bit_cast(f16x8, b[0]), acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[0]), __builtin_bit_cast(f16x8, b[1]), acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[0]), __builtin_bit_cast(f16x8, b[0]), acc0, 0, 0, 0);
+        if (second) {
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[1]), __builtin_bit_cast(f16x8, b[0]), acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[0]), __builtin_bit_cast(f16x8, b[1]), acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[0]), __builtin_bit_cast(f16x8, b[0]), acc1, 0, 0, 0);
+        }
+        if (++kb == KB) { kb = 0; ++tap; }
+    }
+    if (!pvalid) return;
+    const float inv = uz::split_inv_scale(ax) * uz::split_inv_scale(aw);
+    const float* __restrict__ bias = static_cast<const float*>(o.p[2]);
+    if (S == 1) {
+        float* y = static_cast<float*>(o.p[3]) + (size_t)n * McTot * HW + hw;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (m == 1 && !second) break;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = cb * COB + m * 32 + (i >> 2) * 8 + 4 * half + (i & 3);
+                float val = (m == 0 ? acc0[i] : acc1[i]) * inv + (bias ? bias[co] : 0.f);
+                float* dst = y + (size_t)co * HW;
+                if (accumulate) val += *dst;
+                *dst = val;
+            }
+        }
+    } else {
+        float* sl = static_cast<float*>(o.p[4]) + ((size_t)s * N + n) * Mc * HW + hw;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (m == 1 && !second) break;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = cb * COB + m * 32 + (i >> 2) * 8 + 4 * half + (i & 3);
+                sl[(size_t)co * HW] = (m == 0 ? acc0[i] : acc1[i]) * inv;
+            }
+        }
+    }
+}
+__host__ __device__ inline int conv3_wave_tiles(const uz_chain_op& o) {
+    const int P = o.i[4] * o.i[5] * o.i[6];
+    return ((P + PXB - 1) / PXB) * ((o.i[2] + COB - 1) / COB) * o.i[7];
+}
+
+// ---------------------------------------------------------------------------------------------- 3 x 3 convolution, <= 4 input channels
+// tile = 256 pixels x 16 output channels; a thread keeps its pixel's 9 Kc inputs in registers
+constexpr int SMALL_CO = 16;
+__device__ __forceinline__ void conv3_small_tile(const uz_chain_op& o, int tile) {
+    const int Kc = o.i[0], KcTot = o.i[1], Mc = o.i[2], McTot = o.i[3], N = o.i[4], H = o.i[5], W = o.i[6];
+    const int HW = H * W, P = N * HW, PT = (P + NTHREADS - 1) / NTHREADS;
+    const int pt = tile % PT, ct = tile / PT;
+    const int p = pt * NTHREADS + threadIdx.x;
+    if (p >= P) return;
+    const int n = p / HW, hw = p - n * HW, h = hw / W, w = hw - h * W;
+    const float* __restrict__ x = static_cast<const float*>(o.p[0]) + (size_t)n * KcTot * HW;
+    const float* __restrict__ wt = static_cast<const float*>(o.p[1]);
+    const float* __restrict__ bias = static_cast<const float*>(o.p[2]);
+    float xv[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+            const bool inb = c < Kc && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            xv[c][t] = inb ? x[(size_t)c * HW + hh * W + ww] : 0.f;
+        }
+    float* y = static_cast<float*>(o.p[3]) + (size_t)n * McTot * HW + hw;
+    const int co0 = ct * SMALL_CO, co1 = min(Mc, co0 + SMALL_CO);
+    for (int co = co0; co < co1; ++co) {
+        float acc = bias ? bias[co] : 0.f;
+        const float* wr = wt + (size_t)co * Kc * 9;             // uniform address: scalar loads
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < Kc) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = fmaf(wr[c * 9 + t], xv[c][t], acc);
+            }
+        }
+        y[(size_t)co * HW] = acc;
+    }
+}
+// data gradient of the same layers: dx (Kc <= 4 channels) = sum over Mc channels and taps; tile = 64 pixels, the four waves split the
+// Mc channels and add their partial sums through LDS in wave order
+__device__ __forceinline__ void conv3_small_bwd_tile(const uz_chain_op& o, int tile, float* sm /* >= 4 * 64 * 4 */) {
+    const int Kc = o.i[0], KcTot = o.i[1], Mc = o.i[2], McTot = o.i[3], N = o.i[4], H = o.i[5], W = o.i[6], accumulate = o.i[7];
+    const int HW = H * W, P = N * HW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = tile * 64 + lane;
+    const bool pvalid = p < P;
+    const int pc = pvalid ? p : P - 1;
+    const int n = pc / HW, hw = pc - n * HW, h = hw / W, w = hw - h * W;
+    const float* __restrict__ dy = static_cast<const float*>(o.p[0]) + (size_t)n * McTot * HW;
+    const float* __restrict__ wt = static_cast<const float*>(o.p[1]);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int cpw = (Mc + 3) / 4, c0 = wave * cpw, c1 = min(Mc, c0 + cpw);
+    for (int co = c0; co < c1; ++co) {
+        const float* wr = wt + (size_t)co * Kc * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // dx[p] += dy[p - tap offset] * w[co][ci][t]  <=>  gather dy at (h - dy_t, w - dx_t)
+            const int hh = h - (t / 3 - 1), ww = w - (t % 3 - 1);
+            const bool inb = hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const float g = inb ? dy[(size_t)co * HW + hh * W + ww] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < Kc) acc[c] = fmaf(wr[c * 9 + t], g, acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sm[(wave * 4 + c) * 64 + lane] = acc[c];
+    __syncthreads();
+    if (wave == 0 && pvalid) {
+        float* dx = static_cast<float*>(o.p[2]) + (size_t)n * KcTot * HW + hw;
+        for (int c = 0; c < Kc; ++c) {
+            float v = ((sm[(0 * 4 + c) * 64 + lane] + sm[(1 * 4 + c) * 64 + lane]) + sm[(2 * 4 + c) * 64 + lane]) + sm[(3 * 4 + c) * 64 + lane];
+            if (accumulate) v += dx[(size_t)c * HW];
+            dx[(size_t)c * HW] = v;
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------- BatchNorm + ReLU, forward
+// one workgroup per channel; element i = tid + 256 j of the channel's batch lives in register j (the map and the order of every sum are
+// bn_fused_small_fwd's: identical bits for N*H*W <= 4096 given identical y)
+__device__ __forceinline__ void bn_fwd_tile(const uz_chain_op& o, int c, double* smd /* >= 8 */, float* smf /* >= 2 */) {
+    const int C = o.i[0], CtotY = o.i[1], CtotA = o.i[2], N = o.i[3], HW = o.i[4], relu = o.i[5], S = o.i[6];
+    const float eps = o.f[0], momentum = o.f[1];
+    const int total = N * HW, tid = threadIdx.x;
+    float* __restrict__ y = static_cast<float*>(o.p[0]);
+    float v[BN_MAX_EPT];
+    if (S > 1) {
+        const float* __restrict__ slab = static_cast<const float*>(o.p[7]);
+        const float* cbias = static_cast<const float*>(o.p[9]);
+        const float bv = cbias ? cbias[c] : 0.f;
+        const size_t nsl = (size_t)N * C * HW;
+#pragma unroll
+        for (int j = 0; j < BN_MAX_EPT; ++j) {
+            const int i = tid + NTHREADS * j;
+            v[j] = 0.f;
+            if (i < total) {
+                const int b = i / HW, q = i - b * HW;
+                const size_t e = ((size_t)b * C + c) * HW + q;
+                float t = bv;
+                for (int k = 0; k < S; ++k) t += slab[(size_t)k * nsl + e];
+                v[j] = t;
+                y[((size_t)b * CtotY + c) * HW + q] = t;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < BN_MAX_EPT; ++j) {
+            const int i = tid + NTHREADS * j;
+            v[j] = 0.f;
+            if (i < total) {
+                const int b = i / HW, q = i - b * HW;
+                v[j] = y[((size_t)b * CtotY + c) * HW + q];
+            }
+        }
+    }
+    double v2[2] = {0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < BN_MAX_EPT; ++j)
+        if (tid + NTHREADS * j < total) { const double d = v[j]; v2[0] += d; v2[1] += d * d; }
+    uz::block_sum_d<2>(v2, smd);
+    if (tid == 0) {
+        float* save = static_cast<float*>(o.p[5]);
+        float* rmean = static_cast<float*>(o.p[3]);
+        float* rvar = static_cast<float*>(o.p[4]);
+        const double n = (double)total;
+        const double mean = v2[0] / n;
+        double var = v2[1] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        save[c] = (float)mean;
+        save[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) {
+            const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+            rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
+            rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+        }
+        smf[0] = save[c]; smf[1] = save[C + c];
+    }
+    __syncthreads();
+    const float mean = smf[0], rstd = smf[1];
+    const float* gamma = static_cast<const float*>(o.p[1]);
+    const float* beta = static_cast<const float*>(o.p[2]);
+    const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+    const float alpha = g * rstd, beta_ = bb - mean * alpha;
+    const float floor_ = relu ? 0.f : -INFINITY;
+    float* __restrict__ a = static_cast<float*>(o.p[6]);
+    float vmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < BN_MAX_EPT; ++j) {
+        const int i = tid + NTHREADS * j;
+        if (i < total) {
+            const int b = i / HW, q = i - b * HW;
+            const float rr = fmaxf(fmaf(v[j], alpha, beta_), floor_);
+            a[((size_t)b * CtotA + c) * HW + q] = rr;
+            vmax = fmaxf(vmax, fabsf(rr));
+        }
+    }
+    float* amax = static_cast<float*>(o.p[8]);
+    if (amax) {
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, ofs, 64));
+        if ((tid & 63) == 0) amax_publish_key(vmax, amax, (unsigned)c * 4u + (tid >> 6));
+    }
+    __syncthreads();                                            // smd / smf are reused by the workgroup's next tile
+}
+
+// ---------------------------------------------------------------------------------------------- BatchNorm + ReLU, backward
+// dz = dA * (a > 0); dgamma = sum dz x_hat, dbeta = sum dz; dy = alpha (dz - mean(dz) - x_hat mean(dz x_hat)); dbias = sum dy
+// (bn_fused_small_bwd's arithmetic: the same element map and summation order)
+__device__ __forceinline__ void bn_bwd_tile(const uz_chain_op& o, int c, double* smd /* >= 12 */, float* smf /* >= 2 */) {
+    const int C = o.i[0], CtotDa = o.i[1], CtotY = o.i[2], N = o.i[3], HW = o.i[4], relu = o.i[5], S = o.i[6];
+    const int total = N * HW, tid = threadIdx.x;
+    const float* __restrict__ da = static_cast<const float*>(o.p[0]);
+    const float* __restrict__ y = static_cast<const float*>(o.p[1]);
+    const float* gamma = static_cast<const float*>(o.p[2]);
+    const float* save = static_cast<const float*>(o.p[3]);
+    const float mean = save[c], rstd = save[C + c];
+    const float g = gamma ? gamma[c] : 1.f;
+    // beta is not needed: the ReLU mask a > 0 <=> alpha y + beta' > 0 is recomputed from the stored statistics and beta (p[10])
+    const float* beta = static_cast<const float*>(o.p[10]);
+    const float bb = beta ? beta[c] : 0.f;
+    const float alpha = g * rstd, beta_ = bb - mean * alpha;
+    // (dz stays in registers; x_hat is formed again from y in the second pass - the channel's y is an L2 / L1 hit by then - which keeps the
+    //  tile under the launch's 128 registers)
+    float dz[BN_MAX_EPT];
+    const float* __restrict__ slab = static_cast<const float*>(o.p[9]);
+    const size_t nsl = (size_t)N * C * HW;
+    double v2[2] = {0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < BN_MAX_EPT; ++j) {
+        const int i = tid + NTHREADS * j;
+        dz[j] = 0.f;
+        if (i < total) {
+            const int b = i / HW, q = i - b * HW;
+            const float yv = y[((size_t)b * CtotY + c) * HW + q];
+            float d;
+            if (S > 1) {
+                const size_t e = ((size_t)b * C + c) * HW + q;
+                d = 0.f;
+                for (int k = 0; k < S; ++k) d += slab[(size_t)k * nsl + e];
+            } else {
+                d = da[((size_t)b * CtotDa + c) * HW + q];
+            }
+            if (relu && !(fmaf(yv, alpha, beta_) > 0.f)) d = 0.f;
+            dz[j] = d;
+            const float xh = (yv - mean) * rstd;
+            v2[0] += (double)d; v2[1] += (double)(d * xh);
+        }
+    }
+    uz::block_sum_d<2>(v2, smd);
+    if (tid == 0) {
+        float* dgamma = static_cast<float*>(o.p[5]);
+        float* dbeta = static_cast<float*>(o.p[6]);
+        if (dgamma) dgamma[c] = (float)v2[1];
+        if (dbeta) dbeta[c] = (float)v2[0];
+        smf[0] = (float)(v2[0] / (double)total);
+        smf[1] = (float)(v2[1] / (double)total);
+    }
+    __syncthreads();
+    const float m1 = smf[0], m2 = smf[1];
+    float* __restrict__ dyo = static_cast<float*>(o.p[4]);
+    float vmax = 0.f;
+    double sd[1] = {0.0};
+#pragma unroll
+    for (int j = 0; j < BN_MAX_EPT; ++j) {
+        const int i = tid + NTHREADS * j;
+        if (i < total) {
+            const int b = i / HW, q = i - b * HW;
+            const float xh = (y[((size_t)b * CtotY + c) * HW + q] - mean) * rstd;
+            const float r = alpha * (dz[j] - m1 - xh * m2);
+            dyo[((size_t)b * C + c) * HW + q] = r;                // dy: a contiguous [N][C][HW] tensor of its own
+            vmax = fmaxf(vmax, fabsf(r));
+            sd[0] += (double)r;
+        }
+    }
+    float* dbias = static_cast<float*>(o.p[7]);
+    __syncthreads();
+    uz::block_sum_d<1>(sd, smd);
+    if (tid == 0 && dbias) dbias[c] = (float)sd[0];
+    float* amax = static_cast<float*>(o.p[8]);
+    if (amax) {
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, ofs, 64));
+        if ((tid & 63) == 0) amax_publish_key(vmax, amax, (unsigned)c * 4u + (tid >> 6));
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------- pooling / interpolation
+constexpr int RS_PER_TILE = 1024;          // outputs per tile: four per thread
+__device__ __forceinline__ void forward_bound(const uz_chain_op& o, int tile) {
+    const float* xa = static_cast<const float*>(o.p[2]);
+    float* ya = static_cast<float*>(o.p[3]);
+    if (xa && ya && tile == 0 && threadIdx.x == 0) amax_publish_key(amax_read_agent(xa), ya, 0u);
+}
+__device__ __forceinline__ void avgpool_fwd_tile(const uz_chain_op& o, int tile) {
+    const int C = o.i[0], CtotX = o.i[1], CtotY = o.i[2], N = o.i[3], Hi = o.i[4], Wi = o.i[5];
+    const int H = (Hi + 1) / 2, W = (Wi + 1) / 2;
+    forward_bound(o, tile);
+    const float* __restrict__ x = static_cast<const float*>(o.p[0]);
+    float* __restrict__ y = static_cast<float*>(o.p[1]);
+    const long long total = (long long)N * C * H * W;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long e = (long long)tile * RS_PER_TILE + k * NTHREADS + threadIdx.x;
+        if (e >= total) continue;
+        const int ox = (int)(e % W); long long t = e / W;
+        const int oy = (int)(t % H); t /= H;
+        const int c = (int)(t % C), b = (int)(t / C);
+        const float* s = x + ((size_t)b * CtotX + c) * Hi * Wi;
+        const int y0 = 2 * oy, x0 = 2 * ox, y1 = min(y0 + 2, Hi), x1 = min(x0 + 2, Wi);
+        float acc = 0.f;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) acc += s[yy * Wi + xx];
+        y[((size_t)b * CtotY + c) * H * W + oy * W + ox] = acc / (float)((y1 - y0) * (x1 - x0));
+    }
+}
+__device__ __forceinline__ void avgpool_bwd_tile(const uz_chain_op& o, int tile) {
+    const int C = o.i[0], CtotDy = o.i[1], CtotDx = o.i[2], N = o.i[3], Ho = o.i[4], Wo = o.i[5], accumulate = o.i[6];
+    const int H = (Ho + 1) / 2, W = (Wo + 1) / 2;
+    const float* __restrict__ dy = static_cast<const float*>(o.p[0]);
+    float* __restrict__ dx = static_cast<float*>(o.p[1]);
+    const long long total = (long long)N * C * Ho * Wo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long e = (long long)tile * RS_PER_TILE + k * NTHREADS + threadIdx.x;
+        if (e >= total) continue;
+        const int xq = (int)(e % Wo); long long t = e / Wo;
+        const int yq = (int)(t % Ho); t /= Ho;
+        const int c = (int)(t % C), b = (int)(t / C);
+        const int oy = yq >> 1, ox = xq >> 1;
+        const int cnt = (min(2 * oy + 2, Ho) - 2 * oy) * (min(2 * ox + 2, Wo) - 2 * ox);
+        const float v = dy[((size_t)b * CtotDy + c) * H * W + oy * W + ox] / (float)cnt;
+        float* d = dx + ((size_t)b * CtotDx + c) * Ho * Wo + yq * Wo + xq;
+        *d = accumulate ? *d + v : v;
+    }
+}
+__device__ __forceinline__ void src_index(int o, float scale, int ac, int in, int& i0, int& ip, float& l0, float& l1) {
+    float r;
+    if (ac) r = scale * (float)o;
+    else { r = scale * ((float)o + 0.5f) - 0.5f; if (r < 0.f) r = 0.f; }
+    i0 = (int)r;
+    if (i0 > in - 1) i0 = in - 1;
+    ip = (i0 < in - 1) ? 1 : 0;
+    l1 = r - (float)i0;
+    l0 = 1.f - l1;
+}
+__device__ __forceinline__ void bil_scales(int H, int W, int ac, float& sh, float& sw) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    if (ac) { sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f; sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f; }
+    else { sh = 0.5f; sw = 0.5f; }
+}
+__device__ __forceinline__ void bilinear_fwd_tile(const uz_chain_op& o, int tile) {
+    const int C = o.i[0], CtotX = o.i[1], CtotY = o.i[2], N = o.i[3], H = o.i[4], W = o.i[5], ac = o.i[6];
+    const int Ho = 2 * H, Wo = 2 * W;
+    forward_bound(o, tile);
+    float sh, sw;
+    bil_scales(H, W, ac, sh, sw);
+    const float* __restrict__ x = static_cast<const float*>(o.p[0]);
+    float* __restrict__ y = static_cast<float*>(o.p[1]);
+    const long long total = (long long)N * C * Ho * Wo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long e = (long long)tile * RS_PER_TILE + k * NTHREADS + threadIdx.x;
+        if (e >= total) continue;
+        const int ox = (int)(e % Wo); long long t = e / Wo;
+        const int oy = (int)(t % Ho); t /= Ho;
+        const int c = (int)(t % C), b = (int)(t / C);
+        const float* s = x + ((size_t)b * CtotX + c) * H * W;
+        int h1, hp, w1, wp; float h0l, h1l, w0l, w1l;
+        src_index(oy, sh, ac, H, h1, hp, h0l, h1l);
+        src_index(ox, sw, ac, W, w1, wp, w0l, w1l);
+        const float* r0 = s + h1 * W + w1;
+        const float* r1 = r0 + hp * W;
+        y[((size_t)b * CtotY + c) * Ho * Wo + oy * Wo + ox] = h0l * (w0l * r0[0] + w1l * r0[wp]) + h1l * (w0l * r1[0] + w1l * r1[wp]);
+    }
+}
+__device__ __forceinline__ float tap_weight(int o, int osize, float scale, int ac, int isize, int i) {
+    if (o < 0 || o >= osize) return 0.f;
+    int i0, ip; float l0, l1;
+    src_index(o, scale, ac, isize, i0, ip, l0, l1);
+    return (i0 == i ? l0 : 0.f) + (i0 + ip == i ? l1 : 0.f);
+}
+// gather form (bilinear_bwd_k of resample.hip): low-resolution pixel i receives from high-resolution 2i-2 .. 2i+4
+__device__ __forceinline__ void bilinear_bwd_tile(const uz_chain_op& o, int tile) {
+    const int C = o.i[0], CtotDy = o.i[1], CtotDx = o.i[2], N = o.i[3], H = o.i[4], W = o.i[5], ac = o.i[6], accumulate = o.i[7];
+    const int Ho = 2 * H, Wo = 2 * W;
+    float sh, sw;
+    bil_scales(H, W, ac, sh, sw);
+    const float* __restrict__ dy = static_cast<const float*>(o.p[0]);
+    float* __restrict__ dx = static_cast<float*>(o.p[1]);
+    const long long total = (long long)N * C * H * W;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const long long e = (long long)tile * RS_PER_TILE + k * NTHREADS + threadIdx.x;
+        if (e >= total) continue;
+        const int ix = (int)(e % W); long long t = e / W;
+        const int iy = (int)(t % H); t /= H;
+        const int c = (int)(t % C), b = (int)(t / C);
+        const float* s = dy + ((size_t)b * CtotDy + c) * Ho * Wo;
+        const int oy0 = 2 * iy - 2, ox0 = 2 * ix - 2;
+        float wx[7];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) wx[kx] = tap_weight(ox0 + kx, Wo, sw, ac, W, ix);
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            const float wy = tap_weight(oy0 + ky, Ho, sh, ac, H, iy);
+            if (wy != 0.f) {
+                const float* row = s + (oy0 + ky) * Wo + ox0;
+                float ra = 0.f;
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx)
+                    if (wx[kx] != 0.f) ra += wx[kx] * row[kx];
+                acc += wy * ra;
+            }
+        }
+        float* d = dx + ((size_t)b * CtotDx + c) * H * W + iy * W + ix;
+        *d = accumulate ? *d + acc : acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- latent heads (L == 2)
+__device__ __forceinline__ float head_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float head_sigma(float pre, int act) { return act ? expf(pre) : head_softplus(pre); }
+// tile = 64 pixels; wave g accumulates channels g, g + 4, ... ; the four partial sums are added in wave order through LDS
+__device__ __forceinline__ void heads_fwd_tile(const uz_chain_op& o, int tile, float* sm /* >= 4 * 4 * 64 */) {
+    const int Cin = o.i[0], CinTot = o.i[1], N = o.i[2], HW = o.i[3], act = o.i[4];
+    const int P = N * HW, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = tile * 64 + lane;
+    const bool pvalid = p < P;
+    const int pc = pvalid ? p : P - 1;
+    const int n = pc / HW, q = pc - n * HW;
+    const float* __restrict__ h = static_cast<const float*>(o.p[0]) + (size_t)n * CinTot * HW + q;
+    const float* __restrict__ wm = static_cast<const float*>(o.p[1]);
+    const float* __restrict__ wsg = static_cast<const float*>(o.p[3]);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int c = wave; c < Cin; c += 4) {
+        const float v = h[(size_t)c * HW];
+        acc[0] = fmaf(wm[c], v, acc[0]); acc[1] = fmaf(wm[Cin + c], v, acc[1]);
+        acc[2] = fmaf(wsg[c], v, acc[2]); acc[3] = fmaf(wsg[Cin + c], v, acc[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sm[(wave * 4 + k) * 64 + lane] = acc[k];
+    __syncthreads();
+    if (wave == 0 && pvalid) {
+        const float* bm = static_cast<const float*>(o.p[2]);
+        const float* bs = static_cast<const float*>(o.p[4]);
+        const float* eps = static_cast<const float*>(o.p[5]);
+        float* mu = static_cast<float*>(o.p[6]);
+        float* pre = static_cast<float*>(o.p[7]);
+        float* sigma = static_cast<float*>(o.p[8]);
+        float* z = static_cast<float*>(o.p[9]);
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = ((sm[k * 64 + lane] + sm[(4 + k) * 64 + lane]) + sm[(8 + k) * 64 + lane]) + sm[(12 + k) * 64 + lane];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const size_t e = ((size_t)n * 2 + l) * HW + q;
+            const float m = t[l] + (bm ? bm[l] : 0.f), pr = t[2 + l] + (bs ? bs[l] : 0.f);
+            const float sg = head_sigma(pr, act);
+            mu[e] = m; pre[e] = pr; sigma[e] = sg;
+            if (z) z[e] = m + sg * eps[e];
+        }
+    }
+    __syncthreads();
+}
+// dh[c] (+)= w_a[0][c] dy_a[0] + w_a[1][c] dy_a[1] + w_b[0][c] dy_b[0] + w_b[1][c] dy_b[1]   (head a's rows first)
+// tile = 64 pixels x 64 channels: wave g takes channels g, g + 4, ...
+__device__ __forceinline__ void heads_bwd_data_tile(const uz_chain_op& o, int tile) {
+    const int Cin = o.i[0], CinTot = o.i[1], N = o.i[2], HW = o.i[3], accumulate = o.i[4];
+    const int P = N * HW, PT = (P + 63) / 64;
+    const int pt = tile % PT, ct = tile / PT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = pt * 64 + lane;
+    if (p >= P) return;
+    const int n = p / HW, q = p - n * HW;
+    const float* dya = static_cast<const float*>(o.p[0]);
+    const float* dyb = static_cast<const float*>(o.p[1]);
+    const float* __restrict__ wa = static_cast<const float*>(o.p[2]);
+    const float* __restrict__ wb = static_cast<const float*>(o.p[3]);
+    const float a0 = dya[((size_t)n * 2 + 0) * HW + q], a1 = dya[((size_t)n * 2 + 1) * HW + q];
+    const float b0 = dyb[((size_t)n * 2 + 0) * HW + q], b1 = dyb[((size_t)n * 2 + 1) * HW + q];
+    float* dh = static_cast<float*>(o.p[4]) + (size_t)n * CinTot * HW + q;
+    const int c1 = min(Cin, (ct + 1) * 64);
+    for (int c = ct * 64 + wave; c < c1; c += 4) {
+        float v = accumulate ? dh[(size_t)c * HW] : 0.f;
+        v = fmaf(wa[c], a0, v); v = fmaf(wa[Cin + c], a1, v);
+        v = fmaf(wb[c], b0, v); v = fmaf(wb[Cin + c], b1, v);
+        dh[(size_t)c * HW] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- tiles per sub-op (host and device agree)
+__host__ __device__ inline int op_tiles(const uz_chain_op& o) {
+    const int32_t* i = o.i;
+    switch (o.code) {
+        case UZ_CH_CONV3: return (conv3_wave_tiles(o) + 3) / 4;
+        case UZ_CH_CONV3_SMALL: return ((i[4] * i[5] * i[6] + NTHREADS - 1) / NTHREADS) * ((i[2] + SMALL_CO - 1) / SMALL_CO);
+        case UZ_CH_CONV3_SMALL_BWD_DATA: return (i[4] * i[5] * i[6] + 63) / 64;
+        case UZ_CH_BN_FWD: case UZ_CH_BN_BWD: return i[0];
+        case UZ_CH_AVGPOOL_FWD: return (int)(((long long)i[3] * i[0] * ((i[4] + 1) / 2) * ((i[5] + 1) / 2) + RS_PER_TILE - 1) / RS_PER_TILE);
+        case UZ_CH_AVGPOOL_BWD: return (int)(((long long)i[3] * i[0] * i[4] * i[5] + RS_PER_TILE - 1) / RS_PER_TILE);
+        case UZ_CH_BILINEAR_FWD: return (int)(((long long)i[3] * i[0] * 4 * i[4] * i[5] + RS_PER_TILE - 1) / RS_PER_TILE);
+        case UZ_CH_BILINEAR_BWD: return (int)(((long long)i[3] * i[0] * i[4] * i[5] + RS_PER_TILE - 1) / RS_PER_TILE);
+        case UZ_CH_HEADS_FWD: return (i[2] * i[3] + 63) / 64;
+        case UZ_CH_HEADS_BWD_DATA: return ((i[2] * i[3] + 63) / 64) * ((i[0] + 63) / 64);
+        default: return -1;
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS, 4) void chain_kernel(const uz_chain_op* __restrict__ ops, const int32_t* __restrict__ phases, int n_phases,
+                                                         unsigned* state) {
+    __shared__ double smd[16];
+    __shared__ float smf[4 * 4 * 64 + 8];
+    const int wg = blockIdx.x, G = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(state + ST_STAMPS);
+    if (wg == 0 && threadIdx.x == 0) stamps[0] = wall_clock64();
+    for (int ph = 0; ph < n_phases; ++ph) {
+        const int op0 = phases[2 * ph], nops = phases[2 * ph + 1];
+        const uz_chain_op& last = ops[op0 + nops - 1];
+        const int ntiles = last.tile0 + last.ntiles;
+        for (int t = wg; t < ntiles; t += G) {
+            int k = op0;
+            while (k + 1 < op0 + nops && t >= ops[k + 1].tile0) ++k;
+            const uz_chain_op& o = ops[k];
+            const int lt = t - o.tile0;
+            switch (o.code) {
+                case UZ_CH_CONV3: {
+                    const int wt = lt * 4 + wave;
+                    if (wt < conv3_wave_tiles(o)) conv3_wave_tile(o, wt, lane);
+                    break;
+                }
+                case UZ_CH_CONV3_SMALL: conv3_small_tile(o, lt); break;
+                case UZ_CH_CONV3_SMALL_BWD_DATA: conv3_small_bwd_tile(o, lt, smf); break;
+                case UZ_CH_BN_FWD: bn_fwd_tile(o, lt, smd, smf); break;
+                case UZ_CH_BN_BWD: bn_bwd_tile(o, lt, smd, smf); break;
+                case UZ_CH_AVGPOOL_FWD: avgpool_fwd_tile(o, lt); break;
+                case UZ_CH_AVGPOOL_BWD: avgpool_bwd_tile(o, lt); break;
+                case UZ_CH_BILINEAR_FWD: bilinear_fwd_tile(o, lt); break;
+                case UZ_CH_BILINEAR_BWD: bilinear_bwd_tile(o, lt); break;
+                case UZ_CH_HEADS_FWD: heads_fwd_tile(o, lt, smf); break;
+                case UZ_CH_HEADS_BWD_DATA: heads_bwd_data_tile(o, lt); break;
+                default: break;
+            }
+        }
+        if (ph + 1 < n_phases && !grid_barrier(state, (unsigned)G, (unsigned)(ph + 1))) return;
+        if (wg == 0 && threadIdx.x == 0 && ph + 1 < MAX_STAMPS) stamps[ph + 1] = wall_clock64();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- weight images
+// one thread per (tap * KB + kb, m32, lane): eight weights -> the lane's 16 bytes of either piece
+struct PackRow { const float* w; char* img; int Mc, Kc, Cin, dgrad, blk0; };
+__global__ __launch_bounds__(NTHREADS) void chain_pack_kernel(const int64_t* __restrict__ table, int n_layers, const float* __restrict__ w_amax, int* flags) {
+    // find the layer of this block (table rows are 7 int64; blk0 ascending)
+    int lo = 0, hi = n_layers - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)table[(size_t)mid * 7 + 6] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* row = table + (size_t)lo * 7;
+    const float* __restrict__ w = reinterpret_cast<const float*>(row[0]);
+    char* img = reinterpret_cast<char*>(row[1]);
+    const int Mc = (int)row[2], Kc = (int)row[3], Cin = (int)row[4], dgrad = (int)row[5], blk0 = (int)row[6];
+    const int KB = Kc / 16, M32 = Mc / 32;
+    const long long units = (long long)9 * KB * M32 * 64;
+    const long long u = (long long)(blockIdx.x - blk0) * NTHREADS + threadIdx.x;
+    if (u >= units) return;
+    const int lane = (int)(u & 63);
+    long long t = u >> 6;
+    const int m32 = (int)(t % M32); t /= M32;
+    const int kb = (int)(t % KB), tap = (int)(t / KB);
+    const int m = m32 * 32 + (lane & 31), k0 = kb * 16 + 8 * (lane >> 5);
+    const float s = uz::split_scale(uz::amax_read(w_amax));
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        // forward: w[co = m][ci = k][tap]; data gradient: w[co = k][ci = m][8 - tap]   (parameter layout [Cout][Cin][3][3])
+        const size_t e = dgrad ? ((size_t)(k0 + j) * Cin + m) * 9 + (8 - tap) : ((size_t)m * Cin + (k0 + j)) * 9 + tap;
+        v[j] = w[e] * s;
+    }
+    unsigned p1[4], p2[4];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bad |= uz::bound_violated(v[2 * j], v[2 * j + 1]);
+        uz::split2(v[2 * j], v[2 * j + 1], p1[j], p2[j]);
+    }
+    if (bad && flags) atomicOr(flags, uz::FLAG_W_BOUND);
+    char* dst = img + ((size_t)(tap * KB + kb) * M32 + m32) * 2048 + lane * 16;
+    *reinterpret_cast<u32x4*>(dst) = u32x4{p1[0], p1[1], p1[2], p1[3]};
+    *reinterpret_cast<u32x4*>(dst + 1024) = u32x4{p2[0], p2[1], p2[2], p2[3]};
+}
+
+}  // namespace
+
+extern "C" int uz_chain_op_tiles(const uz_chain_op* op) {
+    if (!op) return -1;
+    const int32_t* i = op->i;
+    switch (op->code) {
+        case UZ_CH_CONV3:
+            if (i[0] % 16 || i[2] % 32 || i[0] < 16 || i[7] < 1 || i[7] > 9 * (i[0] / 16)) return -1;
+            break;
+        case UZ_CH_CONV3_SMALL: case UZ_CH_CONV3_SMALL_BWD_DATA:
+            if (i[0] < 1 || i[0] > 4) return -1;
+            break;
+        case UZ_CH_BN_FWD: case UZ_CH_BN_BWD:
+            if ((long long)i[3] * i[4] > (long long)BN_MAX_EPT * NTHREADS) return -1;
+            break;
+        default: break;
+    }
+    return op_tiles(*op);
+}
+extern "C" int uz_chain_conv_ksplit(int Kc, int Mc, int N, int H, int W, int n_workgroups) {
+    if (Kc % 16 || Kc < 16) return 1;
+    const int P = N * H * W, base = ((P + PXB - 1) / PXB) * ((Mc + COB - 1) / COB);        // wave tiles without split
+    const int T = 9 * (Kc / 16);
+    const int want = 4 * n_workgroups;                                                     // one wave tile per wave of the launch
+    int S = (want + base - 1) / base;
+    const int smax = T / MIN_KSTEPS > 0 ? T / MIN_KSTEPS : 1;
+    if (S > smax) S = smax;
+    if (S < 1) S = 1;
+    return S;
+}
+extern "C" size_t uz_chain_packed_bytes(int Kc, int Mc) { return (size_t)9 * (Kc / 16) * (Mc / 32) * 2048; }
+extern "C" int uz_chain_pack_blocks(int Kc, int Mc) { return (int)(((long long)9 * (Kc / 16) * (Mc / 32) * 64 + NTHREADS - 1) / NTHREADS); }
+extern "C" int uz_chain_pack_weights(const int64_t* table, int n_layers, int total_blocks, const float* w_amax, void* stream) {
+    UZ_REQUIRE(table && w_amax && n_layers > 0 && total_blocks > 0, "chain_pack_weights: empty table");
+    hipLaunchKernelGGL(chain_pack_kernel, dim3(total_blocks), dim3(NTHREADS), 0, uz::S(stream), table, n_layers, w_amax, uz::dev_flags_ptr());
+    return uz::check_launch("chain_pack_kernel");
+}
+extern "C" size_t uz_chain_state_bytes(void) { return ST_WORDS * sizeof(unsigned); }
+extern "C" int uz_chain_run(const uz_chain_op* ops, const int32_t* phases, int n_phases, int n_workgroups, void* state, void* stream) {
+    UZ_REQUIRE(ops && phases && state && n_phases > 0, "chain_run: null table");
+    UZ_REQUIRE(n_workgroups >= 1 && n_workgroups <= 1024, "chain_run: %d workgroups outside [1, 1024]", n_workgroups);
+    if (hipMemsetAsync(state, 0, ST_STAMPS * sizeof(unsigned), uz::S(stream)) != hipSuccess) return uz::fail("chain_run: hipMemsetAsync failed");
+    hipLaunchKernelGGL(chain_kernel, dim3(n_workgroups), dim3(NTHREADS), 0, uz::S(stream), ops, phases, n_phases, static_cast<unsigned*>(state));
+    return uz::check_launch("chain_kernel");
+}
+extern "C" int uz_chain_status(const void* state, int* out, void* stream) {
+    UZ_REQUIRE(state && out, "chain_status: null argument");
+    unsigned w = 0;
+    if (hipStreamSynchronize(uz::S(stream)) != hipSuccess) return uz::fail("chain_status: synchronize failed");
+    if (hipMemcpy(&w, static_cast<const unsigned*>(state) + ST_STATUS, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return uz::fail("chain_status: copy failed");
+    *out = (int)w;
+    return 0;
+}
