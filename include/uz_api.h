@@ -474,9 +474,10 @@ void uz_graph_destroy(void* graph_exec);
  * The 16 x 16 ... 2 x 2 levels of PHiSeg (phiseg.py:14-39 encoder levels 3 - 6, :42-73 UpConvolutionalBlock, :76-106 SampleZBlock,
  * :209-221 / :269-277 the likelihood's small planes) are ~340 launches of 5 - 40 us per step on the step's critical chains; beside the
  * device-filling convolutions of the other lanes each of them waits 80 - 180 us for a register slot.  uz_chain_run executes a whole
- * sub-DAG of such ops as PHASES of ONE persistent launch: n_workgroups slim workgroups (256 threads, <= 128 VGPRs, < 8 KB LDS - they
- * start beside any other kernel and then keep their slot) walk the phase table; the sub-ops of one phase are independent and are cut
- * into workgroup tiles (tile0 / ntiles, counted by uz_chain_op_tiles) dealt round-robin; phases are separated by a grid barrier among
+ * sub-DAG of such ops as PHASES of ONE persistent launch: n_workgroups resident workgroups (1024 threads = four waves per SIMD at
+ * <= 128 VGPRs, one per CU at most) walk the phase table; the sub-ops of one phase are independent and are cut into tiles (ntiles,
+ * counted by uz_chain_op_tiles: WAVE tiles for UZ_CH_CONV3, workgroup tiles otherwise) dealt round-robin to the workgroups starting
+ * at workgroup tile0; phases are separated by a grid barrier among
  * the launch's own workgroups (bounded spin: a barrier that does not complete within ~2 s raises the status word and every
  * workgroup leaves - uz_chain_status).  Sub-ops mirror the per-op entry points above (same operands, same results to fp32 rounding;
  * the 3 x 3 convolutions run on the fp16 matrix pipe with two-piece split operands like uz_conv_fwd_ex's split path, staged straight
@@ -496,8 +497,9 @@ enum {
   UZ_CH_BN_BWD,         /* backward of UZ_CH_BN_FWD. p = dA, y, gamma, save, dy [N][C][HW], dgamma, dbeta, dbias|NULL, dy_amax|NULL, slabs|NULL (of dA), beta; i = C, CtotDa, CtotY, N, HW, relu, S */
   UZ_CH_AVGPOOL_BWD,    /* p = dy, dx; i = C, CtotDy, CtotDx, N, H, W (high-resolution plane), accumulate */
   UZ_CH_BILINEAR_BWD,   /* p = dy, dx; i = C, CtotDy, CtotDx, N, H, W (low-resolution plane), align_corners, accumulate */
-  UZ_CH_HEADS_BWD_DATA, /* uz_latent_heads_bwd_data with L == 2: p = dy_a, dy_b, w_a, w_b, dh; i = Cin, CinTot, N, HW, accumulate */
+  UZ_CH_LATENT_HEADS_BWD, /* uz_latent_sample_bwd + uz_latent_heads_bwd_data (L == 2): p = kl_dmu|NULL, kl_dsigma|NULL, dz|NULL, eps, sigma, g_mu (out), g_pre (out), w_sigma, w_mu, dh|NULL; i = Cin, CinTot, N, HW, act, accumulate */
   UZ_CH_CONV3_SMALL_BWD_DATA, /* data gradient of UZ_CH_CONV3_SMALL: p = dy, w [Mc][Kc][3][3], dx; i = Kc (<= 4, channels of dx), KcTot, Mc, McTot, N, H, W, accumulate */
+  UZ_CH_SLAB_SUM,       /* dst (+)= sum_s slabs[s] in slab order: p = slabs [S][N][C][HW], dst; i = S, N, C, CtotDst, HW, accumulate */
   UZ_CH__COUNT
 };
 typedef struct uz_chain_op {
@@ -517,7 +519,7 @@ int    uz_chain_pack_blocks(int Kc, int Mc);                      /* 256-thread 
  * w * split_scale(*w_amax) in MFMA fragment order [tap][Kc / 16][Mc / 32][piece][lane][8]; dgrad: rows = input channels, taps flipped */
 int    uz_chain_pack_weights(const int64_t* table, int n_layers, int total_blocks, const float* w_amax, void* stream);
 size_t uz_chain_state_bytes(void);
-int    uz_chain_run(const uz_chain_op* ops, const int32_t* phases, int n_phases, int n_workgroups, void* state, void* stream);
+int    uz_chain_run(const uz_chain_op* ops, const int32_t* phases, int n_phases, int n_ops, int n_workgroups, void* state, void* stream);
 int    uz_chain_status(const void* state, int* out, void* stream);   /* synchronises; out = 0 ok, else 1 + the phase whose barrier timed out */
 
 /* ---------------------------------------------------------------- data-parallel gradient exchange (RCCL over xGMI)

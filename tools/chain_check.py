@@ -48,6 +48,27 @@ worst.sort(reverse=True)
 print("buffers compared", len(worst))
 for w in worst[:12]:
     print("  ", w)
+# backward chains: the outputs of every sub-op, in phase order, against the per-op tape's buffers of the same name
+from unet_zoo_amd._plan import _ScratchView
+OUT = {"UZ_CH_BN_BWD": [4], "UZ_CH_CONV3": [3], "UZ_CH_CONV3_SMALL_BWD_DATA": [2], "UZ_CH_AVGPOOL_BWD": [1], "UZ_CH_BILINEAR_BWD": [1],
+       "UZ_CH_LATENT_HEADS_BWD": [5, 6, 9], "UZ_CH_SLAB_SUM": [1]}
+shown = 0
+for ch in pc._chains:
+    if ch["which"] != "bwd":
+        continue
+    for e in ch["sub"]:
+        for j in OUT.get(e["code"], []):
+            v = e["p"][j]
+            if not isinstance(v, View):
+                continue
+            r = byname.get(v.buf.name)
+            if r is None:
+                continue
+            tc, tr = pc.tensor(v), pr.tensor(View(r, v.c0, v.C))
+            d = (tc - tr).abs().max().item(); sc = tr.abs().max().item() + 1e-30
+            if d / sc > 1e-3 and shown < 25:
+                shown += 1
+                print("   BWD MISMATCH", ch["net"], "phase", e["level"], e["code"], e["i"], v.buf.name, (v.c0, v.C), "rel", d / sc, "ref max", sc)
 gr = ref._ptab.gflat; gc = net._ptab.gflat
 print("grad rel err (flat, inf-norm / max)", ((gr - gc).abs().max() / gr.abs().max()).item(), "l2 rel", ((gr - gc).norm() / gr.norm()).item())
 for k in range(5):

@@ -188,7 +188,8 @@ class Plan:
         self._nclaims = {}                   # backward writers seen per buffer (conv_relu's folded ReLU backward checks it was the last one)
         self._dbias_jobs = []                # folded ReLU backward: bias gradients still to be summed from their partials (one launch at the tape's end)
         self.chain_px = 0                    # NativeModel.chain_px: planes (N*H*W) up to which a tape's ops run as phases of ONE persistent launch (_chain_pass)
-        self.chain_wgs = 256                 # workgroups of that launch
+        self.chain_wgs = 256                 # workgroups of that launch (forward tape: nothing else runs beside it)
+        self.chain_wgs_bwd = 80              # ... of a backward chain (it runs beside the other lanes' device-filling kernels; at most three chains at once)
         self._chains = []                    # per chain op: dict(sub=[...], phases=[...]) -> device tables built on first resolve
         self._chain_imgs = {}                # tape -> {wkey: dict(off, bytes, mc, kc, cin, dgrad)} packed weight images of the chain convolutions
         self._chain_imgbuf = {}
@@ -1481,6 +1482,21 @@ class Plan:
                 hist[space] = keep
         return deps
 
+    @staticmethod
+    def _chain_net(o):
+        """The sub-network an op belongs to (first component of the name of the tensor / parameter it is about): backward chains are
+        built per sub-network, so that the prior's deep levels - which only wait for the KL gradients - run beside the likelihood's
+        device-filling kernels instead of behind them."""
+        c, p = o["code"], o["p"]
+        ref = {"UZ_OP_BN_RELU_BWD": 1, "UZ_OP_BN_RELU_FWD": 0, "UZ_OP_AVGPOOL_BWD": 0, "UZ_OP_BILINEAR_BWD": 0,
+               "UZ_OP_LATENT_BWD": 5, "UZ_OP_LATENT_HEADS_BWD_DATA": 0}.get(c)
+        if c in ("UZ_OP_CONV_BWD_DATA", "UZ_OP_CONV_FWD"):
+            return p[1][1].split(".")[0] if isinstance(p[1], tuple) else None
+        if ref is None or not isinstance(p[ref], View):
+            return None
+        nm = p[ref].buf.name
+        return (nm[5:] if nm.startswith("grad:") else nm).split(".")[0]
+
     def _chain_eligible_fwd(self, o, px):
         c, i, p = o["code"], o["i"], o["p"]
         b16 = len(i) > 13 and i[13]
@@ -1503,130 +1519,55 @@ class Plan:
             return i[2] == 2 and i[3] * i[4] * i[5] <= px
         return False
 
+    def _chain_eligible_bwd(self, o, px):
+        c, i, p = o["code"], o["i"], o["p"]
+        if len(i) > 13 and i[13]:
+            return False
+        own_dy = lambda r: isinstance(r, _ScratchView) and r.view is not None and r.zkey is None
+        if c == "UZ_OP_BN_RELU_BWD":
+            return (i[4] * i[5] * i[6] <= px and i[8] == 0 and i[9] == 0 and i[10] == 0 and own_dy(p[5]) and isinstance(p[0], View) and p[0].nb is None
+                    and isinstance(p[1], View) and not p[1].buf.packed)
+        if c == "UZ_OP_CONV_BWD_DATA":
+            cout, cin, N, H, W, ks = i[0], i[2], i[4], i[5], i[6], i[7]
+            fold = i[10] if len(i) > 10 else 0
+            if ks != 3 or N * H * W > px or not own_dy(p[0]) or fold not in (0, 3) or (len(i) > 11 and i[11]) or p[2].nb is not None:
+                return False
+            if cin <= 4:
+                return fold == 0
+            return cout % 16 == 0 and cin % 32 == 0 and p[4] is not None
+        if c == "UZ_OP_AVGPOOL_BWD":
+            return i[3] * i[4] * i[5] <= px and (len(p) < 3 or p[2] is None) and p[0].nb is None
+        if c == "UZ_OP_BILINEAR_BWD":
+            return i[3] * 4 * i[4] * i[5] <= px and (len(p) < 3 or p[2] is None) and p[0].nb is None
+        if c == "UZ_OP_LATENT_BWD":
+            return isinstance(p[5], View) and p[5].C == 2 and p[5].N * p[5].H * p[5].W <= px
+        if c == "UZ_OP_LATENT_HEADS_BWD_DATA":
+            return i[0] == 2 and i[3] * i[4] * i[5] <= px
+        return False
+
     def _chain_pass(self):
-        """Collects the small-plane ops of the forward tape into ONE UZ_OP_CHAIN op (uz_chain_run): the sub-DAG is levelled into
-        phases of independent sub-ops, every 3 x 3 convolution gets a split-K factor and a slab buffer of its own, its weights a
-        fragment-ordered image packed once per tape (UZ_OP_CHAIN_PACK).  The tape keeps a valid program order: [every op the chain
-        depends on] [chain] [the rest]; the set must be convex in the dependency DAG (an op outside may not sit between two inside)."""
+        """Collects the small-plane ops of a tape into UZ_OP_CHAIN ops (uz_chain_run): a sub-DAG is levelled into phases of independent
+        sub-ops, every 3 x 3 convolution gets a split-K factor and a slab buffer of its own, its weights a fragment-ordered image packed
+        once per tape (UZ_OP_CHAIN_PACK).  Forward tape: one chain; backward tape: one chain per sub-network (_chain_net).  The tape
+        keeps a valid program order: [every op the chain depends on] [chain] [the rest]; a chain's set must be convex in the dependency
+        DAG (an op outside may not sit between two inside) - offenders and what hangs behind them stay per-op launches."""
         self.chain_info = {}
         px = self._chain_limit()
         if px <= 0:
             return
-        for which, ops, elig in (("fwd", self.fwd_ops, self._chain_eligible_fwd),):
-            if not ops:
-                continue
-            E = [k for k, o in enumerate(ops) if elig(o, px)]
-            if len(E) < 8:
-                continue
-            deps = self._hazard_deps(ops)
-            # a unit's convolution and BatchNorm go together: a BatchNorm whose convolution leaves slabs for it must run where that
-            # convolution runs
-            ywriter = {}
-            for k, o in enumerate(ops):
-                if o["code"] == "UZ_OP_CONV_FWD" and isinstance(o["p"][3], View):
-                    ywriter[(id(o["p"][3].buf), o["p"][3].c0)] = k
-            Es = set(E)
-            changed = True
-            while changed:
-                changed = False
-                for k in sorted(Es):
-                    o = ops[k]
-                    if o["code"] == "UZ_OP_BN_RELU_FWD" and o["i"][9] > 0:
-                        ck = ywriter.get((id(o["p"][0].buf), o["p"][0].c0))
-                        if ck is None or ck not in Es:
-                            Es.discard(k); changed = True
-                    if o["code"] == "UZ_OP_CONV_FWD" and o["i"][9]:
-                        bk = next((j for j in range(k + 1, len(ops)) if ops[j]["code"] == "UZ_OP_BN_RELU_FWD" and ops[j]["p"][0].buf is o["p"][3].buf
-                                   and ops[j]["p"][0].c0 == o["p"][3].c0), None)
-                        if bk is None or bk not in Es:
-                            Es.discard(k); changed = True
-                # convexity: no op outside may both depend on the set and be depended on by it
-                desc = set()                       # ops (in or out) that depend on the set
-                for k in range(len(ops)):
-                    if any(d in Es or d in desc for d in deps[k]):
-                        desc.add(k)
-                bad = {k for k in Es if any((d not in Es) and (d in desc) for d in deps[k])}
-                if bad:
-                    # drop the offenders and everything of the set behind them
-                    drop = set(bad)
-                    for k in sorted(Es):
-                        if any(d in drop for d in deps[k]):
-                            drop.add(k)
-                    Es -= drop
-                    changed = True
-            if len(Es) < 8:
-                continue
-            # ancestors of the set (outside it) go first
-            anc = set()
-            for k in reversed(range(len(ops))):
-                if k in Es or k in anc:
-                    anc.update(d for d in deps[k] if d not in Es)
-            # levels inside the set
-            level = {}
-            for k in sorted(Es):
-                level[k] = 1 + max((level[d] for d in deps[k] if d in Es), default=-1)
-            order = sorted(Es, key=lambda k: (level[k], k))
-            sub, slab_of = [], {}
-            imgs = self._chain_imgs.setdefault(which, {})
-            G = int(os.environ.get("UZ_CHAIN_WGS", str(self.chain_wgs)))
-            for k in order:
-                o = ops[k]
-                c, i, p = o["code"], o["i"], o["p"]
-                if c == "UZ_OP_CONV_FWD":
-                    cin, cout, N, H, W = i[0], i[2], i[4], i[5], i[6]
-                    if cin <= 4:
-                        e = dict(code="UZ_CH_CONV3_SMALL", p=[p[0], p[1], p[2], p[3]], i=[cin, i[1], cout, i[3], N, H, W], f=[])
-                    else:
-                        has_bn = any(ops[j]["code"] == "UZ_OP_BN_RELU_FWD" and j in Es and ops[j]["p"][0].buf is p[3].buf and ops[j]["p"][0].c0 == p[3].c0 for j in range(k + 1, len(ops)))
-                        S = self.L.uz_chain_conv_ksplit(cin, cout, N, H, W, G) if has_bn else 1
-                        wkey = p[1][1]
-                        assert p[1][0] == "param" and p[1][2] == 0, p[1]
-                        if wkey not in imgs:
-                            imgs[wkey] = dict(mc=cout, kc=cin, cin=cin, dgrad=0, bytes=self.L.uz_chain_packed_bytes(cin, cout), blocks=self.L.uz_chain_pack_blocks(cin, cout))
-                        slab = self.vec(wkey + ":chslab", S * N * cout * H * W) if S > 1 else None
-                        if slab is not None:
-                            slab_of[(id(p[3].buf), p[3].c0)] = (slab, S)
-                        e = dict(code="UZ_CH_CONV3", p=[p[0], ("chainimg", which, wkey), p[2] if S == 1 else None, p[3] if S == 1 else None, slab, p[5], p[6]],
-                                 i=[cin, i[1], cout, i[3], N, H, W, S, 0], f=[])
-                        # the image replaces the per-tape LDS image of the split kernels
-                        self._packs["fwd"].pop(wkey, None)
-                elif c == "UZ_OP_BN_RELU_FWD":
-                    slab, S = slab_of.get((id(p[0].buf), p[0].c0), (None, 1))
-                    cbias = None
-                    if S > 1:
-                        ck = ywriter[(id(p[0].buf), p[0].c0)]
-                        cbias = ops[ck]["p"][2]
-                    e = dict(code="UZ_CH_BN_FWD", p=[p[0], p[1], p[2], p[3], p[4], p[5], p[6], slab, p[8], cbias],
-                             i=[i[0], i[1], i[2], i[3], i[4] * i[5], i[7], S], f=[o["f"][0], o["f"][1]])
-                elif c == "UZ_OP_AVGPOOL_FWD":
-                    e = dict(code="UZ_CH_AVGPOOL_FWD", p=[p[0], p[1], p[2], p[3]], i=i[:6], f=[])
-                elif c == "UZ_OP_BILINEAR_FWD":
-                    e = dict(code="UZ_CH_BILINEAR_FWD", p=[p[0], p[1], p[2], p[3]], i=i[:7], f=[])
-                elif c == "UZ_OP_LATENT_HEADS_FWD":
-                    e = dict(code="UZ_CH_HEADS_FWD", p=list(p[:10]), i=[i[0], i[1], i[3], i[4] * i[5], i[6]], f=[])
-                else:
-                    raise AssertionError(c)
-                e["level"], e["orig"] = level[k], o
-                sub.append(e)
-            idx = len(self._chains)
-            self._chains.append(dict(sub=sub, which=which, n_wgs=G))
-            # access of the whole launch = the union of what its sub-ops touch (the packed images instead of the split kernels' ones)
-            acc_ops = []
-            for e in sub:
-                q = dict(e["orig"])
-                q["p"] = list(q["p"])
-                if q["code"] == "UZ_OP_CONV_FWD" and len(q["p"]) > 8:
-                    q["p"][8] = None
-                acc_ops.append(q)
-            n_ph = 1 + max(e["level"] for e in sub)
-            flops = sum(2.0 * e["i"][4] * e["i"][5] * e["i"][6] * e["i"][0] * e["i"][2] * 9 for e in sub if e["code"] == "UZ_CH_CONV3")
-            chain_op = dict(code="UZ_OP_CHAIN", p=[("chaintab", idx, "ops"), ("chaintab", idx, "phases"), ("chaintab", idx, "state")],
-                            i=[n_ph, G, len(sub)], f=[], n=0, gid=("chain", idx), _acc_ops=acc_ops, _which=which,
-                            _cost_s=n_ph * 8e-6 + flops / 150e12)        # (first guess for the lane scheduler; tune_schedule measures it)
-            new_ops = [ops[k] for k in range(len(ops)) if k in anc] + [chain_op] + [ops[k] for k in range(len(ops)) if k not in anc and k not in Es]
-            ops[:] = new_ops
-            self.chain_info[which] = dict(ops=len(sub), phases=n_ph, convs=sum(e["code"] == "UZ_CH_CONV3" for e in sub), workgroups=G)
-        # the chain's weight images: one buffer and one packing launch per tape, a scheduling group of its own behind the parameter bound
+        jobs = [("fwd", self.fwd_ops, self._chain_eligible_fwd, None)]
+        if self.bwd_ops and os.environ.get("UZ_CHAIN_BWD", "1") == "1":
+            nets = []
+            for o in self.bwd_ops:
+                if self._chain_eligible_bwd(o, px):
+                    nt = self._chain_net(o)
+                    if nt not in nets:
+                        nets.append(nt)
+            jobs += [("bwd", self.bwd_ops, self._chain_eligible_bwd, nt) for nt in nets]
+        for which, ops, elig, net in jobs:
+            if ops:
+                self._chain_build(which, ops, elig, net, px)
+        # the chains' weight images: one buffer and one packing launch per tape, a scheduling group of its own behind the parameter bound
         for which, imgs in self._chain_imgs.items():
             if not imgs:
                 continue
@@ -1642,6 +1583,205 @@ class Plan:
             pos = next(k for k, o in enumerate(tape) if o["code"] == "UZ_OP_CHAIN")
             tape.insert(pos, dict(code="UZ_OP_CHAIN_PACK", p=[self.ptr_table(refs), ("amaxw", 0), self._chain_imgbuf[which]], i=[len(imgs), blk], f=[], n=0,
                                   gid=("chainpack", which)))
+
+    def _chain_build(self, which, ops, elig, net, px):
+        fwd = which == "fwd"
+        E = [k for k, o in enumerate(ops) if elig(o, px) and (net is None or self._chain_net(o) == net)]
+        if len(E) < 8:
+            return
+        deps = self._hazard_deps(ops)
+        vkey = lambda v: (id(v.buf), v.c0) if isinstance(v, View) else (id(v.view.buf), v.view.c0)
+        # pairing tables
+        ywriter, bn_of_y, dgrad_of_dx, bn_of_da = {}, {}, {}, {}
+        for k, o in enumerate(ops):
+            c = o["code"]
+            if c == "UZ_OP_CONV_FWD" and isinstance(o["p"][3], View):
+                ywriter[vkey(o["p"][3])] = k
+            elif c == "UZ_OP_BN_RELU_FWD":
+                bn_of_y[vkey(o["p"][0])] = k
+            elif c == "UZ_OP_CONV_BWD_DATA" and isinstance(o["p"][2], View):
+                dgrad_of_dx.setdefault(vkey(o["p"][2]), []).append(k)
+            elif c == "UZ_OP_BN_RELU_BWD" and isinstance(o["p"][0], View):
+                bn_of_da[vkey(o["p"][0])] = k
+        Es = set(E)
+        changed = True
+        while changed:
+            changed = False
+            for k in sorted(Es):
+                o = ops[k]
+                c = o["code"]
+                if c == "UZ_OP_BN_RELU_FWD" and o["i"][9] > 0 and ywriter.get(vkey(o["p"][0])) not in Es:
+                    Es.discard(k); changed = True                 # its convolution leaves slabs for it outside the chain
+                elif c == "UZ_OP_CONV_FWD" and o["i"][9] and bn_of_y.get(vkey(o["p"][3])) not in Es:
+                    Es.discard(k); changed = True
+                elif c == "UZ_OP_BN_RELU_BWD" and len(o["i"]) > 11 and o["i"][11] > 0:
+                    dg = dgrad_of_dx.get(vkey(o["p"][0]), [])
+                    if len(dg) != 1 or dg[0] not in Es:
+                        Es.discard(k); changed = True             # dA arrives as slabs of a data gradient that is not in the chain
+                elif c == "UZ_OP_CONV_BWD_DATA" and len(o["i"]) > 10 and o["i"][10] == 3 and bn_of_da.get(vkey(o["p"][2])) not in Es:
+                    Es.discard(k); changed = True
+                elif c == "UZ_OP_LATENT_BWD" and not (k + 1 < len(ops) and ops[k + 1]["code"] == "UZ_OP_LATENT_HEADS_BWD_DATA" and (k + 1) in Es):
+                    Es.discard(k); changed = True
+                elif c == "UZ_OP_LATENT_HEADS_BWD_DATA" and not (k >= 1 and ops[k - 1]["code"] == "UZ_OP_LATENT_BWD" and (k - 1) in Es):
+                    Es.discard(k); changed = True
+            # convexity: no op outside may both depend on the set and be depended on by it
+            desc = set()
+            for k in range(len(ops)):
+                if any(d in Es or d in desc for d in deps[k]):
+                    desc.add(k)
+            bad = {k for k in Es if any((d not in Es) and (d in desc) for d in deps[k])}
+            if bad:
+                drop = set(bad)
+                for k in sorted(Es):
+                    if any(d in drop for d in deps[k]):
+                        drop.add(k)
+                Es -= drop
+                changed = True
+        if len(Es) < 8:
+            return
+        anc = set()
+        for k in reversed(range(len(ops))):
+            if k in Es or k in anc:
+                anc.update(d for d in deps[k] if d not in Es)
+        # a scheduling group (one unit's ops, same gid, back to back) shares the lane's scratch - a unit's dy, a convolution's split-K
+        # slabs - which the dependency analysis does not see: a group moves in front of the chain as a whole or not at all
+        runs, a0 = [], 0
+        for k in range(1, len(ops) + 1):
+            if k == len(ops) or ops[k]["gid"] != ops[a0]["gid"]:
+                runs.append((a0, k)); a0 = k
+        grew = True
+        while grew:
+            grew = False
+            for a0, b0 in runs:
+                if any(k in anc for k in range(a0, b0)):
+                    for k in range(a0, b0):
+                        if k not in Es and k not in anc:
+                            anc.add(k); grew = True
+            for k in sorted(anc, reverse=True):
+                for d in deps[k]:
+                    if d not in Es and d not in anc:
+                        anc.add(d); grew = True
+        desc = set()
+        for k in range(len(ops)):
+            if any(d in Es or d in desc for d in deps[k]):
+                desc.add(k)
+        if any(k in desc for k in anc):
+            return                                            # a group straddles the chain: leave this tape / sub-network per-op
+        level = {}
+        for k in sorted(Es):
+            level[k] = 1 + max((level[d] for d in deps[k] if d in Es), default=-1)
+        imgs = self._chain_imgs.setdefault(which, {})
+        G = int(os.environ.get("UZ_CHAIN_WGS" if fwd else "UZ_CHAIN_WGS_BWD", str(self.chain_wgs if fwd else self.chain_wgs_bwd)))
+        sub = []
+
+        def emit(k, code, p, i, f=(), lvl=None):
+            sub.append(dict(code=code, p=list(p), i=[int(v) for v in i], f=list(f), level=level[k] if lvl is None else lvl, orig=ops[k], k=k))
+
+        def image(wkey, mc, kc, cin, dgrad):
+            if wkey not in imgs:
+                imgs[wkey] = dict(mc=mc, kc=kc, cin=cin, dgrad=dgrad, bytes=self.L.uz_chain_packed_bytes(kc, mc), blocks=self.L.uz_chain_pack_blocks(kc, mc))
+            return ("chainimg", which, wkey)
+
+        extra_levels = {}            # op index -> 1 when a slab-sum phase was put behind it (shifts everything that depends on it)
+        slab_of = {}
+        for k in sorted(Es, key=lambda k: (level[k], k)):
+            o = ops[k]
+            c, i, p = o["code"], o["i"], o["p"]
+            if c == "UZ_OP_CONV_FWD":
+                cin, cout, N, H, W = i[0], i[2], i[4], i[5], i[6]
+                if cin <= 4:
+                    emit(k, "UZ_CH_CONV3_SMALL", [p[0], p[1], p[2], p[3]], [cin, i[1], cout, i[3], N, H, W])
+                    continue
+                bk = bn_of_y.get(vkey(p[3]))
+                S = self.L.uz_chain_conv_ksplit(cin, cout, N, H, W, G) if (bk in Es) else 1
+                wkey = p[1][1]
+                assert p[1][0] == "param" and p[1][2] == 0, p[1]
+                slab = self.vec(wkey + ":chslab", S * N * cout * H * W) if S > 1 else None
+                if slab is not None:
+                    slab_of[vkey(p[3])] = (slab, S)
+                emit(k, "UZ_CH_CONV3", [p[0], image(wkey, cout, cin, cin, 0), p[2] if S == 1 else None, p[3] if S == 1 else None, slab, p[5], p[6]],
+                     [cin, i[1], cout, i[3], N, H, W, S, 0])
+                self._packs["fwd"].pop(wkey, None)          # the image replaces the per-tape LDS image of the split kernels
+            elif c == "UZ_OP_BN_RELU_FWD":
+                slab, S = slab_of.get(vkey(p[0]), (None, 1))
+                cbias = ops[ywriter[vkey(p[0])]]["p"][2] if S > 1 else None
+                emit(k, "UZ_CH_BN_FWD", [p[0], p[1], p[2], p[3], p[4], p[5], p[6], slab, p[8], cbias], [i[0], i[1], i[2], i[3], i[4] * i[5], i[7], S], [o["f"][0], o["f"][1]])
+            elif c == "UZ_OP_AVGPOOL_FWD":
+                emit(k, "UZ_CH_AVGPOOL_FWD", [p[0], p[1], p[2], p[3]], i[:6])
+            elif c == "UZ_OP_BILINEAR_FWD":
+                emit(k, "UZ_CH_BILINEAR_FWD", [p[0], p[1], p[2], p[3]], i[:7])
+            elif c == "UZ_OP_LATENT_HEADS_FWD":
+                emit(k, "UZ_CH_HEADS_FWD", p[:10], [i[0], i[1], i[3], i[4] * i[5], i[6]])
+            elif c == "UZ_OP_BN_RELU_BWD":
+                slab, S = slab_of.get(("da",) + vkey(p[0]), (None, 1))
+                emit(k, "UZ_CH_BN_BWD", [p[0], p[1], p[2], p[4], p[5].view, p[6], p[7], p[8], p[10], slab, p[3]], [i[1], i[0], i[2], i[4], i[5] * i[6], i[7], S])
+            elif c == "UZ_OP_CONV_BWD_DATA":
+                cout, cin, N, H, W, acc = i[0], i[2], i[4], i[5], i[6], i[8]
+                wkey = p[1][1]
+                assert p[1][0] == "param" and p[1][2] == 0, p[1]
+                if cin <= 4:
+                    emit(k, "UZ_CH_CONV3_SMALL_BWD_DATA", [p[0].view, p[1], p[2]], [cin, i[3], cout, i[1], N, H, W, acc])
+                    continue
+                S = self.L.uz_chain_conv_ksplit(cout, cin, N, H, W, G)
+                folded = len(i) > 10 and i[10] == 3              # the consumer's BatchNorm backward adds the slabs (the only reader of a dA this op alone writes)
+                slab = self.vec(wkey + ":chdslab", S * N * cin * H * W) if S > 1 else None
+                emit(k, "UZ_CH_CONV3", [p[0].view, image(wkey, cin, cout, cin, 1), None, p[2] if S == 1 else None, slab, p[4], p[5]],
+                     [cout, i[1], cin, i[3], N, H, W, S, acc if S == 1 else 0])
+                if S > 1 and folded:
+                    slab_of[("da",) + vkey(p[2])] = (slab, S)
+                elif S > 1:
+                    # other writers / readers of dx: a reduction phase of its own right behind the convolution
+                    extra_levels[k] = 1
+                    emit(k, "UZ_CH_SLAB_SUM", [slab, p[2]], [S, N, cin, i[3], H * W, acc], lvl=level[k] + 0.5)
+                self._packs["bwd"].pop(wkey, None)
+            elif c == "UZ_OP_AVGPOOL_BWD":
+                emit(k, "UZ_CH_AVGPOOL_BWD", [p[0], p[1]], i[:7])
+            elif c == "UZ_OP_BILINEAR_BWD":
+                emit(k, "UZ_CH_BILINEAR_BWD", [p[0], p[1]], i[:8])
+            elif c == "UZ_OP_LATENT_BWD":
+                h = ops[k + 1]
+                hi, hp = h["i"], h["p"]
+                # (head a = the sigma head: LATENT_HEADS_BWD_DATA p = g_pre, g_mu, w_sigma, w_mu, dh)
+                emit(k, "UZ_CH_LATENT_HEADS_BWD", [p[0], p[1], p[2], p[3], p[4], p[5], p[6], hp[2], hp[3], hp[4]], [hi[1], hi[2], hi[3], hi[4] * hi[5], i[0], hi[6]],
+                     lvl=level[k + 1])
+            elif c == "UZ_OP_LATENT_HEADS_BWD_DATA":
+                pass                                              # fused into the sub-op of the LATENT_BWD in front of it
+            else:
+                raise AssertionError(c)
+        # a slab-sum phase sits at level + 0.5: renumber the levels densely, keeping the order
+        if extra_levels:
+            # everything that depends (inside the set) on an op with a slab-sum must come after the half level: recompute levels with that op one deeper
+            lv2 = {}
+            for k in sorted(Es):
+                lv2[k] = max((lv2[d] + 1 + extra_levels.get(d, 0) for d in deps[k] if d in Es), default=0)
+            for e in sub:
+                e["level"] = lv2[e["k"]] + (1 if e["code"] == "UZ_CH_SLAB_SUM" else 0)
+                if e["code"] == "UZ_CH_LATENT_HEADS_BWD":
+                    e["level"] = lv2[e["k"] + 1]
+        sub.sort(key=lambda e: (e["level"], e["k"], e["code"] == "UZ_CH_SLAB_SUM"))
+        dense = {lv: n for n, lv in enumerate(sorted({e["level"] for e in sub}))}
+        for e in sub:
+            e["level"] = dense[e["level"]]
+        idx = len(self._chains)
+        self._chains.append(dict(sub=sub, which=which, n_wgs=G, net=net))
+        # access of the whole launch = the union of what its sub-ops touch (the packed images instead of the split kernels' ones)
+        acc_ops = []
+        for k in sorted(Es):
+            q = dict(ops[k])
+            q["p"] = list(q["p"])
+            if q["code"] == "UZ_OP_CONV_FWD" and len(q["p"]) > 8:
+                q["p"][8] = None
+            if q["code"] == "UZ_OP_CONV_BWD_DATA" and len(q["p"]) > 6:
+                q["p"][6] = None
+            acc_ops.append(q)
+        n_ph = 1 + max(e["level"] for e in sub)
+        flops = sum(2.0 * e["i"][4] * e["i"][5] * e["i"][6] * e["i"][0] * e["i"][2] * 9 for e in sub if e["code"] == "UZ_CH_CONV3")
+        chain_op = dict(code="UZ_OP_CHAIN", p=[("chaintab", idx, "ops"), ("chaintab", idx, "phases"), ("chaintab", idx, "state")],
+                        i=[n_ph, G, len(sub)], f=[], n=0, gid=("chain", idx), _acc_ops=acc_ops, _which=which,
+                        _cost_s=n_ph * 12e-6 + flops / 100e12)        # (first guess for the lane scheduler; tune_schedule measures it)
+        new_ops = [ops[k] for k in range(len(ops)) if k in anc] + [chain_op] + [ops[k] for k in range(len(ops)) if k not in anc and k not in Es]
+        ops[:] = new_ops
+        self.chain_info.setdefault(which, []).append(dict(net=net, ops=len(sub), phases=n_ph, convs=sum(e["code"] == "UZ_CH_CONV3" for e in sub), workgroups=G))
 
     def _chain_tables(self, idx):
         """Device tables of chain `idx` (built once, when the arena exists): the sub-ops in phase order with their tile ranges, the
@@ -1669,7 +1809,9 @@ class Plan:
             if e["level"] != cur:
                 cur, tile0 = e["level"], 0
                 phases.append([k, 0])
-            a.tile0, a.ntiles = tile0, nt
+            # the op's tiles are dealt to the workgroups round-robin from workgroup tile0 on: behind a short op the next one starts
+            # on the workgroups the first left idle
+            a.tile0, a.ntiles = tile0 % ch["n_wgs"], nt
             tile0 += nt
             phases[-1][1] += 1
             e["tile0"], e["ntiles"] = a.tile0, nt
@@ -1963,7 +2105,7 @@ class Plan:
             for q in o["_acc_ops"]:
                 r_, w_, a_ = self._access(q)
                 reads.extend(r_); writes.extend(w_); accs.extend(a_)
-            reads.extend(self._resources(self._chain_imgbuf[o["_which"]]))
+            reads.extend(self._resources(("chainimg", o["_which"], None)))
             # (inside the launch the accumulators of a bound slot are ordered against its readers by the phases; towards the rest of the
             #  tape the launch both accumulates into and reads those slots: declare them written)
             writes.extend(accs)
@@ -2004,7 +2146,7 @@ class Plan:
         if kind == "packw":
             return self._resources(self._packbuf[r[1]]) if r[1] in self._packbuf else [(("packw", r[1]), 0, 1)]      # (before finalize() lays the images out: _chain_pass)
         if kind == "chainimg":
-            return self._resources(self._chain_imgbuf[r[1]])
+            return self._resources(self._chain_imgbuf[r[1]]) if r[1] in self._chain_imgbuf else [(("chainimg", r[1]), 0, 1)]
         if kind == "chaintab":
             return []
         if kind == "win":

@@ -4,8 +4,9 @@
 // :209-221 / :269-277 (the likelihood's small planes), each Conv2D unit = torchlayers.py:18-21.  Per training step these levels
 // are ~340 launches of 5 - 40 us on the step's critical chains, and beside the device-filling convolutions of the other lanes
 // every one of them waits 80 - 180 us for a register slot (profiles/NOTES_r5.md section 4).  Here a sub-DAG of such ops is
-// ONE launch of slim workgroups (256 threads, one wave per SIMD, <= 128 VGPRs, < 8 KB of LDS: a workgroup starts beside any other
-// kernel's waves and then KEEPS its slot) that walk a phase table built by the host (unet-zoo_amd/_plan.py, Plan._chain_pass):
+// ONE launch of resident workgroups (1024 threads = four waves per SIMD at <= 128 VGPRs, one workgroup per CU: the first form of this
+// file ran 256-thread workgroups with one wave per SIMD and was latency-bound everywhere - a tile is a chain of dependent trips to
+// L2, and only other waves hide them) that walk a phase table built by the host (unet-zoo_amd/_plan.py, Plan._chain_pass):
 //
 //   for phase:  for tile = workgroup; tile < tiles of the phase; tile += workgroups:  run the tile of the sub-op it falls into
 //               grid barrier among the launch's own workgroups
@@ -21,10 +22,14 @@
 //   * split-K: the host cuts a convolution's contraction into S slices so that a phase has enough tiles; slices leave partial
 //     sums (slabs) that the unit's BatchNorm adds in slab order (bias first) - deterministic, no atomics on data.
 //   * BatchNorm: one workgroup per channel, the channel's batch (<= 8192 values) in registers, fp64 statistics in a fixed order.
-//   * cross-workgroup visibility: every workgroup ends a phase with s_waitcnt vmcnt(0) + an agent-scope release fence before it
-//     arrives on the barrier counter and starts the next with an agent-scope acquire fence (MI355X_MICROARCH.md, barrier-counter).
-//     Bound slots and the barrier words are only touched with agent-scope atomics.  Every spin is bounded: a barrier that does not
-//     complete raises the status word, every workgroup leaves, uz_chain_status reports the phase.
+//   * cross-workgroup visibility, two forms (template SC1; UZ_CHAIN_SC1 picks): (0) every workgroup ends a phase with s_waitcnt
+//     vmcnt(0) + an agent-scope release fence before it arrives on the barrier counter and starts the next with an agent-scope
+//     acquire fence (MI355X_MICROARCH.md, barrier-counter) - every phase then starts with cold caches; (1) every tensor element that
+//     one workgroup writes and another reads inside the launch is stored write-through and loaded at agent scope (relaxed agent-scope
+//     atomics = global_store / global_load ... sc1), every storing wave drains (vmcnt(0)) before its workgroup's one lane arrives, and
+//     no cache is flushed: parameters, weight images and the op table stay cached (MI355X_MICROARCH.md, hand-off table, first row).
+//     Bound slots and the barrier words are only touched with agent-scope atomics in both forms.  Every spin is bounded: a barrier
+//     that does not complete raises the status word, every workgroup leaves, uz_chain_status reports the phase.
 #include <stdlib.h>
 #include "uz_common.h"
 #include "split_f16.h"
@@ -33,17 +38,27 @@ namespace {
 
 using uz::f32x16; using uz::f16x8; using uz::u32x4;
 
-constexpr int NTHREADS = 256;
+constexpr int NT = 1024, NW = NT / 64;   // threads / waves per workgroup
 constexpr int PXB = 32;            // pixels per wave tile (one MFMA column block)
 constexpr int COB = 64;            // output channels per wave tile (two MFMA row blocks)
-constexpr int BN_MAX_EPT = 32;     // values per thread of a BatchNorm tile: N*H*W <= 8192
+constexpr int BN_MAX_EPT = 8;      // values per thread of a BatchNorm tile: N*H*W <= 8192
 constexpr int MIN_KSTEPS = 6;      // 16-deep k-steps a split-K slice keeps at least
+constexpr int MAX_OPS = 640, MAX_PHASES = 256;      // directory kept in LDS
 
 // state words (unsigned), each on a 64-byte line of its own
 constexpr int ST_ARRIVE = 0, ST_STATUS = 16, ST_STAMPS = 32, MAX_STAMPS = 512, ST_WORDS = ST_STAMPS + 2 * MAX_STAMPS;      // stamps: 100 MHz clock of workgroup 0 at launch and behind every phase (diagnostics)
 constexpr unsigned SPIN_LIMIT = 4u << 20;     // polls of ~0.5 us: ~2 s
 
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// hand-off accesses: data another workgroup of this launch wrote / will read
+template <bool SC1> __device__ __forceinline__ float ldh(const float* p) {
+    if constexpr (SC1) return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else return *p;
+}
+template <bool SC1> __device__ __forceinline__ void sth(float* p, float v) {
+    if constexpr (SC1) __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 __device__ __forceinline__ float amax_read_agent(const float* slot) {
     float m = 0.f;
 #pragma unroll
@@ -56,40 +71,42 @@ __device__ __forceinline__ void amax_publish_key(float m, float* slot, unsigned 
 }
 
 // Grid barrier among the launch's workgroups.  Returns false when the launch is to be abandoned (status word raised).
-__device__ __forceinline__ bool grid_barrier(unsigned* st, unsigned n_wg, unsigned epoch) {
+template <bool SC1>
+__device__ __forceinline__ bool grid_barrier(unsigned* st, unsigned n_wg, unsigned epoch, unsigned* verdict) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every wave: its stores have left
     __syncthreads();
-    __shared__ unsigned verdict;
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler may drop the wait behind the write-back: cdna guide, compiler hazard)
+        if constexpr (!SC1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler may drop the wait behind the write-back: cdna guide, compiler hazard)
+        }
         __hip_atomic_fetch_add(st + ST_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = n_wg * epoch;
         unsigned ok = 1, spins = 0;
         while (ld_agent(st + ST_ARRIVE) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > SPIN_LIMIT || ld_agent(st + ST_STATUS) != 0u) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0u && ld_agent(st + ST_STATUS) != 0u)) {
                 __hip_atomic_fetch_max(st + ST_STATUS, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        verdict = ok;
+        if constexpr (!SC1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *verdict = ok;
     }
     __syncthreads();
-    return verdict != 0u;
+    return *verdict != 0u;
 }
 
 // ---------------------------------------------------------------------------------------------- 3 x 3 convolution, matrix pipe
-// wave tile wt -> (slice s, channel block cb, pixel block pb), pixel block fastest: the four waves of a workgroup tile share the
-// weight fragments of one (s, cb) through L1.
+// wave tile wt -> (slice s, channel block cb, pixel block pb), pixel block fastest
+template <bool SC1>
 __device__ __forceinline__ void conv3_wave_tile(const uz_chain_op& o, int wt, int lane) {
     const int Kc = o.i[0], KcTot = o.i[1], Mc = o.i[2], McTot = o.i[3], N = o.i[4], H = o.i[5], W = o.i[6], S = o.i[7], accumulate = o.i[8];
     const int HW = H * W, P = N * HW, PB = (P + PXB - 1) / PXB, CB = (Mc + COB - 1) / COB;
     const int pb = wt % PB, r = wt / PB, cb = r % CB, s = r / CB;
     if (s >= S) return;
-    const float* __restrict__ x = static_cast<const float*>(o.p[0]);
+    const float* x = static_cast<const float*>(o.p[0]);
     const char* __restrict__ img = static_cast<const char*>(o.p[1]);
     const int half = lane >> 5, l31 = lane & 31;
     const int p = pb * PXB + l31;
@@ -113,7 +130,7 @@ __device__ __forceinline__ void conv3_wave_tile(const uz_chain_op& o, int wt, in
         const float* src = xb + (size_t)(kb * 16) * HW + (inb ? hh * W + ww : hw);
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * HW];
+        for (int j = 0; j < 8; ++j) v[j] = ldh<SC1>(src + (size_t)j * HW);
         // weight fragments: [(tap * KB + kb)][m32][piece][lane][8 halfs]
         const char* wsrc = img + ((size_t)(tap * KB + kb) * M32 + cb * 2) * 2048 + lane * 16;
         u32x4 a0[2], a1[2];
@@ -158,8 +175,8 @@ __device__ __forceinline__ void conv3_wave_tile(const uz_chain_op& o, int wt, in
                 const int co = cb * COB + m * 32 + (i >> 2) * 8 + 4 * half + (i & 3);
                 float val = (m == 0 ? acc0[i] : acc1[i]) * inv + (bias ? bias[co] : 0.f);
                 float* dst = y + (size_t)co * HW;
-                if (accumulate) val += *dst;
-                *dst = val;
+                if (accumulate) val += ldh<SC1>(dst);
+                sth<SC1>(dst, val);
             }
         }
     } else {
@@ -170,7 +187,7 @@ __device__ __forceinline__ void conv3_wave_tile(const uz_chain_op& o, int wt, in
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int co = cb * COB + m * 32 + (i >> 2) * 8 + 4 * half + (i & 3);
-                sl[(size_t)co * HW] = (m == 0 ? acc0[i] : acc1[i]) * inv;
+                sth<SC1>(sl + (size_t)co * HW, (m == 0 ? acc0[i] : acc1[i]) * inv);
             }
         }
     }
@@ -181,16 +198,17 @@ __host__ __device__ inline int conv3_wave_tiles(const uz_chain_op& o) {
 }
 
 // ---------------------------------------------------------------------------------------------- 3 x 3 convolution, <= 4 input channels
-// tile = 256 pixels x 16 output channels; a thread keeps its pixel's 9 Kc inputs in registers
+// tile = NT pixels x 16 output channels; a thread keeps its pixel's 9 Kc inputs in registers
 constexpr int SMALL_CO = 16;
+template <bool SC1>
 __device__ __forceinline__ void conv3_small_tile(const uz_chain_op& o, int tile) {
     const int Kc = o.i[0], KcTot = o.i[1], Mc = o.i[2], McTot = o.i[3], N = o.i[4], H = o.i[5], W = o.i[6];
-    const int HW = H * W, P = N * HW, PT = (P + NTHREADS - 1) / NTHREADS;
+    const int HW = H * W, P = N * HW, PT = (P + NT - 1) / NT;
     const int pt = tile % PT, ct = tile / PT;
-    const int p = pt * NTHREADS + threadIdx.x;
+    const int p = pt * NT + threadIdx.x;
     if (p >= P) return;
     const int n = p / HW, hw = p - n * HW, h = hw / W, w = hw - h * W;
-    const float* __restrict__ x = static_cast<const float*>(o.p[0]) + (size_t)n * KcTot * HW;
+    const float* x = static_cast<const float*>(o.p[0]) + (size_t)n * KcTot * HW;
     const float* __restrict__ wt = static_cast<const float*>(o.p[1]);
     const float* __restrict__ bias = static_cast<const float*>(o.p[2]);
     float xv[4][9];
@@ -200,13 +218,13 @@ __device__ __forceinline__ void conv3_small_tile(const uz_chain_op& o, int tile)
         for (int t = 0; t < 9; ++t) {
             const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
             const bool inb = c < Kc && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            xv[c][t] = inb ? x[(size_t)c * HW + hh * W + ww] : 0.f;
+            xv[c][t] = inb ? ldh<SC1>(x + (size_t)c * HW + hh * W + ww) : 0.f;
         }
     float* y = static_cast<float*>(o.p[3]) + (size_t)n * McTot * HW + hw;
     const int co0 = ct * SMALL_CO, co1 = min(Mc, co0 + SMALL_CO);
     for (int co = co0; co < co1; ++co) {
         float acc = bias ? bias[co] : 0.f;
-        const float* wr = wt + (size_t)co * Kc * 9;             // uniform address: scalar loads
+        const float* wr = wt + (size_t)co * Kc * 9;             // uniform address: scalar loads (parameters: never written inside the launch)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (c < Kc) {
@@ -214,12 +232,13 @@ __device__ __forceinline__ void conv3_small_tile(const uz_chain_op& o, int tile)
                 for (int t = 0; t < 9; ++t) acc = fmaf(wr[c * 9 + t], xv[c][t], acc);
             }
         }
-        y[(size_t)co * HW] = acc;
+        sth<SC1>(y + (size_t)co * HW, acc);
     }
 }
-// data gradient of the same layers: dx (Kc <= 4 channels) = sum over Mc channels and taps; tile = 64 pixels, the four waves split the
+// data gradient of the same layers: dx (Kc <= 4 channels) = sum over Mc channels and taps; tile = 64 pixels, the waves split the
 // Mc channels and add their partial sums through LDS in wave order
-__device__ __forceinline__ void conv3_small_bwd_tile(const uz_chain_op& o, int tile, float* sm /* >= 4 * 64 * 4 */) {
+template <bool SC1>
+__device__ __forceinline__ void conv3_small_bwd_tile(const uz_chain_op& o, int tile, float* sm /* >= NW * 4 * 64 */) {
     const int Kc = o.i[0], KcTot = o.i[1], Mc = o.i[2], McTot = o.i[3], N = o.i[4], H = o.i[5], W = o.i[6], accumulate = o.i[7];
     const int HW = H * W, P = N * HW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -227,10 +246,10 @@ __device__ __forceinline__ void conv3_small_bwd_tile(const uz_chain_op& o, int t
     const bool pvalid = p < P;
     const int pc = pvalid ? p : P - 1;
     const int n = pc / HW, hw = pc - n * HW, h = hw / W, w = hw - h * W;
-    const float* __restrict__ dy = static_cast<const float*>(o.p[0]) + (size_t)n * McTot * HW;
+    const float* dy = static_cast<const float*>(o.p[0]) + (size_t)n * McTot * HW;
     const float* __restrict__ wt = static_cast<const float*>(o.p[1]);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const int cpw = (Mc + 3) / 4, c0 = wave * cpw, c1 = min(Mc, c0 + cpw);
+    const int cpw = (Mc + NW - 1) / NW, c0 = wave * cpw, c1 = min(Mc, c0 + cpw);
     for (int co = c0; co < c1; ++co) {
         const float* wr = wt + (size_t)co * Kc * 9;
 #pragma unroll
@@ -238,7 +257,7 @@ __device__ __forceinline__ void conv3_small_bwd_tile(const uz_chain_op& o, int t
             // dx[p] += dy[p - tap offset] * w[co][ci][t]  <=>  gather dy at (h - dy_t, w - dx_t)
             const int hh = h - (t / 3 - 1), ww = w - (t % 3 - 1);
             const bool inb = hh >= 0 && hh < H && ww >= 0 && ww < W;
-            const float g = inb ? dy[(size_t)co * HW + hh * W + ww] : 0.f;
+            const float g = inb ? ldh<SC1>(dy + (size_t)co * HW + hh * W + ww) : 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (c < Kc) acc[c] = fmaf(wr[c * 9 + t], g, acc[c]);
@@ -250,57 +269,101 @@ __device__ __forceinline__ void conv3_small_bwd_tile(const uz_chain_op& o, int t
     if (wave == 0 && pvalid) {
         float* dx = static_cast<float*>(o.p[2]) + (size_t)n * KcTot * HW + hw;
         for (int c = 0; c < Kc; ++c) {
-            float v = ((sm[(0 * 4 + c) * 64 + lane] + sm[(1 * 4 + c) * 64 + lane]) + sm[(2 * 4 + c) * 64 + lane]) + sm[(3 * 4 + c) * 64 + lane];
-            if (accumulate) v += dx[(size_t)c * HW];
-            dx[(size_t)c * HW] = v;
+            float v = 0.f;
+            for (int g = 0; g < NW; ++g) v += sm[(g * 4 + c) * 64 + lane];
+            if (accumulate) v += ldh<SC1>(dx + (size_t)c * HW);
+            sth<SC1>(dx + (size_t)c * HW, v);
         }
     }
     __syncthreads();
 }
 
+// block-wide sums of NV doubles over NT threads; result valid in thread 0 (wave partial sums added in wave order)
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* smem /* >= NW * NV */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = uz::wave_sum_d(v[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) smem[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double t = smem[i];
+            for (int g = 1; g < NW; ++g) t += smem[g * NV + i];
+            v[i] = t;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- BatchNorm + ReLU, forward
-// one workgroup per channel; element i = tid + 256 j of the channel's batch lives in register j (the map and the order of every sum are
-// bn_fused_small_fwd's: identical bits for N*H*W <= 4096 given identical y)
-__device__ __forceinline__ void bn_fwd_tile(const uz_chain_op& o, int c, double* smd /* >= 8 */, float* smf /* >= 2 */) {
+// one workgroup per channel; element i = tid + NT j of the channel's batch lives in register j; fp64 statistics, fixed order
+template <bool SC1>
+__device__ __forceinline__ void bn_fwd_tile(const uz_chain_op& o, int c, double* smd /* >= 2 NW */, float* smf /* >= 2 */) {
     const int C = o.i[0], CtotY = o.i[1], CtotA = o.i[2], N = o.i[3], HW = o.i[4], relu = o.i[5], S = o.i[6];
     const float eps = o.f[0], momentum = o.f[1];
     const int total = N * HW, tid = threadIdx.x;
-    float* __restrict__ y = static_cast<float*>(o.p[0]);
+    float* y = static_cast<float*>(o.p[0]);
     float v[BN_MAX_EPT];
+    unsigned ey[BN_MAX_EPT];                   // element offsets (tensors of the chain are far below 2^32 elements)
+#pragma unroll
+    for (int j = 0; j < BN_MAX_EPT; ++j) {
+        const int i = tid + NT * j, ic = i < total ? i : 0;
+        const int b = ic / HW, q = ic - b * HW;
+        ey[j] = (unsigned)(((size_t)b * CtotY + c) * HW + q);
+    }
     if (S > 1) {
-        const float* __restrict__ slab = static_cast<const float*>(o.p[7]);
+        const float* slab = static_cast<const float*>(o.p[7]);
         const float* cbias = static_cast<const float*>(o.p[9]);
         const float bv = cbias ? cbias[c] : 0.f;
         const size_t nsl = (size_t)N * C * HW;
+        unsigned es[BN_MAX_EPT];
 #pragma unroll
         for (int j = 0; j < BN_MAX_EPT; ++j) {
-            const int i = tid + NTHREADS * j;
-            v[j] = 0.f;
-            if (i < total) {
-                const int b = i / HW, q = i - b * HW;
-                const size_t e = ((size_t)b * C + c) * HW + q;
-                float t = bv;
-                for (int k = 0; k < S; ++k) t += slab[(size_t)k * nsl + e];
-                v[j] = t;
-                y[((size_t)b * CtotY + c) * HW + q] = t;
+            const int i = tid + NT * j, ic = i < total ? i : 0;
+            const int b = ic / HW, q = ic - b * HW;
+            es[j] = (unsigned)(((size_t)b * C + c) * HW + q);
+            v[j] = bv;
+        }
+        // slabs added in slab order; a chunk's loads are all in flight together (a load of handed-off data is a trip past L2: the loop
+        // is paid in trips, not bytes): 24 slabs at a time where the thread holds one element (planes up to 1024 values), else 2
+        if (total <= NT) {
+            for (int k0 = 0; k0 < S; k0 += 24) {
+                float t[24];
+#pragma unroll
+                for (int u = 0; u < 24; ++u) t[u] = (k0 + u < S && tid < total) ? ldh<SC1>(slab + (size_t)(k0 + u) * nsl + es[0]) : 0.f;
+#pragma unroll
+                for (int u = 0; u < 24; ++u) v[0] += t[u];
+            }
+        } else {
+            for (int k0 = 0; k0 < S; k0 += 2) {
+                float t[2][BN_MAX_EPT];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < BN_MAX_EPT; ++j) t[u][j] = (k0 + u < S && tid + NT * j < total) ? ldh<SC1>(slab + (size_t)(k0 + u) * nsl + es[j]) : 0.f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < BN_MAX_EPT; ++j) v[j] += t[u][j];
             }
         }
+#pragma unroll
+        for (int j = 0; j < BN_MAX_EPT; ++j)
+            if (tid + NT * j < total) sth<SC1>(y + ey[j], v[j]);
     } else {
 #pragma unroll
-        for (int j = 0; j < BN_MAX_EPT; ++j) {
-            const int i = tid + NTHREADS * j;
-            v[j] = 0.f;
-            if (i < total) {
-                const int b = i / HW, q = i - b * HW;
-                v[j] = y[((size_t)b * CtotY + c) * HW + q];
-            }
-        }
+        for (int j = 0; j < BN_MAX_EPT; ++j) v[j] = tid + NT * j < total ? ldh<SC1>(y + ey[j]) : 0.f;
     }
     double v2[2] = {0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < BN_MAX_EPT; ++j)
-        if (tid + NTHREADS * j < total) { const double d = v[j]; v2[0] += d; v2[1] += d * d; }
-    uz::block_sum_d<2>(v2, smd);
+        if (tid + NT * j < total) { const double d = v[j]; v2[0] += d; v2[1] += d * d; }
+    block_sum<2>(v2, smd);
     if (tid == 0) {
         float* save = static_cast<float*>(o.p[5]);
         float* rmean = static_cast<float*>(o.p[3]);
@@ -325,15 +388,15 @@ __device__ __forceinline__ void bn_fwd_tile(const uz_chain_op& o, int c, double*
     const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
     const float alpha = g * rstd, beta_ = bb - mean * alpha;
     const float floor_ = relu ? 0.f : -INFINITY;
-    float* __restrict__ a = static_cast<float*>(o.p[6]);
+    float* a = static_cast<float*>(o.p[6]);
     float vmax = 0.f;
 #pragma unroll
     for (int j = 0; j < BN_MAX_EPT; ++j) {
-        const int i = tid + NTHREADS * j;
+        const int i = tid + NT * j;
         if (i < total) {
             const int b = i / HW, q = i - b * HW;
             const float rr = fmaxf(fmaf(v[j], alpha, beta_), floor_);
-            a[((size_t)b * CtotA + c) * HW + q] = rr;
+            sth<SC1>(a + ((size_t)b * CtotA + c) * HW + q, rr);
             vmax = fmaxf(vmax, fabsf(rr));
         }
     }
@@ -341,110 +404,124 @@ __device__ __forceinline__ void bn_fwd_tile(const uz_chain_op& o, int c, double*
     if (amax) {
 #pragma unroll
         for (int ofs = 32; ofs > 0; ofs >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, ofs, 64));
-        if ((tid & 63) == 0) amax_publish_key(vmax, amax, (unsigned)c * 4u + (tid >> 6));
+        if ((tid & 63) == 0) amax_publish_key(vmax, amax, (unsigned)c * NW + (tid >> 6));
     }
     __syncthreads();                                            // smd / smf are reused by the workgroup's next tile
 }
 
 // ---------------------------------------------------------------------------------------------- BatchNorm + ReLU, backward
 // dz = dA * (a > 0); dgamma = sum dz x_hat, dbeta = sum dz; dy = alpha (dz - mean(dz) - x_hat mean(dz x_hat)); dbias = sum dy
-// (bn_fused_small_bwd's arithmetic: the same element map and summation order)
-__device__ __forceinline__ void bn_bwd_tile(const uz_chain_op& o, int c, double* smd /* >= 12 */, float* smf /* >= 2 */) {
+// (the arithmetic of bn_fused_small_bwd, bn.hip)
+template <bool SC1>
+__device__ __forceinline__ void bn_bwd_tile(const uz_chain_op& o, int c, double* smd /* >= 2 NW */, float* smf /* >= 2 */) {
     const int C = o.i[0], CtotDa = o.i[1], CtotY = o.i[2], N = o.i[3], HW = o.i[4], relu = o.i[5], S = o.i[6];
     const int total = N * HW, tid = threadIdx.x;
-    const float* __restrict__ da = static_cast<const float*>(o.p[0]);
-    const float* __restrict__ y = static_cast<const float*>(o.p[1]);
+    const float* da = static_cast<const float*>(o.p[0]);
+    const float* __restrict__ y = static_cast<const float*>(o.p[1]);      // (written by the forward tape: an earlier launch)
     const float* gamma = static_cast<const float*>(o.p[2]);
     const float* save = static_cast<const float*>(o.p[3]);
-    const float mean = save[c], rstd = save[C + c];
-    const float g = gamma ? gamma[c] : 1.f;
-    // beta is not needed: the ReLU mask a > 0 <=> alpha y + beta' > 0 is recomputed from the stored statistics and beta (p[10])
     const float* beta = static_cast<const float*>(o.p[10]);
-    const float bb = beta ? beta[c] : 0.f;
+    const float mean = save[c], rstd = save[C + c];
+    const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
     const float alpha = g * rstd, beta_ = bb - mean * alpha;
-    // (dz stays in registers; x_hat is formed again from y in the second pass - the channel's y is an L2 / L1 hit by then - which keeps the
-    //  tile under the launch's 128 registers)
-    float dz[BN_MAX_EPT];
-    const float* __restrict__ slab = static_cast<const float*>(o.p[9]);
+    float dz[BN_MAX_EPT], xh[BN_MAX_EPT];
+    const float* slab = static_cast<const float*>(o.p[9]);
     const size_t nsl = (size_t)N * C * HW;
+    unsigned es[BN_MAX_EPT];
+    unsigned masked = 0u;
+#pragma unroll
+    for (int j = 0; j < BN_MAX_EPT; ++j) {
+        const int i = tid + NT * j, ic = i < total ? i : 0;
+        const int b = ic / HW, q = ic - b * HW;
+        const bool ok = i < total;
+        const float yv = ok ? y[((size_t)b * CtotY + c) * HW + q] : 0.f;
+        xh[j] = (yv - mean) * rstd;
+        es[j] = (unsigned)(((size_t)b * C + c) * HW + q);
+        dz[j] = (ok && S <= 1) ? ldh<SC1>(da + ((size_t)b * CtotDa + c) * HW + q) : 0.f;
+        if (relu && !(fmaf(yv, alpha, beta_) > 0.f)) masked |= 1u << j;               // ReLU mask: dz = 0 there (x_hat still enters dy)
+    }
+    if (S > 1) {
+        if (total <= NT) {
+            for (int k0 = 0; k0 < S; k0 += 24) {
+                float t[24];
+#pragma unroll
+                for (int u = 0; u < 24; ++u) t[u] = (k0 + u < S && tid < total) ? ldh<SC1>(slab + (size_t)(k0 + u) * nsl + es[0]) : 0.f;
+#pragma unroll
+                for (int u = 0; u < 24; ++u) dz[0] += t[u];
+            }
+        } else {
+            for (int k0 = 0; k0 < S; k0 += 2) {
+                float t[2][BN_MAX_EPT];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < BN_MAX_EPT; ++j) t[u][j] = (k0 + u < S && tid + NT * j < total) ? ldh<SC1>(slab + (size_t)(k0 + u) * nsl + es[j]) : 0.f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < BN_MAX_EPT; ++j) dz[j] += t[u][j];
+            }
+        }
+    }
     double v2[2] = {0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < BN_MAX_EPT; ++j) {
-        const int i = tid + NTHREADS * j;
-        dz[j] = 0.f;
-        if (i < total) {
-            const int b = i / HW, q = i - b * HW;
-            const float yv = y[((size_t)b * CtotY + c) * HW + q];
-            float d;
-            if (S > 1) {
-                const size_t e = ((size_t)b * C + c) * HW + q;
-                d = 0.f;
-                for (int k = 0; k < S; ++k) d += slab[(size_t)k * nsl + e];
-            } else {
-                d = da[((size_t)b * CtotDa + c) * HW + q];
-            }
-            if (relu && !(fmaf(yv, alpha, beta_) > 0.f)) d = 0.f;
-            dz[j] = d;
-            const float xh = (yv - mean) * rstd;
-            v2[0] += (double)d; v2[1] += (double)(d * xh);
-        }
+        if ((masked >> j) & 1u) dz[j] = 0.f;
+        if (tid + NT * j < total) { v2[0] += (double)dz[j]; v2[1] += (double)(dz[j] * xh[j]); }
     }
-    uz::block_sum_d<2>(v2, smd);
+    block_sum<2>(v2, smd);
     if (tid == 0) {
         float* dgamma = static_cast<float*>(o.p[5]);
         float* dbeta = static_cast<float*>(o.p[6]);
         if (dgamma) dgamma[c] = (float)v2[1];
         if (dbeta) dbeta[c] = (float)v2[0];
-        smf[0] = (float)(v2[0] / (double)total);
-        smf[1] = (float)(v2[1] / (double)total);
+        smf[0] = (float)(v2[0] / total);
+        smf[1] = (float)(v2[1] / total);
     }
     __syncthreads();
     const float m1 = smf[0], m2 = smf[1];
-    float* __restrict__ dyo = static_cast<float*>(o.p[4]);
+    float* dyo = static_cast<float*>(o.p[4]);
     float vmax = 0.f;
     double sd[1] = {0.0};
 #pragma unroll
     for (int j = 0; j < BN_MAX_EPT; ++j) {
-        const int i = tid + NTHREADS * j;
-        if (i < total) {
-            const int b = i / HW, q = i - b * HW;
-            const float xh = (y[((size_t)b * CtotY + c) * HW + q] - mean) * rstd;
-            const float r = alpha * (dz[j] - m1 - xh * m2);
-            dyo[((size_t)b * C + c) * HW + q] = r;                // dy: a contiguous [N][C][HW] tensor of its own
+        if (tid + NT * j < total) {
+            const float r = alpha * (dz[j] - m1 - xh[j] * m2);
+            sth<SC1>(dyo + es[j], r);                              // dy: a contiguous [N][C][HW] tensor of its own
             vmax = fmaxf(vmax, fabsf(r));
             sd[0] += (double)r;
         }
     }
     float* dbias = static_cast<float*>(o.p[7]);
-    __syncthreads();
-    uz::block_sum_d<1>(sd, smd);
+    block_sum<1>(sd, smd);
     if (tid == 0 && dbias) dbias[c] = (float)sd[0];
     float* amax = static_cast<float*>(o.p[8]);
     if (amax) {
 #pragma unroll
         for (int ofs = 32; ofs > 0; ofs >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, ofs, 64));
-        if ((tid & 63) == 0) amax_publish_key(vmax, amax, (unsigned)c * 4u + (tid >> 6));
+        if ((tid & 63) == 0) amax_publish_key(vmax, amax, (unsigned)c * NW + (tid >> 6));
     }
     __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------- pooling / interpolation
-constexpr int RS_PER_TILE = 1024;          // outputs per tile: four per thread
+constexpr int RS_PER_TILE = 4 * NT;          // outputs per tile: four per thread
 __device__ __forceinline__ void forward_bound(const uz_chain_op& o, int tile) {
     const float* xa = static_cast<const float*>(o.p[2]);
     float* ya = static_cast<float*>(o.p[3]);
     if (xa && ya && tile == 0 && threadIdx.x == 0) amax_publish_key(amax_read_agent(xa), ya, 0u);
 }
+template <bool SC1>
 __device__ __forceinline__ void avgpool_fwd_tile(const uz_chain_op& o, int tile) {
     const int C = o.i[0], CtotX = o.i[1], CtotY = o.i[2], N = o.i[3], Hi = o.i[4], Wi = o.i[5];
     const int H = (Hi + 1) / 2, W = (Wi + 1) / 2;
     forward_bound(o, tile);
-    const float* __restrict__ x = static_cast<const float*>(o.p[0]);
-    float* __restrict__ y = static_cast<float*>(o.p[1]);
+    const float* x = static_cast<const float*>(o.p[0]);
+    float* y = static_cast<float*>(o.p[1]);
     const long long total = (long long)N * C * H * W;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const long long e = (long long)tile * RS_PER_TILE + k * NTHREADS + threadIdx.x;
+        const long long e = (long long)tile * RS_PER_TILE + k * NT + threadIdx.x;
         if (e >= total) continue;
         const int ox = (int)(e % W); long long t = e / W;
         const int oy = (int)(t % H); t /= H;
@@ -453,28 +530,29 @@ __device__ __forceinline__ void avgpool_fwd_tile(const uz_chain_op& o, int tile)
         const int y0 = 2 * oy, x0 = 2 * ox, y1 = min(y0 + 2, Hi), x1 = min(x0 + 2, Wi);
         float acc = 0.f;
         for (int yy = y0; yy < y1; ++yy)
-            for (int xx = x0; xx < x1; ++xx) acc += s[yy * Wi + xx];
-        y[((size_t)b * CtotY + c) * H * W + oy * W + ox] = acc / (float)((y1 - y0) * (x1 - x0));
+            for (int xx = x0; xx < x1; ++xx) acc += ldh<SC1>(s + yy * Wi + xx);
+        sth<SC1>(y + ((size_t)b * CtotY + c) * H * W + oy * W + ox, acc / (float)((y1 - y0) * (x1 - x0)));
     }
 }
+template <bool SC1>
 __device__ __forceinline__ void avgpool_bwd_tile(const uz_chain_op& o, int tile) {
     const int C = o.i[0], CtotDy = o.i[1], CtotDx = o.i[2], N = o.i[3], Ho = o.i[4], Wo = o.i[5], accumulate = o.i[6];
     const int H = (Ho + 1) / 2, W = (Wo + 1) / 2;
-    const float* __restrict__ dy = static_cast<const float*>(o.p[0]);
-    float* __restrict__ dx = static_cast<float*>(o.p[1]);
+    const float* dy = static_cast<const float*>(o.p[0]);
+    float* dx = static_cast<float*>(o.p[1]);
     const long long total = (long long)N * C * Ho * Wo;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const long long e = (long long)tile * RS_PER_TILE + k * NTHREADS + threadIdx.x;
+        const long long e = (long long)tile * RS_PER_TILE + k * NT + threadIdx.x;
         if (e >= total) continue;
         const int xq = (int)(e % Wo); long long t = e / Wo;
         const int yq = (int)(t % Ho); t /= Ho;
         const int c = (int)(t % C), b = (int)(t / C);
         const int oy = yq >> 1, ox = xq >> 1;
         const int cnt = (min(2 * oy + 2, Ho) - 2 * oy) * (min(2 * ox + 2, Wo) - 2 * ox);
-        const float v = dy[((size_t)b * CtotDy + c) * H * W + oy * W + ox] / (float)cnt;
+        const float v = ldh<SC1>(dy + ((size_t)b * CtotDy + c) * H * W + oy * W + ox) / (float)cnt;
         float* d = dx + ((size_t)b * CtotDx + c) * Ho * Wo + yq * Wo + xq;
-        *d = accumulate ? *d + v : v;
+        sth<SC1>(d, accumulate ? ldh<SC1>(d) + v : v);
     }
 }
 __device__ __forceinline__ void src_index(int o, float scale, int ac, int in, int& i0, int& ip, float& l0, float& l1) {
@@ -492,18 +570,19 @@ __device__ __forceinline__ void bil_scales(int H, int W, int ac, float& sh, floa
     if (ac) { sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f; sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f; }
     else { sh = 0.5f; sw = 0.5f; }
 }
+template <bool SC1>
 __device__ __forceinline__ void bilinear_fwd_tile(const uz_chain_op& o, int tile) {
     const int C = o.i[0], CtotX = o.i[1], CtotY = o.i[2], N = o.i[3], H = o.i[4], W = o.i[5], ac = o.i[6];
     const int Ho = 2 * H, Wo = 2 * W;
     forward_bound(o, tile);
     float sh, sw;
     bil_scales(H, W, ac, sh, sw);
-    const float* __restrict__ x = static_cast<const float*>(o.p[0]);
-    float* __restrict__ y = static_cast<float*>(o.p[1]);
+    const float* x = static_cast<const float*>(o.p[0]);
+    float* y = static_cast<float*>(o.p[1]);
     const long long total = (long long)N * C * Ho * Wo;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const long long e = (long long)tile * RS_PER_TILE + k * NTHREADS + threadIdx.x;
+        const long long e = (long long)tile * RS_PER_TILE + k * NT + threadIdx.x;
         if (e >= total) continue;
         const int ox = (int)(e % Wo); long long t = e / Wo;
         const int oy = (int)(t % Ho); t /= Ho;
@@ -514,7 +593,8 @@ __device__ __forceinline__ void bilinear_fwd_tile(const uz_chain_op& o, int tile
         src_index(ox, sw, ac, W, w1, wp, w0l, w1l);
         const float* r0 = s + h1 * W + w1;
         const float* r1 = r0 + hp * W;
-        y[((size_t)b * CtotY + c) * Ho * Wo + oy * Wo + ox] = h0l * (w0l * r0[0] + w1l * r0[wp]) + h1l * (w0l * r1[0] + w1l * r1[wp]);
+        const float v00 = ldh<SC1>(r0), v01 = ldh<SC1>(r0 + wp), v10 = ldh<SC1>(r1), v11 = ldh<SC1>(r1 + wp);
+        sth<SC1>(y + ((size_t)b * CtotY + c) * Ho * Wo + oy * Wo + ox, h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11));
     }
 }
 __device__ __forceinline__ float tap_weight(int o, int osize, float scale, int ac, int isize, int i) {
@@ -524,17 +604,18 @@ __device__ __forceinline__ float tap_weight(int o, int osize, float scale, int a
     return (i0 == i ? l0 : 0.f) + (i0 + ip == i ? l1 : 0.f);
 }
 // gather form (bilinear_bwd_k of resample.hip): low-resolution pixel i receives from high-resolution 2i-2 .. 2i+4
+template <bool SC1>
 __device__ __forceinline__ void bilinear_bwd_tile(const uz_chain_op& o, int tile) {
     const int C = o.i[0], CtotDy = o.i[1], CtotDx = o.i[2], N = o.i[3], H = o.i[4], W = o.i[5], ac = o.i[6], accumulate = o.i[7];
     const int Ho = 2 * H, Wo = 2 * W;
     float sh, sw;
     bil_scales(H, W, ac, sh, sw);
-    const float* __restrict__ dy = static_cast<const float*>(o.p[0]);
-    float* __restrict__ dx = static_cast<float*>(o.p[1]);
+    const float* dy = static_cast<const float*>(o.p[0]);
+    float* dx = static_cast<float*>(o.p[1]);
     const long long total = (long long)N * C * H * W;
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
-        const long long e = (long long)tile * RS_PER_TILE + k * NTHREADS + threadIdx.x;
+        const long long e = (long long)tile * RS_PER_TILE + k * NT + threadIdx.x;
         if (e >= total) continue;
         const int ix = (int)(e % W); long long t = e / W;
         const int iy = (int)(t % H); t /= H;
@@ -553,33 +634,34 @@ __device__ __forceinline__ void bilinear_bwd_tile(const uz_chain_op& o, int tile
                 float ra = 0.f;
 #pragma unroll
                 for (int kx = 0; kx < 7; ++kx)
-                    if (wx[kx] != 0.f) ra += wx[kx] * row[kx];
+                    if (wx[kx] != 0.f) ra += wx[kx] * ldh<SC1>(row + kx);
                 acc += wy * ra;
             }
         }
         float* d = dx + ((size_t)b * CtotDx + c) * H * W + iy * W + ix;
-        *d = accumulate ? *d + acc : acc;
+        sth<SC1>(d, accumulate ? ldh<SC1>(d) + acc : acc);
     }
 }
 
 // ---------------------------------------------------------------------------------------------- latent heads (L == 2)
 __device__ __forceinline__ float head_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float head_sigma(float pre, int act) { return act ? expf(pre) : head_softplus(pre); }
-// tile = 64 pixels; wave g accumulates channels g, g + 4, ... ; the four partial sums are added in wave order through LDS
-__device__ __forceinline__ void heads_fwd_tile(const uz_chain_op& o, int tile, float* sm /* >= 4 * 4 * 64 */) {
+// tile = 64 pixels; wave g accumulates channels g, g + NW, ... ; the partial sums are added in wave order through LDS
+template <bool SC1>
+__device__ __forceinline__ void heads_fwd_tile(const uz_chain_op& o, int tile, float* sm /* >= NW * 4 * 64 */) {
     const int Cin = o.i[0], CinTot = o.i[1], N = o.i[2], HW = o.i[3], act = o.i[4];
     const int P = N * HW, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = tile * 64 + lane;
     const bool pvalid = p < P;
     const int pc = pvalid ? p : P - 1;
     const int n = pc / HW, q = pc - n * HW;
-    const float* __restrict__ h = static_cast<const float*>(o.p[0]) + (size_t)n * CinTot * HW + q;
+    const float* h = static_cast<const float*>(o.p[0]) + (size_t)n * CinTot * HW + q;
     const float* __restrict__ wm = static_cast<const float*>(o.p[1]);
     const float* __restrict__ wsg = static_cast<const float*>(o.p[3]);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int c = wave; c < Cin; c += 4) {
-        const float v = h[(size_t)c * HW];
+    for (int c = wave; c < Cin; c += NW) {
+        const float v = ldh<SC1>(h + (size_t)c * HW);
         acc[0] = fmaf(wm[c], v, acc[0]); acc[1] = fmaf(wm[Cin + c], v, acc[1]);
         acc[2] = fmaf(wsg[c], v, acc[2]); acc[3] = fmaf(wsg[Cin + c], v, acc[3]);
     }
@@ -596,99 +678,146 @@ __device__ __forceinline__ void heads_fwd_tile(const uz_chain_op& o, int tile, f
         float* z = static_cast<float*>(o.p[9]);
         float t[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t[k] = ((sm[k * 64 + lane] + sm[(4 + k) * 64 + lane]) + sm[(8 + k) * 64 + lane]) + sm[(12 + k) * 64 + lane];
+        for (int k = 0; k < 4; ++k) {
+            float a = 0.f;
+            for (int g = 0; g < NW; ++g) a += sm[(g * 4 + k) * 64 + lane];
+            t[k] = a;
+        }
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
             const size_t e = ((size_t)n * 2 + l) * HW + q;
             const float m = t[l] + (bm ? bm[l] : 0.f), pr = t[2 + l] + (bs ? bs[l] : 0.f);
             const float sg = head_sigma(pr, act);
-            mu[e] = m; pre[e] = pr; sigma[e] = sg;
-            if (z) z[e] = m + sg * eps[e];
+            sth<SC1>(mu + e, m); sth<SC1>(pre + e, pr); sth<SC1>(sigma + e, sg);
+            if (z) sth<SC1>(z + e, m + sg * eps[e]);
         }
     }
     __syncthreads();
 }
-// dh[c] (+)= w_a[0][c] dy_a[0] + w_a[1][c] dy_a[1] + w_b[0][c] dy_b[0] + w_b[1][c] dy_b[1]   (head a's rows first)
-// tile = 64 pixels x 64 channels: wave g takes channels g, g + 4, ...
-__device__ __forceinline__ void heads_bwd_data_tile(const uz_chain_op& o, int tile) {
-    const int Cin = o.i[0], CinTot = o.i[1], N = o.i[2], HW = o.i[3], accumulate = o.i[4];
-    const int P = N * HW, PT = (P + 63) / 64;
-    const int pt = tile % PT, ct = tile / PT;
+// Backward of a SampleZBlock's tail (phiseg.py:95-105): uz_latent_sample_bwd + uz_latent_heads_bwd_data in one sub-op.
+//   g_mu = kl_dmu + dz, g_sigma = kl_dsigma + dz eps, g_pre = g_sigma * softplus'(pre)  [= 1 - exp(-sigma)]          (written for the heads' weight gradient)
+//   dh[c] (+)= w_sigma[0][c] g_pre[0] + w_sigma[1][c] g_pre[1] + w_mu[0][c] g_mu[0] + w_mu[1][c] g_mu[1]              (the sigma head's rows first)
+// tile = 64 pixels: wave g takes channels g, g + NW, ...; wave 0 stores g_mu / g_pre
+template <bool SC1>
+__device__ __forceinline__ void latent_heads_bwd_tile(const uz_chain_op& o, int tile) {
+    const int Cin = o.i[0], CinTot = o.i[1], N = o.i[2], HW = o.i[3], act = o.i[4], accumulate = o.i[5];
+    const int P = N * HW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int p = pt * 64 + lane;
+    const int p = tile * 64 + lane;
     if (p >= P) return;
     const int n = p / HW, q = p - n * HW;
-    const float* dya = static_cast<const float*>(o.p[0]);
-    const float* dyb = static_cast<const float*>(o.p[1]);
-    const float* __restrict__ wa = static_cast<const float*>(o.p[2]);
-    const float* __restrict__ wb = static_cast<const float*>(o.p[3]);
-    const float a0 = dya[((size_t)n * 2 + 0) * HW + q], a1 = dya[((size_t)n * 2 + 1) * HW + q];
-    const float b0 = dyb[((size_t)n * 2 + 0) * HW + q], b1 = dyb[((size_t)n * 2 + 1) * HW + q];
-    float* dh = static_cast<float*>(o.p[4]) + (size_t)n * CinTot * HW + q;
-    const int c1 = min(Cin, (ct + 1) * 64);
-    for (int c = ct * 64 + wave; c < c1; c += 4) {
-        float v = accumulate ? dh[(size_t)c * HW] : 0.f;
-        v = fmaf(wa[c], a0, v); v = fmaf(wa[Cin + c], a1, v);
-        v = fmaf(wb[c], b0, v); v = fmaf(wb[Cin + c], b1, v);
-        dh[(size_t)c * HW] = v;
+    const float* kdm = static_cast<const float*>(o.p[0]);
+    const float* kds = static_cast<const float*>(o.p[1]);
+    const float* dz = static_cast<const float*>(o.p[2]);
+    const float* eps = static_cast<const float*>(o.p[3]);
+    const float* sigma = static_cast<const float*>(o.p[4]);
+    float* gmu = static_cast<float*>(o.p[5]);
+    float* gpre = static_cast<float*>(o.p[6]);
+    const float* __restrict__ wa = static_cast<const float*>(o.p[7]);      // sigma head
+    const float* __restrict__ wb = static_cast<const float*>(o.p[8]);      // mu head
+    float gm[2], gp[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const size_t e = ((size_t)n * 2 + l) * HW + q;
+        const float gz = dz ? ldh<SC1>(dz + e) : 0.f;
+        gm[l] = (kdm ? kdm[e] : 0.f) + gz;
+        const float gs = (kds ? kds[e] : 0.f) + gz * eps[e];
+        const float sg = sigma[e];
+        gp[l] = gs * (act ? sg : (sg > 20.f ? 1.f : (1.f - expf(-sg))));
+        if (wave == 0) { sth<SC1>(gmu + e, gm[l]); sth<SC1>(gpre + e, gp[l]); }
     }
+    float* dh = static_cast<float*>(o.p[9]);
+    if (!dh) return;
+    dh += (size_t)n * CinTot * HW + q;
+    for (int c = wave; c < Cin; c += NW) {
+        float v = accumulate ? ldh<SC1>(dh + (size_t)c * HW) : 0.f;
+        v = fmaf(wa[c], gp[0], v); v = fmaf(wa[Cin + c], gp[1], v);
+        v = fmaf(wb[c], gm[0], v); v = fmaf(wb[Cin + c], gm[1], v);
+        sth<SC1>(dh + (size_t)c * HW, v);
+    }
+}
+// dst (+)= sum of S slabs [S][N][C][HW] in slab order (a split-K data gradient whose output has other writers)
+template <bool SC1>
+__device__ __forceinline__ void slab_sum_tile(const uz_chain_op& o, int tile) {
+    const int S = o.i[0], N = o.i[1], C = o.i[2], Ctot = o.i[3], HW = o.i[4], accumulate = o.i[5];
+    const float* slab = static_cast<const float*>(o.p[0]);
+    float* dst = static_cast<float*>(o.p[1]);
+    const size_t nsl = (size_t)N * C * HW;
+    const long long e = (long long)tile * NT + threadIdx.x;
+    if (e >= (long long)nsl) return;
+    const int q = (int)(e % HW); long long t = e / HW;
+    const int c = (int)(t % C), b = (int)(t / C);
+    float* d = dst + ((size_t)b * Ctot + c) * HW + q;
+    float v = accumulate ? ldh<SC1>(d) : 0.f;
+    for (int k0 = 0; k0 < S; k0 += 24) {
+        float tt[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) tt[u] = k0 + u < S ? ldh<SC1>(slab + (size_t)(k0 + u) * nsl + e) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 24; ++u) v += tt[u];
+    }
+    sth<SC1>(d, v);
 }
 
 // ---------------------------------------------------------------------------------------------- tiles per sub-op (host and device agree)
+// CONV3 counts WAVE tiles (dealt round-robin to the workgroups, then to their waves); every other sub-op counts workgroup tiles
 __host__ __device__ inline int op_tiles(const uz_chain_op& o) {
     const int32_t* i = o.i;
     switch (o.code) {
-        case UZ_CH_CONV3: return (conv3_wave_tiles(o) + 3) / 4;
-        case UZ_CH_CONV3_SMALL: return ((i[4] * i[5] * i[6] + NTHREADS - 1) / NTHREADS) * ((i[2] + SMALL_CO - 1) / SMALL_CO);
+        case UZ_CH_CONV3: return conv3_wave_tiles(o);
+        case UZ_CH_CONV3_SMALL: return ((i[4] * i[5] * i[6] + NT - 1) / NT) * ((i[2] + SMALL_CO - 1) / SMALL_CO);
         case UZ_CH_CONV3_SMALL_BWD_DATA: return (i[4] * i[5] * i[6] + 63) / 64;
         case UZ_CH_BN_FWD: case UZ_CH_BN_BWD: return i[0];
         case UZ_CH_AVGPOOL_FWD: return (int)(((long long)i[3] * i[0] * ((i[4] + 1) / 2) * ((i[5] + 1) / 2) + RS_PER_TILE - 1) / RS_PER_TILE);
         case UZ_CH_AVGPOOL_BWD: return (int)(((long long)i[3] * i[0] * i[4] * i[5] + RS_PER_TILE - 1) / RS_PER_TILE);
         case UZ_CH_BILINEAR_FWD: return (int)(((long long)i[3] * i[0] * 4 * i[4] * i[5] + RS_PER_TILE - 1) / RS_PER_TILE);
         case UZ_CH_BILINEAR_BWD: return (int)(((long long)i[3] * i[0] * i[4] * i[5] + RS_PER_TILE - 1) / RS_PER_TILE);
-        case UZ_CH_HEADS_FWD: return (i[2] * i[3] + 63) / 64;
-        case UZ_CH_HEADS_BWD_DATA: return ((i[2] * i[3] + 63) / 64) * ((i[0] + 63) / 64);
+        case UZ_CH_HEADS_FWD: case UZ_CH_LATENT_HEADS_BWD: return (i[2] * i[3] + 63) / 64;
+        case UZ_CH_SLAB_SUM: return (int)(((long long)i[1] * i[2] * i[4] + NT - 1) / NT);
         default: return -1;
     }
 }
 
-__global__ __launch_bounds__(NTHREADS, 4) void chain_kernel(const uz_chain_op* __restrict__ ops, const int32_t* __restrict__ phases, int n_phases,
-                                                         unsigned* state) {
-    __shared__ double smd[16];
-    __shared__ float smf[4 * 4 * 64 + 8];
+template <bool SC1>
+__global__ __launch_bounds__(NT) void chain_kernel(const uz_chain_op* __restrict__ ops, const int32_t* __restrict__ phases, int n_phases, int n_ops,
+                                                   unsigned* state) {
+    __shared__ double smd[2 * NW];
+    __shared__ float smf[NW * 4 * 64 + 8];
+    __shared__ int d_code[MAX_OPS], d_t0[MAX_OPS], d_nt[MAX_OPS], d_ph[2 * MAX_PHASES];
+    __shared__ unsigned verdict;
     const int wg = blockIdx.x, G = gridDim.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < n_ops; k += NT) { d_code[k] = ops[k].code; d_t0[k] = ops[k].tile0; d_nt[k] = ops[k].ntiles; }
+    for (int k = threadIdx.x; k < 2 * n_phases; k += NT) d_ph[k] = phases[k];
+    __syncthreads();
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(state + ST_STAMPS);
     if (wg == 0 && threadIdx.x == 0) stamps[0] = wall_clock64();
     for (int ph = 0; ph < n_phases; ++ph) {
-        const int op0 = phases[2 * ph], nops = phases[2 * ph + 1];
-        const uz_chain_op& last = ops[op0 + nops - 1];
-        const int ntiles = last.tile0 + last.ntiles;
-        for (int t = wg; t < ntiles; t += G) {
-            int k = op0;
-            while (k + 1 < op0 + nops && t >= ops[k + 1].tile0) ++k;
+        const int op0 = d_ph[2 * ph], nops = d_ph[2 * ph + 1];
+        for (int k = op0; k < op0 + nops; ++k) {
+            const int code = d_code[k], nt = d_nt[k];
+            int first = wg - d_t0[k];                          // the op's tiles start at workgroup tile0 (mod G)
+            if (first < 0) first += G;
             const uz_chain_op& o = ops[k];
-            const int lt = t - o.tile0;
-            switch (o.code) {
-                case UZ_CH_CONV3: {
-                    const int wt = lt * 4 + wave;
-                    if (wt < conv3_wave_tiles(o)) conv3_wave_tile(o, wt, lane);
+            switch (code) {
+                case UZ_CH_CONV3:
+                    for (int wt = first + G * wave; wt < nt; wt += G * NW) conv3_wave_tile<SC1>(o, wt, lane);
                     break;
-                }
-                case UZ_CH_CONV3_SMALL: conv3_small_tile(o, lt); break;
-                case UZ_CH_CONV3_SMALL_BWD_DATA: conv3_small_bwd_tile(o, lt, smf); break;
-                case UZ_CH_BN_FWD: bn_fwd_tile(o, lt, smd, smf); break;
-                case UZ_CH_BN_BWD: bn_bwd_tile(o, lt, smd, smf); break;
-                case UZ_CH_AVGPOOL_FWD: avgpool_fwd_tile(o, lt); break;
-                case UZ_CH_AVGPOOL_BWD: avgpool_bwd_tile(o, lt); break;
-                case UZ_CH_BILINEAR_FWD: bilinear_fwd_tile(o, lt); break;
-                case UZ_CH_BILINEAR_BWD: bilinear_bwd_tile(o, lt); break;
-                case UZ_CH_HEADS_FWD: heads_fwd_tile(o, lt, smf); break;
-                case UZ_CH_HEADS_BWD_DATA: heads_bwd_data_tile(o, lt); break;
+                case UZ_CH_CONV3_SMALL: for (int t = first; t < nt; t += G) conv3_small_tile<SC1>(o, t); break;
+                case UZ_CH_CONV3_SMALL_BWD_DATA: for (int t = first; t < nt; t += G) conv3_small_bwd_tile<SC1>(o, t, smf); break;
+                case UZ_CH_BN_FWD: for (int t = first; t < nt; t += G) bn_fwd_tile<SC1>(o, t, smd, smf); break;
+                case UZ_CH_BN_BWD: for (int t = first; t < nt; t += G) bn_bwd_tile<SC1>(o, t, smd, smf); break;
+                case UZ_CH_AVGPOOL_FWD: for (int t = first; t < nt; t += G) avgpool_fwd_tile<SC1>(o, t); break;
+                case UZ_CH_AVGPOOL_BWD: for (int t = first; t < nt; t += G) avgpool_bwd_tile<SC1>(o, t); break;
+                case UZ_CH_BILINEAR_FWD: for (int t = first; t < nt; t += G) bilinear_fwd_tile<SC1>(o, t); break;
+                case UZ_CH_BILINEAR_BWD: for (int t = first; t < nt; t += G) bilinear_bwd_tile<SC1>(o, t); break;
+                case UZ_CH_HEADS_FWD: for (int t = first; t < nt; t += G) heads_fwd_tile<SC1>(o, t, smf); break;
+                case UZ_CH_LATENT_HEADS_BWD: for (int t = first; t < nt; t += G) latent_heads_bwd_tile<SC1>(o, t); break;
+                case UZ_CH_SLAB_SUM: for (int t = first; t < nt; t += G) slab_sum_tile<SC1>(o, t); break;
                 default: break;
             }
         }
-        if (ph + 1 < n_phases && !grid_barrier(state, (unsigned)G, (unsigned)(ph + 1))) return;
+        if (ph + 1 < n_phases && !grid_barrier<SC1>(state, (unsigned)G, (unsigned)(ph + 1), &verdict)) return;
         if (wg == 0 && threadIdx.x == 0 && ph + 1 < MAX_STAMPS) stamps[ph + 1] = wall_clock64();
     }
 }
@@ -696,7 +825,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void chain_kernel(const uz_chain_op* _
 // ---------------------------------------------------------------------------------------------- weight images
 // one thread per (tap * KB + kb, m32, lane): eight weights -> the lane's 16 bytes of either piece
 struct PackRow { const float* w; char* img; int Mc, Kc, Cin, dgrad, blk0; };
-__global__ __launch_bounds__(NTHREADS) void chain_pack_kernel(const int64_t* __restrict__ table, int n_layers, const float* __restrict__ w_amax, int* flags) {
+__global__ __launch_bounds__(256) void chain_pack_kernel(const int64_t* __restrict__ table, int n_layers, const float* __restrict__ w_amax, int* flags) {
     // find the layer of this block (table rows are 7 int64; blk0 ascending)
     int lo = 0, hi = n_layers - 1;
     while (lo < hi) {
@@ -709,7 +838,7 @@ __global__ __launch_bounds__(NTHREADS) void chain_pack_kernel(const int64_t* __r
     const int Mc = (int)row[2], Kc = (int)row[3], Cin = (int)row[4], dgrad = (int)row[5], blk0 = (int)row[6];
     const int KB = Kc / 16, M32 = Mc / 32;
     const long long units = (long long)9 * KB * M32 * 64;
-    const long long u = (long long)(blockIdx.x - blk0) * NTHREADS + threadIdx.x;
+    const long long u = (long long)(blockIdx.x - blk0) * 256 + threadIdx.x;
     if (u >= units) return;
     const int lane = (int)(u & 63);
     long long t = u >> 6;
@@ -750,7 +879,7 @@ extern "C" int uz_chain_op_tiles(const uz_chain_op* op) {
             if (i[0] < 1 || i[0] > 4) return -1;
             break;
         case UZ_CH_BN_FWD: case UZ_CH_BN_BWD:
-            if ((long long)i[3] * i[4] > (long long)BN_MAX_EPT * NTHREADS) return -1;
+            if ((long long)i[3] * i[4] > (long long)BN_MAX_EPT * NT) return -1;
             break;
         default: break;
     }
@@ -760,7 +889,7 @@ extern "C" int uz_chain_conv_ksplit(int Kc, int Mc, int N, int H, int W, int n_w
     if (Kc % 16 || Kc < 16) return 1;
     const int P = N * H * W, base = ((P + PXB - 1) / PXB) * ((Mc + COB - 1) / COB);        // wave tiles without split
     const int T = 9 * (Kc / 16);
-    const int want = 4 * n_workgroups;                                                     // one wave tile per wave of the launch
+    const int want = 2 * NW * n_workgroups / 4;                                            // wave tiles wanted: half the launch's waves busy at least
     int S = (want + base - 1) / base;
     const int smax = T / MIN_KSTEPS > 0 ? T / MIN_KSTEPS : 1;
     if (S > smax) S = smax;
@@ -768,18 +897,24 @@ extern "C" int uz_chain_conv_ksplit(int Kc, int Mc, int N, int H, int W, int n_w
     return S;
 }
 extern "C" size_t uz_chain_packed_bytes(int Kc, int Mc) { return (size_t)9 * (Kc / 16) * (Mc / 32) * 2048; }
-extern "C" int uz_chain_pack_blocks(int Kc, int Mc) { return (int)(((long long)9 * (Kc / 16) * (Mc / 32) * 64 + NTHREADS - 1) / NTHREADS); }
+extern "C" int uz_chain_pack_blocks(int Kc, int Mc) { return (int)(((long long)9 * (Kc / 16) * (Mc / 32) * 64 + 255) / 256); }
 extern "C" int uz_chain_pack_weights(const int64_t* table, int n_layers, int total_blocks, const float* w_amax, void* stream) {
     UZ_REQUIRE(table && w_amax && n_layers > 0 && total_blocks > 0, "chain_pack_weights: empty table");
-    hipLaunchKernelGGL(chain_pack_kernel, dim3(total_blocks), dim3(NTHREADS), 0, uz::S(stream), table, n_layers, w_amax, uz::dev_flags_ptr());
+    hipLaunchKernelGGL(chain_pack_kernel, dim3(total_blocks), dim3(256), 0, uz::S(stream), table, n_layers, w_amax, uz::dev_flags_ptr());
     return uz::check_launch("chain_pack_kernel");
 }
 extern "C" size_t uz_chain_state_bytes(void) { return ST_WORDS * sizeof(unsigned); }
-extern "C" int uz_chain_run(const uz_chain_op* ops, const int32_t* phases, int n_phases, int n_workgroups, void* state, void* stream) {
-    UZ_REQUIRE(ops && phases && state && n_phases > 0, "chain_run: null table");
+extern "C" int uz_chain_run(const uz_chain_op* ops, const int32_t* phases, int n_phases, int n_ops, int n_workgroups, void* state, void* stream) {
+    UZ_REQUIRE(ops && phases && state && n_phases > 0 && n_ops > 0, "chain_run: null table");
+    UZ_REQUIRE(n_phases <= MAX_PHASES && n_ops <= MAX_OPS, "chain_run: %d phases / %d sub-ops beyond the directory (%d / %d)", n_phases, n_ops, MAX_PHASES, MAX_OPS);
     UZ_REQUIRE(n_workgroups >= 1 && n_workgroups <= 1024, "chain_run: %d workgroups outside [1, 1024]", n_workgroups);
+    // a grid barrier needs every workgroup resident: one 1024-thread workgroup per CU at most
+    static const int n_cu = [] { int n = 0; if (uz_device_info(&n, nullptr, 0) != 0) n = 0; return n; }();
+    UZ_REQUIRE(n_cu <= 0 || n_workgroups <= n_cu, "chain_run: %d workgroups on %d CUs (a workgroup holds a whole CU's wave slots)", n_workgroups, n_cu);
+    static const int sc1 = [] { const char* e = getenv("UZ_CHAIN_SC1"); return e ? atoi(e) : 1; }();
     if (hipMemsetAsync(state, 0, ST_STAMPS * sizeof(unsigned), uz::S(stream)) != hipSuccess) return uz::fail("chain_run: hipMemsetAsync failed");
-    hipLaunchKernelGGL(chain_kernel, dim3(n_workgroups), dim3(NTHREADS), 0, uz::S(stream), ops, phases, n_phases, static_cast<unsigned*>(state));
+    if (sc1) hipLaunchKernelGGL(chain_kernel<true>, dim3(n_workgroups), dim3(NT), 0, uz::S(stream), ops, phases, n_phases, n_ops, static_cast<unsigned*>(state));
+    else hipLaunchKernelGGL(chain_kernel<false>, dim3(n_workgroups), dim3(NT), 0, uz::S(stream), ops, phases, n_phases, n_ops, static_cast<unsigned*>(state));
     return uz::check_launch("chain_kernel");
 }
 extern "C" int uz_chain_status(const void* state, int* out, void* stream) {

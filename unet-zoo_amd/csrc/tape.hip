@@ -239,7 +239,7 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_LATENT_HEADS_BWD_WEIGHT:
             return uz_latent_heads_bwd_weight(CFP(0), i[0], i[1], CFP(1), CFP(2), i[2], FP(3), FP(4), FP(5), FP(6), i[3], i[4], i[5], p[7], (size_t)o.n, st);
         case UZ_OP_CHAIN:
-            return uz_chain_run(static_cast<const uz_chain_op*>(p[0]), static_cast<const int32_t*>(p[1]), i[0], i[1], p[2], st);
+            return uz_chain_run(static_cast<const uz_chain_op*>(p[0]), static_cast<const int32_t*>(p[1]), i[0], i[2], i[1], p[2], st);
         case UZ_OP_CHAIN_PACK:
             return uz_chain_pack_weights(static_cast<const int64_t*>(p[0]), i[0], i[1], CFP(1), st);
         default:
