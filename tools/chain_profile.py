@@ -57,3 +57,7 @@ for ph, es in enumerate(rows):
 print("by kind:")
 for kind, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"   {kind:40s} {cnt:3d} phases {us:8.1f} us")
+if os.environ.get("UZ_CHAIN_DEBUG_PHASE"):
+    dbg = stt[32 + 1024:].view(torch.int64)
+    base = dbg[0].item()
+    print("in-tile stamps (us since the phase began on the debug workgroup):", {j: round((dbg[j].item() - base) / 100.0, 2) for j in range(32) if dbg[j].item()})

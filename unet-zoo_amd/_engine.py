@@ -160,8 +160,10 @@ class NativeModel(nn.Module):
     # chains no longer carry the weight gradients), Probabilistic U-Net 11.33 -> 11.66 ms (three lanes already interleave its
     # chains) - so it is a per-model default.
     decouple_wgrad_px = 0
-    # Planes (N*H*W pixels) up to which a tape's small-plane ops run as phases of ONE persistent launch (Plan._chain_pass, csrc/chain.hip;
-    # UZ_CHAIN overrides, 0 = off).  PHISeg: 8192 = its 16 x 16 ... 2 x 2 levels at batch 32.
+    # Planes (N*H*W pixels) up to which a tape's small-plane ops run as phases of persistent "chain" launches (Plan._chain_pass,
+    # csrc/chain.hip; UZ_CHAIN overrides; 8192 = PHiSeg's 16 x 16 ... 2 x 2 levels at batch 32).  OFF by default: built, parity-green
+    # and MEASURED SLOWER than the per-op tape on MI355X (round 6: PHiSeg step 15.7 ms per-op; 17.7 ms with the forward chain, 22.3 ms
+    # with forward + backward chains - profiles/NOTES_r6.md says where the time goes).
     chain_px = 0
     decouple_wgrad_prefixes = ()      # sub-networks (parameter-name prefixes) whose weight gradients are decoupled at every size
 

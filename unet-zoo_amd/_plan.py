@@ -1555,7 +1555,9 @@ class Plan:
         px = self._chain_limit()
         if px <= 0:
             return
-        jobs = [("fwd", self.fwd_ops, self._chain_eligible_fwd, None)]
+        only = os.environ.get("UZ_CHAIN_NETS")                # diagnostics: "fwd,prior" = the forward chain and the prior's backward chain only
+        only = None if only is None else set(only.split(","))
+        jobs = [("fwd", self.fwd_ops, self._chain_eligible_fwd, None)] if (only is None or "fwd" in only) else []
         if self.bwd_ops and os.environ.get("UZ_CHAIN_BWD", "1") == "1":
             nets = []
             for o in self.bwd_ops:
@@ -1563,7 +1565,7 @@ class Plan:
                     nt = self._chain_net(o)
                     if nt not in nets:
                         nets.append(nt)
-            jobs += [("bwd", self.bwd_ops, self._chain_eligible_bwd, nt) for nt in nets]
+            jobs += [("bwd", self.bwd_ops, self._chain_eligible_bwd, nt) for nt in nets if only is None or nt in only]
         for which, ops, elig, net in jobs:
             if ops:
                 self._chain_build(which, ops, elig, net, px)

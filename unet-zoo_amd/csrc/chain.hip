@@ -46,18 +46,25 @@ constexpr int MIN_KSTEPS = 6;      // 16-deep k-steps a split-K slice keeps at l
 constexpr int MAX_OPS = 640, MAX_PHASES = 256;      // directory kept in LDS
 
 // state words (unsigned), each on a 64-byte line of its own
-constexpr int ST_ARRIVE = 0, ST_STATUS = 16, ST_STAMPS = 32, MAX_STAMPS = 512, ST_WORDS = ST_STAMPS + 2 * MAX_STAMPS;      // stamps: 100 MHz clock of workgroup 0 at launch and behind every phase (diagnostics)
+constexpr int ST_ARRIVE = 0, ST_STATUS = 16, ST_STAMPS = 32, MAX_STAMPS = 512, ST_DBG = ST_STAMPS + 2 * MAX_STAMPS, MAX_DBG = 64, ST_WORDS = ST_DBG + 2 * MAX_DBG;      // stamps: 100 MHz clock of workgroup 0 at launch and behind every phase (diagnostics)
 constexpr unsigned SPIN_LIMIT = 4u << 20;     // polls of ~0.5 us: ~2 s
 
-__device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// diagnostics (UZ_CHAIN_DEBUG_PHASE): in-tile stamps of ONE workgroup in ONE phase; null otherwise
+__shared__ unsigned long long* g_dbg;
+#define STAMP(id) do { if (g_dbg && threadIdx.x == 0) g_dbg[id] = wall_clock64(); } while (0)
+
+// every shared word is a GLOBAL agent-scope access (address_space(1): global_load / global_store ... sc1, never flat)
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) const unsigned gcu32;
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load((gcu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // hand-off accesses: data another workgroup of this launch wrote / will read
 template <bool SC1> __device__ __forceinline__ float ldh(const float* p) {
-    if constexpr (SC1) return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    else return *p;
+    if constexpr (SC1) return __builtin_bit_cast(float, __hip_atomic_load((gcu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else return *(__attribute__((address_space(1))) const float*)p;
 }
 template <bool SC1> __device__ __forceinline__ void sth(float* p, float v) {
-    if constexpr (SC1) __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
+    if constexpr (SC1) __hip_atomic_store((gu32*)p, __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *(__attribute__((address_space(1))) float*)p = v;
 }
 __device__ __forceinline__ float amax_read_agent(const float* slot) {
     float m = 0.f;
@@ -80,13 +87,13 @@ __device__ __forceinline__ bool grid_barrier(unsigned* st, unsigned n_wg, unsign
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler may drop the wait behind the write-back: cdna guide, compiler hazard)
         }
-        __hip_atomic_fetch_add(st + ST_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add((gu32*)(st + ST_ARRIVE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = n_wg * epoch;
         unsigned ok = 1, spins = 0;
         while (ld_agent(st + ST_ARRIVE) < target) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0u && ld_agent(st + ST_STATUS) != 0u)) {
-                __hip_atomic_fetch_max(st + ST_STATUS, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_max((gu32*)(st + ST_STATUS), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
             }
@@ -218,7 +225,8 @@ __device__ __forceinline__ void conv3_small_tile(const uz_chain_op& o, int tile)
         for (int t = 0; t < 9; ++t) {
             const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
             const bool inb = c < Kc && hh >= 0 && hh < H && ww >= 0 && ww < W;
-            xv[c][t] = inb ? ldh<SC1>(x + (size_t)c * HW + hh * W + ww) : 0.f;
+            const float ld = ldh<SC1>(x + (inb ? (size_t)c * HW + hh * W + ww : (size_t)hw));      // (every load unconditional: a branch per load serialises the trips)
+            xv[c][t] = inb ? ld : 0.f;
         }
     float* y = static_cast<float*>(o.p[3]) + (size_t)n * McTot * HW + hw;
     const int co0 = ct * SMALL_CO, co1 = min(Mc, co0 + SMALL_CO);
@@ -257,7 +265,8 @@ __device__ __forceinline__ void conv3_small_bwd_tile(const uz_chain_op& o, int t
             // dx[p] += dy[p - tap offset] * w[co][ci][t]  <=>  gather dy at (h - dy_t, w - dx_t)
             const int hh = h - (t / 3 - 1), ww = w - (t % 3 - 1);
             const bool inb = hh >= 0 && hh < H && ww >= 0 && ww < W;
-            const float g = inb ? ldh<SC1>(dy + (size_t)co * HW + hh * W + ww) : 0.f;
+            const float gl = ldh<SC1>(dy + (size_t)co * HW + (inb ? hh * W + ww : hw));
+            const float g = inb ? gl : 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (c < Kc) acc[c] = fmaf(wr[c * 9 + t], g, acc[c]);
@@ -307,6 +316,7 @@ __device__ __forceinline__ void bn_fwd_tile(const uz_chain_op& o, int c, double*
     const int C = o.i[0], CtotY = o.i[1], CtotA = o.i[2], N = o.i[3], HW = o.i[4], relu = o.i[5], S = o.i[6];
     const float eps = o.f[0], momentum = o.f[1];
     const int total = N * HW, tid = threadIdx.x;
+    STAMP(9);
     float* y = static_cast<float*>(o.p[0]);
     float v[BN_MAX_EPT];
     unsigned ey[BN_MAX_EPT];                   // element offsets (tensors of the chain are far below 2^32 elements)
@@ -335,9 +345,9 @@ __device__ __forceinline__ void bn_fwd_tile(const uz_chain_op& o, int c, double*
             for (int k0 = 0; k0 < S; k0 += 24) {
                 float t[24];
 #pragma unroll
-                for (int u = 0; u < 24; ++u) t[u] = (k0 + u < S && tid < total) ? ldh<SC1>(slab + (size_t)(k0 + u) * nsl + es[0]) : 0.f;
+                for (int u = 0; u < 24; ++u) t[u] = ldh<SC1>(slab + (size_t)min(k0 + u, S - 1) * nsl + es[0]);
 #pragma unroll
-                for (int u = 0; u < 24; ++u) v[0] += t[u];
+                for (int u = 0; u < 24; ++u) v[0] += (k0 + u < S) ? t[u] : 0.f;
             }
         } else {
             for (int k0 = 0; k0 < S; k0 += 2) {
@@ -345,25 +355,29 @@ __device__ __forceinline__ void bn_fwd_tile(const uz_chain_op& o, int c, double*
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int j = 0; j < BN_MAX_EPT; ++j) t[u][j] = (k0 + u < S && tid + NT * j < total) ? ldh<SC1>(slab + (size_t)(k0 + u) * nsl + es[j]) : 0.f;
+                    for (int j = 0; j < BN_MAX_EPT; ++j) t[u][j] = ldh<SC1>(slab + (size_t)min(k0 + u, S - 1) * nsl + es[j]);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int j = 0; j < BN_MAX_EPT; ++j) v[j] += t[u][j];
+                    for (int j = 0; j < BN_MAX_EPT; ++j) v[j] += (k0 + u < S) ? t[u][j] : 0.f;
             }
         }
+        STAMP(10);
 #pragma unroll
         for (int j = 0; j < BN_MAX_EPT; ++j)
             if (tid + NT * j < total) sth<SC1>(y + ey[j], v[j]);
     } else {
 #pragma unroll
-        for (int j = 0; j < BN_MAX_EPT; ++j) v[j] = tid + NT * j < total ? ldh<SC1>(y + ey[j]) : 0.f;
+        for (int j = 0; j < BN_MAX_EPT; ++j) { const float ld = ldh<SC1>(y + ey[j]); v[j] = tid + NT * j < total ? ld : 0.f; }
     }
+    STAMP(1);
     double v2[2] = {0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < BN_MAX_EPT; ++j)
         if (tid + NT * j < total) { const double d = v[j]; v2[0] += d; v2[1] += d * d; }
+    STAMP(2);
     block_sum<2>(v2, smd);
+    STAMP(3);
     if (tid == 0) {
         float* save = static_cast<float*>(o.p[5]);
         float* rmean = static_cast<float*>(o.p[3]);
@@ -381,7 +395,9 @@ __device__ __forceinline__ void bn_fwd_tile(const uz_chain_op& o, int c, double*
         }
         smf[0] = save[c]; smf[1] = save[C + c];
     }
+    STAMP(4);
     __syncthreads();
+    STAMP(5);
     const float mean = smf[0], rstd = smf[1];
     const float* gamma = static_cast<const float*>(o.p[1]);
     const float* beta = static_cast<const float*>(o.p[2]);
@@ -400,13 +416,16 @@ __device__ __forceinline__ void bn_fwd_tile(const uz_chain_op& o, int c, double*
             vmax = fmaxf(vmax, fabsf(rr));
         }
     }
+    STAMP(6);
     float* amax = static_cast<float*>(o.p[8]);
     if (amax) {
 #pragma unroll
         for (int ofs = 32; ofs > 0; ofs >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, ofs, 64));
         if ((tid & 63) == 0) amax_publish_key(vmax, amax, (unsigned)c * NW + (tid >> 6));
     }
+    STAMP(7);
     __syncthreads();                                            // smd / smf are reused by the workgroup's next tile
+    STAMP(8);
 }
 
 // ---------------------------------------------------------------------------------------------- BatchNorm + ReLU, backward
@@ -434,10 +453,12 @@ __device__ __forceinline__ void bn_bwd_tile(const uz_chain_op& o, int c, double*
         const int i = tid + NT * j, ic = i < total ? i : 0;
         const int b = ic / HW, q = ic - b * HW;
         const bool ok = i < total;
-        const float yv = ok ? y[((size_t)b * CtotY + c) * HW + q] : 0.f;
+        const float yl = y[((size_t)b * CtotY + c) * HW + q];
+        const float yv = ok ? yl : 0.f;
         xh[j] = (yv - mean) * rstd;
         es[j] = (unsigned)(((size_t)b * C + c) * HW + q);
-        dz[j] = (ok && S <= 1) ? ldh<SC1>(da + ((size_t)b * CtotDa + c) * HW + q) : 0.f;
+        const float dl = ldh<SC1>(S <= 1 ? da + ((size_t)b * CtotDa + c) * HW + q : slab + es[j]);      // (S > 1: a dummy address, value unused)
+        dz[j] = (ok && S <= 1) ? dl : 0.f;
         if (relu && !(fmaf(yv, alpha, beta_) > 0.f)) masked |= 1u << j;               // ReLU mask: dz = 0 there (x_hat still enters dy)
     }
     if (S > 1) {
@@ -445,9 +466,9 @@ __device__ __forceinline__ void bn_bwd_tile(const uz_chain_op& o, int c, double*
             for (int k0 = 0; k0 < S; k0 += 24) {
                 float t[24];
 #pragma unroll
-                for (int u = 0; u < 24; ++u) t[u] = (k0 + u < S && tid < total) ? ldh<SC1>(slab + (size_t)(k0 + u) * nsl + es[0]) : 0.f;
+                for (int u = 0; u < 24; ++u) t[u] = ldh<SC1>(slab + (size_t)min(k0 + u, S - 1) * nsl + es[0]);
 #pragma unroll
-                for (int u = 0; u < 24; ++u) dz[0] += t[u];
+                for (int u = 0; u < 24; ++u) dz[0] += (k0 + u < S) ? t[u] : 0.f;
             }
         } else {
             for (int k0 = 0; k0 < S; k0 += 2) {
@@ -455,11 +476,11 @@ __device__ __forceinline__ void bn_bwd_tile(const uz_chain_op& o, int c, double*
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int j = 0; j < BN_MAX_EPT; ++j) t[u][j] = (k0 + u < S && tid + NT * j < total) ? ldh<SC1>(slab + (size_t)(k0 + u) * nsl + es[j]) : 0.f;
+                    for (int j = 0; j < BN_MAX_EPT; ++j) t[u][j] = ldh<SC1>(slab + (size_t)min(k0 + u, S - 1) * nsl + es[j]);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int j = 0; j < BN_MAX_EPT; ++j) dz[j] += t[u][j];
+                    for (int j = 0; j < BN_MAX_EPT; ++j) dz[j] += (k0 + u < S) ? t[u][j] : 0.f;
             }
         }
     }
@@ -519,19 +540,33 @@ __device__ __forceinline__ void avgpool_fwd_tile(const uz_chain_op& o, int tile)
     const float* x = static_cast<const float*>(o.p[0]);
     float* y = static_cast<float*>(o.p[1]);
     const long long total = (long long)N * C * H * W;
+    // (all sixteen loads of a thread are issued before the first use: no branch around a load)
+    float v[4][4];
+    long long ee[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const long long e = (long long)tile * RS_PER_TILE + k * NT + threadIdx.x;
-        if (e >= total) continue;
-        const int ox = (int)(e % W); long long t = e / W;
+        ee[k] = e;
+        const long long ec = e < total ? e : total - 1;
+        const int ox = (int)(ec % W); long long t = ec / W;
         const int oy = (int)(t % H); t /= H;
         const int c = (int)(t % C), b = (int)(t / C);
         const float* s = x + ((size_t)b * CtotX + c) * Hi * Wi;
-        const int y0 = 2 * oy, x0 = 2 * ox, y1 = min(y0 + 2, Hi), x1 = min(x0 + 2, Wi);
-        float acc = 0.f;
-        for (int yy = y0; yy < y1; ++yy)
-            for (int xx = x0; xx < x1; ++xx) acc += ldh<SC1>(s + yy * Wi + xx);
-        sth<SC1>(y + ((size_t)b * CtotY + c) * H * W + oy * W + ox, acc / (float)((y1 - y0) * (x1 - x0)));
+        const int y0 = 2 * oy, x0 = 2 * ox, y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+        v[k][0] = ldh<SC1>(s + y0 * Wi + x0); v[k][1] = ldh<SC1>(s + y0 * Wi + x1);
+        v[k][2] = ldh<SC1>(s + y1 * Wi + x0); v[k][3] = ldh<SC1>(s + y1 * Wi + x1);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (ee[k] >= total) continue;
+        const int ox = (int)(ee[k] % W); long long t = ee[k] / W;
+        const int oy = (int)(t % H); t /= H;
+        const int c = (int)(t % C), b = (int)(t / C);
+        const bool hx = 2 * ox + 1 < Wi, hy = 2 * oy + 1 < Hi;          // ceil mode: the last window of an odd plane is partial
+        float acc = v[k][0];
+        if (hx) acc += v[k][1];
+        if (hy) { acc += v[k][2]; if (hx) acc += v[k][3]; }
+        sth<SC1>(y + ((size_t)b * CtotY + c) * H * W + oy * W + ox, acc / (float)((hx ? 2 : 1) * (hy ? 2 : 1)));
     }
 }
 template <bool SC1>
@@ -541,19 +576,25 @@ __device__ __forceinline__ void avgpool_bwd_tile(const uz_chain_op& o, int tile)
     const float* dy = static_cast<const float*>(o.p[0]);
     float* dx = static_cast<float*>(o.p[1]);
     const long long total = (long long)N * C * Ho * Wo;
+    float g[4], old[4];
+    float* dst[4];
+    int cnt[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const long long e = (long long)tile * RS_PER_TILE + k * NT + threadIdx.x;
-        if (e >= total) continue;
-        const int xq = (int)(e % Wo); long long t = e / Wo;
+        const long long ec = e < total ? e : total - 1;
+        const int xq = (int)(ec % Wo); long long t = ec / Wo;
         const int yq = (int)(t % Ho); t /= Ho;
         const int c = (int)(t % C), b = (int)(t / C);
         const int oy = yq >> 1, ox = xq >> 1;
-        const int cnt = (min(2 * oy + 2, Ho) - 2 * oy) * (min(2 * ox + 2, Wo) - 2 * ox);
-        const float v = ldh<SC1>(dy + ((size_t)b * CtotDy + c) * H * W + oy * W + ox) / (float)cnt;
-        float* d = dx + ((size_t)b * CtotDx + c) * Ho * Wo + yq * Wo + xq;
-        sth<SC1>(d, accumulate ? ldh<SC1>(d) + v : v);
+        cnt[k] = (min(2 * oy + 2, Ho) - 2 * oy) * (min(2 * ox + 2, Wo) - 2 * ox);
+        g[k] = ldh<SC1>(dy + ((size_t)b * CtotDy + c) * H * W + oy * W + ox);
+        dst[k] = e < total ? dx + ((size_t)b * CtotDx + c) * Ho * Wo + yq * Wo + xq : nullptr;
+        old[k] = accumulate ? ldh<SC1>(dx + ((size_t)b * CtotDx + c) * Ho * Wo + yq * Wo + xq) : 0.f;
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (dst[k]) sth<SC1>(dst[k], old[k] + g[k] / (float)cnt[k]);
 }
 __device__ __forceinline__ void src_index(int o, float scale, int ac, int in, int& i0, int& ip, float& l0, float& l1) {
     float r;
@@ -580,22 +621,27 @@ __device__ __forceinline__ void bilinear_fwd_tile(const uz_chain_op& o, int tile
     const float* x = static_cast<const float*>(o.p[0]);
     float* y = static_cast<float*>(o.p[1]);
     const long long total = (long long)N * C * Ho * Wo;
+    float v[4][4], wgt[4][4];
+    float* dst[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const long long e = (long long)tile * RS_PER_TILE + k * NT + threadIdx.x;
-        if (e >= total) continue;
-        const int ox = (int)(e % Wo); long long t = e / Wo;
+        const long long ec = e < total ? e : total - 1;
+        const int ox = (int)(ec % Wo); long long t = ec / Wo;
         const int oy = (int)(t % Ho); t /= Ho;
         const int c = (int)(t % C), b = (int)(t / C);
         const float* s = x + ((size_t)b * CtotX + c) * H * W;
-        int h1, hp, w1, wp; float h0l, h1l, w0l, w1l;
-        src_index(oy, sh, ac, H, h1, hp, h0l, h1l);
-        src_index(ox, sw, ac, W, w1, wp, w0l, w1l);
+        int h1, hp, w1, wp;
+        src_index(oy, sh, ac, H, h1, hp, wgt[k][0], wgt[k][1]);
+        src_index(ox, sw, ac, W, w1, wp, wgt[k][2], wgt[k][3]);
         const float* r0 = s + h1 * W + w1;
         const float* r1 = r0 + hp * W;
-        const float v00 = ldh<SC1>(r0), v01 = ldh<SC1>(r0 + wp), v10 = ldh<SC1>(r1), v11 = ldh<SC1>(r1 + wp);
-        sth<SC1>(y + ((size_t)b * CtotY + c) * Ho * Wo + oy * Wo + ox, h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11));
+        v[k][0] = ldh<SC1>(r0); v[k][1] = ldh<SC1>(r0 + wp); v[k][2] = ldh<SC1>(r1); v[k][3] = ldh<SC1>(r1 + wp);
+        dst[k] = e < total ? y + ((size_t)b * CtotY + c) * Ho * Wo + oy * Wo + ox : nullptr;
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (dst[k]) sth<SC1>(dst[k], wgt[k][0] * (wgt[k][2] * v[k][0] + wgt[k][3] * v[k][1]) + wgt[k][1] * (wgt[k][2] * v[k][2] + wgt[k][3] * v[k][3]));
 }
 __device__ __forceinline__ float tap_weight(int o, int osize, float scale, int ac, int isize, int i) {
     if (o < 0 || o >= osize) return 0.f;
@@ -748,13 +794,14 @@ __device__ __forceinline__ void slab_sum_tile(const uz_chain_op& o, int tile) {
     const int q = (int)(e % HW); long long t = e / HW;
     const int c = (int)(t % C), b = (int)(t / C);
     float* d = dst + ((size_t)b * Ctot + c) * HW + q;
-    float v = accumulate ? ldh<SC1>(d) : 0.f;
+    const float dl = ldh<SC1>(d);
+    float v = accumulate ? dl : 0.f;
     for (int k0 = 0; k0 < S; k0 += 24) {
         float tt[24];
 #pragma unroll
-        for (int u = 0; u < 24; ++u) tt[u] = k0 + u < S ? ldh<SC1>(slab + (size_t)(k0 + u) * nsl + e) : 0.f;
+        for (int u = 0; u < 24; ++u) tt[u] = ldh<SC1>(slab + (size_t)min(k0 + u, S - 1) * nsl + e);
 #pragma unroll
-        for (int u = 0; u < 24; ++u) v += tt[u];
+        for (int u = 0; u < 24; ++u) v += (k0 + u < S) ? tt[u] : 0.f;
     }
     sth<SC1>(d, v);
 }
@@ -780,7 +827,7 @@ __host__ __device__ inline int op_tiles(const uz_chain_op& o) {
 
 template <bool SC1>
 __global__ __launch_bounds__(NT) void chain_kernel(const uz_chain_op* __restrict__ ops, const int32_t* __restrict__ phases, int n_phases, int n_ops,
-                                                   unsigned* state) {
+                                                   unsigned* state, int dbg_phase, int dbg_wg) {
     __shared__ double smd[2 * NW];
     __shared__ float smf[NW * 4 * 64 + 8];
     __shared__ int d_code[MAX_OPS], d_t0[MAX_OPS], d_nt[MAX_OPS], d_ph[2 * MAX_PHASES];
@@ -792,8 +839,15 @@ __global__ __launch_bounds__(NT) void chain_kernel(const uz_chain_op* __restrict
     __syncthreads();
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(state + ST_STAMPS);
     if (wg == 0 && threadIdx.x == 0) stamps[0] = wall_clock64();
+    if (threadIdx.x == 0) g_dbg = nullptr;
     for (int ph = 0; ph < n_phases; ++ph) {
         const int op0 = d_ph[2 * ph], nops = d_ph[2 * ph + 1];
+        if (dbg_phase >= 0) {
+            __syncthreads();
+            if (threadIdx.x == 0) g_dbg = (ph == dbg_phase && wg == dbg_wg) ? reinterpret_cast<unsigned long long*>(state + ST_DBG) : nullptr;
+            __syncthreads();
+            STAMP(0);
+        }
         for (int k = op0; k < op0 + nops; ++k) {
             const int code = d_code[k], nt = d_nt[k];
             int first = wg - d_t0[k];                          // the op's tiles start at workgroup tile0 (mod G)
@@ -817,7 +871,9 @@ __global__ __launch_bounds__(NT) void chain_kernel(const uz_chain_op* __restrict
                 default: break;
             }
         }
+        STAMP(30);
         if (ph + 1 < n_phases && !grid_barrier<SC1>(state, (unsigned)G, (unsigned)(ph + 1), &verdict)) return;
+        STAMP(31);
         if (wg == 0 && threadIdx.x == 0 && ph + 1 < MAX_STAMPS) stamps[ph + 1] = wall_clock64();
     }
 }
@@ -912,9 +968,11 @@ extern "C" int uz_chain_run(const uz_chain_op* ops, const int32_t* phases, int n
     static const int n_cu = [] { int n = 0; if (uz_device_info(&n, nullptr, 0) != 0) n = 0; return n; }();
     UZ_REQUIRE(n_cu <= 0 || n_workgroups <= n_cu, "chain_run: %d workgroups on %d CUs (a workgroup holds a whole CU's wave slots)", n_workgroups, n_cu);
     static const int sc1 = [] { const char* e = getenv("UZ_CHAIN_SC1"); return e ? atoi(e) : 1; }();
+    static const int dbg_phase = [] { const char* e = getenv("UZ_CHAIN_DEBUG_PHASE"); return e ? atoi(e) : -1; }();
+    static const int dbg_wg = [] { const char* e = getenv("UZ_CHAIN_DEBUG_WG"); return e ? atoi(e) : 0; }();
     if (hipMemsetAsync(state, 0, ST_STAMPS * sizeof(unsigned), uz::S(stream)) != hipSuccess) return uz::fail("chain_run: hipMemsetAsync failed");
-    if (sc1) hipLaunchKernelGGL(chain_kernel<true>, dim3(n_workgroups), dim3(NT), 0, uz::S(stream), ops, phases, n_phases, n_ops, static_cast<unsigned*>(state));
-    else hipLaunchKernelGGL(chain_kernel<false>, dim3(n_workgroups), dim3(NT), 0, uz::S(stream), ops, phases, n_phases, n_ops, static_cast<unsigned*>(state));
+    if (sc1) hipLaunchKernelGGL(chain_kernel<true>, dim3(n_workgroups), dim3(NT), 0, uz::S(stream), ops, phases, n_phases, n_ops, static_cast<unsigned*>(state), dbg_phase, dbg_wg);
+    else hipLaunchKernelGGL(chain_kernel<false>, dim3(n_workgroups), dim3(NT), 0, uz::S(stream), ops, phases, n_phases, n_ops, static_cast<unsigned*>(state), dbg_phase, dbg_wg);
     return uz::check_launch("chain_kernel");
 }
 extern "C" int uz_chain_status(const void* state, int* out, void* stream) {

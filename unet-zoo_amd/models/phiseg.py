@@ -93,7 +93,6 @@ def phiseg_spec(input_channels, num_classes, num_filters, reversible=False):
 class PHISeg(NativeModel):
     wgrad_workgroups = 128                     # NativeModel.wgrad_workgroups: 256 -> 1 907, 192 -> 1 946, 128 -> 1 970, 96 -> 1 916, 64 -> 1 778 images/s (one box)
     default_lanes_by_mode = {"lanes": 3}     # host-issued lane replay: 2 lanes 17.7 ms, 3: 16.3, 4: 16.2 (one box, round 5)
-    chain_px = 8192                # see NativeModel.chain_px: the 16 x 16 ... 2 x 2 levels of the forward tape as one persistent launch
     decouple_wgrad_px = 8192       # see NativeModel.decouple_wgrad_px: the 16 x 16 ... 2 x 2 levels at batch 32
     decouple_wgrad_prefixes = ("likelihood",)      # its backward is a single chain (posterior / prior pair up): A/B 1 726 -> 1 744 images/s
 
