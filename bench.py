@@ -367,6 +367,8 @@ def fp32_only_leg(args):
     env = dict(os.environ, UZ_CONV_MATH="f32")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--batch", str(args.batch), "--model", args.model, "--skip-cpu", "--no-profile", "--no-f32-leg"]
+    if args.allow_experiment:
+        cmd.append("--allow-experiment")
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -437,7 +439,40 @@ def launch_ranks(n, argv):
     return 1 if timed_out else max(abs(rc) for rc in rcs)
 
 
-def dry_run(args, rank, world, global_batch):
+def build_info():
+    """uz_build_info() of the library this process loads: what the binary is (variant, piece products per MAC, experiment code, source hash)."""
+    import ctypes as C
+    from unet_zoo_amd import _ffi
+    buf = C.create_string_buffer(1024)
+    _ffi.lib().uz_build_info(buf, 1024)
+    return json.loads(buf.value.decode())
+
+
+def uz_env():
+    """Every UZ_* / queue variable set in this process's environment (the line's config.env): a reader sees which knobs shaped the run."""
+    keys = sorted(k for k in os.environ if k.startswith("UZ_") or k in ("GPU_MAX_HW_QUEUES", "DEBUG_HIP_FORCE_GRAPH_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY"))
+    return {k: os.environ[k] for k in keys}
+
+
+def product_guard(allow):
+    """The line must prove it ran the product: a run with a work-skipping diagnostic (UZ_DIAG_SKIP), another library (UZ_LIB) or a library
+    built with timing-only / diagnostic code (uz_build_info().experiment) is refused - exit status 2 - unless --allow-experiment is given,
+    and then the line carries "experiment": true.  Returns the reasons (empty list: a product run)."""
+    reasons = [f"{k} is set" for k in ("UZ_DIAG_SKIP", "UZ_LIB") if os.environ.get(k)]
+    try:
+        info = build_info()
+        if info.get("experiment"):
+            reasons.append("the library is an experiment build: " + json.dumps({k: v for k, v in info.items() if k != "source_hash"}))
+    except Exception as e:                                   # a library without uz_build_info is not the product either
+        reasons.append(f"uz_build_info failed: {e}")
+    if reasons and not allow:
+        print("bench.py: refusing to report a benchmark line - " + "; ".join(reasons) + " (pass --allow-experiment to run anyway; the line is then marked)",
+              file=sys.stderr)
+        raise SystemExit(2)
+    return reasons
+
+
+def dry_run(args, rank, world, global_batch, experiment=()):
     """UZ_BENCH_DRY=1 (CPU test hook, never used by the driver): the launcher / rendezvous / timing / reporting skeleton of main()
     with a sleep in place of the training step - checks that `--gpus N` really runs N ranks and reports that number."""
     import torch
@@ -467,8 +502,9 @@ def dry_run(args, rank, world, global_batch):
         print(json.dumps(dict(metric="dry run (no GPU work)", value=round(args.batch * world * args.steps / elapsed, 2), unit="images/s", n_gpus=world,
                               steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True,
                               scaling="strong" if args.strong else "weak", vs_baseline=None, dtype="none", data="none",
-                              config=dict(workload="dry run", batch_per_gpu=args.batch, global_batch=global_batch, parallelism=f"dp{world}"),
-                              dp=dict(backend="gloo", nranks=nranks, launcher="self" if os.environ.get("UZ_BENCH_SELF_LAUNCHED") else "external"))))
+                              config=dict(workload="dry run", batch_per_gpu=args.batch, global_batch=global_batch, parallelism=f"dp{world}", build=build_info(), env=uz_env()),
+                              dp=dict(backend="gloo", nranks=nranks, launcher="self" if os.environ.get("UZ_BENCH_SELF_LAUNCHED") else "external"),
+                              **({"experiment": True} if experiment else {}))))
     if world > 1:
         dist.destroy_process_group()
 
@@ -612,7 +648,11 @@ def main():
                          "(= UZ_STORE_B16=1; BASELINE configs[4] 'bf16': the default of --model phiseg3d), or everything in fp32")
     ap.add_argument("--strong", action="store_true", help="strong scaling (SURVEY 8d): the GLOBAL batch stays at --batch (default 32), "
                                                           "each of the N GPUs takes batch / N images")
+    ap.add_argument("--allow-experiment", action="store_true",
+                    help="report a line although a work-skipping / timing-only knob is in play (UZ_DIAG_SKIP, UZ_LIB, a library built with "
+                         "UZ_EXP_* / UZ_DIAG): the line is then marked \"experiment\": true.  Without this flag such a run exits with status 2.")
     args = ap.parse_args()
+    experiment = product_guard(args.allow_experiment)
 
     if args.conv_math is None and args.model == "phiseg3d" and "UZ_CONV_MATH" not in os.environ:
         args.conv_math = "bf16"
@@ -643,7 +683,7 @@ def main():
         global_batch, args.batch = args.batch, args.batch // world
 
     if os.environ.get("UZ_BENCH_DRY") == "1":
-        return dry_run(args, rank, world, global_batch)
+        return dry_run(args, rank, world, global_batch, experiment)
 
     # the fp32-MFMA-only comparison leg runs in a child process BEFORE this process initialises the GPU
     f32_leg = None
@@ -857,8 +897,12 @@ def main():
                                 lanes=getattr(plan, "n_lanes", None),
                                 schedule=(dict(tuned_rounds=args.tune_schedule, **tuned, note="profile-guided lane schedule (Engine.tune_schedule) before the timed region")
                                           if tuned else dict(cost_model=os.environ.get("UZ_SCHED_COST", getattr(plan, "sched_cost", "alone")))),
-                                final_loss=final_loss, conv_math=math_note),
+                                final_loss=final_loss, conv_math=math_note, build=build_info(), env=uz_env(),
+                                chain=getattr(plan, "chain_info", None) or None),
                     roofline=roof)
+        if experiment:
+            line["experiment"] = True
+            line["config"]["experiment_reasons"] = experiment
         if world > 1:
             line["config"]["allreduce"] = "bucketed, overlapped with backward" if not args.no_overlap else "one blocking all-reduce after backward"
             sync = getattr(net, "_dp", None)

@@ -438,6 +438,10 @@ typedef struct uz_op {
   void*    p[12];
 } uz_op;
 int uz_run_tape(const uz_op* ops, int n_ops, void* stream);
+/* What this binary is: writes a JSON object {variant, products_per_mac, exp_patch_dma, exp_pref_all, diag_skip_compiled, source_hash,
+ * experiment} into out (cap bytes) and returns `experiment` (0 for a product build: three piece products per operand pair, no experiment or
+ * diagnostic code compiled in).  bench.py prints it in config.build and refuses to report a line from an experiment build. */
+int uz_build_info(char* out, int cap);
 /* Capture the tape into a hipGraph on `stream` and return an opaque executable handle. */
 int  uz_graph_create(const uz_op* ops, int n_ops, void* stream, void** graph_exec_out);
 /* Lane capture: like uz_graph_create, but the captured graph carries the tape's dependency DAG

@@ -433,3 +433,93 @@ def test_default_routing_keeps_small_planes_off_the_split_path():
         assert L.uz_set_conv_math(0) == 0 and all(L.uz_conv_route(k, 224, 128, 32, 128, 128, 3) == 0 for k in (0, 1, 2))
     finally:
         L.uz_set_conv_math(-1 if os.environ.get("UZ_CONV_MATH") is None else mode)
+
+
+def test_bench_refuses_work_skipping_knobs_and_reports_what_the_binary_is():
+    """the line must prove it ran the product.  bench.py exits with status 2 when UZ_DIAG_SKIP or UZ_LIB is set (or
+    the library says it is an experiment build) unless --allow-experiment is given, and then marks the line; config.build carries
+    uz_build_info() (three piece products, no experiment / diagnostic code, the source hash), config.env every UZ_* variable; the
+    product library has no diag_skip code at all (it is behind -DUZ_DIAG)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "UZ_LIB", "UZ_DIAG_SKIP")}
+    run = lambda env, *flags: subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", *flags], env=dict(base, UZ_BENCH_DRY="1", **env),
+                                             capture_output=True, text=True, timeout=300)
+    ok = run({})
+    assert ok.returncode == 0, ok.stderr[-1000:]
+    d = json.loads(ok.stdout.strip().splitlines()[-1])
+    b = d["config"]["build"]
+    assert b["experiment"] == 0 and b["products_per_mac"] == 3 and b["diag_skip_compiled"] == 0 and b["variant"] == "" and len(b["source_hash"]) == 16
+    assert d["config"]["env"].get("UZ_BENCH_DRY") == "1" and "experiment" not in d
+    for env in (dict(UZ_DIAG_SKIP="conv:8"), dict(UZ_LIB=os.path.join(root, "unet-zoo_amd", "libuz_hip.so"))):
+        r = run(env)
+        assert r.returncode == 2 and not r.stdout.strip() and "refusing" in r.stderr and list(env)[0] in r.stderr, (env, r.returncode, r.stderr[-500:])
+        a = run(env, "--allow-experiment")
+        assert a.returncode == 0 and json.loads(a.stdout.strip().splitlines()[-1])["experiment"] is True
+    syms = subprocess.run(["nm", "-C", os.path.join(root, "unet-zoo_amd", "libuz_hip.so")], capture_output=True, text=True).stdout
+    assert "diag_skip" not in syms and "uz_build_info" in syms
+
+
+def _happens_before(plan, which, ops):
+    sc, n = plan.scheds[which], len(ops)
+    hb, last = [0] * n, {}
+    for k, o in enumerate(ops):
+        m = 0
+        if o["lane"] in last:
+            m |= hb[last[o["lane"]]] | (1 << last[o["lane"]])
+        for w in range(sc[k].n_wait):
+            m |= hb[sc[k].wait[w]] | (1 << sc[k].wait[w])
+        hb[k] = m
+        last[o["lane"]] = k
+    return hb
+
+
+def test_chain_pass_builds_convex_levelled_chains_at_the_headline_size(monkeypatch):
+    """Plan._chain_pass (csrc/chain.hip, UZ_CHAIN=8192: off by default - DESIGN.md section 9): the forward tape's 16 x 16 ... 2 x 2 ops become ONE
+    chain op, the backward tape's one per sub-network.  Checked on the headline plan: (a) inside a chain a sub-op sits in a LATER phase
+    than every sub-op it depends on (the hazard analysis of the per-op tape, restricted to the set); (b) every conflicting pair of the
+    rewritten tape - the chain op carries the union of its sub-ops' accesses - stays ordered by the lane schedule; (c) no scheduling
+    group that shares lane scratch is cut in two by a chain (a unit's BatchNorm backward and its weight gradient stay back to back);
+    (d) the tiles of every sub-op are counted by the library and the chains' phase tables are consistent."""
+    from unet_zoo_amd import _ffi
+    from unet_zoo_amd.models.phiseg import PHISeg
+    if _ffi.lib().uz_get_conv_math() in (0, 3):
+        pytest.skip("the chain's convolutions are two-piece split-fp16")
+    monkeypatch.setenv("UZ_CHAIN", "8192")
+    net = PHISeg(1, 2, [32, 64, 128, 192, 192, 192, 192], device="cpu")
+    net.train()
+    plan = net._build(32, 128, 128, True, True)
+    info = plan.chain_info
+    assert len(info["fwd"]) == 1 and info["fwd"][0]["ops"] > 140 and [c["net"] for c in info["bwd"]] == ["likelihood", "prior", "posterior"]
+    assert sum(o["code"] == "UZ_OP_CHAIN" for o in plan.fwd_ops) == 1 and sum(o["code"] == "UZ_OP_CHAIN" for o in plan.bwd_ops) == 3
+    assert sum(o["code"] == "UZ_OP_CHAIN_PACK" for o in plan.fwd_ops) == 1 and sum(o["code"] == "UZ_OP_CHAIN_PACK" for o in plan.bwd_ops) == 1
+    small = lambda o: o["code"] in ("UZ_OP_CONV_FWD", "UZ_OP_CONV_BWD_DATA") and o["i"][7] == 3 and o["i"][4] * o["i"][5] * o["i"][6] <= 8192
+    assert not any(small(o) for o in plan.fwd_ops + plan.bwd_ops)            # every small 3 x 3 forward / data gradient went into a chain
+    for ch in plan._chains:
+        sub = ch["sub"]
+        origs = [e["orig"] for e in sub]
+        # (a) phases respect the dependencies of the original ops
+        deps = plan._hazard_deps(sorted({id(o): o for o in origs}.values(), key=lambda o: min(e["k"] for e in sub if e["orig"] is o)))
+        order = sorted({id(o): o for o in origs}.values(), key=lambda o: min(e["k"] for e in sub if e["orig"] is o))
+        first = {id(o): min(e["level"] for e in sub if e["orig"] is o) for o in order}
+        last = {id(o): max(e["level"] for e in sub if e["orig"] is o) for o in order}
+        for k, o in enumerate(order):
+            for d in deps[k]:
+                assert last[id(order[d])] < first[id(o)], (ch["net"], order[d]["code"], o["code"])
+        # (d) phase table
+        dev = plan._chain_tables(plan._chains.index(ch))
+        ph = dev["phases"].reshape(-1, 2).tolist()
+        assert sum(n for _, n in ph) == len(sub) and [a for a, _ in ph] == sorted(a for a, _ in ph) and dev["n_phases"] == 1 + max(e["level"] for e in sub)
+        assert all(e["ntiles"] > 0 and 0 <= e["tile0"] < ch["n_wgs"] for e in sub)
+    for which, ops in (("fwd", plan.fwd_ops), ("bwd", plan.bwd_ops)):
+        # (b) every conflicting pair stays ordered
+        pairs, used, _ = _check_lane_schedule(plan, which, ops)
+        assert pairs > 100
+        # (c) a unit whose dy lives in the lane scratch keeps BatchNorm backward, weight gradient and data gradient back to back
+        for k, o in enumerate(ops):
+            if o["code"] == "UZ_OP_BN_RELU_BWD" and type(o["p"][5]).__name__ == "_ScratchView" and o["p"][5].view is None:
+                mates = [q for q in ops if q.get("gid") == o["gid"]]
+                pos = [ops.index(q) for q in mates]
+                assert pos == list(range(pos[0], pos[0] + len(pos))) and len({q["lane"] for q in mates}) == 1, (which, k)

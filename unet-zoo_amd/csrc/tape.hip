@@ -63,9 +63,41 @@ extern "C" int uz_device_info(int* n_cu, char* name, int name_cap) {
     return 0;
 }
 
-// Diagnostics only (tools/what_if.sh): UZ_DIAG_SKIP="conv:8,bn:8,resample:4,convmin:64" drops every convolution / BatchNorm / resampling
+// What this binary is (uz_build_info): a product build multiplies every operand pair with three piece products and carries no
+// experiment code; `make VARIANT=... XFLAGS="-DUZ_EXP_..."` builds say so here, and bench.py refuses to report a line from them.
+#ifndef UZ_VARIANT
+#define UZ_VARIANT ""
+#endif
+#ifndef UZ_SRC_HASH
+#define UZ_SRC_HASH "unknown"
+#endif
+extern "C" int uz_build_info(char* out, int cap) {
+    int products = 3, experiment = 0;
+#ifdef UZ_EXP_PRODUCTS
+    products = UZ_EXP_PRODUCTS; experiment |= (UZ_EXP_PRODUCTS != 3);
+#endif
+    int patch_dma = 0, pref_all = 0, diag = 0;
+#ifdef UZ_EXP_PATCH_DMA
+    patch_dma = 1; experiment = 1;
+#endif
+#ifdef UZ_EXP_PREF_ALL
+    pref_all = 1; experiment = 1;
+#endif
+#ifdef UZ_DIAG
+    diag = 1; experiment = 1;
+#endif
+    if (UZ_VARIANT[0]) experiment = 1;
+    if (out && cap > 0)
+        snprintf(out, (size_t)cap, "{\"variant\": \"%s\", \"products_per_mac\": %d, \"exp_patch_dma\": %d, \"exp_pref_all\": %d, \"diag_skip_compiled\": %d, "
+                                   "\"source_hash\": \"%s\", \"experiment\": %d}", UZ_VARIANT, products, patch_dma, pref_all, diag, UZ_SRC_HASH, experiment);
+    return experiment;
+}
+
+#ifdef UZ_DIAG
+// Diagnostics only, compiled in by `make VARIANT=diag XFLAGS=-DUZ_DIAG` (tools/what_if.sh), never in the product library:
+// UZ_DIAG_SKIP="conv:8,bn:8,resample:4,convmin:64" drops every convolution / BatchNorm / resampling
 // op on planes up to (convmin: from) that height from a tape - the results are garbage, the step time shows what those ops cost
-// on the critical path (an upper bound for any optimisation of them).  Unset in every product run.
+// on the critical path (an upper bound for any optimisation of them).
 static bool diag_skip(const uz_op& o) {
     static const char* env = getenv("UZ_DIAG_SKIP");
     if (!env) return false;
@@ -95,9 +127,12 @@ static bool diag_skip(const uz_op& o) {
         default: return false;
     }
 }
+#endif
 
 static int run_one(const uz_op& o, void* st) {
+#ifdef UZ_DIAG
     if (diag_skip(o)) return 0;
+#endif
     const int32_t* i = o.i;
     const float* f = o.f;
     void* const* p = o.p;
