@@ -751,7 +751,9 @@ def main():
         loss = step()
     tuned = None
     if args.tune_schedule > 0 and not args.no_graphs and net.replay_mode == "lanes":
-        # profile-guided lane schedule (Engine.tune_schedule): set-up work like the graph capture, untimed, and every rank tunes its own
+        # profile-guided lane schedule (Engine.tune_schedule): set-up work like the graph capture, untimed; under data parallelism the call is
+        # COLLECTIVE - every measured duration is max-reduced over the ranks (dp.max_over_ranks), so all ranks end with one schedule and
+        # one bucket exchange order
         tuned = net.tune_schedule(step, rounds=args.tune_schedule)
         for _ in range(2):
             loss = step()

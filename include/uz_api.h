@@ -461,7 +461,7 @@ int  uz_graph_create_lanes(const uz_op* ops, const uz_sched* sched, int n_ops, i
 /* Workgroups a split-path weight gradient (uz_conv_bwd_weight*, 3x3, >= 64 channels) is cut into: a process setting the host makes BEFORE it
  * sizes slab buffers with uz_conv_bwd_weight_slabs and keeps while it runs the calls sized with it (the Python face sets it per model in
  * front of every tape: PHISeg 128, ProbabilisticUnet 192, others 256 = one workgroup per CU).  No counterpart in the reference. */
-void uz_set_wgrad_target(int workgroups);
+void uz_set_wgrad_target(int workgroups);   /* a tape whose slab buffers were sized under another target refuses to run (UZ_OP_CONV_BWD_WEIGHT i[12]) */
 int  uz_get_wgrad_target(void);
 /* The same DAG replayed WITHOUT a hipGraph: lane 0 runs on `stream`, every other lane on a library-owned stream that forks from
  * and joins `stream`; every cross-lane edge is one event that names exactly the op it waits for.  Replaces the reference's

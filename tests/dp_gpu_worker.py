@@ -104,7 +104,15 @@ def main():
     # 2.7e-2 with 1 - 2 tensors beyond 2e-2, tools/dp_seed_scan.sh; seeds 300 / 700 / 900: 1.6e-2 / 4.4e-3 / 5.6e-3, none) - so the
     # test uses a seed without one instead of a gate wide enough to hide a real fault.
     med = sorted(devs)[len(devs) // 2]
-    print(f"rank {rank}: median_rel_dev={med:.3e} tensors_above_2e-2={sum(d >= 2e-2 for d in devs)} seed={seed0}", flush=True)
+    p90 = sorted(devs)[(9 * len(devs)) // 10]
+    above = sum(d >= 2e-2 for d in devs)
+    print(f"rank {rank}: median_rel_dev={med:.3e} p90={p90:.3e} tensors_above_2e-2={above} seed={seed0}", flush=True)
+    if os.environ.get("UZ_DP_TEST_GATE") == "knife_edge":
+        # a gate that does not pass by seed selection.  On a seed WITH a knife-edge ReLU pixel (100, 500) the distribution is
+        # gated instead of the single worst tensor: a mis-bucketed layer moves its weight, bias and BatchNorm tensors - and through the
+        # optimiser step everything downstream - so it shows as MANY tensors beyond 2e-2 and a moved 90th percentile; a knife-edge pixel
+        # moves the one or two tensors it feeds (measured 2.7e-2) and nothing else.
+        sys.exit(0 if (same and med < 1e-3 and p90 < 5e-3 and above <= 2 and worst < 6e-2) else 1)
     sys.exit(0 if (same and worst < 2e-2 and med < 1e-3) else 1)
 
 

@@ -559,3 +559,35 @@ def test_fused_latent_heads_leave_the_training_step_bit_identical(monkeypatch):
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
     for a, b in zip(runs[0][3], runs[1][3]):
         assert torch.equal(a, b)
+
+
+def test_a_tape_replayed_under_another_weight_gradient_grid_refuses_to_run():
+    """uz_set_wgrad_target is process state that sizes the weight-gradient slab buffers when a plan is built AND the
+    grids when its tape runs.  A caller that bypasses NativeModel._run (which restores the model's setting in front of every tape) and
+    replays the backward tape under another target would write up to twice the allocated slabs and reduce the wrong number - silently.
+    The op now carries the slab count its buffer was sized for (UZ_OP_CONV_BWD_WEIGHT i[12]) and the tape runner refuses."""
+    from unet_zoo_amd import _ffi
+    if os.environ.get("UZ_WGS_TARGET"):
+        pytest.skip("UZ_WGS_TARGET pins the target")
+    arrays, meta = G.load("phiseg_full_b32_digest")
+    net, _ = _model(meta)
+    net.train()
+    x, mask, eps = _inputs(meta, 0)
+    net.forward(x, mask, training=True, eps=eps)
+    loss = net.loss(mask)
+    loss.backward()
+    torch.cuda.synchronize()
+    plan, L = net._cur, _ffi.lib()
+    sized = [o["i"][12] for o in plan.bwd_ops if o["code"] == "UZ_OP_CONV_BWD_WEIGHT" and o["i"][11]]
+    assert len(sized) > 50 and all(n > 0 for n in sized)
+    before = L.uz_get_wgrad_target()
+    try:
+        L.uz_set_wgrad_target(256 if before != 256 else 128)
+        with pytest.raises(_ffi.UzError, match="the plan sized"):
+            plan.run("bwd", net._stream())
+    finally:
+        L.uz_set_wgrad_target(before)
+        torch.cuda.synchronize()
+    plan.run("bwd", net._stream())                             # ... and runs again under the setting it was built with
+    torch.cuda.synchronize()
+    assert net.check_bounds() == 0

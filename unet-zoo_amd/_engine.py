@@ -154,6 +154,8 @@ class NativeModel(nn.Module):
     # lanes, Probabilistic U-Net 3 107 -> 3 240 images/s, U-Net / PHiSeg3D unchanged.  (More than four concurrently active hardware
     # queues collapse the step to 27 ms: lanes <= 4, GPU_MAX_HW_QUEUES >= lanes.)
     replay_mode = os.environ.get("UZ_REPLAY", "lanes")
+    if replay_mode not in ("lanes", "graph"):          # (any other value used to select the hipGraph path silently: ADVICE r5)
+        raise ValueError(f"UZ_REPLAY={replay_mode!r}: the replay mode is 'lanes' (host-issued lane replay) or 'graph' (hipGraph)")
     default_lanes_by_mode = {}  # per-model override of default_lanes for a replay mode, e.g. {"lanes": 3}
     # Planes (N*H*W pixels) up to which a layer's weight gradient becomes a scheduling group of its own (Plan._decouple_wgrad;
     # UZ_DECOUPLE_WGRAD overrides).  Measured A/B on one MI355X: PHiSeg 19.49 -> 19.26 ms with 8192 (the deep levels' backward
@@ -191,6 +193,25 @@ class NativeModel(nn.Module):
         dp = getattr(self, "_dp", None)
         if dp is not None and dp.overlap:
             plan.grad_buckets = list(dp.buckets)
+        # Stream budget (measured, DESIGN.md section 2: five or more concurrently active hardware queues collapse a PHiSeg step from 16 to
+        # 27 ms): lanes + the data-parallel communication stream <= 4, and the process needs a hardware queue per lane
+        extra = 1 if (dp is not None and dp.overlap) else 0
+        if plan.n_lanes + extra > 4:
+            import warnings
+            if "UZ_LANES" in os.environ:
+                warnings.warn(f"UZ_LANES={plan.n_lanes} with {extra} communication stream(s): more than four concurrently active streams - "
+                              "measured to collapse the step (16 -> 27 ms on MI355X)", RuntimeWarning)
+            else:
+                plan.n_lanes = 4 - extra
+        try:
+            hwq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        except ValueError:
+            hwq = 4
+        if self.replay_mode == "lanes" and plan.n_lanes > 1 and hwq < plan.n_lanes and not self.__dict__.get("_warned_hwq"):
+            import warnings
+            self.__dict__["_warned_hwq"] = True
+            warnings.warn(f"GPU_MAX_HW_QUEUES={hwq} < {plan.n_lanes} dependency lanes: lanes share hardware queues and serialise "
+                          "(measured: 2 queues 1 741 images/s against 2 035 with 3, PHiSeg)", RuntimeWarning)
         return plan
 
     def enable_graphs(self, flag=True):
@@ -248,15 +269,22 @@ class NativeModel(nn.Module):
             # the tape's DAG issued by the host on one stream per lane, one event per cross-lane edge (uz_run_tape_lanes)
             arr, n = plan.tapes[which]
             rec = self.__dict__.get("_tune_rec")
+            armed = False
             if n and rec is not None:                      # tune_schedule(): one timing event behind every op of this call
                 plan.L.uz_lane_trace(1, n, None, 0)
-            if n:
-                _ffi.check(plan.L.uz_run_tape_lanes(arr, plan.scheds[which], n, plan.n_lanes, C.c_void_p(self._stream())), f"lane replay '{which}'")
-            if n and rec is not None:
-                buf = (C.c_float * n)()
-                got = plan.L.uz_lane_trace(0, 0, buf, n)
-                assert got == n, (got, n)
-                rec.setdefault((id(plan), which), (plan, []))[1].append([buf[k] * 1e3 for k in range(n)])
+                armed = True
+            try:
+                if n:
+                    _ffi.check(plan.L.uz_run_tape_lanes(arr, plan.scheds[which], n, plan.n_lanes, C.c_void_p(self._stream())), f"lane replay '{which}'")
+                if armed:
+                    buf = (C.c_float * n)()
+                    got = plan.L.uz_lane_trace(0, 0, buf, n)
+                    armed = False
+                    assert got == n, (got, n)
+                    rec.setdefault((id(plan), which), (plan, []))[1].append([buf[k] * 1e3 for k in range(n)])
+            finally:
+                if armed:                                  # a replay that raised must not leave the tracer armed for the rest of the process
+                    plan.L.uz_lane_trace(0, 0, None, 0)
             return
         key = (id(plan), which)
         g = self._graphs.get(key)
@@ -316,6 +344,10 @@ class NativeModel(nn.Module):
                     step()
             finally:
                 self.__dict__["_tune_rec"] = None
+            if r == 0 and not any(plan.n_lanes > 1 for plan, _runs in rec.values()):
+                # single-lane plans (U-Net) have nothing to re-schedule: do not spend (rounds + 1) * samples more steps - with their
+                # data-parallel exchanges - to return "initial" 
+                return dict(tape_us={}, step_ms={}, kept="initial")
             for (pid, which), (plan, runs) in rec.items():          # (same plans, same order on every rank: the closure ran the same calls)
                 if plan.n_lanes <= 1:
                     continue

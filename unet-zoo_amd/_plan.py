@@ -396,7 +396,7 @@ class Plan:
             slabbuf = self.vec(wkey + ":wslabs", nslab * 9 * cout * 3 * cin) if nslab else None
             rec["wgrad"] = self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
                        p=[("win", x), gy, self.G(wkey), None, ("scratch", "wgrad"), self.amax_in(x), self.amax_in(gy), None, slabbuf],
-                       i=[3 * cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, 3, 0, 0, 0, 1 if nslab else 0], n=ws)
+                       i=[3 * cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, 3, 0, 0, 0, 1 if nslab else 0, nslab], n=ws)      # i[12]: slabs the buffer was sized for
             if nslab:
                 self.__dict__.setdefault("_wgrad_jobs", []).append((slabbuf, wkey, nslab, cout, 3 * cin, 9, cin))
             x = x_orig
@@ -431,7 +431,7 @@ class Plan:
             rec["wgrad"] = self._emit(self.bwd_ops, "UZ_OP_CONV_BWD_WEIGHT",
                                       p=[x, gy, self.G(wkey, wextra), self.G(db_key, wrow0) if db_key else None, ("scratch", "wgrad"),
                                          self.amax_in(x), self.amax_in(gy), None, slabbuf],
-                                      i=[cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, ks, 0, 0, 0, 1 if nslab else 0], n=ws)
+                                      i=[cin, x.Ctot, cout, gy.Ctot, x.N, x.H, x.W, ks, 0, 0, 0, 1 if nslab else 0, nslab], n=ws)      # i[12]: slabs the buffer was sized for (checked at launch: ADVICE r5)
             if nslab:
                 self.__dict__.setdefault("_wgrad_jobs", []).append((slabbuf, wkey, nslab, cout, cin, ks * ks))
         # dy in a buffer of its own (small planes): the data gradient - the only thing the next layer's backward waits for -
@@ -2229,9 +2229,29 @@ class Plan:
             us = 8.0 + 0.0031 * o["i"][1]                 # HBM-bound: PHiSeg's 106 layers = 95 301 blocks take 300 us
         elif c in ("UZ_OP_MEMSET",):
             us = 8.0
+        elif c in ("UZ_OP_W3D_PERMUTE", "UZ_OP_AVGPOOL3D_FWD", "UZ_OP_AVGPOOL3D_BWD", "UZ_OP_DEPTH_LERP_FWD", "UZ_OP_DEPTH_LERP_BWD",
+                   "UZ_OP_NEAREST3D_FWD", "UZ_OP_NEAREST3D_BWD", "UZ_OP_ADD_VIEWS"):
+            # volume ops stream whole volumes: a flat 25 us was wrong by orders of magnitude (PHiSeg3D's static schedule)
+            us = 12.0 + Plan._vol_bytes(o) / 3.0e6                  # ~3 TB/s realised beside the other lanes' kernels
         else:
             us = 25.0
         return us * 1e-6
+
+    @staticmethod
+    def _vol_bytes(o):
+        """Bytes a volume / view op moves (input + output once), from its i[] (C, ..., D, H, W in the layouts of include/uz_api.h)."""
+        c, i = o["code"], o["i"]
+        if c == "UZ_OP_W3D_PERMUTE":
+            return 8.0 * i[0] * i[1] * 27
+        if c == "UZ_OP_ADD_VIEWS":
+            return 12.0 * i[3] * i[4] * i[5] * i[6]
+        C_, D, H, W = i[0], i[3], i[4], i[5]
+        n = float(C_) * D * H * W
+        if c in ("UZ_OP_AVGPOOL3D_FWD", "UZ_OP_AVGPOOL3D_BWD"):
+            return 4.0 * n * (1.0 + 0.125)
+        if c in ("UZ_OP_DEPTH_LERP_FWD", "UZ_OP_DEPTH_LERP_BWD"):
+            return 4.0 * n * 3.0
+        return 4.0 * n * (1.0 + float(i[6]) * i[6] * (i[7] if len(i) > 7 else 1))
 
     @staticmethod
     def _op_heavy(o):

@@ -158,7 +158,13 @@ static int run_one(const uz_op& o, void* st) {
                                        i[10] == 2 ? CFP(7) : nullptr, i[9], CFP(10), i[12], FP(8), st);
         case UZ_OP_CONV_BWD_WEIGHT:
             // i[8] = x in split storage, p[7] / i[9] = second scale segment of x, i[10] = dy in split storage
-            // i[11]: slabs only, into p[8] (added by UZ_OP_WGRAD_REDUCE_TABLE at the end of the tape)
+            // i[11]: slabs only, into p[8] (added by UZ_OP_WGRAD_REDUCE_TABLE at the end of the tape); i[12]: the slab count p[8] and the
+            // table row were SIZED for when the plan was built.  uz_set_wgrad_target is process state: a caller that replays this tape
+            // under another target would write more slabs than were allocated and reduce the wrong number - refuse instead
+            if (i[11] && i[12] > 0 && uz_conv_bwd_weight_slabs(i[0], i[2], i[4], i[5], i[6], i[7]) != i[12])
+                return uz::fail("conv_bwd_weight: the plan sized %d slabs for this layer, the library would now write %d (uz_set_wgrad_target / "
+                                "uz_set_conv_math changed between plan build and replay: rebuild the plan or restore the setting)",
+                                i[12], uz_conv_bwd_weight_slabs(i[0], i[2], i[4], i[5], i[6], i[7]));
             if (i[13] && i[7] == 1) return uz_conv1x1_bwd_weight_b16(p[0], i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], p[4], (size_t)o.n, i[13] & 1, st);
             if (i[13]) return uz_conv_bwd_weight_b16(p[0], i[0], i[1], p[1], i[2], i[3], FP(2), i[4], i[5], i[6], i[7], p[4], (size_t)o.n, i[13] & 1, (i[13] >> 1) & 1, i[11] ? FP(8) : nullptr, st);      // bit 0 = x, bit 1 = dy in bf16 storage
             return uz_conv_bwd_weight_ex(CFP(0), i[0], i[1], CFP(1), i[2], i[3], FP(2), FP(3), i[4], i[5], i[6], i[7], CFP(5), CFP(6), p[4], (size_t)o.n,
