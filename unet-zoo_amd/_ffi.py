@@ -117,6 +117,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # libuz_hip.so resolves libamdhip64 by soname: when torch is already imported that is the HIP runtime torch ships and has mapped
+    # (ONE runtime per process); loaded FIRST it would pull in the system's copy, and the process would then hold two HIP runtimes -
+    # the second one finds no device ("no ROCm-capable device is detected").  So: torch first, always.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise UzError(f"{LIB_PATH} not found: build the HIP library first (make -C unet-zoo_amd/csrc). "
                       "There is no CPU fallback for the product path.")

@@ -115,29 +115,33 @@ def broadcast_(flat, src=0, group=None):
 # ----------------------------------------------------------------------------------------------
 # Bucketed, overlapped gradient exchange
 # ----------------------------------------------------------------------------------------------
-def param_buckets(ptab, min_floats=1 << 20):
-    """Contiguous [lo, hi) float ranges of the flat gradient buffer, one per sub-network (first component of the
-    state_dict key: posterior / likelihood / prior for PHiSeg; unet / prior / posterior / fcomb for the Probabilistic
-    U-Net).  Neighbours smaller than `min_floats` are merged - a ring all-reduce of a few hundred KB is latency, not
-    bandwidth.  The backward tape finishes these ranges at different times (PHiSeg: prior at ~49 %, likelihood at ~84 %
-    of the tape), which is what the overlap exploits."""
-    runs = []
+def param_buckets(ptab, target_floats=None):
+    """Contiguous [lo, hi) float ranges of the flat gradient buffer, cut at tensor boundaries into BYTE-WEIGHTED slices of about
+    `target_floats` (default 3 Mi floats = 12 MB; UZ_DP_BUCKET_MB overrides).  Rounds 2 - 5 used one bucket per sub-network
+    (PHiSeg: 37.7 / 22.6 / 37.7 MB): under the lane replay the backward tape finishes ALL of them in its last 3 % (the weight
+    gradients of the deep levels - 80 % of the bytes - are the lanes' fillers), so the whole exchange trailed the tape and the LAST
+    bucket alone was 38 % of the bytes.  With slices the last-final bucket is one slice (12 %), the others leave as the tape
+    finalises them, in the order of the scheduled tape (GradSync.order).  A ring all-reduce below a few MB is latency, not
+    bandwidth: slices are not cut finer than that, and a short tail is merged into its neighbour."""
+    if target_floats is None:
+        target_floats = int(float(os.environ.get("UZ_DP_BUCKET_MB", "12")) * (1 << 20) / 4)
+    out, lo, acc = [], 0, 0
+    end = 0
     for key, off in ptab.poff.items():
-        top = key.split(".", 1)[0]
         n = 1
         for s_ in ptab.shape[key]:
             n *= int(s_)
-        if runs and runs[-1][0] == top and runs[-1][2] == off:
-            runs[-1][2] = off + n
+        acc += n
+        end = off + n
+        if acc >= target_floats:
+            out.append([lo, end])
+            lo, acc = end, 0
+    if lo < end:
+        if out and end - lo < target_floats // 2:
+            out[-1][1] = end
         else:
-            runs.append([top, off, off + n])
-    out = []
-    for _, lo, hi in runs:
-        if out and (hi - lo < min_floats or out[-1][1] - out[-1][0] < min_floats):
-            out[-1][1] = hi
-        else:
-            out.append([lo, hi])
-    return [(lo, hi) for lo, hi in out]
+            out.append([lo, end])
+    return [(a_, b_) for a_, b_ in out]
 
 
 class GradSync:
