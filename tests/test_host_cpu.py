@@ -119,6 +119,9 @@ def test_kernel_resource_table_matches_the_sources_and_the_budgets():
     # Footprint discipline of the deep levels' BatchNorm launches: the headline convolution holds two waves x 184 VGPRs per SIMD, so a
     # workgroup with W waves per SIMD starts beside it only under (512 - 2 * 184) / W registers (tools/bench_coresidency.py: 5 us alone,
     # 9 us beside the convolution under the budget, 65 - 77 us above it)
+    # the chain launch (csrc/chain.hip): 1024-thread workgroups = four waves per SIMD need <= 128 registers, and its matrix loop carries no spill
+    ck = tab["chain.hip"]["kernels"]
+    assert all(v["vgpr"] <= 128 and v["scratch"] <= 400 and v["lds"] <= 32 * 1024 for n, v in ck.items() if n.startswith("chain_kernel")), ck
     free = 512 - 2 * k["conv_splitp_db_kernel_2_512_32"]["vgpr"]
     b = tab["bn.hip"]["kernels"]
     for name, waves in (("bn_fused_small_fwd<2>", 1), ("bn_fused_small_bwd<2>", 1), ("bn_fused_small_fwd<8>", 1), ("bn_fused_small_bwd<8>", 1),

@@ -350,6 +350,14 @@ def test_phiseg_b32_gradients_vs_fp64_reference():
     assert np.median(eh) <= 2.5 * np.median(er), (np.median(eh), np.median(er))
     assert np.percentile(eh, 90) <= 1.5 * np.percentile(er, 90), (np.percentile(eh, 90), np.percentile(er, 90))
     assert eh.max() <= 1.5 * er.max(), (eh.max(), er.max())
+    # Per tensor: a systematic error in ONE layer's gradient - which the norm gates of the digest tests (1e-2 of a
+    # tensor's norm) would let through - shows here as a tensor far beyond what the reference's own fp32 arithmetic does to it.  Rounding
+    # through 30+ stacked normalisations is chaotic, so for a handful of tensors either implementation is the unlucky one (measured round
+    # 6: 15 of 368 beyond 3x the reference's error + 2e-4, the worst at 6x): at most 8 % of the tensors may sit there, and none beyond
+    # 12x + 1e-3 - a 1 % systematic error in a layer with a 1e-4 reference error is 100x.
+    assert len(bad) <= 0.08 * len(keys), bad[:10]
+    worst = [(keys[i], eh[i], er[i]) for i in range(len(keys)) if eh[i] > 12.0 * er[i] + 1e-3]
+    assert not worst, worst
 
 
 @pytest.mark.parametrize("fixture", ["phiseg_mid", "phiseg_full_digest"])

@@ -1309,7 +1309,7 @@ class Plan:
             kind = {"UZ_OP_CONV_FWD": 0, "UZ_OP_CONV_BWD_DATA": 1, "UZ_OP_CONV_BWD_WEIGHT": 2}[c]
             W = i[6]
             # (a weight gradient may leave its slabs to the table launch - i[11] - in either storage: uz_conv_bwd_weight_b16 takes slabs_out)
-            if i[7] != 3 or W % 32 or (any(i[8:11]) or any(i[12:]) if kind == 2 else any(i[8:]) and kind != 1):
+            if i[7] != 3 or W % 32 or (any(i[8:11]) or any(i[13:]) if kind == 2 else any(i[8:]) and kind != 1):      # (weight gradient: i[11] slabs-only, i[12] the slab count the buffer was sized for)
                 return False
             if kind == 1 and (any(i[9:]) or len(p) > 7):
                 return False
