@@ -315,7 +315,7 @@ def dominant_kernel_live(net, plan, L, heaviest, reps=20):
     op_i = ops[k]["i"]
     if len(op_i) > 13 and op_i[13]:
         try:
-            pname = next(n for n in ("r5_pmc_traffic_b16.json", "r4_pmc_traffic_b16.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            pname = next(n for n in ("r6_pmc_traffic_b16.json", "r5_pmc_traffic_b16.json", "r4_pmc_traffic_b16.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pname)))
             if f"{cin} -> {cout}" in pmc.get("layer", "") and kind in (0, 1, 2):
                 key = "wgrad_split_kernel<32, 64, 1, 2, 2>" if kind == 2 else next(k_ for k_ in ("conv_b16_db_kernel_4_512_32", "conv_b16_db_kernel_2_512_32", "conv_b16_kernel_2_512_32") if k_ in pmc["kernels"])
@@ -326,7 +326,7 @@ def dominant_kernel_live(net, plan, L, heaviest, reps=20):
                 return out
         except Exception:
             pass
-    for tabname in ("r5_layer_table.json", "r4_layer_table.json", "r3_layer_table.json"):      # per-layer dispatch table (tools/prof_layers.sh), keyed on layer and direction; newest first
+    for tabname in ("r6_layer_table.json", "r5_layer_table.json", "r4_layer_table.json", "r3_layer_table.json"):      # per-layer dispatch table (tools/prof_layers.sh), keyed on layer and direction; newest first
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", tabname)))
             for row in tab["layers"]:

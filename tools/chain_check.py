@@ -11,7 +11,7 @@ B = int(os.environ.get("B", "32"))
 nf = [32, 64, 128, 192, 192, 192, 192]
 torch.manual_seed(0)
 ref = PHISeg(1, 2, nf); ref.chain_px = 0; ref.train()
-net = PHISeg(1, 2, nf); net.train()
+net = PHISeg(1, 2, nf); net.chain_px = 8192; net.train()      # (the chains are off by default: NativeModel.chain_px)
 net.load_state_dict(ref.state_dict())
 g = torch.Generator(device="cpu").manual_seed(1)
 x = (torch.randn(B, 1, 128, 128, generator=g) * 0.25).clamp(-0.5, 0.5).cuda()

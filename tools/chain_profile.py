@@ -8,7 +8,7 @@ from unet_zoo_amd import _ffi
 
 B = int(os.environ.get("B", "32"))
 which = os.environ.get("TAPE", "fwd")
-net = PHISeg(1, 2, [32, 64, 128, 192, 192, 192, 192]); net.train()
+net = PHISeg(1, 2, [32, 64, 128, 192, 192, 192, 192]); net.chain_px = 8192; net.train()      # (off by default; UZ_CHAIN overrides)
 x = (torch.randn(B, 1, 128, 128) * 0.25).clamp(-0.5, 0.5).cuda()
 mask = (torch.rand(B, 1, 128, 128) > 0.7).float().cuda()
 for _ in range(2):

@@ -28,11 +28,11 @@ ab)
     echo -n "$v : "; env $v python bench.py --model ${MODEL:-phiseg} --steps ${STEPS:-30} --warmup 5 --skip-cpu --no-profile --no-f32-leg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], 'img/s', d['ms_per_step'], 'ms')"
   done; done ;;
 layers)
-  bash tools/prof_layers.sh 5 ${1:-20} ${1:-20} > gpurun_out/prof_layers.log 2>&1; tail -24 gpurun_out/prof_layers.log | cut -c1-230 ;;
+  bash tools/prof_layers.sh ${ROUND:-6} ${1:-20} ${1:-20} > gpurun_out/prof_layers.log 2>&1; tail -24 gpurun_out/prof_layers.log | cut -c1-230 ;;
 stats)
   m=${1:-phiseg}; rm -rf gpurun_out/prof_$m
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$m -- python bench.py --model $m --steps 15 --warmup 5 --skip-cpu --no-profile --no-f32-leg > gpurun_out/prof_${m}_line.json 2>/dev/null
-  cp $(ls gpurun_out/prof_$m/*/*kernel_stats.csv | head -1) gpurun_out/r5_bench_kernel_stats_graph_$m.csv; rm -rf gpurun_out/prof_$m
-  head -25 gpurun_out/r5_bench_kernel_stats_graph_$m.csv | cut -c1-160 ;;
+  cp $(ls gpurun_out/prof_$m/*/*kernel_stats.csv | head -1) gpurun_out/r${ROUND:-6}_bench_kernel_stats_graph_$m.csv; rm -rf gpurun_out/prof_$m
+  head -25 gpurun_out/r${ROUND:-6}_bench_kernel_stats_graph_$m.csv | cut -c1-160 ;;
 *) echo "unknown: $what"; exit 2 ;;
 esac
