@@ -25,6 +25,10 @@ eps = None
 
 
 def run(dp, overlap=True, steps=8, timed=0):
+    # every leg starts from a clean process state: the previous leg's model (a 10.7 GB arena, its plans, lane streams' work) is collected
+    # first - as the THIRD live model of the process the serial leg read 21.7 ms against 16.1 ms alone (round 6: not an exchange cost)
+    import gc
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
     torch.manual_seed(1)
     net = PHISeg(1, 2, [32, 64, 128, 192, 192, 192, 192], latent_levels=5, image_size=(1, 128, 128))
     net.train()
@@ -52,7 +56,11 @@ def run(dp, overlap=True, steps=8, timed=0):
     exposed = net._dp.exposed_ms() if dp else None
     nb = len(net._dp.buckets) if dp else 0
     nev = len(net._cur.events) if dp else 0
-    return net._ptab.pflat.clone(), float(loss.detach()), ms, exposed, nb, nev
+    out = (net._ptab.pflat.clone(), float(loss.detach()), ms, exposed, nb, nev)
+    if dp:
+        torch.cuda.synchronize()
+        net._dp.close()                                  # communicator + communication stream: the next leg must not inherit a live stream
+    return out
 
 
 print("rccl version code", _ffi.lib().uz_comm_version())

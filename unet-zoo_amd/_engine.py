@@ -401,6 +401,8 @@ class NativeModel(nn.Module):
         process group runs on nccl, torch.distributed collectives otherwise (gloo test double)."""
         from . import dp
         self._dp_group = group
+        if getattr(self, "_dp", None) is not None:
+            self._dp.close()                   # communicator and communication stream of an earlier call (streams are a scarce resource: dp.GradSync.close)
         self._dp = dp.GradSync(self, None if group is True else group, backend=backend, overlap=overlap)
         self._plans.clear()                # plans built before this call carry no bucket events
         self._drop_graphs()
