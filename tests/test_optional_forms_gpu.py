@@ -17,3 +17,12 @@ def test_optional_weight_gradient_forms_vs_fp64(env):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wgrad_forms_check.py")], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("px", ["2048", "0"], ids=["lds_free", "product"])
+def test_lds_free_small_plane_convolution_vs_fp64(px):
+    """conv_mfma.hip conv_free_kernel (UZ_CONV_FREE_PX; off in the product): forward and data gradient of the 2 x 2 ... 8 x 8 planes,
+    ragged channels, channel-slice views, accumulate - tools/conv_free_check.py, in a child process (the switch is read once)."""
+    e = dict(os.environ); e["UZ_CONV_FREE_PX"] = px
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv_free_check.py")], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

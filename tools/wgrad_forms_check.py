@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Weight gradient through the C ABI (fp32 and split-storage operands) against an fp64 reference, on shapes that take the 64-channel
 split kernels: ragged channel counts, a partial last tile row, a 16-wide plane.  Prints one line per case and ALL OK; exit code 1 on a
-miss.  The form is chosen by the environment (UZ_WG9, UZ_WG_M16): tests/test_wgrad_forms_gpu.py."""
+miss.  The form is chosen by the environment (UZ_WG9, UZ_WG_M16): tests/test_optional_forms_gpu.py."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -244,6 +244,91 @@ __global__ __launch_bounds__(256, UZ_SMALL_OCC ? UZ_SMALL_OCC : (JMAX == 2 ? 2 :
     if (p.y_amax) uz::amax_publish(vmax, p.y_amax);
 }
 
+// ---------------------------------------------------------------- LDS-free form for the small planes (round 6)
+// ONE WAVE per workgroup, no LDS, ~110 VGPRs: such a workgroup needs one wave slot and its registers on ONE SIMD, so it starts beside the
+// double-buffered split convolution (2 x 184 VGPRs per SIMD, 148.5 of 160 KB of LDS on every CU) or a BatchNorm sweep, where a
+// workgroup of the LDS-staged kernel above (four waves, 35 - 52 KB of LDS) waits until a whole CU drains: in the step the 2 x 2 ... 8 x 8
+// levels' convolutions took 3 - 4 x their isolated time (profiles/NOTES_r5.md section 4).  Same arithmetic (v_mfma_f32_32x32x2_f32),
+// same split of the channel loop and the same slabs as the kernel above - it replaces only the main launch of a split-K call.
+// Wave tile: 32 output channels x 32 flattened pixels (n, y, x).  K walks the input channels two at a time (the MFMA's K = 2: lane
+// half h takes channel c + h), nine taps each: the nine weights of a (co, ci) pair are 36 contiguous bytes (two 16-byte loads + one
+// dword), the input comes as one dword per tap and lane (consecutive pixels: coalesced rows).  Loads run one group of two channel
+// pairs (36 registers) ahead of the MFMAs.
+template <bool DGRAD>
+__global__ __launch_bounds__(64) void conv_free_kernel(const ConvP p) {
+    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+    const int P = p.N * p.HW, PB = (P + 31) / 32;
+    int wid = blockIdx.x;
+    const int ksp = wid % p.ksplit; wid /= p.ksplit;
+    const int pb = wid % PB, co0 = (wid / PB) * 32;
+    const int pidx = pb * 32 + l31;
+    const bool pvalid = pidx < P;
+    const int pc = pvalid ? pidx : P - 1;
+    const int n = pc / p.HW, hw = pc - n * p.HW, yy = hw / p.W, xx = hw - yy * p.W;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)(((size_t)(p.N - 1) * p.CinTot + p.Cin) * p.HW * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (unsigned)((size_t)p.wCo * p.wCi * 9 * sizeof(float)), 0x00020000);
+    // byte offsets of the nine taps inside channel 0 of this lane's image; 0x80000000 (+ any channel offset: still past the end of
+    // the buffer, no wrap) = padding, the range check returns 0
+    unsigned boff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int sy = yy + t / 3 - 1, sx = xx + t % 3 - 1;
+        boff[t] = (pvalid && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) ? 4u * (unsigned)(n * p.CinTot * p.HW + sy * p.W + sx) : 0x80000000u;
+    }
+    // weights: forward A[co][ci][tap] = w[co][ci][tap]; data gradient A[m][k][tap] = w[k][co0 + m][8 - tap] (k walks dim 0)
+    const bool mvalid = (co0 + l31) < p.Cout;
+    const unsigned wlane = 36u * (unsigned)(DGRAD ? (co0 + l31) : (co0 + l31) * p.wCi);
+    const unsigned wkstep = 36u * (unsigned)(DGRAD ? p.wCi : 1);          // bytes per step of the K channel
+    const unsigned xstep = 4u * (unsigned)p.HW;
+
+    struct Grp { float a[2][9]; float b[2][9]; };
+    auto gload = [&](Grp& g, int c) __attribute__((always_inline)) {      // channels c .. c + 3 (two pairs; lane half h: c + h, c + 2 + h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ci = c + 2 * q + h;
+            const unsigned cvm = ci < p.Cin ? 0u : 0xFFFFFFFFu;
+            const unsigned wo = (mvalid && ci < p.Cin) ? wlane + (unsigned)ci * wkstep : 0x80000000u;     // (+ 32 bytes of immediate offset: no wrap)
+            const uz::u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rw, wo, 0, 0);
+            const uz::u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rw, wo, 16, 0);
+            const unsigned w2 = __builtin_amdgcn_raw_buffer_load_b32(rw, wo, 32, 0);
+            const unsigned raw[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) g.a[q][t] = __builtin_bit_cast(float, raw[DGRAD ? 8 - t : t]);
+            const unsigned cbase = (unsigned)ci * xstep;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) g.b[q][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (boff[t] + cbase) | cvm, 0, 0));
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto mma = [&](const Grp& g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g.a[q][t], g.b[q][t], acc, 0, 0, 0);
+    };
+    const int nChunksAll = (p.Cin + CK - 1) / CK;
+    const int cBeg = ksp * p.cps * CK, cEnd = min(nChunksAll, ksp * p.cps + p.cps) * CK;       // channel range of this split (multiples of 8)
+    Grp g0, g1;
+    gload(g0, cBeg);
+    for (int c = cBeg; c < cEnd; c += 8) {       // two groups per trip: the registers of a group are named at compile time
+        gload(g1, c + 4);                        // (c + 4 < cEnd always: the range is a multiple of 8 channels)
+        mma(g0);
+        gload(g0, c + 8);                        // past the range: channels >= cEnd are either masked (>= Cin) or finite and unused
+        mma(g1);
+    }
+    if (!pvalid) return;
+    float* base = p.slab + ((size_t)ksp * p.N + n) * p.Cout * p.HW + hw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < p.Cout) base[(size_t)co * p.HW] = acc[r];
+    }
+}
+
 // y[b,co,p] = (accumulate ? y : 0) + bias[co] + sum_s slab[s][b,co,p]  (fixed order), optional ReLU.
 // V = 4: float4 sweep (HW % 4 == 0, 16-byte aligned output view); one 32-bit division pair per vector.
 template <int V>
@@ -479,6 +564,17 @@ static int conv_mfma_impl(const float* x, int Kc, int KcTot, const float* w, int
     const long long grid = base_grid * p.ksplit;
     UZ_REQUIRE(grid < (1ll << 31), "conv: grid too large");
     int rc;
+    // small planes, split chunk loop: the LDS-free one-wave form (conv_free_kernel; UZ_CONV_FREE_PX = largest N * H * W it takes).  OFF by
+    // default: beside the headline convolution a 192 -> 192 @ 4 x 4 call drops from 83 to 53 us (alone 19 -> 17), but the PHiSeg STEP loses
+    // 1.4 % at 2048 and 0.4 % at 512 (two alternations; profiles/NOTES_r6.md section 8): 32-pixel wave tiles re-read the weights once per
+    // tile (64 x on an 8 x 8 plane) and its fp32 MFMAs now sit on every SIMD of the chip beside the split kernels' instead of on a few CUs
+    static const long long free_px = getenv("UZ_CONV_FREE_PX") ? atoll(getenv("UZ_CONV_FREE_PX")) : 0;
+    if (ks == 3 && p.ksplit > 1 && (long long)N * H * W <= free_px && (size_t)N * KcTot * H * W < (1u << 28) && (size_t)p.wCo * wCi * 9 < (1u << 28)) {
+        const long long fgrid = (long long)ceil_div(N * H * W, 32) * ceil_div(Mc, 32) * p.ksplit;
+        if (dgrad) hipLaunchKernelGGL(conv_free_kernel<true>, dim3((unsigned)fgrid), dim3(64), 0, st, p);
+        else hipLaunchKernelGGL(conv_free_kernel<false>, dim3((unsigned)fgrid), dim3(64), 0, st, p);
+        rc = check_launch("conv_free_kernel");
+    } else
     if (ks == 3) rc = dgrad ? launch_ks<3, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<3, false>(p, msub, jmax, (int)grid, smem, st);
     else rc = dgrad ? launch_ks<1, true>(p, msub, jmax, (int)grid, smem, st) : launch_ks<1, false>(p, msub, jmax, (int)grid, smem, st);
     if (rc || p.ksplit == 1 || slabs_only) return rc;
