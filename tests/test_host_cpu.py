@@ -114,8 +114,14 @@ def test_kernel_resource_table_matches_the_sources_and_the_budgets():
     for name, (vmax, smax) in budgets.items():
         assert k[name]["vgpr"] <= vmax and k[name]["scratch"] <= smax, (name, k[name])
     w = tab["conv_wgrad_split.hip"]["kernels"]
-    heavy = [v for n, v in w.items() if n.startswith("wgrad_split_kernel<32, 64, 2")]
-    assert heavy and all(v["vgpr"] <= 256 and v["scratch"] == 0 for v in heavy), heavy      # (236 - 254 since the bound predicate is accumulated over every tile)
+    heavy = [v for n, v in w.items() if n.startswith("wgrad_split_kernel<32, 64, 2") and n.endswith(", 0>")]      # the product's instances (last argument: MFMA shape)
+    assert len(heavy) == 4 and all(v["vgpr"] <= 256 and v["scratch"] == 0 for v in heavy), heavy      # (236 - 254 since the bound predicate is accumulated over every tile)
+    # the optional forms of round 6 (off in the product, NOTES_r6 section 8): the two-image form must not spill, the LDS-free small-plane
+    # convolution has to fit beside the headline convolution's two waves x 184 VGPRs per SIMD (one wave: <= 144 registers, no LDS)
+    assert w["wgrad_db_kernel<1, 1>"]["vgpr"] <= 256 and w["wgrad_db_kernel<1, 1>"]["scratch"] == 0, w["wgrad_db_kernel<1, 1>"]
+    cm = tab["conv_mfma.hip"]["kernels"]
+    for n in ("conv_free_kernel<false>", "conv_free_kernel<true>"):
+        assert cm[n]["vgpr"] <= 128 and cm[n]["scratch"] == 0 and not cm[n]["lds"], (n, cm[n])
     # Footprint discipline of the deep levels' BatchNorm launches: the headline convolution holds two waves x 184 VGPRs per SIMD, so a
     # workgroup with W waves per SIMD starts beside it only under (512 - 2 * 184) / W registers (tools/bench_coresidency.py: 5 us alone,
     # 9 us beside the convolution under the budget, 65 - 77 us above it)

@@ -673,6 +673,209 @@ __global__ __launch_bounds__(NT9, 2) void wgrad9_kernel(const WS p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Third form (round 6): the first form's eight waves and tap groups, but TWO LDS images of a 64-pixel tile (2 rows x 32 columns; 2 x 60 KB)
+// and the staging INSIDE the MFMA loop.  In-kernel stamps of the first form (224 -> 128 @ 128 x 128): 38 % of a tile's cycles are the phase
+// between its two barriers in which all eight waves convert and store the next tile while the matrix pipe idles; the MFMA loop itself runs at
+// 92 % of its MFMA cycles.  Here the tile j + 1 is converted and written to the other image in four portions, one per k-step of tile j, the
+// registers a portion frees are reloaded at once with the same portion of tile j + 3 (two register sets in flight: a load has two tiles'
+// time to arrive, as in the first form), and ONE barrier closes a tile.  Same slabs, same split count, same arithmetic.
+constexpr int PTD = 64;
+template <int XF, int DF>
+__global__ __launch_bounds__(NT) void wgrad_db_kernel(const WS p) {
+    constexpr bool XPK = XF == 1, DPK = DF == 1;
+    constexpr int NP = 2, TW = 32, TH = PTD / TW, XROW = (TW + 8) * 2, PROWS = TH + 2, XCHD = PROWS * XROW + 16, DYROWD = PTD * 2 + 16;
+    constexpr int CT = 64, SROW = TW / 16, KSTEPS = PTD / 16;
+    constexpr int DYPLANE = CT * DYROWD, XPLANE = CT * XCHD, IMG = NP * (DYPLANE + XPLANE);
+    constexpr int DQ = PTD / 4, DQROW = TW / 4, XQ = TW / 4;
+    constexpr int DYSLOTS = CT * DQ / NT;                     // 2
+    constexpr int XQSLOTS = CT * PROWS * XQ / NT;             // 4
+    static_assert(CT * DQ % NT == 0 && CT * PROWS * XQ % NT == 0 && CT * PROWS <= NT, "staging slots");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = (wave ^ (wave >> 2)) & 1;
+    const int wn = (wave >> 1) & 1, wm = wave >> 2;
+    const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);
+    const int nTile = p.nCoT * p.nCiT;
+    const int split = wid / nTile, tl = wid - split * nTile;
+    const int co0 = (tl / p.nCiT) * CT, ci0 = (tl % p.nCiT) * CT;
+
+    for (int i = tid * 16; i < 2 * IMG; i += NT * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0u, 0u, 0u, 0u};
+
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dy), 0, (unsigned)(((size_t)(p.N - 1) * p.CoutTot + p.Cout) * p.HW * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)(((size_t)(p.N - 1) * p.CinTot + p.Cin) * p.HW * 4u), 0x00020000);
+
+    struct RS { f32x4 d[DYSLOTS]; f32x4 x[XQSLOTS]; float xp[2]; };
+    // slot numbering for the portions: dY slots 0 .. 1, X quads 2 .. 5, the pair slot 6; portion = slot % KSTEPS (part < 0: all)
+    auto gload = [&](RS& r, int t, int part) __attribute__((always_inline)) {
+        const unsigned tm = t < p.T ? 0u : 0xFFFFFFFFu;          // past the last tile: every load fails the range check (returns 0)
+        const int txi = t % p.tilesX, t2 = t / p.tilesX;
+        const int x0 = txi * TW, y0 = (t2 % p.tilesY) * TH, b0 = t2 / p.tilesY;
+        const unsigned dbase = 4u * (unsigned)((b0 * p.CoutTot + co0) * p.HW + y0 * p.W + x0);
+#pragma unroll
+        for (int i = 0; i < DYSLOTS; ++i) {
+            if (part >= 0 && i % KSTEPS != part) continue;
+            const int e = tid + i * NT, co = e / DQ, q = e % DQ, row = q / DQROW, c4 = (q % DQROW) * 4;
+            const unsigned m = ((y0 + row) < p.H && (co0 + co) < p.Cout) ? tm : 0xFFFFFFFFu;
+            r.d[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (dbase + 4u * (unsigned)(co * p.HW + row * p.W + c4)) | m, 0, 0));
+        }
+        const int xbase = (b0 * p.CinTot + ci0) * p.HW + y0 * p.W + x0;
+#pragma unroll
+        for (int i = 0; i < XQSLOTS; ++i) {
+            if (part >= 0 && (i + DYSLOTS) % KSTEPS != part) continue;
+            const int e = tid + i * NT;
+            const int q = e % XQ, rr = e / XQ, ci = rr / PROWS, prow = rr - ci * PROWS;
+            const int yy = y0 + prow - 1;
+            const bool rowok = (ci0 + ci) < p.Cin && yy >= 0 && yy < p.H;
+            const int sh = (q == 0 && x0 == 0) ? 1 : 0;
+            const int off = xbase + ci * p.HW + (prow - 1) * p.W + 4 * q - 1 + sh;
+            r.x[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxx, (rowok ? 4u * (unsigned)off : 0xFFFFFFFFu) | tm, 0, 0));
+        }
+        if (part < 0 || (DYSLOTS + XQSLOTS) % KSTEPS == part) {
+            const int e = tid;
+            const int ci = e / PROWS, prow = e - ci * PROWS;
+            const int yy = y0 + prow - 1;
+            const bool rowok = e < CT * PROWS && (ci0 + ci) < p.Cin && yy >= 0 && yy < p.H;
+            const int off = xbase + ci * p.HW + (prow - 1) * p.W + TW - 1;
+            r.xp[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (rowok ? 4u * (unsigned)off : 0xFFFFFFFFu) | tm, 0, 0));
+            r.xp[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, ((rowok && x0 + TW < p.W) ? 4u * (unsigned)(off + 1) : 0xFFFFFFFFu) | tm, 0, 0));
+        }
+    };
+    const float sdy = uz::split_scale(uz::amax_read(p.dy_amax)), sx = uz::split_scale(uz::amax_read(p.x_amax));
+    bool xbad = false, dbad = false;
+    auto xpieces = [&](float v0, float v1, unsigned (&out)[NP]) __attribute__((always_inline)) {
+        if constexpr (XPK) uz::packed_pair(__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), out[0], out[1]);
+        else { xbad |= uz::bound_violated(v0 * sx, v1 * sx); pieces<NP>(v0 * sx, v1 * sx, out); }
+    };
+    auto dpieces = [&](float v0, float v1, unsigned (&out)[NP]) __attribute__((always_inline)) {
+        if constexpr (DPK) uz::packed_pair(__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), out[0], out[1]);
+        else { dbad |= uz::bound_violated(v0 * sdy, v1 * sdy); pieces<NP>(v0 * sdy, v1 * sdy, out); }
+    };
+    auto lstore = [&](const RS& r, int t, char* img, int part) __attribute__((always_inline)) {
+        char* dYl = img;
+        char* Xl = img + NP * DYPLANE;
+        const bool left_edge = t % p.tilesX == 0;
+#pragma unroll
+        for (int i = 0; i < DYSLOTS; ++i) {
+            if (part >= 0 && i % KSTEPS != part) continue;
+            const int e = tid + i * NT, co = e / DQ, q = e % DQ;
+            char* d = dYl + co * DYROWD + ((q / DQROW) * TW + (q % DQROW) * 4) * 2;
+            unsigned pa[NP], pb[NP];
+            dpieces(r.d[i][0], r.d[i][1], pa);
+            dpieces(r.d[i][2], r.d[i][3], pb);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * DYPLANE) = make_uint2(pa[pl], pb[pl]);
+        }
+#pragma unroll
+        for (int i = 0; i < XQSLOTS; ++i) {
+            if (part >= 0 && (i + DYSLOTS) % KSTEPS != part) continue;
+            const int e = tid + i * NT;
+            const int q = e % XQ, rr = e / XQ, ci = rr / PROWS, prow = rr - ci * PROWS;
+            char* d = Xl + ci * XCHD + prow * XROW + q * 8;
+            unsigned pa[NP], pb[NP];
+            const f32x4 v = (left_edge && q == 0) ? f32x4{0.f, r.x[i][0], r.x[i][1], r.x[i][2]} : r.x[i];
+            xpieces(v[0], v[1], pa);
+            xpieces(v[2], v[3], pb);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * XPLANE) = make_uint2(pa[pl], pb[pl]);
+        }
+        if (part < 0 || (DYSLOTS + XQSLOTS) % KSTEPS == part) {
+            if (tid < CT * PROWS) {
+                const int ci = tid / PROWS, prow = tid - ci * PROWS;
+                unsigned pa[NP];
+                xpieces(r.xp[0], r.xp[1], pa);
+                char* d = Xl + ci * XCHD + prow * XROW + XQ * 8;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<unsigned*>(d + pl * XPLANE) = pa[pl];
+            }
+        }
+    };
+
+    auto run = [&](auto ntap_c, auto tap0_c) __attribute__((always_inline)) {
+        constexpr int NTAP = decltype(ntap_c)::value, TAP0 = decltype(tap0_c)::value;
+        constexpr int DY0 = TAP0 / 3;
+        f32x16 acc[NTAP];
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+        const int aoff = (wm * 32 + l31) * DYROWD + h * 16;
+        const int boff = NP * DYPLANE + (wn * 32 + l31) * XCHD + h * 16;
+        // one tile: the MFMAs of tile j out of `rd`, tile j + 1 (registers r) converted into `wr`, r reloaded with tile j + 3
+        auto step = [&](const char* rd, char* wr, RS& r, int t_store, int t_load) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                lstore(r, t_store, wr, s);
+                gload(r, t_load, s);
+                const int srow = s / SROW, scol = (s % SROW) * 16;
+                u32x4 a[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const u32x4*>(rd + aoff + q * DYPLANE + (srow * TW + scol) * 2);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    u32x4 v[NP];
+                    unsigned v4[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const char* src = rd + boff + q * XPLANE + (srow + DY0 + d) * XROW + scol * 2;
+                        v[q] = *reinterpret_cast<const u32x4*>(src);
+                        v4[q] = *reinterpret_cast<const unsigned*>(src + 16);
+                    }
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int tap = (DY0 + d) * 3 + dx, k = tap - TAP0;
+                        if (k >= 0 && k < NTAP) {
+                            u32x4 b[NP];
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) {
+                                if (dx == 0) b[q] = v[q];
+                                else if (dx == 2) b[q] = u32x4{v[q].y, v[q].z, v[q].w, v4[q]};
+                                else b[q] = u32x4{__builtin_amdgcn_alignbit(v[q].y, v[q].x, 16), __builtin_amdgcn_alignbit(v[q].z, v[q].y, 16),
+                                                  __builtin_amdgcn_alignbit(v[q].w, v[q].z, 16), __builtin_amdgcn_alignbit(v4[q], v[q].w, 16)};
+                            }
+                            const int kc = k < 0 ? 0 : (k >= NTAP ? NTAP - 1 : k);
+                            acc[kc] = mma<NP>(acc[kc], a, b);
+                        }
+                    }
+                }
+            }
+        };
+        const int J = (p.T - split + p.S - 1) / p.S;          // tiles of this workgroup: split, split + S, ...
+        RS r0, r1;
+        gload(r0, split, -1);
+        gload(r1, split + p.S, -1);
+        lstore(r0, split, lds, -1);
+        gload(r0, split + 2 * p.S, -1);
+        __syncthreads();
+        for (int j = 0; j < J; j += 2) {
+            step(lds, lds + IMG, r1, split + (j + 1) * p.S, split + (j + 3) * p.S);
+            __syncthreads();
+            if (j + 1 >= J) break;
+            step(lds + IMG, lds, r0, split + (j + 2) * p.S, split + (j + 4) * p.S);
+            __syncthreads();
+        }
+        uz::raise_flag(p.flags, xbad, uz::FLAG_X_BOUND); uz::raise_flag(p.flags, dbad, uz::FLAG_DY_BOUND);
+        float* out = p.slab + (size_t)split * 9 * p.Cout * p.Cin;
+        const int ci = ci0 + wn * 32 + l31;
+        const float inv_dy = uz::split_inv_scale(uz::amax_read(p.dy_amax));
+        const float inv_x = uz::split_inv_scale(uz::amax_read((XPK && p.x_amax2 && ci >= p.seg_channels) ? p.x_amax2 : p.x_amax));
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Cout && ci < p.Cin) out[((size_t)(TAP0 + k) * p.Cout + co) * p.Cin + ci] = acc[k][r] * inv_dy * inv_x;
+            }
+    };
+    if (tg == 0) run(std::integral_constant<int, 5>{}, std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
+}
+
 }  // namespace
 
 namespace uz {
@@ -769,8 +972,26 @@ int wgrad_split_splits(int Cin, int Cout, int N, int H, int W) {
     return s;
 }
 
+// UZ_WG_DB=1: the two-image form (wgrad_db_kernel) for the 64-channel tiles of the 32-wide geometry in the two-piece mode
+static bool wgrad_db_on() { static const int on = getenv("UZ_WG_DB") ? atoi(getenv("UZ_WG_DB")) : 0; return on != 0; }
+template <int XF, int DF>
+static int launch_wgrad_db(WS p, int grid, hipStream_t st) {
+    constexpr size_t smem = 2 * 2 * (size_t)(64 * (PTD * 2 + 16) + 64 * (4 * 80 + 16));
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_db_kernel<XF, DF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail("wgrad_split: cannot raise dynamic LDS limit");
+        attr_done = true;
+    }
+    p.tilesY = ceil_div(p.H, PTD / 32); p.T = p.N * p.tilesX * p.tilesY;         // 64-pixel tiles; the split count stays the first form's
+    hipLaunchKernelGGL((wgrad_db_kernel<XF, DF>), dim3(grid), dim3(NT), smem, st, p);
+    return check_launch("wgrad_db_kernel");
+}
 template <int TWv, int CT, int NP, int XPK = 0, int DPK = 0, int M16 = 0>
 static int launch_wgrad_np(const WS& p, int grid, hipStream_t st) {
+    if constexpr (!M16 && TWv == 32 && CT == 64 && NP == 2 && XPK == 1 && DPK == 1) {       // (fp32 operands: their conversion spills 40 - 50 registers in this form)
+        if (wgrad_db_on()) return launch_wgrad_db<XPK, DPK>(p, grid, st);
+    }
     if constexpr (!M16 && TWv == 32 && CT == 64 && NP == 2) {
         static const int m16 = getenv("UZ_WG_M16") ? atoi(getenv("UZ_WG_M16")) : 0;
         if (m16) return launch_wgrad_np<TWv, CT, NP, XPK, DPK, 1>(p, grid, st);
