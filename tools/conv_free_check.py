@@ -11,6 +11,7 @@ L = _ffi.lib(); dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream
 P = lambda t: None if t is None else t.data_ptr()
 ok = True
+GATE = 6e-6 if os.environ.get("UZ_CONV_MATH") == "split" else 2e-6     # split forced onto the tiny planes: the split kernels' own gate (tests/test_ops_gpu.py)
 for (Cin, Cout, N, H, W) in [(192, 192, 32, 4, 4), (256, 256, 32, 8, 8), (192, 192, 32, 2, 2), (100, 72, 7, 5, 6), (64, 2, 32, 8, 8), (576, 192, 8, 8, 8)]:
     g = torch.Generator(device="cpu").manual_seed(Cin + Cout)
     x = torch.randn(N, Cin + 3, H, W, generator=g).to(dev); w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(dev); b = torch.randn(Cout, generator=g).to(dev)
@@ -27,7 +28,7 @@ for (Cin, Cout, N, H, W) in [(192, 192, 32, 4, 4), (256, 256, 32, 8, 8), (192, 1
     torch.cuda.synchronize()
     e1 = float((y.double() - yr).abs().max() / yr.abs().max()); e2 = float((dx.double() - dx0.double() - dxr).abs().max() / dxr.abs().max())
     parts = (L.uz_conv_splitk_parts(Cin, Cout, N, H, W, 3), L.uz_conv_bwd_splitk_parts(Cin, Cout, N, H, W, 3))
-    good = e1 <= 2e-6 and e2 <= 2e-6
+    good = e1 <= GATE and e2 <= GATE
     ok &= good
     print(f"{Cin}->{Cout} @ {N}x{H}x{W} split parts fwd/bwd {parts}: fwd {e1:.2e} dgrad(accumulate) {e2:.2e} {'ok' if good else 'MISS'}")
 print("ALL OK" if ok else "FAILED"); sys.exit(0 if ok else 1)

@@ -12,6 +12,7 @@ P = lambda t: t.data_ptr()
 def slot(v):
     t = torch.zeros(256, device=dev); t[0] = v; return t
 ok = True
+GATE = 2e-6
 for (Cin, Cout, N, H, W) in [(64, 64, 4, 32, 32), (224, 128, 2, 64, 64), (100, 72, 3, 30, 32), (192, 192, 8, 16, 16), (96, 64, 2, 33, 64)]:
     g = torch.Generator(device="cpu").manual_seed(Cin * 7 + Cout)
     x = torch.randn(N, Cin, H, W, generator=g).clamp_min(0).to(dev); dy = torch.randn(N, Cout, H, W, generator=g).to(dev)
@@ -27,7 +28,7 @@ for (Cin, Cout, N, H, W) in [(64, 64, 4, 32, 32), (224, 128, 2, 64, 64), (100, 7
         _ffi.check(L.uz_conv_bwd_weight_ex(P(xp if pk else x), Cin, Cin, P(dyp if pk else dy), Cout, Cout, P(dw), None, N, H, W, 3, P(xa), P(dya), P(ws), wsb, pk, None, 0, pk, None, st), "wgrad")
         torch.cuda.synchronize()
         err = float((dw.double() - ref).abs().max() / ref.abs().max())
-        good = err <= 2e-6          # tensor-max-relative; the fp32 MFMA kernels measure 3e-7 .. 1e-6 on these shapes
+        good = err <= GATE          # tensor-max-relative; these kernels measure 2e-7 .. 4e-7 on these shapes
         ok &= good
         print(f"{Cin}->{Cout} @ {N}x{H}x{W} route {route} {'split storage' if pk else 'fp32 operands'}: max rel err {err:.2e} {'ok' if good else 'MISS'}")
 print("ALL OK" if ok else "FAILED"); sys.exit(0 if ok else 1)
