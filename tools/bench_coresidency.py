@@ -17,7 +17,7 @@ x = torch.randn(N, Ci, H, W, device=dev).relu_(); w = torch.randn(Co, Ci, 3, 3, 
 xa, wa = slot(float(x.abs().max())), slot(float(w.abs().max()))
 xp = torch.empty_like(x); _ffi.check(L.uz_pack_split(P(x), P(xp), x.numel(), P(xa), torch.cuda.current_stream().cuda_stream), "pack")
 wsb = L.uz_conv_workspace(Ci, Co, N, H, W, 3); ws = torch.empty(wsb // 4 + 64, device=dev)
-sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+sA, sB = torch.cuda.Stream(), torch.cuda.Stream(priority=int(os.environ.get("UZ_CHAIN_STREAM_PRIORITY", "0")))     # (-1 = high priority for the chain of small launches)
 def heavy(st, reps):
     for _ in range(reps):
         _ffi.check(L.uz_conv_fwd_ex(P(xp), Ci, Ci, P(w), None, P(y), Co, Co, N, H, W, 3, 0, P(xa), P(wa), None, P(ws), wsb, None, None, 1, None, 0, st.cuda_stream), "heavy")
