@@ -471,6 +471,31 @@ def test_bench_refuses_work_skipping_knobs_and_reports_what_the_binary_is():
     assert "diag_skip" not in syms and "uz_build_info" in syms
 
 
+def test_bench_cu_share_of_a_reduced_grid_weight_gradient():
+    """bench.py cu_share: the share of the chip a tape op's launch can occupy - 1 for everything except the split-path weight gradient, whose
+    grid is (channel tiles) x (slabs); with the PHiSeg target of 128 workgroups the heaviest layer's launch covers half the CUs (the family's
+    chip_ms_per_step / frac_on_occupied_cus in the bench line are built from it)."""
+    import importlib.util
+    from unet_zoo_amd import _ffi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("uz_bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    L = _ffi.lib()
+    if L.uz_get_conv_math() in (0, 3):
+        pytest.skip("split-path weight gradient only")
+    old = L.uz_get_wgrad_target()
+    try:
+        L.uz_set_wgrad_target(128)
+        wg = dict(code="UZ_OP_CONV_BWD_WEIGHT", i=[224, 224, 128, 128, 32, 128, 128, 3])
+        assert bench.cu_share(wg, L) == 0.5
+        L.uz_set_wgrad_target(256)
+        assert bench.cu_share(wg, L) == 1.0
+        assert bench.cu_share(dict(code="UZ_OP_CONV_FWD", i=[224, 224, 128, 128, 32, 128, 128, 3]), L) == 1.0
+        assert bench.cu_share(dict(code="UZ_OP_CONV_BWD_WEIGHT", i=[192, 192, 192, 192, 32, 4, 4, 3]), L) == 1.0       # fp32 kernels: full grid
+    finally:
+        L.uz_set_wgrad_target(old if old != 256 else 0)
+
+
 def _happens_before(plan, which, ops):
     sc, n = plan.scheds[which], len(ops)
     hb, last = [0] * n, {}
