@@ -13,6 +13,8 @@ zf = float(a[6]) if len(a) > 6 else 0.5
 L = _ffi.lib(); dev = torch.device("cuda", 0)
 x = torch.randn(N, Cin, H, W, device=dev); x = torch.where(torch.rand_like(x) < zf, torch.zeros_like(x), x.abs())
 dy = torch.randn(N, Cout, H, W, device=dev)
+if os.environ.get("UZ_BENCH_ZERO"):          # same instruction stream on all-zero operands: what is left when no bit toggles (clock / power check)
+    x.zero_(); dy.zero_(); x[0, 0, 0, 0] = 1.0; dy[0, 0, 0, 0] = 1.0
 w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
 y = torch.empty(N, Cout, H, W, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
 wsb = max(L.uz_conv_bwd_weight_workspace(Cin, Cout, N, H, W, 3), L.uz_conv_workspace(Cin, Cout, N, H, W, 3))
