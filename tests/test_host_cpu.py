@@ -119,6 +119,7 @@ def test_kernel_resource_table_matches_the_sources_and_the_budgets():
     # the optional forms of round 6 (off in the product, NOTES_r6 section 8): the two-image form must not spill, the LDS-free small-plane
     # convolution has to fit beside the headline convolution's two waves x 184 VGPRs per SIMD (one wave: <= 144 registers, no LDS)
     assert w["wgrad_db_kernel<1, 1>"]["vgpr"] <= 256 and w["wgrad_db_kernel<1, 1>"]["scratch"] == 0, w["wgrad_db_kernel<1, 1>"]
+    assert w["wgrad_half_kernel<1, 1>"]["vgpr"] <= 256 and w["wgrad_half_kernel<1, 1>"]["scratch"] == 0, w["wgrad_half_kernel<1, 1>"]      # two per CU
     cm = tab["conv_mfma.hip"]["kernels"]
     for n in ("conv_free_kernel<false>", "conv_free_kernel<true>"):
         assert cm[n]["vgpr"] <= 128 and cm[n]["scratch"] == 0 and not cm[n]["lds"], (n, cm[n])

@@ -1,5 +1,5 @@
 """The two optional weight-gradient forms of round 6 (conv_wgrad_split.hip: UZ_WG9=1 - four waves, nine taps per wave, two workgroups per CU;
-UZ_WG_M16=1 - the 16x16x32 MFMA shape).  Both are OFF in the product (measured slower, profiles/NOTES_r6.md 8) but stay in the library:
+UZ_WG_M16=1 - the 16x16x32 MFMA shape; UZ_WG_DB=1 - two LDS images; UZ_WG_HALF=1 - half workgroups, 64 x 32 tiles).  All are OFF in the product (measured slower, profiles/NOTES_r6.md 8) but stay in the library:
 this keeps them correct.  The switches are read once per process, so each form runs in a child process (tools/wgrad_forms_check.py)
 against an fp64 reference of autograd's weight gradient (reference: torchlayers.py:18, nn.Conv2d)."""
 import os, subprocess, sys
@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("env", [{"UZ_WG9": "1"}, {"UZ_WG_M16": "1"}, {"UZ_WG9": "0", "UZ_WG_M16": "0"}], ids=["nine_taps", "mfma16", "product"])
+@pytest.mark.parametrize("env", [{"UZ_WG9": "1"}, {"UZ_WG_M16": "1"}, {"UZ_WG_DB": "1"}, {"UZ_WG_HALF": "1"}, {"UZ_WG9": "0", "UZ_WG_M16": "0"}],
+                         ids=["nine_taps", "mfma16", "two_images", "half_workgroups", "product"])
 def test_optional_weight_gradient_forms_vs_fp64(env):
     e = dict(os.environ); e.update(env)
     if e.get("UZ_CONV_MATH", "") in ("f32", "0", "bf16", "3"):

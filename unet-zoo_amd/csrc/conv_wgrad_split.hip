@@ -876,6 +876,202 @@ __global__ __launch_bounds__(NT) void wgrad_db_kernel(const WS p) {
     else run(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Fourth form (round 6): HALF a workgroup of the first form.  256 threads = one wave per SIMD, a 64 x 32 (co x ci) tile of all nine taps
+// (waves = co half x tap group 5 + 4), the first form's 128-pixel tile, single LDS image (66.5 KB) and one-tile register prefetch.  Same
+// split count, twice the workgroups: two INDEPENDENT workgroups fit a CU (<= 256 VGPRs, 133 KB of LDS), so while one waits at its
+// barriers for a tile that was requested ~10 k cycles earlier on a 12 - 13 k-cycle round trip (what the first form's "staging phase"
+// consists of, NOTES_r6 section 8) the other one has the matrix pipe - and with one of them per CU the other half of EVERY CU stays free
+// for the other lanes' kernels (the first form keeps half the CUs whole).  Price: dY is fetched once per 32 input channels instead of
+// once per 64.  This is the form the last review asked for (256 threads, one wave per SIMD, 32 x 64 tile).
+// Measured (NOTES_r6 section 8): with PHiSeg's target of 128 its 256 workgroups spread over ALL CUs and an isolated launch is 25 - 31 % faster
+// (224 -> 128 @ 128 x 128: 1 218 -> 836 us); with two per CU (target 256) it equals the first form (the clock limit); the STEP is 0 - 1.5 % slower at every target
+// (64 ... 256) - what one lane's launch gains by taking the whole chip the other lanes' launches lose.  OFF.
+constexpr int NTH = 256;
+template <int XF, int DF>
+__global__ __launch_bounds__(NTH, 2) void wgrad_half_kernel(const WS p) {
+    constexpr bool XPK = XF == 1, DPK = DF == 1;
+    constexpr int NP = 2;
+    using GEO = WGeo<32>;
+    constexpr int TW = GEO::TW, XROW = GEO::XROW, QROWX = GEO::QROWX, PROWS = GEO::PROWS;
+    constexpr int SROW = TW / 16;
+    constexpr int COT = 64, CIT = 32;
+    constexpr int DYPLANE = COT * DYROW, XPLANE = CIT * XCH;
+    constexpr int DQ = PT / 4, DQROW = TW / 4, XQ = TW / 4;
+    constexpr int DYSLOTS = COT * DQ / NTH;                       // 8
+    constexpr int XQSLOTS = CIT * PROWS * XQ / NTH;               // 6
+    static_assert(COT * DQ % NTH == 0 && CIT * PROWS * XQ % NTH == 0 && CIT * PROWS <= NTH, "staging slots");
+    constexpr int NPARTS = PT / 16;                               // 8 k-steps per tile
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* dYl = lds;
+    char* Xl = lds + NP * DYPLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = (wave ^ (int)blockIdx.x) & 1;                  // two workgroups share a SIMD: neighbours take opposite tap groups
+    const int wm = wave >> 1;
+    const int wid = uz::xcd_remap(blockIdx.x, gridDim.x);
+    const int nTile = p.nCoT * p.nCiT;
+    const int split = wid / nTile, tl = wid - split * nTile;
+    const int co0 = (tl / p.nCiT) * COT, ci0 = (tl % p.nCiT) * CIT;
+
+    for (int i = tid * 16; i < NP * DYPLANE + NP * XPLANE; i += NTH * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0u, 0u, 0u, 0u};
+
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dy), 0, (unsigned)(((size_t)(p.N - 1) * p.CoutTot + p.Cout) * p.HW * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)(((size_t)(p.N - 1) * p.CinTot + p.Cin) * p.HW * 4u), 0x00020000);
+
+    f32x4 dreg[DYSLOTS];
+    f32x4 xq[XQSLOTS];
+    float xp[2];
+    auto gload = [&](int t, int part) __attribute__((always_inline)) {
+        const int txi = t % p.tilesX, t2 = t / p.tilesX;
+        const int x0 = txi * TW, y0 = (t2 % p.tilesY) * (PT / TW), b0 = t2 / p.tilesY;
+        const unsigned dbase = 4u * (unsigned)((b0 * p.CoutTot + co0) * p.HW + y0 * p.W + x0);
+#pragma unroll
+        for (int i = 0; i < DYSLOTS; ++i) {
+            if (part >= 0 && i % NPARTS != part) continue;
+            const int e = tid + i * NTH, co = e / DQ, q = e % DQ, row = q / DQROW, c4 = (q % DQROW) * 4;
+            const unsigned m = ((y0 + row) < p.H && (co0 + co) < p.Cout) ? 0u : 0xFFFFFFFFu;
+            dreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (dbase + 4u * (unsigned)(co * p.HW + row * p.W + c4)) | m, 0, 0));
+        }
+        const int xbase = (b0 * p.CinTot + ci0) * p.HW + y0 * p.W + x0;
+#pragma unroll
+        for (int i = 0; i < XQSLOTS; ++i) {
+            if (part >= 0 && (i + DYSLOTS) % NPARTS != part) continue;
+            const int e = tid + i * NTH;
+            const int q = e % XQ, r = e / XQ, ci = r / PROWS, prow = r - ci * PROWS;
+            const int yy = y0 + prow - 1;
+            const bool rowok = (ci0 + ci) < p.Cin && yy >= 0 && yy < p.H;
+            const int sh = (q == 0 && x0 == 0) ? 1 : 0;
+            const int off = xbase + ci * p.HW + (prow - 1) * p.W + 4 * q - 1 + sh;
+            xq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxx, rowok ? 4u * (unsigned)off : 0xFFFFFFFFu, 0, 0));
+        }
+        if (part < 0 || (DYSLOTS + XQSLOTS) % NPARTS == part) {
+            const int ci = tid / PROWS, prow = tid - ci * PROWS;
+            const int yy = y0 + prow - 1;
+            const bool rowok = tid < CIT * PROWS && (ci0 + ci) < p.Cin && yy >= 0 && yy < p.H;
+            const int off = xbase + ci * p.HW + (prow - 1) * p.W + TW - 1;
+            xp[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, rowok ? 4u * (unsigned)off : 0xFFFFFFFFu, 0, 0));
+            xp[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (rowok && x0 + TW < p.W) ? 4u * (unsigned)(off + 1) : 0xFFFFFFFFu, 0, 0));
+        }
+    };
+    const float sdy = uz::split_scale(uz::amax_read(p.dy_amax)), sx = uz::split_scale(uz::amax_read(p.x_amax));
+    bool xbad = false, dbad = false;
+    auto xpieces = [&](float v0, float v1, unsigned (&out)[NP]) __attribute__((always_inline)) {
+        if constexpr (XPK) uz::packed_pair(__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), out[0], out[1]);
+        else { xbad |= uz::bound_violated(v0 * sx, v1 * sx); pieces<NP>(v0 * sx, v1 * sx, out); }
+    };
+    auto dpieces = [&](float v0, float v1, unsigned (&out)[NP]) __attribute__((always_inline)) {
+        if constexpr (DPK) uz::packed_pair(__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), out[0], out[1]);
+        else { dbad |= uz::bound_violated(v0 * sdy, v1 * sdy); pieces<NP>(v0 * sdy, v1 * sdy, out); }
+    };
+    auto lstore = [&](int t) __attribute__((always_inline)) {
+        const bool left_edge = t % p.tilesX == 0;
+#pragma unroll
+        for (int i = 0; i < DYSLOTS; ++i) {
+            const int e = tid + i * NTH, co = e / DQ, q = e % DQ;
+            char* d = dYl + co * DYROW + ((q / DQROW) * TW + (q % DQROW) * 4) * 2;
+            unsigned pa[NP], pb[NP];
+            dpieces(dreg[i][0], dreg[i][1], pa);
+            dpieces(dreg[i][2], dreg[i][3], pb);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * DYPLANE) = make_uint2(pa[pl], pb[pl]);
+        }
+#pragma unroll
+        for (int i = 0; i < XQSLOTS; ++i) {
+            const int e = tid + i * NTH;
+            const int q = e % XQ, r = e / XQ, ci = r / PROWS, prow = r - ci * PROWS;
+            char* d = Xl + ci * XCH + prow * XROW + q * 8;
+            unsigned pa[NP], pb[NP];
+            const f32x4 v = (left_edge && q == 0) ? f32x4{0.f, xq[i][0], xq[i][1], xq[i][2]} : xq[i];
+            xpieces(v[0], v[1], pa);
+            xpieces(v[2], v[3], pb);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * XPLANE) = make_uint2(pa[pl], pb[pl]);
+        }
+        if (tid < CIT * PROWS) {
+            const int ci = tid / PROWS, prow = tid - ci * PROWS;
+            unsigned pa[NP];
+            xpieces(xp[0], xp[1], pa);
+            char* d = Xl + ci * XCH + prow * XROW + QROWX * 8;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<unsigned*>(d + pl * XPLANE) = pa[pl];
+        }
+    };
+
+    const char* Ab = dYl + (wm * 32 + l31) * DYROW + h * 16;
+    const char* Bb = Xl + l31 * XCH + h * 16;
+
+    auto run = [&](auto ntap_c, auto tap0_c) __attribute__((always_inline)) {
+        constexpr int NTAP = decltype(ntap_c)::value, TAP0 = decltype(tap0_c)::value;
+        constexpr int DY0 = TAP0 / 3;
+        f32x16 acc[NTAP];
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+        int t = split;
+        if (t < p.T) gload(t, -1);
+        for (; t < p.T; t += p.S) {
+            __syncthreads();
+            lstore(t);
+            __syncthreads();
+#pragma unroll
+            for (int si = 0; si < NPARTS; ++si) {
+                gload(t + p.S, si);                  // unconditional: behind the last tile the image index is >= N and every offset fails the range check
+                const int srow = si / SROW, scol = (si % SROW) * 16;
+                u32x4 a[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const u32x4*>(Ab + q * DYPLANE + (srow * TW + scol) * 2);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    u32x4 v[NP];
+                    unsigned v4[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const char* src = Bb + q * XPLANE + (srow + DY0 + d) * XROW + scol * 2;
+                        v[q] = *reinterpret_cast<const u32x4*>(src);
+                        v4[q] = *reinterpret_cast<const unsigned*>(src + 16);
+                    }
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int tap = (DY0 + d) * 3 + dx, k = tap - TAP0;
+                        if (k >= 0 && k < NTAP) {
+                            u32x4 b[NP];
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) {
+                                if (dx == 0) b[q] = v[q];
+                                else if (dx == 2) b[q] = u32x4{v[q].y, v[q].z, v[q].w, v4[q]};
+                                else b[q] = u32x4{__builtin_amdgcn_alignbit(v[q].y, v[q].x, 16), __builtin_amdgcn_alignbit(v[q].z, v[q].y, 16),
+                                                  __builtin_amdgcn_alignbit(v[q].w, v[q].z, 16), __builtin_amdgcn_alignbit(v4[q], v[q].w, 16)};
+                            }
+                            const int kc = k < 0 ? 0 : (k >= NTAP ? NTAP - 1 : k);
+                            acc[kc] = mma<NP>(acc[kc], a, b);
+                        }
+                    }
+                }
+            }
+        }
+        uz::raise_flag(p.flags, xbad, uz::FLAG_X_BOUND); uz::raise_flag(p.flags, dbad, uz::FLAG_DY_BOUND);
+        float* out = p.slab + (size_t)split * 9 * p.Cout * p.Cin;
+        const int ci = ci0 + l31;
+        const float inv_dy = uz::split_inv_scale(uz::amax_read(p.dy_amax));
+        const float inv_x = uz::split_inv_scale(uz::amax_read((XPK && p.x_amax2 && ci >= p.seg_channels) ? p.x_amax2 : p.x_amax));
+#pragma unroll
+        for (int k = 0; k < NTAP; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < p.Cout && ci < p.Cin) out[((size_t)(TAP0 + k) * p.Cout + co) * p.Cin + ci] = acc[k][r] * inv_dy * inv_x;
+            }
+    };
+    if (tg == 0) run(std::integral_constant<int, 5>{}, std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
+}
+
 }  // namespace
 
 namespace uz {
@@ -987,8 +1183,26 @@ static int launch_wgrad_db(WS p, int grid, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_db_kernel<XF, DF>), dim3(grid), dim3(NT), smem, st, p);
     return check_launch("wgrad_db_kernel");
 }
+// UZ_WG_HALF=1: the half-workgroup form (wgrad_half_kernel) for the 64-channel tiles of the 32-wide geometry in the two-piece mode
+static bool wgrad_half_on() { static const int on = getenv("UZ_WG_HALF") ? atoi(getenv("UZ_WG_HALF")) : 0; return on != 0; }
+template <int XF, int DF>
+static int launch_wgrad_half(WS p, hipStream_t st) {
+    constexpr size_t smem = 2 * (size_t)(64 * DYROW) + 2 * (size_t)(32 * XCH);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_half_kernel<XF, DF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return fail("wgrad_split: cannot raise dynamic LDS limit");
+        attr_done = true;
+    }
+    p.nCiT = ceil_div(p.Cin, 32);                                     // 64 x 32 tiles; the split count stays the first form's
+    hipLaunchKernelGGL((wgrad_half_kernel<XF, DF>), dim3(p.nCoT * p.nCiT * p.S), dim3(NTH), smem, st, p);
+    return check_launch("wgrad_half_kernel");
+}
 template <int TWv, int CT, int NP, int XPK = 0, int DPK = 0, int M16 = 0>
 static int launch_wgrad_np(const WS& p, int grid, hipStream_t st) {
+    if constexpr (!M16 && TWv == 32 && CT == 64 && NP == 2 && XPK == 1 && DPK == 1) {
+        if (wgrad_half_on()) return launch_wgrad_half<XPK, DPK>(p, st);
+    }
     if constexpr (!M16 && TWv == 32 && CT == 64 && NP == 2 && XPK == 1 && DPK == 1) {       // (fp32 operands: their conversion spills 40 - 50 registers in this form)
         if (wgrad_db_on()) return launch_wgrad_db<XPK, DPK>(p, grid, st);
     }
