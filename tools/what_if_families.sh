@@ -6,4 +6,6 @@ run() { echo "$1 : $(UZ_DIAG_SKIP="$1" python bench.py --allow-experiment --step
 run "none:0"
 for f in wgrad:128 dgrad:128 fwd:128 bnf:128 bnb:128 bn:128 resample:128 conv:128; do run "$f"; done
 for l in 128 64 32 16; do run "only:$l,conv:$l"; run "only:$l,conv:$l,bn:$l,resample:$l"; done
+# the deep levels (NOTES_r6 section 5)
+for f in wgrad:8 wgrad:16 "bnf:16,fwd:16" "bnb:16,dgrad:16,wgrad:16" "bn:16,conv:16,resample:8" "bn:8,conv:8,resample:4"; do run "$f"; done
 run "none:0"

@@ -98,9 +98,15 @@ extern "C" int uz_build_info(char* out, int cap) {
 // UZ_DIAG_SKIP="conv:8,bn:8,resample:4,convmin:64" drops every convolution / BatchNorm / resampling
 // op on planes up to (convmin: from) that height from a tape - the results are garbage, the step time shows what those ops cost
 // on the critical path (an upper bound for any optimisation of them).
+// The first UZ_DIAG_WARM tape replays (default 8 = four steps) run everything: the skipped ops' outputs then hold the values of a real step
+// (bench.py feeds the same batch every step), so what runs downstream sees realistic operands.  Without it their buffers stay all-zero and the
+// clock-limited kernels downstream run 14 - 20 % faster on zeros (NOTES_r6 section 8) - the first what-if tables of round 6 carried that bias.
+static int g_diag_tapes = 0;
 static bool diag_skip(const uz_op& o) {
     static const char* env = getenv("UZ_DIAG_SKIP");
     if (!env) return false;
+    static const int warm = getenv("UZ_DIAG_WARM") ? atoi(getenv("UZ_DIAG_WARM")) : 8;
+    if (g_diag_tapes <= warm) return false;
     static int conv = -1, bn = -1, rs = -1, convmin = 1 << 30, init = 0, fwd = -1, dgrad = -1, wgrad = -1, bnf = -1, bnb = -1, only = 0;
     if (!init) {
         init = 1;
@@ -439,6 +445,9 @@ int lane_pool_reserve(int n_lanes, int n_events) {
 }
 }  // namespace
 extern "C" int uz_run_tape_lanes(const uz_op* ops, const uz_sched* sched, int n_ops, int n_lanes, void* stream) {
+#ifdef UZ_DIAG
+    if (n_ops > 16) ++g_diag_tapes;
+#endif
     UZ_REQUIRE(n_lanes >= 1 && n_lanes <= UZ_MAX_LANES, "run_tape_lanes: n_lanes %d outside [1,%d]", n_lanes, UZ_MAX_LANES);
     int n_sig = 0;
     for (int k = 0; k < n_ops; ++k) {
