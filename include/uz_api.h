@@ -233,6 +233,13 @@ int uz_bn_relu_bwd_ex(const float* da, int CtotDa, const float* y, int C, int Ct
                       int N, int H, int W, int relu, float* dy_amax, void* workspace,
                       const float* conv_partials, int n_partials, int out_packed, double* dbias_partials,
                       const float* da_slabs, int n_da_slabs, void* stream);   /* da_slabs: dA = the sum of these [n][N][C][H*W] slabs (small planes, uz_conv_bwd_data_slabs); da is then not read */
+/* uz_bn_relu_fwd_ex as two calls (large planes, training, statistics from the convolution's partials): phase 1 = statistics only (table of 4 C floats,
+ * running buffers, the activation's bound; y / a untouched and nullable), phase 2 = the apply pass alone from what phase 1 left.  A following
+ * uz_conv_fwd_bn_ex depends on phase 1 only: the apply pass then runs beside that convolution instead of in front of it. */
+int uz_bn_relu_fwd_phase(const float* y, int C, int CtotY, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float* save_mean_rstd_ab,
+                         float* a, int CtotA, int N, int H, int W, float eps, float momentum,
+                         int relu, float* a_amax, const float* conv_partials, int n_partials, int out_packed, int phase, void* stream);
 int uz_bn_fwd_fused_limit(int H, int W);         /* N*H*W up to which the training-mode uz_bn_relu_fwd(_ex) WITHOUT conv_partials is one launch (statistics + apply from registers) */
 int uz_bn_bwd_fused_limit(int H, int W);         /* N*H*W up to which uz_bn_relu_bwd(_ex) is one launch with the channel's batch on chip: no out_packed / dbias_partials there */
 int uz_bn_bwd_dbias_rows(int N, int H, int W);   /* rows of dbias_partials ([rows][C] doubles, summed by uz_chan_sum_table); 0: small-plane path */
@@ -245,6 +252,14 @@ int uz_conv_fwd_ex(const float* x, int Cin, int CinTot, const float* w, const fl
                    const float* x_amax, const float* w_amax, float* y_amax,
                    void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials,
                    int x_packed, const float* x_amax2, int seg_channels, void* stream);
+/* uz_conv_fwd_ex for a layer that follows a Conv -> BatchNorm -> ReLU unit (reference torchlayers.py:18-21) and reads that unit's
+ * PRE-normalisation output y_prev with its statistics table bn_save ([4][Cin]: mean, rstd, alpha, beta' - uz_bn_relu_fwd_ex): the staging
+ * applies a = max(alpha y_prev + beta', 0) (bn_relu) itself and splits with the scale of a_amax, the bound of the APPLIED activation.
+ * Same values as reading the unit's stored activation; the unit's apply pass leaves the chain of dependent launches.  Split path only. */
+int uz_conv_fwd_bn_ex(const float* y_prev, int Cin, int CinTot, const float* bn_save, int bn_relu,
+                      const float* w, const float* bias, float* y, int Cout, int CoutTot, int N, int H, int W, int ks,
+                      const float* a_amax, const float* w_amax, float* y_amax,
+                      void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials, void* stream);
 int uz_conv_bwd_data_ex(const float* dy, int Cout, int CoutTot, const float* w, float* dx, int Cin, int CinTot,
                         int N, int H, int W, int ks, int accumulate, const float* dy_amax, const float* w_amax,
                         void* workspace, size_t workspace_bytes, const void* packed_w, int dy_packed,

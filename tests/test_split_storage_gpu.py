@@ -360,3 +360,79 @@ def test_data_gradient_slabs_folded_into_small_plane_batchnorm_backward(N, Cin, 
     dg1, db1, dbias1 = (torch.full((Cin,), float("nan"), device=d) for _ in range(3))
     g.call("uz_bn_relu_bwd_ex", None, Cin, y1, Cin, Cin, gamma, beta, save, dy1, Cin, dg1, db1, dbias1, N, H, W, 1, None, bws, None, 0, 0, None, slabs, parts)
     assert torch.equal(dy0, dy1) and torch.equal(dg0, dg1) and torch.equal(db0, db1) and torch.equal(dbias0, dbias1)
+
+
+@pytest.mark.parametrize("N,C1,C2,H,W", UNIT_CASES + [(3, 72, 64, 40, 64), (20, 64, 32, 16, 16)])
+def test_forward_convolution_applies_the_producers_batchnorm_while_staging(N, C1, C2, H, W):
+    """uz_conv_fwd_bn_ex (round 6): conv2 reads conv1's PRE-normalisation output y1 and the unit's statistics table and applies BatchNorm + ReLU in its
+    staging.  Same values as conv2 over the activation the unit's apply pass stores in split storage (uz_bn_relu_fwd_ex, out_packed) - the operand
+    pieces are formed from the same fp32 expression with the same scale - so the outputs agree to the last bit or two, and with torch within
+    the split path's gate.  Covers ragged channel counts (K tail), a partial last tile row and the 16 x 16-pixel geometry."""
+    _need_split()
+    g, L = _g(), _lib()
+    C0 = 40
+    if L.uz_conv_route(0, C1, C2, N, H, W, 3) != 1 or L.uz_conv_bn_partials(C0, C1, N, H, W, 3) <= 0 or N * H * W <= 4096:
+        pytest.skip("shape off the split path in this math mode (or a small plane: split storage starts above 4 096 values per channel)")
+    x = g.rnd(N, C0, H, W, seed=1)
+    w1, b1 = g.rnd(C1, C0, 3, 3, seed=2, scale=0.1), g.rnd(C1, seed=3)
+    w2, b2 = g.rnd(C2, C1, 3, 3, seed=4, scale=0.1), g.rnd(C2, seed=5)
+    gamma, beta = g.rnd(C1, seed=6).abs() + 0.5, g.rnd(C1, seed=7) * 0.3
+    y1r = F.conv2d(x, w1, b1, padding=1)
+    a1r = F.relu(F.batch_norm(y1r, None, None, gamma, beta, training=True, eps=1e-3))
+    y2r = F.conv2d(a1r, w2, b2, padding=1)
+    d = g.dev()
+    xd, w1d, b1d, w2d, b2d, gd, bd = (t.to(d) for t in (x, w1, b1, w2, b2, gamma, beta))
+    npart = L.uz_conv_bn_partials(C0, C1, N, H, W, 3)
+    wsb = max(L.uz_conv_workspace(C0, C1, N, H, W, 3), L.uz_conv_workspace(C1, C2, N, H, W, 3))
+    ws = torch.empty(wsb // 4 + 64, device=d)
+    bws = torch.empty(L.uz_bn_workspace(C1, N, H, W) // 4 + 16, device=d)
+    y1 = torch.empty(N, C1, H, W, device=d)
+    part = torch.empty(npart * C1 * 4, device=d)
+    g.call("uz_conv_fwd_bnstats", xd, C0, C0, w1d, b1d, y1, C1, C1, N, H, W, 3, 0, None, None, None, ws, wsb, None, part)
+    a1 = torch.full((N, C1, H, W), float("nan"), device=d)
+    save = torch.full((4 * C1,), float("nan"), device=d)
+    slot = _slot()
+    g.call("uz_bn_relu_fwd_ex", y1, C1, C1, gd, bd, None, None, save, a1, C1, N, H, W, 1e-3, 0.01, 1, 1, slot, bws, part, npart, 1)
+    y2_stored = torch.empty(N, C2, H, W, device=d)
+    g.call("uz_conv_fwd_ex", a1, C1, C1, w2d, b2d, y2_stored, C2, C2, N, H, W, 3, 0, slot, None, None, ws, wsb, None, None, 1, None, 0)
+    y2_fused = torch.full((N, C2, H, W), float("nan"), device=d)
+    g.call("uz_conv_fwd_bn_ex", y1, C1, C1, save, 1, w2d, b2d, y2_fused, C2, C2, N, H, W, 3, slot, None, None, ws, wsb, None, None)
+    assert g.relerr(y2_fused, y2r) <= 3e-5
+    assert g.maxabs(y2_fused.cpu(), y2_stored.cpu()) <= 2e-6 * float(y2r.abs().max())
+    # without the ReLU (a bare BatchNorm in front): negative activations survive
+    a1n = F.batch_norm(y1r, None, None, gamma, beta, training=True, eps=1e-3)
+    slot_n = _slot(float(a1n.abs().max()))
+    g.call("uz_conv_fwd_bn_ex", y1, C1, C1, save, 0, w2d, b2d, y2_fused, C2, C2, N, H, W, 3, slot_n, None, None, ws, wsb, None, None)
+    assert g.relerr(y2_fused, F.conv2d(a1n, w2, b2, padding=1)) <= 3e-5
+
+
+def test_phiseg_step_with_batchnorm_apply_off_the_chain(monkeypatch):
+    """Plan._bn_offchain_pass (UZ_BN_OFFCHAIN=1, off by default - measured 1 % slower, profiles/NOTES_r6.md section 10): eight units of the headline plan run
+    their BatchNorm as a statistics launch + an apply pass of its own group, and the one convolution that reads each activation applies the
+    normalisation while staging (uz_conv_fwd_bn_ex).  The operand pieces are the ones the apply pass stores, so the step must agree with the default
+    plan far inside the gates between two fp32 implementations: loss to 1e-6, logits to 5e-5, the flat gradient to 1e-3 in l2; and against the real
+    reference's digest with the default gates."""
+    _need_split()
+    from tests import test_phiseg_gpu as P
+    from tests import _golden as G
+    monkeypatch.setenv("UZ_BN_OFFCHAIN", "1")
+    P.test_phiseg_full_size_digest_vs_reference_golden("phiseg_full_b32_digest")
+    arrays, meta = G.load("phiseg_full_b32_digest")
+    x, mask, eps = P._inputs(meta, 0)
+    runs = {}
+    for name, flag in (("off_chain", "1"), ("default", "0")):
+        monkeypatch.setenv("UZ_BN_OFFCHAIN", flag)
+        net, _ = P._model(meta)
+        net.train()
+        s = net.forward(x, mask, training=True, eps=eps)
+        loss = net.loss(mask)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert net._cur.bn_offchain["units"] == (8 if flag == "1" else 0)
+        runs[name] = (float(loss.detach()), [t.clone() for t in s], net._ptab.gflat.clone())
+    g = _g()
+    assert abs(runs["off_chain"][0] - runs["default"][0]) <= 1e-6 * abs(runs["default"][0])
+    for a, b in zip(runs["off_chain"][1], runs["default"][1]):
+        assert g.maxabs(a, b) <= 5e-5
+    ga, gb = runs["off_chain"][2].double(), runs["default"][2].double()
+    assert float((ga - gb).norm() / gb.norm()) <= 1e-3

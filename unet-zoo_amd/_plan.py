@@ -1269,6 +1269,55 @@ class Plan:
                 info["act_views"] += len(wr_list)
         return info
 
+    def _bn_offchain_pass(self):
+        """Takes BatchNorm's apply pass out of the forward's dependency chain (round 6; UZ_BN_OFFCHAIN=1, off by default).  For a Conv -> BatchNorm -> ReLU
+        unit on the large planes whose activation is kept in split storage and read, in the forward tape, by exactly ONE 3 x 3 split-path
+        convolution (the middle layers of every three-convolution block; the weight gradient of that convolution reads it too, in the
+        backward tape): the unit's BatchNorm op becomes two - the statistics launch, which stays in the unit's group, and the apply pass, a
+        group of its own - and the consumer reads the unit's PRE-normalisation output with its statistics table and applies BatchNorm +
+        ReLU in its staging (uz_conv_fwd_bn_ex: the same operand pieces the apply pass stores).  The consumer then depends on the
+        statistics launch only; the apply pass still writes the activation for the weight gradient, beside the chain instead of in it."""
+        info = dict(units=0)
+        self.bn_offchain = info
+        if os.environ.get("UZ_BN_OFFCHAIN", "0") != "1" or self.L.uz_get_conv_math() in (0, 3) or not self.bn_training or self.extra_ops:
+            return info
+        ops = self.fwd_ops
+        for u in [u for u in self.__dict__.get("_units", []) if "bn_fwd" in u]:
+            B = u["bn_fwd"]
+            i = B["i"]
+            if not (len(i) > 10 and i[10] == 1 and i[8] > 0 and i[9] == 0 and i[6] == 1) or (len(i) > 11 and i[11]) or (len(i) > 13 and i[13]):
+                continue                                             # large path, statistics from the convolution's partials, split-storage output
+            if i[3] * i[4] * i[5] <= self.L.uz_bn_fwd_fused_limit(i[4], i[5]) or not any(o is B for o in ops):
+                continue
+            y, a = B["p"][0], B["p"][6]
+            if not (isinstance(a, View) and isinstance(y, View)) or a.nb is not None or y.nb is not None or not a.contiguous:
+                continue
+            readers = [(o, j) for o in ops for j, r in enumerate(o["p"]) if o is not B and isinstance(r, View) and r.buf is a.buf]
+            if len(readers) != 1 or any(isinstance(r, View) and r.buf is a.buf for o in self.loss_ops for r in o["p"]):
+                continue
+            R, j = readers[0]
+            ri, rv = R["i"], R["p"][0]
+            if R["code"] != "UZ_OP_CONV_FWD" or j != 0 or ri[7] != 3 or ri[8] or not (len(ri) > 10 and ri[10] == 1) or (len(ri) > 11 and ri[11]) or \
+                    (len(ri) > 9 and ri[9]) or (len(ri) > 12 and ri[12]) or (len(ri) > 13 and ri[13]) or (rv.c0, rv.C, rv.nb) != (0, a.buf.C, None):
+                continue
+            k = next(n for n, o in enumerate(ops) if o is B)
+            fin = dict(B, p=list(B["p"]), i=(list(i) + [0, 0])[:12], f=list(B["f"]))
+            fin["p"][0] = fin["p"][6] = None
+            fin["i"][11] = 1
+            self._detached = getattr(self, "_detached", 0) + 1
+            app = dict(B, p=list(B["p"]), i=(list(i) + [0, 0])[:12], f=list(B["f"]), gid=("bnapply", self._detached))
+            app["p"][3] = app["p"][4] = app["p"][9] = None
+            app["p"][8] = tuple(app["p"][8][:2])                       # reads the bound the statistics launch published
+            app["i"][11] = 2
+            ops[k:k + 1] = [fin, app]
+            u["bn_fwd"] = fin
+            R["p"] = (list(R["p"]) + [None] * 12)[:12]
+            R["p"][0], R["p"][10], R["p"][11] = y, None, B["p"][5]
+            R["i"] = (list(ri) + [0] * 13)[:13]
+            R["i"][1], R["i"][10], R["i"][12] = y.Ctot, 0, 1 | (int(i[7]) << 1)
+            info["units"] += 1
+        return info
+
     # ------------------------------------------------------------------ bf16 storage (BASELINE config 5: PHiSeg3D "bf16")
     # tensor operand slots of the ops that have a bf16-storage form (include/uz_api.h, "bf16 storage"), in the order of the bits of i[13]
     _B16_SLOTS = {
@@ -1885,6 +1934,7 @@ class Plan:
                 self._emit(self.bwd_ops, "UZ_OP_EVENT_RECORD", p=[("event", b), ("gflat_range", lo, hi)])
         self._bwd = []
         self._round4_passes()
+        self._bn_offchain_pass()
         self._b16_pass()
         self._chain_pass()
         # magnitude-bound slots: zero the forward-side slots and measure the parameter bound at the head of the forward tape,
@@ -2097,6 +2147,8 @@ class Plan:
         gradient view p[2] is NOT written - the consumer's BatchNorm backward reads the slabs instead)."""
         if o["code"] == "UZ_OP_CONV_BWD_DATA" and len(o["i"]) > 10 and o["i"][10] == 3:
             return (7,)
+        if o["code"] == "UZ_OP_BN_RELU_FWD" and len(o["i"]) > 11 and o["i"][11]:
+            return (3, 4, 5) if o["i"][11] == 1 else (6,)          # phase 1: statistics table + running buffers; phase 2: the activation only
         return self._WRITES[o["code"]]
 
     def _access(self, o):
@@ -2195,6 +2247,8 @@ class Plan:
                 rate = min(rate, 20e12)
             return flop / rate + 4e-6
         if c == "UZ_OP_BN_RELU_FWD":
+            if len(i) > 11 and i[11] == 1:
+                return 6e-6                                          # statistics from the convolution's partials: one small launch
             return i[0] * i[3] * i[4] * i[5] * 12.0 / 4e12 + 10e-6
         if c in ("UZ_OP_BN_RELU_BWD", "UZ_OP_RELU_BWD"):
             return i[1] * i[4] * i[5] * i[6] * 20.0 / 4e12 + 14e-6

@@ -1094,11 +1094,11 @@ static int bn_relu_fwd_impl(const float* y, int C, int CtotY, const float* gamma
                             float* a, int CtotA, int N, int H, int W, float eps, float momentum,
                             int training, int relu, float* a_amax, void* workspace,
                             const float* conv_partials, int n_partials, const float* slabs, int n_slabs, const float* conv_bias, void* stream,
-                            int save4 = 0, int out_packed = 0) {
+                            int save4 = 0, int out_packed = 0, int phase = 0) {
     UZ_REQUIRE(C > 0 && N > 0 && H > 0 && W > 0, "bn_relu_fwd: empty tensor");
     const bool mid = training && !conv_partials && !slabs && (size_t)N * H * W > SMALL_LIMIT && (size_t)N * H * W <= (size_t)uz_bn_fwd_fused_limit(H, W) &&
                      vec_ok(H * W, y, a, nullptr);
-    UZ_REQUIRE(!out_packed || (training && (conv_partials || mid) && a_amax && (size_t)N * H * W > SMALL_LIMIT),
+    UZ_REQUIRE(!out_packed || (training && (conv_partials || mid || phase == 2) && a_amax && (size_t)N * H * W > SMALL_LIMIT),
                "bn_relu_fwd_ex: split storage needs the output's bound before the apply pass - training mode, a bound slot, and statistics from the convolution's partials (or the one-launch mid path)");
     UZ_REQUIRE(!conv_partials || (training && n_partials > 0 && (size_t)N * H * W > SMALL_LIMIT), "bn_relu_fwd: convolution partials only serve the training-mode large-plane path");
     UZ_REQUIRE(N <= 65535 && C <= 65535, "bn_relu_fwd: N or C exceeds grid limits");
@@ -1137,10 +1137,14 @@ static int bn_relu_fwd_impl(const float* y, int C, int CtotY, const float* gamma
     const dim3 grid(p.parts, C, N);
     reduction_groups(p);
     const dim3 rgrid(p.parts, C, p.ngrp);
-    if (training && conv_partials) {
+    // phase (uz_bn_relu_fwd_phase): 1 = the statistics launch only (table + bound; y and a are not touched), 2 = the apply pass only (the table holds
+    // this step's statistics already), 0 = both
+    if (phase == 2) p.pre = 1;
+    else if (training && conv_partials) {
         p.pre = 1; p.cpart = conv_partials; p.ncpart = n_partials;
         hipLaunchKernelGGL(bn_finalize_conv_partials, dim3(C), dim3(256), 0, st, p);
         if (int rc = uz::check_launch("bn_finalize_conv_partials")) return rc;
+        if (phase == 1) return 0;
     } else if (training) {
         UZ_REQUIRE(workspace, "bn_relu_fwd: workspace required");
         carve(p, workspace);
@@ -1174,6 +1178,21 @@ extern "C" int uz_bn_relu_fwd_ex(const float* y, int C, int CtotY, const float* 
                                  const float* conv_partials, int n_partials, int out_packed, void* stream) {
     return bn_relu_fwd_impl(y, C, CtotY, gamma, beta, running_mean, running_var, save_mean_rstd_ab, a, CtotA, N, H, W, eps, momentum,
                             training, relu, a_amax, workspace, conv_partials, n_partials, nullptr, 0, nullptr, stream, 1, out_packed);
+}
+// uz_bn_relu_fwd_ex in two launches' worth of calls (large planes, training mode, statistics from the convolution's partials, 4 C statistics table):
+// phase 1 = finalise the statistics (table, running buffers, the activation's bound) - neither y nor a is touched (may be null);
+// phase 2 = the apply pass alone, from the table and the bound phase 1 left (conv_partials unused).  A following convolution that applies
+// the normalisation itself (uz_conv_fwd_bn_ex) depends on phase 1 only.
+extern "C" int uz_bn_relu_fwd_phase(const float* y, int C, int CtotY, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float* save_mean_rstd_ab,
+                                    float* a, int CtotA, int N, int H, int W, float eps, float momentum,
+                                    int relu, float* a_amax, const float* conv_partials, int n_partials, int out_packed, int phase, void* stream) {
+    UZ_REQUIRE(phase == 1 || phase == 2, "bn_relu_fwd_phase: phase 1 (statistics) or 2 (apply)");
+    UZ_REQUIRE((size_t)N * H * W > (size_t)uz_bn_fwd_fused_limit(H, W), "bn_relu_fwd_phase: large planes only (beyond uz_bn_fwd_fused_limit)");
+    UZ_REQUIRE(phase == 2 || (conv_partials && n_partials > 0), "bn_relu_fwd_phase: the statistics phase finalises the convolution's partials");
+    UZ_REQUIRE(phase == 1 || (y && a), "bn_relu_fwd_phase: the apply phase needs y and a");
+    return bn_relu_fwd_impl(y, C, CtotY, gamma, beta, running_mean, running_var, save_mean_rstd_ab, a, CtotA, N, H, W, eps, momentum,
+                            1, relu, a_amax, nullptr, phase == 1 ? conv_partials : nullptr, phase == 1 ? n_partials : 0, nullptr, 0, nullptr, stream, 1, phase == 2 ? out_packed : 0, phase);
 }
 // Conv2d (split-K, fp32 kernel) + BatchNorm + ReLU on the small planes with the convolution's reduce folded in: `slabs` are the
 // n_slabs partial-sum tensors [n_slabs][N][C][H*W] uz_conv_fwd_slabs left in its workspace, conv_bias the convolution's bias

@@ -675,6 +675,23 @@ extern "C" int uz_conv_fwd_ex(const float* x, int Cin, int CinTot, const float* 
     o.x_packed = 1; o.x_amax2 = x_amax2; o.seg_channels = seg_channels;
     return uz::conv_split_ex(x, Cin, CinTot, w, Cin, bias, y, Cout, CoutTot, N, H, W, 0, relu, 0, x_amax, w_amax, y_amax, workspace, packed_w, bn_partials, uz::S(stream), o);
 }
+// uz_conv_fwd_ex for a layer that follows a Conv -> BatchNorm -> ReLU unit (torchlayers.py:18-21), reading that unit's PRE-normalisation
+// output y_prev and its statistics table bn_save ([4][Cin]: mean, rstd, alpha = gamma rstd, beta' = beta - mean alpha, as uz_bn_relu_fwd_ex
+// writes it): the staging computes a = max(alpha y_prev + beta', 0) (bn_relu; zero padding stays zero) and splits it with the scale of
+// a_amax, the bound of the APPLIED activation - the same values the unit's apply pass would have stored, without waiting for that pass.
+// Split-fp16 path only (uz_conv_route() == 1, two-piece mode).
+extern "C" int uz_conv_fwd_bn_ex(const float* y_prev, int Cin, int CinTot, const float* bn_save, int bn_relu,
+                                 const float* w, const float* bias, float* y, int Cout, int CoutTot, int N, int H, int W, int ks,
+                                 const float* a_amax, const float* w_amax, float* y_amax,
+                                 void* workspace, size_t workspace_bytes, const void* packed_w, float* bn_partials, void* stream) {
+    UZ_REQUIRE(y_prev && bn_save && a_amax, "conv_fwd_bn_ex: needs the producer's output, its statistics table and the activation's bound");
+    UZ_REQUIRE(ks == 3 && uz_conv_route(0, Cin, Cout, N, H, W, ks) == 1 && uz::conv_np() == 2, "conv_fwd_bn_ex: this shape / math mode does not take the split-fp16 path");
+    UZ_REQUIRE(workspace && workspace_bytes >= uz::conv_split_workspace(Cin, Cout, N, H, W), "conv_fwd_bn_ex: workspace too small");
+    UZ_REQUIRE(!bn_partials || uz_conv_bn_partials(Cin, Cout, N, H, W, ks) > 0, "conv_fwd_bn_ex: this shape writes no fused statistics (uz_conv_bn_partials() == 0)");
+    uz::SplitOpts o;
+    o.aff = bn_save; o.aff_relu = bn_relu;
+    return uz::conv_split_ex(y_prev, Cin, CinTot, w, Cin, bias, y, Cout, CoutTot, N, H, W, 0, 0, 0, a_amax, w_amax, y_amax, workspace, packed_w, bn_partials, uz::S(stream), o);
+}
 extern "C" int uz_conv_bwd_data_ex(const float* dy, int Cout, int CoutTot, const float* w, float* dx, int Cin, int CinTot,
                                    int N, int H, int W, int ks, int accumulate, const float* dy_amax, const float* w_amax,
                                    void* workspace, size_t workspace_bytes, const void* packed_w, int dy_packed,

@@ -86,6 +86,10 @@ struct SP {
     int* flags; int flag_bit;                     // device flag word (bound violations), nullable; the bit this launch raises: activation (forward) or gradient (data gradient)
     float* bnpart;                                // nullable: per-(pixel tile, row half, channel) {sum, sum of squares, max, max of negated} of y
     int yb16;                                     // y (and what it accumulates onto) is stored as bf16 (single-piece mode, kSplit == 1)
+    // XF == 3: x is the PRE-normalisation output y' of the Conv -> BatchNorm -> ReLU unit in front of this layer and aff its [4][Cin] {mean, rstd,
+    // alpha, beta'} table: the staging applies a = max(alpha y' + beta', 0) (aff_relu; padding stays 0) before the operand split - the unit's apply pass
+    // leaves the chain of dependent launches (it still writes `a` for the weight gradient, beside this layer instead of in front of it)
+    const float* aff; int aff_relu;
 };
 
 
@@ -150,7 +154,8 @@ constexpr int lds_bytes() {
 // tap.  One barrier per chunk instead of two, and no phase in which every wave stages while the matrix pipe idles.
 template <int MSUB, int NTv, int TWv, int NP, int MK = 0, int XF = 0, int DB = 0>
 __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, const int n_tiles) {
-    constexpr bool XPK = XF == 1, XB = XF == 2;
+    constexpr bool XPK = XF == 1, XB = XF == 2, XA = XF == 3;
+    static_assert(!XA || NP == 2, "the folded BatchNorm apply feeds the two-piece mode");
     constexpr unsigned ESZ = XB ? 2u : 4u;               // bytes per input element
     static_assert(!XPK || NP == 2, "split storage is the two-piece fp16 format");
     static_assert(!XB || NP == 1, "bf16 storage feeds the single-piece bf16 mode");
@@ -345,8 +350,28 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
             pieces<NP>(v0 * xs, v1 * xs, out);
         }
     };
+    int cvt_c = 0;                           // XA: the chunk whose values convert() is working on (set by stage / stage_deep)
+    const float aff_floor = (XA && !p.aff_relu) ? -INFINITY : 0.f;
+    auto aff_own = [&](int k) {              // own row, channel k of the chunk: alpha / beta' are wave-uniform (scalar loads)
+        const int ch = cvt_c * CK + k, chc = min(ch, p.Cin - 1);
+        const float t = fmaxf(fmaf(pr[k], p.aff[2 * p.Cin + chc], p.aff[3 * p.Cin + chc]), aff_floor);
+        pr[k] = (gmask[0] == 0u && ch < p.Cin) ? t : 0.f;           // padding pixels and the K tail stay zero
+    };
+    auto aff_shared = [&](int i) {           // shared rows: this lane's channels CE q4 .. CE q4 + CE - 1
+        const int ch = cvt_c * CK + CE * q4 + i, chc = min(ch, p.Cin - 1);
+        const float t = fmaxf(fmaf(pr1[i], p.aff[2 * p.Cin + chc], p.aff[3 * p.Cin + chc]), aff_floor);
+        pr1[i] = (gmask[1] == 0u && ch < p.Cin) ? t : 0.f;
+    };
     auto convert = [&](int j) {              // split / round the values of k 4j .. 4j + 3 (j = 0 also the shared-row share)
         const int i0 = 2 * j;
+        if constexpr (XA) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) aff_own(4 * j + k);
+            if (j == 0) {
+#pragma unroll
+                for (int i = 0; i < CE; ++i) aff_shared(i);
+            }
+        }
         if constexpr (XB) {
             // pair dwords 2 j, 2 j + 1 (channels 8 h2 + 2 j, + 1): own pixel's halves stay, the partner pixel's halves go to the partner
             const unsigned m0 = __builtin_amdgcn_ubfe(pw[2 * j], my_off, my_w), m1 = __builtin_amdgcn_ubfe(pw[2 * j + 1], my_off, my_w);
@@ -371,6 +396,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
         }
     };
     auto stage = [&](int c, int tap) {
+        cvt_c = c;
         if constexpr (DB) {             // weights first (DMA), patch loads over taps 1..4, conversions over taps 5..8
 #ifdef UZ_EXP_PATCH_DMA
             if (tap == 0) { weight_dma(c); patch_dma(c); }
@@ -397,6 +423,7 @@ __device__ __forceinline__ void conv_split_body(const SP& p, const int tile_id, 
     // that taps 0..3 have just converted (chunk c + 1); the packed weights (L2 resident, short latency) stay one chunk ahead and
     // are issued first (tap 4) so that the in-order wait before the LDS writes does not include the patch loads.
     auto stage_deep = [&](int c, int tap, bool more, bool more2) {
+        cvt_c = c + 1;
         if (tap < 4) { if (more) convert(tap); }
         else if (tap == 4) {
             if (more) {
@@ -727,6 +754,10 @@ UZ_SPLIT_KERNEL(conv_split_bn_kernel_1_256_16, 1, 256, 16, 2, 2, 0, UZ_OCC16)
 UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_2_512_32, 2, 512, 32, 2, 2, 1, 1)
 UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_512_32, 1, 512, 32, 2, 2, 1, 4)
 UZ_SPLIT_KERNEL(conv_splitp_bn_kernel_1_256_16, 1, 256, 16, 2, 2, 1, UZ_OCC16P)
+// round 6: the producing unit's BatchNorm apply folded into the staging (conv_splita_*: x = its pre-normalisation output + its statistics table)
+UZ_SPLIT_KERNEL(conv_splita_kernel_2_512_32, 2, 512, 32, 2, 0, 3, 1)
+UZ_SPLIT_KERNEL(conv_splita_kernel_1_512_32, 1, 512, 32, 2, 0, 3, 4)
+UZ_SPLIT_KERNEL(conv_splita_kernel_1_256_16, 1, 256, 16, 2, 0, 3, UZ_OCC16)
 // bf16 STORAGE of the input (the volume path, planes wider than 32): 2-byte patch loads, no conversion while staging
 UZ_SPLIT_KERNEL(conv_b16_kernel_2_512_32, 2, 512, 32, 1, 0, 2, 1)
 UZ_SPLIT_KERNEL(conv_b16_kernel_1_512_32, 1, 512, 32, 1, 0, 2, 4)
@@ -735,6 +766,7 @@ UZ_SPLIT_KERNEL(conv_b16_kernel_1_256_16, 1, 256, 16, 1, 0, 2, 3)
 UZ_SPLIT_KERNEL_(conv_split_db_kernel_2_512_32, 2, 512, 32, 2, 0, 0, 1, 1)
 UZ_SPLIT_KERNEL_(conv_split_relu_db_kernel_2_512_32, 2, 512, 32, 2, 1, 0, 1, 1)
 UZ_SPLIT_KERNEL_(conv_splitp_db_kernel_2_512_32, 2, 512, 32, 2, 0, 1, 1, 1)
+UZ_SPLIT_KERNEL_(conv_splita_db_kernel_2_512_32, 2, 512, 32, 2, 0, 3, 1, 1)
 UZ_SPLIT_KERNEL_(conv_split_bn_db_kernel_2_512_32, 2, 512, 32, 2, 2, 0, 1, 1)
 UZ_SPLIT_KERNEL_(conv_splitp_bn_db_kernel_2_512_32, 2, 512, 32, 2, 2, 1, 1, 1)
 UZ_SPLIT_KERNEL_(conv_bf16_db_kernel_2_512_32, 2, 512, 32, 1, 0, 0, 1, 1)
@@ -781,6 +813,10 @@ template <int MSUB, int NTv, int TWv, int NP>
 int launch(const SP& p, int grid, hipStream_t st, int mk, int xpk, int xb16) {
     if constexpr (NP == 2) {
         if (xb16 || p.yb16) return uz::fail("conv_split: bf16 storage needs the single-piece bf16 mode (uz_set_conv_math(3))");
+        if (p.aff) {
+            if (mk != 0 || xpk) return uz::fail("conv_split: the folded BatchNorm apply takes fp32 input and a plain epilogue");
+            return launch_one<MSUB, NTv, TWv, 2, 0, 3>(p, grid, st);
+        }
         if (xpk) {
             if (mk == 1) return uz::fail("conv_split: the folded ReLU backward takes an fp32 gradient");
             return mk == 2 ? launch_one<MSUB, NTv, TWv, 2, 2, 1>(p, grid, st) : launch_one<MSUB, NTv, TWv, 2, 0, 1>(p, grid, st);
@@ -977,11 +1013,13 @@ static int conv_split_impl(const float* x, int Kc, int KcTot, const float* w, in
     const float* relu_mask = o.mask;
     SP p;
     p.mask = o.mask; p.maskCtot = o.maskCtot; p.mk_save = o.mk_save; p.mk_relu = o.mk_relu;
+    p.aff = o.aff; p.aff_relu = o.aff_relu;
     float* slots = static_cast<float*>(workspace);
     char* image = static_cast<char*>(workspace) + WS_HEAD;
     const int np = conv_np();                            // 1: bf16 single-piece operands (no scales, no bounds)
     UZ_REQUIRE(np == 1 || !packed_w || w_amax, "conv_split: a pre-packed weight image needs the bound it was scaled with");
     UZ_REQUIRE(!o.x_packed || (np == 2 && x_amax), "conv_split: input in split storage needs the two-piece mode and the bound it was scaled from");
+    UZ_REQUIRE(!o.aff || (np == 2 && x_amax && !dgrad && !o.x_packed && o.mk == 0), "conv_split: the folded BatchNorm apply serves a plain forward convolution in the two-piece mode and needs the activation's bound");
     UZ_REQUIRE(!o.x_packed || o.seg_channels == 0 || (o.x_amax2 && o.seg_channels % CK == 0 && o.seg_channels < Kc),
                "conv_split: the second scale segment must start on a multiple of 16 channels inside the view and carry its bound");
     UZ_REQUIRE(o.mk != 2 || (o.mask && o.mk_save && dgrad && bn_partials), "conv_split: the folded BatchNorm reduction needs y, the statistics table and the partial rows");

@@ -150,6 +150,8 @@ static int run_one(const uz_op& o, void* st) {
             if (i[13] && i[7] == 1) return uz_conv1x1_fwd_b16(p[0], i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[13] & 1, st);      // a 1x1 head: only x may be bf16
             if (i[13]) return uz_conv_fwd_b16(p[0], i[0], i[1], CFP(1), CFP(2), p[3], i[2], i[3], i[4], i[5], i[6], i[7], p[4], (size_t)o.n, p[8], FP(9), i[13] & 1, (i[13] >> 1) & 1, st);
             if (i[9]) return uz_conv_fwd_slabs(CFP(0), i[0], i[1], CFP(1), i[2], i[4], i[5], i[6], i[7], p[4], (size_t)o.n, st);      // the unit's BatchNorm adds the slabs
+            // i[12] = 1 | relu << 1: x is the producing unit's PRE-normalisation output, p[11] its statistics table - the staging applies BatchNorm + ReLU
+            if (i[12]) return uz_conv_fwd_bn_ex(CFP(0), i[0], i[1], CFP(11), (i[12] >> 1) & 1, CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], CFP(5), CFP(6), FP(7), p[4], (size_t)o.n, p[8], FP(9), st);
             // i[10] = input in split storage, p[10] / i[11] = bound and first channel of its second scale segment
             return uz_conv_fwd_ex(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), i[2], i[3], i[4], i[5], i[6], i[7], i[8], CFP(5), CFP(6), FP(7), p[4], (size_t)o.n, p[8], FP(9),
                                   i[10], CFP(10), i[11], st);
@@ -178,6 +180,8 @@ static int run_one(const uz_op& o, void* st) {
         case UZ_OP_BN_RELU_FWD:
             if (i[13]) return uz_bn_relu_fwd_b16(p[0], i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), p[6], i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], p[7], CFP(9), i[8], i[13] & 1, (i[13] >> 1) & 1, st);      // bit 0 = y, bit 1 = a in bf16 storage
             if (i[9] > 1) return uz_bn_relu_fwd_slabs(CFP(10), i[9], CFP(11), FP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], FP(8), st);
+            // i[11] = phase (Plan._bn_offchain_pass): 1 statistics only, 2 apply only
+            if (i[11]) return uz_bn_relu_fwd_phase(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[7], FP(8), CFP(9), i[8], i[10], i[11], st);
             // (save holds 4 C floats in plans; i[10] = write the activation as split storage)
             return uz_bn_relu_fwd_ex(CFP(0), i[0], i[1], CFP(1), CFP(2), FP(3), FP(4), FP(5), FP(6), i[2], i[3], i[4], i[5], f[0], f[1], i[6], i[7], FP(8), p[7], CFP(9), i[8], i[10], st);
         case UZ_OP_BN_RELU_BWD:

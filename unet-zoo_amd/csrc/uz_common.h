@@ -75,6 +75,9 @@ struct SplitOpts {
     int mk_relu = 1;
     // bf16 STORAGE (single-piece bf16 mode only, unsplit chunk loops): the input operand / the output tensor hold 2-byte bf16 elements
     int x_b16 = 0, y_b16 = 0;
+    // round 6: x is the pre-normalisation output of the Conv -> BatchNorm -> ReLU unit in front (fp32) and aff its [4][Kc] {mean, rstd, alpha, beta'} table:
+    // the forward convolution's staging applies the unit's BatchNorm + ReLU itself (x_amax = the bound of the APPLIED activation)
+    const float* aff = nullptr; int aff_relu = 0;
 };
 int conv_split_ex(const float* x, int Kc, int KcTot, const float* w, int wCi, const float* bias,
                   float* y, int Mc, int McTot, int N, int H, int W, int dgrad, int relu, int accumulate,
